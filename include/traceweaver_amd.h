@@ -1,0 +1,151 @@
+/*
+ * traceweaver_amd.h -- C-ABI of the MI355X span->parent assignment engine (libtwgpu.so).
+ *
+ * The reference (Sachin-A/TraceWeaver) has no FFI; its drop-in boundary is the Python predictor
+ * protocol (algorithms/README.md:12-73) as used by the executor:
+ *     TraceWeaverV3(all_spans, all_processes).FindAssignments(method, process, in_span_partitions,
+ *         out_span_partitions, parallel, instrumented_hops, true_assignments, invocation_graph)
+ *     -> (all_assignments, all_topk_assignments, not_best_count, n_in, per_span_candidates,
+ *         cnt_unassigned)                       traceweaver_v3.py:1087-1229, executor.py:1172-1175
+ * traceweaver_amd/predictor.py mirrors that signature and drives the functions below through
+ * ctypes.  Strings and (trace_id, span_id) keys never cross this ABI: the shim maps ids <-> indices.
+ *
+ * All pointers are plain host pointers unless a function says otherwise; the caller owns every
+ * host buffer, the engine owns every device buffer.  Every function returns TW_OK (0) or a negative
+ * tw_status; tw_last_error() gives the message.  One engine may be used from one thread at a time.
+ *
+ * Data model ("batch" = independent service units solved together; "unit" = one call of the
+ * reference's FindAssignments):
+ *   - incoming spans of a unit sorted by (start, end)                      executor.py:1112
+ *   - outgoing endpoints in the topological order of the call-order DAG    traceweaver_v1.py:37-39
+ *   - every endpoint's spans sorted by (start, end)
+ *   - timestamps are int64 microseconds (Jaeger JSON startTime / startTime+duration)
+ * Only the no-skip mode of the reference is accelerated: every endpoint must hold exactly as many
+ * outgoing spans as the unit has incoming spans (traceweaver_v3.py:972,1141-1158 "equal_eps");
+ * anything else is rejected with TW_ERR_UNSUPPORTED.
+ */
+#ifndef TRACEWEAVER_AMD_H
+#define TRACEWEAVER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TW_MAX_EP 8      /* outgoing endpoints per unit                                     */
+#define TW_TOPK 5        /* candidates kept per incoming span        traceweaver_v3.py:1109 */
+#define TW_MAX_COMP 5    /* mixture components per edge              traceweaver_v3.py:768  */
+#define TW_MAX_WINDOW 32 /* incoming spans per window (reference cap: 31)    */
+#define TW_CAND_WORDS 2  /* 64-bit words of the per-(span, endpoint) candidate bitmap       */
+
+typedef enum {
+    TW_OK = 0,
+    TW_ERR_ARG = -1,          /* bad argument / inconsistent sizes                                   */
+    TW_ERR_UNSUPPORTED = -2,  /* skip mode (n_out != n_in), E > TW_MAX_EP, topk != TW_TOPK           */
+    TW_ERR_DEVICE = -3,       /* HIP runtime error                                                   */
+    TW_ERR_STATE = -4,        /* call order violated (e.g. pass 2 before pass 1)                     */
+    TW_ERR_WINDOW_WIDTH = -5, /* an incoming span has > 64*TW_CAND_WORDS candidate spans at one      */
+                              /* endpoint (the reference's enumeration is infeasible there too)      */
+    TW_ERR_WINDOW_SIZE = -6,  /* a window holds more than TW_MAX_WINDOW incoming spans                */
+    TW_ERR_NAN_PARAMS = -7    /* a 100-span block has a single sample: std = NaN, the reference      */
+                              /* aborts in the solver (SURVEY.md hazard H3)                          */
+} tw_status;
+
+typedef struct tw_engine tw_engine;
+
+/* Replaces: TraceWeaverV3.__init__ (traceweaver_v3.py:30-54).  device_id = HIP device ordinal. */
+int tw_create(int device_id, tw_engine **out);
+void tw_destroy(tw_engine *e);
+const char *tw_last_error(const tw_engine *e);
+
+/* A batch of independent units in structure-of-arrays form.
+ * Replaces: the in_span_partitions / out_span_partitions / invocation_graph arguments of
+ * FindAssignments (traceweaver_v3.py:1087) for each unit. */
+typedef struct {
+    int32_t n_units;
+    const int64_t *unit_in_off; /* [n_units+1] offsets into in_start/in_end                        */
+    const int32_t *unit_E;      /* [n_units]   outgoing endpoints per unit (1..TW_MAX_EP)           */
+    const int64_t *ep_off;      /* [sum(E)+1]  offsets into out_start/out_end of every (unit,ep)    */
+                                /*             segment, units in order, endpoints in topo order     */
+    const uint8_t *dag;         /* concatenated E*E matrices, dag[p*E+e]=1 <=> edge p->e            */
+                                /*             (executor.py:214-285 FindOrder, transitively closed) */
+    const int32_t *key_rank;    /* [sum(E)]    rank of the endpoint in the partition-key order:     */
+                                /*             networkx in_edges() iteration order of predecessors  */
+    const int64_t *in_start, *in_end;   /* [unit_in_off[n_units]]                                   */
+    const int64_t *out_start, *out_end; /* [ep_off[sum(E)]]                                         */
+    int32_t batch_size;     /* 100  traceweaver_v3.py:1107 */
+    int32_t batch_size_mis; /* 30   traceweaver_v3.py:1108 */
+    int32_t topk;           /* 5    traceweaver_v3.py:1109 */
+} tw_batch;
+
+/* Copies the batch into HBM (span arrays: 16 B per span).  If `spans_on_device` is non-zero the
+ * four span arrays are *device* pointers (already resident, e.g. produced by a device-side loader)
+ * and are copied device-to-device; the small descriptor arrays are always host pointers. */
+int tw_load_batch(tw_engine *e, const tw_batch *b, int spans_on_device);
+
+/* Pass 1 (traceweaver_v3.py:1159-1219, iteration 0): windows (CreateWindows2, :1020-1078),
+ * per-100-span Gaussian parameters (ComputeEpPairDistParams3, :580-646), candidate enumeration
+ * + log-likelihood + top-5 (FindTopKAssignments, :180-465; ScoreAssignmentAsPerInvocationGraph,
+ * traceweaver_v1.py:259-361), exact per-window selection (GetAssignmentsMIS, :1237-1281 +
+ * Gurobi_MIS :1395-1419) and commit with span consumption (AddAssignment, traceweaver_v1.py:433-463). */
+int tw_run_pass1(tw_engine *e);
+
+/* Gap samples implied by the pass-1 assignment, one row of n_in doubles per scored slot of each
+ * unit (ComputeEpPairDistParams5's `durations`, traceweaver_v3.py:717-762); entries of unassigned
+ * incoming spans and rows of unscored slots are NaN.  Slot order per unit (nslot = E*E + 2E):
+ *   [0,E) root(in->e) | E + p*E + e primary(p->e) | E + E*E + e closing(e->in).
+ * `gaps` holds sum_u nslot_u * n_in_u doubles, unit after unit. */
+int tw_get_gaps(tw_engine *e, double *gaps);
+
+/* Mixtures for pass 2 (the fitted sklearn GaussianMixture objects of traceweaver_v3.py:784-786):
+ * mix_n[sum_u nslot_u] components per slot (0 = "(0,0)" fallback, traceweaver_v3.py:765-766),
+ * mix_p[sum_u nslot_u][TW_MAX_COMP][3] = weight, mean, precision_cholesky. */
+int tw_set_mixtures(tw_engine *e, const int32_t *mix_n, const double *mix_p);
+
+/* Pass 2 (iteration 1): same as pass 1 with GaussianMixture.score terms
+ * (traceweaver_v1.py:125-126), reusing the windows. */
+int tw_run_pass2(tw_engine *e);
+
+/* Results of pass `pass` (1 or 2), host buffers, any pointer may be NULL.  Per-unit arrays are
+ * concatenated unit after unit; within a unit [E][n_in] / [TW_TOPK][E][n_in] / [TW_TOPK][n_in].
+ *   parent      int32  chosen outgoing-span index per endpoint, -1 = ("NA","NA")
+ *   topk_idx    int32  top-5 tuples on *all* spans (top_k_2, traceweaver_v3.py:1185), -1 padded
+ *   topk_score  double their scores (NaN padded)
+ *   topk_n      int32  [n_in] number of valid tuples
+ *   chosen      int32  [n_in] rank of the chosen tuple in the span's own candidate list, -1 none
+ *   leaves      int64  [n_in] enumerated tuples of the top_k call (per_span_candidates increment)
+ *   window_end  uint8  [n_in] 1 where a window closes (traceweaver_v3.py:1192)
+ *   unit_stats  int64  [n_units][4]: not_best_count, cnt_unassigned, n_windows, repaired windows */
+typedef struct {
+    int32_t *parent;
+    int32_t *topk_idx;
+    double *topk_score;
+    int32_t *topk_n;
+    int32_t *chosen;
+    int64_t *leaves;
+    uint8_t *window_end;
+    int64_t *unit_stats;
+} tw_results;
+int tw_get_results(tw_engine *e, int pass, const tw_results *r);
+
+/* Pass-1 Gaussian parameters: gauss[sum_u nblk_u * nslot_u][3] = mean, std, log(std_used);
+ * NaN for unscored slots.  nblk_u = ceil(n_in_u / batch_size). */
+int tw_get_gauss_params(tw_engine *e, double *gauss);
+
+/* Timing of the last pass, measured with HIP events on the engine's stream:
+ * ms[0] whole pass, ms[1] candidate-enumeration kernel, ms[2] selection kernel,
+ * ms[3] window construction, ms[4] repair kernel, ms[5] parameter kernels (sort + block sums). */
+int tw_get_timing(tw_engine *e, double *ms, int32_t n);
+
+/* One-shot convenience for a single unit: load, pass 1, (optional) pass 2 with caller-supplied
+ * mixtures, results of the last pass run.  mix_n == NULL => pass 1 only. */
+int tw_assign_service(tw_engine *e, int32_t n_in, const int64_t *in_start, const int64_t *in_end,
+                      int32_t E, const int64_t *out_off, const int64_t *out_start, const int64_t *out_end,
+                      const uint8_t *dag, const int32_t *key_rank, const int32_t *mix_n,
+                      const double *mix_p, const tw_results *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRACEWEAVER_AMD_H */

@@ -1,0 +1,780 @@
+/*
+ * tw_oracle.c -- CPU restatement of TraceWeaver's per-service span->parent assignment
+ *                (TraceWeaverV3.FindAssignments, no-skip mode).
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the *oracle*: a sequential, literal restatement of the
+ * reference algorithm that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use as
+ * the checker.  The product (traceweaver_amd/) never includes, links or calls it.
+ *
+ * Reference (paths relative to /root/reference/src/trace_reconstructor/ports/python):
+ *   V3 = algorithms/traceweaver_v3.py, V1 = algorithms/traceweaver_v1.py, EX = executor.py
+ *
+ *   two_windows()        V3:1020-1078 CreateWindows2 + PerfectCut, candidates from DfsTraverse3 V3:236-288
+ *   two_gauss_params()   V3:580-646   ComputeEpPairDistParams3 (rank-aligned block means, batch-means std)
+ *   two_run_pass()       V3:1159-1219 one iteration of the main loop:
+ *       cutoffs()        V3:182-217   FindCutoffs (bisect on the *remaining* spans, reverse topo order)
+ *       dfs_topk()       V3:292-351   DfsTraverseX feasibility + V3:304-307 heap top-K
+ *       score_tuple()    V1:259-361   ScoreAssignmentAsPerInvocationGraph (no-skip branch)
+ *       term_*()         V1:117-139   GetEpPairCost: norm.logpdf (pass 1) / GaussianMixture.score (pass 2)
+ *       mwis_window()    V3:1237-1281 BuildMISInstance + V3:1395-1419 Gurobi_MIS (exact MWIS)
+ *       commit           V1:433-463   AddAssignment(delete_out_spans=True), V3:1201-1217 counters
+ *   two_gaps()           V3:717-762   gap samples per scored edge from an assignment (for the GMM refit)
+ *
+ * Parity status: pinned against golden vectors frozen from the reference itself run in the build
+ * container (oracle/refrun/gen_golden.py -> tests/golden/ref_*.npz; tests/test_oracle_golden.py).
+ * The selection step (gurobi-optimods==1.1.0 / gurobipy==11.0.2) is a closed-source dependency
+ * that is absent; the goldens were produced with an exact HiGHS MILP stand-in, so parity at that
+ * boundary is "unpinned" wherever the optimum is not unique.
+ *
+ * Arithmetic: all comparisons on int64 microseconds; scores in IEEE double with no FMA
+ * contraction (-ffp-contract=off).  log/exp/log1p follow the published fdlibm algorithms
+ * (e_log.c, e_exp.c, s_log1p.c) so that results do not depend on the host libm build; they agree
+ * with glibc/numpy to <= 1 ulp (tests/test_oracle_math.py).
+ *
+ * Python's heapq and list.sort are emulated operation by operation so that exact score ties
+ * resolve as in the reference (V3:305-307 heappush/heappop, V3:461 sort(reverse=True)).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define TWO_MAX_E 16
+#define TWO_MAX_K 8
+#define TWO_MAX_COMP 5
+#define TWO_MAX_WIN 40 /* in-spans per window (reference cap is 31) */
+
+/* ------------------------------------------------------------------ strict-IEEE elementary fns */
+typedef union { double d; uint64_t u; } two_bits;
+static inline int32_t hi_word(double x) { two_bits b; b.d = x; return (int32_t)(b.u >> 32); }
+static inline uint32_t lo_word(double x) { two_bits b; b.d = x; return (uint32_t)b.u; }
+static inline double set_hi(double x, int32_t hi) { two_bits b; b.d = x; b.u = ((uint64_t)(uint32_t)hi << 32) | (b.u & 0xffffffffu); return b.d; }
+
+double two_log(double x) {
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+        two54 = 1.80143985094819840000e+16, Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+        Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01,
+        Lg6 = 1.531383769920937332e-01, Lg7 = 1.479819860511658591e-01;
+    double hfsq, f, s, z, R, w, t1, t2, dk;
+    int32_t k = 0, hx = hi_word(x), i, j;
+    uint32_t lx = lo_word(x);
+    if (hx < 0x00100000) {
+        if (((hx & 0x7fffffff) | lx) == 0) return -INFINITY;
+        if (hx < 0) return NAN;
+        k -= 54; x *= two54; hx = hi_word(x);
+    }
+    if (hx >= 0x7ff00000) return x + x;
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    i = (hx + 0x95f64) & 0x100000;
+    x = set_hi(x, hx | (i ^ 0x3ff00000));
+    k += (i >> 20);
+    f = x - 1.0;
+    if ((0x000fffff & (2 + hx)) < 3) {
+        if (f == 0.0) { if (k == 0) return 0.0; dk = (double)k; return dk * ln2_hi + dk * ln2_lo; }
+        R = f * f * (0.5 - 0.33333333333333333 * f);
+        if (k == 0) return f - R;
+        dk = (double)k; return dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    s = f / (2.0 + f); dk = (double)k; z = s * s;
+    i = hx - 0x6147a; w = z * z; j = 0x6b851 - hx;
+    t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    i |= j; R = t2 + t1;
+    if (i > 0) {
+        hfsq = 0.5 * f * f;
+        if (k == 0) return f - (hfsq - s * (hfsq + R));
+        return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    if (k == 0) return f - s * (f - R);
+    return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+double two_exp(double x) {
+    static const double o_threshold = 7.09782712893383973096e+02, u_threshold = -7.45133219101941108420e+02,
+        ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00,
+        P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+        P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08, twom1000 = 9.33263618503218878990e-302;
+    double y, hi = 0.0, lo = 0.0, c, t;
+    int32_t k = 0, xsb, hx = hi_word(x);
+    xsb = (hx >> 31) & 1;
+    hx &= 0x7fffffff;
+    if (hx >= 0x40862E42) {
+        if (hx >= 0x7ff00000) {
+            if (((hx & 0xfffff) | lo_word(x)) != 0) return x + x;
+            return xsb == 0 ? x : 0.0;
+        }
+        if (x > o_threshold) return INFINITY;
+        if (x < u_threshold) return 0.0;
+    }
+    if (hx > 0x3fd62e42) {
+        if (hx < 0x3FF0A2B2) {
+            if (xsb == 0) { hi = x - ln2HI; lo = ln2LO; k = 1; } else { hi = x + ln2HI; lo = -ln2LO; k = -1; }
+        } else {
+            k = (int32_t)(invln2 * x + (xsb == 0 ? 0.5 : -0.5));
+            t = (double)k; hi = x - t * ln2HI; lo = t * ln2LO;
+        }
+        x = hi - lo;
+    } else if (hx < 0x3e300000) {
+        return 1.0 + x;
+    } else k = 0;
+    t = x * x;
+    c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    if (k >= -1021) return set_hi(y, hi_word(y) + (k << 20));
+    return set_hi(y, hi_word(y) + ((k + 1000) << 20)) * twom1000;
+}
+
+double two_log1p(double x) {
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+        two54 = 1.80143985094819840000e+16, Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01,
+        Lp3 = 2.857142874366239149e-01, Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01,
+        Lp6 = 1.531383769920937332e-01, Lp7 = 1.479819860511658591e-01;
+    double hfsq, f = 0.0, c = 0.0, s, z, R, u;
+    int32_t k = 1, hx = hi_word(x), hu = 0, ax;
+    ax = hx & 0x7fffffff;
+    if (hx < 0x3FDA827A) {
+        if (ax >= 0x3ff00000) { if (x == -1.0) return -INFINITY; return NAN; }
+        if (ax < 0x3e200000) {
+            if (two54 + x > 0.0 && ax < 0x3c900000) return x;
+            return x - x * x * 0.5;
+        }
+        if (hx > 0 || hx <= ((int32_t)0xbfd2bec3)) { k = 0; f = x; hu = 1; }
+    }
+    if (hx >= 0x7ff00000) return x + x;
+    if (k != 0) {
+        if (hx < 0x43400000) {
+            u = 1.0 + x; hu = hi_word(u); k = (hu >> 20) - 1023;
+            c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
+            c /= u;
+        } else { u = x; hu = hi_word(u); k = (hu >> 20) - 1023; c = 0; }
+        hu &= 0x000fffff;
+        if (hu < 0x6a09e) u = set_hi(u, hu | 0x3ff00000);
+        else { k += 1; u = set_hi(u, hu | 0x3fe00000); hu = (0x00100000 - hu) >> 2; }
+        f = u - 1.0;
+    }
+    hfsq = 0.5 * f * f;
+    if (hu == 0) {
+        if (f == 0.0) { if (k == 0) return 0.0; c += k * ln2_lo; return k * ln2_hi + c; }
+        R = hfsq * (1.0 - 0.66666666666666666 * f);
+        if (k == 0) return f - R;
+        return k * ln2_hi - ((R - (k * ln2_lo + c)) - f);
+    }
+    s = f / (2.0 + f); z = s * s;
+    R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+    if (k == 0) return f - (hfsq - s * (hfsq + R));
+    return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
+}
+
+/* ------------------------------------------------------------------ service description */
+typedef struct {
+    int32_t n_in, E;
+    const int64_t *in_start, *in_end;   /* [n_in], sorted by (start, end)            EX:1112 */
+    const int64_t *out_off;             /* [E+1] offsets into out_*                           */
+    const int64_t *out_start, *out_end; /* per endpoint sorted by (start, end), endpoints in  */
+                                        /* topological order of the DAG              V1:39    */
+    const uint8_t *dag;                 /* [E*E] dag[p*E+e]=1 <=> edge p->e          EX:214   */
+    const int32_t *key_rank;            /* [E] position of endpoint in the partition-key order:*/
+                                        /* in_edges(e) iterate predecessors in this order      */
+    int32_t batch_size, batch_size_mis, topk; /* 100, 30, 5                          V3:1107  */
+} two_service;
+
+#define NSLOT(E) ((E) + (E) * (E) + (E))
+#define SLOT_ROOT(E, e) (e)
+#define SLOT_PRIM(E, p, e) ((E) + (p) * (E) + (e))
+#define SLOT_CLOSE(E, e) ((E) + (E) * (E) + (e))
+
+/* primary edge: DAG edge with no 2-hop alternative (V1:245-254, all_simple_paths cutoff=2) */
+static int is_primary(const two_service *s, int p, int e) {
+    int E = s->E;
+    if (!s->dag[p * E + e]) return 0;
+    for (int m = 0; m < E; m++)
+        if (m != p && m != e && s->dag[p * E + m] && s->dag[m * E + e]) return 0;
+    return 1;
+}
+
+/* predecessors of e in in_edges() order (partition-key order, see FindOrder EX:223-236) */
+static int preds_in_order(const two_service *s, int e, int *out) {
+    int E = s->E, n = 0;
+    for (int p = 0; p < E; p++)
+        if (s->dag[p * E + e]) out[n++] = p;
+    for (int a = 1; a < n; a++) { /* insertion sort by key_rank */
+        int v = out[a], b = a - 1;
+        while (b >= 0 && s->key_rank[out[b]] > s->key_rank[v]) { out[b + 1] = out[b]; b--; }
+        out[b + 1] = v;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------ remaining-span bookkeeping */
+typedef struct {
+    const two_service *s;
+    uint8_t *consumed[TWO_MAX_E]; /* NULL => nothing consumed (full lists) */
+} two_lists;
+
+static inline int64_t n_out(const two_service *s, int e) { return s->out_off[e + 1] - s->out_off[e]; }
+static inline int64_t ostart(const two_service *s, int e, int64_t x) { return s->out_start[s->out_off[e] + x]; }
+static inline int64_t oend(const two_service *s, int e, int64_t x) { return s->out_end[s->out_off[e] + x]; }
+static inline int is_gone(const two_lists *L, int e, int64_t x) { return L->consumed[e] && L->consumed[e][x]; }
+
+/* first remaining index with start >= t (== bisect_left on the reduced list); n if none */
+static int64_t first_remaining_ge(const two_lists *L, int e, int64_t t) {
+    const two_service *s = L->s;
+    int64_t lo = 0, hi = n_out(s, e);
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (ostart(s, e, mid) < t) lo = mid + 1; else hi = mid; }
+    while (lo < n_out(s, e) && is_gone(L, e, lo)) lo++;
+    return lo;
+}
+/* last remaining index with start <= t (== bisect_right - 1 on the reduced list); -1 if none */
+static int64_t last_remaining_le(const two_lists *L, int e, int64_t t) {
+    const two_service *s = L->s;
+    int64_t lo = 0, hi = n_out(s, e);
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (ostart(s, e, mid) <= t) lo = mid + 1; else hi = mid; }
+    lo -= 1;
+    while (lo >= 0 && is_gone(L, e, lo)) lo--;
+    return lo;
+}
+static int64_t last_remaining(const two_lists *L, int e) {
+    int64_t x = n_out(L->s, e) - 1;
+    while (x >= 0 && is_gone(L, e, x)) x--;
+    return x;
+}
+
+/* V3:182-217.  Returns 0, or -1 where the reference would raise IndexError (empty list). */
+static int cutoffs(const two_lists *L, int64_t in_start, int64_t in_end, int64_t *lo, int64_t *hi) {
+    const two_service *s = L->s;
+    int E = s->E;
+    for (int e = E - 1; e >= 0; e--) { /* reverse topological order */
+        int64_t early_exit = in_end;
+        for (int f = e + 1; f < E; f++) {
+            if (!s->dag[e * E + f]) continue;
+            int64_t anchor = hi[f];
+            if (anchor < 0) { /* Python negative index wraps to the last element (hazard H10) */
+                anchor = last_remaining(L, f);
+                if (anchor < 0) return -1;
+            }
+            int64_t st = ostart(s, f, anchor);
+            if (st < early_exit) early_exit = st;
+        }
+        lo[e] = first_remaining_ge(L, e, in_start);
+        hi[e] = last_remaining_le(L, e, early_exit);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ scoring */
+typedef struct {
+    int mode;             /* 0 Gaussian (pass 1), 1 mixtures (pass 2) */
+    const double *gauss;  /* [nslot][2] mean,std for the current block (mode 0) */
+    const int32_t *mix_n; /* [nslot] components, 0 => (0,0) Gaussian fallback V3:765-766 */
+    const double *mix_p;  /* [nslot][5][3] weight, mean, precision_cholesky */
+} two_params;
+
+static const double LOG_SQRT_2PI = 0x1.d67f1c864beb4p-1; /* np.log(np.sqrt(2*np.pi)) */
+static const double LOG_2PI = 0x1.d67f1c864beb4p+0;      /* np.log(2*np.pi) */
+
+/* scipy.stats.norm.logpdf(x, loc, scale) = (-(y*y)/2 - log(sqrt(2pi))) - log(scale), y=(x-loc)/scale */
+static double term_gauss(double mean, double std, int64_t t1, int64_t t2) {
+    if (std < 1.0e-12) std = 0.001; /* V1:130-131 */
+    double x = (double)(t2 - t1);
+    double y = (x - mean) / std;
+    return (-(y * y) / 2.0 - LOG_SQRT_2PI) - two_log(std);
+}
+
+/* sklearn GaussianMixture.score([[x]]) for 1-D 'full' mixtures: _estimate_log_gaussian_prob +
+ * log weights, then scipy.special.logsumexp (scipy>=1.15 form: max split out, log1p) */
+static double term_mix(int n, const double *p, int64_t t1, int64_t t2) {
+    double x = (double)(t2 - t1), a[TWO_MAX_COMP], amax = -INFINITY;
+    for (int k = 0; k < n; k++) {
+        double w = p[k * 3 + 0], mu = p[k * 3 + 1], pc = p[k * 3 + 2];
+        double y = x * pc - mu * pc;
+        double lp = y * y;
+        a[k] = (-0.5 * (LOG_2PI + lp) + two_log(pc)) + two_log(w);
+        if (a[k] > amax) amax = a[k];
+    }
+    double m = 0.0, ssum = 0.0;
+    for (int k = 0; k < n; k++) if (a[k] == amax) m += 1.0;
+    for (int k = 0; k < n; k++) ssum += (a[k] == amax) ? 0.0 : two_exp(a[k] - amax);
+    if (ssum != 0.0) ssum = ssum / m;
+    return (two_log1p(ssum) + two_log(m)) + amax;
+}
+
+static double term(const two_params *P, int slot, int64_t t1, int64_t t2) {
+    if (P->mode == 0) return term_gauss(P->gauss[slot * 2], P->gauss[slot * 2 + 1], t1, t2);
+    if (P->mix_n[slot] <= 0) return term_gauss(0.0, 0.0, t1, t2);
+    return term_mix(P->mix_n[slot], P->mix_p + (size_t)slot * TWO_MAX_COMP * 3, t1, t2);
+}
+
+typedef struct {
+    int npred[TWO_MAX_E];
+    int pred[TWO_MAX_E][TWO_MAX_E];   /* all predecessors in in_edges order */
+    uint8_t prim[TWO_MAX_E][TWO_MAX_E]; /* prim[e][j]: is pred[e][j] -> e primary */
+} two_graph;
+
+static void build_graph(const two_service *s, two_graph *g) {
+    for (int e = 0; e < s->E; e++) {
+        g->npred[e] = preds_in_order(s, e, g->pred[e]);
+        for (int j = 0; j < g->npred[e]; j++) g->prim[e][j] = (uint8_t)is_primary(s, g->pred[e][j], e);
+    }
+}
+
+/* V1:259-361, no-skip branch */
+static double score_tuple(const two_service *s, const two_graph *g, const two_params *P, int64_t in_start,
+                          int64_t in_end, const int64_t *x) {
+    int E = s->E, last_ep = 0;
+    int64_t last_end = oend(s, 0, x[0]);
+    for (int e = 1; e < E; e++) { /* max() keeps the first maximum V1:314 */
+        int64_t en = oend(s, e, x[e]);
+        if (en > last_end) { last_end = en; last_ep = e; }
+    }
+    double cost = 0.0;
+    for (int e = 0; e < E; e++) {
+        for (int j = 0; j < g->npred[e]; j++) {
+            if (!g->prim[e][j]) continue;
+            int p = g->pred[e][j];
+            cost += term(P, SLOT_PRIM(E, p, e), oend(s, p, x[p]), ostart(s, e, x[e]));
+        }
+        if (g->npred[e] == 0) cost += term(P, SLOT_ROOT(E, e), in_start, ostart(s, e, x[e]));
+        if (e == last_ep) cost += term(P, SLOT_CLOSE(E, e), oend(s, e, x[e]), in_end);
+    }
+    return cost;
+}
+
+/* ------------------------------------------------------------------ heapq / list.sort emulation */
+typedef struct { double score; int32_t idx[TWO_MAX_E]; } two_cand;
+
+/* Python (score, [spans]) < (score, [spans]): floats first, then first differing Span by start_mus
+ * (spans.py:51-52).  Distinct spans with equal starts compare "not less" both ways. */
+static int cand_lt(const two_service *s, const two_cand *a, const two_cand *b) {
+    if (a->score != b->score) return a->score < b->score;
+    for (int e = 0; e < s->E; e++)
+        if (a->idx[e] != b->idx[e]) return ostart(s, e, a->idx[e]) < ostart(s, e, b->idx[e]);
+    return 0;
+}
+static void heap_siftdown(const two_service *s, two_cand *h, int startpos, int pos) {
+    two_cand item = h[pos];
+    while (pos > startpos) {
+        int parent = (pos - 1) >> 1;
+        if (cand_lt(s, &item, &h[parent])) { h[pos] = h[parent]; pos = parent; continue; }
+        break;
+    }
+    h[pos] = item;
+}
+static void heap_siftup(const two_service *s, two_cand *h, int n, int pos) {
+    int startpos = pos, child = 2 * pos + 1;
+    two_cand item = h[pos];
+    while (child < n) {
+        int right = child + 1;
+        if (right < n && !cand_lt(s, &h[child], &h[right])) child = right;
+        h[pos] = h[child]; pos = child; child = 2 * pos + 1;
+    }
+    h[pos] = item;
+    heap_siftdown(s, h, startpos, pos);
+}
+static void heap_push_bounded(const two_service *s, two_cand *h, int *n, int K, const two_cand *c) {
+    h[*n] = *c; (*n)++;
+    heap_siftdown(s, h, 0, *n - 1);
+    if (*n > K) { /* heappop */
+        two_cand last = h[*n - 1]; (*n)--;
+        if (*n > 0) { h[0] = last; heap_siftup(s, h, *n, 0); }
+    }
+}
+static void rev(two_cand *a, int n) { for (int i = 0, j = n - 1; i < j; i++, j--) { two_cand t = a[i]; a[i] = a[j]; a[j] = t; } }
+/* CPython list.sort(reverse=True) for n < 64: reverse, count_run, binarysort, reverse */
+static void sort_desc(const two_service *s, two_cand *a, int n) {
+    if (n < 2) return;
+    rev(a, n);
+    int run = 2, descending = 0;
+    if (cand_lt(s, &a[1], &a[0])) {
+        descending = 1;
+        for (int i = 2; i < n; i++, run++) if (!cand_lt(s, &a[i], &a[i - 1])) break;
+    } else {
+        for (int i = 2; i < n; i++, run++) if (cand_lt(s, &a[i], &a[i - 1])) break;
+    }
+    if (descending) rev(a, run);
+    for (int start = run; start < n; start++) {
+        int l = 0, r = start;
+        two_cand pivot = a[start];
+        do { int p = l + ((r - l) >> 1); if (cand_lt(s, &pivot, &a[p])) r = p; else l = p + 1; } while (l < r);
+        for (int p = start; p > l; p--) a[p] = a[p - 1];
+        a[l] = pivot;
+    }
+    rev(a, n);
+}
+
+/* ------------------------------------------------------------------ DFS enumeration */
+typedef void (*leaf_fn)(void *ctx, const int64_t *x);
+
+/* Enumerates feasible tuples in the reference's DFS order (V3:315-351 / V3:254-288):
+ * endpoints in topological order, candidates by increasing index inside [lo,hi], containment
+ * in_start <= s.start, s.end <= in_end, and pred.end <= s.start for every DAG in-edge. */
+static void dfs(const two_lists *L, int64_t in_start, int64_t in_end, const int64_t *lo, const int64_t *hi,
+                leaf_fn fn, void *ctx) {
+    const two_service *s = L->s;
+    int E = s->E, d = 0;
+    int64_t x[TWO_MAX_E];
+    x[0] = lo[0] - 1;
+    while (d >= 0) {
+        int64_t c = x[d] + 1;
+        int found = 0;
+        for (; c <= hi[d]; c++) {
+            if (is_gone(L, d, c)) continue;
+            int64_t st = ostart(s, d, c);
+            if (in_start > st || oend(s, d, c) > in_end) continue;
+            int ok = 1;
+            for (int p = 0; p < d; p++)
+                if (s->dag[p * E + d] && oend(s, p, x[p]) > st) { ok = 0; break; }
+            if (ok) { found = 1; break; }
+        }
+        if (!found) { d--; continue; }
+        x[d] = c;
+        if (d == E - 1) fn(ctx, x);
+        else { d++; x[d] = lo[d] - 1; }
+    }
+}
+
+typedef struct {
+    const two_service *s; const two_graph *g; const two_params *P;
+    int64_t in_start, in_end, leaves;
+    two_cand heap[TWO_MAX_K + 1]; int nheap, K;
+} topk_ctx;
+static void topk_leaf(void *vctx, const int64_t *x) {
+    topk_ctx *c = (topk_ctx *)vctx;
+    two_cand cand;
+    c->leaves++;
+    cand.score = score_tuple(c->s, c->g, c->P, c->in_start, c->in_end, x);
+    for (int e = 0; e < c->s->E; e++) cand.idx[e] = (int32_t)x[e];
+    for (int e = c->s->E; e < TWO_MAX_E; e++) cand.idx[e] = -1;
+    heap_push_bounded(c->s, c->heap, &c->nheap, c->K, &cand);
+}
+/* FindTopKAssignments(preprocess_phase=False) V3:180-465.  Returns #candidates (<=K), -1 on error. */
+static int find_topk(const two_lists *L, const two_graph *g, const two_params *P, int i, two_cand *out, int64_t *leaves) {
+    const two_service *s = L->s;
+    int64_t lo[TWO_MAX_E], hi[TWO_MAX_E];
+    topk_ctx c;
+    if (cutoffs(L, s->in_start[i], s->in_end[i], lo, hi) != 0) return -1;
+    c.s = s; c.g = g; c.P = P; c.in_start = s->in_start[i]; c.in_end = s->in_end[i];
+    c.leaves = 0; c.nheap = 0; c.K = s->topk;
+    dfs(L, c.in_start, c.in_end, lo, hi, topk_leaf, &c);
+    sort_desc(s, c.heap, c.nheap);
+    memcpy(out, c.heap, sizeof(two_cand) * (size_t)c.nheap);
+    *leaves = c.leaves;
+    return c.nheap;
+}
+
+/* ------------------------------------------------------------------ windows (CreateWindows2) */
+typedef struct { const two_service *s; const int64_t *lo; uint64_t **bits; int64_t leaves; } cand_ctx;
+static void cand_leaf(void *vctx, const int64_t *x) {
+    cand_ctx *c = (cand_ctx *)vctx;
+    c->leaves++;
+    for (int e = 0; e < c->s->E; e++) { int64_t r = x[e] - c->lo[e]; c->bits[e][r >> 6] |= 1ull << (r & 63); }
+}
+
+/* out: end_flag[n_in] (1 where (cnt-1) in window_ends, V3:1192), pre_leaves[n_in] (#tuples from
+ * DfsTraverse3), windows[2*n_windows] (start,end) as appended by V3:1062-1072, returns n_windows. */
+int two_windows(const two_service *s, uint8_t *end_flag, int64_t *pre_leaves, int32_t *windows, int32_t max_windows) {
+    int n = s->n_in, E = s->E;
+    two_lists L; L.s = s; memset(L.consumed, 0, sizeof(L.consumed));
+    int64_t *clo = (int64_t *)malloc(sizeof(int64_t) * (size_t)n * E);
+    int64_t *cw = (int64_t *)malloc(sizeof(int64_t) * (size_t)n * E);
+    uint64_t **cbits = (uint64_t **)calloc((size_t)n * E, sizeof(uint64_t *));
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; i++) {
+        int64_t lo[TWO_MAX_E], hi[TWO_MAX_E];
+        uint64_t *bits[TWO_MAX_E];
+        if (cutoffs(&L, s->in_start[i], s->in_end[i], lo, hi) != 0) { rc = -1; break; }
+        for (int e = 0; e < E; e++) {
+            int64_t w = hi[e] - lo[e] + 1; if (w < 0) w = 0;
+            clo[(size_t)i * E + e] = lo[e]; cw[(size_t)i * E + e] = w;
+            bits[e] = cbits[(size_t)i * E + e] = (uint64_t *)calloc((size_t)(w / 64 + 1), sizeof(uint64_t));
+        }
+        cand_ctx c = { s, lo, bits, 0 };
+        dfs(&L, s->in_start[i], s->in_end[i], lo, hi, cand_leaf, &c);
+        if (pre_leaves) pre_leaves[i] = c.leaves;
+    }
+    int nw = 0;
+    if (rc == 0) {
+        memset(end_flag, 0, (size_t)n);
+        int prev = 0, window_start = 0, current_count = 1;
+        for (int i = 0; i < n; i++) {
+            if (i != 0) {
+                int cut = 0;
+                if (i == n - 1) {
+                    current_count = 0;
+                    if (nw < max_windows) { windows[2 * nw] = window_start; windows[2 * nw + 1] = i; } nw++;
+                    end_flag[i] = 1; cut = 1;
+                } else {
+                    /* PerfectCut(i) V3:1024-1039 */
+                    if (i == 1) prev = 0;
+                    else if (s->in_end[i - 1] >= s->in_end[prev]) prev = i - 1;
+                    int disjoint = 1;
+                    for (int e = 0; e < E && disjoint; e++) {
+                        int64_t la = clo[(size_t)prev * E + e], wa = cw[(size_t)prev * E + e];
+                        int64_t lb = clo[(size_t)i * E + e], wb = cw[(size_t)i * E + e];
+                        int64_t from = la > lb ? la : lb, to = (la + wa < lb + wb ? la + wa : lb + wb);
+                        for (int64_t x = from; x < to; x++) {
+                            int64_t ra = x - la, rb = x - lb;
+                            if ((cbits[(size_t)prev * E + e][ra >> 6] >> (ra & 63) & 1) && (cbits[(size_t)i * E + e][rb >> 6] >> (rb & 63) & 1)) { disjoint = 0; break; }
+                        }
+                    }
+                    if (disjoint && s->in_end[prev] <= s->in_end[i]) {
+                        current_count = 0;
+                        if (nw < max_windows) { windows[2 * nw] = window_start; windows[2 * nw + 1] = i - 1; } nw++;
+                        end_flag[i - 1] = 1; window_start = i; cut = 1;
+                    } else if (current_count == s->batch_size_mis) {
+                        current_count = 0;
+                        if (nw < max_windows) { windows[2 * nw] = window_start; windows[2 * nw + 1] = i; } nw++;
+                        end_flag[i] = 1; window_start = i + 1; cut = 1;
+                    }
+                }
+                (void)cut;
+            } else window_start = i;
+            current_count += 1;
+        }
+    }
+    for (size_t j = 0; j < (size_t)n * E; j++) free(cbits[j]);
+    free(cbits); free(clo); free(cw);
+    return rc == 0 ? nw : rc;
+}
+
+/* ------------------------------------------------------------------ pass-1 Gaussian parameters */
+static int cmp_i64(const void *a, const void *b) { int64_t x = *(const int64_t *)a, y = *(const int64_t *)b; return (x > y) - (x < y); }
+
+/* numpy add.reduce over a contiguous double array: 0 + pairwise_sum (n <= 128 branch) */
+static double np_sum(const double *a, int n) {
+    if (n < 8) { double r = 0.0; for (int i = 0; i < n; i++) r += a[i]; return r; }
+    double r[8], res; int i;
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return 0.0 + res;
+}
+/* ComputeDistParams V3:590-617 on rank slice [a,b) of two sorted arrays */
+static void dist_params(const int64_t *t1, const int64_t *t2, int a, int b, double *mean, double *std) {
+    int len = b - a;
+    int64_t s1 = 0, s2 = 0;
+    for (int i = a; i < b; i++) { s1 += t1[i]; s2 += t2[i]; }
+    *mean = (double)(s2 - s1) / (double)len;
+    int nb = 10, bs = (len + nb - 1) / nb, m = 0;
+    double bm[10];
+    for (int k = 0; k < nb; k++) {
+        int st = k * bs, en = (k + 1) * bs < len ? (k + 1) * bs : len;
+        if (en - st > 0) {
+            int64_t u1 = 0, u2 = 0;
+            for (int i = a + st; i < a + en; i++) { u1 += t1[i]; u2 += t2[i]; }
+            bm[m++] = (double)(u2 - u1) / (double)(en - st);
+        }
+    }
+    /* scipy 1.14 tstd = sqrt(np.var(x, ddof=1)) */
+    double mu = np_sum(bm, m) / (double)m, d2[10];
+    for (int k = 0; k < m; k++) { double d = bm[k] - mu; d2[k] = d * d; }
+    double var = np_sum(d2, m) / (double)(m - 1); /* m==1 -> 0/0 = NaN, as the reference (H3) */
+    *std = sqrt((double)bs) * sqrt(var);
+}
+
+/* gauss: [n_blocks][nslot][2]; unscored slots are left NaN.  Returns n_blocks. */
+int two_gauss_params(const two_service *s, double *gauss, int32_t max_blocks) {
+    int n = s->n_in, E = s->E, nslot = NSLOT(E), nb = (n + s->batch_size - 1) / s->batch_size;
+    if (nb > max_blocks) return -1;
+    for (int e = 0; e < E; e++) if (n_out(s, e) < n) return -2; /* rank slices need n_out >= n_in */
+    int64_t *in_end_sorted = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    memcpy(in_end_sorted, s->in_end, sizeof(int64_t) * (size_t)n);
+    qsort(in_end_sorted, (size_t)n, sizeof(int64_t), cmp_i64);
+    int64_t *oes[TWO_MAX_E];
+    for (int e = 0; e < E; e++) {
+        int64_t m = n_out(s, e);
+        oes[e] = (int64_t *)malloc(sizeof(int64_t) * (size_t)m);
+        memcpy(oes[e], s->out_end + s->out_off[e], sizeof(int64_t) * (size_t)m);
+        qsort(oes[e], (size_t)m, sizeof(int64_t), cmp_i64);
+    }
+    for (int i = 0; i < nb * nslot * 2; i++) gauss[i] = NAN;
+    for (int b = 0; b < nb; b++) {
+        int a = b * s->batch_size, z = a + s->batch_size < n ? a + s->batch_size : n;
+        double *g = gauss + (size_t)b * nslot * 2;
+        for (int e = 0; e < E; e++) {
+            int npred = 0;
+            for (int p = 0; p < E; p++) if (s->dag[p * E + e]) npred++;
+            if (npred == 0) dist_params(s->in_start, s->out_start + s->out_off[e], a, z, &g[2 * SLOT_ROOT(E, e)], &g[2 * SLOT_ROOT(E, e) + 1]);
+            for (int p = 0; p < E; p++)
+                if (is_primary(s, p, e)) dist_params(oes[p], s->out_start + s->out_off[e], a, z, &g[2 * SLOT_PRIM(E, p, e)], &g[2 * SLOT_PRIM(E, p, e) + 1]);
+            dist_params(oes[e], in_end_sorted, a, z, &g[2 * SLOT_CLOSE(E, e)], &g[2 * SLOT_CLOSE(E, e) + 1]);
+        }
+    }
+    for (int e = 0; e < E; e++) free(oes[e]);
+    free(in_end_sorted);
+    return nb;
+}
+
+/* ------------------------------------------------------------------ exact MWIS per window */
+typedef struct {
+    int m;                               /* in-spans in the component */
+    int n[TWO_MAX_WIN];                  /* eligible candidate count */
+    int kk[TWO_MAX_WIN][TWO_MAX_K];      /* candidate ids */
+    double w[TWO_MAX_WIN][TWO_MAX_K];
+    const int32_t *idx[TWO_MAX_WIN][TWO_MAX_K];
+    double ub[TWO_MAX_WIN + 1];
+    int E;
+    int cur[TWO_MAX_WIN], best[TWO_MAX_WIN];
+    double best_w;
+    int64_t nodes;
+} mwis_comp;
+
+static int shares(int E, const int32_t *a, const int32_t *b) { for (int e = 0; e < E; e++) if (a[e] == b[e]) return 1; return 0; }
+
+static void mwis_dfs(mwis_comp *c, int d, double acc) {
+    c->nodes++;
+    if (d == c->m) { if (acc > c->best_w) { c->best_w = acc; memcpy(c->best, c->cur, sizeof(int) * (size_t)c->m); } return; }
+    if (acc + c->ub[d] <= c->best_w) return;
+    for (int j = 0; j < c->n[d]; j++) {
+        int ok = 1;
+        for (int q = 0; q < d && ok; q++) if (c->cur[q] >= 0 && shares(c->E, c->idx[q][c->cur[q]], c->idx[d][j])) ok = 0;
+        if (!ok) continue;
+        c->cur[d] = j;
+        mwis_dfs(c, d + 1, acc + c->w[d][j]);
+    }
+    c->cur[d] = -1;
+    mwis_dfs(c, d + 1, acc);
+}
+
+/* Exact maximum-weight independent set of the window's conflict graph (V3:1252-1281, V3:1395-1419).
+ * Canonical procedure (also followed by the GPU engine so that exact ties resolve identically):
+ *   nodes with weight 10000+score <= 0 are never selected; the window is split into connected
+ *   components of the in-span conflict relation; each component is searched depth-first over its
+ *   in-spans in index order, candidates in list order then "none", sums accumulated left to right,
+ *   a subtree is cut when acc + suffix_upper_bound <= best, and only strict improvements replace
+ *   the incumbent.  chosen[i] = candidate index or -1. */
+static int64_t mwis_window(const two_service *s, int m, const int *ncand, two_cand (*cands)[TWO_MAX_K], int *chosen) {
+    int E = s->E, comp[TWO_MAX_WIN];
+    int64_t nodes = 0;
+    for (int i = 0; i < m; i++) { comp[i] = i; chosen[i] = -1; }
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < i; j++) {
+            int hit = 0;
+            for (int a = 0; a < ncand[i] && !hit; a++) {
+                if (!(10000.0 + cands[i][a].score > 0.0)) continue;
+                for (int b = 0; b < ncand[j] && !hit; b++)
+                    if (10000.0 + cands[j][b].score > 0.0 && shares(E, cands[i][a].idx, cands[j][b].idx)) hit = 1;
+            }
+            if (hit) { int ci = comp[i], cj = comp[j], lo = ci < cj ? ci : cj, hi = ci < cj ? cj : ci; for (int t = 0; t < m; t++) if (comp[t] == hi) comp[t] = lo; }
+        }
+    for (int root = 0; root < m; root++) {
+        if (comp[root] != root) continue;
+        mwis_comp c; int members[TWO_MAX_WIN];
+        c.m = 0; c.E = E; c.nodes = 0;
+        for (int i = root; i < m; i++) {
+            if (comp[i] != root) continue;
+            int d = c.m++; members[d] = i; c.n[d] = 0;
+            for (int a = 0; a < ncand[i]; a++) {
+                double w = 10000.0 + cands[i][a].score;
+                if (!(w > 0.0)) continue;
+                c.kk[d][c.n[d]] = a; c.w[d][c.n[d]] = w; c.idx[d][c.n[d]] = cands[i][a].idx; c.n[d]++;
+            }
+        }
+        c.ub[c.m] = 0.0;
+        for (int d = c.m - 1; d >= 0; d--) { double mx = 0.0; for (int j = 0; j < c.n[d]; j++) if (c.w[d][j] > mx) mx = c.w[d][j]; c.ub[d] = c.ub[d + 1] + mx; }
+        for (int d = 0; d < c.m; d++) { c.cur[d] = -1; c.best[d] = -1; }
+        c.best_w = 0.0;
+        mwis_dfs(&c, 0, 0.0);
+        for (int d = 0; d < c.m; d++) chosen[members[d]] = c.best[d] >= 0 ? c.kk[d][c.best[d]] : -1;
+        nodes += c.nodes;
+    }
+    return nodes;
+}
+
+/* ------------------------------------------------------------------ one pass of the main loop */
+/* Outputs (caller-allocated, K = s->topk):
+ *   topk_n[n], topk_idx[n*K*E], topk_score[n*K]   : top_k on the remaining spans (V3:1182)
+ *   topk2_*                                         : top_k_2 on all spans (V3:1185)
+ *   leaves[n]   : DFS leaves of the top_k call (per_span_candidates increment)
+ *   chosen[n]   : index into top_k of the MWIS pick, -1 unassigned
+ *   parent[E*n] : out-span index per endpoint, -1 = ("NA","NA")
+ *   stats[4]    : not_best_count, cnt_unassigned, mwis search nodes, windows solved
+ * gauss: [n_blocks][nslot][2] (mode 0).  Returns 0 or <0 on error. */
+int two_run_pass(const two_service *s, int mode, const double *gauss, const int32_t *mix_n, const double *mix_p,
+                 const uint8_t *end_flag, int32_t *topk_n, int32_t *topk_idx, double *topk_score, int32_t *topk2_n,
+                 int32_t *topk2_idx, double *topk2_score, int64_t *leaves, int32_t *chosen, int32_t *parent, int64_t *stats) {
+    int n = s->n_in, E = s->E, K = s->topk, nslot = NSLOT(E);
+    if (E > TWO_MAX_E || K > TWO_MAX_K) return -3;
+    two_graph g; build_graph(s, &g);
+    two_lists full, rem; full.s = rem.s = s;
+    memset(full.consumed, 0, sizeof(full.consumed));
+    for (int e = 0; e < TWO_MAX_E; e++) rem.consumed[e] = NULL;
+    for (int e = 0; e < E; e++) rem.consumed[e] = (uint8_t *)calloc((size_t)n_out(s, e) + 1, 1);
+    two_params P; P.mode = mode; P.gauss = NULL; P.mix_n = mix_n; P.mix_p = mix_p;
+    static two_cand batch[TWO_MAX_WIN][TWO_MAX_K];
+    int batch_n[TWO_MAX_WIN], batch_i[TWO_MAX_WIN], nbatch = 0, rc = 0;
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    for (int i = 0; i < E * n; i++) parent[i] = -1;
+    for (int i = 0; i < n && rc == 0; i++) {
+        if (mode == 0) P.gauss = gauss + (size_t)(i / s->batch_size) * nslot * 2; /* V3:1173-1178 */
+        two_cand t2[TWO_MAX_K];
+        int64_t lv, lv2;
+        if (nbatch >= TWO_MAX_WIN) { rc = -4; break; }
+        int c1 = find_topk(&rem, &g, &P, i, batch[nbatch], &lv);
+        int c2 = find_topk(&full, &g, &P, i, t2, &lv2);
+        if (c1 < 0 || c2 < 0) { rc = -5; break; }
+        leaves[i] = lv; topk_n[i] = c1; topk2_n[i] = c2;
+        for (int k = 0; k < K; k++) {
+            topk_score[(size_t)i * K + k] = k < c1 ? batch[nbatch][k].score : NAN;
+            topk2_score[(size_t)i * K + k] = k < c2 ? t2[k].score : NAN;
+            for (int e = 0; e < E; e++) {
+                topk_idx[((size_t)i * K + k) * E + e] = k < c1 ? batch[nbatch][k].idx[e] : -1;
+                topk2_idx[((size_t)i * K + k) * E + e] = k < c2 ? t2[k].idx[e] : -1;
+            }
+        }
+        batch_n[nbatch] = c1; batch_i[nbatch] = i; nbatch++;
+        if (end_flag[i]) {
+            int pick[TWO_MAX_WIN];
+            stats[2] += mwis_window(s, nbatch, batch_n, batch, pick);
+            stats[3] += 1;
+            for (int b = 0; b < nbatch; b++) {
+                int ii = batch_i[b];
+                chosen[ii] = pick[b];
+                if (batch_n[b] < 1 || pick[b] < 0) stats[0] += 1;      /* V3:1201-1202 */
+                else if (pick[b] != 0) stats[0] += 1;                  /* V3:1204-1207 */
+                if (pick[b] < 0) { stats[1] += 1; continue; }          /* V3:1217 */
+                for (int e = 0; e < E; e++) {
+                    int32_t x = batch[b][pick[b]].idx[e];
+                    parent[(size_t)e * n + ii] = x;
+                    rem.consumed[e][x] = 1;                            /* V1:457-463 */
+                }
+            }
+            nbatch = 0;
+        }
+    }
+    for (int e = 0; e < E; e++) free(rem.consumed[e]);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ gap samples for the refit */
+/* V3:717-762: per scored slot, gaps implied by an assignment (unassigned in-spans dropped), in
+ * in-span order.  gaps: [nslot][n_in] doubles, counts: [nslot]. */
+int two_gaps(const two_service *s, const int32_t *parent, double *gaps, int32_t *counts) {
+    int n = s->n_in, E = s->E, nslot = NSLOT(E);
+    for (int q = 0; q < nslot; q++) counts[q] = -1; /* -1: slot not scored */
+    for (int e = 0; e < E; e++) {
+        int npred = 0;
+        for (int p = 0; p < E; p++) if (s->dag[p * E + e]) npred++;
+        if (npred == 0) {
+            int q = SLOT_ROOT(E, e), c = 0;
+            for (int i = 0; i < n; i++) { int32_t x = parent[(size_t)e * n + i]; if (x < 0) continue; gaps[(size_t)q * n + c++] = (double)(ostart(s, e, x) - s->in_start[i]); }
+            counts[q] = c;
+        }
+        for (int p = 0; p < E; p++) {
+            if (!is_primary(s, p, e)) continue;
+            int q = SLOT_PRIM(E, p, e), c = 0;
+            for (int i = 0; i < n; i++) {
+                int32_t xp = parent[(size_t)p * n + i], xe = parent[(size_t)e * n + i];
+                if (xp < 0 || xe < 0) continue;
+                gaps[(size_t)q * n + c++] = (double)(ostart(s, e, xe) - oend(s, p, xp));
+            }
+            counts[q] = c;
+        }
+        int q = SLOT_CLOSE(E, e), c = 0;
+        for (int i = 0; i < n; i++) { int32_t x = parent[(size_t)e * n + i]; if (x < 0) continue; gaps[(size_t)q * n + c++] = (double)(s->in_end[i] - oend(s, e, x)); }
+        counts[q] = c;
+    }
+    return 0;
+}

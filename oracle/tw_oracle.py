@@ -1,0 +1,205 @@
+"""ctypes front-end of the CPU oracle (oracle/tw_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg as the checker / CPU baseline.  The product package (traceweaver_amd/) must never import this.
+
+`run_service()` restates TraceWeaverV3.FindAssignments (traceweaver_v3.py:1087-1229, no-skip mode):
+windows -> per-block Gaussian parameters -> pass 1 -> gap samples -> mixture refit -> pass 2.
+The mixture refit (traceweaver_v3.py:764-786) uses scikit-learn exactly as the reference does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libtw_oracle.so")
+TOPK = 5
+MAX_COMP = 5
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "tw_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _LIB_PATH
+
+
+class _Service(ctypes.Structure):
+    _fields_ = [
+        ("n_in", ctypes.c_int32), ("E", ctypes.c_int32),
+        ("in_start", ctypes.c_void_p), ("in_end", ctypes.c_void_p),
+        ("out_off", ctypes.c_void_p), ("out_start", ctypes.c_void_p), ("out_end", ctypes.c_void_p),
+        ("dag", ctypes.c_void_p), ("key_rank", ctypes.c_void_p),
+        ("batch_size", ctypes.c_int32), ("batch_size_mis", ctypes.c_int32), ("topk", ctypes.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        for name in ("two_log", "two_exp", "two_log1p"):
+            getattr(_lib, name).restype = ctypes.c_double
+            getattr(_lib, name).argtypes = [ctypes.c_double]
+        _lib.two_windows.restype = ctypes.c_int
+        _lib.two_gauss_params.restype = ctypes.c_int
+        _lib.two_run_pass.restype = ctypes.c_int
+        _lib.two_gaps.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else ctypes.c_void_p(0)
+
+
+class Service(object):
+    """SoA view of one service: endpoints in topological order, spans sorted by (start, end)."""
+
+    def __init__(self, in_start, in_dur, out_off, out_start, out_dur, dag, key_rank=None,
+                 batch_size=100, batch_size_mis=30, topk=TOPK):
+        self.in_start = np.ascontiguousarray(in_start, dtype=np.int64)
+        self.in_end = self.in_start + np.ascontiguousarray(in_dur, dtype=np.int64)
+        self.out_off = np.ascontiguousarray(out_off, dtype=np.int64)
+        self.out_start = np.ascontiguousarray(out_start, dtype=np.int64)
+        self.out_end = self.out_start + np.ascontiguousarray(out_dur, dtype=np.int64)
+        self.E = len(self.out_off) - 1
+        self.n_in = len(self.in_start)
+        self.dag = np.ascontiguousarray(dag, dtype=np.uint8).reshape(self.E, self.E)
+        self.key_rank = np.ascontiguousarray(
+            np.arange(self.E) if key_rank is None else key_rank, dtype=np.int32)
+        self.c = _Service(self.n_in, self.E, _p(self.in_start), _p(self.in_end), _p(self.out_off),
+                          _p(self.out_start), _p(self.out_end), _p(self.dag), _p(self.key_rank),
+                          batch_size, batch_size_mis, topk)
+        self.topk = topk
+        self.batch_size = batch_size
+
+    @property
+    def nslot(self):
+        return self.E * self.E + 2 * self.E
+
+    def slot_root(self, e):
+        return e
+
+    def slot_prim(self, p, e):
+        return self.E + p * self.E + e
+
+    def slot_close(self, e):
+        return self.E + self.E * self.E + e
+
+
+def windows(svc):
+    n = svc.n_in
+    end_flag = np.zeros(n, dtype=np.uint8)
+    pre = np.zeros(n, dtype=np.int64)
+    win = np.zeros((n + 2, 2), dtype=np.int32)
+    nw = lib().two_windows(ctypes.byref(svc.c), _p(end_flag), _p(pre), _p(win), ctypes.c_int32(n + 2))
+    if nw < 0:
+        raise RuntimeError("two_windows failed: %d" % nw)
+    return end_flag, pre, win[:nw].copy()
+
+
+def gauss_params(svc):
+    nb = (svc.n_in + svc.batch_size - 1) // svc.batch_size
+    g = np.zeros((nb, svc.nslot, 2), dtype=np.float64)
+    rc = lib().two_gauss_params(ctypes.byref(svc.c), _p(g), ctypes.c_int32(nb))
+    if rc < 0:
+        raise RuntimeError("two_gauss_params failed: %d" % rc)
+    return g
+
+
+def run_pass(svc, end_flag, gauss=None, mix_n=None, mix_p=None):
+    """mode 0 (gauss given) or mode 1 (mixtures: mix_n [nslot] int32, mix_p [nslot,5,3] w/mean/prec_chol)."""
+    n, E, K = svc.n_in, svc.E, svc.topk
+    o = {
+        "topk_n": np.zeros(n, np.int32), "topk_idx": np.zeros((n, K, E), np.int32), "topk_score": np.zeros((n, K)),
+        "topk2_n": np.zeros(n, np.int32), "topk2_idx": np.zeros((n, K, E), np.int32), "topk2_score": np.zeros((n, K)),
+        "leaves": np.zeros(n, np.int64), "chosen": np.full(n, -1, np.int32), "parent": np.zeros((E, n), np.int32),
+    }
+    stats = np.zeros(4, np.int64)
+    mode = 0 if gauss is not None else 1
+    if mode == 1:
+        mix_n = np.ascontiguousarray(mix_n, dtype=np.int32)
+        mix_p = np.ascontiguousarray(mix_p, dtype=np.float64)
+        assert mix_p.shape == (svc.nslot, MAX_COMP, 3)
+    else:
+        gauss = np.ascontiguousarray(gauss, dtype=np.float64)
+    rc = lib().two_run_pass(ctypes.byref(svc.c), ctypes.c_int(mode), _p(gauss), _p(mix_n), _p(mix_p), _p(end_flag),
+                            _p(o["topk_n"]), _p(o["topk_idx"]), _p(o["topk_score"]), _p(o["topk2_n"]),
+                            _p(o["topk2_idx"]), _p(o["topk2_score"]), _p(o["leaves"]), _p(o["chosen"]),
+                            _p(o["parent"]), _p(stats))
+    if rc != 0:
+        raise RuntimeError("two_run_pass failed: %d" % rc)
+    o["not_best_count"], o["cnt_unassigned"], o["mwis_nodes"], o["n_windows"] = (int(v) for v in stats)
+    return o
+
+
+def gaps(svc, parent):
+    parent = np.ascontiguousarray(parent, dtype=np.int32)
+    g = np.zeros((svc.nslot, svc.n_in), dtype=np.float64)
+    cnt = np.zeros(svc.nslot, dtype=np.int32)
+    lib().two_gaps(ctypes.byref(svc.c), _p(parent), _p(g), _p(cnt))
+    return [g[q, :cnt[q]].copy() if cnt[q] >= 0 else None for q in range(svc.nslot)]
+
+
+def fit_mixture(durations, n_selected=None):
+    """traceweaver_v3.py:764-786 for one edge: BIC over 1..min(5,#unique) diag fits (global numpy RNG),
+    then a full-covariance refit with random_state=100.  Returns (n, [n,3] weight/mean/prec_chol)."""
+    from sklearn import mixture
+
+    d = np.asarray(durations, dtype=np.float64).reshape(-1, 1)
+    if len(d) == 0:
+        return 0, np.zeros((MAX_COMP, 3))
+    if n_selected is None:
+        max_n = min(len(np.unique(d)), 5)
+        models, n_comps = [], []
+        for n in range(1, max_n + 1):
+            try:
+                models.append(mixture.GaussianMixture(n_components=n, covariance_type="diag").fit(d))
+                n_comps.append(n)
+            except ValueError:
+                continue
+        n_selected = n_comps[int(np.argmin([m.bic(d) for m in models]))]
+    g = mixture.GaussianMixture(n_components=n_selected, random_state=100).fit(d)
+    p = np.zeros((MAX_COMP, 3))
+    p[:n_selected, 0] = g.weights_
+    p[:n_selected, 1] = g.means_.ravel()
+    p[:n_selected, 2] = g.precisions_cholesky_.ravel()
+    return n_selected, p
+
+
+def run_service(svc, mixtures=None, seed=None):
+    """Full two-pass restatement.  `mixtures` = (mix_n, mix_p) overrides the refit (used to compare
+    pass 2 against the reference under identical fitted parameters, SURVEY.md hazard H9)."""
+    if seed is not None:
+        np.random.seed(seed)
+    end_flag, pre, win = windows(svc)
+    g = gauss_params(svc)
+    p1 = run_pass(svc, end_flag, gauss=g)
+    out = {"end_flag": end_flag, "pre_leaves": pre, "windows": win, "gauss": g, "pass1": p1}
+    if mixtures is None:
+        mix_n = np.zeros(svc.nslot, np.int32)
+        mix_p = np.zeros((svc.nslot, MAX_COMP, 3))
+        for q, d in enumerate(gaps(svc, p1["parent"])):
+            if d is not None:
+                mix_n[q], mix_p[q] = fit_mixture(d)
+    else:
+        mix_n, mix_p = mixtures
+    out["mix_n"], out["mix_p"] = mix_n, mix_p
+    out["pass2"] = run_pass(svc, end_flag, mix_n=mix_n, mix_p=mix_p)
+    out["per_span_candidates"] = p1["leaves"] + out["pass2"]["leaves"]
+    return out
+
+
+def service_from_golden(d):
+    return Service(d["in_start"], d["in_dur"], d["out_off"], d["out_start"], d["out_dur"], d["dag"],
+                   key_rank=golden_key_rank(d))
+
+
+def golden_key_rank(d):
+    order = [str(x) for x in d["partition_key_order"]]
+    return np.array([order.index(str(e)) for e in d["out_eps"]], dtype=np.int32)

@@ -1,0 +1,26 @@
+"""Builds libtwgpu_emu.so: the engine source compiled with g++ against the host-emulation shim.
+TEST INFRASTRUCTURE ONLY -- see tests/hostemu/hip/hip_runtime.h."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, "_build", "libtwgpu_emu.so")
+SRC = os.path.join(REPO, "traceweaver_amd", "csrc")
+
+
+def build(force=False):
+    deps = [os.path.join(SRC, f) for f in ("tw_engine.hip", "tw_kernels.h", "tw_device.h")]
+    deps += [os.path.join(REPO, "include", "traceweaver_amd.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
+             os.path.join(HERE, "rocprim", "rocprim.hpp")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    subprocess.check_call([
+        "g++", "-x", "c++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+        "-I", HERE, "-I", os.path.join(REPO, "include"), "-I", SRC, os.path.join(SRC, "tw_engine.hip"), "-o", OUT])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

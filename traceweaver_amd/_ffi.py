@@ -1,0 +1,72 @@
+"""ctypes declarations of include/traceweaver_amd.h.  The shared library must have been built by
+`__graft_entry__.build()` (hipcc, gfx950); there is no fallback: a missing library is an error."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libtwgpu.so")
+
+TW_MAX_EP = 8
+TW_TOPK = 5
+TW_MAX_COMP = 5
+
+STATUS = {0: "TW_OK", -1: "TW_ERR_ARG", -2: "TW_ERR_UNSUPPORTED", -3: "TW_ERR_DEVICE", -4: "TW_ERR_STATE",
+          -5: "TW_ERR_WINDOW_WIDTH", -6: "TW_ERR_WINDOW_SIZE", -7: "TW_ERR_NAN_PARAMS"}
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+class Batch(ctypes.Structure):
+    _fields_ = [
+        ("n_units", ctypes.c_int32),
+        ("unit_in_off", ctypes.c_void_p), ("unit_E", ctypes.c_void_p), ("ep_off", ctypes.c_void_p),
+        ("dag", ctypes.c_void_p), ("key_rank", ctypes.c_void_p),
+        ("in_start", ctypes.c_void_p), ("in_end", ctypes.c_void_p),
+        ("out_start", ctypes.c_void_p), ("out_end", ctypes.c_void_p),
+        ("batch_size", ctypes.c_int32), ("batch_size_mis", ctypes.c_int32), ("topk", ctypes.c_int32),
+    ]
+
+
+class Results(ctypes.Structure):
+    _fields_ = [
+        ("parent", ctypes.c_void_p), ("topk_idx", ctypes.c_void_p), ("topk_score", ctypes.c_void_p),
+        ("topk_n", ctypes.c_void_p), ("chosen", ctypes.c_void_p), ("leaves", ctypes.c_void_p),
+        ("window_end", ctypes.c_void_p), ("unit_stats", ctypes.c_void_p),
+    ]
+
+
+EXPORTS = ["tw_create", "tw_destroy", "tw_last_error", "tw_load_batch", "tw_run_pass1", "tw_get_gaps",
+           "tw_set_mixtures", "tw_run_pass2", "tw_get_results", "tw_get_gauss_params", "tw_get_timing",
+           "tw_assign_service"]
+
+
+def load(path=None):
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise ImportError(
+            "traceweaver_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    vp = ctypes.c_void_p
+    lib.tw_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    lib.tw_destroy.argtypes = [vp]
+    lib.tw_destroy.restype = None
+    lib.tw_last_error.argtypes = [vp]
+    lib.tw_last_error.restype = ctypes.c_char_p
+    lib.tw_load_batch.argtypes = [vp, ctypes.POINTER(Batch), ctypes.c_int]
+    lib.tw_run_pass1.argtypes = [vp]
+    lib.tw_get_gaps.argtypes = [vp, vp]
+    lib.tw_set_mixtures.argtypes = [vp, vp, vp]
+    lib.tw_run_pass2.argtypes = [vp]
+    lib.tw_get_results.argtypes = [vp, ctypes.c_int, ctypes.POINTER(Results)]
+    lib.tw_get_gauss_params.argtypes = [vp, vp]
+    lib.tw_get_timing.argtypes = [vp, vp, ctypes.c_int32]
+    lib.tw_assign_service.argtypes = [vp, ctypes.c_int32, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp,
+                                      ctypes.POINTER(Results)]
+    for name in EXPORTS:
+        if name not in ("tw_destroy", "tw_last_error"):
+            getattr(lib, name).restype = ctypes.c_int
+    return lib

@@ -1,0 +1,284 @@
+// tw_device.h -- device-side data structures and arithmetic of the span->parent assignment engine.
+//
+// Arithmetic contract (DESIGN.md "Scores"): every score is a chain of IEEE-754 binary64 operations
+// in the order the reference evaluates them (traceweaver_v1.py:117-139,259-361), with no FMA
+// contraction (the translation unit is built with -ffp-contract=off).  log / exp / log1p follow the
+// published fdlibm algorithms (e_log.c, e_exp.c, s_log1p.c) so that the result is a pure function of
+// the inputs on any IEEE machine; they agree with glibc/numpy to <= 1 ulp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "traceweaver_amd.h"
+
+namespace tw {
+
+constexpr int kMaxEp = TW_MAX_EP;
+constexpr int kTopK = TW_TOPK;
+constexpr int kMaxComp = TW_MAX_COMP;
+constexpr int kMaxWin = TW_MAX_WINDOW;
+constexpr int kCandWords = TW_CAND_WORDS;
+constexpr int kTile = 256;  // incoming spans per workgroup in the per-span kernels
+constexpr int32_t kNoOwner = 0x7f7f7f7f;
+
+// One service unit as the kernels see it.
+struct UnitDev {
+    int64_t in_off;            // first incoming span in in_start/in_end
+    int64_t ie_off;            // sum of n_in*E of earlier units: base of per-(span,endpoint) arrays
+    int64_t ep_off[kMaxEp + 1];  // global offsets of the endpoint segments in out_start/out_end
+    int32_t n_in;
+    int32_t E;
+    int32_t nblk;              // ceil(n_in / batch_size)
+    int32_t nslot;             // E*E + 2E
+    int64_t gp_off;            // base of this unit's Gaussian parameter table (in slots)
+    int32_t slot_off;          // base of this unit's mixture table (in slots)
+    int32_t tile_off;          // first tile (workgroup) of this unit
+    int32_t ntile;
+    uint8_t pred_mask[kMaxEp];            // bit p set <=> edge p->e (ordering constraint)
+    uint8_t succ_mask[kMaxEp];            // bit f set <=> edge e->f
+    uint8_t npred[kMaxEp];
+    uint8_t pred_list[kMaxEp][kMaxEp];    // predecessors in networkx in_edges() order
+    uint8_t pred_prim[kMaxEp][kMaxEp];    // 1 <=> that in-edge is primary (scored)
+};
+
+struct TileDev {
+    int32_t unit;
+    int32_t first;  // local index of the tile's first incoming span
+};
+
+struct PairVI {
+    int64_t v;
+    int32_t i;
+};
+
+// All device pointers, passed to kernels by value.
+struct Dev {
+    const UnitDev* units;
+    const TileDev* tiles;
+    int32_t n_units, n_tiles;
+    int64_t n_in_total, n_out_total;
+    int32_t batch_size, batch_mis;
+    // spans (SoA, 16 B per span)
+    const int64_t *in_start, *in_end, *out_start, *out_end;
+    // sorted end times for the rank-aligned block statistics
+    int64_t *in_end_sorted, *out_end_sorted;
+    // Gaussian parameters [gp slots][4] = mean, std, log(std_used), std_used
+    double* gparam;
+    // mixtures [slots] / [slots][kMaxComp][4] = mean, prec_chol, log(prec_chol), log(weight)
+    const int32_t* mix_n;
+    const double* mix_c;
+    // per incoming span
+    int64_t* pm_val;    // inclusive prefix max of in_end inside the unit
+    int32_t* pm_idx;    // its arg max (latest on ties)
+    uint8_t* pc;        // PerfectCut(i)
+    int32_t* seg;       // latest PerfectCut position <= i (0 if none)
+    uint8_t* win_end;   // window closes after this span
+    int32_t* wid;       // window id inside the unit
+    int32_t* w_last;    // [in_off + w] last span of window w
+    int32_t* unit_nwin; // [n_units]
+    uint8_t* w_dirty;   // [in_off + w] window needs the exact repair walk
+    int32_t* unit_ndirty;
+    int32_t* tk_n;      // candidates found on all spans (top_k_2)
+    int64_t* leaves;
+    int32_t* chosen;
+    uint8_t* rep;       // 1 <=> candidate list was recomputed with consumed spans masked out
+    int32_t* tkr_n;
+    // per (unit, k, endpoint, span) / (unit, k, span)
+    int32_t *tk_idx, *tkr_idx;
+    double *tk_score, *tkr_score;
+    // per (unit, endpoint, span)
+    int32_t* c_lo;      // first candidate index (full-list cutoff)
+    uint64_t* c_bits;   // kCandWords words: spans that occur in >= 1 feasible tuple
+    int32_t* parent;
+    // per outgoing span
+    int32_t* owner;     // smallest window id that speculatively chose the span
+    // gap samples [gs_off + q*n_in + i]
+    double* gaps;
+    const int64_t* gs_off;  // [n_units]
+    int64_t* unit_stats;    // [n_units][4]
+    int32_t* err;           // first error raised by a kernel (tw_status)
+};
+
+// ---------------------------------------------------------------------------------------------
+// fdlibm-style elementary functions, strict IEEE double
+__device__ __forceinline__ int32_t hi_word(double x) { return (int32_t)(__double_as_longlong(x) >> 32); }
+__device__ __forceinline__ uint32_t lo_word(double x) { return (uint32_t)__double_as_longlong(x); }
+__device__ __forceinline__ double with_hi(double x, int32_t hi) {
+    return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)lo_word(x)));
+}
+__device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+__device__ __forceinline__ double dinf() { return __longlong_as_double(0x7ff0000000000000LL); }
+
+__device__ inline double tw_log(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 two54 = 1.80143985094819840000e+16, Lg1 = 6.666666666666735130e-01,
+                 Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01,
+                 Lg6 = 1.531383769920937332e-01, Lg7 = 1.479819860511658591e-01;
+    int32_t k = 0, hx = hi_word(x);
+    if (hx < 0x00100000) {
+        if (((hx & 0x7fffffff) | lo_word(x)) == 0) return -dinf();
+        if (hx < 0) return dnan();
+        k -= 54;
+        x *= two54;
+        hx = hi_word(x);
+    }
+    if (hx >= 0x7ff00000) return x + x;
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    int32_t i = (hx + 0x95f64) & 0x100000;
+    x = with_hi(x, hx | (i ^ 0x3ff00000));
+    k += (i >> 20);
+    double f = x - 1.0, dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) {
+        if (f == 0.0) return k == 0 ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+        double R = f * f * (0.5 - 0.33333333333333333 * f);
+        return k == 0 ? f - R : dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    double s = f / (2.0 + f), z = s * s, w = z * z;
+    i = hx - 0x6147a;
+    int32_t j = 0x6b851 - hx;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double R = t2 + t1;
+    if ((i | j) > 0) {
+        double hfsq = 0.5 * f * f;
+        return k == 0 ? f - (hfsq - s * (hfsq + R)) : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    return k == 0 ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+__device__ inline double tw_exp(double x) {
+    const double o_threshold = 7.09782712893383973096e+02, u_threshold = -7.45133219101941108420e+02,
+                 ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                 P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08,
+                 twom1000 = 9.33263618503218878990e-302;
+    double hi = 0.0, lo = 0.0;
+    int32_t k = 0, hx = hi_word(x);
+    const int32_t xsb = (hx >> 31) & 1;
+    hx &= 0x7fffffff;
+    if (hx >= 0x40862E42) {
+        if (hx >= 0x7ff00000) {
+            if (((hx & 0xfffff) | lo_word(x)) != 0) return x + x;
+            return xsb == 0 ? x : 0.0;
+        }
+        if (x > o_threshold) return dinf();
+        if (x < u_threshold) return 0.0;
+    }
+    if (hx > 0x3fd62e42) {
+        if (hx < 0x3FF0A2B2) {
+            if (xsb == 0) { hi = x - ln2HI; lo = ln2LO; k = 1; }
+            else { hi = x + ln2HI; lo = -ln2LO; k = -1; }
+        } else {
+            k = (int32_t)(invln2 * x + (xsb == 0 ? 0.5 : -0.5));
+            const double t = (double)k;
+            hi = x - t * ln2HI;
+            lo = t * ln2LO;
+        }
+        x = hi - lo;
+    } else if (hx < 0x3e300000) {
+        return 1.0 + x;
+    }
+    const double t = x * x;
+    const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    const double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    if (k >= -1021) return with_hi(y, hi_word(y) + (k << 20));
+    return with_hi(y, hi_word(y) + ((k + 1000) << 20)) * twom1000;
+}
+
+__device__ inline double tw_log1p(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 two54 = 1.80143985094819840000e+16, Lp1 = 6.666666666666735130e-01,
+                 Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+                 Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01,
+                 Lp6 = 1.531383769920937332e-01, Lp7 = 1.479819860511658591e-01;
+    double f = 0.0, c = 0.0, u;
+    int32_t k = 1, hx = hi_word(x), hu = 0;
+    const int32_t ax = hx & 0x7fffffff;
+    if (hx < 0x3FDA827A) {
+        if (ax >= 0x3ff00000) return x == -1.0 ? -dinf() : dnan();
+        if (ax < 0x3e200000) {
+            if (two54 + x > 0.0 && ax < 0x3c900000) return x;
+            return x - x * x * 0.5;
+        }
+        if (hx > 0 || hx <= ((int32_t)0xbfd2bec3)) { k = 0; f = x; hu = 1; }
+    }
+    if (hx >= 0x7ff00000) return x + x;
+    if (k != 0) {
+        if (hx < 0x43400000) {
+            u = 1.0 + x;
+            hu = hi_word(u);
+            k = (hu >> 20) - 1023;
+            c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
+            c /= u;
+        } else {
+            u = x;
+            hu = hi_word(u);
+            k = (hu >> 20) - 1023;
+            c = 0;
+        }
+        hu &= 0x000fffff;
+        if (hu < 0x6a09e) u = with_hi(u, hu | 0x3ff00000);
+        else { k += 1; u = with_hi(u, hu | 0x3fe00000); hu = (0x00100000 - hu) >> 2; }
+        f = u - 1.0;
+    }
+    const double hfsq = 0.5 * f * f;
+    if (hu == 0) {
+        if (f == 0.0) {
+            if (k == 0) return 0.0;
+            c += k * ln2_lo;
+            return k * ln2_hi + c;
+        }
+        const double R = hfsq * (1.0 - 0.66666666666666666 * f);
+        return k == 0 ? f - R : k * ln2_hi - ((R - (k * ln2_lo + c)) - f);
+    }
+    const double s = f / (2.0 + f), z = s * s;
+    const double R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+    return k == 0 ? f - (hfsq - s * (hfsq + R)) : k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
+}
+
+// numpy's add.reduce over a short contiguous double array: 0 + pairwise_sum (n <= 128 branch)
+__device__ inline double np_sum(const double* a, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r[8];
+    int i;
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return 0.0 + res;
+}
+
+constexpr double kLogSqrt2Pi = 0x1.d67f1c864beb4p-1;  // np.log(np.sqrt(2*np.pi))
+constexpr double kLog2Pi = 0x1.d67f1c864beb4p+0;      // np.log(2*np.pi)
+
+__host__ __device__ inline int slot_root(int E, int e) { return e; }
+__host__ __device__ inline int slot_prim(int E, int p, int e) { return E + p * E + e; }
+__host__ __device__ inline int slot_close(int E, int e) { return E + E * E + e; }
+
+// index helpers for the per-unit result arrays
+__device__ __forceinline__ int64_t ie_index(const UnitDev& U, int e, int i) { return U.ie_off + (int64_t)e * U.n_in + i; }
+__device__ __forceinline__ int64_t tk_index(const UnitDev& U, int k, int e, int i) {
+    return (int64_t)kTopK * U.ie_off + ((int64_t)k * U.E + e) * U.n_in + i;
+}
+__device__ __forceinline__ int64_t tks_index(const UnitDev& U, int k, int i) {
+    return (int64_t)kTopK * U.in_off + (int64_t)k * U.n_in + i;
+}
+
+// XCD-aware tile order: consecutive workgroups are dispatched round-robin over the 8 XCDs, so give
+// every XCD one contiguous range of tiles (neighbouring tiles read neighbouring out-span ranges and
+// then share that XCD's L2).  Bijective for any tile count.
+__device__ __forceinline__ int xcd_tile(int b, int n) {
+    const int q = n / 8, r = n % 8, x = b % 8, j = b / 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+}  // namespace tw

@@ -1,0 +1,454 @@
+// tw_engine.hip -- host side of libtwgpu.so: the C-ABI of include/traceweaver_amd.h on top of the
+// kernels in tw_kernels.h.  One engine = one HIP device + one stream; inputs stay resident in HBM
+// between the two passes (spans are read from host memory exactly once, in tw_load_batch).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "traceweaver_amd.h"
+#include "tw_kernels.h"
+
+using namespace tw;
+
+namespace {
+
+enum { ST_EMPTY = 0, ST_LOADED = 1, ST_PASS1 = 2, ST_MIX = 3, ST_PASS2 = 4 };
+enum { EV_BEGIN = 0, EV_PARAMS, EV_ENUM0, EV_ENUM1, EV_WIN, EV_SEL, EV_REPAIR, EV_END, EV_COUNT };
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+struct tw_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int state = ST_EMPTY;
+    int tile = kTile;   // incoming spans (threads) per workgroup of the per-span kernels
+    int coop = 256;     // threads of the per-unit cooperative kernels
+    std::vector<UnitDev> units;
+    std::vector<TileDev> tiles;
+    std::vector<int64_t> gs_off_h;
+    std::vector<void*> allocs;
+    Dev P{};
+    int64_t n_ie = 0, n_gp = 0, n_slots = 0, n_gaps = 0;
+    // scratch for scans / sort
+    PairVI* agg_pair = nullptr;
+    int32_t* agg_i32 = nullptr;
+    uint32_t *seg_in = nullptr, *seg_out = nullptr;
+    int n_seg_out = 0;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    double* mix_p_dev = nullptr;
+    int32_t* mix_n_dev = nullptr;
+    double* mix_c_dev = nullptr;
+    hipEvent_t ev[EV_COUNT] = {};
+    double ms[6] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(tw_engine* e, int code, const std::string& msg) {
+    e->err = msg;
+    return code;
+}
+
+#define HIPCHK(call)                                                                               \
+    do {                                                                                           \
+        hipError_t _s = (call);                                                                    \
+        if (_s != hipSuccess)                                                                      \
+            return fail(e, TW_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(_s));      \
+    } while (0)
+
+template <class T>
+int dev_alloc(tw_engine* e, T** p, int64_t count) {
+    void* q = nullptr;
+    const size_t bytes = (size_t)std::max<int64_t>(count, 1) * sizeof(T);
+    HIPCHK(hipMalloc(&q, bytes));
+    e->allocs.push_back(q);
+    *p = (T*)q;
+    return TW_OK;
+}
+
+void free_all(tw_engine* e) {
+    for (void* q : e->allocs) (void)hipFree(q);
+    e->allocs.clear();
+    e->state = ST_EMPTY;
+}
+
+const char* kernel_error_text(int code) {
+    switch (code) {
+        case TW_ERR_WINDOW_WIDTH: return "an incoming span has more candidate spans at one endpoint than the candidate bitmap holds";
+        case TW_ERR_WINDOW_SIZE: return "a window holds more than TW_MAX_WINDOW incoming spans";
+        case TW_ERR_NAN_PARAMS: return "a parameter block holds a single sample (std = NaN); the reference aborts here (n_in % 100 == 1)";
+        default: return "kernel reported an error";
+    }
+}
+
+template <class Tr>
+int run_scan(tw_engine* e, typename Tr::T* agg) {
+    const Dev& P = e->P;
+    hipLaunchKernelGGL((k_scan_local<Tr>), dim3(P.n_tiles), dim3(e->tile), 0, e->stream, P, agg);
+    hipLaunchKernelGGL((k_scan_spine<Tr>), dim3(P.n_units), dim3(e->coop), 0, e->stream, P, agg);
+    hipLaunchKernelGGL((k_scan_fix<Tr>), dim3(P.n_tiles), dim3(e->tile), 0, e->stream, P, agg);
+    HIPCHK(hipGetLastError());
+    return TW_OK;
+}
+
+int sort_ends(tw_engine* e) {
+    const Dev& P = e->P;
+    for (int which = 0; which < 2; which++) {
+        const int64_t* in = which == 0 ? P.in_end : P.out_end;
+        int64_t* out = which == 0 ? P.in_end_sorted : P.out_end_sorted;
+        const unsigned size = (unsigned)(which == 0 ? P.n_in_total : P.n_out_total);
+        const unsigned nseg = (unsigned)(which == 0 ? P.n_units : e->n_seg_out);
+        const uint32_t* off = which == 0 ? e->seg_in : e->seg_out;
+        size_t bytes = 0;
+        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, bytes, in, out, size, nseg, off, off + 1, 0, 64, e->stream));
+        if (bytes > e->sort_tmp_bytes) {
+            void* q = nullptr;
+            HIPCHK(hipMalloc(&q, bytes));
+            e->allocs.push_back(q);
+            e->sort_tmp = q;
+            e->sort_tmp_bytes = bytes;
+        }
+        bytes = e->sort_tmp_bytes;
+        HIPCHK(rocprim::segmented_radix_sort_keys(e->sort_tmp, bytes, in, out, size, nseg, off, off + 1, 0, 64, e->stream));
+    }
+    return TW_OK;
+}
+
+int run_pass(tw_engine* e, int pass) {
+    const Dev& P = e->P;
+    const dim3 tiles(P.n_tiles), tb(e->tile);
+    HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
+    HIPCHK(hipMemsetAsync(P.err, 0, sizeof(int32_t), e->stream));
+    HIPCHK(hipMemsetAsync(P.unit_stats, 0, sizeof(int64_t) * 4 * P.n_units, e->stream));
+    HIPCHK(hipMemsetAsync(P.unit_ndirty, 0, sizeof(int32_t) * P.n_units, e->stream));
+    HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
+    if (pass == 1) {
+        int rc = sort_ends(e);
+        if (rc != TW_OK) return rc;
+        const int64_t total = e->n_gp;
+        hipLaunchKernelGGL(k_block_params, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, P, total);
+    }
+    HIPCHK(hipEventRecord(e->ev[EV_PARAMS], e->stream));
+    HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
+    hipLaunchKernelGGL(k_enumerate, tiles, tb, 0, e->stream, P, pass);
+    HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
+    if (pass == 1) {
+        int rc = run_scan<ScanMaxEnd>(e, e->agg_pair);
+        if (rc != TW_OK) return rc;
+        hipLaunchKernelGGL(k_perfect_cut, tiles, tb, 0, e->stream, P);
+        rc = run_scan<ScanSegStart>(e, e->agg_i32);
+        if (rc != TW_OK) return rc;
+        hipLaunchKernelGGL(k_window_flags, tiles, tb, 0, e->stream, P);
+        rc = run_scan<ScanWinId>(e, e->agg_i32);
+        if (rc != TW_OK) return rc;
+        hipLaunchKernelGGL(k_window_index, tiles, tb, 0, e->stream, P);
+    } else {
+        HIPCHK(hipMemsetAsync(P.w_dirty, 0, (size_t)P.n_in_total, e->stream));
+    }
+    HIPCHK(hipEventRecord(e->ev[EV_WIN], e->stream));
+    hipLaunchKernelGGL(k_select, tiles, tb, 0, e->stream, P);
+    HIPCHK(hipEventRecord(e->ev[EV_SEL], e->stream));
+    hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P);
+    hipLaunchKernelGGL(k_detect, tiles, tb, 0, e->stream, P);
+    hipLaunchKernelGGL(k_repair, dim3(P.n_units), dim3(e->coop), 0, e->stream, P, pass);
+    HIPCHK(hipEventRecord(e->ev[EV_REPAIR], e->stream));
+    hipLaunchKernelGGL(k_finalize, tiles, tb, 0, e->stream, P);
+    if (pass == 1) hipLaunchKernelGGL(k_gaps, tiles, tb, 0, e->stream, P);
+    HIPCHK(hipEventRecord(e->ev[EV_END], e->stream));
+    HIPCHK(hipGetLastError());
+    int32_t kerr = 0;
+    HIPCHK(hipMemcpyAsync(&kerr, P.err, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    float f = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, e->ev[EV_BEGIN], e->ev[EV_END])); e->ms[0] = f;
+    HIPCHK(hipEventElapsedTime(&f, e->ev[EV_ENUM0], e->ev[EV_ENUM1])); e->ms[1] = f;
+    HIPCHK(hipEventElapsedTime(&f, e->ev[EV_WIN], e->ev[EV_SEL])); e->ms[2] = f;
+    HIPCHK(hipEventElapsedTime(&f, e->ev[EV_ENUM1], e->ev[EV_WIN])); e->ms[3] = f;
+    HIPCHK(hipEventElapsedTime(&f, e->ev[EV_SEL], e->ev[EV_REPAIR])); e->ms[4] = f;
+    HIPCHK(hipEventElapsedTime(&f, e->ev[EV_BEGIN], e->ev[EV_PARAMS])); e->ms[5] = f;
+    if (kerr != 0) return fail(e, kerr, kernel_error_text(kerr));
+    return TW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tw_create(int device_id, tw_engine** out) {
+    if (out == nullptr) return TW_ERR_ARG;
+    *out = nullptr;
+    tw_engine* e = new tw_engine();
+    e->device = device_id;
+    e->tile = std::min(std::max(env_int("TW_TILE", kTile), 1), kTile);
+    e->coop = std::min(std::max(env_int("TW_COOP_THREADS", 256), 1), kTile);
+    hipError_t s = hipSetDevice(device_id);
+    if (s == hipSuccess) s = hipStreamCreate(&e->stream);
+    for (int i = 0; i < EV_COUNT && s == hipSuccess; i++) s = hipEventCreate(&e->ev[i]);
+    if (s != hipSuccess) {
+        fprintf(stderr, "tw_create: %s\n", hipGetErrorString(s));
+        delete e;
+        return TW_ERR_DEVICE;
+    }
+    *out = e;
+    return TW_OK;
+}
+
+void tw_destroy(tw_engine* e) {
+    if (e == nullptr) return;
+    (void)hipSetDevice(e->device);
+    free_all(e);
+    for (int i = 0; i < EV_COUNT; i++)
+        if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char* tw_last_error(const tw_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
+    if (e == nullptr || b == nullptr) return TW_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    if (b->n_units <= 0) return fail(e, TW_ERR_ARG, "n_units must be positive");
+    if (b->topk != TW_TOPK) return fail(e, TW_ERR_UNSUPPORTED, "topk must be 5 (traceweaver_v3.py:1109)");
+    if (b->batch_size <= 0 || b->batch_size_mis <= 0) return fail(e, TW_ERR_ARG, "batch sizes must be positive");
+    free_all(e);
+    e->units.assign((size_t)b->n_units, UnitDev{});
+    e->tiles.clear();
+    e->gs_off_h.assign((size_t)b->n_units, 0);
+    int64_t ie = 0, gp = 0, slots = 0, gaps = 0, epi = 0, dagi = 0;
+    std::vector<uint32_t> seg_in((size_t)b->n_units + 1), seg_out;
+    for (int u = 0; u < b->n_units; u++) {
+        UnitDev& U = e->units[(size_t)u];
+        const int E = b->unit_E[u];
+        const int64_t n = b->unit_in_off[u + 1] - b->unit_in_off[u];
+        if (E < 1 || E > TW_MAX_EP) return fail(e, TW_ERR_UNSUPPORTED, "unit has E outside [1, TW_MAX_EP]");
+        if (n < 2) return fail(e, TW_ERR_ARG, "a unit needs at least 2 incoming spans (the reference raises on max([]) for 1, traceweaver_v3.py:1119)");
+        if (n > 0x7fffffff / 16) return fail(e, TW_ERR_ARG, "unit too large");
+        U.in_off = b->unit_in_off[u];
+        U.n_in = (int32_t)n;
+        U.E = E;
+        U.ie_off = ie;
+        U.nblk = (int32_t)((n + b->batch_size - 1) / b->batch_size);
+        U.nslot = E * E + 2 * E;
+        U.gp_off = gp;
+        U.slot_off = (int32_t)slots;
+        U.tile_off = (int32_t)e->tiles.size();
+        U.ntile = (int32_t)((n + e->tile - 1) / e->tile);
+        for (int t = 0; t < U.ntile; t++) e->tiles.push_back(TileDev{u, t * e->tile});
+        seg_in[(size_t)u] = (uint32_t)U.in_off;
+        const uint8_t* dag = b->dag + dagi;
+        for (int k = 0; k <= E; k++) U.ep_off[k] = b->ep_off[epi + k];
+        for (int k = 0; k < E; k++) {
+            if (U.ep_off[k + 1] - U.ep_off[k] != n)
+                return fail(e, TW_ERR_UNSUPPORTED, "skip mode: an endpoint's span count differs from the number of incoming spans (traceweaver_v3.py:972,1155-1156)");
+            seg_out.push_back((uint32_t)U.ep_off[k]);
+        }
+        for (int q = 0; q < E; q++) {
+            uint8_t pm = 0, sm = 0;
+            int np = 0;
+            for (int p = 0; p < E; p++) {
+                if (dag[p * E + q]) {
+                    if (p >= q) return fail(e, TW_ERR_ARG, "endpoints are not in topological order of the DAG");
+                    pm |= (uint8_t)(1u << p);
+                    U.pred_list[q][np++] = (uint8_t)p;
+                }
+                if (dag[q * E + p]) sm |= (uint8_t)(1u << p);
+            }
+            U.pred_mask[q] = pm;
+            U.succ_mask[q] = sm;
+            U.npred[q] = (uint8_t)np;
+            // networkx in_edges(): predecessors in partition-key (insertion) order, executor.py:223-236
+            std::stable_sort(U.pred_list[q], U.pred_list[q] + np, [&](uint8_t x, uint8_t y) {
+                return b->key_rank[epi + x] < b->key_rank[epi + y];
+            });
+            for (int j = 0; j < np; j++) {  // primary <=> no 2-hop alternative (traceweaver_v1.py:245-254)
+                const int p = U.pred_list[q][j];
+                bool prim = true;
+                for (int m = 0; m < E; m++)
+                    if (m != p && m != q && dag[p * E + m] && dag[m * E + q]) prim = false;
+                U.pred_prim[q][j] = prim ? 1 : 0;
+            }
+        }
+        e->gs_off_h[(size_t)u] = gaps;
+        ie += n * E;
+        gp += (int64_t)U.nblk * U.nslot;
+        slots += U.nslot;
+        gaps += (int64_t)U.nslot * n;
+        epi += E;
+        dagi += E * E;
+    }
+    const int64_t n_in_total = b->unit_in_off[b->n_units], n_out_total = b->ep_off[epi];
+    if (n_in_total >= (1ll << 31) || n_out_total >= (1ll << 31)) return fail(e, TW_ERR_ARG, "batch exceeds 2^31 spans");
+    seg_in[(size_t)b->n_units] = (uint32_t)n_in_total;
+    seg_out.push_back((uint32_t)n_out_total);
+    e->n_seg_out = (int)seg_out.size() - 1;
+    e->n_ie = ie; e->n_gp = gp; e->n_slots = slots; e->n_gaps = gaps;
+
+    Dev& P = e->P;
+    P = Dev{};
+    P.n_units = b->n_units;
+    P.n_tiles = (int32_t)e->tiles.size();
+    P.n_in_total = n_in_total;
+    P.n_out_total = n_out_total;
+    P.batch_size = b->batch_size;
+    P.batch_mis = b->batch_size_mis;
+    int rc;
+#define ALLOC(ptr, count) do { rc = dev_alloc(e, &(ptr), (count)); if (rc != TW_OK) return rc; } while (0)
+    UnitDev* d_units; TileDev* d_tiles; int64_t *d_is, *d_ie, *d_os, *d_oe, *d_gs;
+    ALLOC(d_units, P.n_units); ALLOC(d_tiles, P.n_tiles);
+    ALLOC(d_is, n_in_total); ALLOC(d_ie, n_in_total); ALLOC(d_os, n_out_total); ALLOC(d_oe, n_out_total);
+    ALLOC(d_gs, P.n_units);
+    ALLOC(P.in_end_sorted, n_in_total); ALLOC(P.out_end_sorted, n_out_total);
+    ALLOC(P.gparam, gp * 4);
+    ALLOC(e->mix_n_dev, slots); ALLOC(e->mix_p_dev, slots * kMaxComp * 3); ALLOC(e->mix_c_dev, slots * kMaxComp * 4);
+    ALLOC(P.pm_val, n_in_total); ALLOC(P.pm_idx, n_in_total); ALLOC(P.pc, n_in_total + 1); ALLOC(P.seg, n_in_total);
+    ALLOC(P.win_end, n_in_total); ALLOC(P.wid, n_in_total); ALLOC(P.w_last, n_in_total);
+    ALLOC(P.unit_nwin, P.n_units); ALLOC(P.w_dirty, n_in_total); ALLOC(P.unit_ndirty, P.n_units);
+    ALLOC(P.tk_n, n_in_total); ALLOC(P.leaves, n_in_total); ALLOC(P.chosen, n_in_total); ALLOC(P.rep, n_in_total);
+    ALLOC(P.tkr_n, n_in_total);
+    ALLOC(P.tk_idx, ie * kTopK); ALLOC(P.tkr_idx, ie * kTopK);
+    ALLOC(P.tk_score, n_in_total * kTopK); ALLOC(P.tkr_score, n_in_total * kTopK);
+    ALLOC(P.c_lo, ie); ALLOC(P.c_bits, ie * kCandWords); ALLOC(P.parent, ie);
+    ALLOC(P.owner, n_out_total);
+    ALLOC(P.gaps, gaps);
+    ALLOC(P.unit_stats, (int64_t)P.n_units * 4); ALLOC(P.err, 1);
+    ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
+    ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
+#undef ALLOC
+    P.units = d_units; P.tiles = d_tiles;
+    P.in_start = d_is; P.in_end = d_ie; P.out_start = d_os; P.out_end = d_oe;
+    P.gs_off = d_gs;
+    P.mix_n = e->mix_n_dev; P.mix_c = e->mix_c_dev;
+    e->sort_tmp = nullptr; e->sort_tmp_bytes = 0;
+    const hipMemcpyKind kind = spans_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIPCHK(hipMemcpyAsync(d_is, b->in_start, sizeof(int64_t) * n_in_total, kind, e->stream));
+    HIPCHK(hipMemcpyAsync(d_ie, b->in_end, sizeof(int64_t) * n_in_total, kind, e->stream));
+    HIPCHK(hipMemcpyAsync(d_os, b->out_start, sizeof(int64_t) * n_out_total, kind, e->stream));
+    HIPCHK(hipMemcpyAsync(d_oe, b->out_end, sizeof(int64_t) * n_out_total, kind, e->stream));
+    HIPCHK(hipMemcpyAsync(d_units, e->units.data(), sizeof(UnitDev) * e->units.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d_tiles, e->tiles.data(), sizeof(TileDev) * e->tiles.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d_gs, e->gs_off_h.data(), sizeof(int64_t) * e->gs_off_h.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->seg_in, seg_in.data(), sizeof(uint32_t) * seg_in.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->seg_out, seg_out.data(), sizeof(uint32_t) * seg_out.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(P.pc, 0, (size_t)n_in_total + 1, e->stream));
+    HIPCHK(hipMemsetAsync(e->mix_n_dev, 0, sizeof(int32_t) * std::max<int64_t>(slots, 1), e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->state = ST_LOADED;
+    return TW_OK;
+}
+
+int tw_run_pass1(tw_engine* e) {
+    if (e == nullptr) return TW_ERR_ARG;
+    if (e->state < ST_LOADED) return fail(e, TW_ERR_STATE, "tw_run_pass1 before tw_load_batch");
+    HIPCHK(hipSetDevice(e->device));
+    const int rc = run_pass(e, 1);
+    if (rc == TW_OK) e->state = ST_PASS1;
+    return rc;
+}
+
+int tw_get_gaps(tw_engine* e, double* gaps) {
+    if (e == nullptr || gaps == nullptr) return TW_ERR_ARG;
+    if (e->state != ST_PASS1) return fail(e, TW_ERR_STATE, "tw_get_gaps is valid right after tw_run_pass1");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(gaps, e->P.gaps, sizeof(double) * e->n_gaps, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TW_OK;
+}
+
+int tw_set_mixtures(tw_engine* e, const int32_t* mix_n, const double* mix_p) {
+    if (e == nullptr || mix_n == nullptr || mix_p == nullptr) return TW_ERR_ARG;
+    if (e->state < ST_PASS1) return fail(e, TW_ERR_STATE, "tw_set_mixtures before tw_run_pass1");
+    HIPCHK(hipSetDevice(e->device));
+    for (int64_t q = 0; q < e->n_slots; q++)
+        if (mix_n[q] < 0 || mix_n[q] > TW_MAX_COMP) return fail(e, TW_ERR_ARG, "mixture component count outside [0, TW_MAX_COMP]");
+    HIPCHK(hipMemcpyAsync(e->mix_n_dev, mix_n, sizeof(int32_t) * e->n_slots, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->mix_p_dev, mix_p, sizeof(double) * e->n_slots * kMaxComp * 3, hipMemcpyHostToDevice, e->stream));
+    const int64_t total = e->n_slots * kMaxComp;
+    hipLaunchKernelGGL(k_mix_consts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, (const double*)e->mix_p_dev, e->mix_c_dev, total);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->state = ST_MIX;
+    return TW_OK;
+}
+
+int tw_run_pass2(tw_engine* e) {
+    if (e == nullptr) return TW_ERR_ARG;
+    if (e->state != ST_MIX && e->state != ST_PASS2) return fail(e, TW_ERR_STATE, "tw_run_pass2 needs tw_run_pass1 and tw_set_mixtures first");
+    HIPCHK(hipSetDevice(e->device));
+    const int rc = run_pass(e, 2);
+    if (rc == TW_OK) e->state = ST_PASS2;
+    return rc;
+}
+
+int tw_get_results(tw_engine* e, int pass, const tw_results* r) {
+    if (e == nullptr || r == nullptr) return TW_ERR_ARG;
+    const bool ok = (pass == 1 && (e->state == ST_PASS1 || e->state == ST_MIX)) || (pass == 2 && e->state == ST_PASS2);
+    if (!ok) return fail(e, TW_ERR_STATE, "results of that pass are not resident (fetch pass-1 results before running pass 2)");
+    HIPCHK(hipSetDevice(e->device));
+    const Dev& P = e->P;
+    const int64_t n = P.n_in_total;
+#define D2H(dst, src, bytes) if ((dst) != nullptr) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, e->stream))
+    D2H(r->parent, P.parent, sizeof(int32_t) * e->n_ie);
+    D2H(r->topk_idx, P.tk_idx, sizeof(int32_t) * e->n_ie * kTopK);
+    D2H(r->topk_score, P.tk_score, sizeof(double) * n * kTopK);
+    D2H(r->topk_n, P.tk_n, sizeof(int32_t) * n);
+    D2H(r->chosen, P.chosen, sizeof(int32_t) * n);
+    D2H(r->leaves, P.leaves, sizeof(int64_t) * n);
+    D2H(r->window_end, P.win_end, sizeof(uint8_t) * n);
+    D2H(r->unit_stats, P.unit_stats, sizeof(int64_t) * 4 * P.n_units);
+#undef D2H
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TW_OK;
+}
+
+int tw_get_gauss_params(tw_engine* e, double* gauss) {
+    if (e == nullptr || gauss == nullptr) return TW_ERR_ARG;
+    if (e->state < ST_PASS1) return fail(e, TW_ERR_STATE, "tw_get_gauss_params before tw_run_pass1");
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<double> tmp((size_t)e->n_gp * 4);
+    HIPCHK(hipMemcpyAsync(tmp.data(), e->P.gparam, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int64_t q = 0; q < e->n_gp; q++)
+        for (int k = 0; k < 3; k++) gauss[q * 3 + k] = tmp[(size_t)q * 4 + k];
+    return TW_OK;
+}
+
+int tw_get_timing(tw_engine* e, double* ms, int32_t n) {
+    if (e == nullptr || ms == nullptr) return TW_ERR_ARG;
+    for (int i = 0; i < n && i < 6; i++) ms[i] = e->ms[i];
+    return TW_OK;
+}
+
+int tw_assign_service(tw_engine* e, int32_t n_in, const int64_t* in_start, const int64_t* in_end, int32_t E,
+                      const int64_t* out_off, const int64_t* out_start, const int64_t* out_end, const uint8_t* dag,
+                      const int32_t* key_rank, const int32_t* mix_n, const double* mix_p, const tw_results* r) {
+    if (e == nullptr) return TW_ERR_ARG;
+    const int64_t in_off[2] = {0, n_in};
+    tw_batch b;
+    b.n_units = 1; b.unit_in_off = in_off; b.unit_E = &E; b.ep_off = out_off; b.dag = dag; b.key_rank = key_rank;
+    b.in_start = in_start; b.in_end = in_end; b.out_start = out_start; b.out_end = out_end;
+    b.batch_size = 100; b.batch_size_mis = 30; b.topk = TW_TOPK;
+    int rc = tw_load_batch(e, &b, 0);
+    if (rc == TW_OK) rc = tw_run_pass1(e);
+    if (rc == TW_OK && mix_n != nullptr) {
+        rc = tw_set_mixtures(e, mix_n, mix_p);
+        if (rc == TW_OK) rc = tw_run_pass2(e);
+    }
+    if (rc == TW_OK && r != nullptr) rc = tw_get_results(e, mix_n != nullptr ? 2 : 1, r);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+"""numpy-level wrapper around the C-ABI (include/traceweaver_amd.h).
+
+A *unit* is one call of the reference's TraceWeaverV3.FindAssignments (traceweaver_v3.py:1087): one
+service, its incoming spans and its outgoing spans per endpoint.  Units of a batch are independent and
+are solved together on one GPU.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (_ffi.STATUS.get(code, "TW_ERR"), code, message))
+        self.code = code
+
+
+class UnitArrays(object):
+    """Structure-of-arrays form of one unit: endpoints in topological order of the call-order DAG
+    (traceweaver_v1.py:37-39), every span list sorted by (start, end) (executor.py:1112)."""
+
+    def __init__(self, in_start, in_end, out_off, out_start, out_end, dag, key_rank=None):
+        self.in_start = np.ascontiguousarray(in_start, dtype=np.int64)
+        self.in_end = np.ascontiguousarray(in_end, dtype=np.int64)
+        self.out_off = np.ascontiguousarray(out_off, dtype=np.int64)
+        self.out_start = np.ascontiguousarray(out_start, dtype=np.int64)
+        self.out_end = np.ascontiguousarray(out_end, dtype=np.int64)
+        self.E = len(self.out_off) - 1
+        self.n_in = len(self.in_start)
+        self.dag = np.ascontiguousarray(dag, dtype=np.uint8).reshape(self.E, self.E)
+        self.key_rank = np.ascontiguousarray(np.arange(self.E) if key_rank is None else key_rank, dtype=np.int32)
+        if len(self.in_end) != self.n_in or len(self.out_start) != self.out_off[-1] or len(self.out_end) != len(self.out_start):
+            raise ValueError("inconsistent unit arrays")
+
+    @property
+    def nslot(self):
+        return self.E * self.E + 2 * self.E
+
+    @property
+    def n_spans(self):
+        return self.n_in + len(self.out_start)
+
+
+def _vp(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else ctypes.c_void_p(0)
+
+
+class Engine(object):
+    def __init__(self, device=0, lib_path=None):
+        self._lib = _ffi.load(lib_path)
+        self._h = ctypes.c_void_p(0)
+        rc = self._lib.tw_create(int(device), ctypes.byref(self._h))
+        if rc != 0:
+            raise EngineError(rc, "tw_create failed on device %d" % device)
+        self.units = []
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            self._lib.tw_destroy(self._h)
+            self._h = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self._lib.tw_last_error(self._h).decode())
+
+    # ------------------------------------------------------------------------------------------
+    def load(self, units, batch_size=100, batch_size_mis=30):
+        """Copy a list of UnitArrays into HBM."""
+        self.units = list(units)
+        in_off = np.zeros(len(units) + 1, dtype=np.int64)
+        np.cumsum([u.n_in for u in units], out=in_off[1:])
+        unit_E = np.array([u.E for u in units], dtype=np.int32)
+        ep_off = [0]
+        base = 0
+        for u in units:
+            ep_off.extend((base + u.out_off[1:]).tolist())
+            base += int(u.out_off[-1])
+        arrays = {
+            "unit_in_off": in_off, "unit_E": unit_E, "ep_off": np.array(ep_off, dtype=np.int64),
+            "dag": np.concatenate([u.dag.ravel() for u in units]),
+            "key_rank": np.concatenate([u.key_rank for u in units]),
+            "in_start": np.concatenate([u.in_start for u in units]),
+            "in_end": np.concatenate([u.in_end for u in units]),
+            "out_start": np.concatenate([u.out_start for u in units]),
+            "out_end": np.concatenate([u.out_end for u in units]),
+        }
+        self._keep = arrays
+        b = _ffi.Batch(len(units), *[_vp(arrays[k]) for k in (
+            "unit_in_off", "unit_E", "ep_off", "dag", "key_rank", "in_start", "in_end", "out_start", "out_end")],
+            batch_size, batch_size_mis, _ffi.TW_TOPK)
+        self._check(self._lib.tw_load_batch(self._h, ctypes.byref(b), 0))
+        self._in_off = in_off
+        self._ie_off = np.concatenate([[0], np.cumsum([u.n_in * u.E for u in units])]).astype(np.int64)
+        self._slot_off = np.concatenate([[0], np.cumsum([u.nslot for u in units])]).astype(np.int64)
+        self._gap_off = np.concatenate([[0], np.cumsum([u.nslot * u.n_in for u in units])]).astype(np.int64)
+        self._nblk = [(u.n_in + batch_size - 1) // batch_size for u in units]
+        self._gp_off = np.concatenate([[0], np.cumsum([nb * u.nslot for nb, u in zip(self._nblk, units)])]).astype(np.int64)
+
+    def run_pass1(self):
+        self._check(self._lib.tw_run_pass1(self._h))
+
+    def run_pass2(self):
+        self._check(self._lib.tw_run_pass2(self._h))
+
+    def gaps(self):
+        """Per unit: [nslot, n_in] gap samples of the pass-1 assignment (NaN = dropped / unscored slot)."""
+        g = np.empty(int(self._gap_off[-1]), dtype=np.float64)
+        self._check(self._lib.tw_get_gaps(self._h, _vp(g)))
+        return [g[self._gap_off[k]:self._gap_off[k + 1]].reshape(u.nslot, u.n_in) for k, u in enumerate(self.units)]
+
+    def set_mixtures(self, mix_n, mix_p):
+        """mix_n / mix_p: per unit arrays [nslot] int32 and [nslot, 5, 3] (weight, mean, precision_cholesky)."""
+        n = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int32).ravel() for a in mix_n]), dtype=np.int32)
+        p = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1, _ffi.TW_MAX_COMP, 3) for a in mix_p]))
+        if len(n) != self._slot_off[-1] or len(p) != len(n):
+            raise ValueError("mixture tables do not match the loaded batch")
+        self._check(self._lib.tw_set_mixtures(self._h, _vp(n), _vp(p)))
+
+    def gauss_params(self):
+        """Per unit: [nblk, nslot, 3] = mean, std, log(std used) of pass 1 (NaN for unscored slots)."""
+        g = np.empty((int(self._gp_off[-1]), 3), dtype=np.float64)
+        self._check(self._lib.tw_get_gauss_params(self._h, _vp(g)))
+        return [g[self._gp_off[k]:self._gp_off[k + 1]].reshape(self._nblk[k], u.nslot, 3) for k, u in enumerate(self.units)]
+
+    def results(self, which):
+        """Per unit dict: parent [E,n], topk_idx [5,E,n], topk_score [5,n], topk_n, chosen, leaves, window_end, stats."""
+        n_in = int(self._in_off[-1])
+        n_ie = int(self._ie_off[-1])
+        K = _ffi.TW_TOPK
+        buf = {
+            "parent": np.empty(n_ie, np.int32), "topk_idx": np.empty(n_ie * K, np.int32),
+            "topk_score": np.empty(n_in * K, np.float64), "topk_n": np.empty(n_in, np.int32),
+            "chosen": np.empty(n_in, np.int32), "leaves": np.empty(n_in, np.int64),
+            "window_end": np.empty(n_in, np.uint8), "unit_stats": np.empty((len(self.units), 4), np.int64),
+        }
+        r = _ffi.Results(*[_vp(buf[k]) for k in ("parent", "topk_idx", "topk_score", "topk_n", "chosen", "leaves",
+                                                 "window_end", "unit_stats")])
+        self._check(self._lib.tw_get_results(self._h, int(which), ctypes.byref(r)))
+        out = []
+        for k, u in enumerate(self.units):
+            a, b = int(self._in_off[k]), int(self._in_off[k + 1])
+            ia, ib = int(self._ie_off[k]), int(self._ie_off[k + 1])
+            st = buf["unit_stats"][k]
+            out.append({
+                "parent": buf["parent"][ia:ib].reshape(u.E, u.n_in),
+                "topk_idx": buf["topk_idx"][K * ia:K * ib].reshape(K, u.E, u.n_in),
+                "topk_score": buf["topk_score"][K * a:K * b].reshape(K, u.n_in),
+                "topk_n": buf["topk_n"][a:b], "chosen": buf["chosen"][a:b], "leaves": buf["leaves"][a:b],
+                "window_end": buf["window_end"][a:b],
+                "not_best_count": int(st[0]), "cnt_unassigned": int(st[1]), "n_windows": int(st[2]),
+                "repaired_windows": int(st[3]),
+            })
+        return out
+
+    def timing(self):
+        """ms of the last pass: total, enumerate kernel, select kernel, windows, claim+detect+repair, params."""
+        ms = np.zeros(6, dtype=np.float64)
+        self._check(self._lib.tw_get_timing(self._h, _vp(ms), 6))
+        return dict(zip(("pass", "enumerate", "select", "windows", "repair", "params"), ms.tolist()))
