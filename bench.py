@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Throughput of the span->parent reconstruction hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one full two-pass reconstruction (TraceWeaverV3.FindAssignments, traceweaver_v3.py:1087-1229)
+of every service unit resident on the GPU: pass 1 (windows, Gaussian parameters, candidate enumeration,
+exact per-window selection, consumption repair) -> per-edge mixture refit -> pass 2.  Spans are already in
+HBM when the timed region starts (tw_load_batch is outside it).  Workload: BASELINE.json config 2 shape --
+the six accelerated services of media_microservices (E in {1,1,1,1,2,4}) -- scaled up with the seed-fixed
+synthetic generator in traceweaver_amd/synth.py (the shipped corpus has 1000 requests per service, which a
+GPU finishes in microseconds).  `value` = spans (incoming + outgoing handed to the engine)
+per second over all ranks.  N > 1: one process per GPU, units sharded, no data-path collective; the only
+collectives are the timing barrier / max-reduce (weak scaling: per-GPU work is fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+ALG_BYTES_PER_SPAN_TWO_PASS = 36  # 16 B read per pass + 4 B parent index written
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-in", type=int, default=100000, help="requests per service unit")
+    ap.add_argument("--replicas", type=int, default=4, help="copies of the 6-service media graph per GPU")
+    ap.add_argument("--concurrency", type=float, default=1.6, help="mean requests in flight per service")
+    ap.add_argument("--fit", default="device", choices=["device", "sklearn"], help="mixture refit between the passes")
+    ap.add_argument("--cpu-sample", type=int, default=4000, help="requests per service in the CPU-baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def fit_mixtures(eng, mode):
+    from traceweaver_amd import gmm
+
+    if mode == "device":
+        eng.fit_mixtures()
+        return
+    gaps = eng.gaps()
+    fitted = [gmm.fit_unit(g) for g in gaps]
+    eng.set_mixtures([f[0] for f in fitted], [f[1] for f in fitted])
+
+
+def one_step(eng, mode):
+    eng.run_pass1()
+    t1 = eng.timing()
+    fit_mixtures(eng, mode)
+    eng.run_pass2()
+    t2 = eng.timing()
+    res = eng.results(2, fields=("parent", "unit_stats"))
+    return t1, t2, res
+
+
+def cpu_baseline(args, seed):
+    """The CPU oracle (a C port of the reference algorithm, 1 thread) on a bounded sample of the same
+    workload: same services, fewer requests per service."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import tw_oracle as T
+    from traceweaver_amd import synth
+
+    units, _ = synth.make_workload(seed, args.cpu_sample, services=synth.MEDIA_SERVICES, concurrency=args.concurrency)
+    spans = sum(u.n_spans for u in units)
+    t0 = time.perf_counter()
+    for u in units:
+        svc = T.Service(u.in_start, u.in_end - u.in_start, u.out_off, u.out_start, u.out_end - u.out_start, u.dag, u.key_rank)
+        T.run_service(svc)
+    dt = time.perf_counter() - t0
+    return {"value": spans / dt, "unit": "spans/s", "cores": 1, "kind": "port",
+            "sample": "oracle/tw_oracle.c two-pass (sklearn refit) on the same 6 media-shape services at %d requests each "
+                      "(%d spans, %.1f s); the Python reference itself measured 235-342 spans/s on one core (BASELINE.md)"
+                      % (args.cpu_sample, spans, dt)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    from traceweaver_amd import synth
+    from traceweaver_amd.engine import Engine
+
+    units, truth = synth.make_workload(1000 + rank, args.n_in, services=synth.MEDIA_SERVICES, replicas=args.replicas,
+                                       concurrency=args.concurrency)
+    spans_rank = sum(u.n_spans for u in units)
+    eng = Engine(local_rank)
+    eng.load(units)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(eng, args.fit)
+    barrier()
+    t0 = time.perf_counter()
+    enum_ms, pass_ms = [], []
+    for _ in range(args.steps):
+        t1, t2, res = one_step(eng, args.fit)
+        enum_ms += [t1["enumerate"], t2["enumerate"]]
+        pass_ms += [t1["pass"], t2["pass"]]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        s = torch.tensor([spans_rank], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        spans_total = float(s.item())
+    else:
+        spans_total = float(spans_rank)
+    acc = float(np.mean([synth.accuracy(r["parent"], tp) for r, tp in zip(res, truth)]))
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = spans_total * args.steps / dt
+        # dominant kernel: k_enumerate, one launch per pass over every resident span
+        enum_avg_ms = float(np.mean(enum_ms))
+        alg_bytes = 20.0 * spans_rank  # per launch: 16 B read + 4 B written per span
+        achieved = alg_bytes / (enum_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "spans/sec reconstructed + assignment accuracy vs ground truth",
+            "value": value, "unit": "spans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64 timestamps, f64 scores", "data": "synthetic",
+            "config": {"workload": "media_microservices shape (6 services, E in {1,1,1,1,2,4}), %d requests/service x %d "
+                                   "replicas per GPU, concurrency %.1f, two-pass reconstruction, %s mixture refit"
+                                   % (args.n_in, args.replicas, args.concurrency, args.fit),
+                       "spans_per_gpu": spans_rank, "parallelism": "units sharded, %d rank(s)" % world},
+            "accuracy": acc,
+            "gpu_pass_ms": {"pass1": float(np.mean(pass_ms[0::2])), "pass2": float(np.mean(pass_ms[1::2]))},
+            "roofline": {"bound": "hbm", "kernel": "k_enumerate", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel_ms": enum_avg_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args, 1000)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,7 +116,9 @@ int tw_run_pass2(tw_engine *e);
  *   chosen      int32  [n_in] rank of the chosen tuple in the span's own candidate list, -1 none
  *   leaves      int64  [n_in] enumerated tuples of the top_k call (per_span_candidates increment)
  *   window_end  uint8  [n_in] 1 where a window closes (traceweaver_v3.py:1192)
- *   unit_stats  int64  [n_units][4]: not_best_count, cnt_unassigned, n_windows, repaired windows */
+ *   unit_stats  int64  [n_units][8]: not_best_count, cnt_unassigned, n_windows, windows re-solved
+ *                      because an earlier window consumed one of their candidates, windows whose
+ *                      exact selection search hit its node budget (incumbent returned), 3 reserved */
 typedef struct {
     int32_t *parent;
     int32_t *topk_idx;

@@ -36,6 +36,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -619,14 +620,98 @@ typedef struct {
     int cur[TWO_MAX_WIN], best[TWO_MAX_WIN];
     double best_w;
     int64_t nodes;
+    int exhausted;
 } mwis_comp;
 
 static int shares(int E, const int32_t *a, const int32_t *b) { for (int e = 0; e < E; e++) if (a[e] == b[e]) return 1; return 0; }
 
+/* Upper bound for the sub-problem "in-spans d..m-1 given the current partial selection": relax every
+ * endpoint but `e`.  What remains is a maximum-weight bipartite matching between the remaining in-spans
+ * and the spans of endpoint e, edge weight = best still-compatible candidate of the in-span that uses the
+ * span; an in-span may stay unmatched (own dummy column, weight 0).  Solved exactly with the Hungarian
+ * algorithm (potentials, shortest augmenting paths; rows have <= K finite entries).  The bound is the
+ * minimum over the endpoints; for E = 1 it is the exact optimum of the sub-problem. */
+#define TWO_MAX_RES (TWO_MAX_WIN * TWO_MAX_K)
+typedef struct {
+    int nrow;
+    int ndeg[TWO_MAX_WIN];
+    int col[TWO_MAX_WIN][TWO_MAX_K];     /* 1-based column ids */
+    double cost[TWO_MAX_WIN][TWO_MAX_K]; /* -weight */
+} match_graph;
+
+static double hungarian_min_cost(const match_graph *g, int ncol_real) {
+    const double INF = 1.0e300;
+    int n = g->nrow, m = ncol_real + n; /* column ncol_real + r is the dummy of row r (cost 0) */
+    double u[TWO_MAX_WIN + 1], v[TWO_MAX_RES + TWO_MAX_WIN + 1], minv[TWO_MAX_RES + TWO_MAX_WIN + 1];
+    int p[TWO_MAX_RES + TWO_MAX_WIN + 1], way[TWO_MAX_RES + TWO_MAX_WIN + 1];
+    unsigned char used[TWO_MAX_RES + TWO_MAX_WIN + 1];
+    for (int j = 0; j <= m; j++) { v[j] = 0.0; p[j] = 0; }
+    for (int i = 0; i <= n; i++) u[i] = 0.0;
+    for (int i = 1; i <= n; i++) {
+        p[0] = i;
+        int j0 = 0;
+        for (int j = 0; j <= m; j++) { minv[j] = INF; used[j] = 0; way[j] = 0; }
+        do {
+            used[j0] = 1;
+            int i0 = p[j0], j1 = 0;
+            double delta = INF;
+            for (int t = 0; t <= g->ndeg[i0 - 1]; t++) {
+                int j = t < g->ndeg[i0 - 1] ? g->col[i0 - 1][t] : ncol_real + i0;
+                double a = t < g->ndeg[i0 - 1] ? g->cost[i0 - 1][t] : 0.0;
+                if (used[j]) continue;
+                double cur = a - u[i0] - v[j];
+                if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+            }
+            for (int j = 1; j <= m; j++) if (!used[j] && minv[j] < delta) { delta = minv[j]; j1 = j; }
+            for (int j = 0; j <= m; j++) {
+                if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+                else if (minv[j] < INF) minv[j] -= delta;
+            }
+            j0 = j1;
+        } while (p[j0] != 0);
+        do { int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
+    }
+    return -v[0];
+}
+
+static double match_bound(mwis_comp *c, int d) {
+    double best = INFINITY;
+    for (int e = 0; e < c->E; e++) {
+        match_graph g;
+        int32_t res[TWO_MAX_RES];
+        int nres = 0;
+        g.nrow = c->m - d;
+        for (int r = 0; r < g.nrow; r++) {
+            int i = d + r;
+            g.ndeg[r] = 0;
+            for (int j = 0; j < c->n[i]; j++) {
+                int ok = 1;
+                for (int q = 0; q < d && ok; q++) if (c->cur[q] >= 0 && shares(c->E, c->idx[q][c->cur[q]], c->idx[i][j])) ok = 0;
+                if (!ok) continue;
+                int32_t x = c->idx[i][j][e];
+                int col = -1;
+                for (int t = 0; t < nres; t++) if (res[t] == x) { col = t + 1; break; }
+                if (col < 0) { res[nres] = x; col = ++nres; }
+                int at = -1;
+                for (int t = 0; t < g.ndeg[r]; t++) if (g.col[r][t] == col) { at = t; break; }
+                if (at < 0) { at = g.ndeg[r]++; g.col[r][at] = col; g.cost[r][at] = -c->w[i][j]; }
+                else if (-c->w[i][j] < g.cost[r][at]) g.cost[r][at] = -c->w[i][j];
+            }
+        }
+        double b = -hungarian_min_cost(&g, nres);
+        if (b < best) best = b;
+    }
+    return best;
+}
+
+#define TWO_SMALL_COMP 5        /* components up to this size are searched with the plain bound only */
+#define TWO_NODE_BUDGET 20000   /* search nodes per component; beyond it the incumbent is returned */
 static void mwis_dfs(mwis_comp *c, int d, double acc) {
+    if (c->nodes >= TWO_NODE_BUDGET) { c->exhausted = 1; return; }
     c->nodes++;
     if (d == c->m) { if (acc > c->best_w) { c->best_w = acc; memcpy(c->best, c->cur, sizeof(int) * (size_t)c->m); } return; }
     if (acc + c->ub[d] <= c->best_w) return;
+    if (c->m > TWO_SMALL_COMP && acc + match_bound(c, d) <= c->best_w) return;
     for (int j = 0; j < c->n[d]; j++) {
         int ok = 1;
         for (int q = 0; q < d && ok; q++) if (c->cur[q] >= 0 && shares(c->E, c->idx[q][c->cur[q]], c->idx[d][j])) ok = 0;
@@ -643,9 +728,13 @@ static void mwis_dfs(mwis_comp *c, int d, double acc) {
  *   nodes with weight 10000+score <= 0 are never selected; the window is split into connected
  *   components of the in-span conflict relation; each component is searched depth-first over its
  *   in-spans in index order, candidates in list order then "none", sums accumulated left to right,
- *   a subtree is cut when acc + suffix_upper_bound <= best, and only strict improvements replace
- *   the incumbent.  chosen[i] = candidate index or -1. */
-static int64_t mwis_window(const two_service *s, int m, const int *ncand, two_cand (*cands)[TWO_MAX_K], int *chosen) {
+ *   a subtree is cut when acc + upper bound <= best (upper bound = sum of the remaining in-spans'
+ *   best weights; for components of more than TWO_SMALL_COMP in-spans additionally the matching
+ *   relaxation above), and only strict improvements replace the incumbent.  The answer is the first
+ *   optimal selection in that depth-first order; it does not depend on the bounds.  A component whose
+ *   search exceeds TWO_NODE_BUDGET nodes returns its incumbent and is reported (stats[4]).
+ *   chosen[i] = candidate index or -1. */
+static int64_t mwis_window(const two_service *s, int m, const int *ncand, two_cand (*cands)[TWO_MAX_K], int *chosen, int *budget_hit) {
     int E = s->E, comp[TWO_MAX_WIN];
     int64_t nodes = 0;
     for (int i = 0; i < m; i++) { comp[i] = i; chosen[i] = -1; }
@@ -662,7 +751,7 @@ static int64_t mwis_window(const two_service *s, int m, const int *ncand, two_ca
     for (int root = 0; root < m; root++) {
         if (comp[root] != root) continue;
         mwis_comp c; int members[TWO_MAX_WIN];
-        c.m = 0; c.E = E; c.nodes = 0;
+        c.m = 0; c.E = E; c.nodes = 0; c.exhausted = 0;
         for (int i = root; i < m; i++) {
             if (comp[i] != root) continue;
             int d = c.m++; members[d] = i; c.n[d] = 0;
@@ -679,6 +768,7 @@ static int64_t mwis_window(const two_service *s, int m, const int *ncand, two_ca
         mwis_dfs(&c, 0, 0.0);
         for (int d = 0; d < c.m; d++) chosen[members[d]] = c.best[d] >= 0 ? c.kk[d][c.best[d]] : -1;
         nodes += c.nodes;
+        if (c.exhausted) *budget_hit = 1;
     }
     return nodes;
 }
@@ -690,7 +780,8 @@ static int64_t mwis_window(const two_service *s, int m, const int *ncand, two_ca
  *   leaves[n]   : DFS leaves of the top_k call (per_span_candidates increment)
  *   chosen[n]   : index into top_k of the MWIS pick, -1 unassigned
  *   parent[E*n] : out-span index per endpoint, -1 = ("NA","NA")
- *   stats[4]    : not_best_count, cnt_unassigned, mwis search nodes, windows solved
+ *   stats[5]    : not_best_count, cnt_unassigned, mwis search nodes, windows solved, windows whose
+ *                 selection search hit the node budget (incumbent returned, optimality not proven)
  * gauss: [n_blocks][nslot][2] (mode 0).  Returns 0 or <0 on error. */
 int two_run_pass(const two_service *s, int mode, const double *gauss, const int32_t *mix_n, const double *mix_p,
                  const uint8_t *end_flag, int32_t *topk_n, int32_t *topk_idx, double *topk_score, int32_t *topk2_n,
@@ -705,7 +796,7 @@ int two_run_pass(const two_service *s, int mode, const double *gauss, const int3
     two_params P; P.mode = mode; P.gauss = NULL; P.mix_n = mix_n; P.mix_p = mix_p;
     static two_cand batch[TWO_MAX_WIN][TWO_MAX_K];
     int batch_n[TWO_MAX_WIN], batch_i[TWO_MAX_WIN], nbatch = 0, rc = 0;
-    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    stats[0] = stats[1] = stats[2] = stats[3] = stats[4] = 0;
     for (int i = 0; i < E * n; i++) parent[i] = -1;
     for (int i = 0; i < n && rc == 0; i++) {
         if (mode == 0) P.gauss = gauss + (size_t)(i / s->batch_size) * nslot * 2; /* V3:1173-1178 */
@@ -727,7 +818,8 @@ int two_run_pass(const two_service *s, int mode, const double *gauss, const int3
         batch_n[nbatch] = c1; batch_i[nbatch] = i; nbatch++;
         if (end_flag[i]) {
             int pick[TWO_MAX_WIN];
-            stats[2] += mwis_window(s, nbatch, batch_n, batch, pick);
+            { int hit = 0; int64_t nn = mwis_window(s, nbatch, batch_n, batch, pick, &hit); stats[2] += nn; stats[4] += hit;
+              if (getenv("TWO_DEBUG_MWIS") && nn > 2000) fprintf(stderr, "mwis window end=%d m=%d nodes=%lld\n", i, nbatch, (long long)nn); }
             stats[3] += 1;
             for (int b = 0; b < nbatch; b++) {
                 int ii = batch_i[b];

@@ -120,7 +120,7 @@ def run_pass(svc, end_flag, gauss=None, mix_n=None, mix_p=None):
         "topk2_n": np.zeros(n, np.int32), "topk2_idx": np.zeros((n, K, E), np.int32), "topk2_score": np.zeros((n, K)),
         "leaves": np.zeros(n, np.int64), "chosen": np.full(n, -1, np.int32), "parent": np.zeros((E, n), np.int32),
     }
-    stats = np.zeros(4, np.int64)
+    stats = np.zeros(5, np.int64)
     mode = 0 if gauss is not None else 1
     if mode == 1:
         mix_n = np.ascontiguousarray(mix_n, dtype=np.int32)
@@ -134,7 +134,7 @@ def run_pass(svc, end_flag, gauss=None, mix_n=None, mix_p=None):
                             _p(o["parent"]), _p(stats))
     if rc != 0:
         raise RuntimeError("two_run_pass failed: %d" % rc)
-    o["not_best_count"], o["cnt_unassigned"], o["mwis_nodes"], o["n_windows"] = (int(v) for v in stats)
+    o["not_best_count"], o["cnt_unassigned"], o["mwis_nodes"], o["n_windows"], o["budget_windows"] = (int(v) for v in stats)
     return o
 
 

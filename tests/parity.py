@@ -1,0 +1,88 @@
+"""Shared engine-vs-oracle comparison used by the host-emulation tier (CPU) and the GPU tier."""
+import numpy as np
+
+import tw_oracle as T
+from conftest import assert_pass_equal
+from traceweaver_amd import synth
+from traceweaver_amd.engine import Engine, UnitArrays
+
+# (seed, n_in, shape, concurrency, granularity_us): from lightly interleaved to size-capped windows with
+# span consumption across windows, plus millisecond-granular timestamps (exact score ties).
+STRESS = [
+    (1, 400, "chain3", 1.5, 1), (2, 400, "chain3", 4, 1), (3, 300, "chain3", 8, 1), (4, 300, "par2", 6, 1),
+    (5, 300, "diamond", 5, 1), (6, 400, "single", 10, 1), (7, 300, "par4", 3, 1), (8, 300, "chain2", 12, 1000),
+    (9, 300, "chain3", 4, 1000), (10, 200, "fan6", 2, 1), (11, 257, "single", 1.2, 1), (12, 2, "chain2", 1, 1),
+    (13, 513, "par2", 2, 1000),
+]
+
+
+def oracle_service(u):
+    return T.Service(u.in_start, u.in_end - u.in_start, u.out_off, u.out_start, u.out_end - u.out_start, u.dag, u.key_rank)
+
+
+def oracle_two_pass(svc, mixtures=None):
+    end_flag, pre, win = T.windows(svc)
+    p1 = T.run_pass(svc, end_flag, gauss=T.gauss_params(svc))
+    if mixtures is None:
+        mix_n = np.zeros(svc.nslot, np.int32)
+        mix_p = np.zeros((svc.nslot, 5, 3))
+        for q, d in enumerate(T.gaps(svc, p1["parent"])):
+            if d is not None:
+                mix_n[q], mix_p[q] = deterministic_mixture(d)
+        mixtures = (mix_n, mix_p)
+    p2 = T.run_pass(svc, end_flag, mix_n=mixtures[0], mix_p=mixtures[1])
+    return end_flag, p1, p2, mixtures
+
+
+def deterministic_mixture(d):
+    """A cheap, deterministic 1-3 component mixture from quantiles (test input for pass 2 only)."""
+    p = np.zeros((5, 3))
+    if len(d) == 0:
+        return 0, p
+    k = 1 if len(np.unique(d)) < 8 else 3
+    parts = np.array_split(np.sort(d), k)
+    for j, part in enumerate(parts):
+        p[j] = (len(part) / len(d), float(part.mean()), 1.0 / np.sqrt(float(part.var()) + 1e-6))
+    return k, p
+
+
+def check_units(lib_path, units, mixtures=None, device=0):
+    """Runs both passes on the engine for a batch of units and compares every unit with the oracle."""
+    eng = Engine(device, lib_path=lib_path)
+    eng.load(units)
+    eng.run_pass1()
+    r1 = eng.results(1)
+    g_eng = eng.gauss_params()
+    gaps_eng = eng.gaps()
+    ora = []
+    for k, u in enumerate(units):
+        svc = oracle_service(u)
+        ora.append((svc,) + oracle_two_pass(svc, None if mixtures is None else mixtures[k]))
+    eng.set_mixtures([o[4][0] for o in ora], [o[4][1] for o in ora])
+    eng.run_pass2()
+    r2 = eng.results(2)
+    eng.close()
+    for k, u in enumerate(units):
+        svc, end_flag, p1, p2, _ = ora[k]
+        tag = "unit %d:" % k
+        g = T.gauss_params(svc)
+        m = ~np.isnan(g[..., 0])
+        assert np.array_equal(g_eng[k][..., 0][m], g[..., 0][m]), tag + " gaussian means"
+        assert np.array_equal(g_eng[k][..., 1][m], g[..., 1][m]), tag + " gaussian stds"
+        assert np.isnan(g_eng[k][..., 0][~m]).all()
+        assert_pass_equal(r1[k], p1, end_flag, tag + " pass 1")
+        for q, go in enumerate(T.gaps(svc, p1["parent"])):
+            ge = gaps_eng[k][q]
+            ge = ge[~np.isnan(ge)]
+            assert (len(ge) == 0) if go is None else np.array_equal(ge, go), tag + " gap samples slot %d" % q
+        assert_pass_equal(r2[k], p2, end_flag, tag + " pass 2")
+    return r1, r2, ora
+
+
+def stress_units(cases):
+    units, truth = [], []
+    for seed, n, shape, conc, gran in cases:
+        u, tp = synth.make_unit(seed, n, shape=shape, concurrency=conc, granularity_us=gran)
+        units.append(u)
+        truth.append(tp)
+    return units, truth

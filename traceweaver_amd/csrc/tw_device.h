@@ -95,7 +95,9 @@ struct Dev {
     // gap samples [gs_off + q*n_in + i]
     double* gaps;
     const int64_t* gs_off;  // [n_units]
-    int64_t* unit_stats;    // [n_units][4]
+    int64_t* unit_stats;    // [n_units][8]
+    int32_t* heavy_count;   // windows deferred to the large-component selection kernel
+    int32_t *heavy_unit, *heavy_win;
     int32_t* err;           // first error raised by a kernel (tw_status)
 };
 

@@ -132,7 +132,8 @@ int run_pass(tw_engine* e, int pass) {
     const dim3 tiles(P.n_tiles), tb(e->tile);
     HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
     HIPCHK(hipMemsetAsync(P.err, 0, sizeof(int32_t), e->stream));
-    HIPCHK(hipMemsetAsync(P.unit_stats, 0, sizeof(int64_t) * 4 * P.n_units, e->stream));
+    HIPCHK(hipMemsetAsync(P.unit_stats, 0, sizeof(int64_t) * 8 * P.n_units, e->stream));
+    HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t), e->stream));
     HIPCHK(hipMemsetAsync(P.unit_ndirty, 0, sizeof(int32_t) * P.n_units, e->stream));
     HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
     if (pass == 1) {
@@ -160,6 +161,7 @@ int run_pass(tw_engine* e, int pass) {
     }
     HIPCHK(hipEventRecord(e->ev[EV_WIN], e->stream));
     hipLaunchKernelGGL(k_select, tiles, tb, 0, e->stream, P);
+    hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)((P.n_in_total / 6 + 64) / 64)), dim3(64), 0, e->stream, P);
     HIPCHK(hipEventRecord(e->ev[EV_SEL], e->stream));
     hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P);
     hipLaunchKernelGGL(k_detect, tiles, tb, 0, e->stream, P);
@@ -324,7 +326,8 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.c_lo, ie); ALLOC(P.c_bits, ie * kCandWords); ALLOC(P.parent, ie);
     ALLOC(P.owner, n_out_total);
     ALLOC(P.gaps, gaps);
-    ALLOC(P.unit_stats, (int64_t)P.n_units * 4); ALLOC(P.err, 1);
+    ALLOC(P.unit_stats, (int64_t)P.n_units * 8); ALLOC(P.err, 1);
+    ALLOC(P.heavy_count, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
 #undef ALLOC
@@ -408,7 +411,7 @@ int tw_get_results(tw_engine* e, int pass, const tw_results* r) {
     D2H(r->chosen, P.chosen, sizeof(int32_t) * n);
     D2H(r->leaves, P.leaves, sizeof(int64_t) * n);
     D2H(r->window_end, P.win_end, sizeof(uint8_t) * n);
-    D2H(r->unit_stats, P.unit_stats, sizeof(int64_t) * 4 * P.n_units);
+    D2H(r->unit_stats, P.unit_stats, sizeof(int64_t) * 8 * P.n_units);
 #undef D2H
     HIPCHK(hipStreamSynchronize(e->stream));
     return TW_OK;

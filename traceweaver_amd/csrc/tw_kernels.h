@@ -560,32 +560,119 @@ __device__ inline bool cands_share(const Dev& P, const UnitDev& U, int i, int a,
     return false;
 }
 
+// Upper bound for "component members d..cm-1 given the current partial selection": relax every
+// endpoint but e; what remains is a maximum-weight bipartite matching between the remaining spans and
+// the outgoing spans of endpoint e (edge weight = best still-compatible candidate using that span, an
+// incoming span may stay unmatched).  Hungarian algorithm with potentials; rows have <= kTopK finite
+// entries.  The bound is the minimum over the endpoints (exact for E = 1).
+constexpr int kSmallComp = 5;        // components up to this size use the plain bound only
+constexpr int kNodeBudget = 20000;   // search nodes per component; beyond it the incumbent is returned
+constexpr int kMaxRes = kMaxWin * kTopK;
+
+struct MatchGraph {
+    int nrow;
+    uint8_t ndeg[kMaxWin];
+    uint8_t col[kMaxWin][kTopK];   // 1-based column ids
+    double cost[kMaxWin][kTopK];   // -weight
+};
+
+__device__ inline double hungarian_min_cost(const MatchGraph& g, int ncol_real) {
+    const double INF = 1.0e300;
+    const int n = g.nrow, m = ncol_real + n;  // column ncol_real + r is the dummy of row r (cost 0)
+    double u[kMaxWin + 1], v[kMaxRes + kMaxWin + 1], minv[kMaxRes + kMaxWin + 1];
+    int16_t p[kMaxRes + kMaxWin + 1], way[kMaxRes + kMaxWin + 1];
+    uint8_t used[kMaxRes + kMaxWin + 1];
+    for (int j = 0; j <= m; j++) { v[j] = 0.0; p[j] = 0; }
+    for (int i = 0; i <= n; i++) u[i] = 0.0;
+    for (int i = 1; i <= n; i++) {
+        p[0] = (int16_t)i;
+        int j0 = 0;
+        for (int j = 0; j <= m; j++) { minv[j] = INF; used[j] = 0; way[j] = 0; }
+        do {
+            used[j0] = 1;
+            const int i0 = p[j0];
+            int j1 = 0;
+            double delta = INF;
+            const int deg = g.ndeg[i0 - 1];
+            for (int t = 0; t <= deg; t++) {
+                const int j = t < deg ? g.col[i0 - 1][t] : ncol_real + i0;
+                const double a = t < deg ? g.cost[i0 - 1][t] : 0.0;
+                if (used[j]) continue;
+                const double cur = a - u[i0] - v[j];
+                if (cur < minv[j]) { minv[j] = cur; way[j] = (int16_t)j0; }
+            }
+            for (int j = 1; j <= m; j++) if (!used[j] && minv[j] < delta) { delta = minv[j]; j1 = j; }
+            for (int j = 0; j <= m; j++) {
+                if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+                else if (minv[j] < INF) minv[j] -= delta;
+            }
+            j0 = j1;
+        } while (p[j0] != 0);
+        do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
+    }
+    return -v[0];
+}
+
+__device__ inline double match_bound(const Dev& P, const UnitDev& U, int first, const uint8_t* mem, int cm, int d,
+                                     const int8_t* cur, const uint8_t* ncand) {
+    double best = dinf();
+    for (int e = 0; e < U.E; e++) {
+        MatchGraph g;
+        int32_t res[kMaxRes];
+        int nres = 0;
+        g.nrow = cm - d;
+        for (int r = 0; r < g.nrow; r++) {
+            const int b = mem[d + r];
+            g.ndeg[r] = 0;
+            for (int k = 0; k < ncand[b]; k++) {
+                const double w = 10000.0 + cand_score(P, U, first + b, k);
+                if (!(w > 0.0)) continue;
+                bool ok = true;
+                for (int q = 0; q < d && ok; q++)
+                    if (cur[q] >= 0 && cands_share(P, U, first + mem[q], cur[q], first + b, k)) ok = false;
+                if (!ok) continue;
+                const int32_t x = cand_idx(P, U, first + b, k, e);
+                int col = -1;
+                for (int t = 0; t < nres; t++) if (res[t] == x) { col = t + 1; break; }
+                if (col < 0) { res[nres] = x; col = ++nres; }
+                int at = -1;
+                for (int t = 0; t < g.ndeg[r]; t++) if (g.col[r][t] == col) { at = t; break; }
+                if (at < 0) { at = g.ndeg[r]++; g.col[r][at] = (uint8_t)col; g.cost[r][at] = -w; }
+                else if (-w < g.cost[r][at]) g.cost[r][at] = -w;
+            }
+        }
+        const double bnd = -hungarian_min_cost(g, nres);
+        if (bnd < best) best = bnd;
+    }
+    return best;
+}
+
 // Canonical procedure (shared with the oracle so that exact ties resolve identically):
 //   node weight 10000 + score (traceweaver_v3.py:1260); nodes with weight <= 0 are never selected;
 //   the window is split into connected components of the span conflict relation; each component is
 //   searched depth-first over its spans in index order, candidates in list order then "none", sums
-//   accumulated left to right; a subtree is cut when acc + suffix bound <= best; only strict
-//   improvements replace the incumbent.
-__device__ void select_window(const Dev& P, const UnitDev& U, int first, int m) {
+//   accumulated left to right; a subtree is cut when acc + upper bound <= best (upper bound = sum of the
+//   remaining spans' best weights; for components of more than kSmallComp spans additionally the
+//   matching relaxation above); only strict improvements replace the incumbent.  The answer is the first
+//   optimal selection in that depth-first order and does not depend on the bounds.  A component whose
+//   search exceeds kNodeBudget nodes keeps its incumbent and the window is counted in unit_stats[4].
+// kHeavy = false: components larger than kSmallComp are not searched; returns false (window deferred to
+// k_select_heavy, which owns the large per-thread arrays of the matching bound).
+template <bool kHeavy>
+__device__ bool select_window(const Dev& P, const UnitDev& U, int unit, int first, int m) {
     if (m == 1) {  // 87 % of the windows on the shipped data sets
         int pick = -1;
+        double best = 0.0;
         const int n = cand_n(P, U, first);
-        for (int k = 0; k < n && pick < 0; k++)
-            if (10000.0 + cand_score(P, U, first, k) > 0.0) pick = k;
-        // single node: the best eligible candidate is the one with the largest weight = first in list
-        // order among equal maxima; the list is sorted descending, so scan for the maximum explicitly
-        if (pick >= 0) {
-            double best = 10000.0 + cand_score(P, U, first, pick);
-            for (int k = pick + 1; k < n; k++) {
-                const double w = 10000.0 + cand_score(P, U, first, k);
-                if (w > best) { best = w; pick = k; }
-            }
+        for (int k = 0; k < n; k++) {
+            const double w = 10000.0 + cand_score(P, U, first, k);
+            if (w > 0.0 && w > best) { best = w; pick = k; }
         }
         P.chosen[U.in_off + first] = pick;
-        return;
+        return true;
     }
     uint8_t comp[kMaxWin], ncand[kMaxWin];
-    for (int b = 0; b < m; b++) { comp[b] = (uint8_t)b; ncand[b] = (uint8_t)cand_n(P, U, first + b); P.chosen[U.in_off + first + b] = -1; }
+    for (int b = 0; b < m; b++) { comp[b] = (uint8_t)b; ncand[b] = (uint8_t)cand_n(P, U, first + b); }
     for (int b = 0; b < m; b++)
         for (int c = 0; c < b; c++) {
             if (comp[b] == comp[c]) continue;
@@ -600,6 +687,16 @@ __device__ void select_window(const Dev& P, const UnitDev& U, int first, int m) 
                 for (int t = 0; t < m; t++) if (comp[t] == hi) comp[t] = lo;
             }
         }
+    if (!kHeavy) {
+        for (int root = 0; root < m; root++) {
+            if (comp[root] != root) continue;
+            int cm = 0;
+            for (int b = root; b < m; b++) cm += (comp[b] == root);
+            if (cm > kSmallComp) return false;
+        }
+    }
+    bool budget_hit = false;
+    for (int b = 0; b < m; b++) P.chosen[U.in_off + first + b] = -1;
     for (int root = 0; root < m; root++) {
         if (comp[root] != root) continue;
         uint8_t mem[kMaxWin];
@@ -615,21 +712,26 @@ __device__ void select_window(const Dev& P, const UnitDev& U, int first, int m) 
             }
             ub[d] = ub[d + 1] + mx;
         }
-        int8_t cur[kMaxWin], best[kMaxWin], next[kMaxWin];
+        int8_t cur[kMaxWin], best[kMaxWin], next[kMaxWin + 1];
         for (int d = 0; d < cm; d++) { cur[d] = -1; best[d] = -1; }
         double best_w = 0.0;
+        int nodes = 0;
         // iterative DFS: next[d] = next option to try at depth d (0..ncand-1 candidates, ncand = "none")
         int d = 0;
         accs[0] = 0.0;
-        next[0] = 0;
         bool entered = true;
         while (d >= 0) {
             if (entered) {
+                if (nodes >= kNodeBudget) { budget_hit = true; break; }
+                nodes++;
                 if (d == cm) {
                     if (accs[d] > best_w) { best_w = accs[d]; for (int t = 0; t < cm; t++) best[t] = cur[t]; }
                     d--; entered = false; continue;
                 }
                 if (accs[d] + ub[d] <= best_w) { d--; entered = false; continue; }
+                if (kHeavy && cm > kSmallComp) {
+                    if (accs[d] + match_bound(P, U, first, mem, cm, d, cur, ncand) <= best_w) { d--; entered = false; continue; }
+                }
                 next[d] = 0;
             }
             const int b = mem[d], nc = ncand[b];
@@ -653,9 +755,11 @@ __device__ void select_window(const Dev& P, const UnitDev& U, int first, int m) 
         }
         for (int t = 0; t < cm; t++) P.chosen[U.in_off + first + mem[t]] = best[t];
     }
+    if (budget_hit) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 4], 1ull);
+    return true;
 }
 
-__global__ void k_select(Dev P) {  // one thread per window
+__global__ void k_select(Dev P) {  // one thread per window; windows with a large component are deferred
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int w = Tl.first + threadIdx.x;
@@ -665,7 +769,20 @@ __global__ void k_select(Dev P) {  // one thread per window
     const int m = last - first + 1;
     if (m <= 0) return;
     if (m > kMaxWin) { raise_err(P, TW_ERR_WINDOW_SIZE); return; }
-    select_window(P, U, first, m);
+    if (!select_window<false>(P, U, Tl.unit, first, m)) {
+        const int slot = atomicAdd(P.heavy_count, 1);
+        P.heavy_unit[slot] = Tl.unit;
+        P.heavy_win[slot] = w;
+    }
+}
+__global__ void k_select_heavy(Dev P) {  // one thread per deferred window
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *P.heavy_count) return;
+    const int unit = P.heavy_unit[t], w = P.heavy_win[t];
+    const UnitDev& U = P.units[unit];
+    const int last = P.w_last[U.in_off + w];
+    const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
+    select_window<true>(P, U, unit, first, last - first + 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -803,7 +920,7 @@ __global__ void k_repair(Dev P, int pass) {
             }
             __threadfence();
             __syncthreads();
-            if (t == 0) { select_window(P, U, first, m); repaired++; }
+            if (t == 0) { select_window<true>(P, U, u, first, m); repaired++; }
             __threadfence();
             __syncthreads();
             // later windows that hold a span chosen here must be re-examined
@@ -824,7 +941,7 @@ __global__ void k_repair(Dev P, int pass) {
         }
         w++;
     }
-    if (t == 0) P.unit_stats[(int64_t)u * 4 + 3] = repaired;
+    if (t == 0) P.unit_stats[(int64_t)u * 8 + 3] = repaired;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -835,9 +952,9 @@ __global__ void k_finalize(Dev P) {
     if (i >= U.n_in) return;
     const int c = P.chosen[U.in_off + i];
     for (int e = 0; e < U.E; e++) P.parent[ie_index(U, e, i)] = c >= 0 ? cand_idx(P, U, i, c, e) : -1;
-    if (c != 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 4 + 0], 1ull);  // traceweaver_v3.py:1201-1207
-    if (c < 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 4 + 1], 1ull);   // traceweaver_v3.py:1217
-    if (i == 0) P.unit_stats[(int64_t)Tl.unit * 4 + 2] = P.unit_nwin[Tl.unit];
+    if (c != 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 8 + 0], 1ull);  // traceweaver_v3.py:1201-1207
+    if (c < 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 8 + 1], 1ull);   // traceweaver_v3.py:1217
+    if (i == 0) P.unit_stats[(int64_t)Tl.unit * 8 + 2] = P.unit_nwin[Tl.unit];
 }
 
 // Gap samples of the current assignment per scored slot (traceweaver_v3.py:717-762); NaN = dropped.

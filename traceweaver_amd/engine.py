@@ -131,34 +131,42 @@ class Engine(object):
         self._check(self._lib.tw_get_gauss_params(self._h, _vp(g)))
         return [g[self._gp_off[k]:self._gp_off[k + 1]].reshape(self._nblk[k], u.nslot, 3) for k, u in enumerate(self.units)]
 
-    def results(self, which):
-        """Per unit dict: parent [E,n], topk_idx [5,E,n], topk_score [5,n], topk_n, chosen, leaves, window_end, stats."""
+    _FIELDS = ("parent", "topk_idx", "topk_score", "topk_n", "chosen", "leaves", "window_end", "unit_stats")
+
+    def results(self, which, fields=None):
+        """Per unit dict: parent [E,n], topk_idx [5,E,n], topk_score [5,n], topk_n, chosen, leaves, window_end
+        and the counters.  `fields` restricts what is copied back from the device."""
+        fields = self._FIELDS if fields is None else tuple(fields)
         n_in = int(self._in_off[-1])
         n_ie = int(self._ie_off[-1])
         K = _ffi.TW_TOPK
-        buf = {
-            "parent": np.empty(n_ie, np.int32), "topk_idx": np.empty(n_ie * K, np.int32),
-            "topk_score": np.empty(n_in * K, np.float64), "topk_n": np.empty(n_in, np.int32),
-            "chosen": np.empty(n_in, np.int32), "leaves": np.empty(n_in, np.int64),
-            "window_end": np.empty(n_in, np.uint8), "unit_stats": np.empty((len(self.units), 4), np.int64),
+        shapes = {
+            "parent": (n_ie, np.int32), "topk_idx": (n_ie * K, np.int32), "topk_score": (n_in * K, np.float64),
+            "topk_n": (n_in, np.int32), "chosen": (n_in, np.int32), "leaves": (n_in, np.int64),
+            "window_end": (n_in, np.uint8), "unit_stats": ((len(self.units), 8), np.int64),
         }
-        r = _ffi.Results(*[_vp(buf[k]) for k in ("parent", "topk_idx", "topk_score", "topk_n", "chosen", "leaves",
-                                                 "window_end", "unit_stats")])
+        buf = {k: (np.empty(*shapes[k]) if k in fields else None) for k in self._FIELDS}
+        r = _ffi.Results(*[_vp(buf[k]) for k in self._FIELDS])
         self._check(self._lib.tw_get_results(self._h, int(which), ctypes.byref(r)))
         out = []
         for k, u in enumerate(self.units):
             a, b = int(self._in_off[k]), int(self._in_off[k + 1])
             ia, ib = int(self._ie_off[k]), int(self._ie_off[k + 1])
-            st = buf["unit_stats"][k]
-            out.append({
-                "parent": buf["parent"][ia:ib].reshape(u.E, u.n_in),
-                "topk_idx": buf["topk_idx"][K * ia:K * ib].reshape(K, u.E, u.n_in),
-                "topk_score": buf["topk_score"][K * a:K * b].reshape(K, u.n_in),
-                "topk_n": buf["topk_n"][a:b], "chosen": buf["chosen"][a:b], "leaves": buf["leaves"][a:b],
-                "window_end": buf["window_end"][a:b],
-                "not_best_count": int(st[0]), "cnt_unassigned": int(st[1]), "n_windows": int(st[2]),
-                "repaired_windows": int(st[3]),
-            })
+            o = {}
+            if buf["parent"] is not None:
+                o["parent"] = buf["parent"][ia:ib].reshape(u.E, u.n_in)
+            if buf["topk_idx"] is not None:
+                o["topk_idx"] = buf["topk_idx"][K * ia:K * ib].reshape(K, u.E, u.n_in)
+            if buf["topk_score"] is not None:
+                o["topk_score"] = buf["topk_score"][K * a:K * b].reshape(K, u.n_in)
+            for name in ("topk_n", "chosen", "leaves", "window_end"):
+                if buf[name] is not None:
+                    o[name] = buf[name][a:b]
+            if buf["unit_stats"] is not None:
+                st = buf["unit_stats"][k]
+                o.update({"not_best_count": int(st[0]), "cnt_unassigned": int(st[1]), "n_windows": int(st[2]),
+                          "repaired_windows": int(st[3]), "budget_windows": int(st[4])})
+            out.append(o)
         return out
 
     def timing(self):

@@ -1,0 +1,142 @@
+"""Synthetic service units in structure-of-arrays form (seed-fixed, integer microseconds).
+
+The shipped Jaeger corpora of the reference hold 1000 requests per application and the Alibaba corpus
+is a Git-LFS pointer, so throughput is measured on synthetic units that keep the
+*shape* of the reference's inputs: one incoming span per request, exactly one outgoing call per
+(request, endpoint) (utils.py:22-32 assumes that), children contained in the parent, and a call-order
+DAG obtained exactly like executor.py:214-285 (FindOrder): a->b iff a finished before b started in
+every request.
+
+`granularity_us=1000` reproduces the millisecond-granular timestamps of the nodejs and Alibaba-shape
+data (alibaba-analysis/real-parser.py:323,329), where exact score ties do occur.
+"""
+import numpy as np
+
+from .engine import UnitArrays
+
+# call structures: list of stages, every stage is a tuple of endpoints called in parallel; stages run
+# one after the other.  Endpoint ids are arbitrary labels.
+SHAPES = {
+    "single": [(0,)],
+    "chain2": [(0,), (1,)],
+    "chain3": [(0,), (1,), (2,)],                 # hotel frontend: search -> reservation -> profile
+    "par2": [(0, 1)],                             # nodejs service1
+    "par4": [(0, 1, 2, 3)],                       # media nginx: four parallel calls
+    "diamond": [(0,), (1, 2), (3,)],
+    "fan6": [(0,), (1, 2, 3, 4), (5,)],
+}
+
+# the six accelerated services of media_microservices (E in {1,1,1,1,2,4})
+MEDIA_SERVICES = ["single", "single", "single", "single", "par2", "par4"]
+HOTEL_SERVICES = ["chain3", "chain2"]
+
+
+def find_order(start, end):
+    """executor.py:214-285 on ground-truth arrays [E, n]: dag[a, b] = 1 iff end[a] <= start[b] in every request."""
+    E = start.shape[0]
+    dag = np.zeros((E, E), dtype=np.uint8)
+    for a in range(E):
+        for b in range(E):
+            if a != b and bool(np.all(end[a] <= start[b])):
+                dag[a, b] = 1
+    return dag
+
+
+def topo_order(dag):
+    """A topological order with ties in index order (what networkx returns for insertion-ordered nodes)."""
+    E = dag.shape[0]
+    indeg = dag.sum(axis=0).astype(int)
+    order, ready = [], [e for e in range(E) if indeg[e] == 0]
+    while ready:
+        e = ready.pop(0)
+        order.append(e)
+        for f in range(E):
+            if dag[e, f]:
+                indeg[f] -= 1
+                if indeg[f] == 0:
+                    ready.append(f)
+    if len(order) != E:
+        raise ValueError("call-order relation is not a DAG")
+    return order
+
+
+def make_unit(seed, n_in, shape="chain3", concurrency=1.5, mean_service_us=4000.0, sigma=0.5,
+              gap_us=300.0, granularity_us=1, t0_us=1_600_000_000_000_000):
+    """Returns (UnitArrays, true_parent [E, n_in] int32).
+
+    concurrency ~ mean number of requests in flight (arrival rate x mean response time)."""
+    rng = np.random.default_rng(seed)
+    stages = SHAPES[shape] if isinstance(shape, str) else shape
+    eps = sorted({e for st in stages for e in st})
+    E = len(eps)
+    n = int(n_in)
+    q = int(granularity_us)
+
+    def ln(mean, size):
+        mu = np.log(mean) - 0.5 * sigma * sigma
+        return np.maximum(1, rng.lognormal(mu, sigma, size)).astype(np.int64)
+
+    start = np.zeros((E, n), dtype=np.int64)
+    end = np.zeros((E, n), dtype=np.int64)
+    t = ln(gap_us, n)  # offset of the first stage relative to the request start
+    for st in stages:
+        stage_end = np.zeros(n, dtype=np.int64)
+        for e in st:
+            s = t + ln(gap_us, n) // 4
+            d = ln(mean_service_us, n)
+            start[e], end[e] = s, s + d
+            stage_end = np.maximum(stage_end, s + d)
+        t = stage_end + ln(gap_us, n)
+    resp = t  # response time of the request
+    mean_resp = float(resp.mean())
+    inter = rng.exponential(mean_resp / max(concurrency, 1e-9), n)
+    in_start = t0_us + np.cumsum(inter).astype(np.int64)
+    in_end = in_start + resp
+    start += in_start
+    end += in_start
+    if q > 1:  # quantise, keeping containment and stage order
+        in_start = in_start // q * q
+        start = start // q * q
+        end = -(-end // q) * q
+        end = np.maximum(end, start)
+        for k in range(1, len(stages)):  # a later stage must not start before the previous stage ended
+            prev_end = np.max(end[list(stages[k - 1])], axis=0)
+            for e in stages[k]:
+                shift = np.maximum(0, prev_end - start[e])
+                start[e] += shift
+                end[e] += shift
+        in_end = np.maximum(-(-in_end // q) * q, end.max(axis=0))
+    dag_true = find_order(start, end)
+    order = topo_order(dag_true)
+    dag = dag_true[np.ix_(order, order)]
+    # sort every list by (start, end) and remember where each request's span went
+    in_perm = np.lexsort((in_end, in_start))
+    in_rank = np.empty(n, dtype=np.int64)
+    in_rank[in_perm] = np.arange(n)
+    out_start, out_end, true_parent = [], [], np.zeros((E, n), dtype=np.int32)
+    for k, e in enumerate(order):
+        perm = np.lexsort((end[e], start[e]))
+        rank = np.empty(n, dtype=np.int64)
+        rank[perm] = np.arange(n)
+        out_start.append(start[e][perm])
+        out_end.append(end[e][perm])
+        true_parent[k, in_rank] = rank
+    unit = UnitArrays(in_start[in_perm], in_end[in_perm], np.arange(E + 1, dtype=np.int64) * n,
+                      np.concatenate(out_start), np.concatenate(out_end), dag)
+    return unit, true_parent
+
+
+def make_workload(seed, n_in_per_unit, services=MEDIA_SERVICES, replicas=1, **kw):
+    """A batch of independent units: `replicas` copies of the given service list (different seeds)."""
+    units, truth = [], []
+    for r in range(replicas):
+        for k, shape in enumerate(services):
+            u, tp = make_unit(seed * 1000003 + r * 101 + k, n_in_per_unit, shape=shape, **kw)
+            units.append(u)
+            truth.append(tp)
+    return units, truth
+
+
+def accuracy(parent, true_parent):
+    """utils.py:62-79 AccuracyForService on index arrays: a request counts when every endpoint matches."""
+    return float(np.all(parent == true_parent, axis=0).mean())
