@@ -103,6 +103,17 @@ int tw_get_gaps(tw_engine *e, double *gaps);
  * mix_p[sum_u nslot_u][TW_MAX_COMP][3] = weight, mean, precision_cholesky. */
 int tw_set_mixtures(tw_engine *e, const int32_t *mix_n, const double *mix_p);
 
+/* Device-side alternative to tw_get_gaps + host fit + tw_set_mixtures: refits every scored edge on the
+ * GPU from the pass-1 gap samples (ComputeEpPairDistParams5, traceweaver_v3.py:764-786): 1..min(5,
+ * #unique) component 1-D mixtures by EM (tol 1e-3, <= 100 iterations, reg_covar 1e-6 as scikit-learn's
+ * defaults), smallest BIC wins.  The reference's k-means++ start drawn from an unseeded global RNG
+ * (not reproducible, SURVEY.md hazard H9) is replaced by a deterministic start from the equal-count
+ * buckets of the sorted samples; see traceweaver_amd/csrc/tw_fit.h. */
+int tw_fit_mixtures(tw_engine *e);
+
+/* The mixture tables currently resident (layout of tw_set_mixtures). */
+int tw_get_mixtures(tw_engine *e, int32_t *mix_n, double *mix_p);
+
 /* Pass 2 (iteration 1): same as pass 1 with GaussianMixture.score terms
  * (traceweaver_v1.py:125-126), reusing the windows. */
 int tw_run_pass2(tw_engine *e);
@@ -137,7 +148,8 @@ int tw_get_gauss_params(tw_engine *e, double *gauss);
 
 /* Timing of the last pass, measured with HIP events on the engine's stream:
  * ms[0] whole pass, ms[1] candidate-enumeration kernel, ms[2] selection kernel,
- * ms[3] window construction, ms[4] repair kernel, ms[5] parameter kernels (sort + block sums). */
+ * ms[3] window construction, ms[4] claim/detect/repair kernels, ms[5] parameter kernels (sort + block
+ * sums), ms[6] last tw_fit_mixtures call. */
 int tw_get_timing(tw_engine *e, double *ms, int32_t n);
 
 /* One-shot convenience for a single unit: load, pass 1, (optional) pass 2 with caller-supplied

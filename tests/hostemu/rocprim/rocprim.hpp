@@ -10,7 +10,9 @@ inline hipError_t segmented_radix_sort_keys(void* temp, size_t& bytes, const Key
                                             hipStream_t = nullptr, bool = false) {
     if (temp == nullptr) { bytes = 16; return hipSuccess; }
     std::copy(in, in + size, out);
-    for (unsigned s = 0; s < segments; s++) std::sort(out + begin[s], out + end[s]);
+    // radix order: NaN (positive quiet NaN, as the engine writes it) sorts after every number
+    auto less = [](const Key& a, const Key& b) { return (a == a) && (!(b == b) || a < b); };
+    for (unsigned s = 0; s < segments; s++) std::sort(out + begin[s], out + end[s], less);
     return hipSuccess;
 }
 }  // namespace rocprim

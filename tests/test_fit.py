@@ -1,0 +1,95 @@
+"""Device-side mixture refit (csrc/tw_fit.h) against a numpy restatement of the same procedure:
+equal-count-bucket start, EM with scikit-learn's stopping rule, BIC selection.  Reduction orders differ
+(workgroup tree vs numpy pairwise), so parameters are compared to 1e-7 relative; pass 2 itself stays
+bit-exact for whatever table was fitted (tests/parity.py feeds the fitted table to the oracle)."""
+import numpy as np
+import pytest
+
+import parity
+from traceweaver_amd import synth
+from traceweaver_amd.engine import Engine
+
+LOG2PI = float(np.log(2 * np.pi))
+
+
+def em_numpy(x, k, tol=1e-3, max_iter=100, reg=1e-6):
+    x = np.sort(np.asarray(x, dtype=np.float64))
+    n = len(x)
+    j = (np.arange(n) * k) // n
+    w = np.array([(j == c).sum() / n for c in range(k)])
+    mu = np.array([x[j == c].mean() for c in range(k)])
+    var = np.array([((x[j == c] - mu[c]) ** 2).sum() / (j == c).sum() + reg for c in range(k)])
+    prev = -np.inf
+    for it in range(max_iter + 1):
+        lp = np.log(w) - 0.5 * (LOG2PI + np.log(var)) - 0.5 * (x[:, None] - mu) ** 2 / var
+        mx = lp.max(axis=1)
+        e = np.exp(lp - mx[:, None])
+        s = e.sum(axis=1)
+        lb = float((mx + np.log(s)).sum() / n)
+        if it == max_iter or abs(lb - prev) < tol:
+            return -2 * lb * n + (3 * k - 1) * np.log(n), w, mu, var
+        prev = lb
+        r = e / s[:, None]
+        d = x[:, None] - mu
+        nk = r.sum(axis=0) + 10 * np.finfo(float).eps
+        dm = (r * d).sum(axis=0) / nk
+        var = (r * d * d).sum(axis=0) / nk - dm * dm + reg
+        mu = mu + dm
+        w = nk / n
+        w = w / w.sum()
+
+
+def fit_numpy(x):
+    x = x[~np.isnan(x)]
+    if len(x) == 0:
+        return 0, None
+    best = None
+    for k in range(1, min(5, len(np.unique(x))) + 1):
+        bic, w, mu, var = em_numpy(x, k)
+        if best is None or bic < best[0]:
+            best = (bic, k, w, mu, var)
+    return best[1], best
+
+
+def check_fit(lib_path, units):
+    eng = Engine(0, lib_path=lib_path)
+    eng.load(units)
+    eng.run_pass1()
+    gaps = eng.gaps()
+    eng.fit_mixtures()
+    mixes = eng.mixtures()
+    eng.run_pass2()
+    r2 = eng.results(2)
+    eng.close()
+    checked = 0
+    for u, g, (mn, mp), res in zip(units, gaps, mixes, r2):
+        for q in range(u.nslot):
+            k, best = fit_numpy(g[q])
+            if k == 0:
+                assert mn[q] == 0
+                continue
+            assert mn[q] == k, "slot %d: component count %d vs %d" % (q, mn[q], k)
+            _, _, w, mu, var = best
+            assert np.allclose(mp[q, :k, 0], w, rtol=1e-7) and np.allclose(mp[q, :k, 1], mu, rtol=1e-7)
+            assert np.allclose(mp[q, :k, 2], 1 / np.sqrt(var), rtol=1e-7)
+            checked += 1
+        # pass 2 with the device-fitted table is bit-exact against the oracle
+        svc = parity.oracle_service(u)
+        import tw_oracle as T
+
+        end_flag, _, _ = T.windows(svc)
+        o2 = T.run_pass(svc, end_flag, mix_n=mn, mix_p=mp)
+        assert np.array_equal(res["parent"], o2["parent"])
+    assert checked > 0
+
+
+def test_device_fit_matches_numpy_restatement(emu_lib):
+    units, _ = parity.stress_units([(31, 600, "chain3", 2, 1), (32, 500, "par2", 3, 1000), (33, 400, "single", 1.5, 1)])
+    check_fit(emu_lib, units)
+
+
+@pytest.mark.gpu
+def test_device_fit_on_gpu():
+    units, _ = parity.stress_units([(31, 6000, "chain3", 2, 1), (32, 5000, "par2", 3, 1000), (33, 40000, "single", 1.5, 1),
+                                    (34, 3000, "diamond", 2, 1)])
+    check_fit(None, units)

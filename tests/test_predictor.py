@@ -1,0 +1,104 @@
+"""`TraceWeaverGPU.FindAssignments` behind the reference's predictor protocol (algorithms/README.md:12-73).
+
+CPU tier: the emulated engine; the GPU tier repeats the end-to-end case on the real library.  The
+end-to-end case re-creates the hotel `frontend` call of the frozen reference run (same spans, same DAG,
+same partition-key order, numpy RNG seeded like the reference run) and must return the same
+assignments, top-5 lists and counters as the reference did -- including the scikit-learn refit between
+the passes, which the predictor replays in the reference's call order."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+class Span(object):
+    """The fields the predictor protocol touches (reference spans.py:1-75)."""
+
+    def __init__(self, trace_id, sid, start_mus, duration_mus):
+        self.trace_id, self.sid, self.start_mus, self.duration_mus = trace_id, sid, int(start_mus), int(duration_mus)
+
+    def GetId(self):
+        return (self.trace_id, self.sid)
+
+
+def protocol_inputs(d):
+    import networkx as nx
+
+    out_eps = [str(x) for x in d["out_eps"]]
+    keys = [str(x) for x in d["partition_key_order"]]
+    n = len(d["in_start"])
+    in_spans = [Span("t%d" % i, "in", d["in_start"][i], d["in_dur"][i]) for i in range(n)]
+    parts = {}
+    for ep in keys:
+        k = out_eps.index(ep)
+        a, b = d["out_off"][k], d["out_off"][k + 1]
+        parts[ep] = [Span("o", "%s_%d" % (ep, j), d["out_start"][a + j], d["out_dur"][a + j]) for j in range(b - a)]
+    g = nx.DiGraph()
+    for ep in keys:
+        g.add_node(ep)
+    for p in keys:
+        for q in keys:
+            if p != q and d["dag"][out_eps.index(p), out_eps.index(q)]:
+                g.add_edge(p, q)
+    truth = {ep: {} for ep in keys}
+    for k, ep in enumerate(out_eps):
+        for i in range(n):
+            truth[ep][in_spans[i].GetId()] = parts[ep][d["true_parent"][k, i]].GetId()
+    return {str(d["in_ep"]): in_spans}, parts, g, truth, out_eps
+
+
+def run_frontend_case(lib_path):
+    from traceweaver_amd.predictor import TraceWeaverGPU
+
+    d = np.load([f for f in GOLDEN if "hotel_load100__frontend" in f][0])
+    in_parts, out_parts, graph, truth, out_eps = protocol_inputs(d)
+    pred = TraceWeaverGPU({}, {}, fit="sklearn", lib_path=lib_path)
+    np.random.seed(int(d["seed"]))  # executor.py seeds through create_cache_hits (transforms.py:155) for "frontend"
+    ret = pred.FindAssignments("MaxScoreBatchSubsetWithSkips", "frontend", in_parts, out_parts, False, [], truth, graph)
+    all_asg, all_topk, not_best, n_in, per_span, unassigned = ret
+    in_spans = list(in_parts.values())[0]
+    assert n_in == len(in_spans) == 1000
+    parent = np.array([[int(all_asg[ep][s.GetId()][1].rsplit("_", 1)[1]) if all_asg[ep][s.GetId()] != ("NA", "NA") else -1
+                        for s in in_spans] for ep in out_eps])
+    assert np.array_equal(parent, d["final_parent"])
+    assert not_best == int(d["not_best_count"]) and unassigned == int(d["cnt_unassigned"])
+    assert [per_span[s.GetId()] for s in in_spans] == d["per_span_candidates"].tolist()
+    for k, ep in enumerate(out_eps):
+        for i, s in enumerate(in_spans):
+            got = [int(x[1].rsplit("_", 1)[1]) for x in all_topk[ep][s.GetId()]]
+            want = [int(v) for v in d["final_topk"][k, i] if v >= 0]
+            assert got == want
+    return pred
+
+
+def test_end_to_end_reproduces_frozen_reference_run(emu_lib):
+    run_frontend_case(emu_lib)
+
+
+def test_skip_mode_is_rejected_loudly(emu_lib):
+    from traceweaver_amd.predictor import TraceWeaverGPU
+
+    d = np.load([f for f in GOLDEN if "hotel_load100__search" in f][0])
+    in_parts, out_parts, graph, truth, out_eps = protocol_inputs(d)
+    out_parts[out_eps[0]].pop()
+    with pytest.raises(NotImplementedError):
+        TraceWeaverGPU({}, {}, lib_path=emu_lib).FindAssignments("MaxScoreBatchSubsetWithSkips", "search", in_parts, out_parts,
+                                                                  False, [], truth, graph)
+
+
+def test_device_refit_mode(emu_lib):
+    """fit="device": same protocol, deterministic EM on the device between the passes."""
+    from traceweaver_amd.predictor import TraceWeaverGPU
+
+    d = np.load([f for f in GOLDEN if "hotel_load100__search" in f][0])
+    in_parts, out_parts, graph, truth, out_eps = protocol_inputs(d)
+    ret = TraceWeaverGPU({}, {}, fit="device", lib_path=emu_lib).FindAssignments(
+        "MaxScoreBatchSubsetWithSkips", "search", in_parts, out_parts, False, [], truth, graph)
+    in_spans = list(in_parts.values())[0]
+    ok = sum(all(ret[0][ep][s.GetId()] == truth[ep][s.GetId()] for ep in out_eps) for s in in_spans)
+    assert ok / len(in_spans) > 0.97    # the frozen reference run scored 0.991 on this service
+
+
+@pytest.mark.gpu
+def test_end_to_end_on_gpu():
+    run_frontend_case(None)

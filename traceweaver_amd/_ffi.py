@@ -39,7 +39,7 @@ class Results(ctypes.Structure):
 
 
 EXPORTS = ["tw_create", "tw_destroy", "tw_last_error", "tw_load_batch", "tw_run_pass1", "tw_get_gaps",
-           "tw_set_mixtures", "tw_run_pass2", "tw_get_results", "tw_get_gauss_params", "tw_get_timing",
+           "tw_set_mixtures", "tw_fit_mixtures", "tw_get_mixtures", "tw_run_pass2", "tw_get_results", "tw_get_gauss_params", "tw_get_timing",
            "tw_assign_service"]
 
 
@@ -61,6 +61,8 @@ def load(path=None):
     lib.tw_get_gaps.argtypes = [vp, vp]
     lib.tw_set_mixtures.argtypes = [vp, vp, vp]
     lib.tw_run_pass2.argtypes = [vp]
+    lib.tw_fit_mixtures.argtypes = [vp]
+    lib.tw_get_mixtures.argtypes = [vp, vp, vp]
     lib.tw_get_results.argtypes = [vp, ctypes.c_int, ctypes.POINTER(Results)]
     lib.tw_get_gauss_params.argtypes = [vp, vp]
     lib.tw_get_timing.argtypes = [vp, vp, ctypes.c_int32]

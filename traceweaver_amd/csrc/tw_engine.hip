@@ -13,6 +13,7 @@
 
 #include "traceweaver_amd.h"
 #include "tw_kernels.h"
+#include "tw_fit.h"
 
 using namespace tw;
 
@@ -51,6 +52,12 @@ struct tw_engine {
     double* mix_p_dev = nullptr;
     int32_t* mix_n_dev = nullptr;
     double* mix_c_dev = nullptr;
+    double* gaps_sorted = nullptr;
+    double* fit_models = nullptr;
+    int32_t* slot_unit = nullptr;
+    uint32_t* seg_gap = nullptr;
+    int64_t n_gap_rows = 0;
+    double fit_ms = 0.0;
     hipEvent_t ev[EV_COUNT] = {};
     double ms[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -294,6 +301,18 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     }
     const int64_t n_in_total = b->unit_in_off[b->n_units], n_out_total = b->ep_off[epi];
     if (n_in_total >= (1ll << 31) || n_out_total >= (1ll << 31)) return fail(e, TW_ERR_ARG, "batch exceeds 2^31 spans");
+    if (gaps >= (1ll << 31)) return fail(e, TW_ERR_ARG, "batch too large: sum of nslot*n_in must stay below 2^31");
+    std::vector<int32_t> slot_unit_h;
+    std::vector<uint32_t> seg_gap_h;
+    for (int u = 0; u < b->n_units; u++) {
+        const UnitDev& U = e->units[(size_t)u];
+        for (int q = 0; q < U.nslot; q++) {
+            slot_unit_h.push_back(u);
+            seg_gap_h.push_back((uint32_t)(e->gs_off_h[(size_t)u] + (int64_t)q * U.n_in));
+        }
+    }
+    seg_gap_h.push_back((uint32_t)gaps);
+    e->n_gap_rows = (int64_t)slot_unit_h.size();
     seg_in[(size_t)b->n_units] = (uint32_t)n_in_total;
     seg_out.push_back((uint32_t)n_out_total);
     e->n_seg_out = (int)seg_out.size() - 1;
@@ -330,6 +349,8 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.heavy_count, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
+    ALLOC(e->gaps_sorted, gaps); ALLOC(e->fit_models, slots * kMaxComp * kModelStride);
+    ALLOC(e->slot_unit, slots); ALLOC(e->seg_gap, (int64_t)seg_gap_h.size());
 #undef ALLOC
     P.units = d_units; P.tiles = d_tiles;
     P.in_start = d_is; P.in_end = d_ie; P.out_start = d_os; P.out_end = d_oe;
@@ -346,6 +367,8 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipMemcpyAsync(d_gs, e->gs_off_h.data(), sizeof(int64_t) * e->gs_off_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->seg_in, seg_in.data(), sizeof(uint32_t) * seg_in.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->seg_out, seg_out.data(), sizeof(uint32_t) * seg_out.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->slot_unit, slot_unit_h.data(), sizeof(int32_t) * slot_unit_h.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->seg_gap, seg_gap_h.data(), sizeof(uint32_t) * seg_gap_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemsetAsync(P.pc, 0, (size_t)n_in_total + 1, e->stream));
     HIPCHK(hipMemsetAsync(e->mix_n_dev, 0, sizeof(int32_t) * std::max<int64_t>(slots, 1), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -384,6 +407,50 @@ int tw_set_mixtures(tw_engine* e, const int32_t* mix_n, const double* mix_p) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     e->state = ST_MIX;
+    return TW_OK;
+}
+
+int tw_fit_mixtures(tw_engine* e) {
+    if (e == nullptr) return TW_ERR_ARG;
+    if (e->state != ST_PASS1) return fail(e, TW_ERR_STATE, "tw_fit_mixtures is valid right after tw_run_pass1");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
+    size_t bytes = 0;
+    const unsigned size = (unsigned)e->n_gaps, nseg = (unsigned)e->n_gap_rows;
+    HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap + 1, 0, 64, e->stream));
+    if (bytes > e->sort_tmp_bytes) {
+        void* q = nullptr;
+        HIPCHK(hipMalloc(&q, bytes));
+        e->allocs.push_back(q);
+        e->sort_tmp = q;
+        e->sort_tmp_bytes = bytes;
+    }
+    bytes = e->sort_tmp_bytes;
+    HIPCHK(rocprim::segmented_radix_sort_keys(e->sort_tmp, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap + 1, 0, 64, e->stream));
+    FitDev F{};
+    F.units = e->P.units; F.n_units = e->P.n_units; F.n_slots = e->n_slots; F.sorted = e->gaps_sorted;
+    F.gs_off = e->P.gs_off; F.slot_unit = e->slot_unit; F.models = e->fit_models; F.mix_n = e->mix_n_dev; F.mix_p = e->mix_p_dev;
+    hipLaunchKernelGGL(k_fit_em, dim3((unsigned)(e->n_slots * kMaxComp)), dim3(std::min(e->coop, kFitThreads)), 0, e->stream, F);
+    hipLaunchKernelGGL(k_fit_select, dim3((unsigned)((e->n_slots + 63) / 64)), dim3(64), 0, e->stream, F);
+    const int64_t total = e->n_slots * kMaxComp;
+    hipLaunchKernelGGL(k_mix_consts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, (const double*)e->mix_p_dev, e->mix_c_dev, total);
+    HIPCHK(hipEventRecord(e->ev[EV_END], e->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    float f = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, e->ev[EV_BEGIN], e->ev[EV_END]));
+    e->fit_ms = f;
+    e->state = ST_MIX;
+    return TW_OK;
+}
+
+int tw_get_mixtures(tw_engine* e, int32_t* mix_n, double* mix_p) {
+    if (e == nullptr || mix_n == nullptr || mix_p == nullptr) return TW_ERR_ARG;
+    if (e->state < ST_MIX) return fail(e, TW_ERR_STATE, "no mixtures resident (tw_fit_mixtures / tw_set_mixtures first)");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(mix_n, e->mix_n_dev, sizeof(int32_t) * e->n_slots, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(mix_p, e->mix_p_dev, sizeof(double) * e->n_slots * kMaxComp * 3, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return TW_OK;
 }
 
@@ -432,6 +499,7 @@ int tw_get_gauss_params(tw_engine* e, double* gauss) {
 int tw_get_timing(tw_engine* e, double* ms, int32_t n) {
     if (e == nullptr || ms == nullptr) return TW_ERR_ARG;
     for (int i = 0; i < n && i < 6; i++) ms[i] = e->ms[i];
+    if (n > 6) ms[6] = e->fit_ms;
     return TW_OK;
 }
 

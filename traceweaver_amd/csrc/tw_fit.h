@@ -1,0 +1,191 @@
+// tw_fit.h -- device-side refit of the per-edge delay mixtures between the two passes
+// (ComputeEpPairDistParams5, traceweaver_v3.py:764-786).
+//
+// The reference fits, per scored edge, 1..min(5, #unique) one-dimensional Gaussian mixtures with
+// scikit-learn (k-means++ initialisation drawn from numpy's *unseeded* global RNG), keeps the
+// component count with the smallest BIC and refits it.  That procedure is not reproducible run to run
+// (SURVEY.md hazard H9: +-1 pp end-to-end accuracy between identical runs), so there is no bit-level
+// target to hit.  The device refit keeps the model family, the EM iteration, its stopping rule
+// (|delta mean log-likelihood| < 1e-3, <= 100 iterations, reg_covar 1e-6) and the BIC selection, and
+// replaces the random initialisation by a deterministic one: the k equal-count buckets of the sorted
+// samples.  One workgroup runs one (edge, k) fit start to finish, so every reduction has a fixed
+// order and the result is a pure function of the samples.
+//
+// traceweaver_amd/gmm.py::fit_edge_sklearn keeps the reference procedure for comparison; pass 2 is
+// bit-exact against the oracle for *any* mixture table (tests feed the fitted tables to both).
+#pragma once
+#include "tw_device.h"
+
+namespace tw {
+
+constexpr int kFitThreads = 256;
+constexpr int kFitStats = 3 * kMaxComp + 1;  // per component: nk, sum r*(x-c), sum r*(x-c)^2; + log-likelihood
+constexpr int kFitMaxIter = 100;
+constexpr double kFitTol = 1.0e-3;
+constexpr double kFitRegCovar = 1.0e-6;
+constexpr int kModelStride = 1 + 3 * kMaxComp;  // bic, w[5], mu[5], var[5]
+
+struct FitDev {
+    const UnitDev* units;
+    int32_t n_units;
+    int64_t n_slots;
+    const double* sorted;   // gap rows sorted ascending, NaN (dropped) last; row q of unit u at gs_off[u] + q*n_in
+    const int64_t* gs_off;
+    const int32_t* slot_unit;  // [n_slots] owning unit
+    double* models;         // [n_slots][kMaxComp][kModelStride]
+    int32_t* mix_n;         // [n_slots]
+    double* mix_p;          // [n_slots][kMaxComp][3] weight, mean, precision_cholesky
+};
+
+// deterministic block reduction of `cnt` doubles per thread (fixed tree, result in sh[0..cnt))
+__device__ inline void block_reduce(double* vals, int cnt, double* sh) {
+    const int t = threadIdx.x, n = blockDim.x;
+    for (int c = 0; c < cnt; c++) sh[c * kFitThreads + t] = vals[c];
+    __syncthreads();
+    int len = n;
+    while (len > 1) {
+        const int half = (len + 1) >> 1;
+        if (t < len - half)
+            for (int c = 0; c < cnt; c++) sh[c * kFitThreads + t] += sh[c * kFitThreads + t + half];
+        __syncthreads();
+        len = half;
+    }
+    for (int c = 0; c < cnt; c++) vals[c] = sh[c * kFitThreads];
+    __syncthreads();
+}
+
+__global__ void k_fit_em(FitDev F) {
+    __shared__ double sh[kFitStats * kFitThreads];
+    __shared__ double par[3 * kMaxComp];  // w, mu, var
+    __shared__ int flag;
+    const int64_t q = blockIdx.x / kMaxComp;
+    const int k = (int)(blockIdx.x % kMaxComp) + 1;
+    const int t = threadIdx.x, nt = blockDim.x;
+    const UnitDev& U = F.units[F.slot_unit[q]];
+    const int n_all = U.n_in;
+    const double* x = F.sorted + F.gs_off[F.slot_unit[q]] + (q - U.slot_off) * (int64_t)n_all;
+    double* model = F.models + (q * kMaxComp + (k - 1)) * kModelStride;
+    double v[kFitStats];
+    // valid samples and distinct values (capped)
+    v[0] = 0.0; v[1] = 0.0;
+    for (int i = t; i < n_all; i += nt) {
+        const double xi = x[i];
+        if (xi != xi) continue;
+        v[0] += 1.0;
+        if (i == 0 || x[i - 1] != xi) v[1] += 1.0;
+    }
+    block_reduce(v, 2, sh);
+    const int n = (int)v[0];
+    const int uniq = (int)v[1];
+    if (n == 0 || k > uniq || k > kMaxComp) {
+        if (t == 0) model[0] = dinf();
+        return;
+    }
+    // initialisation: equal-count buckets of the sorted samples
+    for (int c = 0; c < 2 * kMaxComp; c++) v[c] = 0.0;
+    for (int i = t; i < n; i += nt) {
+        const int j = (int)(((int64_t)i * k) / n);
+        v[j] += 1.0;
+        v[kMaxComp + j] += x[i];
+    }
+    block_reduce(v, 2 * kMaxComp, sh);
+    if (t == 0)
+        for (int j = 0; j < k; j++) { par[j] = v[j] / (double)n; par[kMaxComp + j] = v[kMaxComp + j] / v[j]; }
+    __syncthreads();
+    for (int c = 0; c < kMaxComp; c++) v[c] = 0.0;
+    for (int i = t; i < n; i += nt) {
+        const int j = (int)(((int64_t)i * k) / n);
+        const double d = x[i] - par[kMaxComp + j];
+        v[j] += d * d;
+    }
+    block_reduce(v, kMaxComp, sh);
+    if (t == 0)
+        for (int j = 0; j < k; j++) par[2 * kMaxComp + j] = v[j] / (par[j] * (double)n) + kFitRegCovar;
+    __syncthreads();
+    // EM
+    double prev_lb = -dinf();
+    for (int iter = 0; iter <= kFitMaxIter; iter++) {
+        double lw[kMaxComp], mu[kMaxComp], iv[kMaxComp];
+        for (int j = 0; j < k; j++) {
+            mu[j] = par[kMaxComp + j];
+            iv[j] = 1.0 / par[2 * kMaxComp + j];
+            lw[j] = log(par[j]) - 0.5 * (kLog2Pi + log(par[2 * kMaxComp + j]));
+        }
+        for (int c = 0; c < kFitStats; c++) v[c] = 0.0;
+        for (int i = t; i < n; i += nt) {
+            const double xi = x[i];
+            double lp[kMaxComp], mx = -dinf();
+            for (int j = 0; j < k; j++) {
+                const double d = xi - mu[j];
+                lp[j] = lw[j] - 0.5 * d * d * iv[j];
+                if (lp[j] > mx) mx = lp[j];
+            }
+            double s = 0.0;
+            for (int j = 0; j < k; j++) { lp[j] = exp(lp[j] - mx); s += lp[j]; }
+            v[3 * kMaxComp] += mx + log(s);
+            const double inv = 1.0 / s;
+            for (int j = 0; j < k; j++) {
+                const double r = lp[j] * inv, d = xi - mu[j];
+                v[j] += r;
+                v[kMaxComp + j] += r * d;
+                v[2 * kMaxComp + j] += r * d * d;
+            }
+        }
+        block_reduce(v, kFitStats, sh);
+        const double lb = v[3 * kMaxComp] / (double)n;  // mean log-likelihood under the current parameters
+        // last round only evaluates the likelihood of the final parameters (sklearn's bic() re-scores)
+        const bool stop = (iter == kFitMaxIter) || (fabs(lb - prev_lb) < kFitTol);
+        if (stop) {
+            if (t == 0) {
+                model[0] = -2.0 * lb * (double)n + (double)(3 * k - 1) * log((double)n);
+                for (int j = 0; j < kMaxComp; j++) {
+                    model[1 + j] = j < k ? par[j] : 0.0;
+                    model[1 + kMaxComp + j] = j < k ? par[kMaxComp + j] : 0.0;
+                    model[1 + 2 * kMaxComp + j] = j < k ? par[2 * kMaxComp + j] : 1.0;
+                }
+            }
+            return;
+        }
+        prev_lb = lb;
+        __syncthreads();
+        if (t == 0) {  // M step (shifted moments: c = previous mean of the component)
+            for (int j = 0; j < k; j++) {
+                const double nk = v[j] + 10.0 * 2.220446049250313e-16;
+                const double dm = v[kMaxComp + j] / nk;
+                par[j] = nk / (double)n;
+                par[kMaxComp + j] = mu[j] + dm;
+                par[2 * kMaxComp + j] = v[2 * kMaxComp + j] / nk - dm * dm + kFitRegCovar;
+            }
+            double ws = 0.0;
+            for (int j = 0; j < k; j++) ws += par[j];
+            for (int j = 0; j < k; j++) par[j] /= ws;
+        }
+        __syncthreads();
+    }
+    (void)flag;
+}
+
+// smallest BIC wins (first minimum, like np.argmin over n = 1..5)
+__global__ void k_fit_select(FitDev F) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= F.n_slots) return;
+    int best = -1;
+    double bic = dinf();
+    for (int k = 0; k < kMaxComp; k++) {
+        const double b = F.models[(q * kMaxComp + k) * kModelStride];
+        if (b < bic) { bic = b; best = k; }
+    }
+    F.mix_n[q] = best + 1;
+    for (int j = 0; j < kMaxComp; j++) {
+        double w = 0.0, mu = 0.0, pc = 0.0;
+        if (best >= 0 && j <= best) {
+            const double* m = F.models + (q * kMaxComp + best) * kModelStride;
+            w = m[1 + j]; mu = m[1 + kMaxComp + j]; pc = 1.0 / sqrt(m[1 + 2 * kMaxComp + j]);
+        }
+        F.mix_p[(q * kMaxComp + j) * 3 + 0] = w;
+        F.mix_p[(q * kMaxComp + j) * 3 + 1] = mu;
+        F.mix_p[(q * kMaxComp + j) * 3 + 2] = pc;
+    }
+}
+
+}  // namespace tw

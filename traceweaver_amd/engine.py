@@ -125,6 +125,18 @@ class Engine(object):
             raise ValueError("mixture tables do not match the loaded batch")
         self._check(self._lib.tw_set_mixtures(self._h, _vp(n), _vp(p)))
 
+    def fit_mixtures(self):
+        """Device-side refit of every scored edge from the pass-1 gap samples (see csrc/tw_fit.h)."""
+        self._check(self._lib.tw_fit_mixtures(self._h))
+
+    def mixtures(self):
+        """Per unit (mix_n [nslot], mix_p [nslot, 5, 3]) currently resident on the device."""
+        n = np.empty(int(self._slot_off[-1]), dtype=np.int32)
+        p = np.empty((int(self._slot_off[-1]), _ffi.TW_MAX_COMP, 3), dtype=np.float64)
+        self._check(self._lib.tw_get_mixtures(self._h, _vp(n), _vp(p)))
+        return [(n[self._slot_off[k]:self._slot_off[k + 1]], p[self._slot_off[k]:self._slot_off[k + 1]])
+                for k in range(len(self.units))]
+
     def gauss_params(self):
         """Per unit: [nblk, nslot, 3] = mean, std, log(std used) of pass 1 (NaN for unscored slots)."""
         g = np.empty((int(self._gp_off[-1]), 3), dtype=np.float64)
@@ -171,6 +183,6 @@ class Engine(object):
 
     def timing(self):
         """ms of the last pass: total, enumerate kernel, select kernel, windows, claim+detect+repair, params."""
-        ms = np.zeros(6, dtype=np.float64)
-        self._check(self._lib.tw_get_timing(self._h, _vp(ms), 6))
-        return dict(zip(("pass", "enumerate", "select", "windows", "repair", "params"), ms.tolist()))
+        ms = np.zeros(7, dtype=np.float64)
+        self._check(self._lib.tw_get_timing(self._h, _vp(ms), 7))
+        return dict(zip(("pass", "enumerate", "select", "windows", "repair", "params", "fit"), ms.tolist()))

@@ -1,0 +1,168 @@
+"""`TraceWeaverGPU`: drop-in for the reference's TraceWeaverV3 predictor (predictor index 10,
+"MaxScoreBatchSubsetWithSkips", executor.py:899) on top of the HIP engine.
+
+Same constructor and the same `FindAssignments` signature / 6-tuple as
+algorithms/traceweaver_v3.py:1087-1229, so the executor can register
+
+    ("MaxScoreBatchSubsetWithSkips", TraceWeaverGPU(all_spans, all_processes))
+
+in its predictor table (executor.py:888-900) and everything downstream (accuracy, result pickles,
+plots) runs unchanged -- see INTEGRATION.md.  Spans are only read through `.start_mus`,
+`.duration_mus` and `.GetId()`; (trace_id, span_id) keys never reach the device.
+
+Only the no-skip mode of the reference is accelerated (every endpoint has exactly one outgoing span per
+incoming span; all BASELINE.json configs).  The cache-hit / skip experiments (exp2) raise
+NotImplementedError here rather than silently falling back to a CPU path.
+"""
+import numpy as np
+
+from . import gmm
+from .engine import Engine, UnitArrays
+
+NA = ("NA", "NA")
+
+
+def pack_unit(in_spans, out_span_partitions, out_eps, invocation_graph):
+    """SoA form of one FindAssignments call.  `out_eps` = topological order (traceweaver_v1.py:37-39)."""
+    E = len(out_eps)
+    n_in = len(in_spans)
+    in_start = np.fromiter((s.start_mus for s in in_spans), dtype=np.int64, count=n_in)
+    in_dur = np.fromiter((s.duration_mus for s in in_spans), dtype=np.int64, count=n_in)
+    out_off = np.zeros(E + 1, dtype=np.int64)
+    starts, ends = [], []
+    for k, ep in enumerate(out_eps):
+        spans = out_span_partitions[ep]
+        st = np.fromiter((s.start_mus for s in spans), dtype=np.int64, count=len(spans))
+        du = np.fromiter((s.duration_mus for s in spans), dtype=np.int64, count=len(spans))
+        starts.append(st)
+        ends.append(st + du)
+        out_off[k + 1] = out_off[k] + len(spans)
+    dag = np.zeros((E, E), dtype=np.uint8)
+    for a, p in enumerate(out_eps):
+        for b, q in enumerate(out_eps):
+            if invocation_graph.has_edge(p, q):
+                dag[a, b] = 1
+    keys = list(out_span_partitions.keys())  # networkx in_edges() order = FindOrder's insertion order (executor.py:223-236)
+    key_rank = np.array([keys.index(ep) for ep in out_eps], dtype=np.int32)
+    return UnitArrays(in_start, in_start + in_dur, out_off, np.concatenate(starts), np.concatenate(ends), dag, key_rank)
+
+
+def reference_fit_order(unit, partition_keys_rank):
+    """Slots in the order ComputeEpPairDistParams5 fits them (traceweaver_v3.py:800-818): for every
+    endpoint in partition-key order: root edge (if no predecessor), primary in-edges in in_edges() order,
+    closing edge."""
+    E = unit.E
+    order = []
+    for e in sorted(range(E), key=lambda k: partition_keys_rank[k]):
+        preds = sorted([p for p in range(E) if unit.dag[p, e]], key=lambda k: partition_keys_rank[k])
+        if not preds:
+            order.append(e)
+        for p in preds:
+            two_hop = any(unit.dag[p, m] and unit.dag[m, e] for m in range(E) if m not in (p, e))
+            if not two_hop:
+                order.append(E + p * E + e)
+        order.append(E + E * E + e)
+    return order
+
+
+class TraceWeaverGPU(object):
+    def __init__(self, all_spans, all_processes, device=0, fit="sklearn", replay_true_fit=True, lib_path=None):
+        """fit = "sklearn": the reference's scikit-learn refit between the passes (host), in the reference's
+        call order; with `replay_true_fit` the (discarded) fits on the *true* assignments are replayed too,
+        because they advance numpy's global RNG (traceweaver_v3.py:796-818) -- a seeded run then reproduces
+        a seeded reference run.  fit = "device": deterministic EM on the GPU (csrc/tw_fit.h)."""
+        self.all_spans = all_spans
+        self.all_processes = all_processes
+        self.fit = fit
+        self.replay_true_fit = replay_true_fit
+        self._engine = Engine(device, lib_path=lib_path)
+        self.last_timing = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _host_refit(self, unit, gaps_pred, true_parent):
+        order = reference_fit_order(unit, unit.key_rank)
+        if self.replay_true_fit and true_parent is not None:
+            for q in order:  # results are overwritten by the second round, exactly like the reference
+                row = self._gap_row(unit, true_parent, q)
+                if len(row):
+                    gmm.fit_edge_sklearn(row)
+        mix_n = np.zeros(unit.nslot, dtype=np.int32)
+        mix_p = np.zeros((unit.nslot, gmm.MAX_COMP, 3))
+        for q in order:
+            row = gaps_pred[q]
+            row = row[~np.isnan(row)]
+            mix_n[q], mix_p[q] = gmm.fit_edge_sklearn(row)
+        return mix_n, mix_p
+
+    @staticmethod
+    def _gap_row(unit, parent, q):
+        """Host-side gap samples for an arbitrary assignment (only used to replay the true-assignment fits)."""
+        E, n = unit.E, unit.n_in
+        ok = parent[0] >= 0
+        if q < E:
+            e = q
+            return (unit.out_start[unit.out_off[e] + parent[e][ok]] - unit.in_start[ok]).astype(np.float64)
+        if q < E + E * E:
+            p, e = divmod(q - E, E)
+            return (unit.out_start[unit.out_off[e] + parent[e][ok]] - unit.out_end[unit.out_off[p] + parent[p][ok]]).astype(np.float64)
+        e = q - E - E * E
+        return (unit.in_end[ok] - unit.out_end[unit.out_off[e] + parent[e][ok]]).astype(np.float64)
+
+    # ------------------------------------------------------------------------------------------
+    def FindAssignments(self, method, process, in_span_partitions, out_span_partitions, parallel, instrumented_hops,
+                        true_assignments, invocation_graph, true_skips=False, true_dist=False):
+        assert len(in_span_partitions) == 1                       # traceweaver_v3.py:1088
+        if parallel or true_skips or true_dist or instrumented_hops:
+            raise NotImplementedError("TraceWeaverGPU accelerates predictor 10 (MaxScoreBatchSubsetWithSkips) only")
+        import networkx as nx
+
+        in_ep, in_spans = list(in_span_partitions.items())[0]
+        out_eps = list(nx.topological_sort(invocation_graph))     # traceweaver_v1.py:39
+        n_in = len(in_spans)
+        for ep in out_eps:
+            if len(out_span_partitions[ep]) != n_in:
+                raise NotImplementedError(
+                    "skip mode (endpoint %r has %d spans for %d incoming spans, traceweaver_v3.py:972) is not "
+                    "accelerated; use the reference predictor for the cache-hit experiments" % (ep, len(out_span_partitions[ep]), n_in))
+        unit = pack_unit(in_spans, out_span_partitions, out_eps, invocation_graph)
+        in_ids = [s.GetId() for s in in_spans]
+        out_ids = [[s.GetId() for s in out_span_partitions[ep]] for ep in out_eps]
+        true_parent = None
+        if self.fit == "sklearn" and self.replay_true_fit and true_assignments is not None:
+            true_parent = np.full((unit.E, n_in), -1, dtype=np.int64)
+            for k, ep in enumerate(out_eps):
+                pos = {sid: j for j, sid in enumerate(out_ids[k])}
+                for i, sid in enumerate(in_ids):
+                    true_parent[k, i] = pos.get(true_assignments[ep].get(sid), -1)
+            true_parent[:, (true_parent < 0).any(axis=0)] = -1
+
+        eng = self._engine
+        eng.load([unit])
+        eng.run_pass1()
+        t1 = eng.timing()
+        r1 = eng.results(1, fields=("leaves",))[0]
+        if self.fit == "device":
+            eng.fit_mixtures()
+        else:
+            mix_n, mix_p = self._host_refit(unit, eng.gaps()[0], true_parent)
+            eng.set_mixtures([mix_n], [mix_p])
+        eng.run_pass2()
+        self.last_timing = {"pass1": t1, "pass2": eng.timing()}
+        r2 = eng.results(2)[0]
+
+        all_assignments, all_topk_assignments = {}, {}
+        for k, ep in enumerate(out_eps):
+            ids = out_ids[k]
+            par = r2["parent"][k]
+            all_assignments[ep] = {in_ids[i]: (ids[par[i]] if par[i] >= 0 else NA) for i in range(n_in)}
+            tk = r2["topk_idx"][:, k, :]
+            all_topk_assignments[ep] = {in_ids[i]: [ids[tk[j, i]] for j in range(int(r2["topk_n"][i]))] for i in range(n_in)}
+        per_span_candidates = {}
+        for ep in out_span_partitions.keys():                     # traceweaver_v3.py:1096-1098
+            for key in true_assignments[ep].keys():
+                per_span_candidates[key] = 0
+        leaves = r1["leaves"] + r2["leaves"]
+        for i, sid in enumerate(in_ids):
+            per_span_candidates[sid] = int(leaves[i])
+        return (all_assignments, all_topk_assignments, r2["not_best_count"], n_in, per_span_candidates,
+                r2["cnt_unassigned"])
