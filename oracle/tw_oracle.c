@@ -704,14 +704,14 @@ static double match_bound(mwis_comp *c, int d) {
     return best;
 }
 
-#define TWO_SMALL_COMP 5        /* components up to this size are searched with the plain bound only */
-#define TWO_NODE_BUDGET 20000   /* search nodes per component; beyond it the incumbent is returned */
+#define TWO_PLAIN_NODES 256     /* the matching relaxation is consulted from this many search nodes on */
+#define TWO_NODE_BUDGET 5000    /* search nodes per component; beyond it the incumbent is returned */
 static void mwis_dfs(mwis_comp *c, int d, double acc) {
     if (c->nodes >= TWO_NODE_BUDGET) { c->exhausted = 1; return; }
     c->nodes++;
     if (d == c->m) { if (acc > c->best_w) { c->best_w = acc; memcpy(c->best, c->cur, sizeof(int) * (size_t)c->m); } return; }
     if (acc + c->ub[d] <= c->best_w) return;
-    if (c->m > TWO_SMALL_COMP && acc + match_bound(c, d) <= c->best_w) return;
+    if (c->nodes > TWO_PLAIN_NODES && acc + match_bound(c, d) <= c->best_w) return;
     for (int j = 0; j < c->n[d]; j++) {
         int ok = 1;
         for (int q = 0; q < d && ok; q++) if (c->cur[q] >= 0 && shares(c->E, c->idx[q][c->cur[q]], c->idx[d][j])) ok = 0;
@@ -729,8 +729,8 @@ static void mwis_dfs(mwis_comp *c, int d, double acc) {
  *   components of the in-span conflict relation; each component is searched depth-first over its
  *   in-spans in index order, candidates in list order then "none", sums accumulated left to right,
  *   a subtree is cut when acc + upper bound <= best (upper bound = sum of the remaining in-spans'
- *   best weights; for components of more than TWO_SMALL_COMP in-spans additionally the matching
- *   relaxation above), and only strict improvements replace the incumbent.  The answer is the first
+ *   best weights; once the component's search has visited TWO_PLAIN_NODES nodes additionally the
+ *   matching relaxation above), and only strict improvements replace the incumbent.  The answer is the first
  *   optimal selection in that depth-first order; it does not depend on the bounds.  A component whose
  *   search exceeds TWO_NODE_BUDGET nodes returns its incumbent and is reported (stats[4]).
  *   chosen[i] = candidate index or -1. */

@@ -98,6 +98,9 @@ struct Dev {
     int64_t* unit_stats;    // [n_units][8]
     int32_t* heavy_count;   // windows deferred to the large-component selection kernel
     int32_t *heavy_unit, *heavy_win;
+    int32_t* heavy_in_count;  // [kMaxEp+1] incoming spans deferred to k_enumerate_heavy, per endpoint count E
+    int32_t heavy_in_off[kMaxEp + 2];  // class offsets into heavy_in_unit / heavy_in_idx
+    int32_t *heavy_in_unit, *heavy_in_idx;
     int32_t* err;           // first error raised by a kernel (tw_status)
 };
 

@@ -55,6 +55,8 @@ struct tw_engine {
     double* gaps_sorted = nullptr;
     double* fit_models = nullptr;
     int32_t* slot_unit = nullptr;
+    int32_t* tile_ids = nullptr;            // tiles grouped by the unit's endpoint count
+    int32_t tile_cls_off[kMaxEp + 2] = {};  // class E owns tile_ids[tile_cls_off[E] .. tile_cls_off[E+1])
     uint32_t* seg_gap = nullptr;
     int64_t n_gap_rows = 0;
     double fit_ms = 0.0;
@@ -111,6 +113,18 @@ int run_scan(tw_engine* e, typename Tr::T* agg) {
     return TW_OK;
 }
 
+template <int E>
+void launch_enumerate(tw_engine* e, int pass) {
+    const Dev& P = e->P;
+    const int nt = e->tile_cls_off[E + 1] - e->tile_cls_off[E];
+    if (nt == 0) return;
+    hipLaunchKernelGGL((k_enumerate_light<E>), dim3(nt), dim3(e->tile), 0, e->stream, P, pass,
+                       (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
+    const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
+    const int grid = std::min(cap, 8192);
+    hipLaunchKernelGGL((k_enumerate_heavy<E>), dim3(grid), dim3(std::min(e->coop, kHeavyThreads)), 0, e->stream, P, pass);
+}
+
 int sort_ends(tw_engine* e) {
     const Dev& P = e->P;
     for (int which = 0; which < 2; which++) {
@@ -151,7 +165,9 @@ int run_pass(tw_engine* e, int pass) {
     }
     HIPCHK(hipEventRecord(e->ev[EV_PARAMS], e->stream));
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
-    hipLaunchKernelGGL(k_enumerate, tiles, tb, 0, e->stream, P, pass);
+    HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
+    launch_enumerate<1>(e, pass); launch_enumerate<2>(e, pass); launch_enumerate<3>(e, pass); launch_enumerate<4>(e, pass);
+    launch_enumerate<5>(e, pass); launch_enumerate<6>(e, pass); launch_enumerate<7>(e, pass); launch_enumerate<8>(e, pass);
     HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
     if (pass == 1) {
         int rc = run_scan<ScanMaxEnd>(e, e->agg_pair);
@@ -168,7 +184,7 @@ int run_pass(tw_engine* e, int pass) {
     }
     HIPCHK(hipEventRecord(e->ev[EV_WIN], e->stream));
     hipLaunchKernelGGL(k_select, tiles, tb, 0, e->stream, P);
-    hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)((P.n_in_total / 6 + 64) / 64)), dim3(64), 0, e->stream, P);
+    hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096)), dim3(std::min(e->coop, 64)), 0, e->stream, P);
     HIPCHK(hipEventRecord(e->ev[EV_SEL], e->stream));
     hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P);
     hipLaunchKernelGGL(k_detect, tiles, tb, 0, e->stream, P);
@@ -299,6 +315,17 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         epi += E;
         dagi += E * E;
     }
+    std::vector<int32_t> tile_ids_h;
+    int32_t heavy_off_h[kMaxEp + 2] = {};
+    for (int cls = 0; cls <= kMaxEp; cls++) {
+        e->tile_cls_off[cls] = (int32_t)tile_ids_h.size();
+        heavy_off_h[cls + 1] = heavy_off_h[cls];
+        for (size_t tix = 0; tix < e->tiles.size(); tix++)
+            if (e->units[(size_t)e->tiles[tix].unit].E == cls) tile_ids_h.push_back((int32_t)tix);
+        for (int u = 0; u < b->n_units; u++)
+            if (e->units[(size_t)u].E == cls) heavy_off_h[cls + 1] += e->units[(size_t)u].n_in;
+    }
+    e->tile_cls_off[kMaxEp + 1] = (int32_t)tile_ids_h.size();
     const int64_t n_in_total = b->unit_in_off[b->n_units], n_out_total = b->ep_off[epi];
     if (n_in_total >= (1ll << 31) || n_out_total >= (1ll << 31)) return fail(e, TW_ERR_ARG, "batch exceeds 2^31 spans");
     if (gaps >= (1ll << 31)) return fail(e, TW_ERR_ARG, "batch too large: sum of nslot*n_in must stay below 2^31");
@@ -346,6 +373,9 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.owner, n_out_total);
     ALLOC(P.gaps, gaps);
     ALLOC(P.unit_stats, (int64_t)P.n_units * 8); ALLOC(P.err, 1);
+    ALLOC(e->tile_ids, (int64_t)tile_ids_h.size());
+    ALLOC(P.heavy_in_count, kMaxEp + 1); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
+    for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
     ALLOC(P.heavy_count, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
@@ -367,6 +397,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipMemcpyAsync(d_gs, e->gs_off_h.data(), sizeof(int64_t) * e->gs_off_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->seg_in, seg_in.data(), sizeof(uint32_t) * seg_in.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->seg_out, seg_out.data(), sizeof(uint32_t) * seg_out.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->tile_ids, tile_ids_h.data(), sizeof(int32_t) * tile_ids_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->slot_unit, slot_unit_h.data(), sizeof(int32_t) * slot_unit_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->seg_gap, seg_gap_h.data(), sizeof(uint32_t) * seg_gap_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemsetAsync(P.pc, 0, (size_t)n_in_total + 1, e->stream));

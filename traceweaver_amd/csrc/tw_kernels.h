@@ -3,7 +3,8 @@
 // Kernel map (reference function -> kernel), paths under
 // /root/reference/src/trace_reconstructor/ports/python/algorithms/:
 //   k_block_params      ComputeEpPairDistParams3            traceweaver_v3.py:580-646
-//   k_enumerate         FindCutoffs + DfsTraverseX/3 + ScoreAssignmentAsPerInvocationGraph + heap top-5
+//   k_enumerate_light / k_enumerate_heavy
+//                       FindCutoffs + DfsTraverseX/3 + ScoreAssignmentAsPerInvocationGraph + heap top-5
 //                                                           traceweaver_v3.py:182-351, traceweaver_v1.py:259-361
 //   k_scan_* / k_perfect_cut / k_window_flags / k_window_index
 //                       CreateWindows2 + PerfectCut         traceweaver_v3.py:1020-1078
@@ -34,6 +35,41 @@ __device__ __forceinline__ int upper_bound_i64(const int64_t* a, int n, int64_t 
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (a[mid] <= t) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Galloping variants: spans are rank-aligned in no-skip mode (n_out == n_in, both sorted by start), so the
+// answer lies within a few positions of the incoming span's own rank.  kUpper: first a[x] > t, else >= t.
+template <bool kUpper>
+__device__ __forceinline__ int bound_near(const int64_t* a, int n, int64_t t, int g) {
+    auto before = [&](int x) { return kUpper ? a[x] <= t : a[x] < t; };  // x lies strictly before the answer
+    g = g < 0 ? 0 : (g > n ? n : g);
+    int lo, hi;
+    if (g >= n || !before(g)) {  // answer <= g
+        hi = g;
+        int step = 1;
+        while (true) {
+            lo = hi - step;
+            if (lo < 0) { lo = 0; break; }
+            if (before(lo)) { lo = lo + 1; break; }
+            hi = lo;
+            step <<= 1;
+        }
+    } else {  // answer > g
+        lo = g + 1;
+        int step = 1;
+        while (true) {
+            hi = lo + step - 1;
+            if (hi >= n) { hi = n; break; }
+            if (!before(hi)) break;
+            lo = hi + 1;
+            step <<= 1;
+        }
+    }
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (before(mid)) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
@@ -169,7 +205,7 @@ struct Enumerator {
 
     // FindCutoffs on the full lists (traceweaver_v3.py:182-217): lo = bisect_left(start >= in.start),
     // hi = bisect_right(start <= min(in.end, start of every successor's hi span)) - 1, reverse topo order.
-    __device__ bool cutoffs() {
+    __device__ bool cutoffs(int guess) {
 #pragma unroll
         for (int e = E - 1; e >= 0; e--) {
             const int n = (int)(U.ep_off[e + 1] - U.ep_off[e]);
@@ -182,8 +218,8 @@ struct Enumerator {
                 const int64_t st = os[f][anchor];
                 if (st < t) t = st;
             }
-            lo[e] = lower_bound_i64(os[e], n, in_start);
-            hi[e] = upper_bound_i64(os[e], n, t) - 1;
+            lo[e] = bound_near<false>(os[e], n, in_start, guess);
+            hi[e] = bound_near<true>(os[e], n, t, lo[e]) - 1;
         }
         return true;
     }
@@ -344,16 +380,19 @@ __device__ void setup_enumerator(Enumerator<E>& en, const Dev& P, const UnitDev&
 
 // Speculative enumeration on all spans: this *is* top_k_2 (traceweaver_v3.py:1185) and equals top_k
 // (traceweaver_v3.py:1182) for every span none of whose candidates was consumed by an earlier window.
+//
+// Two tiers.  k_enumerate_light: one thread per incoming span computes the cutoffs and, when the
+// candidate product prod_e (hi_e - lo_e + 1) is small, enumerates it on the spot (mean 1.5-3 tuples on
+// the reference corpora).  Spans with a larger product go to a work list and are enumerated by
+// k_enumerate_heavy, one wavefront per span: the wavefront walks the first E-2 endpoints together and
+// spreads the (x_{E-2}, x_{E-1}) grid over its lanes -- feasibility and the log-likelihood (the costly
+// part) run in parallel, the heap is then fed in enumeration order by lane 0 so that ties resolve
+// exactly as in the sequential reference.
+constexpr int kLightMax = 48;
+constexpr int kHeavyThreads = 64;
+
 template <int E>
-__device__ void enumerate_span(const Dev& P, const UnitDev& U, int i, int pass) {
-    Enumerator<E> en(P, U);
-    setup_enumerator<E>(en, P, U, i, pass);
-    en.cutoffs();
-    bool wide = false;
-#pragma unroll
-    for (int e = 0; e < E; e++) wide |= (en.hi[e] - en.lo[e] + 1 > 64 * kCandWords);
-    if (wide) { raise_err(P, TW_ERR_WINDOW_WIDTH); return; }
-    if (pass == 1) en.template dfs<true, true>(nullptr); else en.template dfs<true, false>(nullptr);
+__device__ void write_result(const Dev& P, const UnitDev& U, int i, int pass, const Enumerator<E>& en) {
     const int64_t g = U.in_off + i;
     P.tk_n[g] = en.nheap;
     P.leaves[g] = en.leaves;
@@ -373,21 +412,144 @@ __device__ void enumerate_span(const Dev& P, const UnitDev& U, int i, int pass) 
     }
 }
 
-__global__ void k_enumerate(Dev P, int pass) {
-    const int tile = xcd_tile(blockIdx.x, P.n_tiles);
+template <int E>
+__global__ void k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
+    const int tile = tile_ids[xcd_tile(blockIdx.x, n_tiles_e)];
     const TileDev T = P.tiles[tile];
     const UnitDev& U = P.units[T.unit];
     const int i = T.first + threadIdx.x;
     if (i >= U.n_in) return;
-    switch (U.E) {
-        case 1: enumerate_span<1>(P, U, i, pass); break;
-        case 2: enumerate_span<2>(P, U, i, pass); break;
-        case 3: enumerate_span<3>(P, U, i, pass); break;
-        case 4: enumerate_span<4>(P, U, i, pass); break;
-        case 5: enumerate_span<5>(P, U, i, pass); break;
-        case 6: enumerate_span<6>(P, U, i, pass); break;
-        case 7: enumerate_span<7>(P, U, i, pass); break;
-        case 8: enumerate_span<8>(P, U, i, pass); break;
+    Enumerator<E> en(P, U);
+    setup_enumerator<E>(en, P, U, i, pass);
+    en.cutoffs(i);
+    bool wide = false, empty = false;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int w = en.hi[e] - en.lo[e] + 1;
+        wide |= (w > 64 * kCandWords);
+        empty |= (w <= 0);
+    }
+    if (wide) { raise_err(P, TW_ERR_WINDOW_WIDTH); return; }
+    int64_t prod = empty ? 0 : 1;
+#pragma unroll
+    for (int e = 0; e < E; e++) if (prod > 0 && prod <= kLightMax) prod *= (en.hi[e] - en.lo[e] + 1);
+    if (prod > kLightMax) {
+        const int slot = atomicAdd(&P.heavy_in_count[E], 1);
+        P.heavy_in_unit[P.heavy_in_off[E] + slot] = T.unit;
+        P.heavy_in_idx[P.heavy_in_off[E] + slot] = i;
+        return;
+    }
+    if (pass == 1) en.template dfs<true, true>(nullptr); else en.template dfs<true, false>(nullptr);
+    write_result<E>(P, U, i, pass, en);
+}
+
+template <int E>
+__global__ void k_enumerate_heavy(Dev P, int pass) {
+    __shared__ double sc[kHeavyThreads];
+    __shared__ uint8_t fl[kHeavyThreads];
+    __shared__ unsigned long long sbits[kMaxEp][kCandWords];
+    constexpr int NP = E >= 2 ? E - 2 : 0;  // endpoints walked together; the remaining one or two are spread over the lanes
+    constexpr int eA = E >= 2 ? E - 2 : 0, eB = E - 1;
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int count = P.heavy_in_count[E];
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        const int unit = P.heavy_in_unit[P.heavy_in_off[E] + item], i = P.heavy_in_idx[P.heavy_in_off[E] + item];
+        const UnitDev& U = P.units[unit];
+        Enumerator<E> en(P, U);
+        setup_enumerator<E>(en, P, U, i, pass);
+        en.cutoffs(i);
+        en.nheap = 0;
+        en.leaves = 0;
+        for (int k = t; k < kMaxEp * kCandWords; k += nt) (&sbits[0][0])[k] = 0;
+        __syncthreads();
+        int32_t x[E];
+        int64_t xs[E], xe[E];
+        const int wA = E >= 2 ? en.hi[eA] - en.lo[eA] + 1 : 1, wB = en.hi[eB] - en.lo[eB] + 1;
+        const int G = wA * wB;
+        int d = 0;
+        if (NP > 0) x[0] = en.lo[0] - 1;
+        bool once = (NP == 0);
+        while (once || d >= 0) {
+            if (NP > 0) {  // next feasible prefix, every lane in lockstep (DfsTraverseX order)
+                int c = x[d] + 1;
+                bool found = false;
+                for (; c <= en.hi[d]; c++) {
+                    const int64_t st = en.os[d][c], e2 = en.oe[d][c];
+                    if (en.in_start > st || e2 > en.in_end) continue;
+                    bool ok = true;
+                    for (int p = 0; p < d; p++)
+                        if (((U.pred_mask[d] >> p) & 1) && xe[p] > st) { ok = false; break; }
+                    if (ok) { xs[d] = st; xe[d] = e2; found = true; break; }
+                }
+                if (!found) { d--; continue; }
+                x[d] = c;
+                if (d < NP - 1) { d++; x[d] = en.lo[d] - 1; continue; }
+            }
+            // the (x_eA, x_eB) grid of this prefix, kHeavyThreads tuples at a time, in enumeration order
+            bool any = false;
+            for (int base = 0; base < G; base += nt) {
+                const int g = base + t;
+                bool ok = g < G;
+                double score = 0.0;
+                if (ok) {
+                    const int a = g / wB, b = g - a * wB;
+                    if (E >= 2) {
+                        const int cA = en.lo[eA] + a;
+                        const int64_t st = en.os[eA][cA], e2 = en.oe[eA][cA];
+                        ok = !(en.in_start > st || e2 > en.in_end);
+                        for (int p = 0; p < eA && ok; p++)
+                            if (((U.pred_mask[eA] >> p) & 1) && xe[p] > st) ok = false;
+                        x[eA] = cA; xs[eA] = st; xe[eA] = e2;
+                    }
+                    if (ok) {
+                        const int cB = en.lo[eB] + b;
+                        const int64_t st = en.os[eB][cB], e2 = en.oe[eB][cB];
+                        ok = !(en.in_start > st || e2 > en.in_end);
+                        for (int p = 0; p < eB && ok; p++)
+                            if (((U.pred_mask[eB] >> p) & 1) && xe[p] > st) ok = false;
+                        x[eB] = cB; xs[eB] = st; xe[eB] = e2;
+                    }
+                    if (ok) {
+                        score = en.score(x, xs, xe);
+                        if (pass == 1) {
+                            if (E >= 2) { const int r = x[eA] - en.lo[eA]; atomicOr(&sbits[eA][r >> 6], 1ull << (r & 63)); }
+                            const int r = x[eB] - en.lo[eB];
+                            atomicOr(&sbits[eB][r >> 6], 1ull << (r & 63));
+                        }
+                    }
+                }
+                fl[t] = ok ? 1 : 0;
+                sc[t] = score;
+                __syncthreads();
+                if (t == 0) {
+                    const int lim = G - base < nt ? G - base : nt;
+                    for (int j = 0; j < lim; j++) {
+                        if (!fl[j]) continue;
+                        any = true;
+                        en.leaves++;
+                        Cand<E> cand;
+                        cand.score = sc[j];
+                        for (int e = 0; e < NP; e++) cand.idx[e] = x[e];
+                        const int gj = base + j, a = gj / wB;
+                        if (E >= 2) cand.idx[eA] = en.lo[eA] + a;
+                        cand.idx[eB] = en.lo[eB] + (gj - a * wB);
+                        en.push(cand);
+                    }
+                }
+                __syncthreads();
+            }
+            if (t == 0 && any && pass == 1)
+                for (int e = 0; e < NP; e++) { const int r = x[e] - en.lo[e]; sbits[e][r >> 6] |= 1ull << (r & 63); }
+            if (NP == 0) break;
+        }
+        __syncthreads();
+        if (t == 0) {
+            en.sort_desc();
+            for (int e = 0; e < E; e++)
+                for (int w = 0; w < kCandWords; w++) en.bits[e][w] = sbits[e][w];
+            write_result<E>(P, U, i, pass, en);
+        }
+        __syncthreads();
     }
 }
 
@@ -560,106 +722,31 @@ __device__ inline bool cands_share(const Dev& P, const UnitDev& U, int i, int a,
     return false;
 }
 
-// Upper bound for "component members d..cm-1 given the current partial selection": relax every
-// endpoint but e; what remains is a maximum-weight bipartite matching between the remaining spans and
-// the outgoing spans of endpoint e (edge weight = best still-compatible candidate using that span, an
-// incoming span may stay unmatched).  Hungarian algorithm with potentials; rows have <= kTopK finite
-// entries.  The bound is the minimum over the endpoints (exact for E = 1).
-constexpr int kSmallComp = 5;        // components up to this size use the plain bound only
-constexpr int kNodeBudget = 20000;   // search nodes per component; beyond it the incumbent is returned
+// Exact selection, canonical procedure (shared with the oracle so that exact ties resolve identically):
+//   node weight 10000 + score (traceweaver_v3.py:1260); nodes with weight <= 0 are never selected; the
+//   window is split into connected components of the span conflict relation; each component is searched
+//   depth-first over its spans in index order, candidates in list order then "none", sums accumulated
+//   left to right; a subtree is cut when acc + upper bound <= best; only strict improvements replace the
+//   incumbent.  The answer is the first optimal selection in that depth-first order and does not depend
+//   on the bound.  Upper bound: sum of the remaining spans' best weights; once a component's search has
+//   visited kPlainNodes nodes, additionally the matching relaxation: relax every endpoint but e -- what
+//   remains is a maximum-weight bipartite matching between the remaining spans and the outgoing spans of
+//   endpoint e (edge weight = best still-compatible candidate using that span, a span may stay
+//   unmatched), solved with the Hungarian algorithm; minimum over the endpoints (exact for E = 1).  A
+//   component whose search exceeds kNodeBudget nodes keeps its incumbent and the window is counted in
+//   unit_stats[4].
+//
+// Mapping: k_select runs one thread per window and finishes every window whose components all resolve
+// inside the plain phase (all of them on the reference corpora); the others are re-solved from scratch
+// by k_select_heavy, one workgroup per window, candidate data and the Hungarian state in LDS, the
+// column scans of the Hungarian algorithm spread over the lanes.
+constexpr int kPlainNodes = 256;
+constexpr int kNodeBudget = 5000;
 constexpr int kMaxRes = kMaxWin * kTopK;
+constexpr int kMaxCols = kMaxRes + kMaxWin + 1;
 
-struct MatchGraph {
-    int nrow;
-    uint8_t ndeg[kMaxWin];
-    uint8_t col[kMaxWin][kTopK];   // 1-based column ids
-    double cost[kMaxWin][kTopK];   // -weight
-};
-
-__device__ inline double hungarian_min_cost(const MatchGraph& g, int ncol_real) {
-    const double INF = 1.0e300;
-    const int n = g.nrow, m = ncol_real + n;  // column ncol_real + r is the dummy of row r (cost 0)
-    double u[kMaxWin + 1], v[kMaxRes + kMaxWin + 1], minv[kMaxRes + kMaxWin + 1];
-    int16_t p[kMaxRes + kMaxWin + 1], way[kMaxRes + kMaxWin + 1];
-    uint8_t used[kMaxRes + kMaxWin + 1];
-    for (int j = 0; j <= m; j++) { v[j] = 0.0; p[j] = 0; }
-    for (int i = 0; i <= n; i++) u[i] = 0.0;
-    for (int i = 1; i <= n; i++) {
-        p[0] = (int16_t)i;
-        int j0 = 0;
-        for (int j = 0; j <= m; j++) { minv[j] = INF; used[j] = 0; way[j] = 0; }
-        do {
-            used[j0] = 1;
-            const int i0 = p[j0];
-            int j1 = 0;
-            double delta = INF;
-            const int deg = g.ndeg[i0 - 1];
-            for (int t = 0; t <= deg; t++) {
-                const int j = t < deg ? g.col[i0 - 1][t] : ncol_real + i0;
-                const double a = t < deg ? g.cost[i0 - 1][t] : 0.0;
-                if (used[j]) continue;
-                const double cur = a - u[i0] - v[j];
-                if (cur < minv[j]) { minv[j] = cur; way[j] = (int16_t)j0; }
-            }
-            for (int j = 1; j <= m; j++) if (!used[j] && minv[j] < delta) { delta = minv[j]; j1 = j; }
-            for (int j = 0; j <= m; j++) {
-                if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
-                else if (minv[j] < INF) minv[j] -= delta;
-            }
-            j0 = j1;
-        } while (p[j0] != 0);
-        do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
-    }
-    return -v[0];
-}
-
-__device__ inline double match_bound(const Dev& P, const UnitDev& U, int first, const uint8_t* mem, int cm, int d,
-                                     const int8_t* cur, const uint8_t* ncand) {
-    double best = dinf();
-    for (int e = 0; e < U.E; e++) {
-        MatchGraph g;
-        int32_t res[kMaxRes];
-        int nres = 0;
-        g.nrow = cm - d;
-        for (int r = 0; r < g.nrow; r++) {
-            const int b = mem[d + r];
-            g.ndeg[r] = 0;
-            for (int k = 0; k < ncand[b]; k++) {
-                const double w = 10000.0 + cand_score(P, U, first + b, k);
-                if (!(w > 0.0)) continue;
-                bool ok = true;
-                for (int q = 0; q < d && ok; q++)
-                    if (cur[q] >= 0 && cands_share(P, U, first + mem[q], cur[q], first + b, k)) ok = false;
-                if (!ok) continue;
-                const int32_t x = cand_idx(P, U, first + b, k, e);
-                int col = -1;
-                for (int t = 0; t < nres; t++) if (res[t] == x) { col = t + 1; break; }
-                if (col < 0) { res[nres] = x; col = ++nres; }
-                int at = -1;
-                for (int t = 0; t < g.ndeg[r]; t++) if (g.col[r][t] == col) { at = t; break; }
-                if (at < 0) { at = g.ndeg[r]++; g.col[r][at] = (uint8_t)col; g.cost[r][at] = -w; }
-                else if (-w < g.cost[r][at]) g.cost[r][at] = -w;
-            }
-        }
-        const double bnd = -hungarian_min_cost(g, nres);
-        if (bnd < best) best = bnd;
-    }
-    return best;
-}
-
-// Canonical procedure (shared with the oracle so that exact ties resolve identically):
-//   node weight 10000 + score (traceweaver_v3.py:1260); nodes with weight <= 0 are never selected;
-//   the window is split into connected components of the span conflict relation; each component is
-//   searched depth-first over its spans in index order, candidates in list order then "none", sums
-//   accumulated left to right; a subtree is cut when acc + upper bound <= best (upper bound = sum of the
-//   remaining spans' best weights; for components of more than kSmallComp spans additionally the
-//   matching relaxation above); only strict improvements replace the incumbent.  The answer is the first
-//   optimal selection in that depth-first order and does not depend on the bounds.  A component whose
-//   search exceeds kNodeBudget nodes keeps its incumbent and the window is counted in unit_stats[4].
-// kHeavy = false: components larger than kSmallComp are not searched; returns false (window deferred to
-// k_select_heavy, which owns the large per-thread arrays of the matching bound).
-template <bool kHeavy>
-__device__ bool select_window(const Dev& P, const UnitDev& U, int unit, int first, int m) {
+// ---- light path: thread-private, plain bound only -------------------------------------------------
+__device__ bool select_window_light(const Dev& P, const UnitDev& U, int first, int m) {
     if (m == 1) {  // 87 % of the windows on the shipped data sets
         int pick = -1;
         double best = 0.0;
@@ -672,7 +759,8 @@ __device__ bool select_window(const Dev& P, const UnitDev& U, int unit, int firs
         return true;
     }
     uint8_t comp[kMaxWin], ncand[kMaxWin];
-    for (int b = 0; b < m; b++) { comp[b] = (uint8_t)b; ncand[b] = (uint8_t)cand_n(P, U, first + b); }
+    int8_t pick[kMaxWin];
+    for (int b = 0; b < m; b++) { comp[b] = (uint8_t)b; ncand[b] = (uint8_t)cand_n(P, U, first + b); pick[b] = -1; }
     for (int b = 0; b < m; b++)
         for (int c = 0; c < b; c++) {
             if (comp[b] == comp[c]) continue;
@@ -687,16 +775,6 @@ __device__ bool select_window(const Dev& P, const UnitDev& U, int unit, int firs
                 for (int t = 0; t < m; t++) if (comp[t] == hi) comp[t] = lo;
             }
         }
-    if (!kHeavy) {
-        for (int root = 0; root < m; root++) {
-            if (comp[root] != root) continue;
-            int cm = 0;
-            for (int b = root; b < m; b++) cm += (comp[b] == root);
-            if (cm > kSmallComp) return false;
-        }
-    }
-    bool budget_hit = false;
-    for (int b = 0; b < m; b++) P.chosen[U.in_off + first + b] = -1;
     for (int root = 0; root < m; root++) {
         if (comp[root] != root) continue;
         uint8_t mem[kMaxWin];
@@ -715,23 +793,18 @@ __device__ bool select_window(const Dev& P, const UnitDev& U, int unit, int firs
         int8_t cur[kMaxWin], best[kMaxWin], next[kMaxWin + 1];
         for (int d = 0; d < cm; d++) { cur[d] = -1; best[d] = -1; }
         double best_w = 0.0;
-        int nodes = 0;
-        // iterative DFS: next[d] = next option to try at depth d (0..ncand-1 candidates, ncand = "none")
-        int d = 0;
+        int nodes = 0, d = 0;
         accs[0] = 0.0;
         bool entered = true;
         while (d >= 0) {
             if (entered) {
-                if (nodes >= kNodeBudget) { budget_hit = true; break; }
+                if (nodes >= kPlainNodes) return false;  // hard component: the whole window goes to k_select_heavy
                 nodes++;
                 if (d == cm) {
                     if (accs[d] > best_w) { best_w = accs[d]; for (int t = 0; t < cm; t++) best[t] = cur[t]; }
                     d--; entered = false; continue;
                 }
                 if (accs[d] + ub[d] <= best_w) { d--; entered = false; continue; }
-                if (kHeavy && cm > kSmallComp) {
-                    if (accs[d] + match_bound(P, U, first, mem, cm, d, cur, ncand) <= best_w) { d--; entered = false; continue; }
-                }
                 next[d] = 0;
             }
             const int b = mem[d], nc = ncand[b];
@@ -753,13 +826,241 @@ __device__ bool select_window(const Dev& P, const UnitDev& U, int unit, int firs
             }
             if (!descended) { cur[d] = -1; d--; entered = false; }
         }
-        for (int t = 0; t < cm; t++) P.chosen[U.in_off + first + mem[t]] = best[t];
+        for (int t = 0; t < cm; t++) pick[mem[t]] = best[t];
     }
-    if (budget_hit) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 4], 1ull);
+    for (int b = 0; b < m; b++) P.chosen[U.in_off + first + b] = pick[b];
     return true;
 }
 
-__global__ void k_select(Dev P) {  // one thread per window; windows with a large component are deferred
+// ---- cooperative path: one workgroup per window --------------------------------------------------
+struct SelectLds {
+    int32_t idx[kMaxWin][kTopK][kMaxEp];
+    double w[kMaxWin][kTopK];  // 10000 + score; <= 0 means not eligible
+    double ub[kMaxWin + 1], accs[kMaxWin + 1];
+    double u[kMaxWin + 1], v[kMaxCols], minv[kMaxCols], cost[kMaxWin][kTopK];
+    double red_val[kTile];
+    double best_w, bound, delta;
+    int32_t res[kMaxRes], red_idx[kTile];
+    int16_t p[kMaxCols], way[kMaxCols];
+    uint8_t used[kMaxCols], ncand[kMaxWin], comp[kMaxWin], mem[kMaxWin], ndeg[kMaxWin], col[kMaxWin][kTopK];
+    int8_t cur[kMaxWin], best[kMaxWin], next[kMaxWin + 1], pick[kMaxWin];
+    int cm, d, nodes, entered, state, j0, j1, nrow, ncol_real, budget_hit;
+};
+enum { SEL_RUN = 0, SEL_NEED_BOUND = 1, SEL_DONE = 2 };
+
+__device__ inline bool lds_share(const SelectLds& L, int E, int b1, int k1, int b2, int k2) {
+    for (int e = 0; e < E; e++)
+        if (L.idx[b1][k1][e] == L.idx[b2][k2][e]) return true;
+    return false;
+}
+
+// Hungarian algorithm on the graph in L (rows = remaining spans, <= kTopK finite entries per row plus
+// the row's own zero-cost dummy column); every thread of the workgroup takes part.  Result: L.bound = -min cost.
+__device__ void hungarian_coop(SelectLds& L) {
+    const double INF = 1.0e300;
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int n = L.nrow, m = L.ncol_real + n;
+    for (int j = t; j <= m; j += nt) { L.v[j] = 0.0; L.p[j] = 0; }
+    for (int i = t; i <= n; i += nt) L.u[i] = 0.0;
+    __syncthreads();
+    for (int i = 1; i <= n; i++) {
+        for (int j = t; j <= m; j += nt) { L.minv[j] = INF; L.used[j] = 0; L.way[j] = 0; }
+        if (t == 0) { L.p[0] = (int16_t)i; L.j0 = 0; }
+        __syncthreads();
+        while (true) {
+            if (t == 0) {
+                const int j0 = L.j0;
+                L.used[j0] = 1;
+                const int i0 = L.p[j0], deg = L.ndeg[i0 - 1];
+                for (int q = 0; q <= deg; q++) {
+                    const int j = q < deg ? L.col[i0 - 1][q] : L.ncol_real + i0;
+                    const double a = q < deg ? L.cost[i0 - 1][q] : 0.0;
+                    if (L.used[j]) continue;
+                    const double cur = a - L.u[i0] - L.v[j];
+                    if (cur < L.minv[j]) { L.minv[j] = cur; L.way[j] = (int16_t)j0; }
+                }
+            }
+            __syncthreads();
+            double dv = INF;
+            int dj = 0;
+            for (int j = 1 + t; j <= m; j += nt)
+                if (!L.used[j] && L.minv[j] < dv) { dv = L.minv[j]; dj = j; }  // ascending j: first minimum of the lane
+            L.red_val[t] = dv;
+            L.red_idx[t] = dj;
+            __syncthreads();
+            if (t == 0) {  // first minimum over all columns = smallest column index among equal minima
+                double best = INF;
+                int bj = 0;
+                for (int q = 0; q < nt; q++)
+                    if (L.red_val[q] < best || (L.red_val[q] == best && L.red_idx[q] != 0 && L.red_idx[q] < bj)) { best = L.red_val[q]; bj = L.red_idx[q]; }
+                L.delta = best;
+                L.j1 = bj;
+            }
+            __syncthreads();
+            const double delta = L.delta;
+            for (int j = t; j <= m; j += nt) {
+                if (L.used[j]) { L.u[L.p[j]] += delta; L.v[j] -= delta; }
+                else if (L.minv[j] < INF) L.minv[j] -= delta;
+            }
+            __syncthreads();
+            if (t == 0) L.j0 = L.j1;
+            __syncthreads();
+            if (L.p[L.j0] == 0) break;
+        }
+        if (t == 0) {
+            int j0 = L.j0;
+            do { const int j1 = L.way[j0]; L.p[j0] = L.p[j1]; j0 = j1; } while (j0);
+        }
+        __syncthreads();
+    }
+    if (t == 0) L.bound = -(-L.v[0]);
+    __syncthreads();
+}
+
+// matching relaxation for members d..cm-1 given L.cur[0..d): L.bound = min over the endpoints
+__device__ void match_bound_coop(SelectLds& L, int E) {
+    const int t = threadIdx.x;
+    double best = dinf();
+    for (int e = 0; e < E; e++) {
+        if (t == 0) {
+            const int d = L.d, cm = L.cm;
+            int nres = 0;
+            L.nrow = cm - d;
+            for (int r = 0; r < L.nrow; r++) {
+                const int b = L.mem[d + r];
+                L.ndeg[r] = 0;
+                for (int k = 0; k < L.ncand[b]; k++) {
+                    const double w = L.w[b][k];
+                    if (!(w > 0.0)) continue;
+                    bool ok = true;
+                    for (int q = 0; q < d && ok; q++)
+                        if (L.cur[q] >= 0 && lds_share(L, E, L.mem[q], L.cur[q], b, k)) ok = false;
+                    if (!ok) continue;
+                    const int32_t x = L.idx[b][k][e];
+                    int col = -1;
+                    for (int q = 0; q < nres; q++) if (L.res[q] == x) { col = q + 1; break; }
+                    if (col < 0) { L.res[nres] = x; col = ++nres; }
+                    int at = -1;
+                    for (int q = 0; q < L.ndeg[r]; q++) if (L.col[r][q] == col) { at = q; break; }
+                    if (at < 0) { at = L.ndeg[r]++; L.col[r][at] = (uint8_t)col; L.cost[r][at] = -w; }
+                    else if (-w < L.cost[r][at]) L.cost[r][at] = -w;
+                }
+            }
+            L.ncol_real = nres;
+        }
+        __syncthreads();
+        hungarian_coop(L);
+        if (L.bound < best) best = L.bound;
+        __syncthreads();
+    }
+    if (t == 0) L.bound = best;
+    __syncthreads();
+}
+
+// thread 0 advances the depth-first search until it needs the matching bound (SEL_NEED_BOUND) or the
+// component is finished (SEL_DONE)
+__device__ void select_step(SelectLds& L, int E, bool resume_with_bound) {
+    int d = L.d;
+    bool entered = L.entered != 0;
+    const int cm = L.cm;
+    if (resume_with_bound) {
+        if (L.accs[d] + L.bound <= L.best_w) { d--; entered = false; }
+        else { L.next[d] = 0; entered = false; }
+    }
+    while (d >= 0) {
+        if (entered) {
+            if (L.nodes >= kNodeBudget) { L.budget_hit = 1; break; }
+            L.nodes++;
+            if (d == cm) {
+                if (L.accs[d] > L.best_w) { L.best_w = L.accs[d]; for (int q = 0; q < cm; q++) L.best[q] = L.cur[q]; }
+                d--; entered = false; continue;
+            }
+            if (L.accs[d] + L.ub[d] <= L.best_w) { d--; entered = false; continue; }
+            if (L.nodes > kPlainNodes) { L.d = d; L.entered = 1; L.state = SEL_NEED_BOUND; return; }
+            L.next[d] = 0;
+        }
+        const int b = L.mem[d], nc = L.ncand[b];
+        int k = L.next[d];
+        bool descended = false;
+        for (; k <= nc; k++) {
+            if (k == nc) {
+                L.cur[d] = -1; L.next[d] = (int8_t)(nc + 1); L.accs[d + 1] = L.accs[d];
+                d++; entered = true; descended = true; break;
+            }
+            const double w = L.w[b][k];
+            if (!(w > 0.0)) continue;
+            bool ok = true;
+            for (int q = 0; q < d && ok; q++)
+                if (L.cur[q] >= 0 && lds_share(L, E, L.mem[q], L.cur[q], b, k)) ok = false;
+            if (!ok) continue;
+            L.cur[d] = (int8_t)k; L.next[d] = (int8_t)(k + 1); L.accs[d + 1] = L.accs[d] + w;
+            d++; entered = true; descended = true; break;
+        }
+        if (!descended) { L.cur[d] = -1; d--; entered = false; }
+    }
+    L.d = d;
+    L.state = SEL_DONE;
+}
+
+__device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int first, int m, SelectLds& L) {
+    const int t = threadIdx.x, nt = blockDim.x, E = U.E;
+    for (int q = t; q < m * kTopK; q += nt) {
+        const int b = q / kTopK, k = q % kTopK;
+        const int n = cand_n(P, U, first + b);
+        L.w[b][k] = k < n ? 10000.0 + cand_score(P, U, first + b, k) : 0.0;
+        for (int e = 0; e < E; e++) L.idx[b][k][e] = k < n ? cand_idx(P, U, first + b, k, e) : -1 - q;
+        if (k == 0) { L.ncand[b] = (uint8_t)n; L.comp[b] = (uint8_t)b; L.pick[b] = -1; }
+    }
+    if (t == 0) L.budget_hit = 0;
+    __syncthreads();
+    if (t == 0) {
+        for (int b = 0; b < m; b++)
+            for (int c = 0; c < b; c++) {
+                if (L.comp[b] == L.comp[c]) continue;
+                bool hit = false;
+                for (int ka = 0; ka < L.ncand[b] && !hit; ka++) {
+                    if (!(L.w[b][ka] > 0.0)) continue;
+                    for (int kb = 0; kb < L.ncand[c] && !hit; kb++)
+                        if (L.w[c][kb] > 0.0 && lds_share(L, E, b, ka, c, kb)) hit = true;
+                }
+                if (hit) {
+                    const uint8_t lo = L.comp[b] < L.comp[c] ? L.comp[b] : L.comp[c], hi = L.comp[b] < L.comp[c] ? L.comp[c] : L.comp[b];
+                    for (int q = 0; q < m; q++) if (L.comp[q] == hi) L.comp[q] = lo;
+                }
+            }
+    }
+    __syncthreads();
+    for (int root = 0; root < m; root++) {
+        if (L.comp[root] != root) continue;  // uniform: comp is in LDS and stable here
+        if (t == 0) {
+            int cm = 0;
+            for (int b = root; b < m; b++) if (L.comp[b] == root) L.mem[cm++] = (uint8_t)b;
+            L.cm = cm;
+            L.ub[cm] = 0.0;
+            for (int d = cm - 1; d >= 0; d--) {
+                double mx = 0.0;
+                for (int k = 0; k < L.ncand[L.mem[d]]; k++) if (L.w[L.mem[d]][k] > mx) mx = L.w[L.mem[d]][k];
+                L.ub[d] = L.ub[d + 1] + mx;
+            }
+            for (int d = 0; d < cm; d++) { L.cur[d] = -1; L.best[d] = -1; }
+            L.best_w = 0.0; L.nodes = 0; L.d = 0; L.accs[0] = 0.0; L.entered = 1; L.state = SEL_RUN;
+            select_step(L, E, false);
+        }
+        __syncthreads();
+        while (L.state == SEL_NEED_BOUND) {
+            match_bound_coop(L, E);
+            if (t == 0) select_step(L, E, true);
+            __syncthreads();
+        }
+        if (t == 0) for (int q = 0; q < L.cm; q++) L.pick[L.mem[q]] = L.best[q];
+        __syncthreads();
+    }
+    for (int b = t; b < m; b += nt) P.chosen[U.in_off + first + b] = L.pick[b];
+    if (t == 0 && L.budget_hit) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 4], 1ull);
+    __syncthreads();
+}
+
+__global__ void k_select(Dev P) {  // one thread per window; windows with a hard component are deferred
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int w = Tl.first + threadIdx.x;
@@ -769,20 +1070,22 @@ __global__ void k_select(Dev P) {  // one thread per window; windows with a larg
     const int m = last - first + 1;
     if (m <= 0) return;
     if (m > kMaxWin) { raise_err(P, TW_ERR_WINDOW_SIZE); return; }
-    if (!select_window<false>(P, U, Tl.unit, first, m)) {
+    if (!select_window_light(P, U, first, m)) {
         const int slot = atomicAdd(P.heavy_count, 1);
         P.heavy_unit[slot] = Tl.unit;
         P.heavy_win[slot] = w;
     }
 }
-__global__ void k_select_heavy(Dev P) {  // one thread per deferred window
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= *P.heavy_count) return;
-    const int unit = P.heavy_unit[t], w = P.heavy_win[t];
-    const UnitDev& U = P.units[unit];
-    const int last = P.w_last[U.in_off + w];
-    const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
-    select_window<true>(P, U, unit, first, last - first + 1);
+__global__ void k_select_heavy(Dev P) {  // persistent workgroups, one deferred window at a time
+    __shared__ SelectLds L;
+    const int count = *P.heavy_count;
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        const int unit = P.heavy_unit[item], w = P.heavy_win[item];
+        const UnitDev& U = P.units[unit];
+        const int last = P.w_last[U.in_off + w];
+        const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
+        select_window_coop(P, U, unit, first, last - first + 1, L);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -843,7 +1146,7 @@ template <int E>
 __device__ void repair_span(const Dev& P, const UnitDev& U, int i, int pass, const uint64_t (*gone)[kCandWords]) {
     Enumerator<E> en(P, U);
     setup_enumerator<E>(en, P, U, i, pass);
-    en.cutoffs();  // same full-list cutoffs as the speculative run: the masks in `gone` are relative to lo[]
+    en.cutoffs(i);  // same full-list cutoffs as the speculative run: the masks in `gone` are relative to lo[]
     en.template dfs<true, false>(gone);
     const int64_t g = U.in_off + i;
     P.tkr_n[g] = en.nheap;
@@ -864,6 +1167,7 @@ __global__ void k_repair(Dev P, int pass) {
     __shared__ int next_w;
     __shared__ int any_gone;
     __shared__ uint64_t gone[kMaxWin][kMaxEp][kCandWords];
+    __shared__ SelectLds L;
     const int u = blockIdx.x;
     const UnitDev& U = P.units[u];
     if (P.unit_ndirty[u] == 0) return;
@@ -920,7 +1224,8 @@ __global__ void k_repair(Dev P, int pass) {
             }
             __threadfence();
             __syncthreads();
-            if (t == 0) { select_window<true>(P, U, u, first, m); repaired++; }
+            select_window_coop(P, U, u, first, m, L);
+            if (t == 0) repaired++;
             __threadfence();
             __syncthreads();
             // later windows that hold a span chosen here must be re-examined
