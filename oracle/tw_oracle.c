@@ -34,6 +34,7 @@
  * Python's heapq and list.sort are emulated operation by operation so that exact score ties
  * resolve as in the reference (V3:305-307 heappush/heappop, V3:461 sort(reverse=True)).
  */
+#include <limits.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -632,10 +633,11 @@ static int shares(int E, const int32_t *a, const int32_t *b) { for (int e = 0; e
  * algorithm (potentials, shortest augmenting paths; rows have <= K finite entries).  The bound is the
  * minimum over the endpoints; for E = 1 it is the exact optimum of the sub-problem. */
 #define TWO_MAX_RES (TWO_MAX_WIN * TWO_MAX_K)
+#define TWO_MATCH_MAX_COLS 256
 typedef struct {
     int nrow;
     int ndeg[TWO_MAX_WIN];
-    int col[TWO_MAX_WIN][TWO_MAX_K];     /* 1-based column ids */
+    int32_t col[TWO_MAX_WIN][TWO_MAX_K]; /* 1-based column ids */
     double cost[TWO_MAX_WIN][TWO_MAX_K]; /* -weight */
 } match_graph;
 
@@ -674,12 +676,11 @@ static double hungarian_min_cost(const match_graph *g, int ncol_real) {
     return -v[0];
 }
 
-static double match_bound(mwis_comp *c, int d) {
-    double best = INFINITY;
+/* returns 1 when some endpoint's relaxation already proves acc + bound <= best (endpoints in order, first hit wins) */
+static int match_prunes(mwis_comp *c, int d, double acc) {
     for (int e = 0; e < c->E; e++) {
         match_graph g;
-        int32_t res[TWO_MAX_RES];
-        int nres = 0;
+        int32_t base = INT32_MAX, top = INT32_MIN;
         g.nrow = c->m - d;
         for (int r = 0; r < g.nrow; r++) {
             int i = d + r;
@@ -689,29 +690,33 @@ static double match_bound(mwis_comp *c, int d) {
                 for (int q = 0; q < d && ok; q++) if (c->cur[q] >= 0 && shares(c->E, c->idx[q][c->cur[q]], c->idx[i][j])) ok = 0;
                 if (!ok) continue;
                 int32_t x = c->idx[i][j][e];
-                int col = -1;
-                for (int t = 0; t < nres; t++) if (res[t] == x) { col = t + 1; break; }
-                if (col < 0) { res[nres] = x; col = ++nres; }
-                int at = -1;
-                for (int t = 0; t < g.ndeg[r]; t++) if (g.col[r][t] == col) { at = t; break; }
-                if (at < 0) { at = g.ndeg[r]++; g.col[r][at] = col; g.cost[r][at] = -c->w[i][j]; }
-                else if (-c->w[i][j] < g.cost[r][at]) g.cost[r][at] = -c->w[i][j];
+                if (x < base) base = x;
+                if (x > top) top = x;
+                g.col[r][g.ndeg[r]] = x; g.cost[r][g.ndeg[r]] = -c->w[i][j]; g.ndeg[r]++;
             }
         }
-        double b = -hungarian_min_cost(&g, nres);
-        if (b < best) best = b;
+        if (top < base) { top = 0; base = 1; }
+        int ncol = top - base + 1; /* columns addressed directly by span index (a row may list a column twice) */
+        if (ncol > TWO_MATCH_MAX_COLS) continue; /* range too wide for the column arrays: this endpoint gives no bound */
+        for (int r = 0; r < g.nrow; r++) for (int t = 0; t < g.ndeg[r]; t++) g.col[r][t] = g.col[r][t] - base + 1;
+        double bnd = -hungarian_min_cost(&g, ncol);
+        if (acc + bnd <= c->best_w) return 1;
     }
-    return best;
+    return 0;
 }
 
-#define TWO_PLAIN_NODES 256     /* the matching relaxation is consulted from this many search nodes on */
-#define TWO_NODE_BUDGET 5000    /* search nodes per component; beyond it the incumbent is returned */
+static int two_plain_nodes = 2048;  /* the matching relaxation is consulted from this many search nodes on */
+static int two_node_budget = 4096;  /* search nodes per component; beyond it the incumbent is returned */
+#define TWO_MATCH_MIN_DEPTH 4       /* ... and only where at least this many in-spans remain below the node */
+#define TWO_PLAIN_NODES two_plain_nodes
+#define TWO_NODE_BUDGET two_node_budget
+void two_set_search_limits(int plain_nodes, int budget) { two_plain_nodes = plain_nodes; two_node_budget = budget; } /* experiments only */
 static void mwis_dfs(mwis_comp *c, int d, double acc) {
     if (c->nodes >= TWO_NODE_BUDGET) { c->exhausted = 1; return; }
     c->nodes++;
     if (d == c->m) { if (acc > c->best_w) { c->best_w = acc; memcpy(c->best, c->cur, sizeof(int) * (size_t)c->m); } return; }
     if (acc + c->ub[d] <= c->best_w) return;
-    if (c->nodes > TWO_PLAIN_NODES && acc + match_bound(c, d) <= c->best_w) return;
+    if (c->nodes > TWO_PLAIN_NODES && c->m - d >= TWO_MATCH_MIN_DEPTH && match_prunes(c, d, acc)) return;
     for (int j = 0; j < c->n[d]; j++) {
         int ok = 1;
         for (int q = 0; q < d && ok; q++) if (c->cur[q] >= 0 && shares(c->E, c->idx[q][c->cur[q]], c->idx[d][j])) ok = 0;
@@ -782,10 +787,12 @@ static int64_t mwis_window(const two_service *s, int m, const int *ncand, two_ca
  *   parent[E*n] : out-span index per endpoint, -1 = ("NA","NA")
  *   stats[5]    : not_best_count, cnt_unassigned, mwis search nodes, windows solved, windows whose
  *                 selection search hit the node budget (incumbent returned, optimality not proven)
- * gauss: [n_blocks][nslot][2] (mode 0).  Returns 0 or <0 on error. */
+ * gauss: [n_blocks][nslot][2] (mode 0).  forced: NULL, or [n] selection to commit instead of the oracle's own
+ * (chosen[] still reports the oracle's).  Returns 0 or <0 on error. */
 int two_run_pass(const two_service *s, int mode, const double *gauss, const int32_t *mix_n, const double *mix_p,
                  const uint8_t *end_flag, int32_t *topk_n, int32_t *topk_idx, double *topk_score, int32_t *topk2_n,
-                 int32_t *topk2_idx, double *topk2_score, int64_t *leaves, int32_t *chosen, int32_t *parent, int64_t *stats) {
+                 int32_t *topk2_idx, double *topk2_score, int64_t *leaves, int32_t *chosen, int32_t *parent, int64_t *stats,
+                 const int32_t *forced) {
     int n = s->n_in, E = s->E, K = s->topk, nslot = NSLOT(E);
     if (E > TWO_MAX_E || K > TWO_MAX_K) return -3;
     two_graph g; build_graph(s, &g);
@@ -823,7 +830,10 @@ int two_run_pass(const two_service *s, int mode, const double *gauss, const int3
             stats[3] += 1;
             for (int b = 0; b < nbatch; b++) {
                 int ii = batch_i[b];
-                chosen[ii] = pick[b];
+                chosen[ii] = pick[b]; /* the oracle's own selection */
+                /* "teacher forcing" (tests only): commit a given selection instead, so that later windows see the
+                 * consumption history of a frozen reference run even where an earlier optimum was not unique */
+                if (forced) pick[b] = forced[ii] < batch_n[b] ? forced[ii] : -1;
                 if (batch_n[b] < 1 || pick[b] < 0) stats[0] += 1;      /* V3:1201-1202 */
                 else if (pick[b] != 0) stats[0] += 1;                  /* V3:1204-1207 */
                 if (pick[b] < 0) { stats[1] += 1; continue; }          /* V3:1217 */

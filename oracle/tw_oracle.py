@@ -112,7 +112,7 @@ def gauss_params(svc):
     return g
 
 
-def run_pass(svc, end_flag, gauss=None, mix_n=None, mix_p=None):
+def run_pass(svc, end_flag, gauss=None, mix_n=None, mix_p=None, forced=None):
     """mode 0 (gauss given) or mode 1 (mixtures: mix_n [nslot] int32, mix_p [nslot,5,3] w/mean/prec_chol)."""
     n, E, K = svc.n_in, svc.E, svc.topk
     o = {
@@ -131,7 +131,8 @@ def run_pass(svc, end_flag, gauss=None, mix_n=None, mix_p=None):
     rc = lib().two_run_pass(ctypes.byref(svc.c), ctypes.c_int(mode), _p(gauss), _p(mix_n), _p(mix_p), _p(end_flag),
                             _p(o["topk_n"]), _p(o["topk_idx"]), _p(o["topk_score"]), _p(o["topk2_n"]),
                             _p(o["topk2_idx"]), _p(o["topk2_score"]), _p(o["leaves"]), _p(o["chosen"]),
-                            _p(o["parent"]), _p(stats))
+                            _p(o["parent"]), _p(stats),
+                            _p(np.ascontiguousarray(forced, dtype=np.int32)) if forced is not None else ctypes.c_void_p(0))
     if rc != 0:
         raise RuntimeError("two_run_pass failed: %d" % rc)
     o["not_best_count"], o["cnt_unassigned"], o["mwis_nodes"], o["n_windows"], o["budget_windows"] = (int(v) for v in stats)

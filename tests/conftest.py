@@ -10,7 +10,10 @@ for p in (REPO, os.path.join(REPO, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-GOLDEN = sorted(glob.glob(os.path.join(REPO, "tests", "golden", "ref_*.npz")))
+# ref_*: reference runs on the shipped corpora; refsyn_*: reference runs on synthetic heavy-load units
+# (size-capped windows, span consumption across windows) -- oracle/refrun/gen_golden*.py
+GOLDEN = sorted(glob.glob(os.path.join(REPO, "tests", "golden", "ref_*.npz"))) + \
+    sorted(glob.glob(os.path.join(REPO, "tests", "golden", "refsyn_*.npz")))
 
 
 def pytest_configure(config):
@@ -18,7 +21,7 @@ def pytest_configure(config):
 
 
 def golden_ids():
-    return [os.path.basename(f)[4:-4] for f in GOLDEN]
+    return [os.path.basename(f)[:-4].split("_", 1)[1] for f in GOLDEN]
 
 
 @pytest.fixture(scope="session")

@@ -77,5 +77,6 @@ using std::min;
 
 template <class T> inline T atomicCAS(T* p, T cmp, T val) { T old = *p; if (old == cmp) *p = val; return old; }
 template <class T> inline T atomicMin(T* p, T v) { T old = *p; if (v < old) *p = v; return old; }
+template <class T> inline T atomicMax(T* p, T v) { T old = *p; if (v > old) *p = v; return old; }
 template <class T> inline T atomicAdd(T* p, T v) { T old = *p; *p = old + v; return old; }
 template <class T> inline T atomicOr(T* p, T v) { T old = *p; *p = old | v; return old; }

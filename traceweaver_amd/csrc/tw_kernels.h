@@ -729,21 +729,23 @@ __device__ inline bool cands_share(const Dev& P, const UnitDev& U, int i, int a,
 //   left to right; a subtree is cut when acc + upper bound <= best; only strict improvements replace the
 //   incumbent.  The answer is the first optimal selection in that depth-first order and does not depend
 //   on the bound.  Upper bound: sum of the remaining spans' best weights; once a component's search has
-//   visited kPlainNodes nodes, additionally the matching relaxation: relax every endpoint but e -- what
-//   remains is a maximum-weight bipartite matching between the remaining spans and the outgoing spans of
-//   endpoint e (edge weight = best still-compatible candidate using that span, a span may stay
-//   unmatched), solved with the Hungarian algorithm; minimum over the endpoints (exact for E = 1).  A
-//   component whose search exceeds kNodeBudget nodes keeps its incumbent and the window is counted in
+//   visited kPlainNodes nodes, at nodes with >= kMatchMinDepth spans left additionally the matching
+//   relaxation: relax every endpoint but e -- what remains is a maximum-weight bipartite matching between
+//   the remaining spans and the outgoing spans of endpoint e (edge weight = best still-compatible
+//   candidate using that span, a span may stay unmatched), solved with the Hungarian algorithm (exact for
+//   E = 1); endpoints are tried in order and the first one that proves acc + bound <= best cuts the node.
+//   A component whose search exceeds kNodeBudget nodes keeps its incumbent and the window is counted in
 //   unit_stats[4].
 //
 // Mapping: k_select runs one thread per window and finishes every window whose components all resolve
 // inside the plain phase (all of them on the reference corpora); the others are re-solved from scratch
 // by k_select_heavy, one workgroup per window, candidate data and the Hungarian state in LDS, the
 // column scans of the Hungarian algorithm spread over the lanes.
-constexpr int kPlainNodes = 256;
-constexpr int kNodeBudget = 5000;
-constexpr int kMaxRes = kMaxWin * kTopK;
-constexpr int kMaxCols = kMaxRes + kMaxWin + 1;
+constexpr int kPlainNodes = 2048;    // the matching relaxation is consulted from this many search nodes on ...
+constexpr int kMatchMinDepth = 4;    // ... and only where at least this many spans remain below the node
+constexpr int kNodeBudget = 4096;    // search nodes per component; beyond it the incumbent is returned
+constexpr int kMatchMaxCols = 256;   // widest span-index range one endpoint's relaxation may address
+constexpr int kMaxCols = kMatchMaxCols + kMaxWin + 1;
 
 // ---- light path: thread-private, plain bound only -------------------------------------------------
 __device__ bool select_window_light(const Dev& P, const UnitDev& U, int first, int m) {
@@ -840,11 +842,11 @@ struct SelectLds {
     double u[kMaxWin + 1], v[kMaxCols], minv[kMaxCols], cost[kMaxWin][kTopK];
     double red_val[kTile];
     double best_w, bound, delta;
-    int32_t res[kMaxRes], red_idx[kTile];
+    int32_t red_idx[kTile], col[kMaxWin][kTopK];
     int16_t p[kMaxCols], way[kMaxCols];
-    uint8_t used[kMaxCols], ncand[kMaxWin], comp[kMaxWin], mem[kMaxWin], ndeg[kMaxWin], col[kMaxWin][kTopK];
+    uint8_t used[kMaxCols], ncand[kMaxWin], comp[kMaxWin], mem[kMaxWin], ndeg[kMaxWin];
     int8_t cur[kMaxWin], best[kMaxWin], next[kMaxWin + 1], pick[kMaxWin];
-    int cm, d, nodes, entered, state, j0, j1, nrow, ncol_real, budget_hit;
+    int cm, d, nodes, entered, state, j0, j1, nrow, ncol_real, budget_hit, base, top, prune;
 };
 enum { SEL_RUN = 0, SEL_NEED_BOUND = 1, SEL_DONE = 2 };
 
@@ -917,43 +919,48 @@ __device__ void hungarian_coop(SelectLds& L) {
     __syncthreads();
 }
 
-// matching relaxation for members d..cm-1 given L.cur[0..d): L.bound = min over the endpoints
-__device__ void match_bound_coop(SelectLds& L, int E) {
-    const int t = threadIdx.x;
-    double best = dinf();
+// matching relaxation for members d..cm-1 given L.cur[0..d): L.prune = 1 as soon as one endpoint proves
+// accs[d] + bound <= best_w.  Columns are addressed directly by span index (no de-duplication: a row may
+// list a column twice, the relax step takes the minimum), so the graph is built by all lanes at once.
+__device__ void match_prunes_coop(SelectLds& L, int E) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    if (t == 0) L.prune = 0;
     for (int e = 0; e < E; e++) {
-        if (t == 0) {
-            const int d = L.d, cm = L.cm;
-            int nres = 0;
-            L.nrow = cm - d;
-            for (int r = 0; r < L.nrow; r++) {
-                const int b = L.mem[d + r];
-                L.ndeg[r] = 0;
-                for (int k = 0; k < L.ncand[b]; k++) {
-                    const double w = L.w[b][k];
-                    if (!(w > 0.0)) continue;
-                    bool ok = true;
-                    for (int q = 0; q < d && ok; q++)
-                        if (L.cur[q] >= 0 && lds_share(L, E, L.mem[q], L.cur[q], b, k)) ok = false;
-                    if (!ok) continue;
-                    const int32_t x = L.idx[b][k][e];
-                    int col = -1;
-                    for (int q = 0; q < nres; q++) if (L.res[q] == x) { col = q + 1; break; }
-                    if (col < 0) { L.res[nres] = x; col = ++nres; }
-                    int at = -1;
-                    for (int q = 0; q < L.ndeg[r]; q++) if (L.col[r][q] == col) { at = q; break; }
-                    if (at < 0) { at = L.ndeg[r]++; L.col[r][at] = (uint8_t)col; L.cost[r][at] = -w; }
-                    else if (-w < L.cost[r][at]) L.cost[r][at] = -w;
-                }
+        const int d = L.d, nrow = L.cm - d;
+        if (t == 0) { L.base = 0x7fffffff; L.top = -0x7fffffff - 1; L.nrow = nrow; }
+        for (int r = t; r < nrow; r += nt) L.ndeg[r] = 0;
+        __syncthreads();
+        for (int r = t; r < nrow; r += nt) {  // one lane per remaining span: compatible candidates in list order
+            const int b = L.mem[d + r];
+            int deg = 0;
+            for (int k = 0; k < L.ncand[b]; k++) {
+                const double w = L.w[b][k];
+                if (!(w > 0.0)) continue;
+                bool ok = true;
+                for (int q = 0; q < d && ok; q++)
+                    if (L.cur[q] >= 0 && lds_share(L, E, L.mem[q], L.cur[q], b, k)) ok = false;
+                if (!ok) continue;
+                const int32_t x = L.idx[b][k][e];
+                atomicMin(&L.base, x);
+                atomicMax(&L.top, x);
+                L.col[r][deg] = x;
+                L.cost[r][deg] = -w;
+                deg++;
             }
-            L.ncol_real = nres;
+            L.ndeg[r] = (uint8_t)deg;
         }
         __syncthreads();
-        hungarian_coop(L);
-        if (L.bound < best) best = L.bound;
+        const int base = L.top < L.base ? 1 : L.base, ncol = L.top < L.base ? 0 : L.top - L.base + 1;
+        if (ncol > kMatchMaxCols) { __syncthreads(); continue; }  // uniform: range too wide, no bound from this endpoint
+        for (int r = t; r < nrow; r += nt)
+            for (int q = 0; q < L.ndeg[r]; q++) L.col[r][q] = L.col[r][q] - base + 1;
+        if (t == 0) L.ncol_real = ncol;
         __syncthreads();
+        hungarian_coop(L);
+        const bool cut = L.accs[L.d] + L.bound <= L.best_w;
+        __syncthreads();
+        if (cut) { if (t == 0) L.prune = 1; break; }
     }
-    if (t == 0) L.bound = best;
     __syncthreads();
 }
 
@@ -964,7 +971,7 @@ __device__ void select_step(SelectLds& L, int E, bool resume_with_bound) {
     bool entered = L.entered != 0;
     const int cm = L.cm;
     if (resume_with_bound) {
-        if (L.accs[d] + L.bound <= L.best_w) { d--; entered = false; }
+        if (L.prune) { d--; entered = false; }
         else { L.next[d] = 0; entered = false; }
     }
     while (d >= 0) {
@@ -976,7 +983,7 @@ __device__ void select_step(SelectLds& L, int E, bool resume_with_bound) {
                 d--; entered = false; continue;
             }
             if (L.accs[d] + L.ub[d] <= L.best_w) { d--; entered = false; continue; }
-            if (L.nodes > kPlainNodes) { L.d = d; L.entered = 1; L.state = SEL_NEED_BOUND; return; }
+            if (L.nodes > kPlainNodes && cm - d >= kMatchMinDepth) { L.d = d; L.entered = 1; L.state = SEL_NEED_BOUND; return; }
             L.next[d] = 0;
         }
         const int b = L.mem[d], nc = L.ncand[b];
@@ -1048,7 +1055,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
         }
         __syncthreads();
         while (L.state == SEL_NEED_BOUND) {
-            match_bound_coop(L, E);
+            match_prunes_coop(L, E);
             if (t == 0) select_step(L, E, true);
             __syncthreads();
         }
