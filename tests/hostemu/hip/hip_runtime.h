@@ -71,6 +71,7 @@ inline void __threadfence() {}
 inline void __threadfence_block() {}
 inline long long __double_as_longlong(double x) { long long r; memcpy(&r, &x, 8); return r; }
 inline double __longlong_as_double(long long x) { double r; memcpy(&r, &x, 8); return r; }
+template <class T> inline T __shfl_down(T v, int) { return v; }  // only reachable with one lane per wavefront
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 using std::max;
 using std::min;

@@ -461,7 +461,7 @@ int tw_fit_mixtures(tw_engine* e) {
     FitDev F{};
     F.units = e->P.units; F.n_units = e->P.n_units; F.n_slots = e->n_slots; F.sorted = e->gaps_sorted;
     F.gs_off = e->P.gs_off; F.slot_unit = e->slot_unit; F.models = e->fit_models; F.mix_n = e->mix_n_dev; F.mix_p = e->mix_p_dev;
-    hipLaunchKernelGGL(k_fit_em, dim3((unsigned)(e->n_slots * kMaxComp)), dim3(std::min(e->coop, kFitThreads)), 0, e->stream, F);
+    hipLaunchKernelGGL(k_fit_em, dim3((unsigned)(e->n_slots * kMaxComp)), dim3(e->coop >= 64 ? kFitThreads : e->coop), 0, e->stream, F);
     hipLaunchKernelGGL(k_fit_select, dim3((unsigned)((e->n_slots + 63) / 64)), dim3(64), 0, e->stream, F);
     const int64_t total = e->n_slots * kMaxComp;
     hipLaunchKernelGGL(k_mix_consts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, (const double*)e->mix_p_dev, e->mix_c_dev, total);

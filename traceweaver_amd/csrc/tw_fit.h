@@ -18,7 +18,8 @@
 
 namespace tw {
 
-constexpr int kFitThreads = 256;
+constexpr int kFitThreads = 1024;
+constexpr int kFitWaves = kFitThreads / 64;
 constexpr int kFitStats = 3 * kMaxComp + 1;  // per component: nk, sum r*(x-c), sum r*(x-c)^2; + log-likelihood
 constexpr int kFitMaxIter = 100;
 constexpr double kFitTol = 1.0e-3;
@@ -37,25 +38,31 @@ struct FitDev {
     double* mix_p;          // [n_slots][kMaxComp][3] weight, mean, precision_cholesky
 };
 
-// deterministic block reduction of `cnt` doubles per thread (fixed tree, result in sh[0..cnt))
+// deterministic block reduction of `cnt` doubles per thread: lanes of a wavefront by shuffles (fixed
+// butterfly order), wavefronts by thread 0 in wavefront order.  Result broadcast to every thread.
 __device__ inline void block_reduce(double* vals, int cnt, double* sh) {
-    const int t = threadIdx.x, n = blockDim.x;
-    for (int c = 0; c < cnt; c++) sh[c * kFitThreads + t] = vals[c];
-    __syncthreads();
-    int len = n;
-    while (len > 1) {
-        const int half = (len + 1) >> 1;
-        if (t < len - half)
-            for (int c = 0; c < cnt; c++) sh[c * kFitThreads + t] += sh[c * kFitThreads + t + half];
-        __syncthreads();
-        len = half;
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int lane = t & 63, wave = t >> 6, nwave = (nt + 63) >> 6;
+    for (int c = 0; c < cnt; c++) {
+        double v = vals[c];
+        for (int off = 32; off >= 1; off >>= 1)
+            if (off < nt) v += __shfl_down(v, off);
+        if (lane == 0) sh[c * kFitWaves + wave] = v;
     }
-    for (int c = 0; c < cnt; c++) vals[c] = sh[c * kFitThreads];
+    __syncthreads();
+    if (t == 0)
+        for (int c = 0; c < cnt; c++) {
+            double v = sh[c * kFitWaves];
+            for (int w = 1; w < nwave; w++) v += sh[c * kFitWaves + w];
+            sh[c * kFitWaves] = v;
+        }
+    __syncthreads();
+    for (int c = 0; c < cnt; c++) vals[c] = sh[c * kFitWaves];
     __syncthreads();
 }
 
 __global__ void k_fit_em(FitDev F) {
-    __shared__ double sh[kFitStats * kFitThreads];
+    __shared__ double sh[kFitStats * kFitWaves];
     __shared__ double par[3 * kMaxComp];  // w, mu, var
     __shared__ int flag;
     const int64_t q = blockIdx.x / kMaxComp;

@@ -448,6 +448,8 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
     __shared__ double sc[kHeavyThreads];
     __shared__ uint8_t fl[kHeavyThreads];
     __shared__ unsigned long long sbits[kMaxEp][kCandWords];
+    __shared__ int degenerate;
+    __shared__ double thresh;  // score of the heap minimum once the heap is full (else -inf)
     constexpr int NP = E >= 2 ? E - 2 : 0;  // endpoints walked together; the remaining one or two are spread over the lanes
     constexpr int eA = E >= 2 ? E - 2 : 0, eB = E - 1;
     const int t = threadIdx.x, nt = blockDim.x;
@@ -461,7 +463,18 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
         en.nheap = 0;
         en.leaves = 0;
         for (int k = t; k < kMaxEp * kCandWords; k += nt) (&sbits[0][0])[k] = 0;
+        if (t == 0) { degenerate = 0; thresh = -dinf(); }
         __syncthreads();
+        // If no two candidate spans of an endpoint start at the same time, Python's (score, [spans]) order is a
+        // strict total order on the tuples, the five kept tuples and their final order do not depend on the
+        // push history, and a tuple strictly below the current heap minimum can be dropped without emulating
+        // its push/pop.  With equal starts (millisecond-granular data) every push is emulated.
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            for (int c = en.lo[e] + 1 + t; c <= en.hi[e]; c += nt)
+                if (en.os[e][c] == en.os[e][c - 1]) degenerate = 1;
+        __syncthreads();
+        const bool exact_replay = degenerate != 0;
         int32_t x[E];
         int64_t xs[E], xe[E];
         const int wA = E >= 2 ? en.hi[eA] - en.lo[eA] + 1 : 1, wB = en.hi[eB] - en.lo[eB] + 1;
@@ -518,7 +531,8 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                         }
                     }
                 }
-                fl[t] = ok ? 1 : 0;
+                // 1 = feasible tuple that must go through the heap, 2 = feasible but provably below the heap minimum
+                fl[t] = !ok ? 0 : ((!exact_replay && score < thresh) ? 2 : 1);
                 sc[t] = score;
                 __syncthreads();
                 if (t == 0) {
@@ -527,6 +541,7 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                         if (!fl[j]) continue;
                         any = true;
                         en.leaves++;
+                        if (fl[j] == 2) continue;
                         Cand<E> cand;
                         cand.score = sc[j];
                         for (int e = 0; e < NP; e++) cand.idx[e] = x[e];
@@ -535,6 +550,7 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                         cand.idx[eB] = en.lo[eB] + (gj - a * wB);
                         en.push(cand);
                     }
+                    if (en.nheap == kTopK) thresh = en.heap[0].score;
                 }
                 __syncthreads();
             }
@@ -746,6 +762,8 @@ constexpr int kMatchMinDepth = 4;    // ... and only where at least this many sp
 constexpr int kNodeBudget = 4096;    // search nodes per component; beyond it the incumbent is returned
 constexpr int kMatchMaxCols = 256;   // widest span-index range one endpoint's relaxation may address
 constexpr int kMaxCols = kMatchMaxCols + kMaxWin + 1;
+constexpr int kLightNodes = 192;     // k_select hands a window over to k_select_heavy after this many nodes (<= kPlainNodes;
+                                     // an engine-internal split: the search itself is the same in both kernels)
 
 // ---- light path: thread-private, plain bound only -------------------------------------------------
 __device__ bool select_window_light(const Dev& P, const UnitDev& U, int first, int m) {
@@ -800,7 +818,7 @@ __device__ bool select_window_light(const Dev& P, const UnitDev& U, int first, i
         bool entered = true;
         while (d >= 0) {
             if (entered) {
-                if (nodes >= kPlainNodes) return false;  // hard component: the whole window goes to k_select_heavy
+                if (nodes >= kLightNodes) return false;  // long search: the whole window goes to k_select_heavy (LDS-resident)
                 nodes++;
                 if (d == cm) {
                     if (accs[d] > best_w) { best_w = accs[d]; for (int t = 0; t < cm; t++) best[t] = cur[t]; }
