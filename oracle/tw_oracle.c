@@ -677,7 +677,9 @@ static double hungarian_min_cost(const match_graph *g, int ncol_real) {
 }
 
 /* returns 1 when some endpoint's relaxation already proves acc + bound <= best (endpoints in order, first hit wins) */
+long long two_match_calls = 0, two_match_endpoints = 0;
 static int match_prunes(mwis_comp *c, int d, double acc) {
+    two_match_calls++;
     for (int e = 0; e < c->E; e++) {
         match_graph g;
         int32_t base = INT32_MAX, top = INT32_MIN;
@@ -699,6 +701,7 @@ static int match_prunes(mwis_comp *c, int d, double acc) {
         int ncol = top - base + 1; /* columns addressed directly by span index (a row may list a column twice) */
         if (ncol > TWO_MATCH_MAX_COLS) continue; /* range too wide for the column arrays: this endpoint gives no bound */
         for (int r = 0; r < g.nrow; r++) for (int t = 0; t < g.ndeg[r]; t++) g.col[r][t] = g.col[r][t] - base + 1;
+        two_match_endpoints++;
         double bnd = -hungarian_min_cost(&g, ncol);
         if (acc + bnd <= c->best_w) return 1;
     }
@@ -826,7 +829,7 @@ int two_run_pass(const two_service *s, int mode, const double *gauss, const int3
         if (end_flag[i]) {
             int pick[TWO_MAX_WIN];
             { int hit = 0; int64_t nn = mwis_window(s, nbatch, batch_n, batch, pick, &hit); stats[2] += nn; stats[4] += hit;
-              if (getenv("TWO_DEBUG_MWIS") && nn > 2000) fprintf(stderr, "mwis window end=%d m=%d nodes=%lld\n", i, nbatch, (long long)nn); }
+              if (getenv("TWO_DEBUG_MWIS") && nn > 192) fprintf(stderr, "mwis window end=%d m=%d nodes=%lld\n", i, nbatch, (long long)nn); }
             stats[3] += 1;
             for (int b = 0; b < nbatch; b++) {
                 int ii = batch_i[b];

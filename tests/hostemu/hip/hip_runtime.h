@@ -72,6 +72,10 @@ inline void __threadfence_block() {}
 inline long long __double_as_longlong(double x) { long long r; memcpy(&r, &x, 8); return r; }
 inline double __longlong_as_double(long long x) { double r; memcpy(&r, &x, 8); return r; }
 template <class T> inline T __shfl_down(T v, int) { return v; }  // only reachable with one lane per wavefront
+// wave intrinsics for a wavefront of one lane (kernels that use them run with one thread per workgroup here)
+inline unsigned long long __ballot(int pred) { return pred ? 1ull : 0ull; }
+template <class T> inline T __shfl(T v, int) { return v; }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 using std::max;
 using std::min;

@@ -445,11 +445,10 @@ __global__ void k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int 
 
 template <int E>
 __global__ void k_enumerate_heavy(Dev P, int pass) {
-    __shared__ double sc[kHeavyThreads];
-    __shared__ uint8_t fl[kHeavyThreads];
+    // One wavefront per span.  Every lane keeps an identical copy of the heap (the pushes are executed in
+    // lockstep with wave-uniform operands), so no shared memory or barrier is needed for it: a lane's
+    // (feasible, score) pair reaches the others through __ballot / __shfl.
     __shared__ unsigned long long sbits[kMaxEp][kCandWords];
-    __shared__ int degenerate;
-    __shared__ double thresh;  // score of the heap minimum once the heap is full (else -inf)
     constexpr int NP = E >= 2 ? E - 2 : 0;  // endpoints walked together; the remaining one or two are spread over the lanes
     constexpr int eA = E >= 2 ? E - 2 : 0, eB = E - 1;
     const int t = threadIdx.x, nt = blockDim.x;
@@ -463,25 +462,24 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
         en.nheap = 0;
         en.leaves = 0;
         for (int k = t; k < kMaxEp * kCandWords; k += nt) (&sbits[0][0])[k] = 0;
-        if (t == 0) { degenerate = 0; thresh = -dinf(); }
-        __syncthreads();
         // If no two candidate spans of an endpoint start at the same time, Python's (score, [spans]) order is a
         // strict total order on the tuples, the five kept tuples and their final order do not depend on the
         // push history, and a tuple strictly below the current heap minimum can be dropped without emulating
         // its push/pop.  With equal starts (millisecond-granular data) every push is emulated.
+        bool dup = false;
 #pragma unroll
         for (int e = 0; e < E; e++)
             for (int c = en.lo[e] + 1 + t; c <= en.hi[e]; c += nt)
-                if (en.os[e][c] == en.os[e][c - 1]) degenerate = 1;
+                if (en.os[e][c] == en.os[e][c - 1]) dup = true;
+        const bool exact_replay = __ballot(dup) != 0;
         __syncthreads();
-        const bool exact_replay = degenerate != 0;
         int32_t x[E];
         int64_t xs[E], xe[E];
         const int wA = E >= 2 ? en.hi[eA] - en.lo[eA] + 1 : 1, wB = en.hi[eB] - en.lo[eB] + 1;
         const int G = wA * wB;
         int d = 0;
         if (NP > 0) x[0] = en.lo[0] - 1;
-        bool once = (NP == 0);
+        const bool once = (NP == 0);
         while (once || d >= 0) {
             if (NP > 0) {  // next feasible prefix, every lane in lockstep (DfsTraverseX order)
                 int c = x[d] + 1;
@@ -498,7 +496,7 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                 x[d] = c;
                 if (d < NP - 1) { d++; x[d] = en.lo[d] - 1; continue; }
             }
-            // the (x_eA, x_eB) grid of this prefix, kHeavyThreads tuples at a time, in enumeration order
+            // the (x_eA, x_eB) grid of this prefix, one wavefront of tuples at a time, in enumeration order
             bool any = false;
             for (int base = 0; base < G; base += nt) {
                 const int g = base + t;
@@ -531,28 +529,22 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                         }
                     }
                 }
-                // 1 = feasible tuple that must go through the heap, 2 = feasible but provably below the heap minimum
-                fl[t] = !ok ? 0 : ((!exact_replay && score < thresh) ? 2 : 1);
-                sc[t] = score;
-                __syncthreads();
-                if (t == 0) {
-                    const int lim = G - base < nt ? G - base : nt;
-                    for (int j = 0; j < lim; j++) {
-                        if (!fl[j]) continue;
-                        any = true;
-                        en.leaves++;
-                        if (fl[j] == 2) continue;
-                        Cand<E> cand;
-                        cand.score = sc[j];
-                        for (int e = 0; e < NP; e++) cand.idx[e] = x[e];
-                        const int gj = base + j, a = gj / wB;
-                        if (E >= 2) cand.idx[eA] = en.lo[eA] + a;
-                        cand.idx[eB] = en.lo[eB] + (gj - a * wB);
-                        en.push(cand);
-                    }
-                    if (en.nheap == kTopK) thresh = en.heap[0].score;
+                const double thresh = en.nheap == kTopK ? en.heap[0].score : -dinf();  // heap minimum once full
+                const unsigned long long feasible = __ballot(ok);
+                unsigned long long todo = __ballot(ok && (exact_replay || !(score < thresh)));
+                en.leaves += __popcll(feasible);
+                any |= feasible != 0;
+                while (todo) {  // in enumeration order; wave-uniform, so every lane performs the same push
+                    const int j = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    Cand<E> cand;
+                    cand.score = __shfl(score, j);
+                    for (int e = 0; e < NP; e++) cand.idx[e] = x[e];
+                    const int gj = base + j, a = gj / wB;
+                    if (E >= 2) cand.idx[eA] = en.lo[eA] + a;
+                    cand.idx[eB] = en.lo[eB] + (gj - a * wB);
+                    en.push(cand);
                 }
-                __syncthreads();
             }
             if (t == 0 && any && pass == 1)
                 for (int e = 0; e < NP; e++) { const int r = x[e] - en.lo[e]; sbits[e][r >> 6] |= 1ull << (r & 63); }
@@ -762,7 +754,8 @@ constexpr int kMatchMinDepth = 4;    // ... and only where at least this many sp
 constexpr int kNodeBudget = 4096;    // search nodes per component; beyond it the incumbent is returned
 constexpr int kMatchMaxCols = 256;   // widest span-index range one endpoint's relaxation may address
 constexpr int kMaxCols = kMatchMaxCols + kMaxWin + 1;
-constexpr int kLightNodes = 192;     // k_select hands a window over to k_select_heavy after this many nodes (<= kPlainNodes;
+constexpr int kUsedWords = 4;        // 256-span window of the per-endpoint "taken" bitmap in k_select_heavy
+constexpr int kLightNodes = 64;      // k_select hands a window over to k_select_heavy after this many nodes (<= kPlainNodes;
                                      // an engine-internal split: the search itself is the same in both kernels)
 
 // ---- light path: thread-private, plain bound only -------------------------------------------------
@@ -864,7 +857,9 @@ struct SelectLds {
     int16_t p[kMaxCols], way[kMaxCols];
     uint8_t used[kMaxCols], ncand[kMaxWin], comp[kMaxWin], mem[kMaxWin], ndeg[kMaxWin];
     int8_t cur[kMaxWin], best[kMaxWin], next[kMaxWin + 1], pick[kMaxWin];
-    int cm, d, nodes, entered, state, j0, j1, nrow, ncol_real, budget_hit, base, top, prune;
+    uint64_t used_bits[kMaxEp][kUsedWords];  // spans taken by the current partial selection, per endpoint, relative to ubase
+    int32_t ubase[kMaxEp];
+    int cm, d, nodes, entered, state, j0, j1, nrow, ncol_real, budget_hit, base, top, prune, use_bits;
 };
 enum { SEL_RUN = 0, SEL_NEED_BOUND = 1, SEL_DONE = 2 };
 
@@ -872,6 +867,27 @@ __device__ inline bool lds_share(const SelectLds& L, int E, int b1, int k1, int 
     for (int e = 0; e < E; e++)
         if (L.idx[b1][k1][e] == L.idx[b2][k2][e]) return true;
     return false;
+}
+
+// does candidate (b, k) clash with the current partial selection L.cur[0..d)?
+__device__ inline bool lds_clash(const SelectLds& L, int E, int d, int b, int k) {
+    if (L.use_bits) {
+        for (int e = 0; e < E; e++) {
+            const int r = L.idx[b][k][e] - L.ubase[e];
+            if ((L.used_bits[e][r >> 6] >> (r & 63)) & 1) return true;
+        }
+        return false;
+    }
+    for (int q = 0; q < d; q++)
+        if (L.cur[q] >= 0 && lds_share(L, E, L.mem[q], L.cur[q], b, k)) return true;
+    return false;
+}
+__device__ inline void lds_mark(SelectLds& L, int E, int b, int k, bool set) {
+    if (!L.use_bits) return;
+    for (int e = 0; e < E; e++) {
+        const int r = L.idx[b][k][e] - L.ubase[e];
+        if (set) L.used_bits[e][r >> 6] |= 1ull << (r & 63); else L.used_bits[e][r >> 6] &= ~(1ull << (r & 63));
+    }
 }
 
 // Hungarian algorithm on the graph in L (rows = remaining spans, <= kTopK finite entries per row plus
@@ -954,10 +970,7 @@ __device__ void match_prunes_coop(SelectLds& L, int E) {
             for (int k = 0; k < L.ncand[b]; k++) {
                 const double w = L.w[b][k];
                 if (!(w > 0.0)) continue;
-                bool ok = true;
-                for (int q = 0; q < d && ok; q++)
-                    if (L.cur[q] >= 0 && lds_share(L, E, L.mem[q], L.cur[q], b, k)) ok = false;
-                if (!ok) continue;
+                if (lds_clash(L, E, d, b, k)) continue;
                 const int32_t x = L.idx[b][k][e];
                 atomicMin(&L.base, x);
                 atomicMax(&L.top, x);
@@ -1005,6 +1018,7 @@ __device__ void select_step(SelectLds& L, int E, bool resume_with_bound) {
             L.next[d] = 0;
         }
         const int b = L.mem[d], nc = L.ncand[b];
+        if (L.cur[d] >= 0) { lds_mark(L, E, b, L.cur[d], false); L.cur[d] = -1; }  // back from the subtree of the previous option
         int k = L.next[d];
         bool descended = false;
         for (; k <= nc; k++) {
@@ -1014,11 +1028,9 @@ __device__ void select_step(SelectLds& L, int E, bool resume_with_bound) {
             }
             const double w = L.w[b][k];
             if (!(w > 0.0)) continue;
-            bool ok = true;
-            for (int q = 0; q < d && ok; q++)
-                if (L.cur[q] >= 0 && lds_share(L, E, L.mem[q], L.cur[q], b, k)) ok = false;
-            if (!ok) continue;
+            if (lds_clash(L, E, d, b, k)) continue;
             L.cur[d] = (int8_t)k; L.next[d] = (int8_t)(k + 1); L.accs[d + 1] = L.accs[d] + w;
+            lds_mark(L, E, b, k, true);
             d++; entered = true; descended = true; break;
         }
         if (!descended) { L.cur[d] = -1; d--; entered = false; }
@@ -1068,6 +1080,18 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
                 L.ub[d] = L.ub[d + 1] + mx;
             }
             for (int d = 0; d < cm; d++) { L.cur[d] = -1; L.best[d] = -1; }
+            L.use_bits = 1;
+            for (int e = 0; e < E; e++) {
+                int32_t lo = 0x7fffffff, hi = -1;
+                for (int d = 0; d < cm; d++)
+                    for (int k = 0; k < L.ncand[L.mem[d]]; k++) {
+                        const int32_t x = L.idx[L.mem[d]][k][e];
+                        lo = x < lo ? x : lo; hi = x > hi ? x : hi;
+                    }
+                L.ubase[e] = lo;
+                if (hi - lo >= 64 * kUsedWords) L.use_bits = 0;
+                for (int q = 0; q < kUsedWords; q++) L.used_bits[e][q] = 0;
+            }
             L.best_w = 0.0; L.nodes = 0; L.d = 0; L.accs[0] = 0.0; L.entered = 1; L.state = SEL_RUN;
             select_step(L, E, false);
         }
