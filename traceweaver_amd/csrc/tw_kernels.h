@@ -384,10 +384,10 @@ __device__ void setup_enumerator(Enumerator<E>& en, const Dev& P, const UnitDev&
 // Two tiers.  k_enumerate_light: one thread per incoming span computes the cutoffs and, when the
 // candidate product prod_e (hi_e - lo_e + 1) is small, enumerates it on the spot (mean 1.5-3 tuples on
 // the reference corpora).  Spans with a larger product go to a work list and are enumerated by
-// k_enumerate_heavy, one wavefront per span: the wavefront walks the first E-2 endpoints together and
-// spreads the (x_{E-2}, x_{E-1}) grid over its lanes -- feasibility and the log-likelihood (the costly
-// part) run in parallel, the heap is then fed in enumeration order by lane 0 so that ties resolve
-// exactly as in the sequential reference.
+// k_enumerate_heavy, one wavefront per span: the wavefront walks the leading endpoints together and
+// spreads the tuples of the trailing endpoints over its lanes -- feasibility and the log-likelihood (the
+// costly part) run in parallel, the heap is then fed in enumeration order (wave-uniform pushes) so that
+// ties resolve exactly as in the sequential reference.
 constexpr int kLightMax = 48;
 constexpr int kHeavyThreads = 64;
 
@@ -449,8 +449,6 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
     // lockstep with wave-uniform operands), so no shared memory or barrier is needed for it: a lane's
     // (feasible, score) pair reaches the others through __ballot / __shfl.
     __shared__ unsigned long long sbits[kMaxEp][kCandWords];
-    constexpr int NP = E >= 2 ? E - 2 : 0;  // endpoints walked together; the remaining one or two are spread over the lanes
-    constexpr int eA = E >= 2 ? E - 2 : 0, eB = E - 1;
     const int t = threadIdx.x, nt = blockDim.x;
     const int count = P.heavy_in_count[E];
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
@@ -475,13 +473,17 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
         __syncthreads();
         int32_t x[E];
         int64_t xs[E], xe[E];
-        const int wA = E >= 2 ? en.hi[eA] - en.lo[eA] + 1 : 1, wB = en.hi[eB] - en.lo[eB] + 1;
-        const int G = wA * wB;
+        // Split the endpoints at L: levels 0..L-1 are walked together (every lane the same prefix), the
+        // tuples of levels L..E-1 -- a grid of G = prod w_e points, in enumeration order -- are spread over
+        // the lanes.  L is the deepest split that still gives the lanes a full wavefront of grid points.
+        int L = E - 1;
+        int64_t G = en.hi[E - 1] - en.lo[E - 1] + 1;
+        while (L > 0 && G < kHeavyThreads) { L--; G *= (en.hi[L] - en.lo[L] + 1); }
         int d = 0;
-        if (NP > 0) x[0] = en.lo[0] - 1;
-        const bool once = (NP == 0);
+        if (L > 0) x[0] = en.lo[0] - 1;
+        const bool once = (L == 0);
         while (once || d >= 0) {
-            if (NP > 0) {  // next feasible prefix, every lane in lockstep (DfsTraverseX order)
+            if (L > 0) {  // next feasible prefix, every lane in lockstep (DfsTraverseX order)
                 int c = x[d] + 1;
                 bool found = false;
                 for (; c <= en.hi[d]; c++) {
@@ -494,39 +496,30 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                 }
                 if (!found) { d--; continue; }
                 x[d] = c;
-                if (d < NP - 1) { d++; x[d] = en.lo[d] - 1; continue; }
+                if (d < L - 1) { d++; x[d] = en.lo[d] - 1; continue; }
             }
-            // the (x_eA, x_eB) grid of this prefix, one wavefront of tuples at a time, in enumeration order
             bool any = false;
-            for (int base = 0; base < G; base += nt) {
-                const int g = base + t;
+            for (int64_t base = 0; base < G; base += nt) {
+                int64_t g = base + t;
                 bool ok = g < G;
                 double score = 0.0;
                 if (ok) {
-                    const int a = g / wB, b = g - a * wB;
-                    if (E >= 2) {
-                        const int cA = en.lo[eA] + a;
-                        const int64_t st = en.os[eA][cA], e2 = en.oe[eA][cA];
-                        ok = !(en.in_start > st || e2 > en.in_end);
-                        for (int p = 0; p < eA && ok; p++)
-                            if (((U.pred_mask[eA] >> p) & 1) && xe[p] > st) ok = false;
-                        x[eA] = cA; xs[eA] = st; xe[eA] = e2;
+                    for (int e = E - 1; e >= L; e--) {  // mixed-radix digits of the grid point, last endpoint fastest
+                        const int w = en.hi[e] - en.lo[e] + 1;
+                        x[e] = en.lo[e] + (int)(g % w);
+                        g /= w;
                     }
-                    if (ok) {
-                        const int cB = en.lo[eB] + b;
-                        const int64_t st = en.os[eB][cB], e2 = en.oe[eB][cB];
+                    for (int e = L; e < E && ok; e++) {
+                        const int64_t st = en.os[e][x[e]], e2 = en.oe[e][x[e]];
                         ok = !(en.in_start > st || e2 > en.in_end);
-                        for (int p = 0; p < eB && ok; p++)
-                            if (((U.pred_mask[eB] >> p) & 1) && xe[p] > st) ok = false;
-                        x[eB] = cB; xs[eB] = st; xe[eB] = e2;
+                        for (int p = 0; p < e && ok; p++)
+                            if (((U.pred_mask[e] >> p) & 1) && xe[p] > st) ok = false;
+                        xs[e] = st; xe[e] = e2;
                     }
                     if (ok) {
                         score = en.score(x, xs, xe);
-                        if (pass == 1) {
-                            if (E >= 2) { const int r = x[eA] - en.lo[eA]; atomicOr(&sbits[eA][r >> 6], 1ull << (r & 63)); }
-                            const int r = x[eB] - en.lo[eB];
-                            atomicOr(&sbits[eB][r >> 6], 1ull << (r & 63));
-                        }
+                        if (pass == 1)
+                            for (int e = L; e < E; e++) { const int r = x[e] - en.lo[e]; atomicOr(&sbits[e][r >> 6], 1ull << (r & 63)); }
                     }
                 }
                 const double thresh = en.nheap == kTopK ? en.heap[0].score : -dinf();  // heap minimum once full
@@ -539,16 +532,19 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                     todo &= todo - 1;
                     Cand<E> cand;
                     cand.score = __shfl(score, j);
-                    for (int e = 0; e < NP; e++) cand.idx[e] = x[e];
-                    const int gj = base + j, a = gj / wB;
-                    if (E >= 2) cand.idx[eA] = en.lo[eA] + a;
-                    cand.idx[eB] = en.lo[eB] + (gj - a * wB);
+                    for (int e = 0; e < L; e++) cand.idx[e] = x[e];
+                    int64_t gj = base + j;
+                    for (int e = E - 1; e >= L; e--) {
+                        const int w = en.hi[e] - en.lo[e] + 1;
+                        cand.idx[e] = en.lo[e] + (int)(gj % w);
+                        gj /= w;
+                    }
                     en.push(cand);
                 }
             }
             if (t == 0 && any && pass == 1)
-                for (int e = 0; e < NP; e++) { const int r = x[e] - en.lo[e]; sbits[e][r >> 6] |= 1ull << (r & 63); }
-            if (NP == 0) break;
+                for (int e = 0; e < L; e++) { const int r = x[e] - en.lo[e]; sbits[e][r >> 6] |= 1ull << (r & 63); }
+            if (L == 0) break;
         }
         __syncthreads();
         if (t == 0) {
