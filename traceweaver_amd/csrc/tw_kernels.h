@@ -449,6 +449,13 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
     // lockstep with wave-uniform operands), so no shared memory or barrier is needed for it: a lane's
     // (feasible, score) pair reaches the others through __ballot / __shfl.
     __shared__ unsigned long long sbits[kMaxEp][kCandWords];
+    // LDS-staged candidate window of the span: start / end of every candidate outgoing span, and the two
+    // score terms that depend on one span only -- root(in.start -> s.start) and closing(s.end -> in.end)
+    // (traceweaver_v1.py:349-357).  They are evaluated once per candidate instead of once per tuple; the
+    // tuple score adds the same doubles in the same order, so it is bit-identical.
+    constexpr int W = 64 * kCandWords;
+    __shared__ int64_t ls[E][W], le[E][W];
+    __shared__ double troot[E][W], tclose[E][W];
     const int t = threadIdx.x, nt = blockDim.x;
     const int count = P.heavy_in_count[E];
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
@@ -466,9 +473,18 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
         // its push/pop.  With equal starts (millisecond-granular data) every push is emulated.
         bool dup = false;
 #pragma unroll
-        for (int e = 0; e < E; e++)
-            for (int c = en.lo[e] + 1 + t; c <= en.hi[e]; c += nt)
-                if (en.os[e][c] == en.os[e][c - 1]) dup = true;
+        for (int e = 0; e < E; e++) {
+            const int w = en.hi[e] - en.lo[e] + 1;
+            for (int r = t; r < w; r += nt) {
+                const int c = en.lo[e] + r;
+                const int64_t st = en.os[e][c], e2 = en.oe[e][c];
+                ls[e][r] = st;
+                le[e][r] = e2;
+                if (r > 0 && en.os[e][c - 1] == st) dup = true;
+                troot[e][r] = U.npred[e] == 0 ? score_term(en.S, slot_root(E, e), en.in_start, st) : 0.0;
+                tclose[e][r] = score_term(en.S, slot_close(E, e), e2, en.in_end);
+            }
+        }
         const bool exact_replay = __ballot(dup) != 0;
         __syncthreads();
         int32_t x[E];
@@ -487,7 +503,7 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                 int c = x[d] + 1;
                 bool found = false;
                 for (; c <= en.hi[d]; c++) {
-                    const int64_t st = en.os[d][c], e2 = en.oe[d][c];
+                    const int64_t st = ls[d][c - en.lo[d]], e2 = le[d][c - en.lo[d]];
                     if (en.in_start > st || e2 > en.in_end) continue;
                     bool ok = true;
                     for (int p = 0; p < d; p++)
@@ -510,14 +526,27 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                         g /= w;
                     }
                     for (int e = L; e < E && ok; e++) {
-                        const int64_t st = en.os[e][x[e]], e2 = en.oe[e][x[e]];
+                        const int64_t st = ls[e][x[e] - en.lo[e]], e2 = le[e][x[e] - en.lo[e]];
                         ok = !(en.in_start > st || e2 > en.in_end);
                         for (int p = 0; p < e && ok; p++)
                             if (((U.pred_mask[e] >> p) & 1) && xe[p] > st) ok = false;
                         xs[e] = st; xe[e] = e2;
                     }
                     if (ok) {
-                        score = en.score(x, xs, xe);
+                        // ScoreAssignmentAsPerInvocationGraph (traceweaver_v1.py:305-361) with tabulated root / closing terms
+                        int last = 0;
+                        int64_t last_end = xe[0];
+                        for (int e = 1; e < E; e++) if (xe[e] > last_end) { last_end = xe[e]; last = e; }
+                        for (int e = 0; e < E; e++) {
+                            const int np = U.npred[e];
+                            for (int j = 0; j < np; j++) {
+                                if (!U.pred_prim[e][j]) continue;
+                                const int p = U.pred_list[e][j];
+                                score += score_term(en.S, slot_prim(E, p, e), xe[p], xs[e]);
+                            }
+                            if (np == 0) score += troot[e][x[e] - en.lo[e]];
+                            if (e == last) score += tclose[e][x[e] - en.lo[e]];
+                        }
                         if (pass == 1)
                             for (int e = L; e < E; e++) { const int r = x[e] - en.lo[e]; atomicOr(&sbits[e][r >> 6], 1ull << (r & 63)); }
                     }
