@@ -102,6 +102,7 @@ struct Dev {
     int32_t heavy_in_off[kMaxEp + 2];  // class offsets into heavy_in_unit / heavy_in_idx
     int32_t *heavy_in_unit, *heavy_in_idx;
     int32_t* err;           // first error raised by a kernel (tw_status)
+    unsigned long long* prof;  // [16] phase timers of -DTW_PROFILE builds
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -376,6 +376,8 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(e->tile_ids, (int64_t)tile_ids_h.size());
     ALLOC(P.heavy_in_count, kMaxEp + 1); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
+    ALLOC(P.prof, 16);
+    HIPCHK(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 16, e->stream));
     ALLOC(P.heavy_count, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
@@ -531,6 +533,14 @@ int tw_get_timing(tw_engine* e, double* ms, int32_t n) {
     if (e == nullptr || ms == nullptr) return TW_ERR_ARG;
     for (int i = 0; i < n && i < 6; i++) ms[i] = e->ms[i];
     if (n > 6) ms[6] = e->fit_ms;
+    return TW_OK;
+}
+
+/* Debug aid, not part of the public header: phase timers of -DTW_PROFILE builds (zeros otherwise). */
+int tw_debug_profile(tw_engine* e, unsigned long long* out16) {
+    if (e == nullptr || out16 == nullptr || e->state < ST_LOADED) return TW_ERR_ARG;
+    HIPCHK(hipMemcpyAsync(out16, e->P.prof, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return TW_OK;
 }
 

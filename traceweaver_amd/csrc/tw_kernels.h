@@ -196,12 +196,13 @@ struct Enumerator {
     const int64_t* os[E];  // endpoint segments
     const int64_t* oe[E];
     int32_t lo[E], hi[E];
-    Cand<E> heap[kTopK + 1];
+    Cand<E> heap_store[kTopK + 1];
+    Cand<E>* heap;  // thread-private heap_store by default; the wavefront kernel points it at LDS
     int nheap;
     int64_t leaves;
     uint64_t bits[E][kCandWords];
 
-    __device__ Enumerator(const Dev& p, const UnitDev& u) : P(p), U(u) {}
+    __device__ Enumerator(const Dev& p, const UnitDev& u) : P(p), U(u), heap(heap_store) {}
 
     // FindCutoffs on the full lists (traceweaver_v3.py:182-217): lo = bisect_left(start >= in.start),
     // hi = bisect_right(start <= min(in.end, start of every successor's hi span)) - 1, reverse topo order.
@@ -391,6 +392,16 @@ __device__ void setup_enumerator(Enumerator<E>& en, const Dev& P, const UnitDev&
 constexpr int kLightMax = 48;
 constexpr int kHeavyThreads = 64;
 
+// Optional phase timers (build with -DTW_PROFILE; read back through tw_debug_profile): cycles spent by
+// lane 0 of every heavy-enumeration wavefront per phase.  Compiled out by default.
+#ifdef TW_PROFILE
+#define TW_T0() long long _tw_t = wall_clock64()
+#define TW_TICK(k) do { if (threadIdx.x == 0) { const long long _n = wall_clock64(); atomicAdd((unsigned long long*)&P.prof[k], (unsigned long long)(_n - _tw_t)); _tw_t = _n; } } while (0)
+#else
+#define TW_T0() do {} while (0)
+#define TW_TICK(k) do {} while (0)
+#endif
+
 template <int E>
 __device__ void write_result(const Dev& P, const UnitDev& U, int i, int pass, const Enumerator<E>& en) {
     const int64_t g = U.in_off + i;
@@ -456,14 +467,19 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
     constexpr int W = 64 * kCandWords;
     __shared__ int64_t ls[E][W], le[E][W];
     __shared__ double troot[E][W], tclose[E][W];
+    __shared__ Cand<E> sheap[kTopK + 1];  // the heap lives in LDS and is manipulated by lane 0 only
+    __shared__ int32_t keep_idx[kTopK][E];
     const int t = threadIdx.x, nt = blockDim.x;
     const int count = P.heavy_in_count[E];
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
         const int unit = P.heavy_in_unit[P.heavy_in_off[E] + item], i = P.heavy_in_idx[P.heavy_in_off[E] + item];
         const UnitDev& U = P.units[unit];
+        TW_T0();
         Enumerator<E> en(P, U);
+        en.heap = sheap;
         setup_enumerator<E>(en, P, U, i, pass);
         en.cutoffs(i);
+        TW_TICK(0);
         en.nheap = 0;
         en.leaves = 0;
         for (int k = t; k < kMaxEp * kCandWords; k += nt) (&sbits[0][0])[k] = 0;
@@ -487,6 +503,15 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
         }
         const bool exact_replay = __ballot(dup) != 0;
         __syncthreads();
+        TW_TICK(1);
+        // Without equal starts the kept tuples are simply the five largest under the total order
+        // (score, enumeration rank): every lane keeps that list in registers (wave-uniform values), the index
+        // tuples of the kept entries sit in LDS slots.  With equal starts the CPython heap is replayed in LDS.
+        double ts[kTopK];
+        int tq[kTopK], tslot[kTopK], nk = 0, seq = -1;
+        long long tg[kTopK];
+#pragma unroll
+        for (int k = 0; k < kTopK; k++) { ts[k] = -dinf(); tq[k] = -1; tg[k] = -1; tslot[k] = k; }
         int32_t x[E];
         int64_t xs[E], xe[E];
         // Split the endpoints at L: levels 0..L-1 are walked together (every lane the same prefix), the
@@ -515,6 +540,7 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                 if (d < L - 1) { d++; x[d] = en.lo[d] - 1; continue; }
             }
             bool any = false;
+            seq++;
             for (int64_t base = 0; base < G; base += nt) {
                 int64_t g = base + t;
                 bool ok = g < G;
@@ -551,25 +577,71 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                             for (int e = L; e < E; e++) { const int r = x[e] - en.lo[e]; atomicOr(&sbits[e][r >> 6], 1ull << (r & 63)); }
                     }
                 }
-                const double thresh = en.nheap == kTopK ? en.heap[0].score : -dinf();  // heap minimum once full
+                TW_TICK(2);
                 const unsigned long long feasible = __ballot(ok);
-                unsigned long long todo = __ballot(ok && (exact_replay || !(score < thresh)));
                 en.leaves += __popcll(feasible);
                 any |= feasible != 0;
-                while (todo) {  // in enumeration order; wave-uniform, so every lane performs the same push
-                    const int j = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    Cand<E> cand;
-                    cand.score = __shfl(score, j);
-                    for (int e = 0; e < L; e++) cand.idx[e] = x[e];
-                    int64_t gj = base + j;
-                    for (int e = E - 1; e >= L; e--) {
-                        const int w = en.hi[e] - en.lo[e] + 1;
-                        cand.idx[e] = en.lo[e] + (int)(gj % w);
-                        gj /= w;
+                if (exact_replay) {
+                    unsigned long long todo = feasible;
+                    while (todo) {  // in enumeration order, CPython's heappush / heappop replayed by lane 0
+                        const int j = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const double sj = __shfl(score, j);
+                        if (t == 0) {
+                            Cand<E> cand;
+                            cand.score = sj;
+                            for (int e = 0; e < L; e++) cand.idx[e] = x[e];
+                            int64_t gj = base + j;
+                            for (int e = E - 1; e >= L; e--) {
+                                const int w = en.hi[e] - en.lo[e] + 1;
+                                cand.idx[e] = en.lo[e] + (int)(gj % w);
+                                gj /= w;
+                            }
+                            en.push(cand);
+                        }
                     }
-                    en.push(cand);
+                } else {
+                    const long long gme = base + t;
+                    // beats the current fifth entry?  (larger score, then later in enumeration order)
+                    bool beats = ok && (nk < kTopK || score > ts[kTopK - 1] ||
+                                        (score == ts[kTopK - 1] && (seq > tq[kTopK - 1] || (seq == tq[kTopK - 1] && gme > tg[kTopK - 1]))));
+                    unsigned long long todo = __ballot(beats);
+                    while (todo) {
+                        const int j = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const double sj = __shfl(score, j);
+                        const long long gj = base + j;
+                        if (nk == kTopK && !(sj > ts[kTopK - 1] || (sj == ts[kTopK - 1] && (seq > tq[kTopK - 1] || (seq == tq[kTopK - 1] && gj > tg[kTopK - 1])))))
+                            continue;  // the list moved on since the ballot
+                        const int last = nk < kTopK ? nk : kTopK - 1;
+                        int slot = 0;  // free slot, or the slot of the entry that drops out
+#pragma unroll
+                        for (int k = 0; k < kTopK; k++) if (k == last) slot = tslot[k];
+                        int pos = last;
+#pragma unroll
+                        for (int k = kTopK - 1; k >= 1; k--) {
+                            if (k == pos && (sj > ts[k - 1] || (sj == ts[k - 1] && (seq > tq[k - 1] || (seq == tq[k - 1] && gj > tg[k - 1]))))) {
+                                ts[k] = ts[k - 1]; tq[k] = tq[k - 1]; tg[k] = tg[k - 1]; tslot[k] = tslot[k - 1];
+                                pos = k - 1;
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < kTopK; k++)
+                            if (k == pos) { ts[k] = sj; tq[k] = seq; tg[k] = gj; tslot[k] = slot; }
+                        if (nk < kTopK) nk++;
+                        if (t == 0) {
+                            for (int e = 0; e < L; e++) keep_idx[slot][e] = x[e];
+                            long long gr = gj;
+                            for (int e = E - 1; e >= L; e--) {
+                                const int w = en.hi[e] - en.lo[e] + 1;
+                                keep_idx[slot][e] = en.lo[e] + (int)(gr % w);
+                                gr /= w;
+                            }
+                        }
+                    }
                 }
+                __syncthreads();
+                TW_TICK(3);
             }
             if (t == 0 && any && pass == 1)
                 for (int e = 0; e < L; e++) { const int r = x[e] - en.lo[e]; sbits[e][r >> 6] |= 1ull << (r & 63); }
@@ -577,12 +649,21 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
         }
         __syncthreads();
         if (t == 0) {
-            en.sort_desc();
+            if (exact_replay) en.sort_desc();
+            else {
+                en.nheap = nk;
+#pragma unroll
+                for (int k = 0; k < kTopK; k++) {
+                    sheap[k].score = ts[k];
+                    for (int e = 0; e < E; e++) sheap[k].idx[e] = k < nk ? keep_idx[tslot[k]][e] : -1;
+                }
+            }
             for (int e = 0; e < E; e++)
                 for (int w = 0; w < kCandWords; w++) en.bits[e][w] = sbits[e][w];
             write_result<E>(P, U, i, pass, en);
         }
         __syncthreads();
+        TW_TICK(4);
     }
 }
 
