@@ -121,7 +121,7 @@ void launch_enumerate(tw_engine* e, int pass) {
     hipLaunchKernelGGL((k_enumerate_light<E>), dim3(nt), dim3(e->tile), 0, e->stream, P, pass,
                        (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
     const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
-    const int grid = std::min(cap, 8192);
+    const int grid = std::min(cap, 4096);  // persistent wavefronts pulling spans from the class' work list
     hipLaunchKernelGGL((k_enumerate_heavy<E>), dim3(grid), dim3(std::min(e->coop, kHeavyThreads)), 0, e->stream, P, pass);
 }
 
@@ -166,6 +166,7 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventRecord(e->ev[EV_PARAMS], e->stream));
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
+    HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
     launch_enumerate<1>(e, pass); launch_enumerate<2>(e, pass); launch_enumerate<3>(e, pass); launch_enumerate<4>(e, pass);
     launch_enumerate<5>(e, pass); launch_enumerate<6>(e, pass); launch_enumerate<7>(e, pass); launch_enumerate<8>(e, pass);
     HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
@@ -374,7 +375,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.gaps, gaps);
     ALLOC(P.unit_stats, (int64_t)P.n_units * 8); ALLOC(P.err, 1);
     ALLOC(e->tile_ids, (int64_t)tile_ids_h.size());
-    ALLOC(P.heavy_in_count, kMaxEp + 1); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
+    ALLOC(P.heavy_in_count, kMaxEp + 1); ALLOC(P.heavy_in_next, kMaxEp + 1); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
     ALLOC(P.prof, 16);
     HIPCHK(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 16, e->stream));

@@ -61,7 +61,7 @@ __device__ inline void block_reduce(double* vals, int cnt, double* sh) {
     __syncthreads();
 }
 
-__global__ void k_fit_em(FitDev F) {
+__global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
     __shared__ double sh[kFitStats * kFitWaves];
     __shared__ double par[3 * kMaxComp];  // w, mu, var
     __shared__ int flag;

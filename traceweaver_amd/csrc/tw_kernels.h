@@ -151,7 +151,9 @@ __device__ __forceinline__ double term_gauss(double mean, double used, double lo
     return (-(y * y) / 2.0 - kLogSqrt2Pi) - logstd;  // scipy.stats.norm.logpdf
 }
 
-__device__ inline double term_mix(int n, const double* c, int64_t t1, int64_t t2) {
+// not inlined: the mixture term is ~1.5k instructions and is called from several places per kernel; keeping one
+// copy keeps the enumeration kernels inside the instruction cache
+__device__ __noinline__ double term_mix(int n, const double* c, int64_t t1, int64_t t2) {
     const double x = (double)(t2 - t1);
     double a[kMaxComp], amax = -dinf();
     for (int k = 0; k < n; k++) {
@@ -424,7 +426,7 @@ __device__ void write_result(const Dev& P, const UnitDev& U, int i, int pass, co
 }
 
 template <int E>
-__global__ void k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
+__global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
     const int tile = tile_ids[xcd_tile(blockIdx.x, n_tiles_e)];
     const TileDev T = P.tiles[tile];
     const UnitDev& U = P.units[T.unit];
@@ -454,90 +456,203 @@ __global__ void k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int 
     write_result<E>(P, U, i, pass, en);
 }
 
+// CPython heap / sort replay on an LDS-resident heap (k_enumerate_heavy, degenerate-tie spans only)
 template <int E>
-__global__ void k_enumerate_heavy(Dev P, int pass) {
-    // One wavefront per span.  Every lane keeps an identical copy of the heap (the pushes are executed in
-    // lockstep with wave-uniform operands), so no shared memory or barrier is needed for it: a lane's
-    // (feasible, score) pair reaches the others through __ballot / __shfl.
+struct LdsHeap {
+    Cand<E>* heap;
+    int nheap;
+    const int64_t* out_start;  // P.out_start
+    const UnitDev* U;
+    __device__ bool lt(const Cand<E>& a, const Cand<E>& b) const {
+        if (a.score != b.score) return a.score < b.score;
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            if (a.idx[e] != b.idx[e]) return out_start[U->ep_off[e] + a.idx[e]] < out_start[U->ep_off[e] + b.idx[e]];
+        return false;
+    }
+    __device__ void siftdown(int startpos, int pos) {
+        const Cand<E> item = heap[pos];
+        while (pos > startpos) {
+            const int parent = (pos - 1) >> 1;
+            if (lt(item, heap[parent])) { heap[pos] = heap[parent]; pos = parent; continue; }
+            break;
+        }
+        heap[pos] = item;
+    }
+    __device__ void siftup(int pos) {
+        const int startpos = pos;
+        const Cand<E> item = heap[pos];
+        int child = 2 * pos + 1;
+        while (child < nheap) {
+            const int right = child + 1;
+            if (right < nheap && !lt(heap[child], heap[right])) child = right;
+            heap[pos] = heap[child];
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        heap[pos] = item;
+        siftdown(startpos, pos);
+    }
+    __device__ void push(const Cand<E>& c) {
+        heap[nheap++] = c;
+        siftdown(0, nheap - 1);
+        if (nheap > kTopK) {
+            const Cand<E> last = heap[--nheap];
+            if (nheap > 0) { heap[0] = last; siftup(0); }
+        }
+    }
+    __device__ void reverse(int n) {
+        for (int i = 0, j = n - 1; i < j; i++, j--) { const Cand<E> t = heap[i]; heap[i] = heap[j]; heap[j] = t; }
+    }
+    __device__ void sort_desc() {
+        const int n = nheap;
+        if (n < 2) return;
+        reverse(n);
+        int run = 2;
+        if (lt(heap[1], heap[0])) {
+            for (int i = 2; i < n; i++, run++) if (!lt(heap[i], heap[i - 1])) break;
+            reverse(run);
+        } else {
+            for (int i = 2; i < n; i++, run++) if (lt(heap[i], heap[i - 1])) break;
+        }
+        for (int start = run; start < n; start++) {
+            int l = 0, r = start;
+            const Cand<E> pivot = heap[start];
+            do {
+                const int p = l + ((r - l) >> 1);
+                if (lt(pivot, heap[p])) r = p; else l = p + 1;
+            } while (l < r);
+            for (int p = start; p > l; p--) heap[p] = heap[p - 1];
+            heap[l] = pivot;
+        }
+        reverse(n);
+    }
+};
+
+// One wavefront per span.  Nothing lives in scratch memory: what is the same for every lane (cut-offs,
+// the prefix being walked, the staged candidate window, the term tables, the replay heap) sits in LDS,
+// what differs per lane (its grid point) sits in registers addressed by compile-time indices.
+template <int E>
+__global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass) {
+    constexpr int W = 64 * kCandWords;
     __shared__ unsigned long long sbits[kMaxEp][kCandWords];
     // LDS-staged candidate window of the span: start / end of every candidate outgoing span, and the two
     // score terms that depend on one span only -- root(in.start -> s.start) and closing(s.end -> in.end)
     // (traceweaver_v1.py:349-357).  They are evaluated once per candidate instead of once per tuple; the
     // tuple score adds the same doubles in the same order, so it is bit-identical.
-    constexpr int W = 64 * kCandWords;
     __shared__ int64_t ls[E][W], le[E][W];
     __shared__ double troot[E][W], tclose[E][W];
-    __shared__ Cand<E> sheap[kTopK + 1];  // the heap lives in LDS and is manipulated by lane 0 only
-    __shared__ int32_t keep_idx[kTopK][E];
+    __shared__ Cand<E> sheap[kTopK + 1];   // CPython heap replay (degenerate ties only), lane 0
+    __shared__ int32_t keep_idx[kTopK][E];  // index tuples of the kept entries otherwise
+    __shared__ int32_t px[E];               // the prefix the wavefront is walking (same for every lane)
+    __shared__ int64_t pxs[E], pxe[E];
     const int t = threadIdx.x, nt = blockDim.x;
     const int count = P.heavy_in_count[E];
-    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+    while (true) {
+        // dynamic work distribution: candidate products span four orders of magnitude, a static split leaves
+        // most wavefronts idle behind the few that drew the large spans
+        int item = 0;
+        if (t == 0) item = atomicAdd(&P.heavy_in_next[E], 1);
+        item = __shfl(item, 0);
+        if (item >= count) break;
         const int unit = P.heavy_in_unit[P.heavy_in_off[E] + item], i = P.heavy_in_idx[P.heavy_in_off[E] + item];
         const UnitDev& U = P.units[unit];
         TW_T0();
-        Enumerator<E> en(P, U);
-        en.heap = sheap;
-        setup_enumerator<E>(en, P, U, i, pass);
-        en.cutoffs(i);
+        const int64_t in_start = P.in_start[U.in_off + i], in_end = P.in_end[U.in_off + i];
+        Scorer S;
+        S.pass = pass;
+        S.gp = P.gparam + (U.gp_off + (int64_t)(i / P.batch_size) * U.nslot) * 4;
+        S.mix_n = P.mix_n + U.slot_off;
+        S.mix_c = P.mix_c + (int64_t)U.slot_off * kMaxComp * 4;
+        // FindCutoffs (traceweaver_v3.py:182-217), reverse topological order; compile-time endpoint indices
+        int32_t lo[E], hi[E];
+#pragma unroll
+        for (int e = E - 1; e >= 0; e--) {
+            const int64_t* os = P.out_start + U.ep_off[e];
+            const int n = (int)(U.ep_off[e + 1] - U.ep_off[e]);
+            int64_t tmax = in_end;
+#pragma unroll
+            for (int f = e + 1; f < E; f++) {
+                if (!((U.succ_mask[e] >> f) & 1)) continue;
+                const int nf = (int)(U.ep_off[f + 1] - U.ep_off[f]);
+                const int anchor = hi[f] >= 0 ? hi[f] : nf - 1;  // Python's [-1] wrap (hazard H10)
+                const int64_t st = P.out_start[U.ep_off[f] + anchor];
+                if (st < tmax) tmax = st;
+            }
+            lo[e] = bound_near<false>(os, n, in_start, i);
+            hi[e] = bound_near<true>(os, n, tmax, lo[e]) - 1;
+        }
         TW_TICK(0);
-        en.nheap = 0;
-        en.leaves = 0;
         for (int k = t; k < kMaxEp * kCandWords; k += nt) (&sbits[0][0])[k] = 0;
-        // If no two candidate spans of an endpoint start at the same time, Python's (score, [spans]) order is a
-        // strict total order on the tuples, the five kept tuples and their final order do not depend on the
-        // push history, and a tuple strictly below the current heap minimum can be dropped without emulating
-        // its push/pop.  With equal starts (millisecond-granular data) every push is emulated.
         bool dup = false;
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            const int w = en.hi[e] - en.lo[e] + 1;
+            const int w = hi[e] - lo[e] + 1;
+            const int64_t* os = P.out_start + U.ep_off[e];
+            const int64_t* oe = P.out_end + U.ep_off[e];
             for (int r = t; r < w; r += nt) {
-                const int c = en.lo[e] + r;
-                const int64_t st = en.os[e][c], e2 = en.oe[e][c];
+                const int c = lo[e] + r;
+                const int64_t st = os[c], e2 = oe[c];
                 ls[e][r] = st;
                 le[e][r] = e2;
-                if (r > 0 && en.os[e][c - 1] == st) dup = true;
-                troot[e][r] = U.npred[e] == 0 ? score_term(en.S, slot_root(E, e), en.in_start, st) : 0.0;
-                tclose[e][r] = score_term(en.S, slot_close(E, e), e2, en.in_end);
+                if (r > 0 && os[c - 1] == st) dup = true;
+                troot[e][r] = U.npred[e] == 0 ? score_term(S, slot_root(E, e), in_start, st) : 0.0;
+                tclose[e][r] = score_term(S, slot_close(E, e), e2, in_end);
             }
         }
+        // If no two candidate spans of an endpoint start at the same time, Python's (score, [spans]) order is a
+        // strict total order on the tuples: the kept tuples are simply the five largest under (score,
+        // enumeration rank) and every lane keeps that list in registers (wave-uniform values).  With equal
+        // starts (millisecond-granular data) the CPython heap is replayed push by push in LDS.
         const bool exact_replay = __ballot(dup) != 0;
+        LdsHeap<E> hp;
+        hp.heap = sheap; hp.nheap = 0; hp.out_start = P.out_start; hp.U = &U;
         __syncthreads();
         TW_TICK(1);
-        // Without equal starts the kept tuples are simply the five largest under the total order
-        // (score, enumeration rank): every lane keeps that list in registers (wave-uniform values), the index
-        // tuples of the kept entries sit in LDS slots.  With equal starts the CPython heap is replayed in LDS.
         double ts[kTopK];
         int tq[kTopK], tslot[kTopK], nk = 0, seq = -1;
         long long tg[kTopK];
 #pragma unroll
         for (int k = 0; k < kTopK; k++) { ts[k] = -dinf(); tq[k] = -1; tg[k] = -1; tslot[k] = k; }
-        int32_t x[E];
-        int64_t xs[E], xe[E];
+        int64_t leaves = 0;
         // Split the endpoints at L: levels 0..L-1 are walked together (every lane the same prefix), the
         // tuples of levels L..E-1 -- a grid of G = prod w_e points, in enumeration order -- are spread over
         // the lanes.  L is the deepest split that still gives the lanes a full wavefront of grid points.
         int L = E - 1;
-        int64_t G = en.hi[E - 1] - en.lo[E - 1] + 1;
-        while (L > 0 && G < kHeavyThreads) { L--; G *= (en.hi[L] - en.lo[L] + 1); }
+        int64_t G = hi[E - 1] - lo[E - 1] + 1;
+#pragma unroll
+        for (int e = E - 2; e >= 0; e--)
+            if (L == e + 1 && G < kHeavyThreads) { L = e; G *= (hi[e] - lo[e] + 1); }
         int d = 0;
-        if (L > 0) x[0] = en.lo[0] - 1;
+        if (L > 0) px[0] = lo[0] - 1;
+        __syncthreads();
         const bool once = (L == 0);
         while (once || d >= 0) {
             if (L > 0) {  // next feasible prefix, every lane in lockstep (DfsTraverseX order)
-                int c = x[d] + 1;
+                int hid = 0, lod = 0;
+#pragma unroll
+                for (int e = 0; e < E; e++) if (e == d) { hid = hi[e]; lod = lo[e]; }
+                int c = px[d] + 1;
                 bool found = false;
-                for (; c <= en.hi[d]; c++) {
-                    const int64_t st = ls[d][c - en.lo[d]], e2 = le[d][c - en.lo[d]];
-                    if (en.in_start > st || e2 > en.in_end) continue;
+                int64_t fst = 0, fen = 0;
+                for (; c <= hid; c++) {
+                    const int64_t st = ls[d][c - lod], e2 = le[d][c - lod];
+                    if (in_start > st || e2 > in_end) continue;
                     bool ok = true;
                     for (int p = 0; p < d; p++)
-                        if (((U.pred_mask[d] >> p) & 1) && xe[p] > st) { ok = false; break; }
-                    if (ok) { xs[d] = st; xe[d] = e2; found = true; break; }
+                        if (((U.pred_mask[d] >> p) & 1) && pxe[p] > st) { ok = false; break; }
+                    if (ok) { fst = st; fen = e2; found = true; break; }
                 }
                 if (!found) { d--; continue; }
-                x[d] = c;
-                if (d < L - 1) { d++; x[d] = en.lo[d] - 1; continue; }
+                px[d] = c; pxs[d] = fst; pxe[d] = fen;  // every lane stores the same values
+                if (d < L - 1) {
+                    d++;
+                    int lon = 0;
+#pragma unroll
+                    for (int e = 0; e < E; e++) if (e == d) lon = lo[e];
+                    px[d] = lon - 1;
+                    continue;
+                }
             }
             bool any = false;
             seq++;
@@ -545,41 +660,58 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                 int64_t g = base + t;
                 bool ok = g < G;
                 double score = 0.0;
-                if (ok) {
-                    for (int e = E - 1; e >= L; e--) {  // mixed-radix digits of the grid point, last endpoint fastest
-                        const int w = en.hi[e] - en.lo[e] + 1;
-                        x[e] = en.lo[e] + (int)(g % w);
+                int32_t x[E];
+                int64_t xs[E], xe[E];
+#pragma unroll
+                for (int e = E - 1; e >= 0; e--) {  // mixed-radix digits of the grid point, last endpoint fastest
+                    if (e >= L) {
+                        const int w = hi[e] - lo[e] + 1;
+                        x[e] = lo[e] + (int)(g % w);
                         g /= w;
+                    } else {
+                        x[e] = px[e]; xs[e] = pxs[e]; xe[e] = pxe[e];
                     }
-                    for (int e = L; e < E && ok; e++) {
-                        const int64_t st = ls[e][x[e] - en.lo[e]], e2 = le[e][x[e] - en.lo[e]];
-                        ok = !(en.in_start > st || e2 > en.in_end);
-                        for (int p = 0; p < e && ok; p++)
+                }
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    if (e >= L && ok) {
+                        const int64_t st = ls[e][x[e] - lo[e]], e2 = le[e][x[e] - lo[e]];
+                        ok = !(in_start > st || e2 > in_end);
+#pragma unroll
+                        for (int p = 0; p < e; p++)
                             if (((U.pred_mask[e] >> p) & 1) && xe[p] > st) ok = false;
                         xs[e] = st; xe[e] = e2;
                     }
-                    if (ok) {
-                        // ScoreAssignmentAsPerInvocationGraph (traceweaver_v1.py:305-361) with tabulated root / closing terms
-                        int last = 0;
-                        int64_t last_end = xe[0];
-                        for (int e = 1; e < E; e++) if (xe[e] > last_end) { last_end = xe[e]; last = e; }
-                        for (int e = 0; e < E; e++) {
-                            const int np = U.npred[e];
-                            for (int j = 0; j < np; j++) {
-                                if (!U.pred_prim[e][j]) continue;
-                                const int p = U.pred_list[e][j];
-                                score += score_term(en.S, slot_prim(E, p, e), xe[p], xs[e]);
-                            }
-                            if (np == 0) score += troot[e][x[e] - en.lo[e]];
-                            if (e == last) score += tclose[e][x[e] - en.lo[e]];
+                }
+                if (ok) {
+                    // ScoreAssignmentAsPerInvocationGraph (traceweaver_v1.py:305-361) with tabulated root / closing terms
+                    int last = 0;
+                    int64_t last_end = xe[0];
+#pragma unroll
+                    for (int e = 1; e < E; e++) if (xe[e] > last_end) { last_end = xe[e]; last = e; }
+#pragma unroll
+                    for (int e = 0; e < E; e++) {
+                        const int np = U.npred[e];
+                        for (int j = 0; j < np; j++) {
+                            if (!U.pred_prim[e][j]) continue;
+                            const int p = U.pred_list[e][j];
+                            int64_t pend = 0;
+#pragma unroll
+                            for (int q = 0; q < E; q++) if (q == p) pend = xe[q];
+                            score += score_term(S, slot_prim(E, p, e), pend, xs[e]);
                         }
-                        if (pass == 1)
-                            for (int e = L; e < E; e++) { const int r = x[e] - en.lo[e]; atomicOr(&sbits[e][r >> 6], 1ull << (r & 63)); }
+                        if (np == 0) score += troot[e][x[e] - lo[e]];
+                        if (e == last) score += tclose[e][x[e] - lo[e]];
+                    }
+                    if (pass == 1) {
+#pragma unroll
+                        for (int e = 0; e < E; e++)
+                            if (e >= L) { const int r = x[e] - lo[e]; atomicOr(&sbits[e][r >> 6], 1ull << (r & 63)); }
                     }
                 }
                 TW_TICK(2);
                 const unsigned long long feasible = __ballot(ok);
-                en.leaves += __popcll(feasible);
+                leaves += __popcll(feasible);
                 any |= feasible != 0;
                 if (exact_replay) {
                     unsigned long long todo = feasible;
@@ -590,21 +722,20 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                         if (t == 0) {
                             Cand<E> cand;
                             cand.score = sj;
-                            for (int e = 0; e < L; e++) cand.idx[e] = x[e];
                             int64_t gj = base + j;
-                            for (int e = E - 1; e >= L; e--) {
-                                const int w = en.hi[e] - en.lo[e] + 1;
-                                cand.idx[e] = en.lo[e] + (int)(gj % w);
-                                gj /= w;
+#pragma unroll
+                            for (int e = E - 1; e >= 0; e--) {
+                                if (e >= L) { const int w = hi[e] - lo[e] + 1; cand.idx[e] = lo[e] + (int)(gj % w); gj /= w; }
+                                else cand.idx[e] = px[e];
                             }
-                            en.push(cand);
+                            hp.push(cand);
                         }
                     }
                 } else {
                     const long long gme = base + t;
                     // beats the current fifth entry?  (larger score, then later in enumeration order)
-                    bool beats = ok && (nk < kTopK || score > ts[kTopK - 1] ||
-                                        (score == ts[kTopK - 1] && (seq > tq[kTopK - 1] || (seq == tq[kTopK - 1] && gme > tg[kTopK - 1]))));
+                    const bool beats = ok && (nk < kTopK || score > ts[kTopK - 1] ||
+                                              (score == ts[kTopK - 1] && (seq > tq[kTopK - 1] || (seq == tq[kTopK - 1] && gme > tg[kTopK - 1]))));
                     unsigned long long todo = __ballot(beats);
                     while (todo) {
                         const int j = __ffsll((long long)todo) - 1;
@@ -613,11 +744,11 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                         const long long gj = base + j;
                         if (nk == kTopK && !(sj > ts[kTopK - 1] || (sj == ts[kTopK - 1] && (seq > tq[kTopK - 1] || (seq == tq[kTopK - 1] && gj > tg[kTopK - 1])))))
                             continue;  // the list moved on since the ballot
-                        const int last = nk < kTopK ? nk : kTopK - 1;
+                        const int lastpos = nk < kTopK ? nk : kTopK - 1;
                         int slot = 0;  // free slot, or the slot of the entry that drops out
 #pragma unroll
-                        for (int k = 0; k < kTopK; k++) if (k == last) slot = tslot[k];
-                        int pos = last;
+                        for (int k = 0; k < kTopK; k++) if (k == lastpos) slot = tslot[k];
+                        int pos = lastpos;
 #pragma unroll
                         for (int k = kTopK - 1; k >= 1; k--) {
                             if (k == pos && (sj > ts[k - 1] || (sj == ts[k - 1] && (seq > tq[k - 1] || (seq == tq[k - 1] && gj > tg[k - 1]))))) {
@@ -630,12 +761,11 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                             if (k == pos) { ts[k] = sj; tq[k] = seq; tg[k] = gj; tslot[k] = slot; }
                         if (nk < kTopK) nk++;
                         if (t == 0) {
-                            for (int e = 0; e < L; e++) keep_idx[slot][e] = x[e];
                             long long gr = gj;
-                            for (int e = E - 1; e >= L; e--) {
-                                const int w = en.hi[e] - en.lo[e] + 1;
-                                keep_idx[slot][e] = en.lo[e] + (int)(gr % w);
-                                gr /= w;
+#pragma unroll
+                            for (int e = E - 1; e >= 0; e--) {
+                                if (e >= L) { const int w = hi[e] - lo[e] + 1; keep_idx[slot][e] = lo[e] + (int)(gr % w); gr /= w; }
+                                else keep_idx[slot][e] = px[e];
                             }
                         }
                     }
@@ -644,23 +774,45 @@ __global__ void k_enumerate_heavy(Dev P, int pass) {
                 TW_TICK(3);
             }
             if (t == 0 && any && pass == 1)
-                for (int e = 0; e < L; e++) { const int r = x[e] - en.lo[e]; sbits[e][r >> 6] |= 1ull << (r & 63); }
+                for (int e = 0; e < L; e++) {
+                    int loe = 0;
+#pragma unroll
+                    for (int q = 0; q < E; q++) if (q == e) loe = lo[q];
+                    const int r = px[e] - loe;
+                    sbits[e][r >> 6] |= 1ull << (r & 63);
+                }
             if (L == 0) break;
         }
         __syncthreads();
         if (t == 0) {
-            if (exact_replay) en.sort_desc();
+            const int64_t g = U.in_off + i;
+            int nout;
+            if (exact_replay) { hp.sort_desc(); nout = hp.nheap; }
             else {
-                en.nheap = nk;
+                nout = nk;
 #pragma unroll
                 for (int k = 0; k < kTopK; k++) {
                     sheap[k].score = ts[k];
-                    for (int e = 0; e < E; e++) sheap[k].idx[e] = k < nk ? keep_idx[tslot[k]][e] : -1;
+                    int sl = 0;
+#pragma unroll
+                    for (int q = 0; q < kTopK; q++) if (q == k) sl = tslot[q];
+                    for (int e = 0; e < E; e++) sheap[k].idx[e] = keep_idx[sl][e];
                 }
             }
-            for (int e = 0; e < E; e++)
-                for (int w = 0; w < kCandWords; w++) en.bits[e][w] = sbits[e][w];
-            write_result<E>(P, U, i, pass, en);
+            P.tk_n[g] = nout;
+            P.leaves[g] = leaves;
+            P.rep[g] = 0;
+            for (int k = 0; k < kTopK; k++) {
+                P.tk_score[tks_index(U, k, i)] = k < nout ? sheap[k].score : dnan();
+                for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, i)] = k < nout ? sheap[k].idx[e] : -1;
+            }
+            if (pass == 1) {
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    P.c_lo[ie_index(U, e, i)] = lo[e];
+                    for (int w = 0; w < kCandWords; w++) P.c_bits[ie_index(U, e, i) * kCandWords + w] = sbits[e][w];
+                }
+            }
         }
         __syncthreads();
         TW_TICK(4);
@@ -1215,7 +1367,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
     __syncthreads();
 }
 
-__global__ void k_select(Dev P) {  // one thread per window; windows with a hard component are deferred
+__global__ void __launch_bounds__(kTile) k_select(Dev P) {  // one thread per window; windows with a hard component are deferred
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int w = Tl.first + threadIdx.x;
@@ -1231,7 +1383,7 @@ __global__ void k_select(Dev P) {  // one thread per window; windows with a hard
         P.heavy_win[slot] = w;
     }
 }
-__global__ void k_select_heavy(Dev P) {  // persistent workgroups, one deferred window at a time
+__global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent workgroups, one deferred window at a time
     __shared__ SelectLds L;
     const int count = *P.heavy_count;
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
@@ -1318,7 +1470,7 @@ __device__ void repair_span(const Dev& P, const UnitDev& U, int i, int pass, con
 
 // One workgroup per unit walks the flagged windows in increasing order.  When window w is visited
 // every earlier window is final, so the set of consumed spans it sees is exact.
-__global__ void k_repair(Dev P, int pass) {
+__global__ void __launch_bounds__(kTile) k_repair(Dev P, int pass) {
     __shared__ int next_w;
     __shared__ int any_gone;
     __shared__ uint64_t gone[kMaxWin][kMaxEp][kCandWords];
