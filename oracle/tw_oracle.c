@@ -719,7 +719,7 @@ static void mwis_dfs(mwis_comp *c, int d, double acc) {
     c->nodes++;
     if (d == c->m) { if (acc > c->best_w) { c->best_w = acc; memcpy(c->best, c->cur, sizeof(int) * (size_t)c->m); } return; }
     if (acc + c->ub[d] <= c->best_w) return;
-    if (c->nodes > TWO_PLAIN_NODES && c->m - d >= TWO_MATCH_MIN_DEPTH && (!getenv("TWO_GATE_B") || 2 * d <= c->m) && match_prunes(c, d, acc)) return;
+    if (c->nodes > TWO_PLAIN_NODES && c->m - d >= TWO_MATCH_MIN_DEPTH && match_prunes(c, d, acc)) return;
     for (int j = 0; j < c->n[d]; j++) {
         int ok = 1;
         for (int q = 0; q < d && ok; q++) if (c->cur[q] >= 0 && shares(c->E, c->idx[q][c->cur[q]], c->idx[d][j])) ok = 0;

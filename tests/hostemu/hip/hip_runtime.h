@@ -77,6 +77,7 @@ template <class T> inline T __shfl_down(T v, int) { return v; }  // only reachab
 inline unsigned long long __ballot(int pred) { return pred ? 1ull : 0ull; }
 template <class T> inline T __shfl(T v, int) { return v; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __ffs(int x) { return __builtin_ffs(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 using std::max;
 using std::min;

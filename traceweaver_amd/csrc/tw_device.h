@@ -97,6 +97,7 @@ struct Dev {
     const int64_t* gs_off;  // [n_units]
     int64_t* unit_stats;    // [n_units][8]
     int32_t* heavy_count;   // windows deferred to the large-component selection kernel
+    int32_t* heavy_next;    // next unclaimed entry of that list
     int32_t *heavy_unit, *heavy_win;
     int32_t* heavy_in_count;  // [kMaxEp+1] incoming spans deferred to k_enumerate_heavy, per endpoint count E
     int32_t* heavy_in_next;   // [kMaxEp+1] next unclaimed entry of the class' work list

@@ -1013,7 +1013,8 @@ constexpr int kNodeBudget = 4096;    // search nodes per component; beyond it th
 constexpr int kMatchMaxCols = 256;   // widest span-index range one endpoint's relaxation may address
 constexpr int kMaxCols = kMatchMaxCols + kMaxWin + 1;
 constexpr int kUsedWords = 4;        // 256-span window of the per-endpoint "taken" bitmap in k_select_heavy
-constexpr int kLightNodes = 64;      // k_select hands a window over to k_select_heavy after this many nodes (<= kPlainNodes;
+constexpr int kLightNodes = 64; 
+constexpr int kCoopMinSpans = 4;     // windows with at least this many spans are solved by k_select_heavy     // k_select hands a window over to k_select_heavy after this many nodes (<= kPlainNodes;
                                      // an engine-internal split: the search itself is the same in both kernels)
 
 // ---- light path: thread-private, plain bound only -------------------------------------------------
@@ -1115,6 +1116,7 @@ struct SelectLds {
     int16_t p[kMaxCols], way[kMaxCols];
     uint8_t used[kMaxCols], ncand[kMaxWin], comp[kMaxWin], mem[kMaxWin], ndeg[kMaxWin];
     int8_t cur[kMaxWin], best[kMaxWin], next[kMaxWin + 1], pick[kMaxWin];
+    uint32_t adj[kMaxWin];  // span conflict relation as bit rows
     uint64_t used_bits[kMaxEp][kUsedWords];  // spans taken by the current partial selection, per endpoint, relative to ubase
     int32_t ubase[kMaxEp];
     int cm, d, nodes, entered, state, j0, j1, nrow, ncol_real, budget_hit, base, top, prune, use_bits;
@@ -1307,22 +1309,37 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
         if (k == 0) { L.ncand[b] = (uint8_t)n; L.comp[b] = (uint8_t)b; L.pick[b] = -1; }
     }
     if (t == 0) L.budget_hit = 0;
+    for (int b = t; b < m; b += nt) L.adj[b] = 0;
     __syncthreads();
-    if (t == 0) {
-        for (int b = 0; b < m; b++)
-            for (int c = 0; c < b; c++) {
-                if (L.comp[b] == L.comp[c]) continue;
-                bool hit = false;
-                for (int ka = 0; ka < L.ncand[b] && !hit; ka++) {
-                    if (!(L.w[b][ka] > 0.0)) continue;
-                    for (int kb = 0; kb < L.ncand[c] && !hit; kb++)
-                        if (L.w[c][kb] > 0.0 && lds_share(L, E, b, ka, c, kb)) hit = true;
-                }
-                if (hit) {
-                    const uint8_t lo = L.comp[b] < L.comp[c] ? L.comp[b] : L.comp[c], hi = L.comp[b] < L.comp[c] ? L.comp[c] : L.comp[b];
-                    for (int q = 0; q < m; q++) if (L.comp[q] == hi) L.comp[q] = lo;
-                }
+    // span conflict relation: b ~ c iff an eligible candidate of b shares an outgoing span with an eligible
+    // candidate of c; one lane per pair
+    for (int q = t; q < m * m; q += nt) {
+        const int b = q / m, c = q % m;
+        if (c >= b) continue;
+        bool hit = false;
+        for (int ka = 0; ka < L.ncand[b] && !hit; ka++) {
+            if (!(L.w[b][ka] > 0.0)) continue;
+            for (int kb = 0; kb < L.ncand[c] && !hit; kb++)
+                if (L.w[c][kb] > 0.0 && lds_share(L, E, b, ka, c, kb)) hit = true;
+        }
+        if (hit) { atomicOr(&L.adj[b], 1u << c); atomicOr(&L.adj[c], 1u << b); }
+    }
+    __syncthreads();
+    if (t == 0) {  // connected components, labelled by their smallest member
+        uint32_t seen = 0;
+        for (int b = 0; b < m; b++) {
+            if ((seen >> b) & 1) continue;
+            uint32_t members = 1u << b, frontier = 1u << b;
+            while (frontier) {
+                const int v = __ffs((int)frontier) - 1;
+                frontier &= frontier - 1;
+                const uint32_t fresh = L.adj[v] & ~members;
+                members |= fresh;
+                frontier |= fresh;
             }
+            seen |= members;
+            for (int v = 0; v < m; v++) if ((members >> v) & 1) L.comp[v] = (uint8_t)b;
+        }
     }
     __syncthreads();
     for (int root = 0; root < m; root++) {
@@ -1377,7 +1394,9 @@ __global__ void __launch_bounds__(kTile) k_select(Dev P) {  // one thread per wi
     const int m = last - first + 1;
     if (m <= 0) return;
     if (m > kMaxWin) { raise_err(P, TW_ERR_WINDOW_SIZE); return; }
-    if (!select_window_light(P, U, first, m)) {
+    // windows of several spans go to the workgroup kernel straight away: their candidate lists are compared
+    // pairwise (O(m^2) tuple comparisons), which is cheap from LDS and spread over the lanes there
+    if (m >= kCoopMinSpans || !select_window_light(P, U, first, m)) {
         const int slot = atomicAdd(P.heavy_count, 1);
         P.heavy_unit[slot] = Tl.unit;
         P.heavy_win[slot] = w;
@@ -1385,8 +1404,14 @@ __global__ void __launch_bounds__(kTile) k_select(Dev P) {  // one thread per wi
 }
 __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent workgroups, one deferred window at a time
     __shared__ SelectLds L;
+    __shared__ int next_item;
     const int count = *P.heavy_count;
-    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+    while (true) {
+        if (threadIdx.x == 0) next_item = atomicAdd(P.heavy_next, 1);  // dynamic distribution: search effort varies by orders of magnitude
+        __syncthreads();
+        const int item = next_item;
+        __syncthreads();
+        if (item >= count) break;
         const int unit = P.heavy_unit[item], w = P.heavy_win[item];
         const UnitDev& U = P.units[unit];
         const int last = P.w_last[U.in_off + w];
