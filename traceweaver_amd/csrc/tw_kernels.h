@@ -1155,17 +1155,18 @@ __device__ inline void lds_mark(SelectLds& L, int E, int b, int k, bool set) {
 __device__ void hungarian_coop(SelectLds& L) {
     const double INF = 1.0e300;
     const int t = threadIdx.x, nt = blockDim.x;
+    const int lane = t & 63, wave = t >> 6, nwave = (nt + 63) >> 6;
     const int n = L.nrow, m = L.ncol_real + n;
     for (int j = t; j <= m; j += nt) { L.v[j] = 0.0; L.p[j] = 0; }
     for (int i = t; i <= n; i += nt) L.u[i] = 0.0;
     __syncthreads();
     for (int i = 1; i <= n; i++) {
         for (int j = t; j <= m; j += nt) { L.minv[j] = INF; L.used[j] = 0; L.way[j] = 0; }
-        if (t == 0) { L.p[0] = (int16_t)i; L.j0 = 0; }
+        if (t == 0) L.p[0] = (int16_t)i;
+        int j0 = 0;  // wave-uniform
         __syncthreads();
         while (true) {
-            if (t == 0) {
-                const int j0 = L.j0;
+            if (t == 0) {  // relax the (<= kTopK + 1) finite entries of row i0
                 L.used[j0] = 1;
                 const int i0 = L.p[j0], deg = L.ndeg[i0 - 1];
                 for (int q = 0; q <= deg; q++) {
@@ -1177,39 +1178,48 @@ __device__ void hungarian_coop(SelectLds& L) {
                 }
             }
             __syncthreads();
+            // first minimum of minv over the unused columns: per lane (ascending j), then across lanes -- the
+            // smaller column index wins among equal values, exactly like the sequential scan
             double dv = INF;
             int dj = 0;
             for (int j = 1 + t; j <= m; j += nt)
-                if (!L.used[j] && L.minv[j] < dv) { dv = L.minv[j]; dj = j; }  // ascending j: first minimum of the lane
-            L.red_val[t] = dv;
-            L.red_idx[t] = dj;
-            __syncthreads();
-            if (t == 0) {  // first minimum over all columns = smallest column index among equal minima
-                double best = INF;
-                int bj = 0;
-                for (int q = 0; q < nt; q++)
-                    if (L.red_val[q] < best || (L.red_val[q] == best && L.red_idx[q] != 0 && L.red_idx[q] < bj)) { best = L.red_val[q]; bj = L.red_idx[q]; }
-                L.delta = best;
-                L.j1 = bj;
+                if (!L.used[j] && L.minv[j] < dv) { dv = L.minv[j]; dj = j; }
+            for (int off = 32; off >= 1; off >>= 1) {
+                if (off < nt) {
+                    const double ov = __shfl_down(dv, off);
+                    const int oj = __shfl_down(dj, off);
+                    if (ov < dv || (ov == dv && oj != 0 && (dj == 0 || oj < dj))) { dv = ov; dj = oj; }
+                }
             }
-            __syncthreads();
-            const double delta = L.delta;
+            if (nwave > 1) {
+                if (lane == 0) { L.red_val[wave] = dv; L.red_idx[wave] = dj; }
+                __syncthreads();
+                dv = L.red_val[0]; dj = L.red_idx[0];
+                for (int q = 1; q < nwave; q++) {
+                    const double ov = L.red_val[q];
+                    const int oj = L.red_idx[q];
+                    if (ov < dv || (ov == dv && oj != 0 && (dj == 0 || oj < dj))) { dv = ov; dj = oj; }
+                }
+            } else {
+                dv = __shfl(dv, 0);
+                dj = __shfl(dj, 0);
+            }
+            const double delta = dv;
             for (int j = t; j <= m; j += nt) {
                 if (L.used[j]) { L.u[L.p[j]] += delta; L.v[j] -= delta; }
                 else if (L.minv[j] < INF) L.minv[j] -= delta;
             }
+            j0 = dj;
             __syncthreads();
-            if (t == 0) L.j0 = L.j1;
-            __syncthreads();
-            if (L.p[L.j0] == 0) break;
+            if (L.p[j0] == 0) break;
         }
         if (t == 0) {
-            int j0 = L.j0;
-            do { const int j1 = L.way[j0]; L.p[j0] = L.p[j1]; j0 = j1; } while (j0);
+            int jj = j0;
+            do { const int j1 = L.way[jj]; L.p[jj] = L.p[j1]; jj = j1; } while (jj);
         }
         __syncthreads();
     }
-    if (t == 0) L.bound = -(-L.v[0]);
+    if (t == 0) L.bound = L.v[0];  // = -(min cost)
     __syncthreads();
 }
 
