@@ -18,7 +18,7 @@
 
 namespace tw {
 
-constexpr int kFitThreads = 1024;
+constexpr int kFitThreads = 512;
 constexpr int kFitWaves = kFitThreads / 64;
 constexpr int kFitStats = 3 * kMaxComp + 1;  // per component: nk, sum r*(x-c), sum r*(x-c)^2; + log-likelihood
 constexpr int kFitMaxIter = 100;
@@ -40,9 +40,11 @@ struct FitDev {
 
 // deterministic block reduction of `cnt` doubles per thread: lanes of a wavefront by shuffles (fixed
 // butterfly order), wavefronts by thread 0 in wavefront order.  Result broadcast to every thread.
-__device__ inline void block_reduce(double* vals, int cnt, double* sh) {
+template <int cnt>
+__device__ inline void block_reduce(double (&vals)[cnt], double* sh) {
     const int t = threadIdx.x, nt = blockDim.x;
     const int lane = t & 63, wave = t >> 6, nwave = (nt + 63) >> 6;
+#pragma unroll
     for (int c = 0; c < cnt; c++) {
         double v = vals[c];
         for (int off = 32; off >= 1; off >>= 1)
@@ -50,13 +52,13 @@ __device__ inline void block_reduce(double* vals, int cnt, double* sh) {
         if (lane == 0) sh[c * kFitWaves + wave] = v;
     }
     __syncthreads();
-    if (t == 0)
-        for (int c = 0; c < cnt; c++) {
-            double v = sh[c * kFitWaves];
-            for (int w = 1; w < nwave; w++) v += sh[c * kFitWaves + w];
-            sh[c * kFitWaves] = v;
-        }
+    if (t < cnt) {  // thread c sums the wavefront partials of statistic c in wavefront order
+        double v = sh[t * kFitWaves];
+        for (int w = 1; w < nwave; w++) v += sh[t * kFitWaves + w];
+        sh[t * kFitWaves] = v;
+    }
     __syncthreads();
+#pragma unroll
     for (int c = 0; c < cnt; c++) vals[c] = sh[c * kFitWaves];
     __syncthreads();
 }
@@ -64,7 +66,6 @@ __device__ inline void block_reduce(double* vals, int cnt, double* sh) {
 __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
     __shared__ double sh[kFitStats * kFitWaves];
     __shared__ double par[3 * kMaxComp];  // w, mu, var
-    __shared__ int flag;
     const int64_t q = blockIdx.x / kMaxComp;
     const int k = (int)(blockIdx.x % kMaxComp) + 1;
     const int t = threadIdx.x, nt = blockDim.x;
@@ -72,79 +73,102 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
     const int n_all = U.n_in;
     const double* x = F.sorted + F.gs_off[F.slot_unit[q]] + (q - U.slot_off) * (int64_t)n_all;
     double* model = F.models + (q * kMaxComp + (k - 1)) * kModelStride;
-    double v[kFitStats];
-    // valid samples and distinct values (capped)
-    v[0] = 0.0; v[1] = 0.0;
+    // every per-thread array below is indexed by compile-time constants only (loops over the components are
+    // unrolled to kMaxComp and predicated with j < k), so nothing spills to scratch memory
+    double c2[2];
+    c2[0] = 0.0; c2[1] = 0.0;
     for (int i = t; i < n_all; i += nt) {
         const double xi = x[i];
         if (xi != xi) continue;
-        v[0] += 1.0;
-        if (i == 0 || x[i - 1] != xi) v[1] += 1.0;
+        c2[0] += 1.0;
+        if (i == 0 || x[i - 1] != xi) c2[1] += 1.0;
     }
-    block_reduce(v, 2, sh);
-    const int n = (int)v[0];
-    const int uniq = (int)v[1];
+    block_reduce<2>(c2, sh);
+    const int n = (int)c2[0];
+    const int uniq = (int)c2[1];
     if (n == 0 || k > uniq || k > kMaxComp) {
         if (t == 0) model[0] = dinf();
         return;
     }
     // initialisation: equal-count buckets of the sorted samples
-    for (int c = 0; c < 2 * kMaxComp; c++) v[c] = 0.0;
+    double b2[2 * kMaxComp];
+#pragma unroll
+    for (int c = 0; c < 2 * kMaxComp; c++) b2[c] = 0.0;
     for (int i = t; i < n; i += nt) {
         const int j = (int)(((int64_t)i * k) / n);
-        v[j] += 1.0;
-        v[kMaxComp + j] += x[i];
+        const double xi = x[i];
+#pragma unroll
+        for (int q = 0; q < kMaxComp; q++) if (q == j) { b2[q] += 1.0; b2[kMaxComp + q] += xi; }
     }
-    block_reduce(v, 2 * kMaxComp, sh);
-    if (t == 0)
-        for (int j = 0; j < k; j++) { par[j] = v[j] / (double)n; par[kMaxComp + j] = v[kMaxComp + j] / v[j]; }
+    block_reduce<2 * kMaxComp>(b2, sh);
+    if (t == 0) {
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) if (j < k) { par[j] = b2[j] / (double)n; par[kMaxComp + j] = b2[kMaxComp + j] / b2[j]; }
+    }
     __syncthreads();
-    for (int c = 0; c < kMaxComp; c++) v[c] = 0.0;
+    double b1[kMaxComp];
+#pragma unroll
+    for (int c = 0; c < kMaxComp; c++) b1[c] = 0.0;
     for (int i = t; i < n; i += nt) {
         const int j = (int)(((int64_t)i * k) / n);
         const double d = x[i] - par[kMaxComp + j];
-        v[j] += d * d;
+#pragma unroll
+        for (int q = 0; q < kMaxComp; q++) if (q == j) b1[q] += d * d;
     }
-    block_reduce(v, kMaxComp, sh);
-    if (t == 0)
-        for (int j = 0; j < k; j++) par[2 * kMaxComp + j] = v[j] / (par[j] * (double)n) + kFitRegCovar;
+    block_reduce<kMaxComp>(b1, sh);
+    if (t == 0) {
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) if (j < k) par[2 * kMaxComp + j] = b1[j] / (par[j] * (double)n) + kFitRegCovar;
+    }
     __syncthreads();
     // EM
     double prev_lb = -dinf();
     for (int iter = 0; iter <= kFitMaxIter; iter++) {
-        double lw[kMaxComp], mu[kMaxComp], iv[kMaxComp];
-        for (int j = 0; j < k; j++) {
-            mu[j] = par[kMaxComp + j];
-            iv[j] = 1.0 / par[2 * kMaxComp + j];
-            lw[j] = log(par[j]) - 0.5 * (kLog2Pi + log(par[2 * kMaxComp + j]));
+        double lw[kMaxComp], mu[kMaxComp], iv[kMaxComp], v[kFitStats];
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) {
+            if (j < k) {
+                mu[j] = par[kMaxComp + j];
+                iv[j] = 1.0 / par[2 * kMaxComp + j];
+                lw[j] = log(par[j]) - 0.5 * (kLog2Pi + log(par[2 * kMaxComp + j]));
+            } else { mu[j] = 0.0; iv[j] = 0.0; lw[j] = -dinf(); }
         }
+#pragma unroll
         for (int c = 0; c < kFitStats; c++) v[c] = 0.0;
         for (int i = t; i < n; i += nt) {
             const double xi = x[i];
             double lp[kMaxComp], mx = -dinf();
-            for (int j = 0; j < k; j++) {
-                const double d = xi - mu[j];
-                lp[j] = lw[j] - 0.5 * d * d * iv[j];
-                if (lp[j] > mx) mx = lp[j];
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) {
+                if (j < k) {
+                    const double d = xi - mu[j];
+                    lp[j] = lw[j] - 0.5 * d * d * iv[j];
+                    if (lp[j] > mx) mx = lp[j];
+                }
             }
             double s = 0.0;
-            for (int j = 0; j < k; j++) { lp[j] = exp(lp[j] - mx); s += lp[j]; }
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) if (j < k) { lp[j] = exp(lp[j] - mx); s += lp[j]; }
             v[3 * kMaxComp] += mx + log(s);
             const double inv = 1.0 / s;
-            for (int j = 0; j < k; j++) {
-                const double r = lp[j] * inv, d = xi - mu[j];
-                v[j] += r;
-                v[kMaxComp + j] += r * d;
-                v[2 * kMaxComp + j] += r * d * d;
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) {
+                if (j < k) {
+                    const double r = lp[j] * inv, d = xi - mu[j];
+                    v[j] += r;
+                    v[kMaxComp + j] += r * d;
+                    v[2 * kMaxComp + j] += r * d * d;
+                }
             }
         }
-        block_reduce(v, kFitStats, sh);
+        block_reduce<kFitStats>(v, sh);
         const double lb = v[3 * kMaxComp] / (double)n;  // mean log-likelihood under the current parameters
         // last round only evaluates the likelihood of the final parameters (sklearn's bic() re-scores)
         const bool stop = (iter == kFitMaxIter) || (fabs(lb - prev_lb) < kFitTol);
         if (stop) {
             if (t == 0) {
                 model[0] = -2.0 * lb * (double)n + (double)(3 * k - 1) * log((double)n);
+#pragma unroll
                 for (int j = 0; j < kMaxComp; j++) {
                     model[1 + j] = j < k ? par[j] : 0.0;
                     model[1 + kMaxComp + j] = j < k ? par[kMaxComp + j] : 0.0;
@@ -156,20 +180,23 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
         prev_lb = lb;
         __syncthreads();
         if (t == 0) {  // M step (shifted moments: c = previous mean of the component)
-            for (int j = 0; j < k; j++) {
-                const double nk = v[j] + 10.0 * 2.220446049250313e-16;
-                const double dm = v[kMaxComp + j] / nk;
-                par[j] = nk / (double)n;
-                par[kMaxComp + j] = mu[j] + dm;
-                par[2 * kMaxComp + j] = v[2 * kMaxComp + j] / nk - dm * dm + kFitRegCovar;
-            }
             double ws = 0.0;
-            for (int j = 0; j < k; j++) ws += par[j];
-            for (int j = 0; j < k; j++) par[j] /= ws;
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) {
+                if (j < k) {
+                    const double nk = v[j] + 10.0 * 2.220446049250313e-16;
+                    const double dm = v[kMaxComp + j] / nk;
+                    par[j] = nk / (double)n;
+                    par[kMaxComp + j] = mu[j] + dm;
+                    par[2 * kMaxComp + j] = v[2 * kMaxComp + j] / nk - dm * dm + kFitRegCovar;
+                    ws += par[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) if (j < k) par[j] /= ws;
         }
         __syncthreads();
     }
-    (void)flag;
 }
 
 // smallest BIC wins (first minimum, like np.argmin over n = 1..5)
