@@ -88,6 +88,7 @@ struct Dev {
     double *tk_score, *tkr_score;
     // per (unit, endpoint, span)
     int32_t* c_lo;      // first candidate index (full-list cutoff)
+    int32_t* c_hi;      // last candidate index
     uint64_t* c_bits;   // kCandWords words: spans that occur in >= 1 feasible tuple
     int32_t* parent;
     // per outgoing span

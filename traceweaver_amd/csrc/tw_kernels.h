@@ -434,7 +434,16 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
     if (i >= U.n_in) return;
     Enumerator<E> en(P, U);
     setup_enumerator<E>(en, P, U, i, pass);
-    en.cutoffs(i);
+    // the cut-offs depend on timestamps only: pass 1 computes and keeps them, the wavefront kernel and pass 2
+    // read them back instead of repeating 2E dependent searches per span
+    if (pass == 1) {
+        en.cutoffs(i);
+#pragma unroll
+        for (int e = 0; e < E; e++) { P.c_lo[ie_index(U, e, i)] = en.lo[e]; P.c_hi[ie_index(U, e, i)] = en.hi[e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; e++) { en.lo[e] = P.c_lo[ie_index(U, e, i)]; en.hi[e] = P.c_hi[ie_index(U, e, i)]; }
+    }
     bool wide = false, empty = false;
 #pragma unroll
     for (int e = 0; e < E; e++) {
@@ -564,24 +573,10 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         S.gp = P.gparam + (U.gp_off + (int64_t)(i / P.batch_size) * U.nslot) * 4;
         S.mix_n = P.mix_n + U.slot_off;
         S.mix_c = P.mix_c + (int64_t)U.slot_off * kMaxComp * 4;
-        // FindCutoffs (traceweaver_v3.py:182-217), reverse topological order; compile-time endpoint indices
+        // cut-offs (FindCutoffs, traceweaver_v3.py:182-217) were computed by k_enumerate_light in pass 1
         int32_t lo[E], hi[E];
 #pragma unroll
-        for (int e = E - 1; e >= 0; e--) {
-            const int64_t* os = P.out_start + U.ep_off[e];
-            const int n = (int)(U.ep_off[e + 1] - U.ep_off[e]);
-            int64_t tmax = in_end;
-#pragma unroll
-            for (int f = e + 1; f < E; f++) {
-                if (!((U.succ_mask[e] >> f) & 1)) continue;
-                const int nf = (int)(U.ep_off[f + 1] - U.ep_off[f]);
-                const int anchor = hi[f] >= 0 ? hi[f] : nf - 1;  // Python's [-1] wrap (hazard H10)
-                const int64_t st = P.out_start[U.ep_off[f] + anchor];
-                if (st < tmax) tmax = st;
-            }
-            lo[e] = bound_near<false>(os, n, in_start, i);
-            hi[e] = bound_near<true>(os, n, tmax, lo[e]) - 1;
-        }
+        for (int e = 0; e < E; e++) { lo[e] = P.c_lo[ie_index(U, e, i)]; hi[e] = P.c_hi[ie_index(U, e, i)]; }
         TW_TICK(0);
         for (int k = t; k < kMaxEp * kCandWords; k += nt) (&sbits[0][0])[k] = 0;
         bool dup = false;
