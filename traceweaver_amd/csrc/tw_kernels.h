@@ -397,11 +397,17 @@ constexpr int kHeavyThreads = 64;
 // Optional phase timers (build with -DTW_PROFILE; read back through tw_debug_profile): cycles spent by
 // lane 0 of every heavy-enumeration wavefront per phase.  Compiled out by default.
 #ifdef TW_PROFILE
-#define TW_T0() long long _tw_t = wall_clock64()
-#define TW_TICK(k) do { if (threadIdx.x == 0) { const long long _n = wall_clock64(); atomicAdd((unsigned long long*)&P.prof[k], (unsigned long long)(_n - _tw_t)); _tw_t = _n; } } while (0)
+#define TW_PROF_DECL() long long _tw_t = 0, _tw_a0 = 0, _tw_a1 = 0, _tw_a2 = 0, _tw_a3 = 0, _tw_a4 = 0, _tw_items = 0
+#define TW_T0() do { _tw_t = wall_clock64(); _tw_items++; } while (0)
+#define TW_TICK(k) do { const long long _n = wall_clock64(); _tw_a##k += _n - _tw_t; _tw_t = _n; } while (0)
+#define TW_PROF_FLUSH() do { if (threadIdx.x == 0) { atomicAdd((unsigned long long*)&P.prof[0], (unsigned long long)_tw_a0); atomicAdd((unsigned long long*)&P.prof[1], (unsigned long long)_tw_a1); \
+    atomicAdd((unsigned long long*)&P.prof[2], (unsigned long long)_tw_a2); atomicAdd((unsigned long long*)&P.prof[3], (unsigned long long)_tw_a3); atomicAdd((unsigned long long*)&P.prof[4], (unsigned long long)_tw_a4); \
+    atomicAdd((unsigned long long*)&P.prof[5], (unsigned long long)_tw_items); atomicMax((unsigned long long*)&P.prof[6], (unsigned long long)(_tw_a0 + _tw_a1 + _tw_a2 + _tw_a3 + _tw_a4)); } } while (0)
 #else
+#define TW_PROF_DECL() do {} while (0)
 #define TW_T0() do {} while (0)
 #define TW_TICK(k) do {} while (0)
+#define TW_PROF_FLUSH() do {} while (0)
 #endif
 
 template <int E>
@@ -557,13 +563,14 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
     __shared__ int64_t pxs[E], pxe[E];
     const int t = threadIdx.x, nt = blockDim.x;
     const int count = P.heavy_in_count[E];
+    TW_PROF_DECL();
     while (true) {
         // dynamic work distribution: candidate products span four orders of magnitude, a static split leaves
         // most wavefronts idle behind the few that drew the large spans
         int item = 0;
         if (t == 0) item = atomicAdd(&P.heavy_in_next[E], 1);
         item = __shfl(item, 0);
-        if (item >= count) break;
+        if (item >= count) { TW_PROF_FLUSH(); break; }
         const int unit = P.heavy_in_unit[P.heavy_in_off[E] + item], i = P.heavy_in_idx[P.heavy_in_off[E] + item];
         const UnitDev& U = P.units[unit];
         TW_T0();
@@ -579,7 +586,6 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         for (int e = 0; e < E; e++) { lo[e] = P.c_lo[ie_index(U, e, i)]; hi[e] = P.c_hi[ie_index(U, e, i)]; }
         TW_TICK(0);
         for (int k = t; k < kMaxEp * kCandWords; k += nt) (&sbits[0][0])[k] = 0;
-        bool dup = false;
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int w = hi[e] - lo[e] + 1;
@@ -590,16 +596,17 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                 const int64_t st = os[c], e2 = oe[c];
                 ls[e][r] = st;
                 le[e][r] = e2;
-                if (r > 0 && os[c - 1] == st) dup = true;
                 troot[e][r] = U.npred[e] == 0 ? score_term(S, slot_root(E, e), in_start, st) : 0.0;
                 tclose[e][r] = score_term(S, slot_close(E, e), e2, in_end);
             }
         }
-        // If no two candidate spans of an endpoint start at the same time, Python's (score, [spans]) order is a
-        // strict total order on the tuples: the kept tuples are simply the five largest under (score,
-        // enumeration rank) and every lane keeps that list in registers (wave-uniform values).  With equal
-        // starts (millisecond-granular data) the CPython heap is replayed push by push in LDS.
-        const bool exact_replay = __ballot(dup) != 0;
+        // Python orders (score, [spans]) tuples by score, then by start_mus of the first differing span; two
+        // tuples whose first differing spans start at the same time are "equivalent" (neither is less), and
+        // only then does the outcome of heapq / list.sort depend on the order of the pushes.  First attempt:
+        // keep the five largest tuples under the strict part of that order in registers (every lane the same
+        // values) and watch for an equivalence that could matter (between the candidate, the evicted entry
+        // or the kept entries).  If one shows up -- millisecond-granular data -- the span is redone with the
+        // CPython heap replayed push by push in LDS (second attempt).
         LdsHeap<E> hp;
         hp.heap = sheap; hp.nheap = 0; hp.out_start = P.out_start; hp.U = &U;
         __syncthreads();
@@ -607,9 +614,44 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         double ts[kTopK];
         int tq[kTopK], tslot[kTopK], nk = 0, seq = -1;
         long long tg[kTopK];
+        bool exact_replay = false, ambiguous = false;
+        int64_t leaves = 0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+        exact_replay = attempt == 1;
+        hp.nheap = 0; nk = 0; seq = -1; leaves = 0;
 #pragma unroll
         for (int k = 0; k < kTopK; k++) { ts[k] = -dinf(); tq[k] = -1; tg[k] = -1; tslot[k] = k; }
-        int64_t leaves = 0;
+        // order of the candidate tuple (prefix px[0..L) + grid point gj) against the kept tuple in LDS slot sl
+        // when their scores are equal: +1 candidate greater, -1 smaller, 0 equivalent
+        auto tie_order = [&](long long gj, int sl, int Ls) -> int {
+            long long gr = gj;
+            int32_t ci[E];
+#pragma unroll
+            for (int e = E - 1; e >= 0; e--) {
+                if (e >= Ls) { const int w = hi[e] - lo[e] + 1; ci[e] = lo[e] + (int)(gr % w); gr /= w; }
+                else ci[e] = px[e];
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int32_t ki = keep_idx[sl][e];
+                if (ci[e] != ki) {
+                    const int64_t a = ls[e][ci[e] - lo[e]], b2 = ls[e][ki - lo[e]];
+                    return a > b2 ? 1 : (a < b2 ? -1 : 0);
+                }
+            }
+            return 0;
+        };
+        auto slot_order = [&](int sa, int sb) -> int {  // same for two kept tuples
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int32_t ia = keep_idx[sa][e], ib = keep_idx[sb][e];
+                if (ia != ib) {
+                    const int64_t a = ls[e][ia - lo[e]], b2 = ls[e][ib - lo[e]];
+                    return a > b2 ? 1 : (a < b2 ? -1 : 0);
+                }
+            }
+            return 0;
+        };
         // Split the endpoints at L: levels 0..L-1 are walked together (every lane the same prefix), the
         // tuples of levels L..E-1 -- a grid of G = prod w_e points, in enumeration order -- are spread over
         // the lanes.  L is the deepest split that still gives the lanes a full wavefront of grid points.
@@ -727,18 +769,37 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         }
                     }
                 } else {
-                    const long long gme = base + t;
-                    // beats the current fifth entry?  (larger score, then later in enumeration order)
-                    const bool beats = ok && (nk < kTopK || score > ts[kTopK - 1] ||
-                                              (score == ts[kTopK - 1] && (seq > tq[kTopK - 1] || (seq == tq[kTopK - 1] && gme > tg[kTopK - 1]))));
+                    // beats the current fifth entry?  score ties are resolved exactly below, so let them through
+                    const bool beats = ok && (nk < kTopK || score >= ts[kTopK - 1]);
                     unsigned long long todo = __ballot(beats);
                     while (todo) {
                         const int j = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
                         const double sj = __shfl(score, j);
                         const long long gj = base + j;
-                        if (nk == kTopK && !(sj > ts[kTopK - 1] || (sj == ts[kTopK - 1] && (seq > tq[kTopK - 1] || (seq == tq[kTopK - 1] && gj > tg[kTopK - 1])))))
-                            continue;  // the list moved on since the ballot
+                        // exact order against every kept entry of equal score (rare): greater[k] / equivalence
+                        int tie[kTopK];
+#pragma unroll
+                        for (int k = 0; k < kTopK; k++) {
+                            tie[k] = 0;
+                            if (k < nk && sj == ts[k]) {
+                                int sl = 0;
+#pragma unroll
+                                for (int q = 0; q < kTopK; q++) if (q == k) sl = tslot[q];
+                                tie[k] = tie_order(gj, sl, L);
+                                if (tie[k] == 0) ambiguous = true;
+                            }
+                        }
+                        if (nk == kTopK) {
+                            if (!(sj > ts[kTopK - 1] || (sj == ts[kTopK - 1] && tie[kTopK - 1] > 0))) continue;  // stays out
+                            // the entry that drops out must be the unique minimum of the kept five
+                            if (ts[kTopK - 2] == ts[kTopK - 1]) {
+                                int sa = 0, sb = 0;
+#pragma unroll
+                                for (int q = 0; q < kTopK; q++) { if (q == kTopK - 2) sa = tslot[q]; if (q == kTopK - 1) sb = tslot[q]; }
+                                if (slot_order(sa, sb) == 0) ambiguous = true;
+                            }
+                        }
                         const int lastpos = nk < kTopK ? nk : kTopK - 1;
                         int slot = 0;  // free slot, or the slot of the entry that drops out
 #pragma unroll
@@ -746,7 +807,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         int pos = lastpos;
 #pragma unroll
                         for (int k = kTopK - 1; k >= 1; k--) {
-                            if (k == pos && (sj > ts[k - 1] || (sj == ts[k - 1] && (seq > tq[k - 1] || (seq == tq[k - 1] && gj > tg[k - 1]))))) {
+                            if (k == pos && (sj > ts[k - 1] || (sj == ts[k - 1] && tie[k - 1] > 0))) {
                                 ts[k] = ts[k - 1]; tq[k] = tq[k - 1]; tg[k] = tg[k - 1]; tslot[k] = tslot[k - 1];
                                 pos = k - 1;
                             }
@@ -778,6 +839,21 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                 }
             if (L == 0) break;
         }
+        if (attempt == 0) {  // the kept tuples themselves must be pairwise ordered
+#pragma unroll
+            for (int a = 0; a < kTopK; a++)
+#pragma unroll
+                for (int b2 = a + 1; b2 < kTopK; b2++)
+                    if (b2 < nk && ts[a] == ts[b2]) {
+                        int sa = 0, sb = 0;
+#pragma unroll
+                        for (int q = 0; q < kTopK; q++) { if (q == a) sa = tslot[q]; if (q == b2) sb = tslot[q]; }
+                        if (slot_order(sa, sb) == 0) ambiguous = true;
+                    }
+            if (!ambiguous) break;
+            __syncthreads();
+        }
+        }  // attempt
         __syncthreads();
         if (t == 0) {
             const int64_t g = U.in_off + i;
