@@ -397,12 +397,13 @@ constexpr int kHeavyThreads = 64;
 // Optional phase timers (build with -DTW_PROFILE; read back through tw_debug_profile): cycles spent by
 // lane 0 of every heavy-enumeration wavefront per phase.  Compiled out by default.
 #ifdef TW_PROFILE
-#define TW_PROF_DECL() long long _tw_t = 0, _tw_a0 = 0, _tw_a1 = 0, _tw_a2 = 0, _tw_a3 = 0, _tw_a4 = 0, _tw_items = 0
-#define TW_T0() do { _tw_t = wall_clock64(); _tw_items++; } while (0)
+#define TW_PROF_DECL() long long _tw_t = wall_clock64(), _tw_a0 = 0, _tw_a1 = 0, _tw_a2 = 0, _tw_a3 = 0, _tw_a4 = 0, _tw_items = 0, _tw_fetch = 0, _tw_born = _tw_t
+#define TW_T0() do { const long long _n = wall_clock64(); _tw_fetch += _n - _tw_t; _tw_t = _n; _tw_items++; } while (0)
 #define TW_TICK(k) do { const long long _n = wall_clock64(); _tw_a##k += _n - _tw_t; _tw_t = _n; } while (0)
 #define TW_PROF_FLUSH() do { if (threadIdx.x == 0) { atomicAdd((unsigned long long*)&P.prof[0], (unsigned long long)_tw_a0); atomicAdd((unsigned long long*)&P.prof[1], (unsigned long long)_tw_a1); \
     atomicAdd((unsigned long long*)&P.prof[2], (unsigned long long)_tw_a2); atomicAdd((unsigned long long*)&P.prof[3], (unsigned long long)_tw_a3); atomicAdd((unsigned long long*)&P.prof[4], (unsigned long long)_tw_a4); \
-    atomicAdd((unsigned long long*)&P.prof[5], (unsigned long long)_tw_items); atomicMax((unsigned long long*)&P.prof[6], (unsigned long long)(_tw_a0 + _tw_a1 + _tw_a2 + _tw_a3 + _tw_a4)); } } while (0)
+    atomicAdd((unsigned long long*)&P.prof[5], (unsigned long long)_tw_items); atomicAdd((unsigned long long*)&P.prof[7], (unsigned long long)_tw_fetch); \
+    atomicAdd((unsigned long long*)&P.prof[8], (unsigned long long)(wall_clock64() - _tw_born)); atomicAdd((unsigned long long*)&P.prof[9], 1ull); atomicMin((unsigned long long*)&P.prof[10], (unsigned long long)_tw_born); atomicMax((unsigned long long*)&P.prof[11], (unsigned long long)_tw_born); atomicMax((unsigned long long*)&P.prof[6], (unsigned long long)(_tw_a0 + _tw_a1 + _tw_a2 + _tw_a3 + _tw_a4)); } } while (0)
 #else
 #define TW_PROF_DECL() do {} while (0)
 #define TW_T0() do {} while (0)
@@ -574,6 +575,9 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         const int unit = P.heavy_in_unit[P.heavy_in_off[E] + item], i = P.heavy_in_idx[P.heavy_in_off[E] + item];
         const UnitDev& U = P.units[unit];
         TW_T0();
+#ifdef TW_PROFILE
+        const long long _tw_item0 = wall_clock64();
+#endif
         const int64_t in_start = P.in_start[U.in_off + i], in_end = P.in_end[U.in_off + i];
         Scorer S;
         S.pass = pass;
@@ -751,7 +755,13 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                 leaves += __popcll(feasible);
                 any |= feasible != 0;
                 if (exact_replay) {
-                    unsigned long long todo = feasible;
+                    // A tuple whose score is strictly below the score of the heap minimum is a no-op on a full heap
+                    // of five: heappush sifts it to the root (slots 5 -> 2 -> 0), heappop removes it again and the
+                    // displaced entries return to the slots they came from (the old root wins the comparison at
+                    // slot 2 because no child is less than its parent) -- the array is bit-identical afterwards.
+                    const int nh = __shfl(hp.nheap, 0);
+                    const double hmin = nh == kTopK ? sheap[0].score : -dinf();
+                    unsigned long long todo = __ballot(ok && !(score < hmin));
                     while (todo) {  // in enumeration order, CPython's heappush / heappop replayed by lane 0
                         const int j = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
@@ -887,6 +897,15 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         }
         __syncthreads();
         TW_TICK(4);
+#ifdef TW_PROFILE
+        if (t == 0) {
+            const unsigned long long dur = (unsigned long long)(wall_clock64() - _tw_item0);
+            unsigned long long gsz = 1;
+            for (int e = 0; e < E; e++) gsz *= (unsigned long long)(hi[e] - lo[e] + 1 > 0 ? hi[e] - lo[e] + 1 : 0);
+            if (gsz > 0xfffffffffull) gsz = 0xfffffffffull;
+            atomicMax((unsigned long long*)&P.prof[12], (dur << 40) | (gsz << 4) | (unsigned long long)(exact_replay ? 1 : 0) | (unsigned long long)(ambiguous ? 2 : 0));
+        }
+#endif
     }
 }
 
