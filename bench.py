@@ -114,10 +114,12 @@ def main():
         one_step(eng, args.fit)
     barrier()
     t0 = time.perf_counter()
-    enum_ms, pass_ms = [], []
+    enum_ms, sel_ms, fit_ms, pass_ms = [], [], [], []
     for _ in range(args.steps):
         t1, t2, res = one_step(eng, args.fit)
         enum_ms += [t1["enumerate"], t2["enumerate"]]
+        sel_ms += [t1["select"], t2["select"]]
+        fit_ms += [t2["fit"]]
         pass_ms += [t1["pass"], t2["pass"]]
     barrier()
     dt = time.perf_counter() - t0
@@ -134,10 +136,19 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = spans_total * args.steps / dt
-        # dominant kernel: k_enumerate, one launch per pass over every resident span
-        enum_avg_ms = float(np.mean(enum_ms))
+        # dominant kernel group, measured live with HIP events on the engine's stream (tw_get_timing): the
+        # enumeration kernels and the selection kernels run once per pass, the refit once per step
+        groups = {"k_enumerate": float(np.mean(enum_ms)), "k_select": float(np.mean(sel_ms)), "k_fit": float(np.mean(fit_ms))}
+        dominant = max(groups, key=lambda k: groups[k] * (1 if k == "k_fit" else 2))
         alg_bytes = 20.0 * spans_rank  # per launch: 16 B read + 4 B written per span
-        achieved = alg_bytes / (enum_avg_ms * 1e-3) / 1e9
+        achieved = alg_bytes / (groups[dominant] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/collect.sh)
+            tj = json.load(open(tpath))
+            g = tj["groups"].get(dominant)
+            if g and tj.get("spans_per_launch") == spans_rank:
+                traffic = g["fetch_bytes_x2"] + g["write_bytes"]
         out = {
             "metric": "spans/sec reconstructed + assignment accuracy vs ground truth",
             "value": value, "unit": "spans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -149,9 +160,10 @@ def main():
                        "spans_per_gpu": spans_rank, "parallelism": "units sharded, %d rank(s)" % world},
             "accuracy": acc,
             "gpu_pass_ms": {"pass1": float(np.mean(pass_ms[0::2])), "pass2": float(np.mean(pass_ms[1::2]))},
-            "roofline": {"bound": "hbm", "kernel": "k_enumerate", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel_ms": enum_avg_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel_ms": groups[dominant], "algorithmic_bytes_per_launch": alg_bytes,
+                         "group_ms_per_launch": groups},
         }
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args, 1000)
