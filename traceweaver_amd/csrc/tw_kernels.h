@@ -432,6 +432,136 @@ __device__ void write_result(const Dev& P, const UnitDev& U, int i, int pass, co
     }
 }
 
+// Per-thread enumeration state with compile-time indexing only (the depth-first walk is unrolled by
+// template recursion over the endpoints), so that it lives in registers: no scratch traffic.
+template <int E>
+struct LightCtx {
+    const UnitDev* U;
+    Scorer S;
+    int64_t in_start, in_end;
+    const int64_t* os[E];
+    const int64_t* oe[E];
+    int32_t lo[E], hi[E], x[E];
+    int64_t xs[E], xe[E];
+    double ts[kTopK];          // kept tuples, best first
+    int32_t tidx[kTopK][E];
+    int nk;
+    int64_t leaves;
+    uint64_t bits[E][kCandWords];
+    bool ambiguous;            // an equivalence (equal score, equal start at the first differing span) could matter
+};
+
+// order of the current tuple c.x against kept tuple k when the scores are equal: +1 greater, -1 smaller, 0 equivalent
+template <int E>
+__device__ __forceinline__ int light_tie(const LightCtx<E>& c, int k) {
+    int res = 0;
+    bool done = false;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        int32_t ki = 0;
+#pragma unroll
+        for (int q = 0; q < kTopK; q++) if (q == k) ki = c.tidx[q][e];
+        if (!done && c.x[e] != ki) {
+            const int64_t a = c.xs[e], b2 = c.os[e][ki];
+            res = a > b2 ? 1 : (a < b2 ? -1 : 0);
+            done = true;
+        }
+    }
+    return res;
+}
+
+template <int E>
+__device__ void light_leaf(LightCtx<E>& c, bool want_bits) {
+    c.leaves++;
+    if (want_bits) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int r = c.x[e] - c.lo[e];
+#pragma unroll
+            for (int w = 0; w < kCandWords; w++) if ((r >> 6) == w) c.bits[e][w] |= 1ull << (r & 63);
+        }
+    }
+    // ScoreAssignmentAsPerInvocationGraph, no-skip branch (traceweaver_v1.py:305-361)
+    const UnitDev& U = *c.U;
+    int last = 0;
+    int64_t last_end = c.xe[0];
+#pragma unroll
+    for (int e = 1; e < E; e++) if (c.xe[e] > last_end) { last_end = c.xe[e]; last = e; }
+    double sj = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int np = U.npred[e];
+        for (int j = 0; j < np; j++) {
+            if (!U.pred_prim[e][j]) continue;
+            const int p = U.pred_list[e][j];
+            int64_t pend = 0;
+#pragma unroll
+            for (int q = 0; q < E; q++) if (q == p) pend = c.xe[q];
+            sj += score_term(c.S, slot_prim(E, p, e), pend, c.xs[e]);
+        }
+        if (np == 0) sj += score_term(c.S, slot_root(E, e), c.in_start, c.xs[e]);
+        if (e == last) sj += score_term(c.S, slot_close(E, e), c.xe[e], c.in_end);
+    }
+    // insert into the kept list (strict part of Python's order; equivalences that could matter are flagged)
+    if (c.nk == kTopK && sj < c.ts[kTopK - 1]) return;
+    int tie[kTopK];
+#pragma unroll
+    for (int k = 0; k < kTopK; k++) {
+        tie[k] = 0;
+        if (k < c.nk && sj == c.ts[k]) { tie[k] = light_tie<E>(c, k); if (tie[k] == 0) c.ambiguous = true; }
+    }
+    if (c.nk == kTopK) {
+        if (!(sj > c.ts[kTopK - 1] || (sj == c.ts[kTopK - 1] && tie[kTopK - 1] > 0))) return;
+        if (c.ts[kTopK - 2] == c.ts[kTopK - 1]) {  // the entry that drops out must be the unique minimum
+            bool same = true, decided = false;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int32_t ia = c.tidx[kTopK - 2][e], ib = c.tidx[kTopK - 1][e];
+                if (!decided && ia != ib) { same = c.os[e][ia] == c.os[e][ib]; decided = true; }
+            }
+            if (same) c.ambiguous = true;
+        }
+    }
+    int pos = c.nk < kTopK ? c.nk : kTopK - 1;
+#pragma unroll
+    for (int k = kTopK - 1; k >= 1; k--) {
+        if (k == pos && (sj > c.ts[k - 1] || (sj == c.ts[k - 1] && tie[k - 1] > 0))) {
+            c.ts[k] = c.ts[k - 1];
+#pragma unroll
+            for (int e = 0; e < E; e++) c.tidx[k][e] = c.tidx[k - 1][e];
+            pos = k - 1;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kTopK; k++)
+        if (k == pos) {
+            c.ts[k] = sj;
+#pragma unroll
+            for (int e = 0; e < E; e++) c.tidx[k][e] = c.x[e];
+        }
+    if (c.nk < kTopK) c.nk++;
+}
+
+template <int E, int D>
+__device__ void light_dfs(LightCtx<E>& c, bool want_bits) {
+    if constexpr (D == E) {
+        light_leaf<E>(c, want_bits);
+    } else {
+        const UnitDev& U = *c.U;
+        for (int cx = c.lo[D]; cx <= c.hi[D]; cx++) {
+            const int64_t st = c.os[D][cx], en = c.oe[D][cx];
+            if (c.in_start > st || en > c.in_end) continue;
+            bool ok = true;
+#pragma unroll
+            for (int p = 0; p < D; p++)
+                if (((U.pred_mask[D] >> p) & 1) && c.xe[p] > st) ok = false;
+            if (!ok) continue;
+            c.x[D] = cx; c.xs[D] = st; c.xe[D] = en;
+            light_dfs<E, D + 1>(c, want_bits);
+        }
+    }
+}
+
 template <int E>
 __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
     const int tile = tile_ids[xcd_tile(blockIdx.x, n_tiles_e)];
@@ -439,37 +569,104 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
     const UnitDev& U = P.units[T.unit];
     const int i = T.first + threadIdx.x;
     if (i >= U.n_in) return;
-    Enumerator<E> en(P, U);
-    setup_enumerator<E>(en, P, U, i, pass);
+    LightCtx<E> c;
+    c.U = &U;
+    c.in_start = P.in_start[U.in_off + i];
+    c.in_end = P.in_end[U.in_off + i];
+    c.S.pass = pass;
+    c.S.gp = P.gparam + (U.gp_off + (int64_t)(i / P.batch_size) * U.nslot) * 4;
+    c.S.mix_n = P.mix_n + U.slot_off;
+    c.S.mix_c = P.mix_c + (int64_t)U.slot_off * kMaxComp * 4;
+#pragma unroll
+    for (int e = 0; e < E; e++) { c.os[e] = P.out_start + U.ep_off[e]; c.oe[e] = P.out_end + U.ep_off[e]; }
     // the cut-offs depend on timestamps only: pass 1 computes and keeps them, the wavefront kernel and pass 2
     // read them back instead of repeating 2E dependent searches per span
     if (pass == 1) {
-        en.cutoffs(i);
+        // FindCutoffs (traceweaver_v3.py:182-217), reverse topological order
 #pragma unroll
-        for (int e = 0; e < E; e++) { P.c_lo[ie_index(U, e, i)] = en.lo[e]; P.c_hi[ie_index(U, e, i)] = en.hi[e]; }
+        for (int e = E - 1; e >= 0; e--) {
+            const int n = (int)(U.ep_off[e + 1] - U.ep_off[e]);
+            int64_t tmax = c.in_end;
+#pragma unroll
+            for (int f = e + 1; f < E; f++) {
+                if (!((U.succ_mask[e] >> f) & 1)) continue;
+                const int nf = (int)(U.ep_off[f + 1] - U.ep_off[f]);
+                const int anchor = c.hi[f] >= 0 ? c.hi[f] : nf - 1;  // Python's [-1] wrap (hazard H10)
+                const int64_t st = c.os[f][anchor];
+                if (st < tmax) tmax = st;
+            }
+            c.lo[e] = bound_near<false>(c.os[e], n, c.in_start, i);
+            c.hi[e] = bound_near<true>(c.os[e], n, tmax, c.lo[e]) - 1;
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) { P.c_lo[ie_index(U, e, i)] = c.lo[e]; P.c_hi[ie_index(U, e, i)] = c.hi[e]; }
     } else {
 #pragma unroll
-        for (int e = 0; e < E; e++) { en.lo[e] = P.c_lo[ie_index(U, e, i)]; en.hi[e] = P.c_hi[ie_index(U, e, i)]; }
+        for (int e = 0; e < E; e++) { c.lo[e] = P.c_lo[ie_index(U, e, i)]; c.hi[e] = P.c_hi[ie_index(U, e, i)]; }
     }
     bool wide = false, empty = false;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int w = en.hi[e] - en.lo[e] + 1;
+        const int w = c.hi[e] - c.lo[e] + 1;
         wide |= (w > 64 * kCandWords);
         empty |= (w <= 0);
     }
     if (wide) { raise_err(P, TW_ERR_WINDOW_WIDTH); return; }
     int64_t prod = empty ? 0 : 1;
 #pragma unroll
-    for (int e = 0; e < E; e++) if (prod > 0 && prod <= kLightMax) prod *= (en.hi[e] - en.lo[e] + 1);
+    for (int e = 0; e < E; e++) if (prod > 0 && prod <= kLightMax) prod *= (c.hi[e] - c.lo[e] + 1);
     if (prod > kLightMax) {
         const int slot = atomicAdd(&P.heavy_in_count[E], 1);
         P.heavy_in_unit[P.heavy_in_off[E] + slot] = T.unit;
         P.heavy_in_idx[P.heavy_in_off[E] + slot] = i;
         return;
     }
-    if (pass == 1) en.template dfs<true, true>(nullptr); else en.template dfs<true, false>(nullptr);
-    write_result<E>(P, U, i, pass, en);
+    c.nk = 0; c.leaves = 0; c.ambiguous = false;
+#pragma unroll
+    for (int k = 0; k < kTopK; k++) c.ts[k] = -dinf();
+#pragma unroll
+    for (int e = 0; e < E; e++)
+#pragma unroll
+        for (int w = 0; w < kCandWords; w++) c.bits[e][w] = 0;
+    if (!empty) light_dfs<E, 0>(c, pass == 1);
+    // the kept tuples themselves must be pairwise ordered
+#pragma unroll
+    for (int a2 = 0; a2 < kTopK; a2++)
+#pragma unroll
+        for (int b2 = a2 + 1; b2 < kTopK; b2++)
+            if (b2 < c.nk && c.ts[a2] == c.ts[b2]) {
+                bool same = true, decided = false;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int32_t ia = c.tidx[a2][e], ib = c.tidx[b2][e];
+                    if (!decided && ia != ib) { same = c.os[e][ia] == c.os[e][ib]; decided = true; }
+                }
+                if (same) c.ambiguous = true;
+            }
+    if (c.ambiguous) {  // rare (millisecond-granular data): replay CPython's heapq / list.sort push by push
+        Enumerator<E> en(P, U);
+        setup_enumerator<E>(en, P, U, i, pass);
+#pragma unroll
+        for (int e = 0; e < E; e++) { en.lo[e] = c.lo[e]; en.hi[e] = c.hi[e]; }
+        if (pass == 1) en.template dfs<true, true>(nullptr); else en.template dfs<true, false>(nullptr);
+        write_result<E>(P, U, i, pass, en);
+        return;
+    }
+    const int64_t g = U.in_off + i;
+    P.tk_n[g] = c.nk;
+    P.leaves[g] = c.leaves;
+    P.rep[g] = 0;
+#pragma unroll
+    for (int k = 0; k < kTopK; k++) {
+        P.tk_score[tks_index(U, k, i)] = k < c.nk ? c.ts[k] : dnan();
+#pragma unroll
+        for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, i)] = k < c.nk ? c.tidx[k][e] : -1;
+    }
+    if (pass == 1) {
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            for (int w = 0; w < kCandWords; w++) P.c_bits[ie_index(U, e, i) * kCandWords + w] = c.bits[e][w];
+    }
 }
 
 // CPython heap / sort replay on an LDS-resident heap (k_enumerate_heavy, degenerate-tie spans only)
