@@ -57,7 +57,8 @@ struct tw_engine {
     int32_t* slot_unit = nullptr;
     int32_t* tile_ids = nullptr;            // tiles grouped by the unit's endpoint count
     int32_t tile_cls_off[kMaxEp + 2] = {};  // class E owns tile_ids[tile_cls_off[E] .. tile_cls_off[E+1])
-    uint32_t* seg_gap = nullptr;
+    uint32_t *seg_gap = nullptr, *seg_gap_end = nullptr;
+    uint8_t* slot_scored = nullptr;
     int64_t n_gap_rows = 0;
     double fit_ms = 0.0;
     hipEvent_t ev[EV_COUNT] = {};
@@ -332,16 +333,28 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     if (n_in_total >= (1ll << 31) || n_out_total >= (1ll << 31)) return fail(e, TW_ERR_ARG, "batch exceeds 2^31 spans");
     if (gaps >= (1ll << 31)) return fail(e, TW_ERR_ARG, "batch too large: sum of nslot*n_in must stay below 2^31");
     std::vector<int32_t> slot_unit_h;
-    std::vector<uint32_t> seg_gap_h;
+    std::vector<uint8_t> slot_scored_h;
+    std::vector<uint32_t> seg_gap_h, seg_gap_end_h;  // gap rows of the scored slots only (the others stay NaN and are never fitted)
     for (int u = 0; u < b->n_units; u++) {
         const UnitDev& U = e->units[(size_t)u];
+        const int E = U.E;
         for (int q = 0; q < U.nslot; q++) {
+            bool scored;
+            if (q < E) scored = U.npred[q] == 0;
+            else if (q < E + E * E) {
+                const int p = (q - E) / E, en = (q - E) % E;
+                scored = false;
+                for (int j = 0; j < U.npred[en]; j++) scored |= (U.pred_list[en][j] == p && U.pred_prim[en][j]);
+            } else scored = true;
             slot_unit_h.push_back(u);
-            seg_gap_h.push_back((uint32_t)(e->gs_off_h[(size_t)u] + (int64_t)q * U.n_in));
+            slot_scored_h.push_back(scored ? 1 : 0);
+            if (scored) {
+                seg_gap_h.push_back((uint32_t)(e->gs_off_h[(size_t)u] + (int64_t)q * U.n_in));
+                seg_gap_end_h.push_back((uint32_t)(e->gs_off_h[(size_t)u] + (int64_t)(q + 1) * U.n_in));
+            }
         }
     }
-    seg_gap_h.push_back((uint32_t)gaps);
-    e->n_gap_rows = (int64_t)slot_unit_h.size();
+    e->n_gap_rows = (int64_t)seg_gap_h.size();
     seg_in[(size_t)b->n_units] = (uint32_t)n_in_total;
     seg_out.push_back((uint32_t)n_out_total);
     e->n_seg_out = (int)seg_out.size() - 1;
@@ -385,7 +398,8 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
     ALLOC(e->gaps_sorted, gaps); ALLOC(e->fit_models, slots * kMaxComp * kModelStride);
-    ALLOC(e->slot_unit, slots); ALLOC(e->seg_gap, (int64_t)seg_gap_h.size());
+    ALLOC(e->slot_unit, slots); ALLOC(e->slot_scored, slots);
+    ALLOC(e->seg_gap, (int64_t)seg_gap_h.size()); ALLOC(e->seg_gap_end, (int64_t)seg_gap_end_h.size());
 #undef ALLOC
     P.units = d_units; P.tiles = d_tiles;
     P.in_start = d_is; P.in_end = d_ie; P.out_start = d_os; P.out_end = d_oe;
@@ -405,6 +419,9 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipMemcpyAsync(e->tile_ids, tile_ids_h.data(), sizeof(int32_t) * tile_ids_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->slot_unit, slot_unit_h.data(), sizeof(int32_t) * slot_unit_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->seg_gap, seg_gap_h.data(), sizeof(uint32_t) * seg_gap_h.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->seg_gap_end, seg_gap_end_h.data(), sizeof(uint32_t) * seg_gap_end_h.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->slot_scored, slot_scored_h.data(), slot_scored_h.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(P.gaps, 0xff, sizeof(double) * std::max<int64_t>(gaps, 1), e->stream));  // all-ones = NaN: rows of unscored slots
     HIPCHK(hipMemsetAsync(P.pc, 0, (size_t)n_in_total + 1, e->stream));
     HIPCHK(hipMemsetAsync(e->mix_n_dev, 0, sizeof(int32_t) * std::max<int64_t>(slots, 1), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -453,7 +470,7 @@ int tw_fit_mixtures(tw_engine* e) {
     HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
     size_t bytes = 0;
     const unsigned size = (unsigned)e->n_gaps, nseg = (unsigned)e->n_gap_rows;
-    HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap + 1, 0, 64, e->stream));
+    HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap_end, 0, 64, e->stream));
     if (bytes > e->sort_tmp_bytes) {
         void* q = nullptr;
         HIPCHK(hipMalloc(&q, bytes));
@@ -462,10 +479,10 @@ int tw_fit_mixtures(tw_engine* e) {
         e->sort_tmp_bytes = bytes;
     }
     bytes = e->sort_tmp_bytes;
-    HIPCHK(rocprim::segmented_radix_sort_keys(e->sort_tmp, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap + 1, 0, 64, e->stream));
+    HIPCHK(rocprim::segmented_radix_sort_keys(e->sort_tmp, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap_end, 0, 64, e->stream));
     FitDev F{};
     F.units = e->P.units; F.n_units = e->P.n_units; F.n_slots = e->n_slots; F.sorted = e->gaps_sorted;
-    F.gs_off = e->P.gs_off; F.slot_unit = e->slot_unit; F.models = e->fit_models; F.mix_n = e->mix_n_dev; F.mix_p = e->mix_p_dev;
+    F.gs_off = e->P.gs_off; F.slot_unit = e->slot_unit; F.slot_scored = e->slot_scored; F.models = e->fit_models; F.mix_n = e->mix_n_dev; F.mix_p = e->mix_p_dev;
     hipLaunchKernelGGL(k_fit_em, dim3((unsigned)(e->n_slots * kMaxComp)), dim3(e->coop >= 64 ? kFitThreads : e->coop), 0, e->stream, F);
     hipLaunchKernelGGL(k_fit_select, dim3((unsigned)((e->n_slots + 63) / 64)), dim3(64), 0, e->stream, F);
     const int64_t total = e->n_slots * kMaxComp;

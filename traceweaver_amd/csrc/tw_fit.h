@@ -33,6 +33,7 @@ struct FitDev {
     const double* sorted;   // gap rows sorted ascending, NaN (dropped) last; row q of unit u at gs_off[u] + q*n_in
     const int64_t* gs_off;
     const int32_t* slot_unit;  // [n_slots] owning unit
+    const uint8_t* slot_scored;  // [n_slots] 1 <=> the slot is a scored edge (its gap row is sorted and fitted)
     double* models;         // [n_slots][kMaxComp][kModelStride]
     int32_t* mix_n;         // [n_slots]
     double* mix_p;          // [n_slots][kMaxComp][3] weight, mean, precision_cholesky
@@ -73,6 +74,10 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
     const int n_all = U.n_in;
     const double* x = F.sorted + F.gs_off[F.slot_unit[q]] + (q - U.slot_off) * (int64_t)n_all;
     double* model = F.models + (q * kMaxComp + (k - 1)) * kModelStride;
+    if (!F.slot_scored[q]) {
+        if (t == 0) model[0] = dinf();
+        return;
+    }
     // every per-thread array below is indexed by compile-time constants only (loops over the components are
     // unrolled to kMaxComp and predicated with j < k), so nothing spills to scratch memory
     double c2[2];

@@ -1902,18 +1902,17 @@ __global__ void k_gaps(Dev P) {
     const int64_t ist = P.in_start[U.in_off + i], ien = P.in_end[U.in_off + i];
     int32_t x[kMaxEp];
     for (int e = 0; e < E; e++) x[e] = P.parent[ie_index(U, e, i)];
-    for (int q = 0; q < U.nslot; q++) out[(int64_t)q * U.n_in + i] = dnan();
+    // only the rows of scored slots are written; the others were filled with NaN once at load time
     for (int e = 0; e < E; e++) {
-        if (x[e] < 0) continue;
-        const int64_t st = P.out_start[U.ep_off[e] + x[e]], en = P.out_end[U.ep_off[e] + x[e]];
-        if (U.npred[e] == 0) out[(int64_t)slot_root(E, e) * U.n_in + i] = (double)(st - ist);
+        const bool have = x[e] >= 0;
+        const int64_t st = have ? P.out_start[U.ep_off[e] + x[e]] : 0, en = have ? P.out_end[U.ep_off[e] + x[e]] : 0;
+        if (U.npred[e] == 0) out[(int64_t)slot_root(E, e) * U.n_in + i] = have ? (double)(st - ist) : dnan();
         for (int j = 0; j < U.npred[e]; j++) {
             if (!U.pred_prim[e][j]) continue;
             const int p = U.pred_list[e][j];
-            if (x[p] < 0) continue;
-            out[(int64_t)slot_prim(E, p, e) * U.n_in + i] = (double)(st - P.out_end[U.ep_off[p] + x[p]]);
+            out[(int64_t)slot_prim(E, p, e) * U.n_in + i] = (have && x[p] >= 0) ? (double)(st - P.out_end[U.ep_off[p] + x[p]]) : dnan();
         }
-        out[(int64_t)slot_close(E, e) * U.n_in + i] = (double)(ien - en);
+        out[(int64_t)slot_close(E, e) * U.n_in + i] = have ? (double)(ien - en) : dnan();
     }
 }
 
