@@ -12,7 +12,8 @@ STRESS = [
     (1, 400, "chain3", 1.5, 1), (2, 400, "chain3", 4, 1), (3, 300, "chain3", 8, 1), (4, 300, "par2", 6, 1),
     (5, 300, "diamond", 5, 1), (6, 400, "single", 10, 1), (7, 300, "par4", 3, 1), (8, 300, "chain2", 12, 1000),
     (9, 300, "chain3", 4, 1000), (10, 200, "fan6", 2, 1), (11, 257, "single", 1.2, 1), (12, 2, "chain2", 1, 1),
-    (13, 513, "par2", 2, 1000),
+    (13, 513, "par2", 2, 1000), (14, 150, "chain5", 2.5, 1), (15, 120, "mix7", 1.5, 1), (16, 100, "mix8", 1.3, 1),
+    (17, 120, "mix8", 1.2, 1000),
 ]
 
 

@@ -61,3 +61,46 @@ def test_error_statuses(emu_lib):
         eng.run_pass2()
     assert ei.value.code == -4
     eng.close()
+
+
+def test_one_shot_entry_point(emu_lib):
+    """tw_assign_service (the single-unit convenience of the C-ABI) through raw ctypes."""
+    import ctypes
+
+    import tw_oracle as T
+    from traceweaver_amd import _ffi, synth
+
+    u, _ = synth.make_unit(51, 300, shape="chain3", concurrency=2)
+    lib = _ffi.load(emu_lib)
+    h = ctypes.c_void_p()
+    assert lib.tw_create(0, ctypes.byref(h)) == 0
+    parent = np.empty(u.E * u.n_in, np.int32)
+    chosen = np.empty(u.n_in, np.int32)
+    res = _ffi.Results(parent.ctypes.data, 0, 0, 0, chosen.ctypes.data, 0, 0, 0)
+    rc = lib.tw_assign_service(h, u.n_in, u.in_start.ctypes.data, u.in_end.ctypes.data, u.E, u.out_off.ctypes.data,
+                               u.out_start.ctypes.data, u.out_end.ctypes.data, u.dag.ctypes.data, u.key_rank.ctypes.data,
+                               None, None, ctypes.byref(res))
+    assert rc == 0, lib.tw_last_error(h)
+    lib.tw_destroy(h)
+    svc = parity.oracle_service(u)
+    end_flag, _, _ = T.windows(svc)
+    o = T.run_pass(svc, end_flag, gauss=T.gauss_params(svc))
+    assert np.array_equal(parent.reshape(u.E, u.n_in), o["parent"]) and np.array_equal(chosen, o["chosen"])
+
+
+def test_window_width_limit_is_reported(emu_lib):
+    """More than 128 candidate spans at one endpoint for one incoming span: TW_ERR_WINDOW_WIDTH, not a wrong answer."""
+    from traceweaver_amd.engine import Engine, EngineError, UnitArrays
+
+    n = 200
+    in_start = np.arange(n, dtype=np.int64) * 10 + 1_000_000
+    in_end = in_start + 100_000                       # every request spans all the others
+    out_start = in_start + 5
+    out_end = out_start + 3
+    u = UnitArrays(in_start, in_end, [0, n], out_start, out_end, [[0]])
+    eng = Engine(0, lib_path=emu_lib)
+    eng.load([u])
+    with pytest.raises(EngineError) as ei:
+        eng.run_pass1()
+    assert ei.value.code == -5
+    eng.close()

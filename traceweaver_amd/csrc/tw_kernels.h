@@ -564,6 +564,7 @@ __device__ void light_dfs(LightCtx<E>& c, bool want_bits) {
 
 template <int E>
 __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
+    if (*P.err != 0) return;  // e.g. NaN parameters (hazard H3): nothing downstream is meaningful
     const int tile = tile_ids[xcd_tile(blockIdx.x, n_tiles_e)];
     const TileDev T = P.tiles[tile];
     const UnitDev& U = P.units[T.unit];
@@ -747,6 +748,7 @@ struct LdsHeap {
 // what differs per lane (its grid point) sits in registers addressed by compile-time indices.
 template <int E>
 __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass) {
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     constexpr int W = 64 * kCandWords;
     __shared__ unsigned long long sbits[kMaxEp][kCandWords];
     // LDS-staged candidate window of the span: start / end of every candidate outgoing span, and the two
@@ -1151,6 +1153,7 @@ struct ScanWinId {  // inclusive count of window ends; the window id is count - 
 
 template <class Tr>
 __global__ void k_scan_local(Dev P, typename Tr::T* agg) {
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     __shared__ typename Tr::T sh[kTile];
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
@@ -1162,6 +1165,7 @@ __global__ void k_scan_local(Dev P, typename Tr::T* agg) {
 }
 template <class Tr>
 __global__ void k_scan_spine(Dev P, typename Tr::T* agg) {  // one workgroup per unit: exclusive scan of its tiles
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     __shared__ typename Tr::T sh[kTile];
     __shared__ typename Tr::T carry_sh;
     const UnitDev& U = P.units[blockIdx.x];
@@ -1182,6 +1186,7 @@ __global__ void k_scan_spine(Dev P, typename Tr::T* agg) {  // one workgroup per
 }
 template <class Tr>
 __global__ void k_scan_fix(Dev P, const typename Tr::T* agg) {
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
@@ -1192,6 +1197,7 @@ __global__ void k_scan_fix(Dev P, const typename Tr::T* agg) {
 // PerfectCut(i) (traceweaver_v3.py:1024-1039): candidates of the latest-ending earlier span and of
 // span i are disjoint, and that earlier span ends no later than span i.
 __global__ void k_perfect_cut(Dev P) {
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
@@ -1224,6 +1230,7 @@ __global__ void k_perfect_cut(Dev P) {
 // Window ends (traceweaver_v3.py:1056-1076): the last span, the span before every PerfectCut, and a
 // size cut every batch_size_mis spans counted from the segment start.
 __global__ void k_window_flags(Dev P) {
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
@@ -1240,6 +1247,7 @@ __global__ void k_window_flags(Dev P) {
     P.win_end[g] = end ? 1 : 0;
 }
 __global__ void k_window_index(Dev P) {  // after the ScanWinId scan: wid currently holds the inclusive count
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
@@ -1682,6 +1690,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
 }
 
 __global__ void __launch_bounds__(kTile) k_select(Dev P) {  // one thread per window; windows with a hard component are deferred
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int w = Tl.first + threadIdx.x;
@@ -1700,6 +1709,7 @@ __global__ void __launch_bounds__(kTile) k_select(Dev P) {  // one thread per wi
     }
 }
 __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent workgroups, one deferred window at a time
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     __shared__ SelectLds L;
     __shared__ int next_item;
     const int count = *P.heavy_count;
@@ -1723,6 +1733,7 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
 // result is final unless one of its candidate spans was taken by an earlier window.  k_claim /
 // k_detect find those windows, k_repair re-solves them in window order.
 __global__ void k_claim(Dev P) {
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
@@ -1733,6 +1744,7 @@ __global__ void k_claim(Dev P) {
     for (int e = 0; e < U.E; e++) atomicMin(&P.owner[U.ep_off[e] + cand_idx(P, U, i, c, e)], w);
 }
 __global__ void k_detect(Dev P) {
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
@@ -1793,6 +1805,7 @@ __device__ void repair_span(const Dev& P, const UnitDev& U, int i, int pass, con
 // One workgroup per unit walks the flagged windows in increasing order.  When window w is visited
 // every earlier window is final, so the set of consumed spans it sees is exact.
 __global__ void __launch_bounds__(kTile) k_repair(Dev P, int pass) {
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     __shared__ int next_w;
     __shared__ int any_gone;
     __shared__ uint64_t gone[kMaxWin][kMaxEp][kCandWords];
@@ -1880,6 +1893,7 @@ __global__ void __launch_bounds__(kTile) k_repair(Dev P, int pass) {
 
 // ---------------------------------------------------------------------------------------------
 __global__ void k_finalize(Dev P) {
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
@@ -1893,6 +1907,7 @@ __global__ void k_finalize(Dev P) {
 
 // Gap samples of the current assignment per scored slot (traceweaver_v3.py:717-762); NaN = dropped.
 __global__ void k_gaps(Dev P) {
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;

@@ -24,6 +24,9 @@ SHAPES = {
     "par4": [(0, 1, 2, 3)],                       # media nginx: four parallel calls
     "diamond": [(0,), (1, 2), (3,)],
     "fan6": [(0,), (1, 2, 3, 4), (5,)],
+    "chain5": [(0,), (1,), (2,), (3,), (4,)],
+    "mix7": [(0, 1), (2,), (3, 4, 5), (6,)],
+    "mix8": [(0,), (1, 2, 3), (4, 5), (6,), (7,)],   # TW_MAX_EP endpoints
 }
 
 # the six accelerated services of media_microservices (E in {1,1,1,1,2,4})
