@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--concurrency", type=float, default=1.6, help="mean requests in flight per service")
     ap.add_argument("--fit", default="device", choices=["device", "sklearn"], help="mixture refit between the passes")
     ap.add_argument("--cpu-sample", type=int, default=4000, help="requests per service in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the timing collectives (nccl = RCCL; gloo lets several ranks share one GPU for testing)")
     return ap.parse_args()
 
 
@@ -89,11 +91,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
 
+    device = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend="gloo")
+    torch.cuda.set_device(device)
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     from traceweaver_amd import synth
     from traceweaver_amd.engine import Engine
@@ -101,7 +108,7 @@ def main():
     units, truth = synth.make_workload(1000 + rank, args.n_in, services=synth.MEDIA_SERVICES, replicas=args.replicas,
                                        concurrency=args.concurrency)
     spans_rank = sum(u.n_spans for u in units)
-    eng = Engine(local_rank)
+    eng = Engine(device)
     eng.load(units)
 
     def barrier():
@@ -124,10 +131,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        s = torch.tensor([spans_rank], dtype=torch.float64, device="cuda")
+        s = torch.tensor([spans_rank], dtype=torch.float64, device=red_dev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         spans_total = float(s.item())
     else:
