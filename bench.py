@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--replicas", type=int, default=4, help="copies of the 6-service media graph per GPU")
     ap.add_argument("--concurrency", type=float, default=1.6, help="mean requests in flight per service")
     ap.add_argument("--fit", default="device", choices=["device", "sklearn"], help="mixture refit between the passes")
-    ap.add_argument("--cpu-sample", type=int, default=4000, help="requests per service in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=40000, help="requests per service in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the timing collectives (nccl = RCCL; gloo lets several ranks share one GPU for testing)")
     return ap.parse_args()

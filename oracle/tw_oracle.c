@@ -708,6 +708,35 @@ static int match_prunes(mwis_comp *c, int d, double acc) {
     return 0;
 }
 
+/* exact optimum of the in-spans d..d+g-1 taken alone (g <= 3): every combination of one eligible candidate or
+ * "none" per in-span whose candidates share no span; weights added left to right */
+#define TWO_GROUP 3
+static double group_opt(const mwis_comp *c, int d, int g) {
+    double best = 0.0;
+    for (int a = 0; a <= c->n[d]; a++) {
+        double sa = a < c->n[d] ? c->w[d][a] : 0.0;
+        if (g == 1) { if (sa > best) best = sa; continue; }
+        for (int b = 0; b <= c->n[d + 1]; b++) {
+            double sb = sa;
+            if (b < c->n[d + 1]) {
+                if (a < c->n[d] && shares(c->E, c->idx[d][a], c->idx[d + 1][b])) continue;
+                sb = a < c->n[d] ? sa + c->w[d + 1][b] : c->w[d + 1][b];
+            }
+            if (g == 2) { if (sb > best) best = sb; continue; }
+            for (int k = 0; k <= c->n[d + 2]; k++) {
+                double sc = sb;
+                if (k < c->n[d + 2]) {
+                    if (a < c->n[d] && shares(c->E, c->idx[d][a], c->idx[d + 2][k])) continue;
+                    if (b < c->n[d + 1] && shares(c->E, c->idx[d + 1][b], c->idx[d + 2][k])) continue;
+                    sc = (a < c->n[d] || b < c->n[d + 1]) ? sb + c->w[d + 2][k] : c->w[d + 2][k];
+                }
+                if (sc > best) best = sc;
+            }
+        }
+    }
+    return best;
+}
+
 static int two_plain_nodes = 2048;  /* the matching relaxation is consulted from this many search nodes on */
 static int two_node_budget = 4096;  /* search nodes per component; beyond it the incumbent is returned */
 #define TWO_MATCH_MIN_DEPTH 4       /* ... and only where at least this many in-spans remain below the node */
@@ -736,9 +765,10 @@ static void mwis_dfs(mwis_comp *c, int d, double acc) {
  *   nodes with weight 10000+score <= 0 are never selected; the window is split into connected
  *   components of the in-span conflict relation; each component is searched depth-first over its
  *   in-spans in index order, candidates in list order then "none", sums accumulated left to right,
- *   a subtree is cut when acc + upper bound <= best (upper bound = sum of the remaining in-spans'
- *   best weights; once the component's search has visited TWO_PLAIN_NODES nodes additionally the
- *   matching relaxation above), and only strict improvements replace the incumbent.  The answer is the first
+ *   a subtree is cut when acc + upper bound <= best (upper bound = the remaining in-spans cut into
+ *   groups of <= 3 consecutive in-spans, each solved exactly on its own, cheapest cutting; once the
+ *   component's search has visited TWO_PLAIN_NODES nodes additionally the matching relaxation above),
+ *   and only strict improvements replace the incumbent.  The answer is the first
  *   optimal selection in that depth-first order; it does not depend on the bounds.  A component whose
  *   search exceeds TWO_NODE_BUDGET nodes returns its incumbent and is reported (stats[4]).
  *   chosen[i] = candidate index or -1. */
@@ -769,8 +799,17 @@ static int64_t mwis_window(const two_service *s, int m, const int *ncand, two_ca
                 c.kk[d][c.n[d]] = a; c.w[d][c.n[d]] = w; c.idx[d][c.n[d]] = cands[i][a].idx; c.n[d]++;
             }
         }
+        /* upper bound of the suffix d..m-1: cut it into groups of 1-3 consecutive in-spans, solve every group
+         * exactly on its own (conflicts inside the group only) and take the cheapest cutting */
         c.ub[c.m] = 0.0;
-        for (int d = c.m - 1; d >= 0; d--) { double mx = 0.0; for (int j = 0; j < c.n[d]; j++) if (c.w[d][j] > mx) mx = c.w[d][j]; c.ub[d] = c.ub[d + 1] + mx; }
+        for (int d = c.m - 1; d >= 0; d--) {
+            double u = 0.0;
+            for (int g = 1; g <= TWO_GROUP && d + g <= c.m; g++) {
+                double cand = group_opt(&c, d, g) + c.ub[d + g];
+                if (g == 1 || cand < u) u = cand;
+            }
+            c.ub[d] = u;
+        }
         for (int d = 0; d < c.m; d++) { c.cur[d] = -1; c.best[d] = -1; }
         c.best_w = 0.0;
         mwis_dfs(&c, 0, 0.0);

@@ -51,6 +51,7 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
 }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorEmu; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 
@@ -58,12 +59,13 @@ template <class K, class... A>
 inline void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
     gridDim = grid;
     blockDim = block;
-    for (unsigned b = 0; b < grid.x; b++)
-        for (unsigned t = 0; t < block.x; t++) {
-            blockIdx = dim3(b, 0, 0);
-            threadIdx = dim3(t, 0, 0);
-            kernel(args...);
-        }
+    for (unsigned by = 0; by < grid.y; by++)
+        for (unsigned b = 0; b < grid.x; b++)
+            for (unsigned t = 0; t < block.x; t++) {
+                blockIdx = dim3(b, by, 0);
+                threadIdx = dim3(t, 0, 0);
+                kernel(args...);
+            }
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
 

@@ -77,6 +77,7 @@ struct Dev {
     int32_t* w_last;    // [in_off + w] last span of window w
     int32_t* unit_nwin; // [n_units]
     uint8_t* w_dirty;   // [in_off + w] window needs the exact repair walk
+    uint8_t* w_conf;    // [in_off + w] the spans' best candidates clash: the window needs the exact search
     int32_t* unit_ndirty;
     int32_t* tk_n;      // candidates found on all spans (top_k_2)
     int64_t* leaves;

@@ -54,12 +54,16 @@ struct tw_engine {
     double* mix_c_dev = nullptr;
     double* gaps_sorted = nullptr;
     double* fit_models = nullptr;
+    double* fit_uval = nullptr;
+    int32_t *fit_ustart = nullptr, *fit_row_n = nullptr, *fit_row_uniq = nullptr;
     int32_t* slot_unit = nullptr;
     int32_t* tile_ids = nullptr;            // tiles grouped by the unit's endpoint count
     int32_t tile_cls_off[kMaxEp + 2] = {};  // class E owns tile_ids[tile_cls_off[E] .. tile_cls_off[E+1])
     uint32_t *seg_gap = nullptr, *seg_gap_end = nullptr;
     uint8_t* slot_scored = nullptr;
     int64_t n_gap_rows = 0;
+    unsigned long long* key_acc = nullptr;  // [2] scratch of k_key_bits
+    unsigned ts_end_bit = 64;               // timestamps differ only below this bit (whole batch)
     double fit_ms = 0.0;
     hipEvent_t ev[EV_COUNT] = {};
     double ms[6] = {0, 0, 0, 0, 0, 0};
@@ -126,6 +130,27 @@ void launch_enumerate(tw_engine* e, int pass) {
     hipLaunchKernelGGL((k_enumerate_heavy<E>), dim3(grid), dim3(std::min(e->coop, kHeavyThreads)), 0, e->stream, P, pass);
 }
 
+// OR of (key ^ first key) and of the keys themselves over a set of index ranges (see k_key_bits)
+int key_bits(tw_engine* e, const void* keys, const uint32_t* seg_begin, const uint32_t* seg_end, int nseg, int64_t total,
+             unsigned long long out[2]) {
+    out[0] = out[1] = 0;
+    if (nseg <= 0 || total <= 0) return TW_OK;
+    HIPCHK(hipMemsetAsync(e->key_acc, 0, 2 * sizeof(unsigned long long), e->stream));
+    const int bx = (int)std::min<int64_t>(std::max<int64_t>(2048 / nseg, 1), total / nseg / 2048 + 1);  // ~2k workgroups at most
+    hipLaunchKernelGGL(k_key_bits, dim3((unsigned)bx, (unsigned)std::min(nseg, 1024)), dim3(e->coop >= 64 ? 256 : e->coop), 0, e->stream,
+                       (const unsigned long long*)keys, seg_begin, seg_end, nseg, e->key_acc);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, e->key_acc, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TW_OK;
+}
+
+unsigned bit_length(unsigned long long x) {
+    unsigned n = 0;
+    while (x) { n++; x >>= 1; }
+    return n;
+}
+
 int sort_ends(tw_engine* e) {
     const Dev& P = e->P;
     for (int which = 0; which < 2; which++) {
@@ -135,7 +160,7 @@ int sort_ends(tw_engine* e) {
         const unsigned nseg = (unsigned)(which == 0 ? P.n_units : e->n_seg_out);
         const uint32_t* off = which == 0 ? e->seg_in : e->seg_out;
         size_t bytes = 0;
-        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, bytes, in, out, size, nseg, off, off + 1, 0, 64, e->stream));
+        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, bytes, in, out, size, nseg, off, off + 1, 0, e->ts_end_bit, e->stream));
         if (bytes > e->sort_tmp_bytes) {
             void* q = nullptr;
             HIPCHK(hipMalloc(&q, bytes));
@@ -144,7 +169,7 @@ int sort_ends(tw_engine* e) {
             e->sort_tmp_bytes = bytes;
         }
         bytes = e->sort_tmp_bytes;
-        HIPCHK(rocprim::segmented_radix_sort_keys(e->sort_tmp, bytes, in, out, size, nseg, off, off + 1, 0, 64, e->stream));
+        HIPCHK(rocprim::segmented_radix_sort_keys(e->sort_tmp, bytes, in, out, size, nseg, off, off + 1, 0, e->ts_end_bit, e->stream));
     }
     return TW_OK;
 }
@@ -186,6 +211,8 @@ int run_pass(tw_engine* e, int pass) {
         HIPCHK(hipMemsetAsync(P.w_dirty, 0, (size_t)P.n_in_total, e->stream));
     }
     HIPCHK(hipEventRecord(e->ev[EV_WIN], e->stream));
+    HIPCHK(hipMemsetAsync(P.w_conf, 0, (size_t)P.n_in_total, e->stream));
+    hipLaunchKernelGGL(k_select_fast, tiles, tb, 0, e->stream, P);
     hipLaunchKernelGGL(k_select, tiles, tb, 0, e->stream, P);
     hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096)), dim3(std::min(e->coop, 64)), 0, e->stream, P);
     HIPCHK(hipEventRecord(e->ev[EV_SEL], e->stream));
@@ -379,7 +406,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(e->mix_n_dev, slots); ALLOC(e->mix_p_dev, slots * kMaxComp * 3); ALLOC(e->mix_c_dev, slots * kMaxComp * 4);
     ALLOC(P.pm_val, n_in_total); ALLOC(P.pm_idx, n_in_total); ALLOC(P.pc, n_in_total + 1); ALLOC(P.seg, n_in_total);
     ALLOC(P.win_end, n_in_total); ALLOC(P.wid, n_in_total); ALLOC(P.w_last, n_in_total);
-    ALLOC(P.unit_nwin, P.n_units); ALLOC(P.w_dirty, n_in_total); ALLOC(P.unit_ndirty, P.n_units);
+    ALLOC(P.unit_nwin, P.n_units); ALLOC(P.w_dirty, n_in_total); ALLOC(P.w_conf, n_in_total); ALLOC(P.unit_ndirty, P.n_units);
     ALLOC(P.tk_n, n_in_total); ALLOC(P.leaves, n_in_total); ALLOC(P.chosen, n_in_total); ALLOC(P.rep, n_in_total);
     ALLOC(P.tkr_n, n_in_total);
     ALLOC(P.tk_idx, ie * kTopK); ALLOC(P.tkr_idx, ie * kTopK);
@@ -391,13 +418,14 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(e->tile_ids, (int64_t)tile_ids_h.size());
     ALLOC(P.heavy_in_count, kMaxEp + 1); ALLOC(P.heavy_in_next, kMaxEp + 1); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
-    ALLOC(P.prof, 16);
+    ALLOC(P.prof, 16); ALLOC(e->key_acc, 2);
     HIPCHK(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 16, e->stream));
     HIPCHK(hipMemsetAsync(P.prof + 10, 0xff, sizeof(unsigned long long), e->stream));
     ALLOC(P.heavy_count, 1); ALLOC(P.heavy_next, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
     ALLOC(e->gaps_sorted, gaps); ALLOC(e->fit_models, slots * kMaxComp * kModelStride);
+    ALLOC(e->fit_uval, gaps); ALLOC(e->fit_ustart, gaps); ALLOC(e->fit_row_n, slots); ALLOC(e->fit_row_uniq, slots);
     ALLOC(e->slot_unit, slots); ALLOC(e->slot_scored, slots);
     ALLOC(e->seg_gap, (int64_t)seg_gap_h.size()); ALLOC(e->seg_gap_end, (int64_t)seg_gap_end_h.size());
 #undef ALLOC
@@ -425,6 +453,17 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipMemsetAsync(P.pc, 0, (size_t)n_in_total + 1, e->stream));
     HIPCHK(hipMemsetAsync(e->mix_n_dev, 0, sizeof(int32_t) * std::max<int64_t>(slots, 1), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    {   // end times of one batch share their upper bits: the sorts of run_pass only look at the bits that differ.
+        // All keys must agree above end_bit, so both arrays are measured against the same reference key.
+        unsigned long long a[2], b[2], first_in = 0, first_out = 0;
+        rc = key_bits(e, d_ie, e->seg_in, e->seg_in + 1, P.n_units, n_in_total, a);
+        if (rc == TW_OK) rc = key_bits(e, d_oe, e->seg_out, e->seg_out + 1, e->n_seg_out, n_out_total, b);
+        if (rc != TW_OK) return rc;
+        HIPCHK(hipMemcpy(&first_in, d_ie, sizeof(first_in), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&first_out, d_oe, sizeof(first_out), hipMemcpyDeviceToHost));
+        e->ts_end_bit = std::max(1u, bit_length(a[0] | b[0] | (first_in ^ first_out)));
+        if (e->ts_end_bit > 63) e->ts_end_bit = 64;  // keys of both signs: full width (sign handling is rocprim's)
+    }
     e->state = ST_LOADED;
     return TW_OK;
 }
@@ -470,7 +509,15 @@ int tw_fit_mixtures(tw_engine* e) {
     HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
     size_t bytes = 0;
     const unsigned size = (unsigned)e->n_gaps, nseg = (unsigned)e->n_gap_rows;
-    HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap_end, 0, 64, e->stream));
+    // gap samples are non-negative integers (and NaN = 0x7ff8...0) stored as doubles: their low mantissa bits
+    // are all zero, the sort starts at the lowest bit set anywhere.  A negative key (none can occur: children
+    // lie inside their parent and follow their predecessors) would flip rocprim's key transform -> full width.
+    unsigned long long kb[2];
+    int rck = key_bits(e, e->P.gaps, e->seg_gap, e->seg_gap_end, (int)nseg, e->n_gaps, kb);
+    if (rck != TW_OK) return rck;
+    unsigned begin_bit = 0;
+    if (kb[1] != 0 && !(kb[1] >> 63)) while (!((kb[1] >> begin_bit) & 1)) begin_bit++;
+    HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap_end, begin_bit, 64, e->stream));
     if (bytes > e->sort_tmp_bytes) {
         void* q = nullptr;
         HIPCHK(hipMalloc(&q, bytes));
@@ -479,10 +526,12 @@ int tw_fit_mixtures(tw_engine* e) {
         e->sort_tmp_bytes = bytes;
     }
     bytes = e->sort_tmp_bytes;
-    HIPCHK(rocprim::segmented_radix_sort_keys(e->sort_tmp, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap_end, 0, 64, e->stream));
+    HIPCHK(rocprim::segmented_radix_sort_keys(e->sort_tmp, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap_end, begin_bit, 64, e->stream));
     FitDev F{};
     F.units = e->P.units; F.n_units = e->P.n_units; F.n_slots = e->n_slots; F.sorted = e->gaps_sorted;
     F.gs_off = e->P.gs_off; F.slot_unit = e->slot_unit; F.slot_scored = e->slot_scored; F.models = e->fit_models; F.mix_n = e->mix_n_dev; F.mix_p = e->mix_p_dev;
+    F.uval = e->fit_uval; F.ustart = e->fit_ustart; F.row_n = e->fit_row_n; F.row_uniq = e->fit_row_uniq;
+    hipLaunchKernelGGL(k_fit_compress, dim3((unsigned)e->n_slots), dim3(e->coop), 0, e->stream, F);
     hipLaunchKernelGGL(k_fit_em, dim3((unsigned)(e->n_slots * kMaxComp)), dim3(e->coop >= 64 ? kFitThreads : e->coop), 0, e->stream, F);
     hipLaunchKernelGGL(k_fit_select, dim3((unsigned)((e->n_slots + 63) / 64)), dim3(64), 0, e->stream, F);
     const int64_t total = e->n_slots * kMaxComp;

@@ -11,6 +11,10 @@
 // samples.  One workgroup runs one (edge, k) fit start to finish, so every reduction has a fixed
 // order and the result is a pure function of the samples.
 //
+// Gaps are integer microseconds, so a row of 10^5 samples holds only 10^2..10^4 distinct values:
+// k_fit_compress turns every sorted row into (value, multiplicity) runs once, and all EM sums run over
+// the runs with the multiplicity as weight (the same sums, grouped by value).
+//
 // traceweaver_amd/gmm.py::fit_edge_sklearn keeps the reference procedure for comparison; pass 2 is
 // bit-exact against the oracle for *any* mixture table (tests feed the fitted tables to both).
 #pragma once
@@ -34,6 +38,10 @@ struct FitDev {
     const int64_t* gs_off;
     const int32_t* slot_unit;  // [n_slots] owning unit
     const uint8_t* slot_scored;  // [n_slots] 1 <=> the slot is a scored edge (its gap row is sorted and fitted)
+    double* uval;           // run-length form of every sorted row: distinct values ascending (row offsets as in `sorted`) ...
+    int32_t* ustart;        // ... and the index of each value's first occurrence in the sorted row
+    int32_t* row_n;         // [n_slots] samples (non-NaN entries) of the row
+    int32_t* row_uniq;      // [n_slots] distinct values of the row
     double* models;         // [n_slots][kMaxComp][kModelStride]
     int32_t* mix_n;         // [n_slots]
     double* mix_p;          // [n_slots][kMaxComp][3] weight, mean, precision_cholesky
@@ -64,6 +72,56 @@ __device__ inline void block_reduce(double (&vals)[cnt], double* sh) {
     __syncthreads();
 }
 
+// One workgroup per scored row: distinct values and their first positions (a head is a sample that differs
+// from its left neighbour; NaN = dropped samples, sorted last, are not counted).
+__global__ void __launch_bounds__(kTile) k_fit_compress(FitDev F) {
+    __shared__ int32_t sh[kTile];
+    __shared__ int32_t carry_sh, n_sh;
+    const int64_t q = blockIdx.x;
+    const int t = threadIdx.x, nt = blockDim.x;
+    if (!F.slot_scored[q]) {
+        if (t == 0) { F.row_n[q] = 0; F.row_uniq[q] = 0; }
+        return;
+    }
+    const UnitDev& U = F.units[F.slot_unit[q]];
+    const int n_all = U.n_in;
+    const int64_t row = F.gs_off[F.slot_unit[q]] + (q - U.slot_off) * (int64_t)n_all;
+    const double* x = F.sorted + row;
+    if (t == 0) { carry_sh = 0; n_sh = 0; }
+    __syncthreads();
+    for (int base = 0; base < n_all; base += nt) {
+        const int i = base + t;
+        double xi = 0.0;
+        bool valid = false, head = false;
+        if (i < n_all) {
+            xi = x[i];
+            valid = xi == xi;
+            head = valid && (i == 0 || x[i - 1] != xi);
+        }
+        // inclusive scan of the head flags
+        sh[t] = head ? 1 : 0;
+        __syncthreads();
+        for (int off = 1; off < nt; off <<= 1) {
+            int a = sh[t];
+            if (t >= off) a += sh[t - off];
+            __syncthreads();
+            sh[t] = a;
+            __syncthreads();
+        }
+        const int carry = carry_sh;
+        if (head) {
+            const int pos = carry + sh[t] - 1;
+            F.uval[row + pos] = xi;
+            F.ustart[row + pos] = i;
+        }
+        if (valid && (i == n_all - 1 || !(x[i + 1] == x[i + 1]))) n_sh = i + 1;  // last sample of the row
+        __syncthreads();
+        if (t == nt - 1) carry_sh = carry + sh[t];
+        __syncthreads();
+    }
+    if (t == 0) { F.row_n[q] = n_sh; F.row_uniq[q] = carry_sh; }
+}
+
 __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
     __shared__ double sh[kFitStats * kFitWaves];
     __shared__ double par[3 * kMaxComp];  // w, mu, var
@@ -71,39 +129,33 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
     const int k = (int)(blockIdx.x % kMaxComp) + 1;
     const int t = threadIdx.x, nt = blockDim.x;
     const UnitDev& U = F.units[F.slot_unit[q]];
-    const int n_all = U.n_in;
-    const double* x = F.sorted + F.gs_off[F.slot_unit[q]] + (q - U.slot_off) * (int64_t)n_all;
+    const int64_t row = F.gs_off[F.slot_unit[q]] + (q - U.slot_off) * (int64_t)U.n_in;
+    const double* xv = F.uval + row;      // distinct values, ascending
+    const int32_t* xa = F.ustart + row;   // first index of each value in the sorted row
     double* model = F.models + (q * kMaxComp + (k - 1)) * kModelStride;
-    if (!F.slot_scored[q]) {
+    const int n = F.row_n[q], uniq = F.row_uniq[q];
+    if (!F.slot_scored[q] || n == 0 || k > uniq || k > kMaxComp) {
         if (t == 0) model[0] = dinf();
         return;
     }
     // every per-thread array below is indexed by compile-time constants only (loops over the components are
     // unrolled to kMaxComp and predicated with j < k), so nothing spills to scratch memory
-    double c2[2];
-    c2[0] = 0.0; c2[1] = 0.0;
-    for (int i = t; i < n_all; i += nt) {
-        const double xi = x[i];
-        if (xi != xi) continue;
-        c2[0] += 1.0;
-        if (i == 0 || x[i - 1] != xi) c2[1] += 1.0;
-    }
-    block_reduce<2>(c2, sh);
-    const int n = (int)c2[0];
-    const int uniq = (int)c2[1];
-    if (n == 0 || k > uniq || k > kMaxComp) {
-        if (t == 0) model[0] = dinf();
-        return;
-    }
-    // initialisation: equal-count buckets of the sorted samples
+    // initialisation: equal-count buckets of the sorted samples -- sample i belongs to bucket floor(i*k/n),
+    // i.e. bucket c owns the index range [ceil(c*n/k), ceil((c+1)*n/k))
     double b2[2 * kMaxComp];
 #pragma unroll
     for (int c = 0; c < 2 * kMaxComp; c++) b2[c] = 0.0;
-    for (int i = t; i < n; i += nt) {
-        const int j = (int)(((int64_t)i * k) / n);
-        const double xi = x[i];
+    for (int r = t; r < uniq; r += nt) {
+        const int64_t a = xa[r], b = r + 1 < uniq ? xa[r + 1] : n;
+        const double xi = xv[r];
 #pragma unroll
-        for (int q = 0; q < kMaxComp; q++) if (q == j) { b2[q] += 1.0; b2[kMaxComp + q] += xi; }
+        for (int c = 0; c < kMaxComp; c++) {
+            if (c < k) {
+                const int64_t lo = ((int64_t)c * n + k - 1) / k, hi = ((int64_t)(c + 1) * n + k - 1) / k;
+                const int64_t ov = (b < hi ? b : hi) - (a > lo ? a : lo);
+                if (ov > 0) { b2[c] += (double)ov; b2[kMaxComp + c] += (double)ov * xi; }
+            }
+        }
     }
     block_reduce<2 * kMaxComp>(b2, sh);
     if (t == 0) {
@@ -114,11 +166,18 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
     double b1[kMaxComp];
 #pragma unroll
     for (int c = 0; c < kMaxComp; c++) b1[c] = 0.0;
-    for (int i = t; i < n; i += nt) {
-        const int j = (int)(((int64_t)i * k) / n);
-        const double d = x[i] - par[kMaxComp + j];
+    for (int r = t; r < uniq; r += nt) {
+        const int64_t a = xa[r], b = r + 1 < uniq ? xa[r + 1] : n;
+        const double xi = xv[r];
 #pragma unroll
-        for (int q = 0; q < kMaxComp; q++) if (q == j) b1[q] += d * d;
+        for (int c = 0; c < kMaxComp; c++) {
+            if (c < k) {
+                const int64_t lo = ((int64_t)c * n + k - 1) / k, hi = ((int64_t)(c + 1) * n + k - 1) / k;
+                const int64_t ov = (b < hi ? b : hi) - (a > lo ? a : lo);
+                const double d = xi - par[kMaxComp + c];
+                if (ov > 0) b1[c] += (double)ov * (d * d);
+            }
+        }
     }
     block_reduce<kMaxComp>(b1, sh);
     if (t == 0) {
@@ -126,7 +185,7 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
         for (int j = 0; j < kMaxComp; j++) if (j < k) par[2 * kMaxComp + j] = b1[j] / (par[j] * (double)n) + kFitRegCovar;
     }
     __syncthreads();
-    // EM
+    // EM over the runs, multiplicity as weight
     double prev_lb = -dinf();
     for (int iter = 0; iter <= kFitMaxIter; iter++) {
         double lw[kMaxComp], mu[kMaxComp], iv[kMaxComp], v[kFitStats];
@@ -140,8 +199,9 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
         }
 #pragma unroll
         for (int c = 0; c < kFitStats; c++) v[c] = 0.0;
-        for (int i = t; i < n; i += nt) {
-            const double xi = x[i];
+        for (int r = t; r < uniq; r += nt) {
+            const double xi = xv[r];
+            const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
             double lp[kMaxComp], mx = -dinf();
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) {
@@ -154,15 +214,15 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
             double s = 0.0;
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) if (j < k) { lp[j] = exp(lp[j] - mx); s += lp[j]; }
-            v[3 * kMaxComp] += mx + log(s);
-            const double inv = 1.0 / s;
+            v[3 * kMaxComp] += cw * (mx + log(s));
+            const double inv = cw / s;
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) {
                 if (j < k) {
-                    const double r = lp[j] * inv, d = xi - mu[j];
-                    v[j] += r;
-                    v[kMaxComp + j] += r * d;
-                    v[2 * kMaxComp + j] += r * d * d;
+                    const double r2 = lp[j] * inv, d = xi - mu[j];
+                    v[j] += r2;
+                    v[kMaxComp + j] += r2 * d;
+                    v[2 * kMaxComp + j] += r2 * d * d;
                 }
             }
         }

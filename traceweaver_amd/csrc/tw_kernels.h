@@ -75,6 +75,37 @@ __device__ __forceinline__ int bound_near(const int64_t* a, int n, int64_t t, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// Which key bits differ at all?  acc[0] |= key ^ first key, acc[1] |= key, over `nseg` index ranges.  The radix
+// sorts then skip the bit positions that are the same in every key (timestamps of one corpus share their
+// upper ~34 bits; gap samples are integers stored as doubles, their low mantissa bits are zero).
+__global__ void k_key_bits(const unsigned long long* keys, const uint32_t* seg_begin, const uint32_t* seg_end, int nseg,
+                           unsigned long long* acc) {
+    const unsigned long long k0 = keys[seg_begin[0]];
+    unsigned long long diff = 0, any = 0;
+    for (int s = blockIdx.y; s < nseg; s += gridDim.y) {
+        const uint32_t a = seg_begin[s], b = seg_end[s];
+        for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
+            const unsigned long long k = keys[i];
+            diff |= k ^ k0;
+            any |= k;
+        }
+    }
+    // one atomic pair per workgroup: wavefronts by shuffles, then through LDS
+    __shared__ unsigned long long sh_diff, sh_any;
+    if (threadIdx.x == 0) { sh_diff = 0; sh_any = 0; }
+    __syncthreads();
+    for (int off = 32; off >= 1; off >>= 1) {
+        if (off < (int)blockDim.x) { diff |= __shfl_down(diff, off); any |= __shfl_down(any, off); }
+    }
+    if ((threadIdx.x & 63) == 0) { atomicOr(&sh_diff, diff); atomicOr(&sh_any, any); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (sh_diff & ~acc[0]) atomicOr(&acc[0], sh_diff);
+        if (sh_any & ~acc[1]) atomicOr(&acc[1], sh_any);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Pass-1 Gaussian parameters: one thread per (unit, 100-span block, slot).
 // mean = (sum t2 - sum t1)/n over rank-aligned sorted arrays, std = sqrt(ceil(n/10)) * tstd(batch means).
 __global__ void k_block_params(Dev P, int64_t total) {
@@ -1289,7 +1320,9 @@ __device__ inline bool cands_share(const Dev& P, const UnitDev& U, int i, int a,
 //   depth-first over its spans in index order, candidates in list order then "none", sums accumulated
 //   left to right; a subtree is cut when acc + upper bound <= best; only strict improvements replace the
 //   incumbent.  The answer is the first optimal selection in that depth-first order and does not depend
-//   on the bound.  Upper bound: sum of the remaining spans' best weights; once a component's search has
+//   on the bound.  Upper bound: the remaining spans cut into groups of <= 3 consecutive spans, every group
+//   solved exactly on its own, cheapest cutting (the sum of the best weights is the all-singletons cutting;
+//   pairs and triples see spans that compete for the same outgoing spans); once a component's search has
 //   visited kPlainNodes nodes, at nodes with >= kMatchMinDepth spans left additionally the matching
 //   relaxation: relax every endpoint but e -- what remains is a maximum-weight bipartite matching between
 //   the remaining spans and the outgoing spans of endpoint e (edge weight = best still-compatible
@@ -1298,9 +1331,10 @@ __device__ inline bool cands_share(const Dev& P, const UnitDev& U, int i, int a,
 //   A component whose search exceeds kNodeBudget nodes keeps its incumbent and the window is counted in
 //   unit_stats[4].
 //
-// Mapping: k_select runs one thread per window and finishes every window whose components all resolve
-// inside the plain phase (all of them on the reference corpora); the others are re-solved from scratch
-// by k_select_heavy, one workgroup per window, candidate data and the Hungarian state in LDS, the
+// Mapping: k_select_fast settles the windows whose best candidates do not clash (one lane per span);
+// k_select runs one thread per remaining window of < kCoopMinSpans spans with the singleton cutting only
+// (any valid bound gives the same answer) and gives up after kLightNodes nodes; the others are solved
+// from scratch by k_select_heavy, one workgroup per window, candidate data and the Hungarian state in LDS, the
 // column scans of the Hungarian algorithm spread over the lanes.
 constexpr int kPlainNodes = 2048;    // the matching relaxation is consulted from this many search nodes on ...
 constexpr int kMatchMinDepth = 4;    // ... and only where at least this many spans remain below the node
@@ -1308,9 +1342,9 @@ constexpr int kNodeBudget = 4096;    // search nodes per component; beyond it th
 constexpr int kMatchMaxCols = 256;   // widest span-index range one endpoint's relaxation may address
 constexpr int kMaxCols = kMatchMaxCols + kMaxWin + 1;
 constexpr int kUsedWords = 4;        // 256-span window of the per-endpoint "taken" bitmap in k_select_heavy
-constexpr int kLightNodes = 64; 
-constexpr int kCoopMinSpans = 4;     // windows with at least this many spans are solved by k_select_heavy     // k_select hands a window over to k_select_heavy after this many nodes (<= kPlainNodes;
+constexpr int kLightNodes = 64;      // k_select hands a window over to k_select_heavy after this many nodes (<= kPlainNodes;
                                      // an engine-internal split: the search itself is the same in both kernels)
+constexpr int kCoopMinSpans = 4;     // conflicted windows with at least this many spans are solved by k_select_heavy
 
 // ---- light path: thread-private, plain bound only -------------------------------------------------
 __device__ bool select_window_light(const Dev& P, const UnitDev& U, int first, int m) {
@@ -1412,6 +1446,7 @@ struct SelectLds {
     uint8_t used[kMaxCols], ncand[kMaxWin], comp[kMaxWin], mem[kMaxWin], ndeg[kMaxWin];
     int8_t cur[kMaxWin], best[kMaxWin], next[kMaxWin + 1], pick[kMaxWin];
     uint32_t adj[kMaxWin];  // span conflict relation as bit rows
+    unsigned long long g2[kMaxWin], g3[kMaxWin];  // bit patterns of the pair / triple optima of the grouped bound (weights are > 0)
     uint64_t used_bits[kMaxEp][kUsedWords];  // spans taken by the current partial selection, per endpoint, relative to ubase
     int32_t ubase[kMaxEp];
     int cm, d, nodes, entered, state, j0, j1, nrow, ncol_real, budget_hit, base, top, prune, use_bits;
@@ -1653,13 +1688,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             int cm = 0;
             for (int b = root; b < m; b++) if (L.comp[b] == root) L.mem[cm++] = (uint8_t)b;
             L.cm = cm;
-            L.ub[cm] = 0.0;
-            for (int d = cm - 1; d >= 0; d--) {
-                double mx = 0.0;
-                for (int k = 0; k < L.ncand[L.mem[d]]; k++) if (L.w[L.mem[d]][k] > mx) mx = L.w[L.mem[d]][k];
-                L.ub[d] = L.ub[d + 1] + mx;
-            }
-            for (int d = 0; d < cm; d++) { L.cur[d] = -1; L.best[d] = -1; }
+            for (int d = 0; d < cm; d++) { L.cur[d] = -1; L.best[d] = -1; L.g2[d] = 0; L.g3[d] = 0; }
             L.use_bits = 1;
             for (int e = 0; e < E; e++) {
                 int32_t lo = 0x7fffffff, hi = -1;
@@ -1671,6 +1700,45 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
                 L.ubase[e] = lo;
                 if (hi - lo >= 64 * kUsedWords) L.use_bits = 0;
                 for (int q = 0; q < kUsedWords; q++) L.used_bits[e][q] = 0;
+            }
+        }
+        __syncthreads();
+        {   // Upper bound of a suffix d..cm-1 of the component: cut it into groups of 1-3 consecutive spans, solve
+            // every group exactly on its own (conflicts inside the group only) and take the cheapest cutting.  It
+            // sees spans that compete for the same outgoing spans (one of them must stay unassigned: -10000), which
+            // the sum of best weights does not.  All pairs and triples are evaluated at once, one (group, combination)
+            // per lane; weights are positive doubles, so the maximum is taken on their bit patterns.
+            const int cm = L.cm, npair = cm > 1 ? cm - 1 : 0, ntrip = cm > 2 ? cm - 2 : 0;
+            constexpr int C = kTopK + 1;  // choices per span: a candidate or "none"
+            const int total = npair * C * C + ntrip * C * C * C;
+            for (int q = t; q < total; q += nt) {
+                int d, g, ch[3];
+                if (q < npair * C * C) { d = q / (C * C); const int c = q % (C * C); ch[0] = c / C; ch[1] = c % C; ch[2] = kTopK; g = 2; }
+                else { const int r = q - npair * C * C; d = r / (C * C * C); const int c = r % (C * C * C); ch[0] = c / (C * C); ch[1] = (c / C) % C; ch[2] = c % C; g = 3; }
+                bool ok = true;
+                double sum = 0.0;
+                for (int x = 0; x < g && ok; x++) {
+                    if (ch[x] == kTopK) continue;  // "none"
+                    const int b = L.mem[d + x];
+                    if (ch[x] >= L.ncand[b] || !(L.w[b][ch[x]] > 0.0)) { ok = false; break; }
+                    for (int y = 0; y < x && ok; y++)
+                        if (ch[y] != kTopK && lds_share(L, E, L.mem[d + y], ch[y], b, ch[x])) ok = false;
+                    sum += L.w[b][ch[x]];  // left to right
+                }
+                if (ok && sum > 0.0) atomicMax(g == 2 ? &L.g2[d] : &L.g3[d], (unsigned long long)__double_as_longlong(sum));
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            const int cm = L.cm;
+            L.ub[cm] = 0.0;
+            for (int d = cm - 1; d >= 0; d--) {
+                double mx = 0.0;
+                for (int k = 0; k < L.ncand[L.mem[d]]; k++) if (L.w[L.mem[d]][k] > mx) mx = L.w[L.mem[d]][k];
+                double u = mx + L.ub[d + 1];
+                if (d + 2 <= cm) { const double c2 = __longlong_as_double((long long)L.g2[d]) + L.ub[d + 2]; if (c2 < u) u = c2; }
+                if (d + 3 <= cm) { const double c3 = __longlong_as_double((long long)L.g3[d]) + L.ub[d + 3]; if (c3 < u) u = c3; }
+                L.ub[d] = u;
             }
             L.best_w = 0.0; L.nodes = 0; L.d = 0; L.accs[0] = 0.0; L.entered = 1; L.state = SEL_RUN;
             select_step(L, E, false);
@@ -1689,7 +1757,39 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(kTile) k_select(Dev P) {  // one thread per window; windows with a hard component are deferred
+// Fast path, one lane per incoming span.  When the best candidates (list position 0) of a window's spans
+// use pairwise different outgoing spans, "everybody takes position 0" is the selection the canonical search
+// returns: it is the first leaf of the depth-first order (position 0 is tried first and nothing clashes), its
+// weight equals the upper bound sum-of-best-weights, and only strict improvements replace the incumbent.
+// A span whose best weight is <= 0 has no eligible candidate at all (lists are sorted) and stays unassigned
+// in every selection.  ~90-99 % of the windows end here; the others are flagged in w_conf and searched by
+// k_select / k_select_heavy.
+__global__ void __launch_bounds__(kTile) k_select_fast(Dev P) {
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
+    const TileDev Tl = P.tiles[blockIdx.x];
+    const UnitDev& U = P.units[Tl.unit];
+    const int i = Tl.first + threadIdx.x;
+    if (i >= U.n_in) return;
+    const int64_t g = U.in_off + i;
+    const bool ok = P.tk_n[g] > 0 && 10000.0 + P.tk_score[tks_index(U, 0, i)] > 0.0;
+    P.chosen[g] = ok ? 0 : -1;
+    if (!ok) return;
+    const int w = P.wid[g];
+    const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
+    if (first >= i || i - first >= kMaxWin) return;  // (an over-long window is reported by k_select)
+    uint32_t elig = 0;
+    for (int j = first; j < i; j++)
+        if (P.tk_n[U.in_off + j] > 0 && 10000.0 + P.tk_score[tks_index(U, 0, j)] > 0.0) elig |= 1u << (j - first);
+    bool clash = false;
+    for (int e = 0; e < U.E && !clash; e++) {
+        const int32_t mine = P.tk_idx[tk_index(U, 0, e, i)];
+        for (uint32_t rest = elig; rest != 0 && !clash; rest &= rest - 1)
+            clash = P.tk_idx[tk_index(U, 0, e, first + __ffs((int)rest) - 1)] == mine;
+    }
+    if (clash) P.w_conf[U.in_off + w] = 1;
+}
+
+__global__ void __launch_bounds__(kTile) k_select(Dev P) {  // one thread per conflicted window; windows with a hard component are deferred
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
@@ -1700,6 +1800,7 @@ __global__ void __launch_bounds__(kTile) k_select(Dev P) {  // one thread per wi
     const int m = last - first + 1;
     if (m <= 0) return;
     if (m > kMaxWin) { raise_err(P, TW_ERR_WINDOW_SIZE); return; }
+    if (!P.w_conf[U.in_off + w]) return;  // settled by k_select_fast
     // windows of several spans go to the workgroup kernel straight away: their candidate lists are compared
     // pairwise (O(m^2) tuple comparisons), which is cheap from LDS and spread over the lanes there
     if (m >= kCoopMinSpans || !select_window_light(P, U, first, m)) {
