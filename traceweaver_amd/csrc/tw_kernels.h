@@ -422,7 +422,10 @@ __device__ void setup_enumerator(Enumerator<E>& en, const Dev& P, const UnitDev&
 // spreads the tuples of the trailing endpoints over its lanes -- feasibility and the log-likelihood (the
 // costly part) run in parallel, the heap is then fed in enumeration order (wave-uniform pushes) so that
 // ties resolve exactly as in the sequential reference.
-constexpr int kLightMax = 48;
+#ifndef TW_LIGHT_MAX
+#define TW_LIGHT_MAX 48
+#endif
+constexpr int kLightMax = TW_LIGHT_MAX;  // largest candidate product the per-thread kernel enumerates itself
 constexpr int kHeavyThreads = 64;
 
 // Optional phase timers (build with -DTW_PROFILE; read back through tw_debug_profile): cycles spent by
