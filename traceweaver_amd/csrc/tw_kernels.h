@@ -483,7 +483,18 @@ struct LightCtx {
     int64_t leaves;
     uint64_t bits[E][kCandWords];
     bool ambiguous;            // an equivalence (equal score, equal start at the first differing span) could matter
+    double troot[E], tclose[E];  // root / closing term of the span currently chosen at each level
+    double* tab;               // this thread's column of the workgroup's LDS term table (stride = workgroup size)
+    int tab_stride;
 };
+
+// Terms that depend on one outgoing span only -- root(in.start -> s.start) and closing(s.end -> in.end),
+// traceweaver_v1.py:349-357 -- are tabulated once per candidate span (the first light_tab_width<E>() candidates of
+// every endpoint, in LDS) instead of being evaluated at every tuple that contains the span; wider endpoints fall
+// back to evaluating at the tree level where the span is chosen.  The tuple score adds the same doubles in the
+// same order, so it is bit-identical.
+template <int E>
+__host__ __device__ constexpr int light_tab_width() { return E == 1 ? 0 : E == 2 ? 8 : E == 3 ? 6 : E == 4 ? 5 : E == 5 ? 4 : E == 6 ? 3 : 2; }
 
 // order of the current tuple c.x against kept tuple k when the scores are equal: +1 greater, -1 smaller, 0 equivalent
 template <int E>
@@ -533,8 +544,8 @@ __device__ void light_leaf(LightCtx<E>& c, bool want_bits) {
             for (int q = 0; q < E; q++) if (q == p) pend = c.xe[q];
             sj += score_term(c.S, slot_prim(E, p, e), pend, c.xs[e]);
         }
-        if (np == 0) sj += score_term(c.S, slot_root(E, e), c.in_start, c.xs[e]);
-        if (e == last) sj += score_term(c.S, slot_close(E, e), c.xe[e], c.in_end);
+        if (np == 0) sj += c.troot[e];
+        if (e == last) sj += c.tclose[e];
     }
     // insert into the kept list (strict part of Python's order; equivalences that could matter are flagged)
     if (c.nk == kTopK && sj < c.ts[kTopK - 1]) return;
@@ -591,6 +602,15 @@ __device__ void light_dfs(LightCtx<E>& c, bool want_bits) {
                 if (((U.pred_mask[D] >> p) & 1) && c.xe[p] > st) ok = false;
             if (!ok) continue;
             c.x[D] = cx; c.xs[D] = st; c.xe[D] = en;
+            constexpr int Wt = light_tab_width<E>();
+            const int r = cx - c.lo[D];
+            if (r < Wt) {
+                c.troot[D] = c.tab[(D * Wt + r) * 2 * c.tab_stride];
+                c.tclose[D] = c.tab[((D * Wt + r) * 2 + 1) * c.tab_stride];
+            } else {
+                c.troot[D] = U.npred[D] == 0 ? score_term(c.S, slot_root(E, D), c.in_start, st) : 0.0;
+                c.tclose[D] = score_term(c.S, slot_close(E, D), en, c.in_end);
+            }
             light_dfs<E, D + 1>(c, want_bits);
         }
     }
@@ -663,6 +683,24 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
     for (int e = 0; e < E; e++)
 #pragma unroll
         for (int w = 0; w < kCandWords; w++) c.bits[e][w] = 0;
+    {   // term table of this thread: [endpoint][candidate][root, closing], one LDS column per thread
+        constexpr int Wt = light_tab_width<E>();
+        __shared__ double tab[(Wt > 0 ? E * Wt * 2 : 1) * kTile];
+        c.tab = tab + threadIdx.x;
+        c.tab_stride = blockDim.x;
+        if (!empty) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int w = c.hi[e] - c.lo[e] + 1;
+                for (int r = 0; r < Wt && r < w; r++) {
+                    const int64_t st = c.os[e][c.lo[e] + r], en = c.oe[e][c.lo[e] + r];
+                    if (c.in_start > st || en > c.in_end) continue;  // not contained: never part of a tuple
+                    c.tab[(e * Wt + r) * 2 * c.tab_stride] = U.npred[e] == 0 ? score_term(c.S, slot_root(E, e), c.in_start, st) : 0.0;
+                    c.tab[((e * Wt + r) * 2 + 1) * c.tab_stride] = score_term(c.S, slot_close(E, e), en, c.in_end);
+                }
+            }
+        }
+    }
     if (!empty) light_dfs<E, 0>(c, pass == 1);
     // the kept tuples themselves must be pairwise ordered
 #pragma unroll
@@ -830,11 +868,27 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             const int64_t* oe = P.out_end + U.ep_off[e];
             for (int r = t; r < w; r += nt) {
                 const int c = lo[e] + r;
-                const int64_t st = os[c], e2 = oe[c];
-                ls[e][r] = st;
-                le[e][r] = e2;
-                troot[e][r] = U.npred[e] == 0 ? score_term(S, slot_root(E, e), in_start, st) : 0.0;
-                tclose[e][r] = score_term(S, slot_close(E, e), e2, in_end);
+                ls[e][r] = os[c];
+                le[e][r] = oe[c];
+            }
+        }
+        __syncthreads();
+        {   // one (candidate span, root | closing) term per lane, all endpoints at once
+            int wsum = 0;
+#pragma unroll
+            for (int e = 0; e < E; e++) wsum += hi[e] - lo[e] + 1;
+            for (int q = t; q < 2 * wsum; q += nt) {
+                int es = 0, r = q >> 1;
+                bool found = false;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int w = hi[e] - lo[e] + 1;
+                    if (!found) { if (r < w) { es = e; found = true; } else r -= w; }
+                }
+                const int64_t st = ls[es][r], e2 = le[es][r];
+                if (in_start > st || e2 > in_end) continue;  // not contained: never part of a tuple
+                if (q & 1) tclose[es][r] = score_term(S, slot_close(E, es), e2, in_end);
+                else troot[es][r] = U.npred[es] == 0 ? score_term(S, slot_root(E, es), in_start, st) : 0.0;
             }
         }
         // Python orders (score, [spans]) tuples by score, then by start_mus of the first differing span; two
