@@ -15,4 +15,12 @@ inline hipError_t segmented_radix_sort_keys(void* temp, size_t& bytes, const Key
     for (unsigned s = 0; s < segments; s++) std::sort(out + begin[s], out + end[s], less);
     return hipSuccess;
 }
+template <class Key>
+inline hipError_t radix_sort_keys(void* temp, size_t& bytes, const Key* in, Key* out, size_t size, unsigned = 0, unsigned = 64,
+                                  hipStream_t = nullptr, bool = false) {
+    if (temp == nullptr) { bytes = 16; return hipSuccess; }
+    std::copy(in, in + size, out);
+    std::sort(out, out + size);
+    return hipSuccess;
+}
 }  // namespace rocprim

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -59,7 +60,10 @@ struct tw_engine {
     int32_t* slot_unit = nullptr;
     int32_t* tile_ids = nullptr;            // tiles grouped by the unit's endpoint count
     int32_t tile_cls_off[kMaxEp + 2] = {};  // class E owns tile_ids[tile_cls_off[E] .. tile_cls_off[E+1])
-    uint32_t *seg_gap = nullptr, *seg_gap_end = nullptr;
+    uint32_t *seg_gap = nullptr, *seg_gap_end = nullptr, *seg_gap_dst = nullptr;
+    unsigned long long *comp_a = nullptr, *comp_b = nullptr;  // composite keys of sort_rows
+    int64_t comp_cap = 0, n_gap_scored = 0;
+    unsigned long long ts_fixed = 0;        // the bits all end times share above ts_end_bit
     uint8_t* slot_scored = nullptr;
     int64_t n_gap_rows = 0;
     unsigned long long* key_acc = nullptr;  // [2] scratch of k_key_bits
@@ -151,27 +155,61 @@ unsigned bit_length(unsigned long long x) {
     return n;
 }
 
-int sort_ends(tw_engine* e) {
-    const Dev& P = e->P;
-    for (int which = 0; which < 2; which++) {
-        const int64_t* in = which == 0 ? P.in_end : P.out_end;
-        int64_t* out = which == 0 ? P.in_end_sorted : P.out_end_sorted;
-        const unsigned size = (unsigned)(which == 0 ? P.n_in_total : P.n_out_total);
-        const unsigned nseg = (unsigned)(which == 0 ? P.n_units : e->n_seg_out);
-        const uint32_t* off = which == 0 ? e->seg_in : e->seg_out;
-        size_t bytes = 0;
-        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, bytes, in, out, size, nseg, off, off + 1, 0, e->ts_end_bit, e->stream));
-        if (bytes > e->sort_tmp_bytes) {
-            void* q = nullptr;
-            HIPCHK(hipMalloc(&q, bytes));
-            e->allocs.push_back(q);
-            e->sort_tmp = q;
-            e->sort_tmp_bytes = bytes;
-        }
-        bytes = e->sort_tmp_bytes;
-        HIPCHK(rocprim::segmented_radix_sort_keys(e->sort_tmp, bytes, in, out, size, nseg, off, off + 1, 0, e->ts_end_bit, e->stream));
+int ensure_sort_tmp(tw_engine* e, size_t bytes) {
+    if (bytes > e->sort_tmp_bytes) {
+        void* q = nullptr;
+        HIPCHK(hipMalloc(&q, bytes));
+        e->allocs.push_back(q);
+        e->sort_tmp = q;
+        e->sort_tmp_bytes = bytes;
     }
     return TW_OK;
+}
+
+// Sorts every row [seg_begin[s], seg_end[s]) of 64-bit keys ascending into `out` (same positions).  Only the bits
+// [begin_bit, end_bit) differ between keys and none of them is a sign bit that is set (callers check); `fixed` holds
+// the common bits.  dst_off[s] = position of row s in the packed array (rows back to back), `packed` = its size.
+// One device-wide radix sort over composite keys (see k_rows_pack); rows too many / keys too wide for 64 bits fall
+// back to rocprim's segmented sort on the raw keys.
+template <class Key>
+int sort_rows(tw_engine* e, const Key* keys, Key* out, unsigned size, const uint32_t* seg_begin, const uint32_t* seg_end,
+              const uint32_t* dst_off, int nseg, int64_t packed, unsigned begin_bit, unsigned end_bit, unsigned long long fixed) {
+    if (nseg <= 0 || packed <= 0) return TW_OK;
+    unsigned segbits = 0;
+    while ((1u << segbits) < (unsigned)nseg) segbits++;
+    const unsigned kb = end_bit - begin_bit;
+    size_t bytes = 0;
+    const bool mixed_signs = std::is_signed<Key>::value && end_bit >= 64;  // composite keys compare unsigned
+    if (kb + segbits > 64 || kb == 0 || packed > e->comp_cap || mixed_signs) {
+        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, bytes, keys, out, size, (unsigned)nseg, seg_begin, seg_end, begin_bit, end_bit, e->stream));
+        int rc = ensure_sort_tmp(e, bytes);
+        if (rc != TW_OK) return rc;
+        bytes = e->sort_tmp_bytes;
+        HIPCHK(rocprim::segmented_radix_sort_keys(e->sort_tmp, bytes, keys, out, size, (unsigned)nseg, seg_begin, seg_end, begin_bit, end_bit, e->stream));
+        return TW_OK;
+    }
+    const int bx = (int)std::min<int64_t>(std::max<int64_t>(4096 / nseg, 1), packed / nseg / 1024 + 1);
+    const dim3 grid((unsigned)bx, (unsigned)std::min(nseg, 1024)), block(e->coop >= 64 ? 256 : e->coop);
+    hipLaunchKernelGGL(k_rows_pack, grid, block, 0, e->stream, (const unsigned long long*)keys, seg_begin, seg_end, dst_off, nseg,
+                       (int)begin_bit, (int)kb, e->comp_a);
+    HIPCHK(rocprim::radix_sort_keys(nullptr, bytes, e->comp_a, e->comp_b, (size_t)packed, 0u, kb + segbits, e->stream));
+    int rc = ensure_sort_tmp(e, bytes);
+    if (rc != TW_OK) return rc;
+    bytes = e->sort_tmp_bytes;
+    HIPCHK(rocprim::radix_sort_keys(e->sort_tmp, bytes, e->comp_a, e->comp_b, (size_t)packed, 0u, kb + segbits, e->stream));
+    hipLaunchKernelGGL(k_rows_unpack, grid, block, 0, e->stream, (const unsigned long long*)e->comp_b, seg_begin, seg_end, dst_off, nseg,
+                       (int)begin_bit, (int)kb, fixed, (unsigned long long*)out);
+    HIPCHK(hipGetLastError());
+    return TW_OK;
+}
+
+int sort_ends(tw_engine* e) {
+    const Dev& P = e->P;
+    int rc = sort_rows(e, P.in_end, P.in_end_sorted, (unsigned)P.n_in_total, e->seg_in, e->seg_in + 1, e->seg_in, P.n_units, P.n_in_total,
+                       0, e->ts_end_bit, e->ts_fixed);
+    if (rc != TW_OK) return rc;
+    return sort_rows(e, P.out_end, P.out_end_sorted, (unsigned)P.n_out_total, e->seg_out, e->seg_out + 1, e->seg_out, e->n_seg_out,
+                     P.n_out_total, 0, e->ts_end_bit, e->ts_fixed);
 }
 
 int run_pass(tw_engine* e, int pass) {
@@ -382,6 +420,9 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         }
     }
     e->n_gap_rows = (int64_t)seg_gap_h.size();
+    std::vector<uint32_t> seg_gap_dst_h(seg_gap_h.size());
+    e->n_gap_scored = 0;
+    for (size_t r = 0; r < seg_gap_h.size(); r++) { seg_gap_dst_h[r] = (uint32_t)e->n_gap_scored; e->n_gap_scored += seg_gap_end_h[r] - seg_gap_h[r]; }
     seg_in[(size_t)b->n_units] = (uint32_t)n_in_total;
     seg_out.push_back((uint32_t)n_out_total);
     e->n_seg_out = (int)seg_out.size() - 1;
@@ -427,7 +468,9 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(e->gaps_sorted, gaps); ALLOC(e->fit_models, slots * kMaxComp * kModelStride);
     ALLOC(e->fit_uval, gaps); ALLOC(e->fit_ustart, gaps); ALLOC(e->fit_row_n, slots); ALLOC(e->fit_row_uniq, slots);
     ALLOC(e->slot_unit, slots); ALLOC(e->slot_scored, slots);
-    ALLOC(e->seg_gap, (int64_t)seg_gap_h.size()); ALLOC(e->seg_gap_end, (int64_t)seg_gap_end_h.size());
+    ALLOC(e->seg_gap, (int64_t)seg_gap_h.size()); ALLOC(e->seg_gap_end, (int64_t)seg_gap_end_h.size()); ALLOC(e->seg_gap_dst, (int64_t)seg_gap_dst_h.size());
+    e->comp_cap = std::max(std::max(n_in_total, n_out_total), e->n_gap_scored);
+    ALLOC(e->comp_a, e->comp_cap); ALLOC(e->comp_b, e->comp_cap);
 #undef ALLOC
     P.units = d_units; P.tiles = d_tiles;
     P.in_start = d_is; P.in_end = d_ie; P.out_start = d_os; P.out_end = d_oe;
@@ -448,6 +491,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipMemcpyAsync(e->slot_unit, slot_unit_h.data(), sizeof(int32_t) * slot_unit_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->seg_gap, seg_gap_h.data(), sizeof(uint32_t) * seg_gap_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->seg_gap_end, seg_gap_end_h.data(), sizeof(uint32_t) * seg_gap_end_h.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->seg_gap_dst, seg_gap_dst_h.data(), sizeof(uint32_t) * seg_gap_dst_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->slot_scored, slot_scored_h.data(), slot_scored_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemsetAsync(P.gaps, 0xff, sizeof(double) * std::max<int64_t>(gaps, 1), e->stream));  // all-ones = NaN: rows of unscored slots
     HIPCHK(hipMemsetAsync(P.pc, 0, (size_t)n_in_total + 1, e->stream));
@@ -463,6 +507,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         HIPCHK(hipMemcpy(&first_out, d_oe, sizeof(first_out), hipMemcpyDeviceToHost));
         e->ts_end_bit = std::max(1u, bit_length(a[0] | b[0] | (first_in ^ first_out)));
         if (e->ts_end_bit > 63) e->ts_end_bit = 64;  // keys of both signs: full width (sign handling is rocprim's)
+        e->ts_fixed = e->ts_end_bit >= 64 ? 0ull : (first_in >> e->ts_end_bit) << e->ts_end_bit;
     }
     e->state = ST_LOADED;
     return TW_OK;
@@ -517,16 +562,18 @@ int tw_fit_mixtures(tw_engine* e) {
     if (rck != TW_OK) return rck;
     unsigned begin_bit = 0;
     if (kb[1] != 0 && !(kb[1] >> 63)) while (!((kb[1] >> begin_bit) & 1)) begin_bit++;
-    HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap_end, begin_bit, 64, e->stream));
-    if (bytes > e->sort_tmp_bytes) {
-        void* q = nullptr;
-        HIPCHK(hipMalloc(&q, bytes));
-        e->allocs.push_back(q);
-        e->sort_tmp = q;
-        e->sort_tmp_bytes = bytes;
+    (void)bytes;
+    if (kb[1] >> 63) {  // a negative sample: leave the key transform to rocprim (never seen; see above)
+        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap_end, 0, 64, e->stream));
+        int rcs = ensure_sort_tmp(e, bytes);
+        if (rcs != TW_OK) return rcs;
+        bytes = e->sort_tmp_bytes;
+        HIPCHK(rocprim::segmented_radix_sort_keys(e->sort_tmp, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap_end, 0, 64, e->stream));
+    } else {  // non-negative doubles order like their bit patterns
+        int rcs = sort_rows(e, (const unsigned long long*)e->P.gaps, (unsigned long long*)e->gaps_sorted, size, e->seg_gap, e->seg_gap_end,
+                            e->seg_gap_dst, (int)nseg, e->n_gap_scored, begin_bit, 64, 0ull);
+        if (rcs != TW_OK) return rcs;
     }
-    bytes = e->sort_tmp_bytes;
-    HIPCHK(rocprim::segmented_radix_sort_keys(e->sort_tmp, bytes, (const double*)e->P.gaps, e->gaps_sorted, size, nseg, e->seg_gap, e->seg_gap_end, begin_bit, 64, e->stream));
     FitDev F{};
     F.units = e->P.units; F.n_units = e->P.n_units; F.n_slots = e->n_slots; F.sorted = e->gaps_sorted;
     F.gs_off = e->P.gs_off; F.slot_unit = e->slot_unit; F.slot_scored = e->slot_scored; F.models = e->fit_models; F.mix_n = e->mix_n_dev; F.mix_p = e->mix_p_dev;

@@ -105,6 +105,29 @@ __global__ void k_key_bits(const unsigned long long* keys, const uint32_t* seg_b
     }
 }
 
+// Rows sorted as one array.  A segmented sort hands every long row to a single workgroup; instead the rows are
+// packed into composite keys (row number above the kb varying key bits), sorted by one device-wide radix sort over
+// kb + log2(rows) bits, and unpacked again.  Bits of a key outside [begin_bit, begin_bit + kb) are the same in
+// every key (k_key_bits) and are restored from `fixed`.
+__global__ void k_rows_pack(const unsigned long long* keys, const uint32_t* seg_begin, const uint32_t* seg_end, const uint32_t* dst_off,
+                            int nseg, int begin_bit, int kb, unsigned long long* comp) {
+    const unsigned long long mask = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
+    for (int s = blockIdx.y; s < nseg; s += gridDim.y) {
+        const uint32_t a = seg_begin[s], b = seg_end[s], d = dst_off[s];
+        for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x)
+            comp[d + (i - a)] = (kb >= 64 ? 0ull : ((unsigned long long)s << kb)) | ((keys[i] >> begin_bit) & mask);
+    }
+}
+__global__ void k_rows_unpack(const unsigned long long* comp, const uint32_t* seg_begin, const uint32_t* seg_end, const uint32_t* dst_off,
+                              int nseg, int begin_bit, int kb, unsigned long long fixed, unsigned long long* out) {
+    const unsigned long long mask = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
+    for (int s = blockIdx.y; s < nseg; s += gridDim.y) {
+        const uint32_t a = seg_begin[s], b = seg_end[s], d = dst_off[s];
+        for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x)
+            out[i] = fixed | ((comp[d + (i - a)] & mask) << begin_bit);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pass-1 Gaussian parameters: one thread per (unit, 100-span block, slot).
 // mean = (sum t2 - sum t1)/n over rank-aligned sorted arrays, std = sqrt(ceil(n/10)) * tstd(batch means).
