@@ -737,6 +737,31 @@ static double group_opt(const mwis_comp *c, int d, int g) {
     return best;
 }
 
+/* Components of up to TWO_BRUTE_MAX in-spans: complete enumeration in depth-first order (candidates in list order,
+ * then "none", first in-span most significant), sums accumulated left to right, strict improvements only.  This is
+ * what the bounded search below returns whenever its bound is exact in floating point; enumerating removes the
+ * dependence on the bound's rounding for the small components (the GPU engine spreads the same enumeration over
+ * the lanes of a wavefront). */
+#define TWO_BRUTE_MAX 4
+static void mwis_enumerate(mwis_comp *c) {
+    int ch[TWO_BRUTE_MAX];
+    for (int t = 0; t < c->m; t++) ch[t] = 0;
+    while (1) {
+        int ok = 1; double sum = 0.0;
+        for (int t = 0; t < c->m && ok; t++) {
+            if (ch[t] == c->n[t]) continue; /* none */
+            for (int q = 0; q < t && ok; q++) if (ch[q] < c->n[q] && shares(c->E, c->idx[q][ch[q]], c->idx[t][ch[t]])) ok = 0;
+            if (ok) sum += c->w[t][ch[t]];
+        }
+        c->nodes++;
+        if (ok && sum > c->best_w) { c->best_w = sum; for (int t = 0; t < c->m; t++) c->best[t] = ch[t] < c->n[t] ? ch[t] : -1; }
+        int t = c->m - 1;
+        while (t >= 0 && ch[t] == c->n[t]) { ch[t] = 0; t--; }
+        if (t < 0) break;
+        ch[t]++;
+    }
+}
+
 static int two_plain_nodes = 2048;  /* the matching relaxation is consulted from this many search nodes on */
 static int two_node_budget = 4096;  /* search nodes per component; beyond it the incumbent is returned */
 #define TWO_MATCH_MIN_DEPTH 4       /* ... and only where at least this many in-spans remain below the node */
@@ -763,7 +788,8 @@ static void mwis_dfs(mwis_comp *c, int d, double acc) {
 /* Exact maximum-weight independent set of the window's conflict graph (V3:1252-1281, V3:1395-1419).
  * Canonical procedure (also followed by the GPU engine so that exact ties resolve identically):
  *   nodes with weight 10000+score <= 0 are never selected; the window is split into connected
- *   components of the in-span conflict relation; each component is searched depth-first over its
+ *   components of the in-span conflict relation; components of <= TWO_BRUTE_MAX in-spans are enumerated
+ *   completely (mwis_enumerate), larger ones are searched depth-first over their
  *   in-spans in index order, candidates in list order then "none", sums accumulated left to right,
  *   a subtree is cut when acc + upper bound <= best (upper bound = the remaining in-spans cut into
  *   groups of <= 3 consecutive in-spans, each solved exactly on its own, cheapest cutting; once the
@@ -812,7 +838,7 @@ static int64_t mwis_window(const two_service *s, int m, const int *ncand, two_ca
         }
         for (int d = 0; d < c.m; d++) { c.cur[d] = -1; c.best[d] = -1; }
         c.best_w = 0.0;
-        mwis_dfs(&c, 0, 0.0);
+        if (c.m <= TWO_BRUTE_MAX) mwis_enumerate(&c); else mwis_dfs(&c, 0, 0.0);
         for (int d = 0; d < c.m; d++) chosen[members[d]] = c.best[d] >= 0 ? c.kk[d][c.best[d]] : -1;
         nodes += c.nodes;
         if (c.exhausted) *budget_hit = 1;

@@ -89,3 +89,4 @@ template <class T> inline T atomicMin(T* p, T v) { T old = *p; if (v < old) *p =
 template <class T> inline T atomicMax(T* p, T v) { T old = *p; if (v > old) *p = v; return old; }
 template <class T> inline T atomicAdd(T* p, T v) { T old = *p; *p = old + v; return old; }
 template <class T> inline T atomicOr(T* p, T v) { T old = *p; *p = old | v; return old; }
+template <class T> inline T atomicExch(T* p, T v) { T old = *p; *p = v; return old; }

@@ -18,7 +18,8 @@ constexpr int kTopK = TW_TOPK;
 constexpr int kMaxComp = TW_MAX_COMP;
 constexpr int kMaxWin = TW_MAX_WINDOW;
 constexpr int kCandWords = TW_CAND_WORDS;
-constexpr int kTile = 256;  // incoming spans per workgroup in the per-span kernels
+constexpr int kTile = 128;  // incoming spans per workgroup in the per-span kernels (measured: 128 beats 64 and 256)
+constexpr int kCoop = 256;  // threads of the per-unit / per-row cooperative kernels
 constexpr int32_t kNoOwner = 0x7f7f7f7f;
 
 // One service unit as the kernels see it.
@@ -77,7 +78,7 @@ struct Dev {
     int32_t* w_last;    // [in_off + w] last span of window w
     int32_t* unit_nwin; // [n_units]
     uint8_t* w_dirty;   // [in_off + w] window needs the exact repair walk
-    uint8_t* w_conf;    // [in_off + w] the spans' best candidates clash: the window needs the exact search
+    int32_t* w_conf;    // [in_off + w] the spans' best candidates clash: the window is on a selection work list
     int32_t* unit_ndirty;
     int32_t* tk_n;      // candidates found on all spans (top_k_2)
     int64_t* leaves;
@@ -98,7 +99,7 @@ struct Dev {
     double* gaps;
     const int64_t* gs_off;  // [n_units]
     int64_t* unit_stats;    // [n_units][8]
-    int32_t* heavy_count;   // windows deferred to the large-component selection kernel
+    int32_t* heavy_count;   // windows whose best candidates clash: work list of k_select_heavy
     int32_t* heavy_next;    // next unclaimed entry of that list
     int32_t *heavy_unit, *heavy_win;
     int32_t* heavy_in_count;  // [kMaxEp+1] incoming spans deferred to k_enumerate_heavy, per endpoint count E

@@ -36,7 +36,7 @@ struct tw_engine {
     std::string err;
     int state = ST_EMPTY;
     int tile = kTile;   // incoming spans (threads) per workgroup of the per-span kernels
-    int coop = 256;     // threads of the per-unit cooperative kernels
+    int coop = kCoop;   // threads of the per-unit cooperative kernels
     std::vector<UnitDev> units;
     std::vector<TileDev> tiles;
     std::vector<int64_t> gs_off_h;
@@ -249,9 +249,8 @@ int run_pass(tw_engine* e, int pass) {
         HIPCHK(hipMemsetAsync(P.w_dirty, 0, (size_t)P.n_in_total, e->stream));
     }
     HIPCHK(hipEventRecord(e->ev[EV_WIN], e->stream));
-    HIPCHK(hipMemsetAsync(P.w_conf, 0, (size_t)P.n_in_total, e->stream));
+    HIPCHK(hipMemsetAsync(P.w_conf, 0, sizeof(int32_t) * (size_t)P.n_in_total, e->stream));
     hipLaunchKernelGGL(k_select_fast, tiles, tb, 0, e->stream, P);
-    hipLaunchKernelGGL(k_select, tiles, tb, 0, e->stream, P);
     hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096)), dim3(std::min(e->coop, 64)), 0, e->stream, P);
     HIPCHK(hipEventRecord(e->ev[EV_SEL], e->stream));
     hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P);
@@ -286,7 +285,7 @@ int tw_create(int device_id, tw_engine** out) {
     tw_engine* e = new tw_engine();
     e->device = device_id;
     e->tile = std::min(std::max(env_int("TW_TILE", kTile), 1), kTile);
-    e->coop = std::min(std::max(env_int("TW_COOP_THREADS", 256), 1), kTile);
+    e->coop = std::min(std::max(env_int("TW_COOP_THREADS", kCoop), 1), kCoop);
     hipError_t s = hipSetDevice(device_id);
     if (s == hipSuccess) s = hipStreamCreate(&e->stream);
     for (int i = 0; i < EV_COUNT && s == hipSuccess; i++) s = hipEventCreate(&e->ev[i]);

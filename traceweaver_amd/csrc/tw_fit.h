@@ -74,8 +74,8 @@ __device__ inline void block_reduce(double (&vals)[cnt], double* sh) {
 
 // One workgroup per scored row: distinct values and their first positions (a head is a sample that differs
 // from its left neighbour; NaN = dropped samples, sorted last, are not counted).
-__global__ void __launch_bounds__(kTile) k_fit_compress(FitDev F) {
-    __shared__ int32_t sh[kTile];
+__global__ void __launch_bounds__(kCoop) k_fit_compress(FitDev F) {
+    __shared__ int32_t sh[kCoop];
     __shared__ int32_t carry_sh, n_sh;
     const int64_t q = blockIdx.x;
     const int t = threadIdx.x, nt = blockDim.x;

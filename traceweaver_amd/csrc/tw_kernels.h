@@ -1277,7 +1277,7 @@ __global__ void k_scan_local(Dev P, typename Tr::T* agg) {
 template <class Tr>
 __global__ void k_scan_spine(Dev P, typename Tr::T* agg) {  // one workgroup per unit: exclusive scan of its tiles
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    __shared__ typename Tr::T sh[kTile];
+    __shared__ typename Tr::T sh[kCoop];
     __shared__ typename Tr::T carry_sh;
     const UnitDev& U = P.units[blockIdx.x];
     const int t = threadIdx.x, n = blockDim.x;
@@ -1411,107 +1411,18 @@ __device__ inline bool cands_share(const Dev& P, const UnitDev& U, int i, int a,
 //   A component whose search exceeds kNodeBudget nodes keeps its incumbent and the window is counted in
 //   unit_stats[4].
 //
-// Mapping: k_select_fast settles the windows whose best candidates do not clash (one lane per span);
-// k_select runs one thread per remaining window of < kCoopMinSpans spans with the singleton cutting only
-// (any valid bound gives the same answer) and gives up after kLightNodes nodes; the others are solved
-// from scratch by k_select_heavy, one workgroup per window, candidate data and the Hungarian state in LDS, the
-// column scans of the Hungarian algorithm spread over the lanes.
+// Mapping: k_select_fast settles the windows whose best candidates do not clash (one lane per span) and
+// lists the others; k_select_heavy solves a listed window per workgroup (one wavefront), candidate data
+// and the search state in LDS: components of <= kBruteMax spans by complete enumeration spread over the
+// lanes, larger ones by the depth-first search (thread 0) with the grouped bound evaluated by all lanes
+// and the column scans of the Hungarian algorithm spread over the lanes.
 constexpr int kPlainNodes = 2048;    // the matching relaxation is consulted from this many search nodes on ...
 constexpr int kMatchMinDepth = 4;    // ... and only where at least this many spans remain below the node
 constexpr int kNodeBudget = 4096;    // search nodes per component; beyond it the incumbent is returned
 constexpr int kMatchMaxCols = 256;   // widest span-index range one endpoint's relaxation may address
 constexpr int kMaxCols = kMatchMaxCols + kMaxWin + 1;
 constexpr int kUsedWords = 4;        // 256-span window of the per-endpoint "taken" bitmap in k_select_heavy
-constexpr int kLightNodes = 64;      // k_select hands a window over to k_select_heavy after this many nodes (<= kPlainNodes;
-                                     // an engine-internal split: the search itself is the same in both kernels)
-constexpr int kCoopMinSpans = 4;     // conflicted windows with at least this many spans are solved by k_select_heavy
-
-// ---- light path: thread-private, plain bound only -------------------------------------------------
-__device__ bool select_window_light(const Dev& P, const UnitDev& U, int first, int m) {
-    if (m == 1) {  // 87 % of the windows on the shipped data sets
-        int pick = -1;
-        double best = 0.0;
-        const int n = cand_n(P, U, first);
-        for (int k = 0; k < n; k++) {
-            const double w = 10000.0 + cand_score(P, U, first, k);
-            if (w > 0.0 && w > best) { best = w; pick = k; }
-        }
-        P.chosen[U.in_off + first] = pick;
-        return true;
-    }
-    uint8_t comp[kMaxWin], ncand[kMaxWin];
-    int8_t pick[kMaxWin];
-    for (int b = 0; b < m; b++) { comp[b] = (uint8_t)b; ncand[b] = (uint8_t)cand_n(P, U, first + b); pick[b] = -1; }
-    for (int b = 0; b < m; b++)
-        for (int c = 0; c < b; c++) {
-            if (comp[b] == comp[c]) continue;
-            bool hit = false;
-            for (int ka = 0; ka < ncand[b] && !hit; ka++) {
-                if (!(10000.0 + cand_score(P, U, first + b, ka) > 0.0)) continue;
-                for (int kb = 0; kb < ncand[c] && !hit; kb++)
-                    if (10000.0 + cand_score(P, U, first + c, kb) > 0.0 && cands_share(P, U, first + b, ka, first + c, kb)) hit = true;
-            }
-            if (hit) {
-                const uint8_t lo = comp[b] < comp[c] ? comp[b] : comp[c], hi = comp[b] < comp[c] ? comp[c] : comp[b];
-                for (int t = 0; t < m; t++) if (comp[t] == hi) comp[t] = lo;
-            }
-        }
-    for (int root = 0; root < m; root++) {
-        if (comp[root] != root) continue;
-        uint8_t mem[kMaxWin];
-        int cm = 0;
-        for (int b = root; b < m; b++) if (comp[b] == root) mem[cm++] = (uint8_t)b;
-        double ub[kMaxWin + 1], accs[kMaxWin + 1];
-        ub[cm] = 0.0;
-        for (int d = cm - 1; d >= 0; d--) {
-            double mx = 0.0;
-            for (int k = 0; k < ncand[mem[d]]; k++) {
-                const double w = 10000.0 + cand_score(P, U, first + mem[d], k);
-                if (w > 0.0 && w > mx) mx = w;
-            }
-            ub[d] = ub[d + 1] + mx;
-        }
-        int8_t cur[kMaxWin], best[kMaxWin], next[kMaxWin + 1];
-        for (int d = 0; d < cm; d++) { cur[d] = -1; best[d] = -1; }
-        double best_w = 0.0;
-        int nodes = 0, d = 0;
-        accs[0] = 0.0;
-        bool entered = true;
-        while (d >= 0) {
-            if (entered) {
-                if (nodes >= kLightNodes) return false;  // long search: the whole window goes to k_select_heavy (LDS-resident)
-                nodes++;
-                if (d == cm) {
-                    if (accs[d] > best_w) { best_w = accs[d]; for (int t = 0; t < cm; t++) best[t] = cur[t]; }
-                    d--; entered = false; continue;
-                }
-                if (accs[d] + ub[d] <= best_w) { d--; entered = false; continue; }
-                next[d] = 0;
-            }
-            const int b = mem[d], nc = ncand[b];
-            int k = next[d];
-            bool descended = false;
-            for (; k <= nc; k++) {
-                if (k == nc) {  // "none"
-                    cur[d] = -1; next[d] = (int8_t)(nc + 1); accs[d + 1] = accs[d];
-                    d++; entered = true; descended = true; break;
-                }
-                const double w = 10000.0 + cand_score(P, U, first + b, k);
-                if (!(w > 0.0)) continue;
-                bool ok = true;
-                for (int q = 0; q < d && ok; q++)
-                    if (cur[q] >= 0 && cands_share(P, U, first + mem[q], cur[q], first + b, k)) ok = false;
-                if (!ok) continue;
-                cur[d] = (int8_t)k; next[d] = (int8_t)(k + 1); accs[d + 1] = accs[d] + w;
-                d++; entered = true; descended = true; break;
-            }
-            if (!descended) { cur[d] = -1; d--; entered = false; }
-        }
-        for (int t = 0; t < cm; t++) pick[mem[t]] = best[t];
-    }
-    for (int b = 0; b < m; b++) P.chosen[U.in_off + first + b] = pick[b];
-    return true;
-}
+constexpr int kBruteMax = 4;         // components of up to this many spans are solved by complete enumeration (see select_brute)
 
 // ---- cooperative path: one workgroup per window --------------------------------------------------
 struct SelectLds {
@@ -1519,9 +1430,9 @@ struct SelectLds {
     double w[kMaxWin][kTopK];  // 10000 + score; <= 0 means not eligible
     double ub[kMaxWin + 1], accs[kMaxWin + 1];
     double u[kMaxWin + 1], v[kMaxCols], minv[kMaxCols], cost[kMaxWin][kTopK];
-    double red_val[kTile];
+    double red_val[kCoop / 64];
     double best_w, bound, delta;
-    int32_t red_idx[kTile], col[kMaxWin][kTopK];
+    int32_t red_idx[kCoop / 64], col[kMaxWin][kTopK];
     int16_t p[kMaxCols], way[kMaxCols];
     uint8_t used[kMaxCols], ncand[kMaxWin], comp[kMaxWin], mem[kMaxWin], ndeg[kMaxWin];
     int8_t cur[kMaxWin], best[kMaxWin], next[kMaxWin + 1], pick[kMaxWin];
@@ -1719,6 +1630,68 @@ __device__ void select_step(SelectLds& L, int E, bool resume_with_bound) {
     L.state = SEL_DONE;
 }
 
+// Complete enumeration of a component of cm <= kBruteMax spans by all lanes: combination index = the choices
+// (candidate 0..kTopK-1, then kTopK = "none") as digits, first span most significant, so that increasing index is
+// exactly the depth-first order of the canonical search; sums are accumulated left to right; the winner is the
+// largest sum, the smallest index among equal sums, and must beat the empty selection (sum 0) strictly.  The
+// canonical search visits at most 1 + 6 + ... + 6^4 = 1555 < kNodeBudget nodes on such a component, so it always
+// completes and returns this very selection.
+__device__ void select_brute(SelectLds& L, int E) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int lane = t & 63, wave = t >> 6, nwave = (nt + 63) >> 6;
+    constexpr int C = kTopK + 1;
+    const int cm = L.cm;
+    int total = 1;
+    for (int x = 0; x < cm; x++) total *= C;
+    double bsum = 0.0;
+    int bidx = 0x7fffffff;
+    for (int q = t; q < total; q += nt) {
+        int ch[kBruteMax], rest = q;
+#pragma unroll
+        for (int x = kBruteMax - 1; x >= 0; x--) {
+            if (x < cm) { ch[x] = rest % C; rest /= C; } else ch[x] = kTopK;
+        }
+        bool ok = true;
+        double sum = 0.0;
+#pragma unroll
+        for (int x = 0; x < kBruteMax; x++) {
+            if (x < cm && ok && ch[x] != kTopK) {
+                const int b = L.mem[x];
+                if (ch[x] >= L.ncand[b] || !(L.w[b][ch[x]] > 0.0)) ok = false;
+#pragma unroll
+                for (int y = 0; y < x; y++)
+                    if (ok && ch[y] != kTopK && lds_share(L, E, L.mem[y], ch[y], b, ch[x])) ok = false;
+                if (ok) sum += L.w[b][ch[x]];
+            }
+        }
+        if (ok && sum > bsum) { bsum = sum; bidx = q; }  // own indices increase: the first maximum stays
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        if (off < nt) {
+            const double os = __shfl_down(bsum, off);
+            const int oi = __shfl_down(bidx, off);
+            if (os > bsum || (os == bsum && oi < bidx)) { bsum = os; bidx = oi; }
+        }
+    }
+    if (nwave > 1) {
+        __syncthreads();
+        if (lane == 0) { L.red_val[wave] = bsum; L.red_idx[wave] = bidx; }
+        __syncthreads();
+        if (t == 0)
+            for (int q = 1; q < nwave; q++)
+                if (L.red_val[q] > bsum || (L.red_val[q] == bsum && L.red_idx[q] < bidx)) { bsum = L.red_val[q]; bidx = L.red_idx[q]; }
+    }
+    if (t == 0) {
+        int rest = bidx;
+        for (int x = cm - 1; x >= 0; x--) {
+            const int k = bsum > 0.0 ? rest % C : kTopK;
+            rest /= C;
+            L.pick[L.mem[x]] = (int8_t)(k == kTopK ? -1 : k);
+        }
+    }
+    __syncthreads();
+}
+
 __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int first, int m, SelectLds& L) {
     const int t = threadIdx.x, nt = blockDim.x, E = U.E;
     for (int q = t; q < m * kTopK; q += nt) {
@@ -1768,9 +1741,10 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             int cm = 0;
             for (int b = root; b < m; b++) if (L.comp[b] == root) L.mem[cm++] = (uint8_t)b;
             L.cm = cm;
-            for (int d = 0; d < cm; d++) { L.cur[d] = -1; L.best[d] = -1; L.g2[d] = 0; L.g3[d] = 0; }
+            // (the rest prepares the depth-first search of a component too large for complete enumeration)
+            for (int d = 0; d < cm && cm > kBruteMax; d++) { L.cur[d] = -1; L.best[d] = -1; L.g2[d] = 0; L.g3[d] = 0; }
             L.use_bits = 1;
-            for (int e = 0; e < E; e++) {
+            for (int e = 0; e < E && cm > kBruteMax; e++) {
                 int32_t lo = 0x7fffffff, hi = -1;
                 for (int d = 0; d < cm; d++)
                     for (int k = 0; k < L.ncand[L.mem[d]]; k++) {
@@ -1783,6 +1757,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             }
         }
         __syncthreads();
+        if (L.cm <= kBruteMax) { select_brute(L, E); continue; }  // uniform: cm is in LDS and stable here
         {   // Upper bound of a suffix d..cm-1 of the component: cut it into groups of 1-3 consecutive spans, solve
             // every group exactly on its own (conflicts inside the group only) and take the cheapest cutting.  It
             // sees spans that compete for the same outgoing spans (one of them must stay unassigned: -10000), which
@@ -1842,8 +1817,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
 // returns: it is the first leaf of the depth-first order (position 0 is tried first and nothing clashes), its
 // weight equals the upper bound sum-of-best-weights, and only strict improvements replace the incumbent.
 // A span whose best weight is <= 0 has no eligible candidate at all (lists are sorted) and stays unassigned
-// in every selection.  ~90-99 % of the windows end here; the others are flagged in w_conf and searched by
-// k_select / k_select_heavy.
+// in every selection.  ~90-99 % of the windows end here; the others are listed for k_select_heavy.
 __global__ void __launch_bounds__(kTile) k_select_fast(Dev P) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
@@ -1853,10 +1827,10 @@ __global__ void __launch_bounds__(kTile) k_select_fast(Dev P) {
     const int64_t g = U.in_off + i;
     const bool ok = P.tk_n[g] > 0 && 10000.0 + P.tk_score[tks_index(U, 0, i)] > 0.0;
     P.chosen[g] = ok ? 0 : -1;
-    if (!ok) return;
     const int w = P.wid[g];
     const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
-    if (first >= i || i - first >= kMaxWin) return;  // (an over-long window is reported by k_select)
+    if (i - first >= kMaxWin) { raise_err(P, TW_ERR_WINDOW_SIZE); return; }
+    if (!ok || first >= i) return;
     uint32_t elig = 0;
     for (int j = first; j < i; j++)
         if (P.tk_n[U.in_off + j] > 0 && 10000.0 + P.tk_score[tks_index(U, 0, j)] > 0.0) elig |= 1u << (j - first);
@@ -1866,29 +1840,14 @@ __global__ void __launch_bounds__(kTile) k_select_fast(Dev P) {
         for (uint32_t rest = elig; rest != 0 && !clash; rest &= rest - 1)
             clash = P.tk_idx[tk_index(U, 0, e, first + __ffs((int)rest) - 1)] == mine;
     }
-    if (clash) P.w_conf[U.in_off + w] = 1;
-}
-
-__global__ void __launch_bounds__(kTile) k_select(Dev P) {  // one thread per conflicted window; windows with a hard component are deferred
-    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    const TileDev Tl = P.tiles[blockIdx.x];
-    const UnitDev& U = P.units[Tl.unit];
-    const int w = Tl.first + threadIdx.x;
-    if (w >= U.n_in || w >= P.unit_nwin[Tl.unit]) return;
-    const int last = P.w_last[U.in_off + w];
-    const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
-    const int m = last - first + 1;
-    if (m <= 0) return;
-    if (m > kMaxWin) { raise_err(P, TW_ERR_WINDOW_SIZE); return; }
-    if (!P.w_conf[U.in_off + w]) return;  // settled by k_select_fast
-    // windows of several spans go to the workgroup kernel straight away: their candidate lists are compared
-    // pairwise (O(m^2) tuple comparisons), which is cheap from LDS and spread over the lanes there
-    if (m >= kCoopMinSpans || !select_window_light(P, U, first, m)) {
+    // the first lane that finds a clash puts the window on the work list of k_select_heavy
+    if (clash && atomicExch(&P.w_conf[U.in_off + w], 1) == 0) {
         const int slot = atomicAdd(P.heavy_count, 1);
         P.heavy_unit[slot] = Tl.unit;
         P.heavy_win[slot] = w;
     }
 }
+
 __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent workgroups, one deferred window at a time
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     __shared__ SelectLds L;
@@ -1985,7 +1944,7 @@ __device__ void repair_span(const Dev& P, const UnitDev& U, int i, int pass, con
 
 // One workgroup per unit walks the flagged windows in increasing order.  When window w is visited
 // every earlier window is final, so the set of consumed spans it sees is exact.
-__global__ void __launch_bounds__(kTile) k_repair(Dev P, int pass) {
+__global__ void __launch_bounds__(kCoop) k_repair(Dev P, int pass) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     __shared__ int next_w;
     __shared__ int any_gone;
