@@ -78,6 +78,9 @@ template <class T> inline T __shfl_down(T v, int) { return v; }  // only reachab
 // wave intrinsics for a wavefront of one lane (kernels that use them run with one thread per workgroup here)
 inline unsigned long long __ballot(int pred) { return pred ? 1ull : 0ull; }
 template <class T> inline T __shfl(T v, int) { return v; }
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+inline void __builtin_amdgcn_wave_barrier() {}
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffs(int x) { return __builtin_ffs(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }

@@ -22,6 +22,27 @@ namespace tw {
 // small helpers
 __device__ __forceinline__ void raise_err(const Dev& P, int code) { atomicCAS(P.err, 0, code); }
 
+// Appends to a work list with one atomic per wavefront instead of one per lane (same-address atomics serialise
+// at ~20 ns each): the first active lane reserves slots for every lane that has an entry.  Returns the slot or -1.
+__device__ __forceinline__ int wave_append(int32_t* counter, bool pred) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0) return -1;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader);
+    return pred ? base + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
+}
+// Barrier of a workgroup that is a single wavefront: LDS operations of one wavefront execute in program order, so
+// only the compiler has to be kept from reordering.  (__syncthreads() would also wait for every outstanding global
+// load/store -- the release fence at workgroup scope -- which costs microseconds per use in the work-list kernels.)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+constexpr int kWorkChunk = 4;  // work-list entries a wavefront claims per atomic
+
 __device__ __forceinline__ int lower_bound_i64(const int64_t* a, int n, int64_t t) {  // first a[x] >= t
     int lo = 0, hi = n;
     while (lo < hi) {
@@ -693,11 +714,13 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
     int64_t prod = empty ? 0 : 1;
 #pragma unroll
     for (int e = 0; e < E; e++) if (prod > 0 && prod <= kLightMax) prod *= (c.hi[e] - c.lo[e] + 1);
-    if (prod > kLightMax) {
-        const int slot = atomicAdd(&P.heavy_in_count[E], 1);
-        P.heavy_in_unit[P.heavy_in_off[E] + slot] = T.unit;
-        P.heavy_in_idx[P.heavy_in_off[E] + slot] = i;
-        return;
+    {
+        const int slot = wave_append(&P.heavy_in_count[E], prod > kLightMax);
+        if (slot >= 0) {
+            P.heavy_in_unit[P.heavy_in_off[E] + slot] = T.unit;
+            P.heavy_in_idx[P.heavy_in_off[E] + slot] = i;
+            return;
+        }
     }
     c.nk = 0; c.leaves = 0; c.ambiguous = false;
 #pragma unroll
@@ -739,14 +762,16 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
                 }
                 if (same) c.ambiguous = true;
             }
-    if (c.ambiguous) {  // rare (millisecond-granular data): replay CPython's heapq / list.sort push by push
-        Enumerator<E> en(P, U);
-        setup_enumerator<E>(en, P, U, i, pass);
-#pragma unroll
-        for (int e = 0; e < E; e++) { en.lo[e] = c.lo[e]; en.hi[e] = c.hi[e]; }
-        if (pass == 1) en.template dfs<true, true>(nullptr); else en.template dfs<true, false>(nullptr);
-        write_result<E>(P, U, i, pass, en);
-        return;
+    {
+        // rare (millisecond-granular data): CPython's heapq / list.sort must be replayed push by push.  That needs
+        // dynamically indexed per-thread state; keeping it out of this kernel keeps this kernel free of scratch
+        // memory (measured: 8x faster) -- the span goes to the wavefront kernel, which replays from LDS.
+        const int slot = wave_append(&P.heavy_in_count[E], c.ambiguous);
+        if (slot >= 0) {
+            P.heavy_in_unit[P.heavy_in_off[E] + slot] = T.unit;
+            P.heavy_in_idx[P.heavy_in_off[E] + slot] = i;
+            return;
+        }
     }
     const int64_t g = U.in_off + i;
     P.tk_n[g] = c.nk;
@@ -859,14 +884,21 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
     const int t = threadIdx.x, nt = blockDim.x;
     const int count = P.heavy_in_count[E];
     TW_PROF_DECL();
+    int chunk_pos = 0, chunk_end = 0;
     while (true) {
         // dynamic work distribution: candidate products span four orders of magnitude, a static split leaves
         // most wavefronts idle behind the few that drew the large spans
-        int item = 0;
-        if (t == 0) item = atomicAdd(&P.heavy_in_next[E], 1);
-        item = __shfl(item, 0);
-        if (item >= count) { TW_PROF_FLUSH(); break; }
-        const int unit = P.heavy_in_unit[P.heavy_in_off[E] + item], i = P.heavy_in_idx[P.heavy_in_off[E] + item];
+        if (chunk_pos == chunk_end) {
+            if (t == 0) chunk_pos = atomicAdd(&P.heavy_in_next[E], kWorkChunk);
+            chunk_pos = __shfl(chunk_pos, 0);
+            chunk_end = chunk_pos + kWorkChunk < count ? chunk_pos + kWorkChunk : count;
+            if (chunk_pos >= count) { TW_PROF_FLUSH(); break; }
+        }
+        const int item = chunk_pos++;
+        // wave-uniform by construction; telling the compiler so turns every access to the unit descriptor below
+        // into a scalar load (SGPRs, constant cache) instead of 64 lanes loading the same address
+        const int unit = __builtin_amdgcn_readfirstlane(P.heavy_in_unit[P.heavy_in_off[E] + item]);
+        const int i = __builtin_amdgcn_readfirstlane(P.heavy_in_idx[P.heavy_in_off[E] + item]);
         const UnitDev& U = P.units[unit];
         TW_T0();
 #ifdef TW_PROFILE
@@ -882,6 +914,19 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         int32_t lo[E], hi[E];
 #pragma unroll
         for (int e = 0; e < E; e++) { lo[e] = P.c_lo[ie_index(U, e, i)]; hi[e] = P.c_hi[ie_index(U, e, i)]; }
+        // the unit's call-order DAG in registers (it is consulted at every grid point; read from the descriptor in
+        // global memory each of those reads is a scalar load with its own wait): predecessor masks, predecessor
+        // counts, and per endpoint the predecessor list in in_edges() order packed 4 bits each (index | primary << 3)
+        uint32_t dag_pm[E], dag_np[E], dag_pl[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            dag_pm[e] = U.pred_mask[e];
+            dag_np[e] = U.npred[e];
+            uint32_t pk = 0;
+#pragma unroll
+            for (int j = 0; j < E; j++) pk |= (j < (int)dag_np[e] ? ((uint32_t)U.pred_list[e][j] | ((uint32_t)U.pred_prim[e][j] << 3)) : 0u) << (4 * j);
+            dag_pl[e] = pk;
+        }
         TW_TICK(0);
         for (int k = t; k < kMaxEp * kCandWords; k += nt) (&sbits[0][0])[k] = 0;
 #pragma unroll
@@ -895,7 +940,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                 le[e][r] = oe[c];
             }
         }
-        __syncthreads();
+        wave_sync();
         {   // one (candidate span, root | closing) term per lane, all endpoints at once
             int wsum = 0;
 #pragma unroll
@@ -911,7 +956,12 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                 const int64_t st = ls[es][r], e2 = le[es][r];
                 if (in_start > st || e2 > in_end) continue;  // not contained: never part of a tuple
                 if (q & 1) tclose[es][r] = score_term(S, slot_close(E, es), e2, in_end);
-                else troot[es][r] = U.npred[es] == 0 ? score_term(S, slot_root(E, es), in_start, st) : 0.0;
+                else {
+                    bool is_root = false;
+#pragma unroll
+                    for (int e = 0; e < E; e++) if (e == es) is_root = dag_np[e] == 0;
+                    troot[es][r] = is_root ? score_term(S, slot_root(E, es), in_start, st) : 0.0;
+                }
             }
         }
         // Python orders (score, [spans]) tuples by score, then by start_mus of the first differing span; two
@@ -923,11 +973,11 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         // CPython heap replayed push by push in LDS (second attempt).
         LdsHeap<E> hp;
         hp.heap = sheap; hp.nheap = 0; hp.out_start = P.out_start; hp.U = &U;
-        __syncthreads();
+        wave_sync();
         TW_TICK(1);
         double ts[kTopK];
         int tq[kTopK], tslot[kTopK], nk = 0, seq = -1;
-        long long tg[kTopK];
+        int tg[kTopK];
         bool exact_replay = false, ambiguous = false;
         int64_t leaves = 0;
         for (int attempt = 0; attempt < 2; attempt++) {
@@ -937,8 +987,8 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         for (int k = 0; k < kTopK; k++) { ts[k] = -dinf(); tq[k] = -1; tg[k] = -1; tslot[k] = k; }
         // order of the candidate tuple (prefix px[0..L) + grid point gj) against the kept tuple in LDS slot sl
         // when their scores are equal: +1 candidate greater, -1 smaller, 0 equivalent
-        auto tie_order = [&](long long gj, int sl, int Ls) -> int {
-            long long gr = gj;
+        auto tie_order = [&](int gj, int sl, int Ls) -> int {
+            int gr = gj;
             int32_t ci[E];
 #pragma unroll
             for (int e = E - 1; e >= 0; e--) {
@@ -970,19 +1020,20 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         // tuples of levels L..E-1 -- a grid of G = prod w_e points, in enumeration order -- are spread over
         // the lanes.  L is the deepest split that still gives the lanes a full wavefront of grid points.
         int L = E - 1;
-        int64_t G = hi[E - 1] - lo[E - 1] + 1;
+        int G = hi[E - 1] - lo[E - 1] + 1;  // < 64 * 128: the grid stops growing once it fills the wavefront
 #pragma unroll
         for (int e = E - 2; e >= 0; e--)
             if (L == e + 1 && G < kHeavyThreads) { L = e; G *= (hi[e] - lo[e] + 1); }
         int d = 0;
         if (L > 0) px[0] = lo[0] - 1;
-        __syncthreads();
+        wave_sync();
         const bool once = (L == 0);
         while (once || d >= 0) {
             if (L > 0) {  // next feasible prefix, every lane in lockstep (DfsTraverseX order)
                 int hid = 0, lod = 0;
+                uint32_t pmd = 0;
 #pragma unroll
-                for (int e = 0; e < E; e++) if (e == d) { hid = hi[e]; lod = lo[e]; }
+                for (int e = 0; e < E; e++) if (e == d) { hid = hi[e]; lod = lo[e]; pmd = dag_pm[e]; }
                 int c = px[d] + 1;
                 bool found = false;
                 int64_t fst = 0, fen = 0;
@@ -991,7 +1042,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                     if (in_start > st || e2 > in_end) continue;
                     bool ok = true;
                     for (int p = 0; p < d; p++)
-                        if (((U.pred_mask[d] >> p) & 1) && pxe[p] > st) { ok = false; break; }
+                        if (((pmd >> p) & 1) && pxe[p] > st) { ok = false; break; }
                     if (ok) { fst = st; fen = e2; found = true; break; }
                 }
                 if (!found) { d--; continue; }
@@ -1007,8 +1058,8 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             }
             bool any = false;
             seq++;
-            for (int64_t base = 0; base < G; base += nt) {
-                int64_t g = base + t;
+            for (int base = 0; base < G; base += nt) {
+                int g = base + t;
                 bool ok = g < G;
                 double score = 0.0;
                 int32_t x[E];
@@ -1030,7 +1081,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         ok = !(in_start > st || e2 > in_end);
 #pragma unroll
                         for (int p = 0; p < e; p++)
-                            if (((U.pred_mask[e] >> p) & 1) && xe[p] > st) ok = false;
+                            if (((dag_pm[e] >> p) & 1) && xe[p] > st) ok = false;
                         xs[e] = st; xe[e] = e2;
                     }
                 }
@@ -1042,10 +1093,11 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                     for (int e = 1; e < E; e++) if (xe[e] > last_end) { last_end = xe[e]; last = e; }
 #pragma unroll
                     for (int e = 0; e < E; e++) {
-                        const int np = U.npred[e];
+                        const int np = (int)dag_np[e];
                         for (int j = 0; j < np; j++) {
-                            if (!U.pred_prim[e][j]) continue;
-                            const int p = U.pred_list[e][j];
+                            const uint32_t pj = (dag_pl[e] >> (4 * j)) & 15u;
+                            if (!(pj & 8u)) continue;
+                            const int p = (int)(pj & 7u);
                             int64_t pend = 0;
 #pragma unroll
                             for (int q = 0; q < E; q++) if (q == p) pend = xe[q];
@@ -1079,7 +1131,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         if (t == 0) {
                             Cand<E> cand;
                             cand.score = sj;
-                            int64_t gj = base + j;
+                            int gj = base + j;
 #pragma unroll
                             for (int e = E - 1; e >= 0; e--) {
                                 if (e >= L) { const int w = hi[e] - lo[e] + 1; cand.idx[e] = lo[e] + (int)(gj % w); gj /= w; }
@@ -1096,7 +1148,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         const int j = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
                         const double sj = __shfl(score, j);
-                        const long long gj = base + j;
+                        const int gj = base + j;
                         // exact order against every kept entry of equal score (rare): greater[k] / equivalence
                         int tie[kTopK];
 #pragma unroll
@@ -1137,7 +1189,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                             if (k == pos) { ts[k] = sj; tq[k] = seq; tg[k] = gj; tslot[k] = slot; }
                         if (nk < kTopK) nk++;
                         if (t == 0) {
-                            long long gr = gj;
+                            int gr = gj;
 #pragma unroll
                             for (int e = E - 1; e >= 0; e--) {
                                 if (e >= L) { const int w = hi[e] - lo[e] + 1; keep_idx[slot][e] = lo[e] + (int)(gr % w); gr /= w; }
@@ -1146,7 +1198,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         }
                     }
                 }
-                __syncthreads();
+                wave_sync();
                 TW_TICK(3);
             }
             if (t == 0 && any && pass == 1)
@@ -1171,16 +1223,13 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         if (slot_order(sa, sb) == 0) ambiguous = true;
                     }
             if (!ambiguous) break;
-            __syncthreads();
+            wave_sync();
         }
         }  // attempt
-        __syncthreads();
+        wave_sync();
         if (t == 0) {
-            const int64_t g = U.in_off + i;
-            int nout;
-            if (exact_replay) { hp.sort_desc(); nout = hp.nheap; }
+            if (exact_replay) hp.sort_desc();
             else {
-                nout = nk;
 #pragma unroll
                 for (int k = 0; k < kTopK; k++) {
                     sheap[k].score = ts[k];
@@ -1190,22 +1239,29 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                     for (int e = 0; e < E; e++) sheap[k].idx[e] = keep_idx[sl][e];
                 }
             }
-            P.tk_n[g] = nout;
-            P.leaves[g] = leaves;
-            P.rep[g] = 0;
-            for (int k = 0; k < kTopK; k++) {
-                P.tk_score[tks_index(U, k, i)] = k < nout ? sheap[k].score : dnan();
-                for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, i)] = k < nout ? sheap[k].idx[e] : -1;
+        }
+        wave_sync();
+        {   // results leave through all lanes: one (entry, field) per lane
+            const int64_t g = U.in_off + i;
+            const int nout = exact_replay ? __shfl(hp.nheap, 0) : nk;
+            if (t == 0) { P.tk_n[g] = nout; P.leaves[g] = leaves; P.rep[g] = 0; }
+            for (int q = t; q < kTopK * (E + 1); q += nt) {
+                const int k = q / (E + 1), f = q % (E + 1);
+                if (f == E) P.tk_score[tks_index(U, k, i)] = k < nout ? sheap[k].score : dnan();
+                else P.tk_idx[tk_index(U, k, f, i)] = k < nout ? sheap[k].idx[f] : -1;
             }
             if (pass == 1) {
+                for (int q = t; q < E * (kCandWords + 1); q += nt) {
+                    const int e = q / (kCandWords + 1), f = q % (kCandWords + 1);
+                    int loe = 0;
 #pragma unroll
-                for (int e = 0; e < E; e++) {
-                    P.c_lo[ie_index(U, e, i)] = lo[e];
-                    for (int w = 0; w < kCandWords; w++) P.c_bits[ie_index(U, e, i) * kCandWords + w] = sbits[e][w];
+                    for (int x = 0; x < E; x++) if (x == e) loe = lo[x];
+                    if (f == kCandWords) P.c_lo[ie_index(U, e, i)] = loe;
+                    else P.c_bits[ie_index(U, e, i) * kCandWords + f] = sbits[e][f];
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         TW_TICK(4);
 #ifdef TW_PROFILE
         if (t == 0) {
@@ -1841,8 +1897,8 @@ __global__ void __launch_bounds__(kTile) k_select_fast(Dev P) {
             clash = P.tk_idx[tk_index(U, 0, e, first + __ffs((int)rest) - 1)] == mine;
     }
     // the first lane that finds a clash puts the window on the work list of k_select_heavy
-    if (clash && atomicExch(&P.w_conf[U.in_off + w], 1) == 0) {
-        const int slot = atomicAdd(P.heavy_count, 1);
+    const int slot = wave_append(P.heavy_count, clash && atomicExch(&P.w_conf[U.in_off + w], 1) == 0);
+    if (slot >= 0) {
         P.heavy_unit[slot] = Tl.unit;
         P.heavy_win[slot] = w;
     }
@@ -1853,13 +1909,18 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
     __shared__ SelectLds L;
     __shared__ int next_item;
     const int count = *P.heavy_count;
+    int chunk_pos = 0, chunk_end = 0;
     while (true) {
-        if (threadIdx.x == 0) next_item = atomicAdd(P.heavy_next, 1);  // dynamic distribution: search effort varies by orders of magnitude
-        __syncthreads();
-        const int item = next_item;
-        __syncthreads();
-        if (item >= count) break;
-        const int unit = P.heavy_unit[item], w = P.heavy_win[item];
+        if (chunk_pos == chunk_end) {  // dynamic distribution (search effort varies by orders of magnitude), kWorkChunk windows per atomic
+            if (threadIdx.x == 0) next_item = atomicAdd(P.heavy_next, kWorkChunk);
+            __syncthreads();
+            chunk_pos = next_item;
+            __syncthreads();
+            chunk_end = chunk_pos + kWorkChunk < count ? chunk_pos + kWorkChunk : count;
+            if (chunk_pos >= count) break;
+        }
+        const int item = chunk_pos++;
+        const int unit = __builtin_amdgcn_readfirstlane(P.heavy_unit[item]), w = __builtin_amdgcn_readfirstlane(P.heavy_win[item]);  // wave-uniform: scalar loads below
         const UnitDev& U = P.units[unit];
         const int last = P.w_last[U.in_off + w];
         const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
