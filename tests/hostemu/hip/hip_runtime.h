@@ -78,6 +78,7 @@ template <class T> inline T __shfl_down(T v, int) { return v; }  // only reachab
 // wave intrinsics for a wavefront of one lane (kernels that use them run with one thread per workgroup here)
 inline unsigned long long __ballot(int pred) { return pred ? 1ull : 0ull; }
 template <class T> inline T __shfl(T v, int) { return v; }
+template <class T> inline T __shfl_xor(T v, int) { return v; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 inline void __builtin_amdgcn_wave_barrier() {}

@@ -120,7 +120,7 @@ __device__ __forceinline__ double with_hi(double x, int32_t hi) {
 __device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000LL); }
 __device__ __forceinline__ double dinf() { return __longlong_as_double(0x7ff0000000000000LL); }
 
-__device__ __noinline__ double tw_log(double x) {
+__device__ inline double tw_log(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  two54 = 1.80143985094819840000e+16, Lg1 = 6.666666666666735130e-01,
                  Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
@@ -159,7 +159,7 @@ __device__ __noinline__ double tw_log(double x) {
     return k == 0 ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
 }
 
-__device__ __noinline__ double tw_exp(double x) {
+__device__ inline double tw_exp(double x) {
     const double o_threshold = 7.09782712893383973096e+02, u_threshold = -7.45133219101941108420e+02,
                  ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
                  invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
@@ -200,7 +200,7 @@ __device__ __noinline__ double tw_exp(double x) {
     return with_hi(y, hi_word(y) + ((k + 1000) << 20)) * twom1000;
 }
 
-__device__ __noinline__ double tw_log1p(double x) {
+__device__ inline double tw_log1p(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  two54 = 1.80143985094819840000e+16, Lp1 = 6.666666666666735130e-01,
                  Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,

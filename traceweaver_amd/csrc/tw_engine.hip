@@ -659,6 +659,16 @@ int tw_debug_profile(tw_engine* e, unsigned long long* out16) {
     return TW_OK;
 }
 
+/* Debug aid, not part of the public header: sizes of the work lists of the last pass --
+ * out[0] = windows listed for k_select_heavy, out[1 + E] = spans listed for k_enumerate_heavy<E>. */
+int tw_debug_worklists(tw_engine* e, int32_t* out) {
+    if (e == nullptr || out == nullptr || e->state < ST_PASS1) return TW_ERR_ARG;
+    HIPCHK(hipMemcpyAsync(out, e->P.heavy_count, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(out + 1, e->P.heavy_in_count, sizeof(int32_t) * (kMaxEp + 1), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TW_OK;
+}
+
 int tw_assign_service(tw_engine* e, int32_t n_in, const int64_t* in_start, const int64_t* in_end, int32_t E,
                       const int64_t* out_off, const int64_t* out_start, const int64_t* out_end, const uint8_t* dag,
                       const int32_t* key_rank, const int32_t* mix_n, const double* mix_p, const tw_results* r) {

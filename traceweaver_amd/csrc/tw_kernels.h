@@ -41,6 +41,9 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+__device__ __forceinline__ void group_sync() {  // workgroup barrier of kernels that run with one wavefront or several
+    if (blockDim.x <= 64) wave_sync(); else __syncthreads();
+}
 constexpr int kWorkChunk = 4;  // work-list entries a wavefront claims per atomic
 
 __device__ __forceinline__ int lower_bound_i64(const int64_t* a, int n, int64_t t) {  // first a[x] >= t
@@ -242,7 +245,7 @@ __device__ __noinline__ double term_mix(int n, const double* c, int64_t t1, int6
     for (int k = 0; k < n; k++) if (a[k] == amax) m += 1.0;
     for (int k = 0; k < n; k++) s += (a[k] == amax) ? 0.0 : tw_exp(a[k] - amax);
     if (s != 0.0) s = s / m;
-    return (tw_log1p(s) + tw_log(m)) + amax;
+    return (tw_log1p(s) + (m == 1.0 ? 0.0 : tw_log(m))) + amax;  // log(1.0) is exactly 0.0
 }
 
 __device__ __forceinline__ double score_term(const Scorer& S, int slot, int64_t t1, int64_t t2) {
@@ -1144,6 +1147,20 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                     // beats the current fifth entry?  score ties are resolved exactly below, so let them through
                     const bool beats = ok && (nk < kTopK || score >= ts[kTopK - 1]);
                     unsigned long long todo = __ballot(beats);
+                    if (__popcll(todo) > 2 * kTopK) {
+                        // many candidates at once (the first batches of a span): only the five best of this batch, and
+                        // whatever ties with the fifth, can be among the final five -- the others are strictly below five
+                        // tuples of this very batch.  thr = fifth largest score of the batch (5 rounds of wave maximum).
+                        double rest = beats ? score : -dinf(), thr = -dinf();
+                        for (int r = 0; r < kTopK; r++) {
+                            double m = rest;
+                            for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(m, off); m = o > m ? o : m; }
+                            thr = m;
+                            const unsigned long long at = __ballot(rest == m);
+                            if (t == __ffsll((long long)at) - 1) rest = -dinf();
+                        }
+                        todo = __ballot(beats && score >= thr);
+                    }
                     while (todo) {
                         const int j = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
@@ -1477,7 +1494,7 @@ constexpr int kMatchMinDepth = 4;    // ... and only where at least this many sp
 constexpr int kNodeBudget = 4096;    // search nodes per component; beyond it the incumbent is returned
 constexpr int kMatchMaxCols = 256;   // widest span-index range one endpoint's relaxation may address
 constexpr int kMaxCols = kMatchMaxCols + kMaxWin + 1;
-constexpr int kUsedWords = 4;        // 256-span window of the per-endpoint "taken" bitmap in k_select_heavy
+constexpr int kBlkWords = (kMaxWin * kTopK + 63) / 64;  // words of a mask over all candidates of a component
 constexpr int kBruteMax = 4;         // components of up to this many spans are solved by complete enumeration (see select_brute)
 
 // ---- cooperative path: one workgroup per window --------------------------------------------------
@@ -1493,10 +1510,12 @@ struct SelectLds {
     uint8_t used[kMaxCols], ncand[kMaxWin], comp[kMaxWin], mem[kMaxWin], ndeg[kMaxWin];
     int8_t cur[kMaxWin], best[kMaxWin], next[kMaxWin + 1], pick[kMaxWin];
     uint32_t adj[kMaxWin];  // span conflict relation as bit rows
+    uint32_t cmask[kBruteMax][kTopK], celig[kBruteMax];  // select_brute: conflicts among / eligibility of the component's candidates
     unsigned long long g2[kMaxWin], g3[kMaxWin];  // bit patterns of the pair / triple optima of the grouped bound (weights are > 0)
-    uint64_t used_bits[kMaxEp][kUsedWords];  // spans taken by the current partial selection, per endpoint, relative to ubase
-    int32_t ubase[kMaxEp];
-    int cm, d, nodes, entered, state, j0, j1, nrow, ncol_real, budget_hit, base, top, prune, use_bits;
+    // depth-first search: conflicts of candidate k of member x with the candidates of the other members as a bit
+    // mask over (member y, candidate k2) -> bit y*kTopK+k2, and per depth the union of the masks of the choices above
+    unsigned long long cmask3[kMaxWin][kTopK][kBlkWords], blk[kMaxWin + 1][kBlkWords];
+    int cm, d, nodes, entered, state, j0, j1, nrow, ncol_real, budget_hit, base, top, prune;
 };
 enum { SEL_RUN = 0, SEL_NEED_BOUND = 1, SEL_DONE = 2 };
 
@@ -1506,25 +1525,10 @@ __device__ inline bool lds_share(const SelectLds& L, int E, int b1, int k1, int 
     return false;
 }
 
-// does candidate (b, k) clash with the current partial selection L.cur[0..d)?
-__device__ inline bool lds_clash(const SelectLds& L, int E, int d, int b, int k) {
-    if (L.use_bits) {
-        for (int e = 0; e < E; e++) {
-            const int r = L.idx[b][k][e] - L.ubase[e];
-            if ((L.used_bits[e][r >> 6] >> (r & 63)) & 1) return true;
-        }
-        return false;
-    }
-    for (int q = 0; q < d; q++)
-        if (L.cur[q] >= 0 && lds_share(L, E, L.mem[q], L.cur[q], b, k)) return true;
-    return false;
-}
-__device__ inline void lds_mark(SelectLds& L, int E, int b, int k, bool set) {
-    if (!L.use_bits) return;
-    for (int e = 0; e < E; e++) {
-        const int r = L.idx[b][k][e] - L.ubase[e];
-        if (set) L.used_bits[e][r >> 6] |= 1ull << (r & 63); else L.used_bits[e][r >> 6] &= ~(1ull << (r & 63));
-    }
+// is candidate k of member x blocked by the choices made above depth d?
+__device__ inline bool lds_blocked(const SelectLds& L, int d, int x, int k) {
+    const int bit = x * kTopK + k;
+    return (L.blk[d][bit >> 6] >> (bit & 63)) & 1ull;
 }
 
 // Hungarian algorithm on the graph in L (rows = remaining spans, <= kTopK finite entries per row plus
@@ -1536,12 +1540,12 @@ __device__ void hungarian_coop(SelectLds& L) {
     const int n = L.nrow, m = L.ncol_real + n;
     for (int j = t; j <= m; j += nt) { L.v[j] = 0.0; L.p[j] = 0; }
     for (int i = t; i <= n; i += nt) L.u[i] = 0.0;
-    __syncthreads();
+    group_sync();
     for (int i = 1; i <= n; i++) {
         for (int j = t; j <= m; j += nt) { L.minv[j] = INF; L.used[j] = 0; L.way[j] = 0; }
         if (t == 0) L.p[0] = (int16_t)i;
         int j0 = 0;  // wave-uniform
-        __syncthreads();
+        group_sync();
         while (true) {
             if (t == 0) {  // relax the (<= kTopK + 1) finite entries of row i0
                 L.used[j0] = 1;
@@ -1554,7 +1558,7 @@ __device__ void hungarian_coop(SelectLds& L) {
                     if (cur < L.minv[j]) { L.minv[j] = cur; L.way[j] = (int16_t)j0; }
                 }
             }
-            __syncthreads();
+            group_sync();
             // first minimum of minv over the unused columns: per lane (ascending j), then across lanes -- the
             // smaller column index wins among equal values, exactly like the sequential scan
             double dv = INF;
@@ -1570,7 +1574,7 @@ __device__ void hungarian_coop(SelectLds& L) {
             }
             if (nwave > 1) {
                 if (lane == 0) { L.red_val[wave] = dv; L.red_idx[wave] = dj; }
-                __syncthreads();
+                group_sync();
                 dv = L.red_val[0]; dj = L.red_idx[0];
                 for (int q = 1; q < nwave; q++) {
                     const double ov = L.red_val[q];
@@ -1587,17 +1591,17 @@ __device__ void hungarian_coop(SelectLds& L) {
                 else if (L.minv[j] < INF) L.minv[j] -= delta;
             }
             j0 = dj;
-            __syncthreads();
+            group_sync();
             if (L.p[j0] == 0) break;
         }
         if (t == 0) {
             int jj = j0;
             do { const int j1 = L.way[jj]; L.p[jj] = L.p[j1]; jj = j1; } while (jj);
         }
-        __syncthreads();
+        group_sync();
     }
     if (t == 0) L.bound = L.v[0];  // = -(min cost)
-    __syncthreads();
+    group_sync();
 }
 
 // matching relaxation for members d..cm-1 given L.cur[0..d): L.prune = 1 as soon as one endpoint proves
@@ -1610,14 +1614,14 @@ __device__ void match_prunes_coop(SelectLds& L, int E) {
         const int d = L.d, nrow = L.cm - d;
         if (t == 0) { L.base = 0x7fffffff; L.top = -0x7fffffff - 1; L.nrow = nrow; }
         for (int r = t; r < nrow; r += nt) L.ndeg[r] = 0;
-        __syncthreads();
+        group_sync();
         for (int r = t; r < nrow; r += nt) {  // one lane per remaining span: compatible candidates in list order
             const int b = L.mem[d + r];
             int deg = 0;
             for (int k = 0; k < L.ncand[b]; k++) {
                 const double w = L.w[b][k];
                 if (!(w > 0.0)) continue;
-                if (lds_clash(L, E, d, b, k)) continue;
+                if (lds_blocked(L, d, d + r, k)) continue;
                 const int32_t x = L.idx[b][k][e];
                 atomicMin(&L.base, x);
                 atomicMax(&L.top, x);
@@ -1627,24 +1631,25 @@ __device__ void match_prunes_coop(SelectLds& L, int E) {
             }
             L.ndeg[r] = (uint8_t)deg;
         }
-        __syncthreads();
+        group_sync();
         const int base = L.top < L.base ? 1 : L.base, ncol = L.top < L.base ? 0 : L.top - L.base + 1;
-        if (ncol > kMatchMaxCols) { __syncthreads(); continue; }  // uniform: range too wide, no bound from this endpoint
+        if (ncol > kMatchMaxCols) { group_sync(); continue; }  // uniform: range too wide, no bound from this endpoint
         for (int r = t; r < nrow; r += nt)
             for (int q = 0; q < L.ndeg[r]; q++) L.col[r][q] = L.col[r][q] - base + 1;
         if (t == 0) L.ncol_real = ncol;
-        __syncthreads();
+        group_sync();
         hungarian_coop(L);
         const bool cut = L.accs[L.d] + L.bound <= L.best_w;
-        __syncthreads();
+        group_sync();
         if (cut) { if (t == 0) L.prune = 1; break; }
     }
-    __syncthreads();
+    group_sync();
 }
 
 // thread 0 advances the depth-first search until it needs the matching bound (SEL_NEED_BOUND) or the
 // component is finished (SEL_DONE)
 __device__ void select_step(SelectLds& L, int E, bool resume_with_bound) {
+    static_assert(kBlkWords == 3, "the blocked mask is kept in three registers");
     int d = L.d;
     bool entered = L.entered != 0;
     const int cm = L.cm;
@@ -1652,35 +1657,40 @@ __device__ void select_step(SelectLds& L, int E, bool resume_with_bound) {
         if (L.prune) { d--; entered = false; }
         else { L.next[d] = 0; entered = false; }
     }
+    unsigned long long b0 = 0, b1 = 0, b2 = 0;  // candidates blocked at depth d (valid after a descent; reloaded after a return)
+    bool have = false;
     while (d >= 0) {
         if (entered) {
             if (L.nodes >= kNodeBudget) { L.budget_hit = 1; break; }
             L.nodes++;
             if (d == cm) {
                 if (L.accs[d] > L.best_w) { L.best_w = L.accs[d]; for (int q = 0; q < cm; q++) L.best[q] = L.cur[q]; }
-                d--; entered = false; continue;
+                d--; entered = false; have = false; continue;
             }
-            if (L.accs[d] + L.ub[d] <= L.best_w) { d--; entered = false; continue; }
+            if (L.accs[d] + L.ub[d] <= L.best_w) { d--; entered = false; have = false; continue; }
             if (L.nodes > kPlainNodes && cm - d >= kMatchMinDepth) { L.d = d; L.entered = 1; L.state = SEL_NEED_BOUND; return; }
             L.next[d] = 0;
         }
+        if (!have) { b0 = L.blk[d][0]; b1 = L.blk[d][1]; b2 = L.blk[d][2]; have = true; }
         const int b = L.mem[d], nc = L.ncand[b];
-        if (L.cur[d] >= 0) { lds_mark(L, E, b, L.cur[d], false); L.cur[d] = -1; }  // back from the subtree of the previous option
         int k = L.next[d];
         bool descended = false;
         for (; k <= nc; k++) {
-            if (k == nc) {
+            if (k == nc) {  // "none"
                 L.cur[d] = -1; L.next[d] = (int8_t)(nc + 1); L.accs[d + 1] = L.accs[d];
+                L.blk[d + 1][0] = b0; L.blk[d + 1][1] = b1; L.blk[d + 1][2] = b2;
                 d++; entered = true; descended = true; break;
             }
             const double w = L.w[b][k];
             if (!(w > 0.0)) continue;
-            if (lds_clash(L, E, d, b, k)) continue;
+            const int bit = d * kTopK + k;
+            if (((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull) continue;
             L.cur[d] = (int8_t)k; L.next[d] = (int8_t)(k + 1); L.accs[d + 1] = L.accs[d] + w;
-            lds_mark(L, E, b, k, true);
+            b0 |= L.cmask3[d][k][0]; b1 |= L.cmask3[d][k][1]; b2 |= L.cmask3[d][k][2];
+            L.blk[d + 1][0] = b0; L.blk[d + 1][1] = b1; L.blk[d + 1][2] = b2;
             d++; entered = true; descended = true; break;
         }
-        if (!descended) { L.cur[d] = -1; d--; entered = false; }
+        if (!descended) { L.cur[d] = -1; d--; entered = false; have = false; }
     }
     L.d = d;
     L.state = SEL_DONE;
@@ -1697,30 +1707,48 @@ __device__ void select_brute(SelectLds& L, int E) {
     const int lane = t & 63, wave = t >> 6, nwave = (nt + 63) >> 6;
     constexpr int C = kTopK + 1;
     const int cm = L.cm;
+    // conflicts among the component's <= 20 candidates as bit masks (bit y*kTopK+k2 of cmask[x][k]: candidate k of
+    // member x shares an outgoing span with candidate k2 of member y), so that a combination is checked with one
+    // mask per chosen candidate instead of 2E index comparisons per pair of chosen candidates
+    for (int q = t; q < kBruteMax * kTopK + kBruteMax; q += nt) {
+        if (q < kBruteMax * kTopK) L.cmask[q / kTopK][q % kTopK] = 0; else L.celig[q - kBruteMax * kTopK] = 0;
+    }
+    group_sync();
+    for (int q = t; q < cm * kTopK * cm; q += nt) {
+        const int x = q / (kTopK * cm), k = (q / cm) % kTopK, y = q % cm;
+        const int bx = L.mem[x], by = L.mem[y];
+        if (k >= L.ncand[bx] || !(L.w[bx][k] > 0.0)) continue;
+        if (y == x) { atomicOr(&L.celig[x], 1u << k); continue; }
+        uint32_t bits = 0;
+        for (int k2 = 0; k2 < L.ncand[by]; k2++)
+            if (L.w[by][k2] > 0.0 && lds_share(L, E, bx, k, by, k2)) bits |= 1u << (y * kTopK + k2);
+        if (bits) atomicOr(&L.cmask[x][k], bits);
+    }
+    group_sync();
     int total = 1;
     for (int x = 0; x < cm; x++) total *= C;
     double bsum = 0.0;
     int bidx = 0x7fffffff;
     for (int q = t; q < total; q += nt) {
-        int ch[kBruteMax], rest = q;
+        int rest = q;
+        int ch[kBruteMax];
 #pragma unroll
         for (int x = kBruteMax - 1; x >= 0; x--) {
             if (x < cm) { ch[x] = rest % C; rest /= C; } else ch[x] = kTopK;
         }
         bool ok = true;
+        uint32_t sel = 0, clash = 0;
         double sum = 0.0;
 #pragma unroll
         for (int x = 0; x < kBruteMax; x++) {
-            if (x < cm && ok && ch[x] != kTopK) {
-                const int b = L.mem[x];
-                if (ch[x] >= L.ncand[b] || !(L.w[b][ch[x]] > 0.0)) ok = false;
-#pragma unroll
-                for (int y = 0; y < x; y++)
-                    if (ok && ch[y] != kTopK && lds_share(L, E, L.mem[y], ch[y], b, ch[x])) ok = false;
-                if (ok) sum += L.w[b][ch[x]];
+            if (x < cm && ch[x] != kTopK) {
+                ok = ok && ((L.celig[x] >> ch[x]) & 1u);
+                sel |= 1u << (x * kTopK + ch[x]);
+                clash |= L.cmask[x][ch[x]];
+                sum += L.w[L.mem[x]][ch[x]];  // left to right
             }
         }
-        if (ok && sum > bsum) { bsum = sum; bidx = q; }  // own indices increase: the first maximum stays
+        if (ok && (sel & clash) == 0 && sum > bsum) { bsum = sum; bidx = q; }  // own indices increase: the first maximum stays
     }
     for (int off = 32; off >= 1; off >>= 1) {
         if (off < nt) {
@@ -1730,9 +1758,9 @@ __device__ void select_brute(SelectLds& L, int E) {
         }
     }
     if (nwave > 1) {
-        __syncthreads();
+        group_sync();
         if (lane == 0) { L.red_val[wave] = bsum; L.red_idx[wave] = bidx; }
-        __syncthreads();
+        group_sync();
         if (t == 0)
             for (int q = 1; q < nwave; q++)
                 if (L.red_val[q] > bsum || (L.red_val[q] == bsum && L.red_idx[q] < bidx)) { bsum = L.red_val[q]; bidx = L.red_idx[q]; }
@@ -1745,11 +1773,30 @@ __device__ void select_brute(SelectLds& L, int E) {
             L.pick[L.mem[x]] = (int8_t)(k == kTopK ? -1 : k);
         }
     }
-    __syncthreads();
+    group_sync();
 }
 
-__device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int first, int m, SelectLds& L) {
+// Optional phase timers of the selection kernel (build with -DTW_PROFILE_SEL; read back through tw_debug_profile):
+// accumulated per wavefront in registers, flushed once when the wavefront retires.  Compiled out by default.
+#ifdef TW_PROFILE_SEL
+__device__ long long g_sel_acc[8];
+#define TW_SEL_T0() long long _st = wall_clock64()
+#define TW_SEL_TICK(k) do { const long long _n = wall_clock64(); sel_acc[k] += _n - _st; _st = _n; } while (0)
+#define TW_SEL_DECL() long long sel_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TW_SEL_FLUSH() do { if (threadIdx.x == 0) for (int _k = 0; _k < 8; _k++) atomicAdd((unsigned long long*)&P.prof[_k], (unsigned long long)sel_acc[_k]); } while (0)
+#define TW_SEL_ARG , long long (&sel_acc)[8]
+#define TW_SEL_PASS , sel_acc
+#else
+#define TW_SEL_T0() do {} while (0)
+#define TW_SEL_TICK(k) do {} while (0)
+#define TW_SEL_DECL() do {} while (0)
+#define TW_SEL_FLUSH() do {} while (0)
+#define TW_SEL_ARG
+#define TW_SEL_PASS
+#endif
+__device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int first, int m, SelectLds& L TW_SEL_ARG) {
     const int t = threadIdx.x, nt = blockDim.x, E = U.E;
+    TW_SEL_T0();
     for (int q = t; q < m * kTopK; q += nt) {
         const int b = q / kTopK, k = q % kTopK;
         const int n = cand_n(P, U, first + b);
@@ -1759,7 +1806,8 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
     }
     if (t == 0) L.budget_hit = 0;
     for (int b = t; b < m; b += nt) L.adj[b] = 0;
-    __syncthreads();
+    group_sync();
+    TW_SEL_TICK(0);
     // span conflict relation: b ~ c iff an eligible candidate of b shares an outgoing span with an eligible
     // candidate of c; one lane per pair
     for (int q = t; q < m * m; q += nt) {
@@ -1773,7 +1821,8 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
         }
         if (hit) { atomicOr(&L.adj[b], 1u << c); atomicOr(&L.adj[c], 1u << b); }
     }
-    __syncthreads();
+    group_sync();
+    TW_SEL_TICK(1);
     if (t == 0) {  // connected components, labelled by their smallest member
         uint32_t seen = 0;
         for (int b = 0; b < m; b++) {
@@ -1790,30 +1839,37 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             for (int v = 0; v < m; v++) if ((members >> v) & 1) L.comp[v] = (uint8_t)b;
         }
     }
-    __syncthreads();
+    group_sync();
+    TW_SEL_TICK(2);
     for (int root = 0; root < m; root++) {
         if (L.comp[root] != root) continue;  // uniform: comp is in LDS and stable here
+        TW_SEL_TICK(6);
         if (t == 0) {
             int cm = 0;
             for (int b = root; b < m; b++) if (L.comp[b] == root) L.mem[cm++] = (uint8_t)b;
             L.cm = cm;
             // (the rest prepares the depth-first search of a component too large for complete enumeration)
             for (int d = 0; d < cm && cm > kBruteMax; d++) { L.cur[d] = -1; L.best[d] = -1; L.g2[d] = 0; L.g3[d] = 0; }
-            L.use_bits = 1;
-            for (int e = 0; e < E && cm > kBruteMax; e++) {
-                int32_t lo = 0x7fffffff, hi = -1;
-                for (int d = 0; d < cm; d++)
-                    for (int k = 0; k < L.ncand[L.mem[d]]; k++) {
-                        const int32_t x = L.idx[L.mem[d]][k][e];
-                        lo = x < lo ? x : lo; hi = x > hi ? x : hi;
+        }
+        group_sync();
+        TW_SEL_TICK(3);
+        if (L.cm <= kBruteMax) { select_brute(L, E); TW_SEL_TICK(4); continue; }  // uniform: cm is in LDS and stable here
+        {   // conflict masks of the component's candidates (only between members whose candidate lists meet at all)
+            const int cm = L.cm;
+            for (int q = t; q < cm * kTopK * kBlkWords; q += nt) (&L.cmask3[0][0][0])[q] = 0;
+            for (int q = t; q < kBlkWords; q += nt) L.blk[0][q] = 0;
+            group_sync();
+            for (int q = t; q < cm * kTopK * cm; q += nt) {
+                const int x = q / (kTopK * cm), k = (q / cm) % kTopK, y = q % cm;
+                const int bx = L.mem[x], by = L.mem[y];
+                if (y == x || !((L.adj[bx] >> by) & 1u) || k >= L.ncand[bx] || !(L.w[bx][k] > 0.0)) continue;
+                for (int k2 = 0; k2 < L.ncand[by]; k2++)
+                    if (L.w[by][k2] > 0.0 && lds_share(L, E, bx, k, by, k2)) {
+                        const int bit = y * kTopK + k2;
+                        atomicOr(&L.cmask3[x][k][bit >> 6], 1ull << (bit & 63));
                     }
-                L.ubase[e] = lo;
-                if (hi - lo >= 64 * kUsedWords) L.use_bits = 0;
-                for (int q = 0; q < kUsedWords; q++) L.used_bits[e][q] = 0;
             }
         }
-        __syncthreads();
-        if (L.cm <= kBruteMax) { select_brute(L, E); continue; }  // uniform: cm is in LDS and stable here
         {   // Upper bound of a suffix d..cm-1 of the component: cut it into groups of 1-3 consecutive spans, solve
             // every group exactly on its own (conflicts inside the group only) and take the cheapest cutting.  It
             // sees spans that compete for the same outgoing spans (one of them must stay unassigned: -10000), which
@@ -1839,7 +1895,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
                 if (ok && sum > 0.0) atomicMax(g == 2 ? &L.g2[d] : &L.g3[d], (unsigned long long)__double_as_longlong(sum));
             }
         }
-        __syncthreads();
+        group_sync();
         if (t == 0) {
             const int cm = L.cm;
             L.ub[cm] = 0.0;
@@ -1854,18 +1910,21 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             L.best_w = 0.0; L.nodes = 0; L.d = 0; L.accs[0] = 0.0; L.entered = 1; L.state = SEL_RUN;
             select_step(L, E, false);
         }
-        __syncthreads();
+        group_sync();
         while (L.state == SEL_NEED_BOUND) {
             match_prunes_coop(L, E);
             if (t == 0) select_step(L, E, true);
-            __syncthreads();
+            group_sync();
         }
         if (t == 0) for (int q = 0; q < L.cm; q++) L.pick[L.mem[q]] = L.best[q];
-        __syncthreads();
+        group_sync();
+        TW_SEL_TICK(5);
     }
+    TW_SEL_TICK(6);
     for (int b = t; b < m; b += nt) P.chosen[U.in_off + first + b] = L.pick[b];
     if (t == 0 && L.budget_hit) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 4], 1ull);
-    __syncthreads();
+    group_sync();
+    TW_SEL_TICK(7);
 }
 
 // Fast path, one lane per incoming span.  When the best candidates (list position 0) of a window's spans
@@ -1910,21 +1969,22 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
     __shared__ int next_item;
     const int count = *P.heavy_count;
     int chunk_pos = 0, chunk_end = 0;
+    TW_SEL_DECL();
     while (true) {
         if (chunk_pos == chunk_end) {  // dynamic distribution (search effort varies by orders of magnitude), kWorkChunk windows per atomic
             if (threadIdx.x == 0) next_item = atomicAdd(P.heavy_next, kWorkChunk);
-            __syncthreads();
+            group_sync();
             chunk_pos = next_item;
-            __syncthreads();
+            group_sync();
             chunk_end = chunk_pos + kWorkChunk < count ? chunk_pos + kWorkChunk : count;
-            if (chunk_pos >= count) break;
+            if (chunk_pos >= count) { TW_SEL_FLUSH(); break; }
         }
         const int item = chunk_pos++;
         const int unit = __builtin_amdgcn_readfirstlane(P.heavy_unit[item]), w = __builtin_amdgcn_readfirstlane(P.heavy_win[item]);  // wave-uniform: scalar loads below
         const UnitDev& U = P.units[unit];
         const int last = P.w_last[U.in_off + w];
         const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
-        select_window_coop(P, U, unit, first, last - first + 1, L);
+        select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS);
     }
 }
 
@@ -2017,6 +2077,7 @@ __global__ void __launch_bounds__(kCoop) k_repair(Dev P, int pass) {
     const int t = threadIdx.x, nt = blockDim.x, nwin = P.unit_nwin[u];
     int w = 0;
     int64_t repaired = 0;
+    TW_SEL_DECL();
     while (true) {
         // next flagged window >= w
         __syncthreads();
@@ -2067,7 +2128,7 @@ __global__ void __launch_bounds__(kCoop) k_repair(Dev P, int pass) {
             }
             __threadfence();
             __syncthreads();
-            select_window_coop(P, U, u, first, m, L);
+            select_window_coop(P, U, u, first, m, L TW_SEL_PASS);
             if (t == 0) repaired++;
             __threadfence();
             __syncthreads();
