@@ -152,6 +152,30 @@ int tw_get_gauss_params(tw_engine *e, double *gauss);
  * sums), ms[6] last tw_fit_mixtures call. */
 int tw_get_timing(tw_engine *e, double *ms, int32_t n);
 
+/* ---- neighbours of the hot path on the same device arrays -------------------------------
+ *
+ * Replaces: FindOrder (executor.py:214-285), the call-order DAG the scorer is given: dag[a*E+b] = 1 iff in every
+ * request the true call to endpoint a ended no later than the true call to endpoint b started.  Works on units
+ * *before* they are loaded (endpoints in any order, e.g. partition-key order): unit_in_off / unit_E / ep_off /
+ * out_start / out_end as in tw_batch, true_child[sum_u E_u * n_in_u] = per unit [E][n_in] index of the true
+ * outgoing span of request i at endpoint e in that endpoint's list (< 0 = unknown).  dag_out[sum_u E_u*E_u]. */
+int tw_find_order(tw_engine *e, int32_t n_units, const int64_t *unit_in_off, const int32_t *unit_E,
+                  const int64_t *ep_off, const int64_t *out_start, const int64_t *out_end,
+                  const int32_t *true_child, uint8_t *dag_out);
+
+/* Ground truth of the loaded batch for tw_evaluate: true_child in the layout of tw_results.parent;
+ * in_trace[n_in_total] (may be NULL) = trace number in [0, n_traces) of every incoming span, for the per-trace
+ * (end-to-end) accuracy.  Call after tw_load_batch. */
+int tw_set_truth(tw_engine *e, const int32_t *true_child, const int32_t *in_trace, int64_t n_traces);
+
+/* Replaces: AccuracyForService / TopKAccuracyForService (helpers/utils.py:62-97) and AccuracyEndToEnd /
+ * TopKAccuracyEndToEnd (helpers/utils.py:99-145) as reductions over the resident results of the last pass run.
+ * per_unit[n_units][4] = requests, requests with every endpoint right, requests whose top-5 list holds the true
+ * tuple, requests left unassigned.  trace_flags (may be NULL; needs in_trace): [2][n_traces] uint8, 1 = some span of
+ * the trace is wrong (exact / top-5) -- combine across ranks with a MAX all-reduce; e2e[2] (may be NULL) = traces
+ * right under the exact / the top-5 criterion on this engine alone. */
+int tw_evaluate(tw_engine *e, int64_t *per_unit, uint8_t *trace_flags, int64_t *e2e);
+
 /* One-shot convenience for a single unit: load, pass 1, (optional) pass 2 with caller-supplied
  * mixtures, results of the last pass run.  mix_n == NULL => pass 1 only. */
 int tw_assign_service(tw_engine *e, int32_t n_in, const int64_t *in_start, const int64_t *in_end,

@@ -40,7 +40,7 @@ class Results(ctypes.Structure):
 
 EXPORTS = ["tw_create", "tw_destroy", "tw_last_error", "tw_load_batch", "tw_run_pass1", "tw_get_gaps",
            "tw_set_mixtures", "tw_fit_mixtures", "tw_get_mixtures", "tw_run_pass2", "tw_get_results", "tw_get_gauss_params", "tw_get_timing",
-           "tw_assign_service"]
+           "tw_assign_service", "tw_find_order", "tw_set_truth", "tw_evaluate"]
 
 
 def load(path=None):
@@ -68,6 +68,9 @@ def load(path=None):
     lib.tw_get_timing.argtypes = [vp, vp, ctypes.c_int32]
     lib.tw_assign_service.argtypes = [vp, ctypes.c_int32, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp,
                                       ctypes.POINTER(Results)]
+    lib.tw_find_order.argtypes = [vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    lib.tw_set_truth.argtypes = [vp, vp, vp, ctypes.c_int64]
+    lib.tw_evaluate.argtypes = [vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("tw_destroy", "tw_last_error"):
             getattr(lib, name).restype = ctypes.c_int

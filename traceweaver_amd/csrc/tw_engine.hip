@@ -15,6 +15,7 @@
 #include "traceweaver_amd.h"
 #include "tw_kernels.h"
 #include "tw_fit.h"
+#include "tw_eval.h"
 
 using namespace tw;
 
@@ -64,6 +65,10 @@ struct tw_engine {
     unsigned long long *comp_a = nullptr, *comp_b = nullptr;  // composite keys of sort_rows
     int64_t comp_cap = 0, n_gap_scored = 0;
     unsigned long long ts_fixed = 0;        // the bits all end times share above ts_end_bit
+    int32_t *truth = nullptr, *in_trace = nullptr;  // tw_set_truth
+    uint8_t* trace_bad = nullptr;           // [2][n_traces]
+    unsigned long long* eval_counts = nullptr;  // [n_units][4] + [2]
+    int64_t n_traces = 0, trace_cap = 0;
     uint8_t* slot_scored = nullptr;
     int64_t n_gap_rows = 0;
     unsigned long long* key_acc = nullptr;  // [2] scratch of k_key_bits
@@ -100,6 +105,7 @@ int dev_alloc(tw_engine* e, T** p, int64_t count) {
 void free_all(tw_engine* e) {
     for (void* q : e->allocs) (void)hipFree(q);
     e->allocs.clear();
+    e->truth = nullptr; e->in_trace = nullptr; e->trace_bad = nullptr; e->eval_counts = nullptr; e->n_traces = 0; e->trace_cap = 0;
     e->state = ST_EMPTY;
 }
 
@@ -656,6 +662,119 @@ int tw_debug_profile(tw_engine* e, unsigned long long* out16) {
     if (e == nullptr || out16 == nullptr || e->state < ST_LOADED) return TW_ERR_ARG;
     HIPCHK(hipMemcpyAsync(out16, e->P.prof, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return TW_OK;
+}
+
+int tw_find_order(tw_engine* e, int32_t n_units, const int64_t* unit_in_off, const int32_t* unit_E, const int64_t* ep_off,
+                  const int64_t* out_start, const int64_t* out_end, const int32_t* true_child, uint8_t* dag_out) {
+    if (e == nullptr || n_units <= 0 || !unit_in_off || !unit_E || !ep_off || !out_start || !out_end || !true_child || !dag_out) return TW_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<int64_t> ep_base((size_t)n_units), ie_off((size_t)n_units);
+    int64_t epi = 0, ie = 0, max_n = 0;
+    for (int u = 0; u < n_units; u++) {
+        if (unit_E[u] < 1 || unit_E[u] > TW_MAX_EP) return fail(e, TW_ERR_UNSUPPORTED, "unit has E outside [1, TW_MAX_EP]");
+        const int64_t n = unit_in_off[u + 1] - unit_in_off[u];
+        ep_base[(size_t)u] = epi; ie_off[(size_t)u] = ie;
+        epi += unit_E[u]; ie += n * unit_E[u];
+        max_n = std::max(max_n, n);
+    }
+    const int64_t n_out = ep_off[epi];
+    std::vector<void*> tmp;
+    auto up = [&](const void* src, size_t bytes, void** dst) -> hipError_t {
+        hipError_t s = hipMalloc(dst, std::max<size_t>(bytes, 8));
+        if (s != hipSuccess) return s;
+        tmp.push_back(*dst);
+        return hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, e->stream);
+    };
+    OrderDev O{};
+    O.n_units = n_units;
+    void *d_io, *d_E, *d_eb, *d_eo, *d_ie, *d_os, *d_oe, *d_tr, *d_v;
+    hipError_t s = up(unit_in_off, sizeof(int64_t) * (size_t)(n_units + 1), &d_io);
+    if (s == hipSuccess) s = up(unit_E, sizeof(int32_t) * (size_t)n_units, &d_E);
+    if (s == hipSuccess) s = up(ep_base.data(), sizeof(int64_t) * (size_t)n_units, &d_eb);
+    if (s == hipSuccess) s = up(ep_off, sizeof(int64_t) * (size_t)(epi + 1), &d_eo);
+    if (s == hipSuccess) s = up(ie_off.data(), sizeof(int64_t) * (size_t)n_units, &d_ie);
+    if (s == hipSuccess) s = up(out_start, sizeof(int64_t) * (size_t)n_out, &d_os);
+    if (s == hipSuccess) s = up(out_end, sizeof(int64_t) * (size_t)n_out, &d_oe);
+    if (s == hipSuccess) s = up(true_child, sizeof(int32_t) * (size_t)ie, &d_tr);
+    if (s == hipSuccess) { s = hipMalloc(&d_v, sizeof(unsigned long long) * (size_t)n_units); if (s == hipSuccess) tmp.push_back(d_v); }
+    if (s == hipSuccess) s = hipMemsetAsync(d_v, 0, sizeof(unsigned long long) * (size_t)n_units, e->stream);
+    std::vector<unsigned long long> viol((size_t)n_units, 0ull);
+    if (s == hipSuccess) {
+        O.unit_in_off = (const int64_t*)d_io; O.unit_E = (const int32_t*)d_E; O.ep_base = (const int64_t*)d_eb; O.ep_off = (const int64_t*)d_eo;
+        O.ie_off = (const int64_t*)d_ie; O.out_start = (const int64_t*)d_os; O.out_end = (const int64_t*)d_oe; O.truth = (const int32_t*)d_tr;
+        O.viol = (unsigned long long*)d_v;
+        const int threads = e->coop >= 64 ? 256 : e->coop;
+        const unsigned bx = (unsigned)std::min<int64_t>((max_n + threads - 1) / threads + 1, 1024);
+        for (int u0 = 0; u0 < n_units && s == hipSuccess; u0 += 32768) {  // grid.y is limited to 65535
+            OrderDev Q = O;
+            Q.unit_in_off += u0; Q.unit_E += u0; Q.ep_base += u0; Q.ie_off += u0; Q.viol += u0;
+            hipLaunchKernelGGL(k_find_order, dim3(bx, (unsigned)std::min(n_units - u0, 32768)), dim3((unsigned)threads), 0, e->stream, Q);
+            s = hipGetLastError();
+        }
+        if (s == hipSuccess) s = hipMemcpyAsync(viol.data(), d_v, sizeof(unsigned long long) * (size_t)n_units, hipMemcpyDeviceToHost, e->stream);
+        if (s == hipSuccess) s = hipStreamSynchronize(e->stream);
+    }
+    for (void* q : tmp) (void)hipFree(q);
+    if (s != hipSuccess) return fail(e, TW_ERR_DEVICE, std::string("tw_find_order: ") + hipGetErrorString(s));
+    int64_t di = 0;
+    for (int u = 0; u < n_units; u++) {
+        const int E = unit_E[u];
+        for (int a = 0; a < E; a++)
+            for (int b = 0; b < E; b++) dag_out[di + a * E + b] = (a != b && !((viol[(size_t)u] >> (a * TW_MAX_EP + b)) & 1ull)) ? 1 : 0;
+        di += E * E;
+    }
+    return TW_OK;
+}
+
+int tw_set_truth(tw_engine* e, const int32_t* true_child, const int32_t* in_trace, int64_t n_traces) {
+    if (e == nullptr || true_child == nullptr) return TW_ERR_ARG;
+    if (e->state < ST_LOADED) return fail(e, TW_ERR_STATE, "tw_set_truth before tw_load_batch");
+    if (in_trace != nullptr && n_traces <= 0) return fail(e, TW_ERR_ARG, "in_trace given without n_traces");
+    HIPCHK(hipSetDevice(e->device));
+    int rc;
+    if (e->truth == nullptr) {
+        rc = dev_alloc(e, &e->truth, e->n_ie); if (rc != TW_OK) return rc;
+        rc = dev_alloc(e, &e->eval_counts, (int64_t)e->P.n_units * 4 + 2); if (rc != TW_OK) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(e->truth, true_child, sizeof(int32_t) * e->n_ie, hipMemcpyHostToDevice, e->stream));
+    e->n_traces = 0;
+    if (in_trace != nullptr) {  // (buffers are freed with the batch)
+        if (e->in_trace == nullptr) { rc = dev_alloc(e, &e->in_trace, e->P.n_in_total); if (rc != TW_OK) return rc; }
+        if (e->trace_bad == nullptr || n_traces > e->trace_cap) {
+            rc = dev_alloc(e, &e->trace_bad, 2 * n_traces); if (rc != TW_OK) return rc;
+            e->trace_cap = n_traces;
+        }
+        HIPCHK(hipMemcpyAsync(e->in_trace, in_trace, sizeof(int32_t) * e->P.n_in_total, hipMemcpyHostToDevice, e->stream));
+        e->n_traces = n_traces;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TW_OK;
+}
+
+int tw_evaluate(tw_engine* e, int64_t* per_unit, uint8_t* trace_flags, int64_t* e2e) {
+    if (e == nullptr || per_unit == nullptr) return TW_ERR_ARG;
+    if (e->state != ST_PASS1 && e->state != ST_MIX && e->state != ST_PASS2) return fail(e, TW_ERR_STATE, "tw_evaluate needs the results of a pass");
+    if (e->truth == nullptr) return fail(e, TW_ERR_STATE, "tw_evaluate before tw_set_truth");
+    if ((trace_flags != nullptr || e2e != nullptr) && e->n_traces == 0) return fail(e, TW_ERR_STATE, "per-trace accuracy needs in_trace (tw_set_truth)");
+    HIPCHK(hipSetDevice(e->device));
+    const Dev& P = e->P;
+    const int64_t nc = (int64_t)P.n_units * 4 + 2;
+    HIPCHK(hipMemsetAsync(e->eval_counts, 0, sizeof(unsigned long long) * nc, e->stream));
+    if (e->n_traces > 0) HIPCHK(hipMemsetAsync(e->trace_bad, 0, (size_t)(2 * e->n_traces), e->stream));
+    hipLaunchKernelGGL(k_evaluate, dim3(P.n_tiles), dim3(e->tile), 0, e->stream, P, (const int32_t*)e->truth,
+                       (const int32_t*)(e->n_traces > 0 ? e->in_trace : nullptr), e->eval_counts, e->trace_bad,
+                       e->n_traces > 0 ? e->trace_bad + e->n_traces : nullptr);
+    if (e->n_traces > 0 && e2e != nullptr)
+        hipLaunchKernelGGL(k_count_flags, dim3((unsigned)std::min<int64_t>(e->n_traces / 1024 + 1, 1024)), dim3(e->coop >= 64 ? 256 : e->coop), 0, e->stream,
+                           (const uint8_t*)e->trace_bad, (const uint8_t*)(e->trace_bad + e->n_traces), e->n_traces, e->eval_counts + (nc - 2));
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned long long> h((size_t)nc);
+    HIPCHK(hipMemcpyAsync(h.data(), e->eval_counts, sizeof(unsigned long long) * nc, hipMemcpyDeviceToHost, e->stream));
+    if (trace_flags != nullptr) HIPCHK(hipMemcpyAsync(trace_flags, e->trace_bad, (size_t)(2 * e->n_traces), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int64_t q = 0; q < (int64_t)P.n_units * 4; q++) per_unit[q] = (int64_t)h[(size_t)q];
+    if (e2e != nullptr) { e2e[0] = (int64_t)h[(size_t)nc - 2]; e2e[1] = (int64_t)h[(size_t)nc - 1]; }
     return TW_OK;
 }
 

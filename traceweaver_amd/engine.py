@@ -56,6 +56,7 @@ class Engine(object):
             raise EngineError(rc, "tw_create failed on device %d" % device)
         self.units = []
         self._keep = None
+        self._n_traces = 0
 
     def close(self):
         if self._h:
@@ -179,6 +180,58 @@ class Engine(object):
                 o.update({"not_best_count": int(st[0]), "cnt_unassigned": int(st[1]), "n_windows": int(st[2]),
                           "repaired_windows": int(st[3]), "budget_windows": int(st[4])})
             out.append(o)
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def set_truth(self, true_parent, in_trace=None, n_traces=0):
+        """Ground truth of the loaded batch: per unit [E, n_in] index of the true outgoing span; optionally per
+        unit [n_in] trace numbers in [0, n_traces) for the per-trace (end-to-end) accuracy."""
+        t = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int32).ravel() for a in true_parent]), dtype=np.int32)
+        if len(t) != self._ie_off[-1]:
+            raise ValueError("truth does not match the loaded batch")
+        tr = None
+        if in_trace is not None:
+            tr = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int32).ravel() for a in in_trace]), dtype=np.int32)
+            if len(tr) != self._in_off[-1]:
+                raise ValueError("in_trace does not match the loaded batch")
+        self._n_traces = int(n_traces) if tr is not None else 0
+        self._check(self._lib.tw_set_truth(self._h, _vp(t), _vp(tr), int(n_traces)))
+
+    def evaluate(self, trace_flags=False):
+        """helpers/utils.py:62-145 on the device, for the last pass run.  Returns per unit
+        {n_in, correct, correct_topk, unassigned, accuracy, topk_accuracy} and, when trace numbers were given,
+        (traces right, traces right under top-5) -- plus the raw [2, n_traces] wrong-flags if asked for."""
+        per = np.zeros((len(self.units), 4), dtype=np.int64)
+        flags = np.zeros((2, self._n_traces), dtype=np.uint8) if (trace_flags and self._n_traces) else None
+        e2e = np.zeros(2, dtype=np.int64) if self._n_traces else None
+        self._check(self._lib.tw_evaluate(self._h, _vp(per), _vp(flags), _vp(e2e)))
+        out = [{"n_in": int(r[0]), "correct": int(r[1]), "correct_topk": int(r[2]), "unassigned": int(r[3]),
+                "accuracy": float(r[1]) / max(int(r[0]), 1), "topk_accuracy": float(r[2]) / max(int(r[0]), 1)} for r in per]
+        if e2e is None:
+            return out
+        return (out, (int(e2e[0]), int(e2e[1])), flags) if trace_flags else (out, (int(e2e[0]), int(e2e[1])))
+
+    def find_order(self, units, true_parent):
+        """executor.py:214-285 (FindOrder) on the device for units that need not be loaded (endpoints in any
+        order): per unit the uint8 [E, E] call-order relation implied by the true assignments."""
+        units = list(units)
+        in_off = np.zeros(len(units) + 1, dtype=np.int64)
+        np.cumsum([u.n_in for u in units], out=in_off[1:])
+        unit_E = np.array([u.E for u in units], dtype=np.int32)
+        ep_off, base = [0], 0
+        for u in units:
+            ep_off.extend((base + u.out_off[1:]).tolist())
+            base += int(u.out_off[-1])
+        ep_off = np.array(ep_off, dtype=np.int64)
+        os_ = np.ascontiguousarray(np.concatenate([u.out_start for u in units]))
+        oe_ = np.ascontiguousarray(np.concatenate([u.out_end for u in units]))
+        t = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int32).ravel() for a in true_parent]), dtype=np.int32)
+        dag = np.zeros(int(sum(int(e) * int(e) for e in unit_E)), dtype=np.uint8)
+        self._check(self._lib.tw_find_order(self._h, len(units), _vp(in_off), _vp(unit_E), _vp(ep_off), _vp(os_), _vp(oe_), _vp(t), _vp(dag)))
+        out, p = [], 0
+        for e in unit_E:
+            out.append(dag[p:p + int(e) * int(e)].reshape(int(e), int(e)).copy())
+            p += int(e) * int(e)
         return out
 
     def timing(self):
