@@ -183,6 +183,65 @@ int tw_assign_service(tw_engine *e, int32_t n_in, const int64_t *in_start, const
                       const uint8_t *dag, const int32_t *key_rank, const int32_t *mix_n,
                       const double *mix_p, const tw_results *r);
 
+/* ---- Jaeger-JSON ingest -> structure of arrays (host side) ------------------------------------
+ *
+ * Replaces the reference's loader for corpora that need no span rewriting: GetAllTracesInDir / TimeOrder
+ * (executor.py:287-339), ParseJsonTrace / ParseSpansJson / ParseProcessesJson(2) (executor.py:342-384,451-461,
+ * 755-793), ProcessTraceData (executor.py:795-849), PartitionSpansByEndPoint (executor.py:1104-1113),
+ * GetGroundTruth (helpers/utils.py:22-32), FindOrder + nx.topological_sort (executor.py:214-285,
+ * traceweaver_v1.py:37-39).  The dataset-specific fix-ups (FixSpans / FixSpans2 / self-loop renaming) are not
+ * reproduced.  Names are interned: every *_name / service / span_id field below is a string id for
+ * tw_corpus_string(). */
+typedef struct tw_corpus tw_corpus;
+int tw_corpus_create(tw_corpus **out);
+void tw_corpus_destroy(tw_corpus *c);
+const char *tw_corpus_last_error(const tw_corpus *c);   /* first file that failed to parse, if any */
+
+/* Parses one-trace-per-file Jaeger JSON ({"data":[{"traceID","spans":[...],"processes":{...}}]}, or the
+ * requestType shape of alibaba-analysis/real-parser.py:308-359), n_threads parser threads (<= 0: up to 16),
+ * orders the traces by the start of their root span and adds those whose root operation is `first_span`
+ * (NULL / "" = any; executor.py:757-763,841) until max_traces (> 0; the reference stops at 1001,
+ * executor.py:873) traces are held.  Files that do not parse or break an assumption the reference asserts on
+ * are counted, not fatal. */
+int tw_corpus_add_files(tw_corpus *c, const char *const *paths, int32_t n_paths, const char *first_span,
+                        int64_t max_traces, int32_t n_threads);
+
+/* out6 = spans held, traces held, files seen, files that failed to parse, traces filtered out, strings. */
+int tw_corpus_counts(const tw_corpus *c, int64_t *out6);
+const char *tw_corpus_string(const tw_corpus *c, int32_t id);
+
+/* The span table (one row per span reached from its trace's root, in walk order); caller-allocated columns of
+ * tw_corpus_counts()[0] entries, any may be NULL.  parent = row of the referenced span (-1 for roots),
+ * kind: 1 server (incoming), 2 client (outgoing). */
+typedef struct {
+    int32_t *trace, *span_id, *service, *op_name, *parent;
+    int64_t *start, *duration;
+    uint8_t *kind;
+} tw_span_table;
+int tw_corpus_span_table(const tw_corpus *c, tw_span_table *t);
+
+/* Every service with a single caller whose endpoints each hold one call per request becomes a unit, in the
+ * layout tw_load_batch takes (first nine fields = tw_batch's); pointers stay owned by the corpus and are valid
+ * until the next call.  true_child / in_trace as in tw_find_order / tw_set_truth; in_row / out_row = span-table
+ * row of every incoming / outgoing span (to translate results back to (trace id, span id)); skipped[4] =
+ * services left out because they have several callers (executor.py:1126-1128), because an endpoint's span count
+ * differs from the number of requests (skip mode) or E > TW_MAX_EP, because they hold < 2 requests, because the
+ * call-order relation has a cycle. */
+typedef struct {
+    int32_t n_units;
+    const int64_t *unit_in_off;
+    const int32_t *unit_E;
+    const int64_t *ep_off;
+    const uint8_t *dag;
+    const int32_t *key_rank;
+    const int64_t *in_start, *in_end, *out_start, *out_end;
+    const int32_t *true_child, *in_trace, *in_row, *out_row;
+    const int32_t *unit_service, *ep_name, *in_ep_name;
+    int64_t n_traces;
+    int32_t skipped[4];
+} tw_unit_set;
+int tw_corpus_build_units(tw_corpus *c, tw_unit_set *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ SRC = os.path.join(REPO, "traceweaver_amd", "csrc")
 
 
 def build(force=False):
-    deps = [os.path.join(SRC, f) for f in ("tw_engine.hip", "tw_kernels.h", "tw_device.h", "tw_fit.h")]
+    deps = [os.path.join(SRC, f) for f in ("tw_engine.hip", "tw_kernels.h", "tw_device.h", "tw_fit.h", "tw_eval.h", "tw_ingest.cpp")]
     deps += [os.path.join(REPO, "include", "traceweaver_amd.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
              os.path.join(HERE, "rocprim", "rocprim.hpp")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
@@ -18,7 +18,8 @@ def build(force=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     subprocess.check_call([
         "g++", "-x", "c++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
-        "-I", HERE, "-I", os.path.join(REPO, "include"), "-I", SRC, os.path.join(SRC, "tw_engine.hip"), "-o", OUT])
+        "-I", HERE, "-I", os.path.join(REPO, "include"), "-I", SRC, os.path.join(SRC, "tw_engine.hip"),
+        "-x", "c++", os.path.join(SRC, "tw_ingest.cpp"), "-pthread", "-o", OUT])
     return OUT
 
 

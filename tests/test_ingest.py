@@ -1,0 +1,174 @@
+"""Native Jaeger-JSON ingest (csrc/tw_ingest.cpp) against (a) a plain-Python restatement of what
+the reference's executor does between reading a directory and calling the predictor (executor.py:287-339,
+755-849,1080-1135; helpers/utils.py:22-32) on generated corpora, and (b) the inputs frozen from the reference
+itself for the hotel corpus (tests/golden/ref_hotel_*; needs /root/reference for the JSON files)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from traceweaver_amd import synth
+from traceweaver_amd.engine import Engine
+from traceweaver_amd.ingest import Corpus
+
+REF_DATA = "/root/reference/data/hotel_reservation"
+
+
+def python_pipeline(paths, first_span, max_traces=1001):
+    """The reference's loader restated with dicts and lists (no span rewriting)."""
+    starts, docs = [], []
+    for p in paths:
+        d = json.load(open(p))["data"][0]
+        docs.append(d)
+        root = next((s for s in d["spans"] if len(s["references"]) == 0), None)
+        starts.append(float(root["startTime"]) if root else float("inf"))
+    order = sorted(range(len(paths)), key=lambda i: (starts[i], i))
+    ins, outs, spans_all, service_of, cnt = {}, {}, {}, {}, 0
+    for i in order:
+        d = docs[i]
+        tid = d["traceID"]
+        procs = {k: v["serviceName"] for k, v in d["processes"].items()}
+        spans = {}
+        for s in d["spans"]:
+            kind = [t["value"] for t in s["tags"] if t["key"] == "span.kind"][0]
+            spans[s["spanID"]] = dict(sid=s["spanID"], tid=tid, start=s["startTime"], dur=s["duration"], op=s["operationName"],
+                                      refs=[r["spanID"] for r in s["references"]], svc=procs[s["processID"]], kind=kind, children=[])
+        root = None
+        for s in spans.values():
+            if not s["refs"]:
+                root = s
+            for r in s["refs"]:
+                spans[r]["children"].append(s["sid"])
+        for s in spans.values():
+            s["children"].sort(key=lambda c: spans[c]["start"])
+        if first_span and root["op"] != first_span:
+            continue
+
+        def walk(s):
+            (outs if s["kind"] == "client" else ins).setdefault(s["svc"], []).append(s)
+            for c in s["children"]:
+                walk(spans[c])
+        walk(root)
+        spans_all.update({(tid, k): v for k, v in spans.items()})
+        cnt += 1
+        if cnt >= max_traces:
+            break
+    units = {}
+    for svc in outs:
+        def parts(lst, key):
+            out = {}
+            for s in lst:
+                out.setdefault(key(s), []).append(s)
+            for v in out.values():
+                v.sort(key=lambda x: (x["start"], x["start"] + x["dur"]))
+            return out
+        ip = parts(ins[svc], lambda s: ("client_" + s["op"]) if not s["refs"] else spans_all[(s["tid"], s["refs"][0])]["svc"])
+        op = parts(outs[svc], lambda s: spans_all[(s["tid"], s["children"][0])]["svc"])
+        if len(ip) != 1:
+            continue
+        in_ep, in_spans = list(ip.items())[0]
+        keys = list(op.keys())
+        truth = {k: [next((j for j, o in enumerate(op[k]) if o["tid"] == s["tid"]), -1) for s in in_spans] for k in keys}
+        E = len(keys)
+        rel = np.ones((E, E), np.uint8) - np.eye(E, dtype=np.uint8)
+        for i in range(len(in_spans)):
+            for a in range(E):
+                for b in range(E):
+                    if a != b:
+                        x, y = op[keys[a]][truth[keys[a]][i]], op[keys[b]][truth[keys[b]][i]]
+                        if x["start"] + x["dur"] > y["start"]:
+                            rel[a, b] = 0
+        topo = synth.topo_order(rel)
+        units[svc] = dict(in_ep=in_ep, out_eps=[keys[a] for a in topo], key_rank=topo,
+                          in_start=np.array([s["start"] for s in in_spans]), in_end=np.array([s["start"] + s["dur"] for s in in_spans]),
+                          out_start=np.concatenate([[o["start"] for o in op[keys[a]]] for a in topo]),
+                          out_end=np.concatenate([[o["start"] + o["dur"] for o in op[keys[a]]] for a in topo]),
+                          dag=rel[np.ix_(topo, topo)], truth=np.array([truth[keys[a]] for a in topo]),
+                          in_ids=[(s["tid"], s["sid"]) for s in in_spans])
+    return units
+
+
+@pytest.mark.parametrize("app,conc", [(synth.HOTEL_APP, 2.0), (synth.FANOUT_APP, 1.3)])
+def test_native_ingest_matches_python_restatement(emu_lib, tmp_path, app, conc):
+    paths = synth.write_jaeger_corpus(str(tmp_path), 5, 300, app=app, concurrency=conc)
+    paths = sorted(paths, reverse=True)  # any file order: the loader orders traces by root start
+    ref = python_pipeline(paths, app["root_op"])
+    c = Corpus(lib_path=emu_lib)
+    counts = c.add_files(paths, first_span=app["root_op"], threads=3)
+    assert counts["traces"] == 300 and counts["files_rejected"] == 0
+    units, skipped, n_traces = c.units()
+    assert n_traces == 300 and sum(skipped.values()) == 0
+    assert [u.service for u in units] == list(ref.keys())
+    table = c.span_table()
+    for u in units:
+        r, a = ref[u.service], u.arrays
+        assert u.in_ep == r["in_ep"] and u.out_eps == r["out_eps"] and a.key_rank.tolist() == r["key_rank"]
+        assert np.array_equal(a.in_start, r["in_start"]) and np.array_equal(a.in_end, r["in_end"])
+        assert np.array_equal(a.out_start, r["out_start"]) and np.array_equal(a.out_end, r["out_end"])
+        assert np.array_equal(a.dag, r["dag"]) and np.array_equal(u.true_parent, r["truth"])
+        got = [c.string(table["span_id"][row]) for row in u.in_rows]
+        assert got == [sid for _, sid in r["in_ids"]]          # rows translate back to span ids
+    c.close()
+
+
+def test_first_span_filter_and_limits(emu_lib, tmp_path):
+    paths = synth.write_jaeger_corpus(str(tmp_path / "a"), 1, 40, app=synth.HOTEL_APP)
+    other = synth.write_jaeger_corpus(str(tmp_path / "b"), 2, 10, app=synth.FANOUT_APP)
+    bad = tmp_path / "broken.json"
+    bad.write_text('{"data": [{"traceID": "x", "spans": [')
+    c = Corpus(lib_path=emu_lib)
+    counts = c.add_files(paths + other + [str(bad)], first_span="HTTP GET /hotels", max_traces=25)
+    assert counts["traces"] == 25 and counts["files_rejected"] == 1 and "broken.json" in c.first_error()
+    units, _, _ = c.units()
+    assert {u.service for u in units} == {"frontend", "search"} and all(u.arrays.n_in == 25 for u in units)
+    c.close()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="the reference's data directory is not present")
+@pytest.mark.parametrize("dataset", ["hotel_load100", "hotel_load150"])
+def test_native_ingest_reproduces_the_reference_inputs(emu_lib, dataset):
+    c = Corpus(lib_path=emu_lib)
+    c.add_directory(os.path.join(REF_DATA, dataset), first_span="HTTP GET /hotels", max_traces=1001)
+    units, skipped, _ = c.units()
+    assert sum(skipped.values()) == 0 and len(units) == 2
+    for u in units:
+        g = np.load([p for p in GOLDEN if "%s__%s" % (dataset, u.service) in p][0])
+        a = u.arrays
+        assert np.array_equal(a.in_start, g["in_start"]) and np.array_equal(a.in_end - a.in_start, g["in_dur"])
+        assert np.array_equal(a.out_off, g["out_off"]) and np.array_equal(a.out_start, g["out_start"])
+        assert np.array_equal(a.out_end - a.out_start, g["out_dur"]) and np.array_equal(a.dag, g["dag"])
+        assert u.out_eps == [str(x) for x in g["out_eps"]] and u.in_ep == str(g["in_ep"])
+        assert np.array_equal(u.true_parent, g["true_parent"])
+        order = [str(x) for x in g["partition_key_order"]]
+        assert a.key_rank.tolist() == [order.index(e) for e in u.out_eps]
+    c.close()
+
+
+def reconstruct(lib_path, tmp_path):
+    paths = synth.write_jaeger_corpus(str(tmp_path), 9, 2000, app=synth.FANOUT_APP, concurrency=1.4)
+    c = Corpus(lib_path=lib_path)
+    c.add_files(paths, first_span="compose", max_traces=0)
+    units, _, n_traces = c.units()
+    eng = Engine(0, lib_path=lib_path)
+    eng.load([u.arrays for u in units])
+    eng.set_truth([u.true_parent for u in units], [u.in_trace for u in units], n_traces)
+    eng.run_pass1()
+    eng.fit_mixtures()
+    eng.run_pass2()
+    per, (right, right_topk) = eng.evaluate()
+    eng.close()
+    c.close()
+    assert [u.service for u in units] == ["gateway", "text"] and [u.arrays.E for u in units] == [4, 2]
+    assert all(p["accuracy"] > 0.9 for p in per) and right_topk >= right > 0.85 * n_traces
+    return per
+
+
+def test_json_to_assignment_end_to_end_emulated(emu_lib, tmp_path):
+    reconstruct(emu_lib, tmp_path)
+
+
+@pytest.mark.gpu
+def test_json_to_assignment_end_to_end_gpu(tmp_path):
+    reconstruct(None, tmp_path)

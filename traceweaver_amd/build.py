@@ -8,11 +8,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libtwgpu.so")
-SOURCES = ["tw_engine.hip", "tw_kernels.h", "tw_device.h", "tw_fit.h"]
+SOURCES = ["tw_engine.hip", "tw_kernels.h", "tw_device.h", "tw_fit.h", "tw_eval.h", "tw_ingest.cpp"]
 
 # -ffp-contract=off: scores are chains of plain IEEE double operations in the reference's order;
 # an FMA would change the last bit and with it the resolution of exact ties (DESIGN.md "Scores").
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread"]
 
 
 def needs_build():
@@ -30,7 +30,7 @@ def build(force=False, extra_flags=()):
         raise RuntimeError("hipcc not found: the HIP engine cannot be built (there is no CPU fallback)")
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [hipcc] + FLAGS + list(extra_flags) + ["-I", os.path.join(REPO, "include"), "-I", SRC,
-                                                 os.path.join(SRC, "tw_engine.hip"), "-o", OUT]
+                                                 os.path.join(SRC, "tw_engine.hip"), os.path.join(SRC, "tw_ingest.cpp"), "-o", OUT]
     subprocess.check_call(cmd)
     return OUT
 

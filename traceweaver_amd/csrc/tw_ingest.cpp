@@ -1,0 +1,572 @@
+// tw_ingest.cpp -- Jaeger-JSON ingest into the engine's structure-of-arrays form (host side of libtwgpu.so;
+// SURVEY.md 8 f1).  Replaces the reference's Python loader for the corpora that need no span rewriting:
+//   GetAllTracesInDir / TimeOrder            executor.py:287-339   traces ordered by the start of their root span
+//   ParseJsonTrace / ParseSpansJson          executor.py:342-384,755-793   one trace per file, {"data":[{traceID, spans, processes}]}
+//   ParseProcessesJson / ParseProcessesJson2 executor.py:451-461   processID -> serviceName (or the id itself for requestType data)
+//   ProcessTraceData                         executor.py:795-849   pre-order walk from the root, children by start time;
+//                                                                  server spans = incoming, client spans = outgoing of their service
+//   PartitionSpansByEndPoint                 executor.py:1104-1113 by caller ("client_<op>" for roots) / callee service, sorted (start, end)
+//   GetGroundTruth                           helpers/utils.py:22-32 first outgoing span of the same trace per endpoint
+//   FindOrder + nx.topological_sort          executor.py:214-285, traceweaver_v1.py:37-39
+// The dataset-specific span surgery of the reference (FixSpans for nodejs, FixSpans2 for media, self-loop renaming
+// for the Alibaba parser output; executor.py:386-448,463-750) is not reproduced: such corpora are ingested by the
+// reference's loader and handed over through the predictor protocol.
+//
+// Strings never reach the GPU: every name is interned, units carry string ids and span-table rows so that the
+// caller can translate indices back to (trace id, span id) keys.
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "traceweaver_amd.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Minimal JSON reader (RFC 8259 values; numbers keep an exact int64 when they are integers).
+struct JVal {
+    enum Type { Null, Bool, Num, Str, Arr, Obj } type = Null;
+    bool b = false, is_int = false;
+    int64_t i = 0;
+    double d = 0.0;
+    std::string s;
+    std::vector<JVal> arr;
+    std::vector<std::pair<std::string, JVal>> obj;
+    const JVal* get(const char* key) const {
+        if (type != Obj) return nullptr;
+        for (const auto& kv : obj)
+            if (kv.first == key) return &kv.second;
+        return nullptr;
+    }
+};
+
+struct JParser {
+    const char* p;
+    const char* end;
+    std::string err;
+    int depth = 0;
+    bool fail(const char* m) { if (err.empty()) err = m; return false; }
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+    static void utf8(std::string& out, unsigned cp) {
+        if (cp < 0x80) out.push_back((char)cp);
+        else if (cp < 0x800) { out.push_back((char)(0xC0 | (cp >> 6))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+        else if (cp < 0x10000) { out.push_back((char)(0xE0 | (cp >> 12))); out.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+        else { out.push_back((char)(0xF0 | (cp >> 18))); out.push_back((char)(0x80 | ((cp >> 12) & 0x3F))); out.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+    }
+    bool hex4(unsigned& v) {
+        if (end - p < 4) return fail("truncated \\u escape");
+        v = 0;
+        for (int k = 0; k < 4; k++) {
+            const char c = *p++;
+            v <<= 4;
+            if (c >= '0' && c <= '9') v |= (unsigned)(c - '0');
+            else if (c >= 'a' && c <= 'f') v |= (unsigned)(c - 'a' + 10);
+            else if (c >= 'A' && c <= 'F') v |= (unsigned)(c - 'A' + 10);
+            else return fail("bad \\u escape");
+        }
+        return true;
+    }
+    bool str(std::string& out) {
+        if (p >= end || *p != '"') return fail("expected string");
+        p++;
+        out.clear();
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                p++;
+                if (p >= end) return fail("truncated escape");
+                const char c = *p++;
+                switch (c) {
+                    case '"': out.push_back('"'); break;
+                    case '\\': out.push_back('\\'); break;
+                    case '/': out.push_back('/'); break;
+                    case 'b': out.push_back('\b'); break;
+                    case 'f': out.push_back('\f'); break;
+                    case 'n': out.push_back('\n'); break;
+                    case 'r': out.push_back('\r'); break;
+                    case 't': out.push_back('\t'); break;
+                    case 'u': {
+                        unsigned cp;
+                        if (!hex4(cp)) return false;
+                        if (cp >= 0xD800 && cp < 0xDC00 && end - p >= 6 && p[0] == '\\' && p[1] == 'u') {
+                            p += 2;
+                            unsigned lo;
+                            if (!hex4(lo)) return false;
+                            cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                        }
+                        utf8(out, cp);
+                        break;
+                    }
+                    default: return fail("bad escape");
+                }
+            } else out.push_back(*p++);
+        }
+        if (p >= end) return fail("unterminated string");
+        p++;
+        return true;
+    }
+    bool value(JVal& v) {
+        ws();
+        if (p >= end) return fail("unexpected end of input");
+        if (++depth > 256) return fail("nesting too deep");
+        bool ok = true;
+        const char c = *p;
+        if (c == '{') {
+            v.type = JVal::Obj;
+            p++;
+            ws();
+            if (p < end && *p == '}') p++;
+            else {
+                while (ok) {
+                    ws();
+                    std::string key;
+                    if (!str(key)) { ok = false; break; }
+                    ws();
+                    if (p >= end || *p != ':') { ok = fail("expected ':'"); break; }
+                    p++;
+                    v.obj.emplace_back(std::move(key), JVal());
+                    if (!value(v.obj.back().second)) { ok = false; break; }
+                    ws();
+                    if (p < end && *p == ',') { p++; continue; }
+                    if (p < end && *p == '}') { p++; break; }
+                    ok = fail("expected ',' or '}'");
+                }
+            }
+        } else if (c == '[') {
+            v.type = JVal::Arr;
+            p++;
+            ws();
+            if (p < end && *p == ']') p++;
+            else {
+                while (ok) {
+                    v.arr.emplace_back();
+                    if (!value(v.arr.back())) { ok = false; break; }
+                    ws();
+                    if (p < end && *p == ',') { p++; continue; }
+                    if (p < end && *p == ']') { p++; break; }
+                    ok = fail("expected ',' or ']'");
+                }
+            }
+        } else if (c == '"') {
+            v.type = JVal::Str;
+            ok = str(v.s);
+        } else if (c == 't' && end - p >= 4 && !memcmp(p, "true", 4)) { v.type = JVal::Bool; v.b = true; p += 4; }
+        else if (c == 'f' && end - p >= 5 && !memcmp(p, "false", 5)) { v.type = JVal::Bool; v.b = false; p += 5; }
+        else if (c == 'n' && end - p >= 4 && !memcmp(p, "null", 4)) { v.type = JVal::Null; p += 4; }
+        else if (c == '-' || (c >= '0' && c <= '9')) {
+            const char* q = p;
+            bool integral = true;
+            if (*q == '-') q++;
+            while (q < end && *q >= '0' && *q <= '9') q++;
+            if (q < end && (*q == '.' || *q == 'e' || *q == 'E')) {
+                integral = false;
+                while (q < end && ((*q >= '0' && *q <= '9') || *q == '.' || *q == 'e' || *q == 'E' || *q == '+' || *q == '-')) q++;
+            }
+            const std::string tok(p, q);
+            v.type = JVal::Num;
+            v.d = strtod(tok.c_str(), nullptr);
+            if (integral && tok.size() <= 19) { v.is_int = true; v.i = strtoll(tok.c_str(), nullptr, 10); }
+            p = q;
+        } else ok = fail("unexpected character");
+        depth--;
+        return ok;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+struct SpanTmp {
+    std::string sid, op, pid;
+    std::vector<std::pair<std::string, std::string>> refs;  // (traceID, spanID)
+    int64_t start = 0, dur = 0;
+    int kind = 0;  // 1 server, 2 client
+};
+struct TraceTmp {
+    bool ok = false;
+    std::string error, trace_id;
+    std::vector<SpanTmp> spans;
+    std::vector<std::pair<std::string, std::string>> processes;  // pid -> service
+    bool request_type = false;
+    double root_start = 0.0;  // TimeOrder key (executor.py:287-317); +inf when the file has no root span
+    bool has_root = false;
+};
+
+bool number_i64(const JVal* v, int64_t& out) {
+    if (v == nullptr || v->type != JVal::Num) return false;
+    out = v->is_int ? v->i : (int64_t)v->d;
+    return true;
+}
+
+// ParseJsonTrace + ParseSpansJson (executor.py:342-384,755-793): one trace per file
+void parse_trace(const char* buf, size_t len, TraceTmp& T) {
+    JParser P{buf, buf + len, std::string(), 0};
+    JVal root;
+    if (!P.value(root)) { T.error = "JSON: " + P.err; return; }
+    const JVal* data = root.get("data");
+    if (data == nullptr || data->type != JVal::Arr || data->arr.size() != 1) { T.error = "expected exactly one trace under \"data\""; return; }
+    const JVal& d = data->arr[0];
+    const JVal* tid = d.get("traceID");
+    const JVal* spans = d.get("spans");
+    if (tid == nullptr || tid->type != JVal::Str || spans == nullptr || spans->type != JVal::Arr || spans->arr.empty()) { T.error = "trace without traceID / spans"; return; }
+    T.trace_id = tid->s;
+    T.request_type = spans->arr[0].get("requestType") != nullptr;  // executor.py:774
+    for (const JVal& s : spans->arr) {
+        SpanTmp sp;
+        const JVal *sid = s.get("spanID"), *stid = s.get("traceID"), *pid = s.get("processID"), *tags = s.get("tags"), *refs = s.get("references");
+        if (sid == nullptr || sid->type != JVal::Str || pid == nullptr || pid->type != JVal::Str) { T.error = "span without spanID / processID"; return; }
+        if (stid == nullptr || stid->type != JVal::Str || stid->s != T.trace_id) { T.error = "different trace ids for spans in the same trace"; return; }  // executor.py:367-372
+        sp.sid = sid->s;
+        sp.pid = pid->s;
+        if (!number_i64(s.get("startTime"), sp.start) || !number_i64(s.get("duration"), sp.dur)) { T.error = "span without startTime / duration"; return; }
+        const JVal* op = s.get("requestType");
+        if (op == nullptr) op = s.get("operationName");
+        if (op != nullptr && op->type == JVal::Str) sp.op = op->s;
+        if (tags != nullptr && tags->type == JVal::Arr)
+            for (const JVal& t : tags->arr) {
+                const JVal *k = t.get("key"), *v = t.get("value");
+                if (k != nullptr && k->type == JVal::Str && k->s == "span.kind" && v != nullptr && v->type == JVal::Str)
+                    sp.kind = v->s == "server" ? 1 : (v->s == "client" ? 2 : 3);
+            }
+        if (refs != nullptr && refs->type == JVal::Arr)
+            for (const JVal& r : refs->arr) {
+                const JVal *rt = r.get("traceID"), *rs = r.get("spanID");
+                if (rt == nullptr || rs == nullptr || rt->type != JVal::Str || rs->type != JVal::Str) { T.error = "malformed reference"; return; }
+                sp.refs.emplace_back(rt->s, rs->s);
+            }
+        if (sp.refs.empty() && !T.has_root) { T.has_root = true; T.root_start = (double)sp.start; }  // first span without references
+        T.spans.push_back(std::move(sp));
+    }
+    if (T.request_type) {  // ParseProcessesJson2: the process id is the service name
+        for (const SpanTmp& sp : T.spans) T.processes.emplace_back(sp.pid, sp.pid);
+    } else {
+        const JVal* procs = d.get("processes");
+        if (procs == nullptr || procs->type != JVal::Obj) { T.error = "trace without a process map"; return; }
+        for (const auto& kv : procs->obj) {
+            const JVal* name = kv.second.get("serviceName");
+            if (name == nullptr || name->type != JVal::Str) { T.error = "process without serviceName"; return; }
+            T.processes.emplace_back(kv.first, name->s);
+        }
+    }
+    T.ok = true;
+}
+
+bool read_file(const char* path, std::string& out) {
+    FILE* f = fopen(path, "rb");
+    if (f == nullptr) return false;
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    const size_t got = n > 0 ? fread(&out[0], 1, (size_t)n, f) : 0;
+    fclose(f);
+    return got == out.size();
+}
+
+struct SpanRow {
+    int32_t trace, sid, service, op, parent, n_children, first_child_service;
+    int64_t start, dur;
+    uint8_t kind;
+};
+
+}  // namespace
+
+struct tw_corpus {
+    std::string err;
+    std::vector<std::string> strings;
+    std::unordered_map<std::string, int32_t> string_ids;
+    std::vector<SpanRow> rows;                 // spans reached from the root of an accepted trace, pre-order
+    std::vector<int32_t> trace_name;           // string id per accepted trace
+    std::vector<int32_t> service_order;        // services in order of their first outgoing span
+    std::unordered_map<int32_t, std::vector<int32_t>> in_rows, out_rows;  // per service, in walk order
+    int64_t files_total = 0, files_rejected = 0, traces_filtered = 0;
+    // last unit set built
+    std::vector<int64_t> u_in_off, u_ep_off, u_in_start, u_in_end, u_out_start, u_out_end;
+    std::vector<int32_t> u_E, u_key_rank, u_truth, u_in_trace, u_in_row, u_out_row, u_service, u_ep_name, u_in_ep;
+    std::vector<uint8_t> u_dag;
+    int32_t skipped_multi_in = 0, skipped_skip_mode = 0, skipped_small = 0, skipped_cyclic = 0;
+
+    int32_t intern(const std::string& s) {
+        auto it = string_ids.find(s);
+        if (it != string_ids.end()) return it->second;
+        const int32_t id = (int32_t)strings.size();
+        strings.push_back(s);
+        string_ids.emplace(s, id);
+        return id;
+    }
+};
+
+namespace {
+
+// ProcessTraceData (executor.py:795-849) for one parsed trace; returns false (and leaves the corpus untouched)
+// when the trace breaks an assumption the reference asserts on.
+bool add_trace(tw_corpus* c, const TraceTmp& T, const std::string& first_span) {
+    const int n = (int)T.spans.size();
+    std::unordered_map<std::string, int> by_sid;
+    for (int i = 0; i < n; i++) by_sid[T.spans[(size_t)i].sid] = i;  // later duplicates win, like the dict of the reference
+    std::unordered_map<std::string, std::string> proc;
+    for (const auto& kv : T.processes) proc[kv.first] = kv.second;
+    int root = -1;
+    std::vector<std::vector<int>> children((size_t)n);
+    std::vector<int> parent((size_t)n, -1);
+    for (int i = 0; i < n; i++) {
+        const SpanTmp& s = T.spans[(size_t)i];
+        if (by_sid[s.sid] != i) continue;  // shadowed duplicate
+        if (s.refs.empty()) root = i;      // the last span without references (executor.py:823-825)
+        for (const auto& r : s.refs) {
+            auto it = by_sid.find(r.second);
+            if (r.first != T.trace_id || it == by_sid.end()) return false;  // spans[par_id] would raise
+            children[(size_t)it->second].push_back(i);
+        }
+        if (!s.refs.empty()) parent[(size_t)i] = by_sid[s.refs[0].second];
+    }
+    if (root < 0) return false;
+    if (!first_span.empty() && T.spans[(size_t)root].op != first_span) return false;  // executor.py:841
+    for (auto& ch : children)
+        std::stable_sort(ch.begin(), ch.end(), [&](int a, int b) { return T.spans[(size_t)a].start < T.spans[(size_t)b].start; });
+    // pre-order walk; validate before touching the corpus
+    std::vector<int> order, stack{root};
+    std::vector<char> seen((size_t)n, 0);
+    while (!stack.empty()) {
+        const int v = stack.back();
+        stack.pop_back();
+        if (seen[(size_t)v]) return false;  // a span referenced twice / a cycle
+        seen[(size_t)v] = 1;
+        order.push_back(v);
+        const SpanTmp& s = T.spans[(size_t)v];
+        if (s.kind != 1 && s.kind != 2) return false;                 // AddSpanToProcess asserts on other kinds
+        if (proc.find(s.pid) == proc.end()) return false;
+        if (s.kind == 2 && children[(size_t)v].size() != 1) return false;   // GetChildProcess asserts one child
+        if (v != root && s.refs.size() != 1) return false;            // GetParentProcess asserts one reference
+        for (size_t k = children[(size_t)v].size(); k-- > 0;) stack.push_back(children[(size_t)v][k]);
+    }
+    const int32_t trace_no = (int32_t)c->trace_name.size();
+    c->trace_name.push_back(c->intern(T.trace_id));
+    std::vector<int32_t> row_of((size_t)n, -1);
+    const int32_t base = (int32_t)c->rows.size();
+    for (size_t k = 0; k < order.size(); k++) row_of[(size_t)order[k]] = base + (int32_t)k;
+    for (int v : order) {
+        const SpanTmp& s = T.spans[(size_t)v];
+        SpanRow r;
+        r.trace = trace_no;
+        r.sid = c->intern(s.sid);
+        r.service = c->intern(proc[s.pid]);
+        r.op = c->intern(s.op);
+        r.parent = parent[(size_t)v] >= 0 ? row_of[(size_t)parent[(size_t)v]] : -1;
+        r.n_children = (int32_t)children[(size_t)v].size();
+        r.first_child_service = r.n_children > 0 ? c->intern(proc[T.spans[(size_t)children[(size_t)v][0]].pid]) : -1;
+        r.start = s.start;
+        r.dur = s.dur;
+        r.kind = (uint8_t)s.kind;
+        const int32_t row = (int32_t)c->rows.size();
+        c->rows.push_back(r);
+        if (s.kind == 2) {
+            if (c->out_rows.find(r.service) == c->out_rows.end()) c->service_order.push_back(r.service);
+            c->out_rows[r.service].push_back(row);
+        } else c->in_rows[r.service].push_back(row);
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tw_corpus_create(tw_corpus** out) {
+    if (out == nullptr) return TW_ERR_ARG;
+    *out = new tw_corpus();
+    return TW_OK;
+}
+void tw_corpus_destroy(tw_corpus* c) { delete c; }
+const char* tw_corpus_last_error(const tw_corpus* c) { return c ? c->err.c_str() : "null corpus"; }
+
+int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths, const char* first_span, int64_t max_traces,
+                        int32_t n_threads) {
+    if (c == nullptr || (n_paths > 0 && paths == nullptr) || n_paths < 0) return TW_ERR_ARG;
+    std::vector<TraceTmp> parsed((size_t)n_paths);
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        std::string buf;
+        for (int i = next.fetch_add(1); i < n_paths; i = next.fetch_add(1)) {
+            if (!read_file(paths[i], buf)) { parsed[(size_t)i].error = "cannot read file"; continue; }
+            parse_trace(buf.data(), buf.size(), parsed[(size_t)i]);
+        }
+    };
+    // <= 0: up to 16 parser threads, one per ~64 files (measured on the 256-thread host: 1 thread 0.4 M spans/s, 8 threads 1.0 M, 256 threads 0.13 M)
+    const int want = n_threads <= 0 ? std::min(std::min((int)std::thread::hardware_concurrency(), 16), n_paths / 64 + 1) : n_threads;
+    const int nt = std::max(1, std::min(want, std::max(n_paths, 1)));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    // TimeOrder (executor.py:314-318): by the start of the root span, files without one last; ties keep the given order
+    std::vector<int> idx((size_t)n_paths);
+    for (int i = 0; i < n_paths; i++) idx[(size_t)i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+        const TraceTmp &A = parsed[(size_t)a], &B = parsed[(size_t)b];
+        const bool ra = A.ok && A.has_root, rb = B.ok && B.has_root;
+        if (ra != rb) return ra;
+        return ra && A.root_start < B.root_start;
+    });
+    const std::string fs = first_span ? first_span : "";
+    int64_t accepted = (int64_t)c->trace_name.size();
+    for (int i = 0; i < n_paths; i++) {  // parse failures are reported whether or not the trace limit is reached first
+        c->files_total++;
+        if (parsed[(size_t)i].ok) continue;
+        c->files_rejected++;
+        if (c->err.empty()) c->err = std::string(paths[i]) + ": " + parsed[(size_t)i].error;
+    }
+    for (int i : idx) {
+        const TraceTmp& T = parsed[(size_t)i];
+        if (!T.ok) continue;
+        if (add_trace(c, T, fs)) accepted++; else c->traces_filtered++;
+        if (max_traces > 0 && accepted >= max_traces) break;  // executor.py:873 stops after 1001 accepted traces
+    }
+    return TW_OK;
+}
+
+int tw_corpus_counts(const tw_corpus* c, int64_t* out6) {
+    if (c == nullptr || out6 == nullptr) return TW_ERR_ARG;
+    out6[0] = (int64_t)c->rows.size(); out6[1] = (int64_t)c->trace_name.size(); out6[2] = c->files_total;
+    out6[3] = c->files_rejected; out6[4] = c->traces_filtered; out6[5] = (int64_t)c->strings.size();
+    return TW_OK;
+}
+
+const char* tw_corpus_string(const tw_corpus* c, int32_t id) {
+    if (c == nullptr || id < 0 || (size_t)id >= c->strings.size()) return nullptr;
+    return c->strings[(size_t)id].c_str();
+}
+
+int tw_corpus_span_table(const tw_corpus* c, tw_span_table* t) {
+    if (c == nullptr || t == nullptr) return TW_ERR_ARG;
+    const int64_t n = (int64_t)c->rows.size();
+    for (int64_t i = 0; i < n; i++) {
+        const SpanRow& r = c->rows[(size_t)i];
+        if (t->trace) t->trace[i] = r.trace;
+        if (t->span_id) t->span_id[i] = r.sid;
+        if (t->service) t->service[i] = r.service;
+        if (t->op_name) t->op_name[i] = r.op;
+        if (t->parent) t->parent[i] = r.parent;
+        if (t->start) t->start[i] = r.start;
+        if (t->duration) t->duration[i] = r.dur;
+        if (t->kind) t->kind[i] = r.kind;
+    }
+    return TW_OK;
+}
+
+int tw_corpus_build_units(tw_corpus* c, tw_unit_set* out) {
+    if (c == nullptr || out == nullptr) return TW_ERR_ARG;
+    c->u_in_off.assign(1, 0); c->u_ep_off.assign(1, 0);
+    c->u_in_start.clear(); c->u_in_end.clear(); c->u_out_start.clear(); c->u_out_end.clear();
+    c->u_E.clear(); c->u_key_rank.clear(); c->u_truth.clear(); c->u_in_trace.clear(); c->u_in_row.clear(); c->u_out_row.clear();
+    c->u_service.clear(); c->u_ep_name.clear(); c->u_in_ep.clear(); c->u_dag.clear();
+    c->skipped_multi_in = c->skipped_skip_mode = c->skipped_small = c->skipped_cyclic = 0;
+    const auto by_time = [&](int32_t a, int32_t b) {
+        const SpanRow &A = c->rows[(size_t)a], &B = c->rows[(size_t)b];
+        return A.start != B.start ? A.start < B.start : A.start + A.dur < B.start + B.dur;
+    };
+    for (int32_t svc : c->service_order) {
+        auto in_it = c->in_rows.find(svc);
+        if (in_it == c->in_rows.end()) continue;
+        // PartitionSpansByEndPoint: keys in order of first appearance, each partition sorted by (start, end), stable
+        std::vector<int32_t> in_keys, out_keys;
+        std::unordered_map<int32_t, std::vector<int32_t>> in_part, out_part;
+        for (int32_t row : in_it->second) {
+            const SpanRow& r = c->rows[(size_t)row];
+            const int32_t key = r.parent < 0 ? c->intern("client_" + c->strings[(size_t)r.op]) : c->rows[(size_t)r.parent].service;
+            if (in_part.find(key) == in_part.end()) in_keys.push_back(key);
+            in_part[key].push_back(row);
+        }
+        for (int32_t row : c->out_rows[svc]) {
+            const int32_t key = c->rows[(size_t)row].first_child_service;
+            if (out_part.find(key) == out_part.end()) out_keys.push_back(key);
+            out_part[key].push_back(row);
+        }
+        if (in_keys.size() != 1) { c->skipped_multi_in++; continue; }  // executor.py:1126-1128
+        std::vector<int32_t>& ins = in_part[in_keys[0]];
+        std::stable_sort(ins.begin(), ins.end(), by_time);
+        const int64_t n = (int64_t)ins.size();
+        const int E = (int)out_keys.size();
+        bool equal = true;
+        for (int32_t k : out_keys) {
+            std::stable_sort(out_part[k].begin(), out_part[k].end(), by_time);
+            equal = equal && (int64_t)out_part[k].size() == n;
+        }
+        if (!equal || E > TW_MAX_EP) { c->skipped_skip_mode++; continue; }   // skip mode / too many endpoints: not accelerated
+        if (n < 2) { c->skipped_small++; continue; }
+        // GetGroundTruth: first outgoing span of the same trace per endpoint (key order)
+        std::vector<std::vector<int32_t>> truth((size_t)E, std::vector<int32_t>((size_t)n, -1));
+        for (int a = 0; a < E; a++) {
+            std::unordered_map<int32_t, int32_t> first;
+            const std::vector<int32_t>& part = out_part[out_keys[(size_t)a]];
+            for (int32_t j = 0; j < (int32_t)part.size(); j++) first.emplace(c->rows[(size_t)part[(size_t)j]].trace, j);
+            for (int64_t i = 0; i < n; i++) {
+                auto it = first.find(c->rows[(size_t)ins[(size_t)i]].trace);
+                if (it != first.end()) truth[(size_t)a][(size_t)i] = it->second;
+            }
+        }
+        // FindOrder: a -> b iff a ended no later than b started in every request
+        std::vector<uint8_t> rel((size_t)(E * E), 1);
+        for (int a = 0; a < E; a++) rel[(size_t)(a * E + a)] = 0;
+        for (int64_t i = 0; i < n; i++)
+            for (int a = 0; a < E; a++) {
+                const int32_t xa = truth[(size_t)a][(size_t)i];
+                if (xa < 0) continue;
+                const SpanRow& A = c->rows[(size_t)out_part[out_keys[(size_t)a]][(size_t)xa]];
+                for (int b = 0; b < E; b++) {
+                    const int32_t xb = truth[(size_t)b][(size_t)i];
+                    if (a == b || xb < 0) continue;
+                    if (A.start + A.dur > c->rows[(size_t)out_part[out_keys[(size_t)b]][(size_t)xb]].start) rel[(size_t)(a * E + b)] = 0;
+                }
+            }
+        // nx.topological_sort: generations of zero in-degree nodes, ties in insertion (= key) order
+        std::vector<int> indeg((size_t)E, 0), topo;
+        for (int a = 0; a < E; a++) for (int b = 0; b < E; b++) indeg[(size_t)b] += rel[(size_t)(a * E + b)];
+        std::vector<int> ready;
+        for (int a = 0; a < E; a++) if (indeg[(size_t)a] == 0) ready.push_back(a);
+        for (size_t h = 0; h < ready.size(); h++) {
+            const int a = ready[h];
+            topo.push_back(a);
+            for (int b = 0; b < E; b++) if (rel[(size_t)(a * E + b)] && --indeg[(size_t)b] == 0) ready.push_back(b);
+        }
+        if ((int)topo.size() != E) { c->skipped_cyclic++; continue; }
+        // emit
+        c->u_service.push_back(svc);
+        c->u_in_ep.push_back(in_keys[0]);
+        c->u_E.push_back(E);
+        for (int64_t i = 0; i < n; i++) {
+            const SpanRow& r = c->rows[(size_t)ins[(size_t)i]];
+            c->u_in_start.push_back(r.start); c->u_in_end.push_back(r.start + r.dur);
+            c->u_in_trace.push_back(r.trace); c->u_in_row.push_back(ins[(size_t)i]);
+        }
+        c->u_in_off.push_back(c->u_in_off.back() + n);
+        for (int k = 0; k < E; k++) {
+            const int a = topo[(size_t)k];
+            const std::vector<int32_t>& part = out_part[out_keys[(size_t)a]];
+            for (int32_t row : part) {
+                const SpanRow& r = c->rows[(size_t)row];
+                c->u_out_start.push_back(r.start); c->u_out_end.push_back(r.start + r.dur); c->u_out_row.push_back(row);
+            }
+            c->u_ep_off.push_back(c->u_ep_off.back() + (int64_t)part.size());
+            c->u_ep_name.push_back(out_keys[(size_t)a]);
+            c->u_key_rank.push_back(a);
+            for (int64_t i = 0; i < n; i++) c->u_truth.push_back(truth[(size_t)a][(size_t)i]);
+        }
+        for (int k = 0; k < E; k++) for (int l = 0; l < E; l++) c->u_dag.push_back(rel[(size_t)(topo[(size_t)k] * E + topo[(size_t)l])]);
+    }
+    out->n_units = (int32_t)c->u_E.size();
+    out->unit_in_off = c->u_in_off.data(); out->unit_E = c->u_E.data(); out->ep_off = c->u_ep_off.data();
+    out->dag = c->u_dag.data(); out->key_rank = c->u_key_rank.data();
+    out->in_start = c->u_in_start.data(); out->in_end = c->u_in_end.data(); out->out_start = c->u_out_start.data(); out->out_end = c->u_out_end.data();
+    out->true_child = c->u_truth.data(); out->in_trace = c->u_in_trace.data(); out->in_row = c->u_in_row.data(); out->out_row = c->u_out_row.data();
+    out->unit_service = c->u_service.data(); out->ep_name = c->u_ep_name.data(); out->in_ep_name = c->u_in_ep.data();
+    out->n_traces = (int64_t)c->trace_name.size();
+    out->skipped[0] = c->skipped_multi_in; out->skipped[1] = c->skipped_skip_mode; out->skipped[2] = c->skipped_small; out->skipped[3] = c->skipped_cyclic;
+    return TW_OK;
+}
+
+}  // extern "C"

@@ -143,3 +143,84 @@ def make_workload(seed, n_in_per_unit, services=MEDIA_SERVICES, replicas=1, **kw
 def accuracy(parent, true_parent):
     """utils.py:62-79 AccuracyForService on index arrays: a request counts when every endpoint matches."""
     return float(np.all(parent == true_parent, axis=0).mean())
+
+
+# ---------------------------------------------------------------------------------------------
+# Jaeger-JSON corpora (one trace per file, the shape of the reference's data/*/ directories): a small
+# application as a call tree -- every service handles a request with a server span and calls its callees
+# through client spans, stage after stage.
+HOTEL_APP = {"root_op": "HTTP GET /hotels", "root": "frontend",
+             "calls": {"frontend": [("search",), ("reservation",), ("profile",)], "search": [("geo",), ("rate",)]}}
+FANOUT_APP = {"root_op": "compose", "root": "gateway",
+              "calls": {"gateway": [("auth",), ("text", "media", "user")], "text": [("url", "mention")]}}
+
+
+def write_jaeger_corpus(directory, seed, n_traces, app=HOTEL_APP, concurrency=1.5, mean_service_us=800.0, gap_us=60.0,
+                        sigma=0.5, t0_us=1_655_760_000_000_000):
+    """Writes n_traces files <trace id>.json under `directory` and returns the list of paths.  Children lie inside
+    their parent, stages follow one another, requests arrive as a Poisson process whose rate gives about
+    `concurrency` requests in flight at the root."""
+    import json
+    import os
+
+    rng = np.random.default_rng(seed)
+    os.makedirs(directory, exist_ok=True)
+
+    def ln(mean):
+        mu = np.log(mean) - 0.5 * sigma * sigma
+        return max(1, int(rng.lognormal(mu, sigma)))
+
+    services = [app["root"]]
+    for callees in app["calls"].values():
+        for st in callees:
+            for s in st:
+                if s not in services:
+                    services.append(s)
+    pids = {s: "p%d" % (k + 1) for k, s in enumerate(services)}
+    arrivals, t, paths = [], t0_us, []
+    # a first pass fixes the mean response time so that the arrival rate matches the requested concurrency
+    probe = []
+
+    def build(service, start, tid, spans, parent_sid, op):
+        """server span of `service` starting at `start`; returns its end time"""
+        sid = "%016x" % rng.integers(1, 2 ** 62)
+        cur = start + ln(gap_us)
+        for stage in app["calls"].get(service, []):
+            stage_end = cur
+            for callee in stage:
+                c_start = cur + ln(gap_us) // 4
+                c_sid = "%016x" % rng.integers(1, 2 ** 62)
+                s_start = c_start + ln(gap_us) // 2
+                s_end = build(callee, s_start, tid, spans, c_sid, "/%s/Handle" % callee)
+                c_end = s_end + ln(gap_us) // 2
+                spans.append({"traceID": tid, "spanID": c_sid, "operationName": "/%s/Handle" % callee,
+                              "references": [{"refType": "CHILD_OF", "traceID": tid, "spanID": sid}], "startTime": int(c_start),
+                              "duration": int(c_end - c_start), "tags": [{"key": "span.kind", "type": "string", "value": "client"}],
+                              "logs": [], "processID": pids[service], "warnings": None})
+                stage_end = max(stage_end, c_end)
+            cur = stage_end + ln(gap_us)
+        end = cur + ln(mean_service_us)
+        refs = [] if parent_sid is None else [{"refType": "CHILD_OF", "traceID": tid, "spanID": parent_sid}]
+        spans.append({"traceID": tid, "spanID": sid, "operationName": op, "references": refs, "startTime": int(start),
+                      "duration": int(end - start), "tags": [{"key": "span.kind", "type": "string", "value": "server"}],
+                      "logs": [], "processID": pids[service], "warnings": None})
+        return end
+
+    for _ in range(16):
+        sp = []
+        probe.append(build(app["root"], 0, "probe", sp, None, app["root_op"]))
+    mean_resp = float(np.mean(probe))
+    for k in range(n_traces):
+        t += int(rng.exponential(mean_resp / max(concurrency, 1e-9))) + 1
+        tid = "%016x" % (0x1000 + k)
+        spans = []
+        build(app["root"], t, tid, spans, None, app["root_op"])
+        order = rng.permutation(len(spans))  # Jaeger does not store spans in any particular order
+        doc = {"data": [{"traceID": tid, "spans": [spans[j] for j in order],
+                         "processes": {pids[s]: {"serviceName": s, "tags": []} for s in services}, "warnings": None}],
+               "total": 0, "limit": 0, "offset": 0, "errors": None}
+        path = os.path.join(directory, tid + ".json")
+        with open(path, "w") as f:
+            json.dump(doc, f)
+        paths.append(path)
+    return paths
