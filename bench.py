@@ -154,9 +154,10 @@ def main():
         alg_bytes = 20.0 * spans_rank  # per launch: 16 B read + 4 B written per span
         achieved = alg_bytes / (groups[dominant] * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/collect.sh)
-            tj = json.load(open(tpath))
+        import glob
+        tpaths = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))
+        if tpaths:  # HBM bytes per launch from the newest committed rocprofv3 PMC passes (profiles/collect.sh)
+            tj = json.load(open(tpaths[-1]))
             g = tj["groups"].get(dominant)
             if g and tj.get("spans_per_launch") == spans_rank:
                 traffic = g["fetch_bytes_x2"] + g["write_bytes"]

@@ -28,8 +28,12 @@ def group_of(name):
         return "k_select"
     if "k_fit" in name:
         return "k_fit"
-    if "rocprim" in name or "k_block_params" in name:
+    if "rocprim" in name or "k_rows_" in name or "k_key_bits" in name:
+        return "sort"
+    if "k_block_params" in name:
         return "params"
+    if "k_evaluate" in name or "k_count_flags" in name:
+        return "evaluate"
     if any(k in name for k in ("k_scan", "k_perfect_cut", "k_window")):
         return "windows"
     if any(k in name for k in ("k_claim", "k_detect", "k_repair")):
@@ -66,7 +70,7 @@ def main():
     spans = bench["config"]["spans_per_gpu"]
     traffic = {"tag": tag, "workload": bench["config"]["workload"], "spans_per_launch": spans, "launch_sets": passes, "groups": {}}
     for g in sorted(dur, key=lambda k: -dur[k]):
-        n = passes if g in ("k_enumerate", "k_select", "repair") else passes // 2
+        n = passes if g in ("k_enumerate", "k_select", "repair") else passes // 2   # per pass / per step
         traffic["groups"][g] = {
             "avg_ms_per_launch_set": dur[g] / n / 1e6,
             "fetch_bytes_raw": fetch.get(g, 0.0) / n, "fetch_bytes_x2": 2 * fetch.get(g, 0.0) / n,

@@ -773,7 +773,13 @@ int tw_evaluate(tw_engine* e, int64_t* per_unit, uint8_t* trace_flags, int64_t* 
     HIPCHK(hipMemcpyAsync(h.data(), e->eval_counts, sizeof(unsigned long long) * nc, hipMemcpyDeviceToHost, e->stream));
     if (trace_flags != nullptr) HIPCHK(hipMemcpyAsync(trace_flags, e->trace_bad, (size_t)(2 * e->n_traces), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    for (int64_t q = 0; q < (int64_t)P.n_units * 4; q++) per_unit[q] = (int64_t)h[(size_t)q];
+    for (int u = 0; u < P.n_units; u++) {
+        const int64_t n = e->units[(size_t)u].n_in;
+        per_unit[u * 4 + 0] = n;
+        per_unit[u * 4 + 1] = n - (int64_t)h[(size_t)u * 4 + 1];
+        per_unit[u * 4 + 2] = n - (int64_t)h[(size_t)u * 4 + 2];
+        per_unit[u * 4 + 3] = (int64_t)h[(size_t)u * 4 + 3];
+    }
     if (e2e != nullptr) { e2e[0] = (int64_t)h[(size_t)nc - 2]; e2e[1] = (int64_t)h[(size_t)nc - 1]; }
     return TW_OK;
 }

@@ -55,7 +55,7 @@ __global__ void k_find_order(OrderDev O) {
 //   top-k  some tuple of the span's top-5 list equals the true tuple            utils.py:81-97
 // and, when a trace index per incoming span is given, the per-trace flags of AccuracyEndToEnd /
 // TopKAccuracyEndToEnd (utils.py:99-145): a trace is correct iff no span of it is wrong in any unit.
-// counts[unit] = {n_in, exact, top-k, unassigned}.
+// counts[unit] = {-, requests that are wrong, requests whose list misses the true tuple, requests left unassigned}.
 __global__ void __launch_bounds__(kTile) k_evaluate(Dev P, const int32_t* truth, const int32_t* in_trace, unsigned long long* counts,
                                                    uint8_t* trace_bad, uint8_t* trace_bad_topk) {
     const TileDev Tl = P.tiles[blockIdx.x];
@@ -84,13 +84,13 @@ __global__ void __launch_bounds__(kTile) k_evaluate(Dev P, const int32_t* truth,
             }
         }
     }
-    const unsigned long long me = __ballot(exact), mt = __ballot(topk), mu = __ballot(unassigned), ml = __ballot(live);
+    // what is counted is the rare outcome (wrong / not in the list / unassigned): most wavefronts add nothing
+    const unsigned long long me = __ballot(live && !exact), mt = __ballot(live && !topk), mu = __ballot(unassigned);
     if ((threadIdx.x & 63) == 0) {
         unsigned long long* c = counts + (int64_t)Tl.unit * 4;
-        atomicAdd(&c[0], (unsigned long long)__popcll(ml));
-        atomicAdd(&c[1], (unsigned long long)__popcll(me));
-        atomicAdd(&c[2], (unsigned long long)__popcll(mt));
-        atomicAdd(&c[3], (unsigned long long)__popcll(mu));
+        if (me) atomicAdd(&c[1], (unsigned long long)__popcll(me));
+        if (mt) atomicAdd(&c[2], (unsigned long long)__popcll(mt));
+        if (mu) atomicAdd(&c[3], (unsigned long long)__popcll(mu));
     }
 }
 
