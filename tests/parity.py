@@ -87,3 +87,19 @@ def stress_units(cases):
         units.append(u)
         truth.append(tp)
     return units, truth
+
+
+def assert_assignment_properties(u, par):
+    """Size-independent properties of a parent array [E, n]: all endpoints or none per request, every outgoing
+    span used at most once, children inside the parent, call order respected."""
+    assigned = par[0] >= 0
+    assert ((par >= 0) == assigned).all()
+    for e in range(u.E):
+        x = par[e][assigned]
+        assert len(np.unique(x)) == len(x)
+        s = u.out_start[u.out_off[e] + x]
+        en = u.out_end[u.out_off[e] + x]
+        assert (s >= u.in_start[assigned]).all() and (en <= u.in_end[assigned]).all()
+        for p in range(e):
+            if u.dag[p, e]:
+                assert (u.out_end[u.out_off[p] + par[p][assigned]] <= s).all()

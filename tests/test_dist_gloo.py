@@ -72,6 +72,69 @@ def test_two_rank_partition_and_gather():
         assert full == want                                                    # every rank holds the full, identical result
 
 
+def _e2e_worker(rank, world, port, q, lib_path, corpus_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      TW_TILE="1", TW_COOP_THREADS="1")   # the host-emulation build runs one thread per workgroup
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    import torch.distributed as dist
+
+    from traceweaver_amd import sharding
+    from traceweaver_amd.engine import Engine
+    from traceweaver_amd.ingest import Corpus
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = Corpus(lib_path=lib_path)
+    c.add_directory(corpus_dir, first_span="compose", max_traces=0)
+    units, _, n_traces = c.units()
+    parts = sharding.shard_units([sharding.unit_cost(u.arrays) for u in units], world)
+    mine = [units[k] for k in parts[rank]]
+    eng = Engine(0, lib_path=lib_path)
+    eng.load([u.arrays for u in mine])
+    eng.set_truth([u.true_parent for u in mine], [u.in_trace for u in mine], n_traces)
+    eng.run_pass1()
+    per, local, flags = eng.evaluate(trace_flags=True)
+    total = sharding.end_to_end_accuracy(flags, dist=dist)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, parts, local, total, [p["correct"] for p in per]))
+
+
+def test_two_rank_end_to_end_accuracy(emu_lib, tmp_path):
+    """Services of one trace solved on different ranks: per-trace accuracy needs the MAX all-reduce of the
+    wrong-flags (the one collective of the evaluation path)."""
+    from traceweaver_amd import sharding, synth
+    from traceweaver_amd.engine import Engine
+    from traceweaver_amd.ingest import Corpus
+
+    synth.write_jaeger_corpus(str(tmp_path), 4, 400, app=synth.FANOUT_APP, concurrency=3.0)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_e2e_worker, args=(r, world, port, q, emu_lib, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single process, all units on one engine
+    c = Corpus(lib_path=emu_lib)
+    c.add_directory(str(tmp_path), first_span="compose", max_traces=0)
+    units, _, n_traces = c.units()
+    eng = Engine(0, lib_path=emu_lib)
+    eng.load([u.arrays for u in units])
+    eng.set_truth([u.true_parent for u in units], [u.in_trace for u in units], n_traces)
+    eng.run_pass1()
+    per, (right, right_topk) = eng.evaluate()
+    assert len(units) == 2 and got[0][1] == got[1][1] and sorted(k for p in got[0][1] for k in p) == [0, 1]
+    for rank, parts, local, total, correct in got:
+        assert total == (right, right_topk, n_traces)                 # every rank: the global per-trace figures
+        assert correct == [per[k]["correct"] for k in parts[rank]]
+        assert local[0] >= right                                      # a rank alone sees fewer wrong traces
+    assert right < n_traces                                           # the workload does produce wrong traces
+
+
 def test_shard_units_is_deterministic_and_complete():
     from traceweaver_amd import sharding
 

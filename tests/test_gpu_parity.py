@@ -85,6 +85,40 @@ def test_media_shape_at_scale():
         assert r["window_end"][-1] == 1 and r["n_windows"] == int(r["window_end"].sum())
 
 
+def test_nodejs_fileio_shape_at_scale():
+    """BASELINE config 3 shape (4 services, E in {1,2,1,1}, millisecond-granular, heavily interleaved): full
+    comparison with the oracle at 20k requests per service -- exact score ties everywhere."""
+    units, truth = synth.make_nodejs_workload(13, 20000, concurrency=4.0)
+    r1, r2, _ = parity.check_units(None, units)
+    for u, r in zip(units, r2):
+        parity.assert_assignment_properties(u, r["parent"])
+
+
+def test_alibaba_shape_1m_span_slice():
+    """BASELINE config 4 size: a 1 M-span slice of Alibaba-shape call graphs (15 graphs, 39 services, E up to 8,
+    millisecond timestamps, zero network gap) in one batch.  Every third unit is compared with the oracle in
+    full; all units must satisfy the size-independent properties, and the device-side accuracy must agree with
+    the host's."""
+    from traceweaver_amd.engine import Engine
+
+    units, truth, _ = synth.make_alibaba_workload(3, 1_000_000)
+    assert 990_000 <= sum(u.n_spans for u in units) <= 1_010_000
+    parity.check_units(None, units[::3])
+    eng = Engine(0)
+    eng.load(units)
+    eng.set_truth(truth)
+    eng.run_pass1()
+    eng.fit_mixtures()
+    eng.run_pass2()
+    res = eng.results(2, fields=("parent", "unit_stats"))
+    per = eng.evaluate()
+    eng.close()
+    for u, tp, r, ev in zip(units, truth, res, per):
+        parity.assert_assignment_properties(u, r["parent"])
+        assert ev["correct"] == int(np.all(r["parent"] == tp, axis=0).sum())
+    assert np.mean([ev["accuracy"] for ev in per]) > 0.9
+
+
 def test_results_are_deterministic_and_order_independent():
     units, _ = synth.make_workload(11, 5000, services=synth.HOTEL_SERVICES + ["par2"], concurrency=3)
     from traceweaver_amd.engine import Engine

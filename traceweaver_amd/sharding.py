@@ -66,3 +66,19 @@ def gather_parents(local_parents, local_ids, n_units, dist=None, device="cpu"):
             out[int(k)] = br[pos:pos + int(E) * int(n)].reshape(int(E), int(n)).copy()
             pos += int(E) * int(n)
     return out
+
+
+def end_to_end_accuracy(trace_flags, dist=None, device="cpu"):
+    """AccuracyEndToEnd / TopKAccuracyEndToEnd (helpers/utils.py:99-145) when the services of a trace were solved
+    on different ranks: a trace is right iff no rank saw a wrong span of it.  `trace_flags` = the [2, n_traces]
+    uint8 wrong-flags of this rank's tw_evaluate (exact / top-5 criterion); one MAX all-reduce (RCCL over xGMI with
+    backend "nccl"; n_traces bytes, latency-bound) combines them.  Returns (traces right, traces right under top-5,
+    n_traces) on every rank."""
+    flags = np.ascontiguousarray(trace_flags, dtype=np.uint8)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        import torch
+
+        t = torch.from_numpy(flags.copy()).to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        flags = t.cpu().numpy()
+    return int((flags[0] == 0).sum()), int((flags[1] == 0).sum()), int(flags.shape[1])

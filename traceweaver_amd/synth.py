@@ -224,3 +224,43 @@ def write_jaeger_corpus(directory, seed, n_traces, app=HOTEL_APP, concurrency=1.
             json.dump(doc, f)
         paths.append(path)
     return paths
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs 3-5 as unit sets.
+# nodejs_microservices_with_arbitrary_file_io: 4 services, E in {1, 2, 1, 1}, millisecond-granular
+# timestamps, heavily interleaved requests.
+NODEJS_SERVICES = ["single", "par2", "single", "single"]
+
+# Alibaba-shape call graphs (15 graphs, depth 2-5, fan-out 1-6, chains and parallel
+# stages mixed, millisecond timestamps, no network gap): the per-service shapes that occur in them.
+ALIBABA_GRAPHS = [
+    ["single", "chain2"], ["par2", "single", "single"], ["chain3", "single"], ["fan6", "single", "chain2"],
+    ["diamond", "par2"], ["mix7", "single"], ["chain5", "single", "single"], ["par4", "chain2", "single"],
+    ["mix8", "par2"], ["chain2", "chain2", "single"], ["par2", "par2", "single"], ["diamond", "chain3"],
+    ["fan6", "par4"], ["chain3", "par2", "single"], ["single", "single", "par4", "chain2"],
+]
+
+
+def make_nodejs_workload(seed, n_in_per_unit, concurrency=4.0, replicas=1):
+    return make_workload(seed, n_in_per_unit, services=NODEJS_SERVICES, replicas=replicas, concurrency=concurrency,
+                         granularity_us=1000, mean_service_us=6000.0, gap_us=1500.0)
+
+
+def make_alibaba_workload(seed, total_spans, graphs=None, concurrency=1.3):
+    """About `total_spans` engine spans (incoming + outgoing) spread evenly over the services of the call graphs;
+    millisecond-granular, zero-gap timestamps as real-parser.py:323-353 emits them.  Returns (units, truth, graph id
+    of every unit)."""
+    graphs = list(range(len(ALIBABA_GRAPHS))) if graphs is None else list(graphs)
+    shapes = [(g, s) for g in graphs for s in ALIBABA_GRAPHS[g]]
+    per_request = sum(1 + len({e for st in SHAPES[s] for e in st}) for _, s in shapes)
+    n_in = max(2, int(total_spans // per_request))
+    n_in += 1 if n_in % 100 == 1 else 0   # a last parameter block of one request has no variance (hazard H3)
+    units, truth, gid = [], [], []
+    for k, (g, s) in enumerate(shapes):
+        u, tp = make_unit(seed * 7919 + k, n_in, shape=s, concurrency=concurrency, granularity_us=1000,
+                          mean_service_us=8000.0, gap_us=1.0)
+        units.append(u)
+        truth.append(tp)
+        gid.append(g)
+    return units, truth, gid
