@@ -102,8 +102,8 @@ struct Dev {
     int32_t* heavy_count;   // windows whose best candidates clash: work list of k_select_heavy
     int32_t* heavy_next;    // next unclaimed entry of that list
     int32_t *heavy_unit, *heavy_win;
-    int32_t* heavy_in_count;  // [kMaxEp+1] incoming spans deferred to k_enumerate_heavy, per endpoint count E
-    int32_t* heavy_in_next;   // [kMaxEp+1] next unclaimed entry of the class' work list
+    int32_t* heavy_in_count;  // [2][kMaxEp+1] incoming spans deferred to k_enumerate_heavy per endpoint count E: narrow, wide windows
+    int32_t* heavy_in_next;   // [2][kMaxEp+1] next unclaimed entry of each list
     int32_t heavy_in_off[kMaxEp + 2];  // class offsets into heavy_in_unit / heavy_in_idx
     int32_t *heavy_in_unit, *heavy_in_idx;
     int32_t* err;           // first error raised by a kernel (tw_status)

@@ -137,7 +137,8 @@ void launch_enumerate(tw_engine* e, int pass) {
                        (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
     const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
     const int grid = std::min(cap, 4096);  // persistent wavefronts pulling spans from the class' work list
-    hipLaunchKernelGGL((k_enumerate_heavy<E>), dim3(grid), dim3(std::min(e->coop, kHeavyThreads)), 0, e->stream, P, pass);
+    hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), dim3(std::min(e->coop, kHeavyThreads)), 0, e->stream, P, pass);
+    hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), dim3(std::min(e->coop, kHeavyThreads)), 0, e->stream, P, pass);
 }
 
 // OR of (key ^ first key) and of the keys themselves over a set of index ranges (see k_key_bits)
@@ -236,8 +237,8 @@ int run_pass(tw_engine* e, int pass) {
     }
     HIPCHK(hipEventRecord(e->ev[EV_PARAMS], e->stream));
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
-    HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
-    HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
+    HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
+    HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
     launch_enumerate<1>(e, pass); launch_enumerate<2>(e, pass); launch_enumerate<3>(e, pass); launch_enumerate<4>(e, pass);
     launch_enumerate<5>(e, pass); launch_enumerate<6>(e, pass); launch_enumerate<7>(e, pass); launch_enumerate<8>(e, pass);
     HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
@@ -462,7 +463,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.gaps, gaps);
     ALLOC(P.unit_stats, (int64_t)P.n_units * 8); ALLOC(P.err, 1);
     ALLOC(e->tile_ids, (int64_t)tile_ids_h.size());
-    ALLOC(P.heavy_in_count, kMaxEp + 1); ALLOC(P.heavy_in_next, kMaxEp + 1); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
+    ALLOC(P.heavy_in_count, 2 * (kMaxEp + 1)); ALLOC(P.heavy_in_next, 2 * (kMaxEp + 1)); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
     ALLOC(P.prof, 16); ALLOC(e->key_acc, 2);
     HIPCHK(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 16, e->stream));
@@ -789,8 +790,10 @@ int tw_evaluate(tw_engine* e, int64_t* per_unit, uint8_t* trace_flags, int64_t* 
 int tw_debug_worklists(tw_engine* e, int32_t* out) {
     if (e == nullptr || out == nullptr || e->state < ST_PASS1) return TW_ERR_ARG;
     HIPCHK(hipMemcpyAsync(out, e->P.heavy_count, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(out + 1, e->P.heavy_in_count, sizeof(int32_t) * (kMaxEp + 1), hipMemcpyDeviceToHost, e->stream));
+    int32_t both[2 * (kMaxEp + 1)];
+    HIPCHK(hipMemcpyAsync(both, e->P.heavy_in_count, sizeof(both), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    for (int k = 0; k <= kMaxEp; k++) out[1 + k] = both[k] + both[kMaxEp + 1 + k];
     return TW_OK;
 }
 

@@ -513,6 +513,21 @@ __device__ void write_result(const Dev& P, const UnitDev& U, int i, int pass, co
     }
 }
 
+// Work list of k_enumerate_heavy<E, W>: the class' slice [heavy_in_off[E], heavy_in_off[E+1]) of heavy_in_unit /
+// heavy_in_idx is filled from the front with the spans whose candidate windows are all <= kNarrow wide (served by
+// the small-LDS instantiation, more wavefronts per CU) and from the back with the others.
+constexpr int kNarrow = 32;
+template <int E>
+__device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narrow, int unit, int i) {
+    const int sn = wave_append(&P.heavy_in_count[E], pred && narrow);
+    const int sw = wave_append(&P.heavy_in_count[kMaxEp + 1 + E], pred && !narrow);
+    if (!pred) return false;
+    const int pos = narrow ? P.heavy_in_off[E] + sn : P.heavy_in_off[E + 1] - 1 - sw;
+    P.heavy_in_unit[pos] = unit;
+    P.heavy_in_idx[pos] = i;
+    return true;
+}
+
 // Per-thread enumeration state with compile-time indexing only (the depth-first walk is unrolled by
 // template recursion over the endpoints), so that it lives in registers: no scratch traffic.
 template <int E>
@@ -706,25 +721,19 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
 #pragma unroll
         for (int e = 0; e < E; e++) { c.lo[e] = P.c_lo[ie_index(U, e, i)]; c.hi[e] = P.c_hi[ie_index(U, e, i)]; }
     }
-    bool wide = false, empty = false;
+    bool wide = false, empty = false, narrow = true;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int w = c.hi[e] - c.lo[e] + 1;
         wide |= (w > 64 * kCandWords);
+        narrow &= (w <= kNarrow);
         empty |= (w <= 0);
     }
     if (wide) { raise_err(P, TW_ERR_WINDOW_WIDTH); return; }
     int64_t prod = empty ? 0 : 1;
 #pragma unroll
     for (int e = 0; e < E; e++) if (prod > 0 && prod <= kLightMax) prod *= (c.hi[e] - c.lo[e] + 1);
-    {
-        const int slot = wave_append(&P.heavy_in_count[E], prod > kLightMax);
-        if (slot >= 0) {
-            P.heavy_in_unit[P.heavy_in_off[E] + slot] = T.unit;
-            P.heavy_in_idx[P.heavy_in_off[E] + slot] = i;
-            return;
-        }
-    }
+    if (heavy_append<E>(P, prod > kLightMax, narrow, T.unit, i)) return;
     c.nk = 0; c.leaves = 0; c.ambiguous = false;
 #pragma unroll
     for (int k = 0; k < kTopK; k++) c.ts[k] = -dinf();
@@ -765,17 +774,10 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
                 }
                 if (same) c.ambiguous = true;
             }
-    {
-        // rare (millisecond-granular data): CPython's heapq / list.sort must be replayed push by push.  That needs
-        // dynamically indexed per-thread state; keeping it out of this kernel keeps this kernel free of scratch
-        // memory (measured: 8x faster) -- the span goes to the wavefront kernel, which replays from LDS.
-        const int slot = wave_append(&P.heavy_in_count[E], c.ambiguous);
-        if (slot >= 0) {
-            P.heavy_in_unit[P.heavy_in_off[E] + slot] = T.unit;
-            P.heavy_in_idx[P.heavy_in_off[E] + slot] = i;
-            return;
-        }
-    }
+    // rare (millisecond-granular data): CPython's heapq / list.sort must be replayed push by push.  That needs
+    // dynamically indexed per-thread state; keeping it out of this kernel keeps this kernel free of scratch memory
+    // (measured: 8x faster) -- the span goes to the wavefront kernel, which replays from LDS.
+    if (heavy_append<E>(P, c.ambiguous, narrow, T.unit, i)) return;
     const int64_t g = U.in_off + i;
     P.tk_n[g] = c.nk;
     P.leaves[g] = c.leaves;
@@ -869,10 +871,12 @@ struct LdsHeap {
 // One wavefront per span.  Nothing lives in scratch memory: what is the same for every lane (cut-offs,
 // the prefix being walked, the staged candidate window, the term tables, the replay heap) sits in LDS,
 // what differs per lane (its grid point) sits in registers addressed by compile-time indices.
-template <int E>
+template <int E, int W>
 __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    constexpr int W = 64 * kCandWords;
+    static_assert(W == kNarrow || W == 64 * kCandWords, "one instantiation per half of the work list");
+    constexpr bool kWide = W != kNarrow;
+    constexpr int kList = kWide ? kMaxEp + 1 + E : E;
     __shared__ unsigned long long sbits[kMaxEp][kCandWords];
     // LDS-staged candidate window of the span: start / end of every candidate outgoing span, and the two
     // score terms that depend on one span only -- root(in.start -> s.start) and closing(s.end -> in.end)
@@ -885,14 +889,14 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
     __shared__ int32_t px[E];               // the prefix the wavefront is walking (same for every lane)
     __shared__ int64_t pxs[E], pxe[E];
     const int t = threadIdx.x, nt = blockDim.x;
-    const int count = P.heavy_in_count[E];
+    const int count = P.heavy_in_count[kList];
     TW_PROF_DECL();
     int chunk_pos = 0, chunk_end = 0;
     while (true) {
         // dynamic work distribution: candidate products span four orders of magnitude, a static split leaves
         // most wavefronts idle behind the few that drew the large spans
         if (chunk_pos == chunk_end) {
-            if (t == 0) chunk_pos = atomicAdd(&P.heavy_in_next[E], kWorkChunk);
+            if (t == 0) chunk_pos = atomicAdd(&P.heavy_in_next[kList], kWorkChunk);
             chunk_pos = __shfl(chunk_pos, 0);
             chunk_end = chunk_pos + kWorkChunk < count ? chunk_pos + kWorkChunk : count;
             if (chunk_pos >= count) { TW_PROF_FLUSH(); break; }
@@ -900,8 +904,9 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         const int item = chunk_pos++;
         // wave-uniform by construction; telling the compiler so turns every access to the unit descriptor below
         // into a scalar load (SGPRs, constant cache) instead of 64 lanes loading the same address
-        const int unit = __builtin_amdgcn_readfirstlane(P.heavy_in_unit[P.heavy_in_off[E] + item]);
-        const int i = __builtin_amdgcn_readfirstlane(P.heavy_in_idx[P.heavy_in_off[E] + item]);
+        const int pos = kWide ? P.heavy_in_off[E + 1] - 1 - item : P.heavy_in_off[E] + item;
+        const int unit = __builtin_amdgcn_readfirstlane(P.heavy_in_unit[pos]);
+        const int i = __builtin_amdgcn_readfirstlane(P.heavy_in_idx[pos]);
         const UnitDev& U = P.units[unit];
         TW_T0();
 #ifdef TW_PROFILE
