@@ -99,7 +99,7 @@ struct Dev {
     double* gaps;
     const int64_t* gs_off;  // [n_units]
     int64_t* unit_stats;    // [n_units][8]
-    int32_t* heavy_count;   // windows whose best candidates clash: work list of k_select_heavy
+    int32_t* heavy_count;   // [3] windows whose best candidates clash (work list of k_select_heavy): -, long ones (front), short ones (back)
     int32_t* heavy_next;    // next unclaimed entry of that list
     int32_t *heavy_unit, *heavy_win;
     int32_t* heavy_in_count;  // [2][kMaxEp+1] incoming spans deferred to k_enumerate_heavy per endpoint count E: narrow, wide windows

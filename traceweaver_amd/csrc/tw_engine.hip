@@ -225,7 +225,7 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
     HIPCHK(hipMemsetAsync(P.err, 0, sizeof(int32_t), e->stream));
     HIPCHK(hipMemsetAsync(P.unit_stats, 0, sizeof(int64_t) * 8 * P.n_units, e->stream));
-    HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t), e->stream));
+    HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 3, e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t), e->stream));
     HIPCHK(hipMemsetAsync(P.unit_ndirty, 0, sizeof(int32_t) * P.n_units, e->stream));
     HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
@@ -468,7 +468,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.prof, 16); ALLOC(e->key_acc, 2);
     HIPCHK(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 16, e->stream));
     HIPCHK(hipMemsetAsync(P.prof + 10, 0xff, sizeof(unsigned long long), e->stream));
-    ALLOC(P.heavy_count, 1); ALLOC(P.heavy_next, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);
+    ALLOC(P.heavy_count, 3); ALLOC(P.heavy_next, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
     ALLOC(e->gaps_sorted, gaps); ALLOC(e->fit_models, slots * kMaxComp * kModelStride);
@@ -789,10 +789,12 @@ int tw_evaluate(tw_engine* e, int64_t* per_unit, uint8_t* trace_flags, int64_t* 
  * out[0] = windows listed for k_select_heavy, out[1 + E] = spans listed for k_enumerate_heavy<E>. */
 int tw_debug_worklists(tw_engine* e, int32_t* out) {
     if (e == nullptr || out == nullptr || e->state < ST_PASS1) return TW_ERR_ARG;
-    HIPCHK(hipMemcpyAsync(out, e->P.heavy_count, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    int32_t sel[3];
+    HIPCHK(hipMemcpyAsync(sel, e->P.heavy_count, sizeof(sel), hipMemcpyDeviceToHost, e->stream));
     int32_t both[2 * (kMaxEp + 1)];
     HIPCHK(hipMemcpyAsync(both, e->P.heavy_in_count, sizeof(both), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    out[0] = sel[1] + sel[2];
     for (int k = 0; k <= kMaxEp; k++) out[1 + k] = both[k] + both[kMaxEp + 1 + k];
     return TW_OK;
 }

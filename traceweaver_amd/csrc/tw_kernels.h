@@ -1500,6 +1500,7 @@ constexpr int kNodeBudget = 4096;    // search nodes per component; beyond it th
 constexpr int kMatchMaxCols = 256;   // widest span-index range one endpoint's relaxation may address
 constexpr int kMaxCols = kMatchMaxCols + kMaxWin + 1;
 constexpr int kBlkWords = (kMaxWin * kTopK + 63) / 64;  // words of a mask over all candidates of a component
+constexpr int kBigWindow = 8;        // windows of at least this many spans are served first by k_select_heavy
 constexpr int kBruteMax = 4;         // components of up to this many spans are solved by complete enumeration (see select_brute)
 
 // ---- cooperative path: one workgroup per window --------------------------------------------------
@@ -1662,27 +1663,35 @@ __device__ void select_step(SelectLds& L, int E, bool resume_with_bound) {
         if (L.prune) { d--; entered = false; }
         else { L.next[d] = 0; entered = false; }
     }
-    unsigned long long b0 = 0, b1 = 0, b2 = 0;  // candidates blocked at depth d (valid after a descent; reloaded after a return)
+    // hot state in registers: node counter, incumbent weight, and -- valid after a descent, reloaded after a return --
+    // the weight accumulated above depth d and the candidates blocked at depth d
+    int nodes = L.nodes;
+    double best_w = L.best_w, acc = 0.0;
+    unsigned long long b0 = 0, b1 = 0, b2 = 0;
     bool have = false;
+    if (entered && d >= 0) { acc = L.accs[d]; b0 = L.blk[d][0]; b1 = L.blk[d][1]; b2 = L.blk[d][2]; have = true; }
     while (d >= 0) {
         if (entered) {
-            if (L.nodes >= kNodeBudget) { L.budget_hit = 1; break; }
-            L.nodes++;
+            if (nodes >= kNodeBudget) { L.budget_hit = 1; break; }
+            nodes++;
             if (d == cm) {
-                if (L.accs[d] > L.best_w) { L.best_w = L.accs[d]; for (int q = 0; q < cm; q++) L.best[q] = L.cur[q]; }
+                if (acc > best_w) { best_w = acc; for (int q = 0; q < cm; q++) L.best[q] = L.cur[q]; }
                 d--; entered = false; have = false; continue;
             }
-            if (L.accs[d] + L.ub[d] <= L.best_w) { d--; entered = false; have = false; continue; }
-            if (L.nodes > kPlainNodes && cm - d >= kMatchMinDepth) { L.d = d; L.entered = 1; L.state = SEL_NEED_BOUND; return; }
+            if (acc + L.ub[d] <= best_w) { d--; entered = false; have = false; continue; }
+            if (nodes > kPlainNodes && cm - d >= kMatchMinDepth) {
+                L.d = d; L.entered = 1; L.state = SEL_NEED_BOUND; L.nodes = nodes; L.best_w = best_w;
+                return;
+            }
             L.next[d] = 0;
         }
-        if (!have) { b0 = L.blk[d][0]; b1 = L.blk[d][1]; b2 = L.blk[d][2]; have = true; }
+        if (!have) { acc = L.accs[d]; b0 = L.blk[d][0]; b1 = L.blk[d][1]; b2 = L.blk[d][2]; have = true; }
         const int b = L.mem[d], nc = L.ncand[b];
-        int k = L.next[d];
+        int k = entered ? 0 : L.next[d];
         bool descended = false;
         for (; k <= nc; k++) {
             if (k == nc) {  // "none"
-                L.cur[d] = -1; L.next[d] = (int8_t)(nc + 1); L.accs[d + 1] = L.accs[d];
+                L.cur[d] = -1; L.next[d] = (int8_t)(nc + 1); L.accs[d + 1] = acc;
                 L.blk[d + 1][0] = b0; L.blk[d + 1][1] = b1; L.blk[d + 1][2] = b2;
                 d++; entered = true; descended = true; break;
             }
@@ -1690,7 +1699,9 @@ __device__ void select_step(SelectLds& L, int E, bool resume_with_bound) {
             if (!(w > 0.0)) continue;
             const int bit = d * kTopK + k;
             if (((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull) continue;
-            L.cur[d] = (int8_t)k; L.next[d] = (int8_t)(k + 1); L.accs[d + 1] = L.accs[d] + w;
+            L.cur[d] = (int8_t)k; L.next[d] = (int8_t)(k + 1);
+            acc = acc + w;
+            L.accs[d + 1] = acc;
             b0 |= L.cmask3[d][k][0]; b1 |= L.cmask3[d][k][1]; b2 |= L.cmask3[d][k][2];
             L.blk[d + 1][0] = b0; L.blk[d + 1][1] = b1; L.blk[d + 1][2] = b2;
             d++; entered = true; descended = true; break;
@@ -1698,6 +1709,8 @@ __device__ void select_step(SelectLds& L, int E, bool resume_with_bound) {
         if (!descended) { L.cur[d] = -1; d--; entered = false; have = false; }
     }
     L.d = d;
+    L.nodes = nodes;
+    L.best_w = best_w;
     L.state = SEL_DONE;
 }
 
@@ -1961,10 +1974,16 @@ __global__ void __launch_bounds__(kTile) k_select_fast(Dev P) {
             clash = P.tk_idx[tk_index(U, 0, e, first + __ffs((int)rest) - 1)] == mine;
     }
     // the first lane that finds a clash puts the window on the work list of k_select_heavy
-    const int slot = wave_append(P.heavy_count, clash && atomicExch(&P.w_conf[U.in_off + w], 1) == 0);
-    if (slot >= 0) {
-        P.heavy_unit[slot] = Tl.unit;
-        P.heavy_win[slot] = w;
+    // Long windows can take a thousand times longer than short ones: they are listed from the front and served
+    // first, the short ones from the back of the same array, so that no long search starts when the kernel is
+    // about to drain.
+    const bool listed = clash && atomicExch(&P.w_conf[U.in_off + w], 1) == 0;
+    const bool big = listed && P.w_last[U.in_off + w] - first + 1 >= kBigWindow;
+    const int sb = wave_append(&P.heavy_count[1], big), ss = wave_append(&P.heavy_count[2], listed && !big);
+    if (listed) {
+        const int pos = big ? sb : (int)(P.n_in_total / 2) - ss;
+        P.heavy_unit[pos] = Tl.unit;
+        P.heavy_win[pos] = w;
     }
 }
 
@@ -1972,7 +1991,7 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     __shared__ SelectLds L;
     __shared__ int next_item;
-    const int count = *P.heavy_count;
+    const int n_big = P.heavy_count[1], count = n_big + P.heavy_count[2];
     int chunk_pos = 0, chunk_end = 0;
     TW_SEL_DECL();
     while (true) {
@@ -1985,11 +2004,22 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
             if (chunk_pos >= count) { TW_SEL_FLUSH(); break; }
         }
         const int item = chunk_pos++;
-        const int unit = __builtin_amdgcn_readfirstlane(P.heavy_unit[item]), w = __builtin_amdgcn_readfirstlane(P.heavy_win[item]);  // wave-uniform: scalar loads below
+        const int pos = item < n_big ? item : (int)(P.n_in_total / 2) - (item - n_big);
+        const int unit = __builtin_amdgcn_readfirstlane(P.heavy_unit[pos]), w = __builtin_amdgcn_readfirstlane(P.heavy_win[pos]);  // wave-uniform: scalar loads below
         const UnitDev& U = P.units[unit];
         const int last = P.w_last[U.in_off + w];
         const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
+#ifdef TW_PROFILE_SEL
+        const long long _w0 = wall_clock64();
+#endif
         select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS);
+#ifdef TW_PROFILE_SEL
+        if (threadIdx.x == 0) {
+            const unsigned long long dur = (unsigned long long)(wall_clock64() - _w0);
+            atomicMax((unsigned long long*)&P.prof[8], (dur << 24) | ((unsigned long long)(last - first + 1) << 16) | (unsigned long long)(L.nodes & 0xffff));
+            atomicAdd((unsigned long long*)&P.prof[9], dur);
+        }
+#endif
     }
 }
 
