@@ -75,10 +75,12 @@ __device__ inline void block_reduce(double (&vals)[cnt], double* sh) {
 // One workgroup per scored row: distinct values and their first positions (a head is a sample that differs
 // from its left neighbour; NaN = dropped samples, sorted last, are not counted).
 __global__ void __launch_bounds__(kCoop) k_fit_compress(FitDev F) {
-    __shared__ int32_t sh[kCoop];
+    constexpr int R = 4;  // chunks of blockDim samples per round: their loads are in flight together
+    __shared__ int32_t wave_heads[R][kCoop / 64];
     __shared__ int32_t carry_sh, n_sh;
     const int64_t q = blockIdx.x;
     const int t = threadIdx.x, nt = blockDim.x;
+    const int lane = t & 63, wave = t >> 6, nwave = (nt + 63) >> 6;
     if (!F.slot_scored[q]) {
         if (t == 0) { F.row_n[q] = 0; F.row_uniq[q] = 0; }
         return;
@@ -89,36 +91,45 @@ __global__ void __launch_bounds__(kCoop) k_fit_compress(FitDev F) {
     const double* x = F.sorted + row;
     if (t == 0) { carry_sh = 0; n_sh = 0; }
     __syncthreads();
-    for (int base = 0; base < n_all; base += nt) {
-        const int i = base + t;
-        double xi = 0.0;
-        bool valid = false, head = false;
-        if (i < n_all) {
-            xi = x[i];
-            valid = xi == xi;
-            head = valid && (i == 0 || x[i - 1] != xi);
+    for (int base = 0; base < n_all; base += R * nt) {
+        double xi[R];
+        bool head[R];
+        int before[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const int i = base + j * nt + t;
+            xi[j] = 0.0;
+            head[j] = false;
+            if (i < n_all) {
+                xi[j] = x[i];
+                const bool valid = xi[j] == xi[j];
+                head[j] = valid && (i == 0 || x[i - 1] != xi[j]);
+                if (valid && (i == n_all - 1 || !(x[i + 1] == x[i + 1]))) n_sh = i + 1;  // last sample of the row
+            }
         }
-        // inclusive scan of the head flags
-        sh[t] = head ? 1 : 0;
-        __syncthreads();
-        for (int off = 1; off < nt; off <<= 1) {
-            int a = sh[t];
-            if (t >= off) a += sh[t - off];
-            __syncthreads();
-            sh[t] = a;
-            __syncthreads();
+        // position of a head = heads before it: within the wavefront from the ballot, across wavefronts and chunks through LDS
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const unsigned long long heads = __ballot(head[j]);
+            before[j] = __popcll(heads & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_heads[j][wave] = __popcll(heads);
         }
-        const int carry = carry_sh;
-        if (head) {
-            const int pos = carry + sh[t] - 1;
-            F.uval[row + pos] = xi;
-            F.ustart[row + pos] = i;
+        __syncthreads();
+        int pos = carry_sh;
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            int chunk = 0, mine = 0;
+            for (int w = 0; w < nwave; w++) { const int c = wave_heads[j][w]; if (w < wave) mine += c; chunk += c; }
+            if (head[j]) {
+                F.uval[row + pos + mine + before[j]] = xi[j];
+                F.ustart[row + pos + mine + before[j]] = base + j * nt + t;
+            }
+            pos += chunk;
         }
-        if (valid && (i == n_all - 1 || !(x[i + 1] == x[i + 1]))) n_sh = i + 1;  // last sample of the row
         __syncthreads();
-        if (t == nt - 1) carry_sh = carry + sh[t];
-        __syncthreads();
+        if (t == 0) carry_sh = pos;  // (the next round's barrier orders this update before its use)
     }
+    __syncthreads();
     if (t == 0) { F.row_n[q] = n_sh; F.row_uniq[q] = carry_sh; }
 }
 
