@@ -189,8 +189,8 @@ int tw_assign_service(tw_engine *e, int32_t n_in, const int64_t *in_start, const
  * (executor.py:287-339), ParseJsonTrace / ParseSpansJson / ParseProcessesJson(2) (executor.py:342-384,451-461,
  * 755-793), ProcessTraceData (executor.py:795-849), PartitionSpansByEndPoint (executor.py:1104-1113),
  * GetGroundTruth (helpers/utils.py:22-32), FindOrder + nx.topological_sort (executor.py:214-285,
- * traceweaver_v1.py:37-39).  The dataset-specific fix-ups (FixSpans / FixSpans2 / self-loop renaming) are not
- * reproduced.  Names are interned: every *_name / service / span_id field below is a string id for
+ * traceweaver_v1.py:37-39), FixSpans / FixSpans2 (executor.py:505-537,542-645).  The self-loop renaming applied to
+ * the Alibaba parser output (executor.py:386-448) is not reproduced.  Names are interned: every *_name / service / span_id field below is a string id for
  * tw_corpus_string(). */
 typedef struct tw_corpus tw_corpus;
 int tw_corpus_create(tw_corpus **out);
@@ -204,11 +204,23 @@ const char *tw_corpus_last_error(const tw_corpus *c);   /* first file that faile
  * executor.py:873) traces are held.  Files that do not parse or break an assumption the reference asserts on
  * are counted, not fatal. */
 int tw_corpus_add_files(tw_corpus *c, const char *const *paths, int32_t n_paths, const char *first_span,
-                        int64_t max_traces, int32_t n_threads);
+                        int64_t max_traces, int32_t n_threads, int32_t fix);
+
+/* `fix` = the span surgery the reference applies to some of its corpora before the walk (executor.py:776-779):
+ *   TW_FIX_NONE          plain Jaeger exports (hotel; --fix 2..5)
+ *   TW_FIX_CLIENT_TWINS  FixSpans (executor.py:505-537; nodejs, --fix 0): every hop is logged once, as a server span;
+ *                        each gets a client twin "<id>_client" in the calling service, which is looked up in the
+ *                        static service -> caller map given with tw_corpus_set_callers (executor.py:109-115)
+ *   TW_FIX_REROOT        FixSpans2 (executor.py:542-645; media, --fix 1): the span named first_span becomes the root,
+ *                        same-process children are dropped, every remaining hop gets a client twin in its parent's
+ *                        process, spans are ordered by start time */
+enum { TW_FIX_NONE = 0, TW_FIX_CLIENT_TWINS = 1, TW_FIX_REROOT = 2 };
+int tw_corpus_set_callers(tw_corpus *c, const char *const *service, const char *const *caller, int32_t n);
 
 /* out6 = spans held, traces held, files seen, files that failed to parse, traces filtered out, strings. */
 int tw_corpus_counts(const tw_corpus *c, int64_t *out6);
 const char *tw_corpus_string(const tw_corpus *c, int32_t id);
+int tw_corpus_trace_names(const tw_corpus *c, int32_t *out);   /* string id of the traceID of trace 0 .. traces-1 */
 
 /* The span table (one row per span reached from its trace's root, in walk order); caller-allocated columns of
  * tw_corpus_counts()[0] entries, any may be NULL.  parent = row of the referenced span (-1 for roots),
@@ -237,6 +249,7 @@ typedef struct {
     const int64_t *in_start, *in_end, *out_start, *out_end;
     const int32_t *true_child, *in_trace, *in_row, *out_row;
     const int32_t *unit_service, *ep_name, *in_ep_name;
+    const int32_t *unit_order;   /* position of the unit's service among the services that make calls (the executor's process_id, executor.py:1079) */
     int64_t n_traces;
     int32_t skipped[4];
 } tw_unit_set;

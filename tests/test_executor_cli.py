@@ -1,0 +1,70 @@
+"""The reference's command line (executor.py:38-74) on the native chain: JSON directory -> ingest -> both passes ->
+accuracy -> the reference's result files.  CPU tier through the host-emulation build; the figures are compared
+with the frozen reference run of the same corpus (accuracy within the reference's own run-to-run spread, the
+pass-independent parts exactly)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+REF = "/root/reference"
+
+
+def run_cli(tmp_path, emu_lib, rel, fix, name):
+    from traceweaver_amd import executor
+
+    out = str(tmp_path) + "/"
+    argv = ["--relative_path", rel, "--compressed", "0", "--cache_rate", "0", "--fix", str(fix), "--test_name", name,
+            "--load_level", "100", "--compress_factor", "1", "--repeat_factor", "1", "--execute_parallel", "0",
+            "--results_directory", out, "--clear_cache", "1", "--predictor_indices", "10",
+            "--project_root", REF, "--engine_library", emu_lib]
+    executor.main(argv)
+    suffix = "_%s_100_1_1_0.0.pickle" % name
+    return {k: pickle.load(open(out + k + suffix, "rb")) for k in ("accuracy", "process_acc", "confidence_scores", "bin_acc", "e2e")}
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/data"), reason="the reference's data directory is not present")
+def test_hotel_run_matches_the_frozen_reference_run(emu_lib, tmp_path):
+    got = run_cli(tmp_path, emu_lib, "data/hotel_reservation/hotel_load100/", 2, "hotel_test")
+    gold = {str(np.load(p)["process"]): np.load(p) for p in GOLDEN if "hotel_load100__" in p}
+    method = "MaxScoreBatchSubsetWithSkips"
+    assert set(got["accuracy"]) == {method, method + "TopK"}
+    # same services under the same process ids, same request counts
+    assert got["process_acc"].keys() == {(method, 0), (method, 1)} and set(got["confidence_scores"]) == set(gold)
+    for svc, (acc, not_best, n) in got["confidence_scores"].items():
+        g = gold[svc]
+        ref_acc = float(np.all(g["final_parent"] == g["true_parent"], axis=0).mean())
+        assert n == len(g["in_start"]) and abs(acc - ref_acc) < 0.015 and abs(not_best - int(g["not_best_count"])) <= 15
+    ref_e2e = float(gold["frontend"]["e2e_accuracy"])
+    assert abs(got["accuracy"][method] - ref_e2e) < 1.5 and got["accuracy"][method + "TopK"] >= got["accuracy"][method]
+    assert [p for p, _, _ in got["bin_acc"][method]] == [10.0 * (b + 1) for b in range(10)]
+    true_traces, pred_traces = got["e2e"][method]
+    assert len(true_traces) == len(pred_traces) == 1000
+    tid, spans = next(iter(true_traces.items()))
+    assert len(spans) == 5 and all(s[0] == tid for s in spans)      # frontend: 3 calls, search: 2 calls per request
+
+
+def test_unsupported_settings_are_refused(emu_lib, tmp_path):
+    from traceweaver_amd import executor
+
+    base = ["--relative_path", "x", "--fix", "2", "--results_directory", str(tmp_path) + "/", "--engine_library", emu_lib]
+    for extra in (["--cache_rate", "0.3"], ["--cache_rate", "0", "--compress_factor", "4"], ["--cache_rate", "0", "--predictor_indices", "4,10"],
+                  ["--cache_rate", "0", "--parallel", "1"]):
+        with pytest.raises(SystemExit) as ei:
+            executor.main(base + extra)
+        assert "not supported here" in str(ei.value)
+
+
+def test_generated_corpus_end_to_end(emu_lib, tmp_path):
+    """No reference data needed: a generated plain-Jaeger corpus through the same command line."""
+    from traceweaver_amd import executor, synth
+
+    synth.write_jaeger_corpus(str(tmp_path / "corpus"), 11, 400, app=synth.HOTEL_APP, concurrency=1.5)
+    out = str(tmp_path / "res") + "/"
+    executor.main(["--absolute_path", str(tmp_path / "corpus"), "--cache_rate", "0", "--fix", "2", "--results_directory", out,
+                   "--test_name", "gen", "--load_level", "7", "--engine_library", emu_lib])
+    acc = pickle.load(open(out + "accuracy_gen_7_1_1_0.0.pickle", "rb"))
+    assert acc["MaxScoreBatchSubsetWithSkips"] > 85.0

@@ -1,7 +1,7 @@
 """Native Jaeger-JSON ingest (csrc/tw_ingest.cpp) against (a) a plain-Python restatement of what
 the reference's executor does between reading a directory and calling the predictor (executor.py:287-339,
 755-849,1080-1135; helpers/utils.py:22-32) on generated corpora, and (b) the inputs frozen from the reference
-itself for the hotel corpus (tests/golden/ref_hotel_*; needs /root/reference for the JSON files)."""
+itself for every shipped corpus (tests/golden/ref_*; needs /root/reference for the JSON files)."""
 import json
 import os
 
@@ -13,7 +13,7 @@ from traceweaver_amd import synth
 from traceweaver_amd.engine import Engine
 from traceweaver_amd.ingest import Corpus
 
-REF_DATA = "/root/reference/data/hotel_reservation"
+REF_DATA = "/root/reference/data/hotel_reservation"   # (its parent holds all corpora)
 
 
 def python_pipeline(paths, first_span, max_traces=1001):
@@ -126,15 +126,33 @@ def test_first_span_filter_and_limits(emu_lib, tmp_path):
     c.close()
 
 
+# (golden name, directory under the reference's data/, --fix): every corpus the goldens were frozen from
+REFERENCE_CORPORA = [
+    ("hotel_load100", "hotel_reservation/hotel_load100", 2), ("hotel_load150", "hotel_reservation/hotel_load150", 2),
+    ("media_load100", "media_microservices/media_load100", 1), ("media_load150", "media_microservices/media_load150", 1),
+    ("nodeio_1", "nodejs_microservices_with_arbitrary_file_io/node_1", 0),
+    ("nodeio_0.6", "nodejs_microservices_with_arbitrary_file_io/node_0.6", 0),
+    ("node_load150", "nodejs_microservices/node_load150", 0),
+]
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="the reference's data directory is not present")
-@pytest.mark.parametrize("dataset", ["hotel_load100", "hotel_load150"])
-def test_native_ingest_reproduces_the_reference_inputs(emu_lib, dataset):
+@pytest.mark.parametrize("name,rel,fix", REFERENCE_CORPORA, ids=[c[0] for c in REFERENCE_CORPORA])
+def test_native_ingest_reproduces_the_reference_inputs(emu_lib, name, rel, fix):
+    """The arrays the native loader hands the engine == the arrays the reference's executor handed TraceWeaverV3 in
+    the frozen runs (tests/golden/ref_*): plain Jaeger (hotel), FixSpans2 (media), FixSpans (nodejs)."""
+    from traceweaver_amd.ingest import REFERENCE_FIX
+
+    first_span, surgery = REFERENCE_FIX[fix]
     c = Corpus(lib_path=emu_lib)
-    c.add_directory(os.path.join(REF_DATA, dataset), first_span="HTTP GET /hotels", max_traces=1001)
+    counts = c.add_directory(os.path.join(os.path.dirname(REF_DATA), rel), first_span=first_span, max_traces=1001, fix=surgery)
+    assert counts["traces"] == 1000 and counts["files_rejected"] == 0 and counts["traces_filtered"] == 0
     units, skipped, _ = c.units()
-    assert sum(skipped.values()) == 0 and len(units) == 2
+    golden = {os.path.basename(p)[len("ref_%s__" % name):-4]: p for p in GOLDEN if os.path.basename(p).startswith("ref_%s__" % name)}
+    assert {u.service for u in units} == set(golden)          # the same services reach the predictor
+    assert skipped["several_callers"] == (1 if fix == 1 else 0)   # media: compose-review-service (executor.py:1126-1128)
     for u in units:
-        g = np.load([p for p in GOLDEN if "%s__%s" % (dataset, u.service) in p][0])
+        g = np.load(golden[u.service])
         a = u.arrays
         assert np.array_equal(a.in_start, g["in_start"]) and np.array_equal(a.in_end - a.in_start, g["in_dur"])
         assert np.array_equal(a.out_off, g["out_off"]) and np.array_equal(a.out_start, g["out_start"])

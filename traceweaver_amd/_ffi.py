@@ -37,7 +37,7 @@ class SpanTable(ctypes.Structure):
 class UnitSet(ctypes.Structure):
     _fields_ = [("n_units", ctypes.c_int32)] + [(k, ctypes.c_void_p) for k in (
         "unit_in_off", "unit_E", "ep_off", "dag", "key_rank", "in_start", "in_end", "out_start", "out_end",
-        "true_child", "in_trace", "in_row", "out_row", "unit_service", "ep_name", "in_ep_name")] + [
+        "true_child", "in_trace", "in_row", "out_row", "unit_service", "ep_name", "in_ep_name", "unit_order")] + [
         ("n_traces", ctypes.c_int64), ("skipped", ctypes.c_int32 * 4)]
 
 
@@ -52,8 +52,8 @@ class Results(ctypes.Structure):
 EXPORTS = ["tw_create", "tw_destroy", "tw_last_error", "tw_load_batch", "tw_run_pass1", "tw_get_gaps",
            "tw_set_mixtures", "tw_fit_mixtures", "tw_get_mixtures", "tw_run_pass2", "tw_get_results", "tw_get_gauss_params", "tw_get_timing",
            "tw_assign_service", "tw_find_order", "tw_set_truth", "tw_evaluate",
-           "tw_corpus_create", "tw_corpus_destroy", "tw_corpus_last_error", "tw_corpus_add_files", "tw_corpus_counts",
-           "tw_corpus_string", "tw_corpus_span_table", "tw_corpus_build_units"]
+           "tw_corpus_create", "tw_corpus_destroy", "tw_corpus_last_error", "tw_corpus_add_files", "tw_corpus_set_callers", "tw_corpus_counts",
+           "tw_corpus_string", "tw_corpus_trace_names", "tw_corpus_span_table", "tw_corpus_build_units"]
 
 
 def load(path=None):
@@ -89,10 +89,12 @@ def load(path=None):
     lib.tw_corpus_destroy.restype = None
     lib.tw_corpus_last_error.argtypes = [vp]
     lib.tw_corpus_last_error.restype = ctypes.c_char_p
-    lib.tw_corpus_add_files.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int32]
+    lib.tw_corpus_add_files.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+    lib.tw_corpus_set_callers.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32]
     lib.tw_corpus_counts.argtypes = [vp, vp]
     lib.tw_corpus_string.argtypes = [vp, ctypes.c_int32]
     lib.tw_corpus_string.restype = ctypes.c_char_p
+    lib.tw_corpus_trace_names.argtypes = [vp, vp]
     lib.tw_corpus_span_table.argtypes = [vp, ctypes.POINTER(SpanTable)]
     lib.tw_corpus_build_units.argtypes = [vp, ctypes.POINTER(UnitSet)]
     for name in EXPORTS:

@@ -8,9 +8,8 @@
 //   PartitionSpansByEndPoint                 executor.py:1104-1113 by caller ("client_<op>" for roots) / callee service, sorted (start, end)
 //   GetGroundTruth                           helpers/utils.py:22-32 first outgoing span of the same trace per endpoint
 //   FindOrder + nx.topological_sort          executor.py:214-285, traceweaver_v1.py:37-39
-// The dataset-specific span surgery of the reference (FixSpans for nodejs, FixSpans2 for media, self-loop renaming
-// for the Alibaba parser output; executor.py:386-448,463-750) is not reproduced: such corpora are ingested by the
-// reference's loader and handed over through the predictor protocol.
+//   FixSpans / FixSpans2                     executor.py:505-537,542-645   the span surgery the nodejs / media corpora need
+// The self-loop renaming the reference applies to the Alibaba parser output (executor.py:386-448) is not reproduced.
 //
 // Strings never reach the GPU: every name is interned, units carry string ids and span-table rows so that the
 // caller can translate indices back to (trace id, span id) keys.
@@ -284,9 +283,10 @@ struct tw_corpus {
     std::vector<int32_t> service_order;        // services in order of their first outgoing span
     std::unordered_map<int32_t, std::vector<int32_t>> in_rows, out_rows;  // per service, in walk order
     int64_t files_total = 0, files_rejected = 0, traces_filtered = 0;
+    std::unordered_map<std::string, std::string> caller_of;  // service -> calling service (FixSpans' process_map_1)
     // last unit set built
     std::vector<int64_t> u_in_off, u_ep_off, u_in_start, u_in_end, u_out_start, u_out_end;
-    std::vector<int32_t> u_E, u_key_rank, u_truth, u_in_trace, u_in_row, u_out_row, u_service, u_ep_name, u_in_ep;
+    std::vector<int32_t> u_E, u_key_rank, u_truth, u_in_trace, u_in_row, u_out_row, u_service, u_ep_name, u_in_ep, u_order;
     std::vector<uint8_t> u_dag;
     int32_t skipped_multi_in = 0, skipped_skip_mode = 0, skipped_small = 0, skipped_cyclic = 0;
 
@@ -301,6 +301,125 @@ struct tw_corpus {
 };
 
 namespace {
+
+// FixSpans (executor.py:505-537; nodejs corpora, --fix 0): the instrumentation logs every hop once, as a server span
+// in the callee (the root as a client span).  Every server span gets a client twin "<sid>_client" with the same
+// timestamps in the calling service (static service -> caller map, executor.py:109-115) and is re-pointed at it;
+// client spans become server spans.  Twins are appended after the original spans (dict order matters: it breaks
+// ties between equal timestamps further down).  Returns false where the reference would raise.
+bool fix_client_twins(TraceTmp& T, const std::unordered_map<std::string, std::string>& caller_of) {
+    std::unordered_map<std::string, std::string> proc, pid_of_service;
+    for (const auto& kv : T.processes) proc[kv.first] = kv.second;
+    for (const SpanTmp& s : T.spans) {
+        auto it = proc.find(s.pid);
+        if (it == proc.end()) return false;
+        pid_of_service[it->second] = s.pid;  // process_map_2: the last pid seen per service
+    }
+    std::vector<SpanTmp> twins;
+    for (SpanTmp& s : T.spans) {
+        if (s.kind == 2) s.kind = 1;
+        else if (s.kind == 1) {
+            if (s.refs.empty()) return false;
+            auto c = caller_of.find(proc[s.pid]);
+            if (c == caller_of.end()) return false;
+            auto p = pid_of_service.find(c->second);
+            if (p == pid_of_service.end()) return false;
+            SpanTmp twin = s;
+            twin.sid = s.sid + "_client";
+            twin.pid = p->second;
+            twin.kind = 2;
+            s.refs[0] = std::make_pair(twin.refs[0].first, twin.sid);
+            twins.push_back(std::move(twin));
+        }
+    }
+    for (SpanTmp& t : twins) T.spans.push_back(std::move(t));
+    return true;
+}
+
+// FixSpans2 (executor.py:542-645; media corpora, --fix 1): the span named `root_op` ("ComposeReview") becomes the
+// root (its ancestors are dropped, its span id becomes the trace id, its children are re-pointed), spans whose parent
+// runs in the same process are dropped, every remaining span becomes a server span and -- unless it is the root --
+// gets a client twin "<sid>_client" in its parent's process; finally the spans are ordered by start time (stable).
+bool fix_reroot(TraceTmp& T, const std::string& root_op) {
+    struct Node { SpanTmp s; std::string key; bool alive; };
+    std::vector<Node> nodes;          // insertion order of the reference's dict `new_spans`
+    std::unordered_map<std::string, int> at;  // key (span id at insertion) -> index of the live entry
+    for (const SpanTmp& s : T.spans) {
+        auto it = at.find(s.sid);
+        if (it != at.end()) { nodes[(size_t)it->second].s = s; continue; }  // duplicate key: value replaced in place
+        at[s.sid] = (int)nodes.size();
+        nodes.push_back(Node{s, s.sid, true});
+    }
+    const int n0 = (int)nodes.size();
+    // step 1: re-root
+    for (int i = 0; i < n0; i++) {
+        if (nodes[(size_t)i].s.op != root_op) continue;
+        const std::string old_key = nodes[(size_t)i].key;
+        if (nodes[(size_t)i].s.refs.empty()) return false;
+        std::string up = nodes[(size_t)i].s.refs[0].second;          // DeleteAncestors
+        while (true) {
+            auto it = at.find(up);
+            if (it == at.end() || !nodes[(size_t)it->second].alive) return false;
+            Node& a = nodes[(size_t)it->second];
+            // the reference walks the *original* spans' references and deletes from the copy
+            a.alive = false;
+            at.erase(it);
+            if (a.s.refs.empty()) break;
+            up = a.s.refs[0].second;
+        }
+        for (int j = 0; j < n0; j++) {                               // ChangeChildReferences (looks at the original spans)
+            const SpanTmp& o = T.spans[(size_t)j];
+            if (!o.refs.empty() && o.refs[0].second == old_key && o.refs[0].first == T.trace_id) {
+                auto it = at.find(o.sid);
+                if (it == at.end()) return false;
+                nodes[(size_t)it->second].s.refs[0] = std::make_pair(T.trace_id, T.trace_id);
+            }
+        }
+        SpanTmp moved = nodes[(size_t)i].s;
+        moved.sid = T.trace_id;
+        moved.refs.clear();
+        nodes[(size_t)i].alive = false;                              // del new_spans[span_id] ...
+        at.erase(old_key);
+        auto ex = at.find(T.trace_id);                               // ... new_spans[(trace_id, trace_id)] = span
+        if (ex != at.end()) nodes[(size_t)ex->second].s = moved;
+        else { at[T.trace_id] = (int)nodes.size(); nodes.push_back(Node{moved, T.trace_id, true}); }
+    }
+    // step 2: drop spans whose parent runs in the same process (parents looked up in the state after step 1)
+    {
+        std::vector<int> drop;
+        for (size_t i = 0; i < nodes.size(); i++) {
+            if (!nodes[i].alive || nodes[i].s.refs.empty()) continue;
+            auto it = at.find(nodes[i].s.refs[0].second);
+            if (it == at.end()) return false;                        // FindParentProcess would raise
+            if (nodes[(size_t)it->second].s.pid == nodes[i].s.pid) drop.push_back((int)i);
+        }
+        for (int i : drop) { nodes[(size_t)i].alive = false; at.erase(nodes[(size_t)i].key); }
+    }
+    // step 3: everything is a server span; non-roots get a client twin in the parent's process
+    std::vector<SpanTmp> out, twins;
+    for (size_t i = 0; i < nodes.size(); i++) {
+        if (!nodes[i].alive) continue;
+        SpanTmp s = nodes[i].s;
+        s.kind = 1;
+        if (!s.refs.empty()) {
+            auto it = at.find(s.refs[0].second);
+            if (it == at.end()) return false;
+            SpanTmp twin = s;
+            twin.sid = s.sid + "_client";
+            twin.pid = nodes[(size_t)it->second].s.pid;
+            twin.kind = 2;
+            s.refs[0] = std::make_pair(twin.refs[0].first, twin.sid);
+            twins.push_back(std::move(twin));
+        }
+        // the dict key stays the id the span was inserted under; the walk below looks spans up by their sid field,
+        // which differs from the key only for the re-rooted span (key == sid == trace id there)
+        out.push_back(std::move(s));
+    }
+    for (SpanTmp& t : twins) out.push_back(std::move(t));
+    std::stable_sort(out.begin(), out.end(), [](const SpanTmp& a, const SpanTmp& b) { return a.start < b.start; });
+    T.spans = std::move(out);
+    return true;
+}
 
 // ProcessTraceData (executor.py:795-849) for one parsed trace; returns false (and leaves the corpus untouched)
 // when the trace breaks an assumption the reference asserts on.
@@ -384,9 +503,16 @@ int tw_corpus_create(tw_corpus** out) {
 void tw_corpus_destroy(tw_corpus* c) { delete c; }
 const char* tw_corpus_last_error(const tw_corpus* c) { return c ? c->err.c_str() : "null corpus"; }
 
+int tw_corpus_set_callers(tw_corpus* c, const char* const* service, const char* const* caller, int32_t n) {
+    if (c == nullptr || n < 0 || (n > 0 && (service == nullptr || caller == nullptr))) return TW_ERR_ARG;
+    c->caller_of.clear();
+    for (int i = 0; i < n; i++) c->caller_of[service[i]] = caller[i];
+    return TW_OK;
+}
+
 int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths, const char* first_span, int64_t max_traces,
-                        int32_t n_threads) {
-    if (c == nullptr || (n_paths > 0 && paths == nullptr) || n_paths < 0) return TW_ERR_ARG;
+                        int32_t n_threads, int32_t fix) {
+    if (c == nullptr || (n_paths > 0 && paths == nullptr) || n_paths < 0 || fix < 0 || fix > 2) return TW_ERR_ARG;
     std::vector<TraceTmp> parsed((size_t)n_paths);
     std::atomic<int> next(0);
     auto work = [&]() {
@@ -421,9 +547,12 @@ int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths,
         if (c->err.empty()) c->err = std::string(paths[i]) + ": " + parsed[(size_t)i].error;
     }
     for (int i : idx) {
-        const TraceTmp& T = parsed[(size_t)i];
+        TraceTmp& T = parsed[(size_t)i];
         if (!T.ok) continue;
-        if (add_trace(c, T, fs)) accepted++; else c->traces_filtered++;
+        bool ok = true;
+        if (fix == TW_FIX_CLIENT_TWINS) ok = fix_client_twins(T, c->caller_of);
+        else if (fix == TW_FIX_REROOT) ok = fix_reroot(T, fs);
+        if (ok && add_trace(c, T, fs)) accepted++; else c->traces_filtered++;
         if (max_traces > 0 && accepted >= max_traces) break;  // executor.py:873 stops after 1001 accepted traces
     }
     return TW_OK;
@@ -439,6 +568,12 @@ int tw_corpus_counts(const tw_corpus* c, int64_t* out6) {
 const char* tw_corpus_string(const tw_corpus* c, int32_t id) {
     if (c == nullptr || id < 0 || (size_t)id >= c->strings.size()) return nullptr;
     return c->strings[(size_t)id].c_str();
+}
+
+int tw_corpus_trace_names(const tw_corpus* c, int32_t* out) {
+    if (c == nullptr || out == nullptr) return TW_ERR_ARG;
+    for (size_t i = 0; i < c->trace_name.size(); i++) out[i] = c->trace_name[i];
+    return TW_OK;
 }
 
 int tw_corpus_span_table(const tw_corpus* c, tw_span_table* t) {
@@ -463,13 +598,15 @@ int tw_corpus_build_units(tw_corpus* c, tw_unit_set* out) {
     c->u_in_off.assign(1, 0); c->u_ep_off.assign(1, 0);
     c->u_in_start.clear(); c->u_in_end.clear(); c->u_out_start.clear(); c->u_out_end.clear();
     c->u_E.clear(); c->u_key_rank.clear(); c->u_truth.clear(); c->u_in_trace.clear(); c->u_in_row.clear(); c->u_out_row.clear();
-    c->u_service.clear(); c->u_ep_name.clear(); c->u_in_ep.clear(); c->u_dag.clear();
+    c->u_service.clear(); c->u_ep_name.clear(); c->u_in_ep.clear(); c->u_dag.clear(); c->u_order.clear();
     c->skipped_multi_in = c->skipped_skip_mode = c->skipped_small = c->skipped_cyclic = 0;
     const auto by_time = [&](int32_t a, int32_t b) {
         const SpanRow &A = c->rows[(size_t)a], &B = c->rows[(size_t)b];
         return A.start != B.start ? A.start < B.start : A.start + A.dur < B.start + B.dur;
     };
+    int32_t order = -1;
     for (int32_t svc : c->service_order) {
+        order++;
         auto in_it = c->in_rows.find(svc);
         if (in_it == c->in_rows.end()) continue;
         // PartitionSpansByEndPoint: keys in order of first appearance, each partition sorted by (start, end), stable
@@ -536,6 +673,7 @@ int tw_corpus_build_units(tw_corpus* c, tw_unit_set* out) {
         if ((int)topo.size() != E) { c->skipped_cyclic++; continue; }
         // emit
         c->u_service.push_back(svc);
+        c->u_order.push_back(order);
         c->u_in_ep.push_back(in_keys[0]);
         c->u_E.push_back(E);
         for (int64_t i = 0; i < n; i++) {
@@ -563,7 +701,7 @@ int tw_corpus_build_units(tw_corpus* c, tw_unit_set* out) {
     out->dag = c->u_dag.data(); out->key_rank = c->u_key_rank.data();
     out->in_start = c->u_in_start.data(); out->in_end = c->u_in_end.data(); out->out_start = c->u_out_start.data(); out->out_end = c->u_out_end.data();
     out->true_child = c->u_truth.data(); out->in_trace = c->u_in_trace.data(); out->in_row = c->u_in_row.data(); out->out_row = c->u_out_row.data();
-    out->unit_service = c->u_service.data(); out->ep_name = c->u_ep_name.data(); out->in_ep_name = c->u_in_ep.data();
+    out->unit_service = c->u_service.data(); out->ep_name = c->u_ep_name.data(); out->in_ep_name = c->u_in_ep.data(); out->unit_order = c->u_order.data();
     out->n_traces = (int64_t)c->trace_name.size();
     out->skipped[0] = c->skipped_multi_in; out->skipped[1] = c->skipped_skip_mode; out->skipped[2] = c->skipped_small; out->skipped[3] = c->skipped_cyclic;
     return TW_OK;

@@ -12,10 +12,19 @@ from . import _ffi
 from .engine import UnitArrays
 
 
+# executor.py:109-115 (process_map_1): which service calls which in the reference's nodejs application
+NODEJS_CALLERS = {"service5": "service3", "service4": "service2", "service2": "service1", "service3": "service1",
+                  "service1": "init-service"}
+
+# executor.py:757-763: --fix value -> (operation name of the roots that are kept, span surgery)
+REFERENCE_FIX = {0: ("init-span", "client_twins"), 1: ("ComposeReview", "reroot"), 2: ("HTTP GET /hotels", None),
+                 3: ("HTTP GET /recommendations", None), 4: ("[Todo] CompleteTodoCommandHandler", None), 5: (None, None)}
+
+
 class IngestedUnit(object):
     """One service as the hot path sees it, plus what is needed to translate results back."""
 
-    def __init__(self, arrays, true_parent, in_trace, service, in_ep, out_eps, in_rows, out_rows):
+    def __init__(self, arrays, true_parent, in_trace, service, in_ep, out_eps, in_rows, out_rows, process_id=0):
         self.arrays = arrays              # UnitArrays (endpoints in topological order)
         self.true_parent = true_parent    # [E, n_in] int32 index of the true outgoing span per endpoint
         self.in_trace = in_trace          # [n_in] trace number of every incoming span
@@ -24,6 +33,7 @@ class IngestedUnit(object):
         self.out_eps = out_eps            # callee names, topological order
         self.in_rows = in_rows            # span-table row of every incoming span
         self.out_rows = out_rows          # per endpoint: span-table rows of its outgoing spans
+        self.process_id = process_id      # position among the services that make calls (executor.py:1079)
 
 
 class Corpus(object):
@@ -44,12 +54,21 @@ class Corpus(object):
         except Exception:
             pass
 
-    def add_files(self, paths, first_span=None, max_traces=1001, threads=0):
+    def add_files(self, paths, first_span=None, max_traces=1001, threads=0, fix=None, callers=None):
         """executor.py:287-339,864-874: traces in time order, roots filtered by operation name, at most
-        `max_traces` kept (the reference's literal 1001; 0 = no limit)."""
+        `max_traces` kept (the reference's literal 1001; 0 = no limit).  `fix`: None / "client_twins" (FixSpans,
+        nodejs corpora; `callers` = service -> calling service, default the reference's table) / "reroot" (FixSpans2,
+        media corpora)."""
+        mode = {None: 0, "none": 0, "client_twins": 1, "reroot": 2}[fix]
+        if mode == 1:
+            callers = NODEJS_CALLERS if callers is None else callers
+            k = (ctypes.c_char_p * len(callers))(*[x.encode() for x in callers.keys()])
+            v = (ctypes.c_char_p * len(callers))(*[x.encode() for x in callers.values()])
+            if self._lib.tw_corpus_set_callers(self._h, k, v, len(callers)) != 0:
+                raise RuntimeError("tw_corpus_set_callers failed")
         paths = [os.fsencode(p) for p in paths]
         arr = (ctypes.c_char_p * len(paths))(*paths)
-        rc = self._lib.tw_corpus_add_files(self._h, arr, len(paths), first_span.encode() if first_span else None, int(max_traces), int(threads))
+        rc = self._lib.tw_corpus_add_files(self._h, arr, len(paths), first_span.encode() if first_span else None, int(max_traces), int(threads), mode)
         if rc != 0:
             raise RuntimeError("tw_corpus_add_files failed: %d" % rc)
         return self.counts()
@@ -69,6 +88,12 @@ class Corpus(object):
     def string(self, idx):
         s = self._lib.tw_corpus_string(self._h, int(idx))
         return s.decode() if s is not None else None
+
+    def trace_names(self):
+        """String id of the traceID of every trace held (trace numbers index this array)."""
+        out = np.zeros(self.counts()["traces"], dtype=np.int32)
+        self._lib.tw_corpus_trace_names(self._h, ctypes.c_void_p(out.ctypes.data))
+        return out
 
     def span_table(self):
         """Columns of the span table as numpy arrays (names as string ids, see string())."""
@@ -105,6 +130,7 @@ class Corpus(object):
         truth = view(us.true_child, int((E.astype(np.int64) * np.diff(in_off)).sum()), np.int32)
         in_trace, in_row, out_row = view(us.in_trace, n_in, np.int32), view(us.in_row, n_in, np.int32), view(us.out_row, n_out, np.int32)
         svc, epn, inep = view(us.unit_service, n, np.int32), view(us.ep_name, n_ep, np.int32), view(us.in_ep_name, n, np.int32)
+        order = view(us.unit_order, n, np.int32)
         out, ep0, d0, t0 = [], 0, 0, 0
         for u in range(n):
             e, a, b = int(E[u]), int(in_off[u]), int(in_off[u + 1])
@@ -114,7 +140,7 @@ class Corpus(object):
             tp = truth[t0:t0 + e * (b - a)].reshape(e, b - a)
             rows = [out_row[int(ep_off[ep0 + k]):int(ep_off[ep0 + k + 1])] for k in range(e)]
             out.append(IngestedUnit(arrays, tp, in_trace[a:b], self.string(svc[u]), self.string(inep[u]),
-                                    [self.string(x) for x in epn[ep0:ep0 + e]], in_row[a:b], rows))
+                                    [self.string(x) for x in epn[ep0:ep0 + e]], in_row[a:b], rows, int(order[u])))
             ep0 += e
             d0 += e * e
             t0 += e * (b - a)
