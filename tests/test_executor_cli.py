@@ -47,6 +47,23 @@ def test_hotel_run_matches_the_frozen_reference_run(emu_lib, tmp_path):
     assert len(spans) == 5 and all(s[0] == tid for s in spans)      # frontend: 3 calls, search: 2 calls per request
 
 
+@pytest.mark.skipif(not os.path.isdir(REF + "/data"), reason="the reference's data directory is not present")
+@pytest.mark.parametrize("name,rel,fix,n_services", [("media_load100", "data/media_microservices/media_load100/", 1, 6),
+                                                     ("nodeio_1", "data/nodejs_microservices_with_arbitrary_file_io/node_1/", 0, 4)])
+def test_corpora_that_need_span_surgery(emu_lib, tmp_path, name, rel, fix, n_services):
+    """FixSpans2 (media) / FixSpans (nodejs) corpora through the command line: same services as the frozen reference
+    run, per-service accuracy within the reference's run-to-run spread of its own figure."""
+    got = run_cli(tmp_path, emu_lib, rel, fix, name)
+    gold = {str(np.load(p)["process"]): np.load(p) for p in GOLDEN if "ref_%s__" % name in p}
+    assert set(got["confidence_scores"]) == set(gold) and len(gold) == n_services
+    for svc, (acc, not_best, n) in got["confidence_scores"].items():
+        g = gold[svc]
+        ref_acc = float(np.all(g["final_parent"] == g["true_parent"], axis=0).mean())
+        assert n == len(g["in_start"]) and abs(acc - ref_acc) < 0.03, (svc, acc, ref_acc)
+    ref_e2e = float(next(iter(gold.values()))["e2e_accuracy"])
+    assert abs(got["accuracy"]["MaxScoreBatchSubsetWithSkips"] - ref_e2e) < 3.0
+
+
 def test_unsupported_settings_are_refused(emu_lib, tmp_path):
     from traceweaver_amd import executor
 
