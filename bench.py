@@ -85,6 +85,26 @@ def cpu_baseline(args, seed):
                       % (args.cpu_sample, spans, dt)}
 
 
+def ingest_rate(n_traces=3000, threads=8):
+    """Host side of the chain, informational: Jaeger JSON files -> service units through the native
+    loader (tw_corpus_*), files in the page cache.  Not part of `value` (whose inputs are resident in HBM)."""
+    import tempfile
+
+    from traceweaver_amd import synth
+    from traceweaver_amd.ingest import Corpus
+
+    with tempfile.TemporaryDirectory() as d:
+        paths = synth.write_jaeger_corpus(d, 3, n_traces, app=synth.HOTEL_APP)
+        c = Corpus()
+        t0 = time.perf_counter()
+        counts = c.add_files(paths, first_span=None, max_traces=0, threads=threads)
+        units, _, _ = c.units()
+        dt = time.perf_counter() - t0
+        c.close()
+    return {"value": counts["spans"] / dt, "unit": "spans/s", "threads": threads, "traces": n_traces, "services": len(units),
+            "what": "Jaeger JSON (one trace per file) -> span table -> per-service SoA units, native loader"}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -179,6 +199,7 @@ def main():
         }
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args, 1000)
+            out["ingest"] = ingest_rate()
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
