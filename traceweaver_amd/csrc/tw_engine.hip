@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -42,6 +43,12 @@ struct tw_engine {
     std::vector<TileDev> tiles;
     std::vector<int64_t> gs_off_h;
     std::vector<void*> allocs;
+    // the arrays of a batch live in one device allocation that is kept (and grown) across tw_load_batch calls:
+    // ~60 hipMalloc / hipFree pairs per batch otherwise cost as much as the transfer itself
+    void* arena = nullptr;
+    size_t arena_cap = 0;
+    bool arena_open = false;
+    std::vector<std::pair<std::function<void(void*)>, size_t>> arena_req;
     Dev P{};
     int64_t n_ie = 0, n_gp = 0, n_slots = 0, n_gaps = 0;
     // scratch for scans / sort
@@ -94,11 +101,33 @@ int fail(tw_engine* e, int code, const std::string& msg) {
 
 template <class T>
 int dev_alloc(tw_engine* e, T** p, int64_t count) {
-    void* q = nullptr;
     const size_t bytes = (size_t)std::max<int64_t>(count, 1) * sizeof(T);
+    if (e->arena_open) {  // tw_load_batch: collected, placed by arena_commit
+        *p = nullptr;
+        e->arena_req.emplace_back([p](void* q) { *p = (T*)q; }, (bytes + 255) / 256 * 256);
+        return TW_OK;
+    }
+    void* q = nullptr;
     HIPCHK(hipMalloc(&q, bytes));
     e->allocs.push_back(q);
     *p = (T*)q;
+    return TW_OK;
+}
+
+int arena_commit(tw_engine* e) {
+    e->arena_open = false;
+    size_t total = 0;
+    for (const auto& r : e->arena_req) total += r.second;
+    if (total > e->arena_cap) {
+        if (e->arena != nullptr) (void)hipFree(e->arena);
+        e->arena = nullptr;
+        e->arena_cap = 0;
+        HIPCHK(hipMalloc(&e->arena, total));
+        e->arena_cap = total;
+    }
+    size_t off = 0;
+    for (const auto& r : e->arena_req) { r.first((char*)e->arena + off); off += r.second; }
+    e->arena_req.clear();
     return TW_OK;
 }
 
@@ -309,6 +338,7 @@ void tw_destroy(tw_engine* e) {
     if (e == nullptr) return;
     (void)hipSetDevice(e->device);
     free_all(e);
+    if (e->arena != nullptr) (void)hipFree(e->arena);
     for (int i = 0; i < EV_COUNT; i++)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -444,6 +474,8 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     P.batch_mis = b->batch_size_mis;
     int rc;
 #define ALLOC(ptr, count) do { rc = dev_alloc(e, &(ptr), (count)); if (rc != TW_OK) return rc; } while (0)
+    e->arena_req.clear();
+    e->arena_open = true;
     UnitDev* d_units; TileDev* d_tiles; int64_t *d_is, *d_ie, *d_os, *d_oe, *d_gs;
     ALLOC(d_units, P.n_units); ALLOC(d_tiles, P.n_tiles);
     ALLOC(d_is, n_in_total); ALLOC(d_ie, n_in_total); ALLOC(d_os, n_out_total); ALLOC(d_oe, n_out_total);
@@ -466,8 +498,6 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.heavy_in_count, 2 * (kMaxEp + 1)); ALLOC(P.heavy_in_next, 2 * (kMaxEp + 1)); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
     ALLOC(P.prof, 16); ALLOC(e->key_acc, 2);
-    HIPCHK(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 16, e->stream));
-    HIPCHK(hipMemsetAsync(P.prof + 10, 0xff, sizeof(unsigned long long), e->stream));
     ALLOC(P.heavy_count, 3); ALLOC(P.heavy_next, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
@@ -478,6 +508,10 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     e->comp_cap = std::max(std::max(n_in_total, n_out_total), e->n_gap_scored);
     ALLOC(e->comp_a, e->comp_cap); ALLOC(e->comp_b, e->comp_cap);
 #undef ALLOC
+    rc = arena_commit(e);
+    if (rc != TW_OK) return rc;
+    HIPCHK(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 16, e->stream));
+    HIPCHK(hipMemsetAsync(P.prof + 10, 0xff, sizeof(unsigned long long), e->stream));
     P.units = d_units; P.tiles = d_tiles;
     P.in_start = d_is; P.in_end = d_ie; P.out_start = d_os; P.out_end = d_oe;
     P.gs_off = d_gs;
@@ -501,6 +535,9 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipMemcpyAsync(e->slot_scored, slot_scored_h.data(), slot_scored_h.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemsetAsync(P.gaps, 0xff, sizeof(double) * std::max<int64_t>(gaps, 1), e->stream));  // all-ones = NaN: rows of unscored slots
     HIPCHK(hipMemsetAsync(P.pc, 0, (size_t)n_in_total + 1, e->stream));
+    // top-5 lists: all-ones = index -1 / score NaN; the enumeration kernels write only the entries a span has
+    HIPCHK(hipMemsetAsync(P.tk_idx, 0xff, sizeof(int32_t) * (size_t)std::max<int64_t>(ie * kTopK, 1), e->stream));
+    HIPCHK(hipMemsetAsync(P.tk_score, 0xff, sizeof(double) * (size_t)std::max<int64_t>(n_in_total * kTopK, 1), e->stream));
     HIPCHK(hipMemsetAsync(e->mix_n_dev, 0, sizeof(int32_t) * std::max<int64_t>(slots, 1), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     {   // end times of one batch share their upper bits: the sorts of run_pass only look at the bits that differ.

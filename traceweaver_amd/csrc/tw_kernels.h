@@ -500,9 +500,10 @@ __device__ void write_result(const Dev& P, const UnitDev& U, int i, int pass, co
     P.rep[g] = 0;
 #pragma unroll
     for (int k = 0; k < kTopK; k++) {
-        P.tk_score[tks_index(U, k, i)] = k < en.nheap ? en.heap[k].score : dnan();
+        if (k >= en.nheap) continue;  // unused entries keep the -1 / NaN pattern they were given at load time
+        P.tk_score[tks_index(U, k, i)] = en.heap[k].score;
 #pragma unroll
-        for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, i)] = k < en.nheap ? en.heap[k].idx[e] : -1;
+        for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, i)] = en.heap[k].idx[e];
     }
     if (pass == 1) {
 #pragma unroll
@@ -797,9 +798,13 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
     P.rep[g] = 0;
 #pragma unroll
     for (int k = 0; k < kTopK; k++) {
-        P.tk_score[tks_index(U, k, i)] = k < c.nk ? c.ts[k] : dnan();
+        // a span's list has min(5, feasible tuples) entries in every pass; the unused entries keep the -1 / NaN
+        // pattern of tw_load_batch and are never written (most lists are short: this halves the store traffic)
+        if (k < c.nk) {
+            P.tk_score[tks_index(U, k, i)] = c.ts[k];
 #pragma unroll
-        for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, i)] = k < c.nk ? c.tidx[k][e] : -1;
+            for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, i)] = c.tidx[k][e];
+        }
     }
     if (pass == 1) {
 #pragma unroll
@@ -1282,8 +1287,9 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             if (t == 0) { P.tk_n[g] = nout; P.leaves[g] = leaves; P.rep[g] = 0; }
             for (int q = t; q < kTopK * (E + 1); q += nt) {
                 const int k = q / (E + 1), f = q % (E + 1);
-                if (f == E) P.tk_score[tks_index(U, k, i)] = k < nout ? sheap[k].score : dnan();
-                else P.tk_idx[tk_index(U, k, f, i)] = k < nout ? sheap[k].idx[f] : -1;
+                if (k >= nout) continue;  // unused entries keep the -1 / NaN pattern they were given at load time
+                if (f == E) P.tk_score[tks_index(U, k, i)] = sheap[k].score;
+                else P.tk_idx[tk_index(U, k, f, i)] = sheap[k].idx[f];
             }
             if (pass == 1) {
                 for (int q = t; q < E * (kCandWords + 1); q += nt) {
