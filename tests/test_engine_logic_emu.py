@@ -104,3 +104,31 @@ def test_window_width_limit_is_reported(emu_lib):
         eng.run_pass1()
     assert ei.value.code == -5
     eng.close()
+
+
+def test_engine_reuse_across_batches_of_different_size(emu_lib):
+    """One engine, several tw_load_batch calls (the device arena is kept and grown): results must not depend on
+    what was loaded before."""
+    from traceweaver_amd import synth
+    from traceweaver_amd.engine import Engine
+
+    small, _ = parity.stress_units([(51, 120, "par2", 2, 1)])
+    big, _ = parity.stress_units([(52, 700, "chain3", 3, 1), (53, 500, "par4", 1.5, 1000)])
+
+    def solve(eng, units):
+        eng.load(units)
+        eng.run_pass1()
+        eng.fit_mixtures()
+        eng.run_pass2()
+        return eng.results(2)
+
+    fresh_small = solve(Engine(0, lib_path=emu_lib), small)
+    fresh_big = solve(Engine(0, lib_path=emu_lib), big)
+    eng = Engine(0, lib_path=emu_lib)
+    for units, want in ((small, fresh_small), (big, fresh_big), (small, fresh_small), (big, fresh_big)):
+        got = solve(eng, units)
+        for g, w in zip(got, want):
+            for key in ("parent", "topk_idx", "chosen", "leaves", "window_end", "topk_n"):
+                assert np.array_equal(g[key], w[key]), key
+            assert np.array_equal(g["topk_score"], w["topk_score"], equal_nan=True)
+    eng.close()
