@@ -132,3 +132,32 @@ def test_engine_reuse_across_batches_of_different_size(emu_lib):
                 assert np.array_equal(g[key], w[key]), key
             assert np.array_equal(g["topk_score"], w["topk_score"], equal_nan=True)
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_units_match_oracle(emu_lib, seed):
+    """Randomised sweep over shapes, load, timestamp granularity and sizes (including sizes around the tile / block
+    boundaries): every unit bit-identical to the oracle in both passes."""
+    rng = np.random.default_rng(1000 + seed)
+    shapes = list(synth_shapes())
+    cases = []
+    for k in range(7):
+        shape = shapes[int(rng.integers(len(shapes)))]
+        n = int(rng.choice([2, 3, 57, 99, 100, 127, 128, 129, 200, 255, 256, 257, 301, 402]))
+        n += 1 if n % 100 == 1 else 0                       # a last block of one request has no variance (hazard H3)
+        wide = len({e for st in synth_shape(shape) for e in st}) >= 6
+        conc = float(rng.choice([1.1, 1.5, 2.5] if wide else [1.1, 2.0, 4.0, 7.0, 11.0]))   # wide fan-outs: bounded candidate products
+        gran = int(rng.choice([1, 1, 1000]))
+        cases.append((seed * 100 + k, n, shape, conc, gran))
+    units, _ = parity.stress_units(cases)
+    parity.check_units(emu_lib, units)
+
+
+def synth_shapes():
+    from traceweaver_amd import synth
+    return synth.SHAPES.keys()
+
+
+def synth_shape(name):
+    from traceweaver_amd import synth
+    return synth.SHAPES[name]
