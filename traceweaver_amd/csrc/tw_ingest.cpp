@@ -367,8 +367,8 @@ bool fix_reroot(TraceTmp& T, const std::string& root_op) {
             if (a.s.refs.empty()) break;
             up = a.s.refs[0].second;
         }
-        for (int j = 0; j < n0; j++) {                               // ChangeChildReferences (looks at the original spans)
-            const SpanTmp& o = T.spans[(size_t)j];
+        for (size_t j = 0; j < T.spans.size(); j++) {                // ChangeChildReferences (looks at the original spans)
+            const SpanTmp& o = T.spans[j];
             if (!o.refs.empty() && o.refs[0].second == old_key && o.refs[0].first == T.trace_id) {
                 auto it = at.find(o.sid);
                 if (it == at.end()) return false;
