@@ -29,30 +29,16 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// Minimal JSON reader (RFC 8259 values; numbers keep an exact int64 when they are integers).
-struct JVal {
-    enum Type { Null, Bool, Num, Str, Arr, Obj } type = Null;
-    bool b = false, is_int = false;
-    int64_t i = 0;
-    double d = 0.0;
-    std::string s;
-    std::vector<JVal> arr;
-    std::vector<std::pair<std::string, JVal>> obj;
-    const JVal* get(const char* key) const {
-        if (type != Obj) return nullptr;
-        for (const auto& kv : obj)
-            if (kv.first == key) return &kv.second;
-        return nullptr;
-    }
-};
-
-struct JParser {
+// JSON scanner (RFC 8259): no document tree -- the loader walks the text once, copies out the handful of fields it
+// needs and skips everything else (tags it does not read, logs, warnings) without allocating.
+struct Scan {
     const char* p;
     const char* end;
     std::string err;
-    int depth = 0;
     bool fail(const char* m) { if (err.empty()) err = m; return false; }
     void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+    bool eat(char c) { ws(); if (p < end && *p == c) { p++; return true; } return false; }
+    bool expect(char c, const char* m) { return eat(c) ? true : fail(m); }
     static void utf8(std::string& out, unsigned cp) {
         if (cp < 0x80) out.push_back((char)cp);
         else if (cp < 0x800) { out.push_back((char)(0xC0 | (cp >> 6))); out.push_back((char)(0x80 | (cp & 0x3F))); }
@@ -72,110 +58,114 @@ struct JParser {
         }
         return true;
     }
-    bool str(std::string& out) {
+    // a string value; `out` == nullptr just skips it
+    bool str(std::string* out) {
+        ws();
         if (p >= end || *p != '"') return fail("expected string");
         p++;
-        out.clear();
-        while (p < end && *p != '"') {
-            if (*p == '\\') {
-                p++;
-                if (p >= end) return fail("truncated escape");
-                const char c = *p++;
-                switch (c) {
-                    case '"': out.push_back('"'); break;
-                    case '\\': out.push_back('\\'); break;
-                    case '/': out.push_back('/'); break;
-                    case 'b': out.push_back('\b'); break;
-                    case 'f': out.push_back('\f'); break;
-                    case 'n': out.push_back('\n'); break;
-                    case 'r': out.push_back('\r'); break;
-                    case 't': out.push_back('\t'); break;
-                    case 'u': {
-                        unsigned cp;
-                        if (!hex4(cp)) return false;
-                        if (cp >= 0xD800 && cp < 0xDC00 && end - p >= 6 && p[0] == '\\' && p[1] == 'u') {
-                            p += 2;
-                            unsigned lo;
-                            if (!hex4(lo)) return false;
-                            cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
-                        }
-                        utf8(out, cp);
-                        break;
+        if (out) out->clear();
+        while (true) {
+            const char* q = p;
+            while (q < end && *q != '"' && *q != '\\') q++;   // plain run
+            if (q >= end) return fail("unterminated string");
+            if (out) out->append(p, q);
+            p = q;
+            if (*p == '"') { p++; return true; }
+            p++;  // backslash
+            if (p >= end) return fail("truncated escape");
+            const char c = *p++;
+            char lit = 0;
+            switch (c) {
+                case '"': lit = '"'; break;
+                case '\\': lit = '\\'; break;
+                case '/': lit = '/'; break;
+                case 'b': lit = '\b'; break;
+                case 'f': lit = '\f'; break;
+                case 'n': lit = '\n'; break;
+                case 'r': lit = '\r'; break;
+                case 't': lit = '\t'; break;
+                case 'u': {
+                    unsigned cp;
+                    if (!hex4(cp)) return false;
+                    if (cp >= 0xD800 && cp < 0xDC00 && end - p >= 6 && p[0] == '\\' && p[1] == 'u') {
+                        p += 2;
+                        unsigned lo;
+                        if (!hex4(lo)) return false;
+                        cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
                     }
-                    default: return fail("bad escape");
+                    if (out) utf8(*out, cp);
+                    continue;
                 }
-            } else out.push_back(*p++);
+                default: return fail("bad escape");
+            }
+            if (out) out->push_back(lit);
         }
-        if (p >= end) return fail("unterminated string");
-        p++;
+    }
+    // a number as int64 (exact when it is written as an integer, truncated toward zero otherwise)
+    bool i64(int64_t& out) {
+        ws();
+        const char* q = p;
+        bool integral = true;
+        if (q < end && *q == '-') q++;
+        if (q >= end || *q < '0' || *q > '9') return fail("expected number");
+        while (q < end && *q >= '0' && *q <= '9') q++;
+        if (q < end && (*q == '.' || *q == 'e' || *q == 'E')) {
+            integral = false;
+            while (q < end && ((*q >= '0' && *q <= '9') || *q == '.' || *q == 'e' || *q == 'E' || *q == '+' || *q == '-')) q++;
+        }
+        const std::string tok(p, q);
+        out = (integral && tok.size() <= 19) ? strtoll(tok.c_str(), nullptr, 10) : (int64_t)strtod(tok.c_str(), nullptr);
+        p = q;
         return true;
     }
-    bool value(JVal& v) {
+    bool skip(int depth = 0) {  // any value
         ws();
         if (p >= end) return fail("unexpected end of input");
-        if (++depth > 256) return fail("nesting too deep");
-        bool ok = true;
+        if (depth > 256) return fail("nesting too deep");
         const char c = *p;
-        if (c == '{') {
-            v.type = JVal::Obj;
+        if (c == '"') return str(nullptr);
+        if (c == '{' || c == '[') {
+            const char close = c == '{' ? '}' : ']';
             p++;
-            ws();
-            if (p < end && *p == '}') p++;
-            else {
-                while (ok) {
-                    ws();
-                    std::string key;
-                    if (!str(key)) { ok = false; break; }
-                    ws();
-                    if (p >= end || *p != ':') { ok = fail("expected ':'"); break; }
-                    p++;
-                    v.obj.emplace_back(std::move(key), JVal());
-                    if (!value(v.obj.back().second)) { ok = false; break; }
-                    ws();
-                    if (p < end && *p == ',') { p++; continue; }
-                    if (p < end && *p == '}') { p++; break; }
-                    ok = fail("expected ',' or '}'");
-                }
+            if (eat(close)) return true;
+            while (true) {
+                if (c == '{') { if (!str(nullptr) || !expect(':', "expected ':'")) return false; }
+                if (!skip(depth + 1)) return false;
+                if (eat(',')) continue;
+                return expect(close, c == '{' ? "expected ',' or '}'" : "expected ',' or ']'");
             }
-        } else if (c == '[') {
-            v.type = JVal::Arr;
-            p++;
-            ws();
-            if (p < end && *p == ']') p++;
-            else {
-                while (ok) {
-                    v.arr.emplace_back();
-                    if (!value(v.arr.back())) { ok = false; break; }
-                    ws();
-                    if (p < end && *p == ',') { p++; continue; }
-                    if (p < end && *p == ']') { p++; break; }
-                    ok = fail("expected ',' or ']'");
-                }
-            }
-        } else if (c == '"') {
-            v.type = JVal::Str;
-            ok = str(v.s);
-        } else if (c == 't' && end - p >= 4 && !memcmp(p, "true", 4)) { v.type = JVal::Bool; v.b = true; p += 4; }
-        else if (c == 'f' && end - p >= 5 && !memcmp(p, "false", 5)) { v.type = JVal::Bool; v.b = false; p += 5; }
-        else if (c == 'n' && end - p >= 4 && !memcmp(p, "null", 4)) { v.type = JVal::Null; p += 4; }
-        else if (c == '-' || (c >= '0' && c <= '9')) {
-            const char* q = p;
-            bool integral = true;
-            if (*q == '-') q++;
-            while (q < end && *q >= '0' && *q <= '9') q++;
-            if (q < end && (*q == '.' || *q == 'e' || *q == 'E')) {
-                integral = false;
-                while (q < end && ((*q >= '0' && *q <= '9') || *q == '.' || *q == 'e' || *q == 'E' || *q == '+' || *q == '-')) q++;
-            }
-            const std::string tok(p, q);
-            v.type = JVal::Num;
-            v.d = strtod(tok.c_str(), nullptr);
-            if (integral && tok.size() <= 19) { v.is_int = true; v.i = strtoll(tok.c_str(), nullptr, 10); }
-            p = q;
-        } else ok = fail("unexpected character");
-        depth--;
-        return ok;
+        }
+        if (c == 't' && end - p >= 4 && !memcmp(p, "true", 4)) { p += 4; return true; }
+        if (c == 'f' && end - p >= 5 && !memcmp(p, "false", 5)) { p += 5; return true; }
+        if (c == 'n' && end - p >= 4 && !memcmp(p, "null", 4)) { p += 4; return true; }
+        int64_t dummy;
+        if (c == '-' || (c >= '0' && c <= '9')) return i64(dummy);
+        return fail("unexpected character");
     }
+    // for (auto key : object): calls f(key) positioned at the value; f must consume the value
+    template <class F>
+    bool object(F&& f) {
+        if (!expect('{', "expected object")) return false;
+        if (eat('}')) return true;
+        std::string key;
+        while (true) {
+            if (!str(&key) || !expect(':', "expected ':'")) return false;
+            if (!f(key)) return false;
+            if (eat(',')) continue;
+            return expect('}', "expected ',' or '}'");
+        }
+    }
+    template <class F>
+    bool array(F&& f) {  // f() consumes one element
+        if (!expect('[', "expected array")) return false;
+        if (eat(']')) return true;
+        while (true) {
+            if (!f()) return false;
+            if (eat(',')) continue;
+            return expect(']', "expected ',' or ']'");
+        }
+    }
+    bool is_string() { ws(); return p < end && *p == '"'; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -195,62 +185,120 @@ struct TraceTmp {
     bool has_root = false;
 };
 
-bool number_i64(const JVal* v, int64_t& out) {
-    if (v == nullptr || v->type != JVal::Num) return false;
-    out = v->is_int ? v->i : (int64_t)v->d;
-    return true;
-}
-
 // ParseJsonTrace + ParseSpansJson (executor.py:342-384,755-793): one trace per file
 void parse_trace(const char* buf, size_t len, TraceTmp& T) {
-    JParser P{buf, buf + len, std::string(), 0};
-    JVal root;
-    if (!P.value(root)) { T.error = "JSON: " + P.err; return; }
-    const JVal* data = root.get("data");
-    if (data == nullptr || data->type != JVal::Arr || data->arr.size() != 1) { T.error = "expected exactly one trace under \"data\""; return; }
-    const JVal& d = data->arr[0];
-    const JVal* tid = d.get("traceID");
-    const JVal* spans = d.get("spans");
-    if (tid == nullptr || tid->type != JVal::Str || spans == nullptr || spans->type != JVal::Arr || spans->arr.empty()) { T.error = "trace without traceID / spans"; return; }
-    T.trace_id = tid->s;
-    T.request_type = spans->arr[0].get("requestType") != nullptr;  // executor.py:774
-    for (const JVal& s : spans->arr) {
-        SpanTmp sp;
-        const JVal *sid = s.get("spanID"), *stid = s.get("traceID"), *pid = s.get("processID"), *tags = s.get("tags"), *refs = s.get("references");
-        if (sid == nullptr || sid->type != JVal::Str || pid == nullptr || pid->type != JVal::Str) { T.error = "span without spanID / processID"; return; }
-        if (stid == nullptr || stid->type != JVal::Str || stid->s != T.trace_id) { T.error = "different trace ids for spans in the same trace"; return; }  // executor.py:367-372
-        sp.sid = sid->s;
-        sp.pid = pid->s;
-        if (!number_i64(s.get("startTime"), sp.start) || !number_i64(s.get("duration"), sp.dur)) { T.error = "span without startTime / duration"; return; }
-        const JVal* op = s.get("requestType");
-        if (op == nullptr) op = s.get("operationName");
-        if (op != nullptr && op->type == JVal::Str) sp.op = op->s;
-        if (tags != nullptr && tags->type == JVal::Arr)
-            for (const JVal& t : tags->arr) {
-                const JVal *k = t.get("key"), *v = t.get("value");
-                if (k != nullptr && k->type == JVal::Str && k->s == "span.kind" && v != nullptr && v->type == JVal::Str)
-                    sp.kind = v->s == "server" ? 1 : (v->s == "client" ? 2 : 3);
-            }
-        if (refs != nullptr && refs->type == JVal::Arr)
-            for (const JVal& r : refs->arr) {
-                const JVal *rt = r.get("traceID"), *rs = r.get("spanID");
-                if (rt == nullptr || rs == nullptr || rt->type != JVal::Str || rs->type != JVal::Str) { T.error = "malformed reference"; return; }
-                sp.refs.emplace_back(rt->s, rs->s);
-            }
-        if (sp.refs.empty() && !T.has_root) { T.has_root = true; T.root_start = (double)sp.start; }  // first span without references
-        T.spans.push_back(std::move(sp));
-    }
+    Scan S{buf, buf + len, std::string()};
+    int n_traces = 0;
+    bool have_tid = false, have_spans = false, have_procs = false, bad_span = false, first_span = true;
+    std::string why, key_s, val_s;
+    std::vector<std::string> span_tids;  // the traceID key of the trace may come after its spans in the text
+    const bool ok = S.object([&](const std::string& k0) {
+        if (k0 != "data") return S.skip();
+        return S.array([&]() {
+            if (++n_traces > 1) return S.skip();
+            return S.object([&](const std::string& k1) {
+                if (k1 == "traceID") { have_tid = S.is_string(); return have_tid ? S.str(&T.trace_id) : S.skip(); }
+                if (k1 == "processes") {
+                    S.ws();
+                    if (S.p >= S.end || *S.p != '{') return S.skip();
+                    have_procs = true;
+                    return S.object([&](const std::string& pid) {
+                        std::string name;
+                        bool named = false;
+                        S.ws();
+                        if (S.p >= S.end || *S.p != '{') { if (why.empty()) why = "process without serviceName"; bad_span = true; return S.skip(); }
+                        if (!S.object([&](const std::string& k3) {
+                                if (k3 == "serviceName" && S.is_string() && !named) { named = true; return S.str(&name); }
+                                return S.skip();
+                            })) return false;
+                        if (!named) { if (why.empty()) why = "process without serviceName"; bad_span = true; }
+                        T.processes.emplace_back(pid, name);
+                        return true;
+                    });
+                }
+                if (k1 != "spans") return S.skip();
+                S.ws();
+                if (S.p >= S.end || *S.p != '[') return S.skip();
+                have_spans = true;
+                return S.array([&]() {
+                    SpanTmp sp;
+                    std::string stid, req;
+                    bool has_sid = false, has_pid = false, has_tid = false, has_start = false, has_dur = false, has_op = false, has_req = false;
+                    S.ws();
+                    if (S.p >= S.end || *S.p != '{') { bad_span = true; if (why.empty()) why = "span without spanID / processID"; return S.skip(); }
+                    if (!S.object([&](const std::string& k2) {
+                            if (k2 == "spanID" && S.is_string() && !has_sid) { has_sid = true; return S.str(&sp.sid); }
+                            if (k2 == "processID" && S.is_string() && !has_pid) { has_pid = true; return S.str(&sp.pid); }
+                            if (k2 == "traceID" && S.is_string() && !has_tid) { has_tid = true; return S.str(&stid); }
+                            if (k2 == "operationName" && !has_op) { has_op = true; return S.is_string() ? S.str(&sp.op) : S.skip(); }
+                            if (k2 == "requestType" && !has_req) { has_req = true; if (S.is_string()) return S.str(&req); req.clear(); return S.skip(); }
+                            if ((k2 == "startTime" && !has_start) || (k2 == "duration" && !has_dur)) {
+                                S.ws();
+                                const bool num = S.p < S.end && (*S.p == '-' || (*S.p >= '0' && *S.p <= '9'));
+                                if (!num) return S.skip();
+                                if (k2 == "startTime") { has_start = true; return S.i64(sp.start); }
+                                has_dur = true;
+                                return S.i64(sp.dur);
+                            }
+                            if (k2 == "tags") {
+                                S.ws();
+                                if (S.p >= S.end || *S.p != '[') return S.skip();
+                                return S.array([&]() {
+                                    S.ws();
+                                    if (S.p >= S.end || *S.p != '{') return S.skip();
+                                    bool is_kind = false, have_val = false;
+                                    if (!S.object([&](const std::string& k3) {
+                                            if (k3 == "key" && S.is_string()) { if (!S.str(&key_s)) return false; is_kind = key_s == "span.kind"; return true; }
+                                            if (k3 == "value" && S.is_string()) { have_val = true; return S.str(&val_s); }
+                                            return S.skip();
+                                        })) return false;
+                                    if (is_kind && have_val) sp.kind = val_s == "server" ? 1 : (val_s == "client" ? 2 : 3);
+                                    return true;
+                                });
+                            }
+                            if (k2 == "references") {
+                                S.ws();
+                                if (S.p >= S.end || *S.p != '[') return S.skip();
+                                return S.array([&]() {
+                                    std::string rt, rs;
+                                    bool hrt = false, hrs = false;
+                                    S.ws();
+                                    if (S.p >= S.end || *S.p != '{') { bad_span = true; if (why.empty()) why = "malformed reference"; return S.skip(); }
+                                    if (!S.object([&](const std::string& k3) {
+                                            if (k3 == "traceID" && S.is_string()) { hrt = true; return S.str(&rt); }
+                                            if (k3 == "spanID" && S.is_string()) { hrs = true; return S.str(&rs); }
+                                            return S.skip();
+                                        })) return false;
+                                    if (!hrt || !hrs) { bad_span = true; if (why.empty()) why = "malformed reference"; }
+                                    sp.refs.emplace_back(std::move(rt), std::move(rs));
+                                    return true;
+                                });
+                            }
+                            return S.skip();
+                        })) return false;
+                    if (!has_sid || !has_pid) { bad_span = true; if (why.empty()) why = "span without spanID / processID"; }
+                    else if (!has_tid) { bad_span = true; if (why.empty()) why = "different trace ids for spans in the same trace"; }  // executor.py:367-372
+                    else if (!has_start || !has_dur) { bad_span = true; if (why.empty()) why = "span without startTime / duration"; }
+                    if (has_req) sp.op = req;  // executor.py:358-361: requestType wins over operationName
+                    if (first_span) { T.request_type = has_req; first_span = false; }   // executor.py:774
+                    if (sp.refs.empty() && !T.has_root) { T.has_root = true; T.root_start = (double)sp.start; }  // first span without references
+                    T.spans.push_back(std::move(sp));
+                    span_tids.push_back(std::move(stid));
+                    return true;
+                });
+            });
+        });
+    });
+    if (!ok) { T.error = "JSON: " + S.err; return; }
+    if (n_traces != 1) { T.error = "expected exactly one trace under \"data\""; return; }
+    if (!have_tid || !have_spans || T.spans.empty()) { T.error = "trace without traceID / spans"; return; }
+    if (bad_span) { T.error = why; return; }
+    for (const std::string& t : span_tids)
+        if (t != T.trace_id) { T.error = "different trace ids for spans in the same trace"; return; }  // executor.py:367-372
     if (T.request_type) {  // ParseProcessesJson2: the process id is the service name
+        T.processes.clear();
         for (const SpanTmp& sp : T.spans) T.processes.emplace_back(sp.pid, sp.pid);
-    } else {
-        const JVal* procs = d.get("processes");
-        if (procs == nullptr || procs->type != JVal::Obj) { T.error = "trace without a process map"; return; }
-        for (const auto& kv : procs->obj) {
-            const JVal* name = kv.second.get("serviceName");
-            if (name == nullptr || name->type != JVal::Str) { T.error = "process without serviceName"; return; }
-            T.processes.emplace_back(kv.first, name->s);
-        }
-    }
+    } else if (!have_procs) { T.error = "trace without a process map"; return; }
     T.ok = true;
 }
 
@@ -421,9 +469,15 @@ bool fix_reroot(TraceTmp& T, const std::string& root_op) {
     return true;
 }
 
-// ProcessTraceData (executor.py:795-849) for one parsed trace; returns false (and leaves the corpus untouched)
-// when the trace breaks an assumption the reference asserts on.
-bool add_trace(tw_corpus* c, const TraceTmp& T, const std::string& first_span) {
+// ProcessTraceData (executor.py:795-849) for one parsed trace, in two steps: the walk (any thread, touches only the
+// trace) and the append to the corpus (one thread, in trace order).  walk_trace returns false (nothing is kept)
+// when the trace breaks an assumption the reference asserts on or its root is not `first_span`.
+struct Walked {
+    std::vector<int> order, parent, n_children;      // pre-order; per span (local index): parent, number of children
+    std::vector<std::string> service, child_service; // per span: its service, the service of its first child ("" = none)
+};
+
+bool walk_trace(const TraceTmp& T, const std::string& first_span, Walked& W) {
     const int n = (int)T.spans.size();
     std::unordered_map<std::string, int> by_sid;
     for (int i = 0; i < n; i++) by_sid[T.spans[(size_t)i].sid] = i;  // later duplicates win, like the dict of the reference
@@ -431,7 +485,7 @@ bool add_trace(tw_corpus* c, const TraceTmp& T, const std::string& first_span) {
     for (const auto& kv : T.processes) proc[kv.first] = kv.second;
     int root = -1;
     std::vector<std::vector<int>> children((size_t)n);
-    std::vector<int> parent((size_t)n, -1);
+    W.parent.assign((size_t)n, -1);
     for (int i = 0; i < n; i++) {
         const SpanTmp& s = T.spans[(size_t)i];
         if (by_sid[s.sid] != i) continue;  // shadowed duplicate
@@ -441,43 +495,58 @@ bool add_trace(tw_corpus* c, const TraceTmp& T, const std::string& first_span) {
             if (r.first != T.trace_id || it == by_sid.end()) return false;  // spans[par_id] would raise
             children[(size_t)it->second].push_back(i);
         }
-        if (!s.refs.empty()) parent[(size_t)i] = by_sid[s.refs[0].second];
+        if (!s.refs.empty()) W.parent[(size_t)i] = by_sid[s.refs[0].second];
     }
     if (root < 0) return false;
     if (!first_span.empty() && T.spans[(size_t)root].op != first_span) return false;  // executor.py:841
     for (auto& ch : children)
         std::stable_sort(ch.begin(), ch.end(), [&](int a, int b) { return T.spans[(size_t)a].start < T.spans[(size_t)b].start; });
-    // pre-order walk; validate before touching the corpus
-    std::vector<int> order, stack{root};
+    std::vector<int> stack{root};
     std::vector<char> seen((size_t)n, 0);
+    W.order.clear();
+    W.n_children.assign((size_t)n, 0);
+    W.service.assign((size_t)n, std::string());
+    W.child_service.assign((size_t)n, std::string());
     while (!stack.empty()) {
         const int v = stack.back();
         stack.pop_back();
         if (seen[(size_t)v]) return false;  // a span referenced twice / a cycle
         seen[(size_t)v] = 1;
-        order.push_back(v);
+        W.order.push_back(v);
         const SpanTmp& s = T.spans[(size_t)v];
         if (s.kind != 1 && s.kind != 2) return false;                 // AddSpanToProcess asserts on other kinds
-        if (proc.find(s.pid) == proc.end()) return false;
+        auto pit = proc.find(s.pid);
+        if (pit == proc.end()) return false;
         if (s.kind == 2 && children[(size_t)v].size() != 1) return false;   // GetChildProcess asserts one child
         if (v != root && s.refs.size() != 1) return false;            // GetParentProcess asserts one reference
+        W.service[(size_t)v] = pit->second;
+        W.n_children[(size_t)v] = (int)children[(size_t)v].size();
+        if (!children[(size_t)v].empty()) {
+            auto cit = proc.find(T.spans[(size_t)children[(size_t)v][0]].pid);
+            if (cit != proc.end()) W.child_service[(size_t)v] = cit->second;
+        }
         for (size_t k = children[(size_t)v].size(); k-- > 0;) stack.push_back(children[(size_t)v][k]);
     }
+    return true;
+}
+
+void append_trace(tw_corpus* c, const TraceTmp& T, const Walked& W) {
     const int32_t trace_no = (int32_t)c->trace_name.size();
     c->trace_name.push_back(c->intern(T.trace_id));
-    std::vector<int32_t> row_of((size_t)n, -1);
+    std::vector<int32_t> row_of(T.spans.size(), -1);
     const int32_t base = (int32_t)c->rows.size();
-    for (size_t k = 0; k < order.size(); k++) row_of[(size_t)order[k]] = base + (int32_t)k;
-    for (int v : order) {
+    for (size_t k = 0; k < W.order.size(); k++) row_of[(size_t)W.order[k]] = base + (int32_t)k;
+    for (int v : W.order) {
         const SpanTmp& s = T.spans[(size_t)v];
         SpanRow r;
         r.trace = trace_no;
-        r.sid = c->intern(s.sid);
-        r.service = c->intern(proc[s.pid]);
+        r.sid = (int32_t)c->strings.size();   // span ids are unique per trace: stored, not looked up
+        c->strings.push_back(s.sid);
+        r.service = c->intern(W.service[(size_t)v]);
         r.op = c->intern(s.op);
-        r.parent = parent[(size_t)v] >= 0 ? row_of[(size_t)parent[(size_t)v]] : -1;
-        r.n_children = (int32_t)children[(size_t)v].size();
-        r.first_child_service = r.n_children > 0 ? c->intern(proc[T.spans[(size_t)children[(size_t)v][0]].pid]) : -1;
+        r.parent = W.parent[(size_t)v] >= 0 ? row_of[(size_t)W.parent[(size_t)v]] : -1;
+        r.n_children = W.n_children[(size_t)v];
+        r.first_child_service = r.n_children > 0 ? c->intern(W.child_service[(size_t)v]) : -1;
         r.start = s.start;
         r.dur = s.dur;
         r.kind = (uint8_t)s.kind;
@@ -488,7 +557,6 @@ bool add_trace(tw_corpus* c, const TraceTmp& T, const std::string& first_span) {
             c->out_rows[r.service].push_back(row);
         } else c->in_rows[r.service].push_back(row);
     }
-    return true;
 }
 
 }  // namespace
@@ -514,12 +582,21 @@ int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths,
                         int32_t n_threads, int32_t fix) {
     if (c == nullptr || (n_paths > 0 && paths == nullptr) || n_paths < 0 || fix < 0 || fix > 2) return TW_ERR_ARG;
     std::vector<TraceTmp> parsed((size_t)n_paths);
+    std::vector<Walked> walked((size_t)n_paths);
+    std::vector<char> usable((size_t)n_paths, 0);
+    const std::string fs = first_span ? first_span : "";
     std::atomic<int> next(0);
-    auto work = [&]() {
+    auto work = [&]() {  // everything that touches one trace only: read, parse, span surgery, walk
         std::string buf;
         for (int i = next.fetch_add(1); i < n_paths; i = next.fetch_add(1)) {
-            if (!read_file(paths[i], buf)) { parsed[(size_t)i].error = "cannot read file"; continue; }
-            parse_trace(buf.data(), buf.size(), parsed[(size_t)i]);
+            TraceTmp& T = parsed[(size_t)i];
+            if (!read_file(paths[i], buf)) { T.error = "cannot read file"; continue; }
+            parse_trace(buf.data(), buf.size(), T);
+            if (!T.ok) continue;
+            bool ok = true;
+            if (fix == TW_FIX_CLIENT_TWINS) ok = fix_client_twins(T, c->caller_of);
+            else if (fix == TW_FIX_REROOT) ok = fix_reroot(T, fs);
+            usable[(size_t)i] = ok && walk_trace(T, fs, walked[(size_t)i]);
         }
     };
     // <= 0: up to 16 parser threads, one per ~64 files (measured on the 256-thread host: 1 thread 0.4 M spans/s, 8 threads 1.0 M, 256 threads 0.13 M)
@@ -538,7 +615,6 @@ int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths,
         if (ra != rb) return ra;
         return ra && A.root_start < B.root_start;
     });
-    const std::string fs = first_span ? first_span : "";
     int64_t accepted = (int64_t)c->trace_name.size();
     for (int i = 0; i < n_paths; i++) {  // parse failures are reported whether or not the trace limit is reached first
         c->files_total++;
@@ -547,12 +623,9 @@ int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths,
         if (c->err.empty()) c->err = std::string(paths[i]) + ": " + parsed[(size_t)i].error;
     }
     for (int i : idx) {
-        TraceTmp& T = parsed[(size_t)i];
+        const TraceTmp& T = parsed[(size_t)i];
         if (!T.ok) continue;
-        bool ok = true;
-        if (fix == TW_FIX_CLIENT_TWINS) ok = fix_client_twins(T, c->caller_of);
-        else if (fix == TW_FIX_REROOT) ok = fix_reroot(T, fs);
-        if (ok && add_trace(c, T, fs)) accepted++; else c->traces_filtered++;
+        if (usable[(size_t)i]) { append_trace(c, T, walked[(size_t)i]); accepted++; } else c->traces_filtered++;
         if (max_traces > 0 && accepted >= max_traces) break;  // executor.py:873 stops after 1001 accepted traces
     }
     return TW_OK;
