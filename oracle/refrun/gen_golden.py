@@ -53,6 +53,11 @@ DATASETS = [
     ("nodeio_1", "data/nodejs_microservices_with_arbitrary_file_io/node_1/", 0),
     ("nodeio_0.6", "data/nodejs_microservices_with_arbitrary_file_io/node_0.6/", 0),
     ("node_load150", "data/nodejs_microservices/node_load150/", 0),
+    # lighter load levels of the same applications
+    ("hotel_load50", "data/hotel_reservation/hotel_load50/", 2),
+    ("media_load50", "data/media_microservices/media_load50/", 1),
+    ("node_load100", "data/nodejs_microservices/node_load100/", 0),
+    ("nodeio_0.2", "data/nodejs_microservices_with_arbitrary_file_io/node_0.2/", 0),
 ]
 
 

@@ -133,6 +133,9 @@ REFERENCE_CORPORA = [
     ("nodeio_1", "nodejs_microservices_with_arbitrary_file_io/node_1", 0),
     ("nodeio_0.6", "nodejs_microservices_with_arbitrary_file_io/node_0.6", 0),
     ("node_load150", "nodejs_microservices/node_load150", 0),
+    ("hotel_load50", "hotel_reservation/hotel_load50", 2), ("media_load50", "media_microservices/media_load50", 1),
+    ("node_load100", "nodejs_microservices/node_load100", 0),
+    ("nodeio_0.2", "nodejs_microservices_with_arbitrary_file_io/node_0.2", 0),
 ]
 
 
