@@ -136,6 +136,14 @@ REFERENCE_CORPORA = [
     ("hotel_load50", "hotel_reservation/hotel_load50", 2), ("media_load50", "media_microservices/media_load50", 1),
     ("node_load100", "nodejs_microservices/node_load100", 0),
     ("nodeio_0.2", "nodejs_microservices_with_arbitrary_file_io/node_0.2", 0),
+    ("hotel_load25", "hotel_reservation/hotel_load25", 2), ("hotel_load75", "hotel_reservation/hotel_load75", 2),
+    ("hotel_load125", "hotel_reservation/hotel_load125", 2),
+    ("media_load25", "media_microservices/media_load25", 1), ("media_load125", "media_microservices/media_load125", 1),
+    ("node_load25", "nodejs_microservices/node_load25", 0), ("node_load50", "nodejs_microservices/node_load50", 0),
+    ("node_load75", "nodejs_microservices/node_load75", 0), ("node_load125", "nodejs_microservices/node_load125", 0),
+    ("nodeio_0", "nodejs_microservices_with_arbitrary_file_io/node_0", 0),
+    ("nodeio_0.4", "nodejs_microservices_with_arbitrary_file_io/node_0.4", 0),
+    ("nodeio_0.8", "nodejs_microservices_with_arbitrary_file_io/node_0.8", 0),
 ]
 
 
