@@ -64,6 +64,21 @@ def test_corpora_that_need_span_surgery(emu_lib, tmp_path, name, rel, fix, n_ser
     assert abs(got["accuracy"]["MaxScoreBatchSubsetWithSkips"] - ref_e2e) < 3.0
 
 
+def _all_corpora():
+    from test_ingest import REFERENCE_CORPORA
+    return REFERENCE_CORPORA
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/data"), reason="the reference's data directory is not present")
+@pytest.mark.parametrize("name,rel,fix", _all_corpora(), ids=[c[0] for c in _all_corpora()])
+def test_end_to_end_accuracy_tracks_the_reference_on_every_corpus(emu_lib, tmp_path, name, rel, fix):
+    got = run_cli(tmp_path, emu_lib, "data/" + rel + "/", fix, name)
+    g = np.load([p for p in GOLDEN if "ref_%s__" % name in p][0])
+    method = "MaxScoreBatchSubsetWithSkips"
+    assert abs(got["accuracy"][method] - float(g["e2e_accuracy"])) < 3.5
+    assert abs(got["accuracy"][method + "TopK"] - float(g["e2e_topk_accuracy"])) < 1.5
+
+
 def test_unsupported_settings_are_refused(emu_lib, tmp_path):
     from traceweaver_amd import executor
 
