@@ -1,0 +1,105 @@
+"""The reference's simple baseline predictors on index arrays (executor.py:888-900 indices 4, 5, 7):
+
+    FCFS          algorithms/fcfs.py:10-26          request i takes the i-th call of every endpoint
+    ArrivalOrder  algorithms/arrival_order.py:13-65  first endpoint FCFS, later ones in the order the previous calls returned
+    vPath         algorithms/vpath.py:48-89          event sweep: a call belongs to the request that was last seen active
+
+They are host code in the reference (Python) and stay host code here (numpy); they exist so that
+`traceweaver_amd.executor` can serve the baseline columns of the reference's experiments next to the accelerated
+predictor.  Inputs: a `UnitArrays` (endpoints in topological order; `key_rank` gives the partition-key order the
+reference iterates in).  Output: parent [E, n_in] int32 in the unit's endpoint order, -1 = ("NA", "NA").
+WAP5 (algorithms/wap5.py, index 3) is not provided.
+"""
+import numpy as np
+
+
+def _key_order(unit):
+    return [int(k) for k in np.argsort(unit.key_rank, kind="stable")]   # endpoints as out_span_partitions.items() yields them
+
+
+def fcfs(unit):
+    n = unit.n_in
+    parent = np.full((unit.E, n), -1, dtype=np.int32)
+    for e in range(unit.E):
+        m = int(unit.out_off[e + 1] - unit.out_off[e])
+        parent[e, :min(n, m)] = np.arange(min(n, m), dtype=np.int32)
+    return parent
+
+
+def arrival_order(unit):
+    n = unit.n_in
+    parent = np.full((unit.E, n), -1, dtype=np.int32)
+    eps = _key_order(unit)
+    # GetOutEpsInOrder (helpers/utils.py:15-21): endpoints by the start of their first span (list.sort is stable)
+    o_eps = sorted(eps, key=lambda e: int(unit.out_start[unit.out_off[e]]))
+    prev = None   # indices (into the previous endpoint's list) in the order they are handed out
+    for pos, e in enumerate(o_eps):
+        m = int(unit.out_off[e + 1] - unit.out_off[e])
+        if pos == 0:
+            order = np.arange(m)
+        else:
+            pe = o_eps[pos - 1]
+            ends = unit.out_end[unit.out_off[pe]:unit.out_off[pe + 1]][prev]
+            sort_order = list(np.argsort(ends))                      # arrival_order.py:40 (numpy's default sort, as there)
+            if len(prev) <= m:
+                sort_order = sort_order[:m] + list(range(len(prev), m))
+            else:
+                sort_order = [x for x in sort_order if x < m]
+            order = np.array(sort_order, dtype=np.int64)
+        k = min(n, len(order))
+        parent[e, :k] = order[:k]
+        prev = order
+    return parent
+
+
+def vpath(unit, true_parent):
+    """`true_parent` [E, n_in] is only used the way the reference uses trace ids: to find the request a returning
+    call belongs to (vpath.py:42-46,81-84)."""
+    n, E = unit.n_in, unit.E
+    eps = _key_order(unit)
+    t, key, kind, idx, epv = [], [], [], [], []
+    # construction order of vpath.py:52-62: incoming spans (request, response), then every endpoint's calls
+    t += [unit.in_start, unit.in_end]; key += [np.full(n, 1), np.full(n, 4)]; kind += [np.zeros(n, int), np.ones(n, int)]
+    idx += [np.arange(n), np.arange(n)]; epv += [np.full(n, -1), np.full(n, -1)]
+    # (request and response of one span are adjacent in the reference's list; interleave below)
+    seq = [np.arange(n) * 2, np.arange(n) * 2 + 1]
+    base = 2 * n
+    owner = []
+    for e in eps:
+        a, b = int(unit.out_off[e]), int(unit.out_off[e + 1])
+        m = b - a
+        t += [unit.out_start[a:b], unit.out_end[a:b]]; key += [np.full(m, 2), np.full(m, 3)]
+        kind += [np.full(m, 2), np.full(m, 3)]; idx += [np.arange(m), np.arange(m)]; epv += [np.full(m, e), np.full(m, e)]
+        seq += [base + np.arange(m) * 2, base + np.arange(m) * 2 + 1]
+        base += 2 * m
+        inv = np.full(m, -1, dtype=np.int64)                          # request whose true call this is (first one wins)
+        tp = np.asarray(true_parent[e])
+        ok = tp >= 0
+        inv[tp[ok][::-1]] = np.flatnonzero(ok)[::-1]
+        owner.append(inv)
+    t, key, kind, idx, epv, seq = (np.concatenate(x) for x in (t, key, kind, idx, epv, seq))
+    first = np.argsort(seq, kind="stable")                            # the reference's list order
+    t, key, kind, idx, epv = t[first], key[first], kind[first], idx[first], epv[first]
+    order = np.lexsort((key, t.astype(np.float64)))                   # stable sort by (float(time), sort_key), vpath.py:64
+    parent = np.full((E, n), -1, dtype=np.int32)
+    own = {e: owner[k] for k, e in enumerate(eps)}
+    latest = -1
+    for j in order:
+        k = kind[j]
+        if k == 0:
+            latest = int(idx[j])
+        elif k == 1:
+            latest = -1
+        elif k == 2:
+            if latest >= 0:
+                parent[epv[j], latest] = idx[j]
+        else:
+            p = int(own[int(epv[j])][idx[j]])
+            if p >= 0:
+                latest = p
+    return parent
+
+
+def accuracy(parent, true_parent):
+    """helpers/utils.py:62-79."""
+    return float(np.all(parent == true_parent, axis=0).mean())

@@ -13,8 +13,9 @@ reference pickles its own Span objects there).  Everything between reading the d
 in libtwgpu.so: native ingest (tw_corpus_*), both passes of every service in one batch, device refit, device
 accuracy reductions.
 
-What it does not do (and says so instead of approximating): other predictor indices, the cache-hit / load / repeat
-transforms (--cache_rate > 0, --compress_factor != 1, --repeat_factor != 1), --parallel / --instrumented, tar
+Indices 4 (FCFS), 5 (ArrivalOrder) and 7 (vPath) run as host baselines (traceweaver_amd/baselines.py, identical to the
+reference's classes) and add their columns to the same files.  What it does not do (and says so instead of
+approximating): the other predictor indices (WAP5 = 3 among them), the cache-hit / load / repeat transforms (--cache_rate > 0, --compress_factor != 1, --repeat_factor != 1), --parallel / --instrumented, tar
 archives (--compressed 1).  For those keep the reference's executor and register the predictor.
 The mixture refit between the passes is the deterministic device refit, so figures agree with a reference run to
 within the run-to-run spread the reference itself has (its k-means++ start is drawn from an unseeded RNG,
@@ -61,11 +62,20 @@ def parse_args(argv=None):
     return args
 
 
-def unsupported(args):
+BASELINES = {4: "FCFS", 5: "ArrivalOrder", 7: "vPath"}   # predictors[4], [5], [7] (executor.py:888-900), host code like the reference's
+
+
+def requested(args):
     idx = [int(x) for x in args.predictor_indices.split(",") if x.strip() != ""]
+    return idx if idx else [10]
+
+
+def unsupported(args):
     problems = []
-    if idx and idx != [10]:
-        problems.append("--predictor_indices %s (only index 10, %s, runs on the GPU)" % (args.predictor_indices, METHOD))
+    bad = [i for i in requested(args) if i != 10 and i not in BASELINES]
+    if bad:
+        problems.append("--predictor_indices %s (index 10 runs on the GPU, %s as host baselines; not %s)"
+                        % (args.predictor_indices, sorted(BASELINES), bad))
     if args.compressed:
         problems.append("--compressed 1")
     if args.cache_rate != 0:
@@ -78,6 +88,7 @@ def unsupported(args):
 
 
 def run(args):
+    from . import baselines
     from .engine import Engine
     from .ingest import Corpus, REFERENCE_FIX
 
@@ -97,54 +108,72 @@ def run(args):
     names = corpus.trace_names()
     trace_id = lambda k: corpus.string(names[k])
     key = lambda row: (trace_id(table["trace"][row]), corpus.string(table["span_id"][row]))
-
-    eng = Engine(args.device, lib_path=args.engine_library)
-    t1 = time.time()
-    eng.load([u.arrays for u in units])
-    eng.set_truth([u.true_parent for u in units], [u.in_trace for u in units], n_traces)
-    eng.run_pass1()
-    eng.fit_mixtures()
-    eng.run_pass2()
-    per, _, flags = eng.evaluate(trace_flags=True)
-    res = eng.results(2, fields=("parent", "unit_stats"))
-    print("--- %s seconds --- (%d services, both passes, refit, accuracy)" % (time.time() - t1, len(units)))
-    eng.close()
-
-    accuracy_per_process, confidence, true_traces, pred_traces = {}, {}, {}, {}
     seen = np.zeros(n_traces, dtype=bool)
-    for u, ev, r in zip(units, per, res):
-        print("Accuracy for service %s: %.3f%%\n" % (u.service, ev["accuracy"] * 100))
-        print("Top K accuracy for service %s: %.3f%%\n" % (u.service, ev["topk_accuracy"] * 100))
-        accuracy_per_process[(METHOD, u.process_id)] = ev["accuracy"]
-        confidence[u.service] = [ev["accuracy"], r["not_best_count"], u.arrays.n_in]
+    for u in units:
         seen[u.in_trace] = True
-        for i in range(u.arrays.n_in):                       # helpers/utils.py:216-252
-            tid = trace_id(u.in_trace[i])
-            tt, pt = true_traces.setdefault(tid, []), pred_traces.setdefault(tid, [])
-            for e in range(u.arrays.E):
-                tt.append(int(u.out_rows[e][u.true_parent[e, i]]) if u.true_parent[e, i] >= 0 else None)
-                pt.append(int(u.out_rows[e][r["parent"][e, i]]) if r["parent"][e, i] >= 0 else None)
-    order = lambda rows: [key(x) if x is not None else None for x in sorted(rows, key=lambda x: float("inf") if x is None else table["start"][x])]
-    traces_overall = {METHOD: [{t: order(v) for t, v in true_traces.items()}, {t: order(v) for t, v in pred_traces.items()}]}
-    right = int((~flags[0].astype(bool) & seen).sum())
-    right_k = int((~flags[1].astype(bool) & seen).sum())
     total = int(seen.sum())
-    accuracy_overall = {METHOD: right / total * 100, METHOD + "TopK": right_k / total * 100}
+    roots = [x for x in np.flatnonzero(table["parent"] < 0) if seen[table["trace"][x]]]
+
+    accuracy_overall, accuracy_per_process, confidence, traces_overall, bins = {}, {}, {}, {}, {}
+
+    def record(method, parents, bad_flags):
+        """accuracy_*, e2e_*, bin_acc_* entries of one method from its parent arrays and per-trace wrong-flags."""
+        true_traces, pred_traces = {}, {}
+        for u, par in zip(units, parents):
+            for i in range(u.arrays.n_in):                       # helpers/utils.py:216-252
+                tid = trace_id(u.in_trace[i])
+                tt, pt = true_traces.setdefault(tid, []), pred_traces.setdefault(tid, [])
+                for e in range(u.arrays.E):
+                    tt.append(int(u.out_rows[e][u.true_parent[e, i]]) if u.true_parent[e, i] >= 0 else None)
+                    pt.append(int(u.out_rows[e][par[e, i]]) if par[e, i] >= 0 else None)
+        order = lambda rows: [key(x) if x is not None else None for x in sorted(rows, key=lambda x: float("inf") if x is None else table["start"][x])]
+        traces_overall[method] = [{t: order(v) for t, v in true_traces.items()}, {t: order(v) for t, v in pred_traces.items()}]
+        for name, bad in bad_flags.items():
+            accuracy_overall[name] = int((~bad.astype(bool) & seen).sum()) / total * 100
+            # BinAccuracyByResponseTimes (helpers/utils.py:187-214): traces ordered by the duration of their root span
+            rows = sorted((int(table["duration"][x]), trace_id(table["trace"][x]), int(bad[table["trace"][x]] == 0)) for x in roots)
+            acc, prev_c, prev_n, csum = [], 0, 0, np.cumsum([c for _, _, c in rows])
+            for b in range(10):
+                j = int(len(rows) * (b + 1) / 10 - 1)
+                c, n = int(csum[j]) - prev_c, (j + 1) - prev_n
+                prev_c, prev_n = prev_c + c, prev_n + n
+                acc.append(((b + 1) * 100 / 10, c / n, rows[j][0] / 1000.0))
+            bins[name] = acc
+
+    for index in requested(args):
+        if index == 10:
+            eng = Engine(args.device, lib_path=args.engine_library)
+            t1 = time.time()
+            eng.load([u.arrays for u in units])
+            eng.set_truth([u.true_parent for u in units], [u.in_trace for u in units], n_traces)
+            eng.run_pass1()
+            eng.fit_mixtures()
+            eng.run_pass2()
+            per, _, flags = eng.evaluate(trace_flags=True)
+            res = eng.results(2, fields=("parent", "unit_stats"))
+            print("--- %s seconds --- (%d services, both passes, refit, accuracy)" % (time.time() - t1, len(units)))
+            eng.close()
+            for u, ev, r in zip(units, per, res):
+                print("Accuracy for service %s: %.3f%%\n" % (u.service, ev["accuracy"] * 100))
+                print("Top K accuracy for service %s: %.3f%%\n" % (u.service, ev["topk_accuracy"] * 100))
+                accuracy_per_process[(METHOD, u.process_id)] = ev["accuracy"]
+                confidence[u.service] = [ev["accuracy"], r["not_best_count"], u.arrays.n_in]
+            record(METHOD, [r["parent"] for r in res], {METHOD: flags[0], METHOD + "TopK": flags[1]})
+        else:
+            method = BASELINES[index]
+            fn = {"FCFS": lambda u: baselines.fcfs(u.arrays), "ArrivalOrder": lambda u: baselines.arrival_order(u.arrays),
+                  "vPath": lambda u: baselines.vpath(u.arrays, u.true_parent)}[method]
+            parents, bad = [], np.zeros(n_traces, dtype=np.uint8)
+            for u in units:
+                par = fn(u)
+                ok = np.all(par == u.true_parent, axis=0)
+                print("Accuracy for service %s: %.3f%%\n" % (u.service, ok.mean() * 100))
+                accuracy_per_process[(method, u.process_id)] = float(ok.mean())
+                bad[u.in_trace[~ok]] = 1
+                parents.append(par)
+            record(method, parents, {method: bad})
     for k, v in accuracy_overall.items():
         print("End-to-end accuracy for method %s: %.3f%%" % (k, v))
-
-    # BinAccuracyByResponseTimes (helpers/utils.py:187-214): traces ordered by the duration of their root span
-    roots = np.flatnonzero(table["parent"] < 0)
-    bins = {}
-    for name, bad in ((METHOD, flags[0]), (METHOD + "TopK", flags[1])):
-        rows = sorted((int(table["duration"][x]), trace_id(table["trace"][x]), int(bad[table["trace"][x]] == 0)) for x in roots if seen[table["trace"][x]])
-        acc, prev_c, prev_n, csum = [], 0, 0, np.cumsum([c for _, _, c in rows])
-        for b in range(10):
-            j = int(len(rows) * (b + 1) / 10 - 1)
-            c, n = int(csum[j]) - prev_c, (j + 1) - prev_n
-            prev_c, prev_n = prev_c + c, prev_n + n
-            acc.append(((b + 1) * 100 / 10, c / n, rows[j][0] / 1000.0))
-        bins[name] = acc
 
     os.makedirs(os.path.dirname(args.results_directory) or ".", exist_ok=True)   # the name is used as a prefix, like the reference does
     suffix = "_%s_%s_%s_%s_%s.pickle" % (args.test_name, args.load_level, int(args.compress_factor), int(args.repeat_factor), args.cache_rate)
@@ -160,7 +189,7 @@ def main(argv=None):
     args = parse_args(argv)
     problems = unsupported(args)
     if problems:
-        sys.exit("traceweaver_amd.executor runs predictor 10 (%s) without transforms; not supported here: %s.\n"
+        sys.exit("traceweaver_amd.executor runs predictor 10 (%s) and the baselines 4, 5, 7 without transforms; not supported here: %s.\n"
                  "Use the reference's executor with TraceWeaverGPU registered in its predictor table (INTEGRATION.md section 2)."
                  % (METHOD, "; ".join(problems)))
     run(args)
