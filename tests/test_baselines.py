@@ -74,6 +74,49 @@ def check_units(units):
             assert np.array_equal(to_parent(u, ref, in_parts, parts), mine), (u.service, name)
 
 
+def check_wap5(units):
+    """One reference instance and one of ours, fed the services in the same order (state leaks between services)."""
+    import copy
+
+    saved = list(sys.path)
+    sys.path.insert(0, REF_PY)
+    try:
+        from algorithms.wap5 import WAP5
+    finally:
+        sys.path[:] = saved
+    ref, mine = WAP5({}, {}), baselines.WAP5()
+    for u in units:
+        a = u.arrays
+        trace_in = ["t%d" % k for k in u.in_trace]
+        trace_out = [["x%d_%d" % (e, j) for j in range(int(a.out_off[e + 1] - a.out_off[e]))] for e in range(a.E)]
+        in_parts, parts, truth = protocol_inputs(u, trace_in, trace_out)
+        got = ref.FindAssignments("WAP5", u.service, copy.deepcopy(in_parts), copy.deepcopy(parts), False, [], truth)
+        options = mine.assign(a, u.out_eps)
+        in_spans = list(in_parts.values())[0]
+        for e, ep in enumerate(u.out_eps):
+            pos = {s.GetId(): j for j, s in enumerate(parts[ep])}
+            for i, s in enumerate(in_spans):
+                want = [pos[x] for x in got[ep][s.GetId()] if tuple(x) != ("NA", "NA")]
+                assert options[e][i] == want, (u.service, ep, i)
+
+
+def test_wap5_on_generated_corpora(emu_lib, tmp_path):
+    synth.write_jaeger_corpus(str(tmp_path), 23, 300, app=synth.HOTEL_APP, concurrency=2.0)
+    c = Corpus(lib_path=emu_lib)
+    c.add_directory(str(tmp_path), first_span="HTTP GET /hotels", max_traces=0)
+    check_wap5(c.units()[0])
+    c.close()
+
+
+@pytest.mark.parametrize("rel,fix", [("hotel_reservation/hotel_load100", 2), ("nodejs_microservices/node_load150", 0)])
+def test_wap5_on_reference_corpora(emu_lib, rel, fix):
+    first, surgery = REFERENCE_FIX[fix]
+    c = Corpus(lib_path=emu_lib)
+    c.add_directory("/root/reference/data/" + rel, first_span=first, max_traces=1001, fix=surgery)
+    check_wap5(c.units()[0])
+    c.close()
+
+
 def test_baselines_on_generated_corpora(emu_lib, tmp_path):
     for app, conc in ((synth.HOTEL_APP, 2.5), (synth.FANOUT_APP, 1.6)):
         d = tmp_path / app["root"]

@@ -1,14 +1,14 @@
-"""The reference's simple baseline predictors on index arrays (executor.py:888-900 indices 4, 5, 7):
+"""The reference's baseline predictors on index arrays (executor.py:888-900 indices 3, 4, 5, 7):
 
     FCFS          algorithms/fcfs.py:10-26          request i takes the i-th call of every endpoint
     ArrivalOrder  algorithms/arrival_order.py:13-65  first endpoint FCFS, later ones in the order the previous calls returned
     vPath         algorithms/vpath.py:48-89          event sweep: a call belongs to the request that was last seen active
+    WAP5          algorithms/wap5.py:257-351         most likely preceding request under an exponential delay model (class WAP5 below)
 
 They are host code in the reference (Python) and stay host code here (numpy); they exist so that
 `traceweaver_amd.executor` can serve the baseline columns of the reference's experiments next to the accelerated
 predictor.  Inputs: a `UnitArrays` (endpoints in topological order; `key_rank` gives the partition-key order the
 reference iterates in).  Output: parent [E, n_in] int32 in the unit's endpoint order, -1 = ("NA", "NA").
-WAP5 (algorithms/wap5.py, index 3) is not provided.
 """
 import numpy as np
 
@@ -103,3 +103,73 @@ def vpath(unit, true_parent):
 def accuracy(parent, true_parent):
     """helpers/utils.py:62-79."""
     return float(np.all(parent == true_parent, axis=0).mean())
+
+
+class WAP5(object):
+    """algorithms/wap5.py:324-351 (FindAssignments and what it calls: BuildDistributions :257-275, ScoreParents
+    :282-316).  The reference keeps one instance for all services of a run, and two pieces of its state leak from
+    one service to the next: the delay samples per callee *name* (`distribution_values`) and the picked-flags of
+    spans; both are reproduced, so call `assign` service after service in the executor's order.
+
+    Returns per unit a list-valued assignment like the reference's ({request: [calls]} per endpoint), as
+    `options[e][i]` = list of outgoing-span indices (empty = [("NA", "NA")]); `parent()` applies the reference's
+    accuracy rule (helpers/utils.py:68-73: a request with more than one option for an endpoint counts as wrong)."""
+
+    MAGIC_DELAY = 4
+
+    def __init__(self):
+        self.distribution_values = {}
+
+    def assign(self, unit, ep_names):
+        import math
+        import statistics
+
+        n, E = unit.n_in, unit.E
+        large_delay = int((unit.in_end - unit.in_start).max())
+        options = [[[] for _ in range(n)] for _ in range(E)]
+        for e in _key_order(unit):                                   # for out_ep in out_span_partitions.keys()
+            a, b = int(unit.out_off[e]), int(unit.out_off[e + 1])
+            m = b - a
+            # spans = incoming + outgoing of this endpoint, stable sort by start (incoming first on ties)
+            start = np.concatenate([unit.in_start, unit.out_start[a:b]])
+            is_client = np.concatenate([np.zeros(n, bool), np.ones(m, bool)])
+            idx = np.concatenate([np.arange(n), np.arange(m)])
+            order = np.argsort(start, kind="stable")
+            start, is_client, idx = start[order], is_client[order], idx[order]
+            values = self.distribution_values.setdefault(ep_names[e], [])
+            # BuildDistributions: delay to the nearest preceding incoming span, if within the longest request duration
+            for i in np.flatnonzero(is_client):
+                sent = int(start[i])
+                for j in range(i - 1, -1, -1):
+                    if sent - int(start[j]) > large_delay:
+                        break
+                    if not is_client[j]:
+                        values.append(sent - int(start[j]))
+                        break
+            # ScoreParents
+            mean = statistics.mean(values)                            # constant during the loop below
+            limit = self.MAGIC_DELAY * mean
+            logpdf = lambda t: -t / mean - math.log(mean)             # scipy.stats.expon.logpdf(t, scale=mean)
+            picked = np.zeros(n, bool)                                # already_picked, reset for the spans of this call
+            for i in np.flatnonzero(is_client):
+                sent = int(start[i])
+                cands = []
+                for j in range(i - 1, -1, -1):
+                    if sent - int(start[j]) > limit:
+                        cands.append((-1, logpdf(limit)))             # ("Spontaneous", p)
+                        break
+                    if not is_client[j] and not picked[idx[j]]:
+                        cands.append((int(idx[j]), logpdf(sent - int(start[j]))))
+                        picked[idx[j]] = True
+                cands.sort(key=lambda x: x[1])                        # stable, ascending: the last entry wins
+                if cands and cands[-1][0] >= 0:
+                    options[e][cands[-1][0]].append(int(idx[i]))
+        return options
+
+    @staticmethod
+    def parent(unit, options):
+        par = np.full((unit.E, unit.n_in), -1, dtype=np.int32)
+        for e in range(unit.E):
+            for i, opt in enumerate(options[e]):
+                par[e, i] = opt[0] if len(opt) == 1 else (-1 if not opt else -2)   # -2: several options = wrong
+        return par

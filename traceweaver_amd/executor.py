@@ -13,9 +13,10 @@ reference pickles its own Span objects there).  Everything between reading the d
 in libtwgpu.so: native ingest (tw_corpus_*), both passes of every service in one batch, device refit, device
 accuracy reductions.
 
-Indices 4 (FCFS), 5 (ArrivalOrder) and 7 (vPath) run as host baselines (traceweaver_amd/baselines.py, identical to the
-reference's classes) and add their columns to the same files.  What it does not do (and says so instead of
-approximating): the other predictor indices (WAP5 = 3 among them), the cache-hit / load / repeat transforms (--cache_rate > 0, --compress_factor != 1, --repeat_factor != 1), --parallel / --instrumented, tar
+Indices 3 (WAP5), 4 (FCFS), 5 (ArrivalOrder) and 7 (vPath) run as host baselines (traceweaver_amd/baselines.py,
+identical to the reference's classes) and add their columns to the same files -- `exps/exp1`'s "3,4,7,10" runs as is.
+What it does not do (and says so instead of approximating): the other predictor indices (the older TraceWeaver
+variants 0-2, 6, 8, 9), the cache-hit / load / repeat transforms (--cache_rate > 0, --compress_factor != 1, --repeat_factor != 1), --parallel / --instrumented, tar
 archives (--compressed 1).  For those keep the reference's executor and register the predictor.
 The mixture refit between the passes is the deterministic device refit, so figures agree with a reference run to
 within the run-to-run spread the reference itself has (its k-means++ start is drawn from an unseeded RNG,
@@ -62,7 +63,7 @@ def parse_args(argv=None):
     return args
 
 
-BASELINES = {4: "FCFS", 5: "ArrivalOrder", 7: "vPath"}   # predictors[4], [5], [7] (executor.py:888-900), host code like the reference's
+BASELINES = {3: "WAP5", 4: "FCFS", 5: "ArrivalOrder", 7: "vPath"}   # predictors[3], [4], [5], [7] (executor.py:888-900), host code like the reference's
 
 
 def requested(args):
@@ -116,16 +117,20 @@ def run(args):
 
     accuracy_overall, accuracy_per_process, confidence, traces_overall, bins = {}, {}, {}, {}, {}
 
-    def record(method, parents, bad_flags):
-        """accuracy_*, e2e_*, bin_acc_* entries of one method from its parent arrays and per-trace wrong-flags."""
+    def record(method, parents, bad_flags, options=None):
+        """accuracy_*, e2e_*, bin_acc_* entries of one method from its parent arrays (or, for WAP5, its option lists)
+        and per-trace wrong-flags."""
         true_traces, pred_traces = {}, {}
-        for u, par in zip(units, parents):
+        for k, (u, par) in enumerate(zip(units, parents)):
             for i in range(u.arrays.n_in):                       # helpers/utils.py:216-252
                 tid = trace_id(u.in_trace[i])
                 tt, pt = true_traces.setdefault(tid, []), pred_traces.setdefault(tid, [])
                 for e in range(u.arrays.E):
                     tt.append(int(u.out_rows[e][u.true_parent[e, i]]) if u.true_parent[e, i] >= 0 else None)
-                    pt.append(int(u.out_rows[e][par[e, i]]) if par[e, i] >= 0 else None)
+                    if options is not None:
+                        pt.extend([int(u.out_rows[e][x]) for x in options[k][e][i]] or [None])
+                    else:
+                        pt.append(int(u.out_rows[e][par[e, i]]) if par[e, i] >= 0 else None)
         order = lambda rows: [key(x) if x is not None else None for x in sorted(rows, key=lambda x: float("inf") if x is None else table["start"][x])]
         traces_overall[method] = [{t: order(v) for t, v in true_traces.items()}, {t: order(v) for t, v in pred_traces.items()}]
         for name, bad in bad_flags.items():
@@ -161,17 +166,22 @@ def run(args):
             record(METHOD, [r["parent"] for r in res], {METHOD: flags[0], METHOD + "TopK": flags[1]})
         else:
             method = BASELINES[index]
+            wap5, all_options = baselines.WAP5(), []               # one instance for the run: its state leaks across services
             fn = {"FCFS": lambda u: baselines.fcfs(u.arrays), "ArrivalOrder": lambda u: baselines.arrival_order(u.arrays),
-                  "vPath": lambda u: baselines.vpath(u.arrays, u.true_parent)}[method]
+                  "vPath": lambda u: baselines.vpath(u.arrays, u.true_parent), "WAP5": None}[method]
             parents, bad = [], np.zeros(n_traces, dtype=np.uint8)
             for u in units:
-                par = fn(u)
+                if method == "WAP5":
+                    all_options.append(wap5.assign(u.arrays, u.out_eps))
+                    par = baselines.WAP5.parent(u.arrays, all_options[-1])
+                else:
+                    par = fn(u)
                 ok = np.all(par == u.true_parent, axis=0)
                 print("Accuracy for service %s: %.3f%%\n" % (u.service, ok.mean() * 100))
                 accuracy_per_process[(method, u.process_id)] = float(ok.mean())
                 bad[u.in_trace[~ok]] = 1
                 parents.append(par)
-            record(method, parents, {method: bad})
+            record(method, parents, {method: bad}, options=all_options if method == "WAP5" else None)
     for k, v in accuracy_overall.items():
         print("End-to-end accuracy for method %s: %.3f%%" % (k, v))
 
@@ -189,7 +199,7 @@ def main(argv=None):
     args = parse_args(argv)
     problems = unsupported(args)
     if problems:
-        sys.exit("traceweaver_amd.executor runs predictor 10 (%s) and the baselines 4, 5, 7 without transforms; not supported here: %s.\n"
+        sys.exit("traceweaver_amd.executor runs predictor 10 (%s) and the baselines 3, 4, 5, 7 without transforms; not supported here: %s.\n"
                  "Use the reference's executor with TraceWeaverGPU registered in its predictor table (INTEGRATION.md section 2)."
                  % (METHOD, "; ".join(problems)))
     run(args)
