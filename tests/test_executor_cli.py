@@ -117,3 +117,24 @@ def test_generated_corpus_end_to_end(emu_lib, tmp_path):
                    "--test_name", "gen", "--load_level", "7", "--engine_library", emu_lib])
     acc = pickle.load(open(out + "accuracy_gen_7_1_1_0.0.pickle", "rb"))
     assert acc["MaxScoreBatchSubsetWithSkips"] > 85.0
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/data"), reason="the reference's data directory is not present")
+def test_reference_path_shim(emu_lib, tmp_path):
+    """The path and the argument list exps/exp1/run_experiment.sh uses (lines 5-18, 40-46), as a subprocess."""
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    out = str(tmp_path) + "/"
+    env = dict(os.environ, TRACEWEAVER_ROOT=REF, TW_TILE="1", TW_COOP_THREADS="1")
+    cmd = [sys.executable, os.path.join(REPO, "src/trace_reconstructor/ports/python/executor.py"),
+           "--relative_path", "data/hotel_reservation/hotel_load25/", "--compressed", "0", "--cache_rate", "0", "--fix", "2",
+           "--test_name", "hotel_test", "--load_level", "25", "--compress_factor", "1", "--repeat_factor", "1",
+           "--execute_parallel", "0", "--results_directory", out, "--clear_cache", "1", "--predictor_indices", "3,4,7,10",
+           "--engine_library", emu_lib]
+    subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, timeout=300)
+    acc = pickle.load(open(out + "accuracy_hotel_test_25_1_1_0.0.pickle", "rb"))
+    assert set(acc) == {"WAP5", "FCFS", "vPath", "MaxScoreBatchSubsetWithSkips", "MaxScoreBatchSubsetWithSkipsTopK"}
+    assert acc["MaxScoreBatchSubsetWithSkips"] == 100.0       # the frozen reference run scored 100.0 here too
