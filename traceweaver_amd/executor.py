@@ -90,7 +90,7 @@ def unsupported(args):
 
 def run(args):
     from . import baselines
-    from .engine import Engine
+    from .engine import Engine, EngineError
     from .ingest import Corpus, REFERENCE_FIX
 
     if args.fix not in REFERENCE_FIX:
@@ -151,7 +151,14 @@ def run(args):
             t1 = time.time()
             eng.load([u.arrays for u in units])
             eng.set_truth([u.true_parent for u in units], [u.in_trace for u in units], n_traces)
-            eng.run_pass1()
+            try:
+                eng.run_pass1()
+            except EngineError as ex:
+                if ex.code == -7:   # TW_ERR_NAN_PARAMS, SURVEY.md hazard H3 (e.g. media_load75: 1500 files, 1001 traces kept)
+                    raise SystemExit("%s\nThe reference fails on this input too (scipy.stats.tstd of one batch mean is NaN, "
+                                     "traceweaver_v3.py:611). Keep a multiple-of-100-plus-anything-but-1 number of traces, "
+                                     "e.g. --max_traces 1000." % ex)
+                raise
             eng.fit_mixtures()
             eng.run_pass2()
             per, _, flags = eng.evaluate(trace_flags=True)
