@@ -77,6 +77,14 @@ typedef struct {
     int32_t batch_size;     /* 100  traceweaver_v3.py:1107 */
     int32_t batch_size_mis; /* 30   traceweaver_v3.py:1108 */
     int32_t topk;           /* 5    traceweaver_v3.py:1109 */
+    /* Load-scaled units (helpers/transforms.py:10-40 repeat_change_spans, called at executor.py:1146-1148 when
+     * --compress_factor > 1): the reference's timestamps are Python floats there (start / load_factor).  Such a
+     * unit is handed over with its timestamps as exact integers in units of unit_time_scale[u] microseconds (a
+     * power of two, e.g. 2^-3): comparisons are then the reference's float comparisons, differences are
+     * (double)(t2 - t1) * scale exactly, and the sums of ComputeEpPairDistParams3 (traceweaver_v3.py:593,605)
+     * accumulate in binary64 left to right as Python's sum() does over floats.  NULL = every unit holds plain
+     * int64 microseconds (exact integer sums, as Python does over ints). */
+    const double *unit_time_scale; /* [n_units] or NULL */
 } tw_batch;
 
 /* Copies the batch into HBM (span arrays: 16 B per span).  If `spans_on_device` is non-zero the

@@ -180,6 +180,14 @@ typedef struct {
     const int32_t *key_rank;            /* [E] position of endpoint in the partition-key order:*/
                                         /* in_edges(e) iterate predecessors in this order      */
     int32_t batch_size, batch_size_mis, topk; /* 100, 30, 5                          V3:1107  */
+    /* Load-scaled inputs (helpers/transforms.py:10-40, executor.py:1146-1148): the reference's timestamps are Python
+     * floats there.  They are handed over as exact integers in units of time_scale microseconds (a power of two),
+     * so every comparison is the reference's float comparison and every difference t2 - t1 (exact in binary64
+     * for neighbouring timestamps) is (double)(t2 - t1) * time_scale.  float_time != 0 additionally selects
+     * float accumulation where the reference sums timestamps (V3:593,605: Python's sum() over floats adds
+     * sequentially in binary64).  time_scale = 1, float_time = 0: the integer-microsecond case. */
+    double time_scale;
+    int32_t float_time;
 } two_service;
 
 #define NSLOT(E) ((E) + (E) * (E) + (E))
@@ -277,9 +285,10 @@ static const double LOG_SQRT_2PI = 0x1.d67f1c864beb4p-1; /* np.log(np.sqrt(2*np.
 static const double LOG_2PI = 0x1.d67f1c864beb4p+0;      /* np.log(2*np.pi) */
 
 /* scipy.stats.norm.logpdf(x, loc, scale) = (-(y*y)/2 - log(sqrt(2pi))) - log(scale), y=(x-loc)/scale */
+static double g_time_scale = 1.0; /* two_service.time_scale of the service being scored (set by the entry points) */
 static double term_gauss(double mean, double std, int64_t t1, int64_t t2) {
     if (std < 1.0e-12) std = 0.001; /* V1:130-131 */
-    double x = (double)(t2 - t1);
+    double x = (double)(t2 - t1) * g_time_scale;
     double y = (x - mean) / std;
     return (-(y * y) / 2.0 - LOG_SQRT_2PI) - two_log(std);
 }
@@ -287,7 +296,7 @@ static double term_gauss(double mean, double std, int64_t t1, int64_t t2) {
 /* sklearn GaussianMixture.score([[x]]) for 1-D 'full' mixtures: _estimate_log_gaussian_prob +
  * log weights, then scipy.special.logsumexp (scipy>=1.15 form: max split out, log1p) */
 static double term_mix(int n, const double *p, int64_t t1, int64_t t2) {
-    double x = (double)(t2 - t1), a[TWO_MAX_COMP], amax = -INFINITY;
+    double x = (double)(t2 - t1) * g_time_scale, a[TWO_MAX_COMP], amax = -INFINITY;
     for (int k = 0; k < n; k++) {
         double w = p[k * 3 + 0], mu = p[k * 3 + 1], pc = p[k * 3 + 2];
         double y = x * pc - mu * pc;
@@ -554,19 +563,33 @@ static double np_sum(const double *a, int n) {
     return 0.0 + res;
 }
 /* ComputeDistParams V3:590-617 on rank slice [a,b) of two sorted arrays */
-static void dist_params(const int64_t *t1, const int64_t *t2, int a, int b, double *mean, double *std) {
+static void dist_params(const two_service *s, const int64_t *t1, const int64_t *t2, int a, int b, double *mean, double *std) {
     int len = b - a;
-    int64_t s1 = 0, s2 = 0;
-    for (int i = a; i < b; i++) { s1 += t1[i]; s2 += t2[i]; }
-    *mean = (double)(s2 - s1) / (double)len;
     int nb = 10, bs = (len + nb - 1) / nb, m = 0;
     double bm[10];
-    for (int k = 0; k < nb; k++) {
-        int st = k * bs, en = (k + 1) * bs < len ? (k + 1) * bs : len;
-        if (en - st > 0) {
-            int64_t u1 = 0, u2 = 0;
-            for (int i = a + st; i < a + en; i++) { u1 += t1[i]; u2 += t2[i]; }
-            bm[m++] = (double)(u2 - u1) / (double)(en - st);
+    if (!s->float_time) { /* Python ints: exact sums, one correctly rounded division */
+        int64_t s1 = 0, s2 = 0;
+        for (int i = a; i < b; i++) { s1 += t1[i]; s2 += t2[i]; }
+        *mean = (double)(s2 - s1) / (double)len;
+        for (int k = 0; k < nb; k++) {
+            int st = k * bs, en = (k + 1) * bs < len ? (k + 1) * bs : len;
+            if (en - st > 0) {
+                int64_t u1 = 0, u2 = 0;
+                for (int i = a + st; i < a + en; i++) { u1 += t1[i]; u2 += t2[i]; }
+                bm[m++] = (double)(u2 - u1) / (double)(en - st);
+            }
+        }
+    } else { /* Python floats: sum() adds left to right in binary64 (scaling by a power of two commutes with rounding) */
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = a; i < b; i++) { s1 += (double)t1[i]; s2 += (double)t2[i]; }
+        *mean = (s2 - s1) / (double)len;
+        for (int k = 0; k < nb; k++) {
+            int st = k * bs, en = (k + 1) * bs < len ? (k + 1) * bs : len;
+            if (en - st > 0) {
+                double u1 = 0.0, u2 = 0.0;
+                for (int i = a + st; i < a + en; i++) { u1 += (double)t1[i]; u2 += (double)t2[i]; }
+                bm[m++] = (u2 - u1) / (double)(en - st);
+            }
         }
     }
     /* scipy 1.14 tstd = sqrt(np.var(x, ddof=1)) */
@@ -574,6 +597,8 @@ static void dist_params(const int64_t *t1, const int64_t *t2, int a, int b, doub
     for (int k = 0; k < m; k++) { double d = bm[k] - mu; d2[k] = d * d; }
     double var = np_sum(d2, m) / (double)(m - 1); /* m==1 -> 0/0 = NaN, as the reference (H3) */
     *std = sqrt((double)bs) * sqrt(var);
+    *mean *= s->time_scale; /* exact: a power of two */
+    *std *= s->time_scale;
 }
 
 /* gauss: [n_blocks][nslot][2]; unscored slots are left NaN.  Returns n_blocks. */
@@ -598,10 +623,10 @@ int two_gauss_params(const two_service *s, double *gauss, int32_t max_blocks) {
         for (int e = 0; e < E; e++) {
             int npred = 0;
             for (int p = 0; p < E; p++) if (s->dag[p * E + e]) npred++;
-            if (npred == 0) dist_params(s->in_start, s->out_start + s->out_off[e], a, z, &g[2 * SLOT_ROOT(E, e)], &g[2 * SLOT_ROOT(E, e) + 1]);
+            if (npred == 0) dist_params(s, s->in_start, s->out_start + s->out_off[e], a, z, &g[2 * SLOT_ROOT(E, e)], &g[2 * SLOT_ROOT(E, e) + 1]);
             for (int p = 0; p < E; p++)
-                if (is_primary(s, p, e)) dist_params(oes[p], s->out_start + s->out_off[e], a, z, &g[2 * SLOT_PRIM(E, p, e)], &g[2 * SLOT_PRIM(E, p, e) + 1]);
-            dist_params(oes[e], in_end_sorted, a, z, &g[2 * SLOT_CLOSE(E, e)], &g[2 * SLOT_CLOSE(E, e) + 1]);
+                if (is_primary(s, p, e)) dist_params(s, oes[p], s->out_start + s->out_off[e], a, z, &g[2 * SLOT_PRIM(E, p, e)], &g[2 * SLOT_PRIM(E, p, e) + 1]);
+            dist_params(s, oes[e], in_end_sorted, a, z, &g[2 * SLOT_CLOSE(E, e)], &g[2 * SLOT_CLOSE(E, e) + 1]);
         }
     }
     for (int e = 0; e < E; e++) free(oes[e]);
@@ -863,6 +888,7 @@ int two_run_pass(const two_service *s, int mode, const double *gauss, const int3
                  const int32_t *forced) {
     int n = s->n_in, E = s->E, K = s->topk, nslot = NSLOT(E);
     if (E > TWO_MAX_E || K > TWO_MAX_K) return -3;
+    g_time_scale = s->time_scale;
     two_graph g; build_graph(s, &g);
     two_lists full, rem; full.s = rem.s = s;
     memset(full.consumed, 0, sizeof(full.consumed));
@@ -929,7 +955,7 @@ int two_gaps(const two_service *s, const int32_t *parent, double *gaps, int32_t 
         for (int p = 0; p < E; p++) if (s->dag[p * E + e]) npred++;
         if (npred == 0) {
             int q = SLOT_ROOT(E, e), c = 0;
-            for (int i = 0; i < n; i++) { int32_t x = parent[(size_t)e * n + i]; if (x < 0) continue; gaps[(size_t)q * n + c++] = (double)(ostart(s, e, x) - s->in_start[i]); }
+            for (int i = 0; i < n; i++) { int32_t x = parent[(size_t)e * n + i]; if (x < 0) continue; gaps[(size_t)q * n + c++] = (double)(ostart(s, e, x) - s->in_start[i]) * s->time_scale; }
             counts[q] = c;
         }
         for (int p = 0; p < E; p++) {
@@ -938,12 +964,12 @@ int two_gaps(const two_service *s, const int32_t *parent, double *gaps, int32_t 
             for (int i = 0; i < n; i++) {
                 int32_t xp = parent[(size_t)p * n + i], xe = parent[(size_t)e * n + i];
                 if (xp < 0 || xe < 0) continue;
-                gaps[(size_t)q * n + c++] = (double)(ostart(s, e, xe) - oend(s, p, xp));
+                gaps[(size_t)q * n + c++] = (double)(ostart(s, e, xe) - oend(s, p, xp)) * s->time_scale;
             }
             counts[q] = c;
         }
         int q = SLOT_CLOSE(E, e), c = 0;
-        for (int i = 0; i < n; i++) { int32_t x = parent[(size_t)e * n + i]; if (x < 0) continue; gaps[(size_t)q * n + c++] = (double)(s->in_end[i] - oend(s, e, x)); }
+        for (int i = 0; i < n; i++) { int32_t x = parent[(size_t)e * n + i]; if (x < 0) continue; gaps[(size_t)q * n + c++] = (double)(s->in_end[i] - oend(s, e, x)) * s->time_scale; }
         counts[q] = c;
     }
     return 0;

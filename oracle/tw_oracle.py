@@ -33,6 +33,7 @@ class _Service(ctypes.Structure):
         ("out_off", ctypes.c_void_p), ("out_start", ctypes.c_void_p), ("out_end", ctypes.c_void_p),
         ("dag", ctypes.c_void_p), ("key_rank", ctypes.c_void_p),
         ("batch_size", ctypes.c_int32), ("batch_size_mis", ctypes.c_int32), ("topk", ctypes.c_int32),
+        ("time_scale", ctypes.c_double), ("float_time", ctypes.c_int32),
     ]
 
 
@@ -61,12 +62,26 @@ class Service(object):
     """SoA view of one service: endpoints in topological order, spans sorted by (start, end)."""
 
     def __init__(self, in_start, in_dur, out_off, out_start, out_dur, dag, key_rank=None,
-                 batch_size=100, batch_size_mis=30, topk=TOPK):
-        self.in_start = np.ascontiguousarray(in_start, dtype=np.int64)
-        self.in_end = self.in_start + np.ascontiguousarray(in_dur, dtype=np.int64)
+                 batch_size=100, batch_size_mis=30, topk=TOPK, time_scale=None):
+        # time_scale (a power of two): the int64 inputs are load-scaled timestamps in units of time_scale microseconds
+        self.time_scale, self.float_time = (1.0, 0) if time_scale is None else (float(time_scale), 1)
+        if np.asarray(in_start).dtype.kind == "f":
+            # load-scaled inputs (helpers/transforms.py:10-40): float64 starts, int durations; ends = fl(start + dur)
+            # as the reference forms them.  Handed to the C code as exact integers in units of 2^-k microseconds.
+            fs = [np.asarray(in_start, dtype=np.float64), np.asarray(out_start, dtype=np.float64)]
+            fe = [fs[0] + np.asarray(in_dur, dtype=np.float64), fs[1] + np.asarray(out_dur, dtype=np.float64)]
+            k = exact_binary_exponent(fs + fe)
+            self.time_scale, self.float_time = float(np.ldexp(1.0, -k)), 1
+            self.in_start, self.out_start = (np.ldexp(a, k).astype(np.int64) for a in fs)
+            self.in_end, self.out_end = (np.ldexp(a, k).astype(np.int64) for a in fe)
+            for a, b in zip(fs + fe, (self.in_start, self.out_start, self.in_end, self.out_end)):
+                assert np.array_equal(np.ldexp(b.astype(np.float64), -k), a)
+        else:
+            self.in_start = np.ascontiguousarray(in_start, dtype=np.int64)
+            self.in_end = self.in_start + np.ascontiguousarray(in_dur, dtype=np.int64)
+            self.out_start = np.ascontiguousarray(out_start, dtype=np.int64)
+            self.out_end = self.out_start + np.ascontiguousarray(out_dur, dtype=np.int64)
         self.out_off = np.ascontiguousarray(out_off, dtype=np.int64)
-        self.out_start = np.ascontiguousarray(out_start, dtype=np.int64)
-        self.out_end = self.out_start + np.ascontiguousarray(out_dur, dtype=np.int64)
         self.E = len(self.out_off) - 1
         self.n_in = len(self.in_start)
         self.dag = np.ascontiguousarray(dag, dtype=np.uint8).reshape(self.E, self.E)
@@ -74,7 +89,7 @@ class Service(object):
             np.arange(self.E) if key_rank is None else key_rank, dtype=np.int32)
         self.c = _Service(self.n_in, self.E, _p(self.in_start), _p(self.in_end), _p(self.out_off),
                           _p(self.out_start), _p(self.out_end), _p(self.dag), _p(self.key_rank),
-                          batch_size, batch_size_mis, topk)
+                          batch_size, batch_size_mis, topk, self.time_scale, self.float_time)
         self.topk = topk
         self.batch_size = batch_size
 
@@ -90,6 +105,23 @@ class Service(object):
 
     def slot_close(self, e):
         return self.E + self.E * self.E + e
+
+
+def exact_binary_exponent(arrays):
+    """Smallest k >= 0 such that every value of the float64 arrays is an integer multiple of 2^-k."""
+    k = 0
+    for a in arrays:
+        a = np.asarray(a, dtype=np.float64)
+        a = a[a != 0]
+        if len(a) == 0:
+            continue
+        m, e = np.frexp(a)                                   # a = m * 2^e, 0.5 <= |m| < 1
+        mant = np.abs(np.ldexp(m, 53)).astype(np.int64)      # 53-bit integer mantissa
+        tz = np.zeros(len(a), dtype=np.int64)
+        low = mant & -mant                                   # lowest set bit
+        tz = np.log2(low.astype(np.float64)).astype(np.int64)
+        k = max(k, int(np.max(53 - e - tz)))
+    return k
 
 
 def windows(svc):

@@ -18,7 +18,8 @@ STRESS = [
 
 
 def oracle_service(u):
-    return T.Service(u.in_start, u.in_end - u.in_start, u.out_off, u.out_start, u.out_end - u.out_start, u.dag, u.key_rank)
+    return T.Service(u.in_start, u.in_end - u.in_start, u.out_off, u.out_start, u.out_end - u.out_start, u.dag, u.key_rank,
+                     time_scale=getattr(u, "time_scale", None))
 
 
 def oracle_two_pass(svc, mixtures=None):

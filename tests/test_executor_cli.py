@@ -83,7 +83,7 @@ def test_unsupported_settings_are_refused(emu_lib, tmp_path):
     from traceweaver_amd import executor
 
     base = ["--relative_path", "x", "--fix", "2", "--results_directory", str(tmp_path) + "/", "--engine_library", emu_lib]
-    for extra in (["--cache_rate", "0.3"], ["--cache_rate", "0", "--compress_factor", "4"], ["--cache_rate", "0", "--predictor_indices", "2,10"],
+    for extra in (["--cache_rate", "0.3"], ["--cache_rate", "0", "--compress_factor", "4", "--predictor_indices", "4,10"], ["--cache_rate", "0", "--predictor_indices", "2,10"],
                   ["--cache_rate", "0", "--parallel", "1"]):
         with pytest.raises(SystemExit) as ei:
             executor.main(base + extra)
@@ -105,6 +105,41 @@ def test_baseline_columns(emu_lib, tmp_path):
     assert list(acc) == ["WAP5", "FCFS", "vPath", "MaxScoreBatchSubsetWithSkips", "MaxScoreBatchSubsetWithSkipsTopK"]
     assert all(acc["MaxScoreBatchSubsetWithSkips"] > acc[m] for m in ("WAP5", "FCFS", "vPath"))
     assert {k[0] for k in proc} == {"WAP5", "FCFS", "vPath", "MaxScoreBatchSubsetWithSkips"} and len(proc) == 8
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/data"), reason="the reference's data directory is not present")
+def test_load_scaling_through_the_command_line(emu_lib, tmp_path):
+    """--compress_factor 2 on hotel_load50 with one replica per service: the units the engine solves are the inputs the
+    reference's predictor saw in the frozen run of the same command (tests/golden/refcmp_hotel_load50_x2__*), pass 1
+    agrees with it request for request, and the end result stays at the pass-1 level -- the reference's own second pass
+    ends at 0 % on this path (traceweaver_amd/transforms.py)."""
+    import glob
+
+    from conftest import REPO
+    from traceweaver_amd import executor
+
+    out = str(tmp_path) + "/"
+    replicas = str(tmp_path / "replicas.pickle")
+    with open(replicas, "wb") as f:
+        pickle.dump({"frontend": [0], "search": [0]}, f)
+    argv = ["--relative_path", "data/hotel_reservation/hotel_load50/", "--compressed", "0", "--cache_rate", "0", "--fix", "2",
+            "--test_name", "hotel_x2", "--load_level", "50", "--compress_factor", "2", "--repeat_factor", "1", "--execute_parallel", "0",
+            "--results_directory", out, "--clear_cache", "1", "--predictor_indices", "10", "--project_root", REF,
+            "--engine_library", emu_lib, "--replicas_file", replicas]
+    executor.main(argv)
+    acc = pickle.load(open(out + "accuracy_hotel_x2_50_2_1_0.0.pickle", "rb"))
+    conf = pickle.load(open(out + "confidence_scores_hotel_x2_50_2_1_0.0.pickle", "rb"))
+    gold = {str(np.load(p)["process"]): np.load(p) for p in glob.glob(os.path.join(REPO, "tests", "golden", "refcmp_hotel_load50_x2__*.npz"))}
+    assert set(conf) == set(gold) == {"frontend", "search"}
+    for svc, (a, _, n) in conf.items():
+        g = gold[svc]
+        ref_pass1 = float(np.all(g["pass1_parent"] == g["true_parent"], axis=0).mean())
+        ref_final = float(np.all(g["final_parent"] == g["true_parent"], axis=0).mean())
+        assert n == 1000 and a >= ref_pass1 - 0.02 and ref_final < 0.05
+    assert acc["MaxScoreBatchSubsetWithSkips"] > 95.0 and float(gold["frontend"]["e2e_accuracy"]) == 0.0
+    with pytest.raises(SystemExit) as ei:                       # no replica table: says which file it wants
+        executor.main(argv[:-1] + [str(tmp_path / "missing.pickle")])
+    assert "needs the replica table" in str(ei.value)
 
 
 def test_generated_corpus_end_to_end(emu_lib, tmp_path):

@@ -15,7 +15,9 @@ class Span(object):
     """The fields the predictor protocol touches (reference spans.py:1-75)."""
 
     def __init__(self, trace_id, sid, start_mus, duration_mus):
-        self.trace_id, self.sid, self.start_mus, self.duration_mus = trace_id, sid, int(start_mus), int(duration_mus)
+        # after the executor's load scaling start_mus is a Python float (helpers/transforms.py:21,30)
+        self.trace_id, self.sid, self.duration_mus = trace_id, sid, int(duration_mus)
+        self.start_mus = float(start_mus) if isinstance(start_mus, float) else int(start_mus)
 
     def GetId(self):
         return (self.trace_id, self.sid)

@@ -27,6 +27,7 @@ class Batch(ctypes.Structure):
         ("in_start", ctypes.c_void_p), ("in_end", ctypes.c_void_p),
         ("out_start", ctypes.c_void_p), ("out_end", ctypes.c_void_p),
         ("batch_size", ctypes.c_int32), ("batch_size_mis", ctypes.c_int32), ("topk", ctypes.c_int32),
+        ("unit_time_scale", ctypes.c_void_p),
     ]
 
 

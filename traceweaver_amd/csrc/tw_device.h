@@ -40,6 +40,8 @@ struct UnitDev {
     uint8_t npred[kMaxEp];
     uint8_t pred_list[kMaxEp][kMaxEp];    // predecessors in networkx in_edges() order
     uint8_t pred_prim[kMaxEp][kMaxEp];    // 1 <=> that in-edge is primary (scored)
+    double tscale;             // microseconds per timestamp unit (tw_batch.unit_time_scale; 1.0 for integer microseconds)
+    int32_t float_time;        // timestamps are images of binary64 values: sums of timestamps accumulate in binary64
 };
 
 struct TileDev {

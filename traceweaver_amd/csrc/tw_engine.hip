@@ -2,6 +2,7 @@
 // kernels in tw_kernels.h.  One engine = one HIP device + one stream; inputs stay resident in HBM
 // between the two passes (spans are read from host memory exactly once, in tw_load_batch).
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -367,6 +368,12 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         if (n < 2) return fail(e, TW_ERR_ARG, "a unit needs at least 2 incoming spans (the reference raises on max([]) for 1, traceweaver_v3.py:1119)");
         if (n > 0x7fffffff / 16) return fail(e, TW_ERR_ARG, "unit too large");
         U.in_off = b->unit_in_off[u];
+        U.tscale = b->unit_time_scale != nullptr ? b->unit_time_scale[u] : 1.0;
+        U.float_time = b->unit_time_scale != nullptr ? 1 : 0;
+        {
+            int ex = 0;
+            if (!(U.tscale > 0.0) || std::frexp(U.tscale, &ex) != 0.5) return fail(e, TW_ERR_ARG, "unit_time_scale must be a positive power of two");
+        }
         U.n_in = (int32_t)n;
         U.E = E;
         U.ie_off = ie;
@@ -583,7 +590,7 @@ int tw_set_mixtures(tw_engine* e, const int32_t* mix_n, const double* mix_p) {
     HIPCHK(hipMemcpyAsync(e->mix_n_dev, mix_n, sizeof(int32_t) * e->n_slots, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->mix_p_dev, mix_p, sizeof(double) * e->n_slots * kMaxComp * 3, hipMemcpyHostToDevice, e->stream));
     const int64_t total = e->n_slots * kMaxComp;
-    hipLaunchKernelGGL(k_mix_consts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, (const double*)e->mix_p_dev, e->mix_c_dev, total);
+    hipLaunchKernelGGL(k_mix_consts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, (const double*)e->mix_p_dev, (const int32_t*)e->mix_n_dev, (const int32_t*)e->slot_unit, e->P.units, e->mix_c_dev, total);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     e->state = ST_MIX;
@@ -625,7 +632,7 @@ int tw_fit_mixtures(tw_engine* e) {
     hipLaunchKernelGGL(k_fit_em, dim3((unsigned)(e->n_slots * kMaxComp)), dim3(e->coop >= 64 ? kFitThreads : e->coop), 0, e->stream, F);
     hipLaunchKernelGGL(k_fit_select, dim3((unsigned)((e->n_slots + 63) / 64)), dim3(64), 0, e->stream, F);
     const int64_t total = e->n_slots * kMaxComp;
-    hipLaunchKernelGGL(k_mix_consts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, (const double*)e->mix_p_dev, e->mix_c_dev, total);
+    hipLaunchKernelGGL(k_mix_consts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, (const double*)e->mix_p_dev, (const int32_t*)e->mix_n_dev, (const int32_t*)e->slot_unit, e->P.units, e->mix_c_dev, total);
     HIPCHK(hipEventRecord(e->ev[EV_END], e->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -685,6 +692,8 @@ int tw_get_gauss_params(tw_engine* e, double* gauss) {
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int64_t q = 0; q < e->n_gp; q++)
         for (int k = 0; k < 3; k++) gauss[q * 3 + k] = tmp[(size_t)q * 4 + k];
+    for (const UnitDev& U : e->units)  // the device keeps the means in timestamp units (k_block_params)
+        for (int64_t q = U.gp_off; q < U.gp_off + (int64_t)U.nblk * U.nslot; q++) gauss[q * 3] *= U.tscale;
     return TW_OK;
 }
 
@@ -844,7 +853,7 @@ int tw_assign_service(tw_engine* e, int32_t n_in, const int64_t* in_start, const
     tw_batch b;
     b.n_units = 1; b.unit_in_off = in_off; b.unit_E = &E; b.ep_off = out_off; b.dag = dag; b.key_rank = key_rank;
     b.in_start = in_start; b.in_end = in_end; b.out_start = out_start; b.out_end = out_end;
-    b.batch_size = 100; b.batch_size_mis = 30; b.topk = TW_TOPK;
+    b.batch_size = 100; b.batch_size_mis = 30; b.topk = TW_TOPK; b.unit_time_scale = nullptr;
     int rc = tw_load_batch(e, &b, 0);
     if (rc == TW_OK) rc = tw_run_pass1(e);
     if (rc == TW_OK && mix_n != nullptr) {

@@ -183,35 +183,65 @@ __global__ void k_block_params(Dev P, int64_t total) {
     }
     if (t1 == nullptr) { out[0] = out[1] = out[2] = out[3] = dnan(); return; }
     const int a = b * P.batch_size, z = min(a + P.batch_size, U.n_in), len = z - a;
-    int64_t s1 = 0, s2 = 0;
-    double bm[10];
+    double bm[10], mean;
     const int bs = (len + 9) / 10;
     int m = 0;
-    for (int kb = 0; kb < 10; kb++) {
-        const int st = kb * bs, en = min((kb + 1) * bs, len);
-        if (en - st <= 0) continue;
-        int64_t u1 = 0, u2 = 0;
-        for (int i = a + st; i < a + en; i++) { u1 += t1[i]; u2 += t2[i]; }
-        s1 += u1; s2 += u2;
-        bm[m++] = (double)(u2 - u1) / (double)(en - st);
+    if (!U.float_time) {  // integer microseconds: Python sums ints exactly, one correctly rounded division
+        int64_t s1 = 0, s2 = 0;
+        for (int kb = 0; kb < 10; kb++) {
+            const int st = kb * bs, en = min((kb + 1) * bs, len);
+            if (en - st <= 0) continue;
+            int64_t u1 = 0, u2 = 0;
+            for (int i = a + st; i < a + en; i++) { u1 += t1[i]; u2 += t2[i]; }
+            s1 += u1; s2 += u2;
+            bm[m++] = (double)(u2 - u1) / (double)(en - st);
+        }
+        mean = (double)(s2 - s1) / (double)len;
+    } else {  // load-scaled unit: Python's sum() over floats adds left to right in binary64 (helpers/transforms.py:21,30
+              // make every timestamp a float); the timestamps are exact images of those floats, and scaling by a power
+              // of two commutes with every rounding below, so the scale is applied once at the end
+        double s1 = 0.0, s2 = 0.0;
+        for (int kb = 0; kb < 10; kb++) {
+            const int st = kb * bs, en = min((kb + 1) * bs, len);
+            if (en - st <= 0) continue;
+            double u1 = 0.0, u2 = 0.0;
+            for (int i = a + st; i < a + en; i++) {
+                const double v1 = (double)t1[i], v2 = (double)t2[i];
+                u1 += v1; u2 += v2; s1 += v1; s2 += v2;
+            }
+            bm[m++] = (u2 - u1) / (double)(en - st);
+        }
+        mean = (s2 - s1) / (double)len;
     }
-    const double mean = (double)(s2 - s1) / (double)len;
     const double mu = np_sum(bm, m) / (double)m;
     double d2[10];
     for (int kb = 0; kb < m; kb++) { const double d = bm[kb] - mu; d2[kb] = d * d; }
     const double var = np_sum(d2, m) / (double)(m - 1);
-    const double sd = sqrt((double)bs) * sqrt(var);
+    const double sd = (sqrt((double)bs) * sqrt(var)) * U.tscale;  // in microseconds
     if (sd != sd) raise_err(P, TW_ERR_NAN_PARAMS);
     const double used = sd < 1.0e-12 ? 0.001 : sd;  // traceweaver_v1.py:130-131
-    out[0] = mean; out[1] = sd; out[2] = tw_log(used); out[3] = used;
+    // The scorer works on raw timestamp differences: y = (x*tscale - mean*tscale) / used == (x - mean) / (used / tscale)
+    // bit for bit when tscale is a power of two, so the mean stays in timestamp units and the divisor is rescaled;
+    // tw_get_gauss_params reports the mean in microseconds.
+    out[0] = mean; out[1] = sd; out[2] = tw_log(used); out[3] = used / U.tscale;
 }
 
-// Mixture constants for pass 2: [slot][comp] = mean, prec_chol, log(prec_chol), log(weight)
-__global__ void k_mix_consts(const double* mix_p, double* mix_c, int64_t total) {
+// Mixture constants for pass 2: [slot][comp] = mean * prec_chol, prec_chol * tscale, log(prec_chol), log(weight).
+// sklearn evaluates y = x * prec_chol - mean * prec_chol with x in microseconds; on raw timestamp differences
+// (x = d * tscale, tscale a power of two) d * (prec_chol * tscale) is the same binary64 number as (d * tscale) * prec_chol.
+// Slots without a mixture (n <= 0: the "(0,0)" fallback of traceweaver_v3.py:765-766, scored as a Gaussian with
+// mean 0 and std 0.001, traceweaver_v1.py:130-131) get those Gaussian constants in component 0.
+__global__ void k_mix_consts(const double* mix_p, const int32_t* mix_n, const int32_t* slot_unit, const UnitDev* units, double* mix_c, int64_t total) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
+    const int64_t slot = g / kMaxComp;
+    const double tscale = units[slot_unit[slot]].tscale;
+    if (mix_n[slot] <= 0) {
+        if (g % kMaxComp == 0) { mix_c[g * 4 + 0] = 0.0; mix_c[g * 4 + 1] = 0.001 / tscale; mix_c[g * 4 + 2] = tw_log(0.001); mix_c[g * 4 + 3] = 0.0; }
+        return;
+    }
     const double w = mix_p[g * 3 + 0], mu = mix_p[g * 3 + 1], pc = mix_p[g * 3 + 2];
-    mix_c[g * 4 + 0] = mu; mix_c[g * 4 + 1] = pc; mix_c[g * 4 + 2] = tw_log(pc); mix_c[g * 4 + 3] = tw_log(w);
+    mix_c[g * 4 + 0] = mu * pc; mix_c[g * 4 + 1] = pc * tscale; mix_c[g * 4 + 2] = tw_log(pc); mix_c[g * 4 + 3] = tw_log(w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -223,20 +253,18 @@ struct Scorer {
     const double* mix_c; // [nslot][kMaxComp][4]
 };
 
-__device__ __forceinline__ double term_gauss(double mean, double used, double logstd, int64_t t1, int64_t t2) {
-    const double x = (double)(t2 - t1);
+// x = t2 - t1 in timestamp units; mean in the same units, `used` = std / tscale (k_block_params)
+__device__ __forceinline__ double term_gauss(double mean, double used, double logstd, double x) {
     const double y = (x - mean) / used;
     return (-(y * y) / 2.0 - kLogSqrt2Pi) - logstd;  // scipy.stats.norm.logpdf
 }
 
 // not inlined: the mixture term is ~1.5k instructions and is called from several places per kernel; keeping one
 // copy keeps the enumeration kernels inside the instruction cache
-__device__ __noinline__ double term_mix(int n, const double* c, int64_t t1, int64_t t2) {
-    const double x = (double)(t2 - t1);
+__device__ __noinline__ double term_mix(int n, const double* c, double x) {
     double a[kMaxComp], amax = -dinf();
     for (int k = 0; k < n; k++) {
-        const double mu = c[k * 4 + 0], pc = c[k * 4 + 1];
-        const double y = x * pc - mu * pc;
+        const double y = x * c[k * 4 + 1] - c[k * 4 + 0];  // x_us * prec_chol - mean * prec_chol (k_mix_consts)
         const double lp = y * y;
         a[k] = (-0.5 * (kLog2Pi + lp) + c[k * 4 + 2]) + c[k * 4 + 3];  // sklearn _estimate_weighted_log_prob
         if (a[k] > amax) amax = a[k];
@@ -249,13 +277,15 @@ __device__ __noinline__ double term_mix(int n, const double* c, int64_t t1, int6
 }
 
 __device__ __forceinline__ double score_term(const Scorer& S, int slot, int64_t t1, int64_t t2) {
+    const double x = (double)(t2 - t1);
     if (S.pass == 1) {
         const double* g = S.gp + slot * 4;
-        return term_gauss(g[0], g[3], g[2], t1, t2);
+        return term_gauss(g[0], g[3], g[2], x);
     }
     const int n = S.mix_n[slot];
-    if (n <= 0) return term_gauss(0.0, 0.001, tw_log(0.001), t1, t2);  // "(0,0)" fallback, traceweaver_v3.py:765-766
-    return term_mix(n, S.mix_c + (int64_t)slot * kMaxComp * 4, t1, t2);
+    const double* c = S.mix_c + (int64_t)slot * kMaxComp * 4;
+    if (n <= 0) return term_gauss(c[0], c[1], c[2], x);  // "(0,0)" fallback, traceweaver_v3.py:765-766 (constants from k_mix_consts)
+    return term_mix(n, c, x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2237,13 +2267,13 @@ __global__ void k_gaps(Dev P) {
     for (int e = 0; e < E; e++) {
         const bool have = x[e] >= 0;
         const int64_t st = have ? P.out_start[U.ep_off[e] + x[e]] : 0, en = have ? P.out_end[U.ep_off[e] + x[e]] : 0;
-        if (U.npred[e] == 0) out[(int64_t)slot_root(E, e) * U.n_in + i] = have ? (double)(st - ist) : dnan();
+        if (U.npred[e] == 0) out[(int64_t)slot_root(E, e) * U.n_in + i] = have ? (double)(st - ist) * U.tscale : dnan();
         for (int j = 0; j < U.npred[e]; j++) {
             if (!U.pred_prim[e][j]) continue;
             const int p = U.pred_list[e][j];
-            out[(int64_t)slot_prim(E, p, e) * U.n_in + i] = (have && x[p] >= 0) ? (double)(st - P.out_end[U.ep_off[p] + x[p]]) : dnan();
+            out[(int64_t)slot_prim(E, p, e) * U.n_in + i] = (have && x[p] >= 0) ? (double)(st - P.out_end[U.ep_off[p] + x[p]]) * U.tscale : dnan();
         }
-        out[(int64_t)slot_close(E, e) * U.n_in + i] = have ? (double)(ien - en) : dnan();
+        out[(int64_t)slot_close(E, e) * U.n_in + i] = have ? (double)(ien - en) * U.tscale : dnan();
     }
 }
 

@@ -21,7 +21,10 @@ class UnitArrays(object):
     """Structure-of-arrays form of one unit: endpoints in topological order of the call-order DAG
     (traceweaver_v1.py:37-39), every span list sorted by (start, end) (executor.py:1112)."""
 
-    def __init__(self, in_start, in_end, out_off, out_start, out_end, dag, key_rank=None):
+    def __init__(self, in_start, in_end, out_off, out_start, out_end, dag, key_rank=None, time_scale=None):
+        # time_scale: None = int64 microseconds.  A power of two = the timestamps are exact images of binary64
+        # values in units of time_scale microseconds (load-scaled units, traceweaver_amd.transforms).
+        self.time_scale = None if time_scale is None else float(time_scale)
         self.in_start = np.ascontiguousarray(in_start, dtype=np.int64)
         self.in_end = np.ascontiguousarray(in_end, dtype=np.int64)
         self.out_off = np.ascontiguousarray(out_off, dtype=np.int64)
@@ -94,10 +97,14 @@ class Engine(object):
             "out_start": np.concatenate([u.out_start for u in units]),
             "out_end": np.concatenate([u.out_end for u in units]),
         }
+        scaled = [u.time_scale is not None for u in units]
+        if any(scaled) and not all(scaled):
+            raise ValueError("a batch holds either integer-microsecond units or load-scaled units, not both")
+        arrays["unit_time_scale"] = np.array([u.time_scale for u in units], dtype=np.float64) if all(scaled) else None
         self._keep = arrays
         b = _ffi.Batch(len(units), *[_vp(arrays[k]) for k in (
             "unit_in_off", "unit_E", "ep_off", "dag", "key_rank", "in_start", "in_end", "out_start", "out_end")],
-            batch_size, batch_size_mis, _ffi.TW_TOPK)
+            batch_size, batch_size_mis, _ffi.TW_TOPK, _vp(arrays["unit_time_scale"]))
         self._check(self._lib.tw_load_batch(self._h, ctypes.byref(b), 0))
         self._in_off = in_off
         self._ie_off = np.concatenate([[0], np.cumsum([u.n_in * u.E for u in units])]).astype(np.int64)

@@ -15,9 +15,15 @@ accuracy reductions.
 
 Indices 3 (WAP5), 4 (FCFS), 5 (ArrivalOrder) and 7 (vPath) run as host baselines (traceweaver_amd/baselines.py,
 identical to the reference's classes) and add their columns to the same files -- `exps/exp1`'s "3,4,7,10" runs as is.
+`--compress_factor N` (N > 1) applies the reference's load scaling (helpers/transforms.py:10-40, executor.py:1086-1097,
+1146-1148) to every service before it is solved: per-service load factor max(1, ceil(N / #replicas)) with the replica
+table read from data/misc/service_to_replica_new.pickle under the project root (executor.py:912), timestamps handed to
+the engine as exact images of the reference's floats (traceweaver_amd/transforms.py).  `--repeat_factor` is accepted and,
+as in the reference (repeat_change_spans never reads it), only shows up in the result file names.
 What it does not do (and says so instead of approximating): the other predictor indices (the older TraceWeaver
-variants 0-2, 6, 8, 9), the cache-hit / load / repeat transforms (--cache_rate > 0, --compress_factor != 1, --repeat_factor != 1), --parallel / --instrumented, tar
-archives (--compressed 1).  For those keep the reference's executor and register the predictor.
+variants 0-2, 6, 8, 9), cache-hit injection (--cache_rate > 0: skip mode), the host baselines together with load
+scaling, --parallel / --instrumented, tar archives (--compressed 1).  For those keep the reference's executor and
+register the predictor.
 The mixture refit between the passes is the deterministic device refit, so figures agree with a reference run to
 within the run-to-run spread the reference itself has (its k-means++ start is drawn from an unseeded RNG,
 SURVEY.md hazard H9), not digit for digit.
@@ -55,6 +61,8 @@ def parse_args(argv=None):
     # additions (defaults keep the reference's behaviour)
     ap.add_argument("--project_root", type=q, default=os.getcwd(), help="what --relative_path is relative to")
     ap.add_argument("--max_traces", type=int, default=1001, help="the reference's literal limit (executor.py:873); 0 = all")
+    ap.add_argument("--replicas_file", type=q, default=None,
+                    help="pickle {service: [replica ids]} for --compress_factor > 1 (default: data/misc/service_to_replica_new.pickle under --project_root, executor.py:912)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--engine_library", type=q, default=None, help=argparse.SUPPRESS)   # tests: host-emulation build
     args = ap.parse_args(argv)
@@ -81,11 +89,33 @@ def unsupported(args):
         problems.append("--compressed 1")
     if args.cache_rate != 0:
         problems.append("--cache_rate %g (cache-hit injection = skip mode)" % args.cache_rate)
-    if args.compress_factor != 1 or args.repeat_factor != 1:
-        problems.append("--compress_factor / --repeat_factor != 1 (load transforms)")
+    if args.compress_factor > 1 and any(i in BASELINES for i in requested(args)):
+        problems.append("--compress_factor > 1 together with the host baselines 3, 4, 5, 7 (only index 10 runs on load-scaled units)")
     if args.parallel or args.instrumented:
         problems.append("--parallel / --instrumented")
     return problems
+
+
+def scale_load(units, args, trace_id):
+    """Load scaling of every unit (helpers/transforms.py:10-40) with the per-service factor of executor.py:1086-1097."""
+    from . import transforms
+    from .ingest import IngestedUnit
+
+    path = args.replicas_file or os.path.join(args.project_root, "data/misc/service_to_replica_new.pickle")
+    if not os.path.exists(path):
+        raise SystemExit("--compress_factor %g needs the replica table %s ({service: [replica ids]}, executor.py:912)" % (args.compress_factor, path))
+    with open(path, "rb") as f:
+        replicas = pickle.load(f)
+    out = []
+    for u in units:
+        if u.service not in replicas:
+            raise SystemExit("service %s is not in the replica table %s (the reference stops here too, executor.py:1098-1101)" % (u.service, path))
+        factor = transforms.load_factor(args.compress_factor, len(replicas[u.service]))
+        print("Process: %s  replicas: %d  dynamic load factor: %d" % (u.service, len(replicas[u.service]), factor))
+        s = transforms.compress_unit(u.arrays, u.true_parent, factor, trace_key=[trace_id(t) for t in u.in_trace])
+        out.append(IngestedUnit(s.arrays, s.true_parent, u.in_trace[s.in_perm], u.service, u.in_ep, u.out_eps, u.in_rows[s.in_perm],
+                                [r[p] for r, p in zip(u.out_rows, s.out_perm)], u.process_id))
+    return out
 
 
 def run(args):
@@ -108,6 +138,8 @@ def run(args):
     table = corpus.span_table()
     names = corpus.trace_names()
     trace_id = lambda k: corpus.string(names[k])
+    if args.compress_factor > 1:                                   # executor.py:1086-1097,1146-1148
+        units = scale_load(units, args, trace_id)
     key = lambda row: (trace_id(table["trace"][row]), corpus.string(table["span_id"][row]))
     seen = np.zeros(n_traces, dtype=bool)
     for u in units:
@@ -206,7 +238,7 @@ def main(argv=None):
     args = parse_args(argv)
     problems = unsupported(args)
     if problems:
-        sys.exit("traceweaver_amd.executor runs predictor 10 (%s) and the baselines 3, 4, 5, 7 without transforms; not supported here: %s.\n"
+        sys.exit("traceweaver_amd.executor runs predictor 10 (%s, with or without load scaling) and the baselines 3, 4, 5, 7; not supported here: %s.\n"
                  "Use the reference's executor with TraceWeaverGPU registered in its predictor table (INTEGRATION.md section 2)."
                  % (METHOD, "; ".join(problems)))
     run(args)

@@ -26,14 +26,19 @@ def pack_unit(in_spans, out_span_partitions, out_eps, invocation_graph):
     """SoA form of one FindAssignments call.  `out_eps` = topological order (traceweaver_v1.py:37-39)."""
     E = len(out_eps)
     n_in = len(in_spans)
-    in_start = np.fromiter((s.start_mus for s in in_spans), dtype=np.int64, count=n_in)
-    in_dur = np.fromiter((s.duration_mus for s in in_spans), dtype=np.int64, count=n_in)
+    # After the executor's load scaling (helpers/transforms.py:10-40, --compress_factor > 1) start_mus is a Python float;
+    # such a unit goes to the engine as the exact integer image of those floats (traceweaver_amd/transforms.py).
+    scaled = any(isinstance(s.start_mus, float) for s in in_spans[:1]) or any(
+        isinstance(s.start_mus, float) for ep in out_eps for s in out_span_partitions[ep][:1])
+    tdt = np.float64 if scaled else np.int64
+    in_start = np.fromiter((s.start_mus for s in in_spans), dtype=tdt, count=n_in)
+    in_dur = np.fromiter((s.duration_mus for s in in_spans), dtype=tdt, count=n_in)
     out_off = np.zeros(E + 1, dtype=np.int64)
     starts, ends = [], []
     for k, ep in enumerate(out_eps):
         spans = out_span_partitions[ep]
-        st = np.fromiter((s.start_mus for s in spans), dtype=np.int64, count=len(spans))
-        du = np.fromiter((s.duration_mus for s in spans), dtype=np.int64, count=len(spans))
+        st = np.fromiter((s.start_mus for s in spans), dtype=tdt, count=len(spans))
+        du = np.fromiter((s.duration_mus for s in spans), dtype=tdt, count=len(spans))
         starts.append(st)
         ends.append(st + du)
         out_off[k + 1] = out_off[k] + len(spans)
@@ -44,6 +49,11 @@ def pack_unit(in_spans, out_span_partitions, out_eps, invocation_graph):
                 dag[a, b] = 1
     keys = list(out_span_partitions.keys())  # networkx in_edges() order = FindOrder's insertion order (executor.py:223-236)
     key_rank = np.array([keys.index(ep) for ep in out_eps], dtype=np.int32)
+    if scaled:
+        from .transforms import to_exact_units
+
+        (i_s, i_e, o_s, o_e), scale = to_exact_units([in_start, in_start + in_dur, np.concatenate(starts), np.concatenate(ends)])
+        return UnitArrays(i_s, i_e, out_off, o_s, o_e, dag, key_rank, time_scale=scale)
     return UnitArrays(in_start, in_start + in_dur, out_off, np.concatenate(starts), np.concatenate(ends), dag, key_rank)
 
 
@@ -99,14 +109,15 @@ class TraceWeaverGPU(object):
         """Host-side gap samples for an arbitrary assignment (only used to replay the true-assignment fits)."""
         E, n = unit.E, unit.n_in
         ok = parent[0] >= 0
+        us = 1.0 if unit.time_scale is None else unit.time_scale   # microseconds per timestamp unit (exact: a power of two)
         if q < E:
             e = q
-            return (unit.out_start[unit.out_off[e] + parent[e][ok]] - unit.in_start[ok]).astype(np.float64)
+            return (unit.out_start[unit.out_off[e] + parent[e][ok]] - unit.in_start[ok]).astype(np.float64) * us
         if q < E + E * E:
             p, e = divmod(q - E, E)
-            return (unit.out_start[unit.out_off[e] + parent[e][ok]] - unit.out_end[unit.out_off[p] + parent[p][ok]]).astype(np.float64)
+            return (unit.out_start[unit.out_off[e] + parent[e][ok]] - unit.out_end[unit.out_off[p] + parent[p][ok]]).astype(np.float64) * us
         e = q - E - E * E
-        return (unit.in_end[ok] - unit.out_end[unit.out_off[e] + parent[e][ok]]).astype(np.float64)
+        return (unit.in_end[ok] - unit.out_end[unit.out_off[e] + parent[e][ok]]).astype(np.float64) * us
 
     # ------------------------------------------------------------------------------------------
     def FindAssignments(self, method, process, in_span_partitions, out_span_partitions, parallel, instrumented_hops,
