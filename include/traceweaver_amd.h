@@ -197,8 +197,8 @@ int tw_assign_service(tw_engine *e, int32_t n_in, const int64_t *in_start, const
  * (executor.py:287-339), ParseJsonTrace / ParseSpansJson / ParseProcessesJson(2) (executor.py:342-384,451-461,
  * 755-793), ProcessTraceData (executor.py:795-849), PartitionSpansByEndPoint (executor.py:1104-1113),
  * GetGroundTruth (helpers/utils.py:22-32), FindOrder + nx.topological_sort (executor.py:214-285,
- * traceweaver_v1.py:37-39), FixSpans / FixSpans2 (executor.py:505-537,542-645).  The self-loop renaming applied to
- * the Alibaba parser output (executor.py:386-448) is not reproduced.  Names are interned: every *_name / service / span_id field below is a string id for
+ * traceweaver_v1.py:37-39), FixSpans / FixSpans2 (executor.py:505-537,542-645) and the rewrite of the Alibaba parser
+ * output (executor.py:377-448).  Names are interned: every *_name / service / span_id field below is a string id for
  * tw_corpus_string(). */
 typedef struct tw_corpus tw_corpus;
 int tw_corpus_create(tw_corpus **out);
@@ -215,14 +215,25 @@ int tw_corpus_add_files(tw_corpus *c, const char *const *paths, int32_t n_paths,
                         int64_t max_traces, int32_t n_threads, int32_t fix);
 
 /* `fix` = the span surgery the reference applies to some of its corpora before the walk (executor.py:776-779):
- *   TW_FIX_NONE          plain Jaeger exports (hotel; --fix 2..5)
+ *   TW_FIX_NONE          plain Jaeger exports (hotel; --fix 2..4)
  *   TW_FIX_CLIENT_TWINS  FixSpans (executor.py:505-537; nodejs, --fix 0): every hop is logged once, as a server span;
  *                        each gets a client twin "<id>_client" in the calling service, which is looked up in the
  *                        static service -> caller map given with tw_corpus_set_callers (executor.py:109-115)
  *   TW_FIX_REROOT        FixSpans2 (executor.py:542-645; media, --fix 1): the span named first_span becomes the root,
  *                        same-process children are dropped, every remaining hop gets a client twin in its parent's
- *                        process, spans are ordered by start time */
-enum { TW_FIX_NONE = 0, TW_FIX_CLIENT_TWINS = 1, TW_FIX_REROOT = 2 };
+ *                        process, spans are ordered by start time
+ *   TW_FIX_RPC_TWINS     ParseSpansJson with first_span == None (executor.py:377-448; --fix 5, the output of
+ *                        alibaba-analysis/real-parser.py): every call is logged twice under one rpc id, as a server record in
+ *                        the callee and a client record in the caller; the client record becomes "<rpc id>.client" and
+ *                        the server record is re-pointed at it; a service that calls itself gets a stand-in callee
+ *                        "<callee>@<rpc id>-loop" (the reference draws a random name ending in "-loop"), one per rpc id
+ *                        for the whole corpus, traces visited in time order; traces in which a child span is not
+ *                        contained in its parent are dropped (counted as filtered) */
+enum { TW_FIX_NONE = 0, TW_FIX_CLIENT_TWINS = 1, TW_FIX_REROOT = 2, TW_FIX_RPC_TWINS = 3 };
+/* serviceLoopMap (executor.py:396): the service a "...-loop" stand-in was split from (its replica count is what the
+ * load factor of executor.py:1092-1096 uses), NULL if `service` is not a stand-in. */
+const char *tw_corpus_loop_origin(const tw_corpus *c, const char *service);
+/* The static service -> caller map of TW_FIX_CLIENT_TWINS. */
 int tw_corpus_set_callers(tw_corpus *c, const char *const *service, const char *const *caller, int32_t n);
 
 /* out6 = spans held, traces held, files seen, files that failed to parse, traces filtered out, strings. */

@@ -17,7 +17,9 @@ class Span(object):
     """The attributes the baseline classes read (reference spans.py:1-75)."""
 
     def __init__(self, trace_id, sid, start, dur, kind):
-        self.trace_id, self.sid, self.start_mus, self.duration_mus, self.span_kind = trace_id, sid, int(start), int(dur), kind
+        # after the executor's load scaling start_mus is a float (helpers/transforms.py:21,30); durations stay ints
+        self.trace_id, self.sid, self.duration_mus, self.span_kind = trace_id, sid, int(dur), kind
+        self.start_mus = float(start) if isinstance(start, float) else int(start)
 
     def GetId(self):
         return (self.trace_id, self.sid)
@@ -38,11 +40,17 @@ def reference_classes():
 def protocol_inputs(u, trace_of_in, trace_of_out):
     """Partitions in partition-key order, as the executor hands them to a predictor."""
     a = u.arrays
-    in_spans = [Span(trace_of_in[i], "in%d" % i, a.in_start[i], a.in_end[i] - a.in_start[i], "server") for i in range(a.n_in)]
+    if a.time_scale is None:
+        i_s, i_d, o_s, o_d = a.in_start, a.in_end - a.in_start, a.out_start, a.out_end - a.out_start
+    else:   # a load-scaled unit: the float starts it is the exact image of, the integer durations
+        i_s, o_s = a.in_start * a.time_scale, a.out_start * a.time_scale
+        i_d, o_d = np.rint((a.in_end - a.in_start) * a.time_scale), np.rint((a.out_end - a.out_start) * a.time_scale)
+        assert np.array_equal(i_s + i_d, a.in_end * a.time_scale) and np.array_equal(o_s + o_d, a.out_end * a.time_scale)
+    in_spans = [Span(trace_of_in[i], "in%d" % i, i_s[i], i_d[i], "server") for i in range(a.n_in)]
     parts, keys = {}, [int(k) for k in np.argsort(a.key_rank, kind="stable")]
     for e in keys:
         o0, o1 = int(a.out_off[e]), int(a.out_off[e + 1])
-        parts[u.out_eps[e]] = [Span(trace_of_out[e][j], "o%d_%d" % (e, j), a.out_start[o0 + j], a.out_end[o0 + j] - a.out_start[o0 + j], "client")
+        parts[u.out_eps[e]] = [Span(trace_of_out[e][j], "o%d_%d" % (e, j), o_s[o0 + j], o_d[o0 + j], "client")
                                for j in range(o1 - o0)]
     truth = {u.out_eps[e]: {in_spans[i].GetId(): parts[u.out_eps[e]][u.true_parent[e, i]].GetId() for i in range(a.n_in)} for e in keys}
     return {u.in_ep: in_spans}, parts, truth
@@ -136,4 +144,30 @@ def test_baselines_on_reference_corpora(emu_lib, rel, fix):
     c.add_directory("/root/reference/data/" + rel, first_span=first, max_traces=1001, fix=surgery)
     units, _, _ = c.units()
     check_units(units)
+    c.close()
+
+
+def _scaled(units, factor):
+    """The units after the executor's load scaling (traceweaver_amd/transforms.py)."""
+    from traceweaver_amd import transforms
+    from traceweaver_amd.ingest import IngestedUnit
+
+    out = []
+    for u in units:
+        s = transforms.compress_unit(u.arrays, u.true_parent, factor, trace_key=["t%d" % k for k in u.in_trace])
+        out.append(IngestedUnit(s.arrays, s.true_parent, u.in_trace[s.in_perm], u.service, u.in_ep, u.out_eps, u.in_rows[s.in_perm],
+                                [r[p] for r, p in zip(u.out_rows, s.out_perm)], u.process_id))
+    return out
+
+
+@pytest.mark.parametrize("factor", [3, 7])
+def test_baselines_on_load_scaled_units(emu_lib, tmp_path, factor):
+    """--compress_factor > 1 hands the reference's classes float timestamps; ours read the exact integer image of them."""
+    synth.write_jaeger_corpus(str(tmp_path), 29, 300, app=synth.HOTEL_APP, concurrency=1.2)
+    c = Corpus(lib_path=emu_lib)
+    c.add_directory(str(tmp_path), first_span="HTTP GET /hotels", max_traces=0)
+    units = _scaled(c.units()[0], factor)
+    assert all(u.arrays.time_scale < 1.0 for u in units)
+    check_units(units)
+    check_wap5(units)
     c.close()

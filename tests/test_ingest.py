@@ -2,6 +2,7 @@
 the reference's executor does between reading a directory and calling the predictor (executor.py:287-339,
 755-849,1080-1135; helpers/utils.py:22-32) on generated corpora, and (b) the inputs frozen from the reference
 itself for every shipped corpus (tests/golden/ref_*; needs /root/reference for the JSON files)."""
+import glob
 import json
 import os
 
@@ -201,3 +202,67 @@ def test_json_to_assignment_end_to_end_emulated(emu_lib, tmp_path):
 @pytest.mark.gpu
 def test_json_to_assignment_end_to_end_gpu(tmp_path):
     reconstruct(None, tmp_path)
+
+
+# ------------------------------------------------------------------------------------------------
+# --fix 5: the output shape of alibaba-analysis/real-parser.py (rpc-id span ids, a server + a client record per call,
+# self-calls split off as "...-loop" services, traces breaking containment dropped) -- executor.py:377-448.
+# tests/golden/refali_*.npz: the unmodified reference parsed a generated corpus of that shape and ran predictor 10
+# (oracle/refrun/gen_golden_alibaba.py); the corpus is regenerated here from the recorded seed.
+ALI = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refali_*.npz")))
+
+
+def _ali_cases():
+    names = sorted({os.path.basename(p)[len("refali_"):].rsplit("__", 1)[0] for p in ALI})
+    return [(n, [p for p in ALI if os.path.basename(p).startswith("refali_%s__" % n)]) for n in names]
+
+
+def _same_service(mine, ref):
+    return mine == ref or (mine.endswith("-loop") and ref.endswith("-loop"))   # the reference draws that name at random
+
+
+@pytest.mark.parametrize("name,files", _ali_cases(), ids=[c[0] for c in _ali_cases()])
+def test_alibaba_parser_shape_matches_the_reference_inputs(emu_lib, tmp_path, name, files):
+    from traceweaver_amd import transforms
+
+    gs = sorted((np.load(p) for p in files), key=lambda g: int(g["service_order"]))
+    seed, n_traces = (int(x) for x in gs[0]["corpus"])
+    conc, viol = (float(x) for x in gs[0]["corpus_params"])
+    factor = int(gs[0]["compress_factor"])
+    replicas = dict(zip((str(s) for s in gs[0]["replica_names"]), (int(r) for r in gs[0]["replica_counts"])))
+    synth.write_alibaba_corpus(str(tmp_path), seed, n_traces, concurrency=conc, violations=viol)
+    c = Corpus(lib_path=emu_lib)
+    counts = c.add_directory(str(tmp_path), first_span=None, max_traces=1001, fix="rpc_twins")
+    assert counts["files_rejected"] == 0 and counts["traces_filtered"] > 0 and counts["traces"] == len(gs[0]["in_start"])
+    units, skipped, _ = c.units()
+    assert sum(skipped.values()) == 0
+    loops = [u for u in units if u.service.endswith("-loop")]
+    assert len(loops) == 1 and c.loop_origin(loops[0].service) == "cart" and c.loop_origin("cart") is None
+    if factor == 1:
+        assert len(units) == len(gs)                          # the same services reach the predictor, in the same order
+    names = c.trace_names()
+    table = c.span_table()
+    for g in gs:
+        u = units[int(g["service_order"])]
+        assert _same_service(u.service, str(g["process"])) and u.process_id == int(g["service_order"])
+        assert len(u.out_eps) == len(g["out_eps"]) and all(_same_service(a, str(b)) for a, b in zip(u.out_eps, g["out_eps"]))
+        assert _same_service(u.in_ep, str(g["in_ep"]))
+        tids = [c.string(names[t]) for t in u.in_trace]
+        a, truth = u.arrays, u.true_parent
+        if factor > 1:                                        # executor.py:1086-1097 + helpers/transforms.py:10-40
+            f = transforms.load_factor(factor, replicas[c.loop_origin(u.service) or u.service])
+            s = transforms.compress_unit(a, truth, f, trace_key=tids)
+            assert np.array_equal(s.in_start, g["in_start"]) and np.array_equal(s.out_start, g["out_start"])   # the reference's floats
+            a, truth, tids = s.arrays, s.true_parent, [tids[i] for i in s.in_perm]
+            in_sid = [c.string(table["span_id"][r]) for r in u.in_rows[s.in_perm]]
+            assert np.array_equal(a.in_end - a.in_start, (g["in_dur"] / a.time_scale).astype(np.int64))
+        else:
+            in_sid = [c.string(table["span_id"][r]) for r in u.in_rows]
+            assert np.array_equal(a.in_start, g["in_start"]) and np.array_equal(a.in_end - a.in_start, g["in_dur"])
+            assert np.array_equal(a.out_start, g["out_start"]) and np.array_equal(a.out_end - a.out_start, g["out_dur"])
+        assert np.array_equal(a.out_off, g["out_off"]) and np.array_equal(a.dag, g["dag"])
+        assert tids == [str(t) for t in g["in_trace_id"]] and in_sid == [str(x) for x in g["in_span_id"]]
+        assert np.array_equal(truth, g["true_parent"])
+        order = [str(x) for x in g["partition_key_order"]]
+        assert a.key_rank.tolist() == [order.index(str(e)) for e in g["out_eps"]]
+    c.close()

@@ -54,7 +54,7 @@ EXPORTS = ["tw_create", "tw_destroy", "tw_last_error", "tw_load_batch", "tw_run_
            "tw_set_mixtures", "tw_fit_mixtures", "tw_get_mixtures", "tw_run_pass2", "tw_get_results", "tw_get_gauss_params", "tw_get_timing",
            "tw_assign_service", "tw_find_order", "tw_set_truth", "tw_evaluate",
            "tw_corpus_create", "tw_corpus_destroy", "tw_corpus_last_error", "tw_corpus_add_files", "tw_corpus_set_callers", "tw_corpus_counts",
-           "tw_corpus_string", "tw_corpus_trace_names", "tw_corpus_span_table", "tw_corpus_build_units"]
+           "tw_corpus_string", "tw_corpus_loop_origin", "tw_corpus_trace_names", "tw_corpus_span_table", "tw_corpus_build_units"]
 
 
 def load(path=None):
@@ -95,10 +95,12 @@ def load(path=None):
     lib.tw_corpus_counts.argtypes = [vp, vp]
     lib.tw_corpus_string.argtypes = [vp, ctypes.c_int32]
     lib.tw_corpus_string.restype = ctypes.c_char_p
+    lib.tw_corpus_loop_origin.argtypes = [vp, ctypes.c_char_p]
+    lib.tw_corpus_loop_origin.restype = ctypes.c_char_p
     lib.tw_corpus_trace_names.argtypes = [vp, vp]
     lib.tw_corpus_span_table.argtypes = [vp, ctypes.POINTER(SpanTable)]
     lib.tw_corpus_build_units.argtypes = [vp, ctypes.POINTER(UnitSet)]
     for name in EXPORTS:
-        if name not in ("tw_destroy", "tw_last_error", "tw_corpus_destroy", "tw_corpus_last_error", "tw_corpus_string"):
+        if name not in ("tw_destroy", "tw_last_error", "tw_corpus_destroy", "tw_corpus_last_error", "tw_corpus_string", "tw_corpus_loop_origin"):
             getattr(lib, name).restype = ctypes.c_int
     return lib

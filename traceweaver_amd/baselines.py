@@ -13,6 +13,20 @@ reference iterates in).  Output: parent [E, n_in] int32 in the unit's endpoint o
 import numpy as np
 
 
+def _times(unit):
+    """(in_start, in_end, out_start, out_end, in_dur, num): the timestamps as the reference's classes see them -- int64
+    microseconds, or for a load-scaled unit (traceweaver_amd/transforms.py) the float64 values they are exact images of;
+    `num` turns one of them into the Python number the reference computes with; durations stay the integers they were."""
+    scale = getattr(unit, "time_scale", None)
+    if scale is None:
+        return unit.in_start, unit.in_end, unit.out_start, unit.out_end, unit.in_end - unit.in_start, int
+    f = lambda a: a.astype(np.float64) * scale
+    in_dur = getattr(unit, "in_dur", None)
+    if in_dur is None:
+        in_dur = np.rint(f(unit.in_end - unit.in_start)).astype(np.int64)
+    return f(unit.in_start), f(unit.in_end), f(unit.out_start), f(unit.out_end), in_dur, float
+
+
 def _key_order(unit):
     return [int(k) for k in np.argsort(unit.key_rank, kind="stable")]   # endpoints as out_span_partitions.items() yields them
 
@@ -30,8 +44,9 @@ def arrival_order(unit):
     n = unit.n_in
     parent = np.full((unit.E, n), -1, dtype=np.int32)
     eps = _key_order(unit)
+    _, _, out_start, out_end, _, num = _times(unit)
     # GetOutEpsInOrder (helpers/utils.py:15-21): endpoints by the start of their first span (list.sort is stable)
-    o_eps = sorted(eps, key=lambda e: int(unit.out_start[unit.out_off[e]]))
+    o_eps = sorted(eps, key=lambda e: num(out_start[unit.out_off[e]]))
     prev = None   # indices (into the previous endpoint's list) in the order they are handed out
     for pos, e in enumerate(o_eps):
         m = int(unit.out_off[e + 1] - unit.out_off[e])
@@ -39,7 +54,7 @@ def arrival_order(unit):
             order = np.arange(m)
         else:
             pe = o_eps[pos - 1]
-            ends = unit.out_end[unit.out_off[pe]:unit.out_off[pe + 1]][prev]
+            ends = out_end[unit.out_off[pe]:unit.out_off[pe + 1]][prev]
             sort_order = list(np.argsort(ends))                      # arrival_order.py:40 (numpy's default sort, as there)
             if len(prev) <= m:
                 sort_order = sort_order[:m] + list(range(len(prev), m))
@@ -57,9 +72,10 @@ def vpath(unit, true_parent):
     call belongs to (vpath.py:42-46,81-84)."""
     n, E = unit.n_in, unit.E
     eps = _key_order(unit)
+    in_start, in_end, out_start, out_end, _, _ = _times(unit)
     t, key, kind, idx, epv = [], [], [], [], []
     # construction order of vpath.py:52-62: incoming spans (request, response), then every endpoint's calls
-    t += [unit.in_start, unit.in_end]; key += [np.full(n, 1), np.full(n, 4)]; kind += [np.zeros(n, int), np.ones(n, int)]
+    t += [in_start, in_end]; key += [np.full(n, 1), np.full(n, 4)]; kind += [np.zeros(n, int), np.ones(n, int)]
     idx += [np.arange(n), np.arange(n)]; epv += [np.full(n, -1), np.full(n, -1)]
     # (request and response of one span are adjacent in the reference's list; interleave below)
     seq = [np.arange(n) * 2, np.arange(n) * 2 + 1]
@@ -68,7 +84,7 @@ def vpath(unit, true_parent):
     for e in eps:
         a, b = int(unit.out_off[e]), int(unit.out_off[e + 1])
         m = b - a
-        t += [unit.out_start[a:b], unit.out_end[a:b]]; key += [np.full(m, 2), np.full(m, 3)]
+        t += [out_start[a:b], out_end[a:b]]; key += [np.full(m, 2), np.full(m, 3)]
         kind += [np.full(m, 2), np.full(m, 3)]; idx += [np.arange(m), np.arange(m)]; epv += [np.full(m, e), np.full(m, e)]
         seq += [base + np.arange(m) * 2, base + np.arange(m) * 2 + 1]
         base += 2 * m
@@ -125,13 +141,14 @@ class WAP5(object):
         import statistics
 
         n, E = unit.n_in, unit.E
-        large_delay = int((unit.in_end - unit.in_start).max())
+        in_start, _, out_start, _, in_dur, num = _times(unit)
+        large_delay = int(in_dur.max())
         options = [[[] for _ in range(n)] for _ in range(E)]
         for e in _key_order(unit):                                   # for out_ep in out_span_partitions.keys()
             a, b = int(unit.out_off[e]), int(unit.out_off[e + 1])
             m = b - a
             # spans = incoming + outgoing of this endpoint, stable sort by start (incoming first on ties)
-            start = np.concatenate([unit.in_start, unit.out_start[a:b]])
+            start = np.concatenate([in_start, out_start[a:b]])
             is_client = np.concatenate([np.zeros(n, bool), np.ones(m, bool)])
             idx = np.concatenate([np.arange(n), np.arange(m)])
             order = np.argsort(start, kind="stable")
@@ -139,12 +156,12 @@ class WAP5(object):
             values = self.distribution_values.setdefault(ep_names[e], [])
             # BuildDistributions: delay to the nearest preceding incoming span, if within the longest request duration
             for i in np.flatnonzero(is_client):
-                sent = int(start[i])
+                sent = num(start[i])
                 for j in range(i - 1, -1, -1):
-                    if sent - int(start[j]) > large_delay:
+                    if sent - num(start[j]) > large_delay:
                         break
                     if not is_client[j]:
-                        values.append(sent - int(start[j]))
+                        values.append(sent - num(start[j]))
                         break
             # ScoreParents
             mean = statistics.mean(values)                            # constant during the loop below
@@ -152,14 +169,14 @@ class WAP5(object):
             logpdf = lambda t: -t / mean - math.log(mean)             # scipy.stats.expon.logpdf(t, scale=mean)
             picked = np.zeros(n, bool)                                # already_picked, reset for the spans of this call
             for i in np.flatnonzero(is_client):
-                sent = int(start[i])
+                sent = num(start[i])
                 cands = []
                 for j in range(i - 1, -1, -1):
-                    if sent - int(start[j]) > limit:
+                    if sent - num(start[j]) > limit:
                         cands.append((-1, logpdf(limit)))             # ("Spontaneous", p)
                         break
                     if not is_client[j] and not picked[idx[j]]:
-                        cands.append((int(idx[j]), logpdf(sent - int(start[j]))))
+                        cands.append((int(idx[j]), logpdf(sent - num(start[j]))))
                         picked[idx[j]] = True
                 cands.sort(key=lambda x: x[1])                        # stable, ascending: the last entry wins
                 if cands and cands[-1][0] >= 0:

@@ -1,5 +1,5 @@
 // tw_ingest.cpp -- Jaeger-JSON ingest into the engine's structure-of-arrays form (host side of libtwgpu.so;
-// SURVEY.md 8 f1).  Replaces the reference's Python loader for the corpora that need no span rewriting:
+// SURVEY.md 8 f1).  Replaces the reference's Python loader:
 //   GetAllTracesInDir / TimeOrder            executor.py:287-339   traces ordered by the start of their root span
 //   ParseJsonTrace / ParseSpansJson          executor.py:342-384,755-793   one trace per file, {"data":[{traceID, spans, processes}]}
 //   ParseProcessesJson / ParseProcessesJson2 executor.py:451-461   processID -> serviceName (or the id itself for requestType data)
@@ -9,12 +9,14 @@
 //   GetGroundTruth                           helpers/utils.py:22-32 first outgoing span of the same trace per endpoint
 //   FindOrder + nx.topological_sort          executor.py:214-285, traceweaver_v1.py:37-39
 //   FixSpans / FixSpans2                     executor.py:505-537,542-645   the span surgery the nodejs / media corpora need
-// The self-loop renaming the reference applies to the Alibaba parser output (executor.py:386-448) is not reproduced.
+//   ParseSpansJson, first_span == None       executor.py:377-448   the rewrite of the Alibaba parser's output (--fix 5): client twins,
+//                                                                  self-call stand-in services, containment filter
 //
 // Strings never reach the GPU: every name is interned, units carry string ids and span-table rows so that the
 // caller can translate indices back to (trace id, span id) keys.
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -171,6 +173,8 @@ struct Scan {
 // ------------------------------------------------------------------------------------------------
 struct SpanTmp {
     std::string sid, op, pid;
+    std::string caller, callee;  // upstream / downstream service of the call (alibaba-analysis/real-parser.py:318,320)
+    bool has_caller = false, has_callee = false;
     std::vector<std::pair<std::string, std::string>> refs;  // (traceID, spanID)
     int64_t start = 0, dur = 0;
     int kind = 0;  // 1 server, 2 client
@@ -231,6 +235,8 @@ void parse_trace(const char* buf, size_t len, TraceTmp& T) {
                             if (k2 == "processID" && S.is_string() && !has_pid) { has_pid = true; return S.str(&sp.pid); }
                             if (k2 == "traceID" && S.is_string() && !has_tid) { has_tid = true; return S.str(&stid); }
                             if (k2 == "operationName" && !has_op) { has_op = true; return S.is_string() ? S.str(&sp.op) : S.skip(); }
+                            if (k2 == "caller" && S.is_string() && !sp.has_caller) { sp.has_caller = true; return S.str(&sp.caller); }
+                            if (k2 == "callee" && S.is_string() && !sp.has_callee) { sp.has_callee = true; return S.str(&sp.callee); }
                             if (k2 == "requestType" && !has_req) { has_req = true; if (S.is_string()) return S.str(&req); req.clear(); return S.skip(); }
                             if ((k2 == "startTime" && !has_start) || (k2 == "duration" && !has_dur)) {
                                 S.ws();
@@ -332,6 +338,8 @@ struct tw_corpus {
     std::unordered_map<int32_t, std::vector<int32_t>> in_rows, out_rows;  // per service, in walk order
     int64_t files_total = 0, files_rejected = 0, traces_filtered = 0;
     std::unordered_map<std::string, std::string> caller_of;  // service -> calling service (FixSpans' process_map_1)
+    std::unordered_map<std::string, std::string> loop_by_rpc;  // selfLoopMap: rpc id -> stand-in service of a self-call (executor.py:386-399)
+    std::unordered_map<std::string, std::string> loop_origin;  // serviceLoopMap: stand-in service -> the service that called itself
     // last unit set built
     std::vector<int64_t> u_in_off, u_ep_off, u_in_start, u_in_end, u_out_start, u_out_end;
     std::vector<int32_t> u_E, u_key_rank, u_truth, u_in_trace, u_in_row, u_out_row, u_service, u_ep_name, u_in_ep, u_order;
@@ -469,6 +477,77 @@ bool fix_reroot(TraceTmp& T, const std::string& root_op) {
     return true;
 }
 
+// ParseSpansJson with first_span == None (executor.py:377-448; the output of alibaba-analysis/real-parser.py, --fix 5):
+// every call is logged twice under one rpc id -- a server record in the callee and a client record with the same
+// timestamps in the caller.  The client record is renamed "<rpc id>.client" and the server record re-pointed at it;
+// a service calling itself gets a stand-in callee "...-loop" (one per rpc id, for the whole corpus: the map lives in
+// the corpus and traces are visited in time order, as the reference does), the client spans below such an rpc id move
+// into the process of their parent span, and a trace in which a child is not contained in its parent is dropped.
+// The reference draws the stand-in names at random (helpers/misc.py:17-19); here they are "<callee>@<rpc id>-loop".
+// Returns false when the trace is dropped.
+bool fix_rpc_twins(TraceTmp& T, tw_corpus* c) {
+    auto sanitized = [](const std::string& sid) {
+        return sid.size() >= 7 && sid.compare(sid.size() - 7, 7, ".client") == 0 ? sid.substr(0, sid.size() - 7) : sid;
+    };
+    for (SpanTmp& s : T.spans) {                                       // step 1
+        if (s.kind == 2) s.sid += ".client";
+        if (s.kind == 1 && s.refs.size() == 1) s.refs[0].second = s.sid + ".client";
+        if (!s.has_caller || !s.has_callee) return false;              // span["caller"] would raise
+        if (s.caller == s.callee) {
+            const std::string rpc = sanitized(s.sid);
+            auto it = c->loop_by_rpc.find(rpc);
+            if (it == c->loop_by_rpc.end()) {
+                const std::string name = s.callee + "@" + rpc + "-loop";
+                it = c->loop_by_rpc.emplace(rpc, name).first;
+                c->loop_origin[name] = s.callee;
+            }
+            s.callee = it->second;
+            if (s.kind == 1) s.pid = it->second;
+        }
+    }
+    const int n = (int)T.spans.size();
+    std::unordered_map<std::string, int> by_sid;                       // the dict `spans`: later duplicates replace the value
+    for (int i = 0; i < n; i++) by_sid[T.spans[(size_t)i].sid] = i;
+    std::vector<std::vector<int>> children((size_t)n);
+    int root = -1;
+    for (int i = 0; i < n; i++) {                                      // steps 2-3 (dict order = first insertion of each key)
+        const SpanTmp& s = T.spans[(size_t)i];
+        if (by_sid[s.sid] != i) continue;
+        if (s.refs.empty()) { if (root < 0) root = i; continue; }      // next(span for span in spans.values() if span.IsRoot())
+        if (s.refs[0].first != T.trace_id) continue;
+        auto it = by_sid.find(s.refs[0].second);
+        if (it != by_sid.end()) children[(size_t)it->second].push_back(i);
+    }
+    if (root < 0) return true;                                         // nothing to check; the walk rejects the trace
+    std::vector<char> seen((size_t)n, 0);
+    std::function<bool(int)> contained = [&](int v) {                  // check_time_constraints
+        if (seen[(size_t)v]) return false;
+        seen[(size_t)v] = 1;
+        const SpanTmp& p = T.spans[(size_t)v];
+        for (int ch : children[(size_t)v]) {
+            const SpanTmp& q = T.spans[(size_t)ch];
+            if (!(p.start <= q.start && p.start + p.dur >= q.start + q.dur)) return false;
+            if (!contained(ch)) return false;
+        }
+        return true;
+    };
+    if (!contained(root)) return false;
+    std::function<void(int)> update = [&](int v) {                     // update_references
+        for (int ch : children[(size_t)v]) {
+            if (T.spans[(size_t)ch].kind == 2) T.spans[(size_t)ch].pid = T.spans[(size_t)v].pid;
+            update(ch);
+        }
+    };
+    std::function<void(int)> traverse = [&](int v) {                   // traverse_and_update
+        if (c->loop_by_rpc.count(sanitized(T.spans[(size_t)v].sid))) update(v);
+        for (int ch : children[(size_t)v]) traverse(ch);
+    };
+    traverse(root);
+    T.processes.clear();                                               // ParseProcessesJson2 on the rewritten records
+    for (const SpanTmp& s : T.spans) T.processes.emplace_back(s.pid, s.pid);
+    return true;
+}
+
 // ProcessTraceData (executor.py:795-849) for one parsed trace, in two steps: the walk (any thread, touches only the
 // trace) and the append to the corpus (one thread, in trace order).  walk_trace returns false (nothing is kept)
 // when the trace breaks an assumption the reference asserts on or its root is not `first_span`.
@@ -580,7 +659,7 @@ int tw_corpus_set_callers(tw_corpus* c, const char* const* service, const char* 
 
 int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths, const char* first_span, int64_t max_traces,
                         int32_t n_threads, int32_t fix) {
-    if (c == nullptr || (n_paths > 0 && paths == nullptr) || n_paths < 0 || fix < 0 || fix > 2) return TW_ERR_ARG;
+    if (c == nullptr || (n_paths > 0 && paths == nullptr) || n_paths < 0 || fix < 0 || fix > 3) return TW_ERR_ARG;
     std::vector<TraceTmp> parsed((size_t)n_paths);
     std::vector<Walked> walked((size_t)n_paths);
     std::vector<char> usable((size_t)n_paths, 0);
@@ -596,6 +675,7 @@ int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths,
             bool ok = true;
             if (fix == TW_FIX_CLIENT_TWINS) ok = fix_client_twins(T, c->caller_of);
             else if (fix == TW_FIX_REROOT) ok = fix_reroot(T, fs);
+            else if (fix == TW_FIX_RPC_TWINS) continue;   // needs the corpus-wide self-call map: done below, in time order
             usable[(size_t)i] = ok && walk_trace(T, fs, walked[(size_t)i]);
         }
     };
@@ -623,8 +703,9 @@ int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths,
         if (c->err.empty()) c->err = std::string(paths[i]) + ": " + parsed[(size_t)i].error;
     }
     for (int i : idx) {
-        const TraceTmp& T = parsed[(size_t)i];
+        TraceTmp& T = parsed[(size_t)i];
         if (!T.ok) continue;
+        if (fix == TW_FIX_RPC_TWINS) usable[(size_t)i] = fix_rpc_twins(T, c) && walk_trace(T, fs, walked[(size_t)i]);
         if (usable[(size_t)i]) { append_trace(c, T, walked[(size_t)i]); accepted++; } else c->traces_filtered++;
         if (max_traces > 0 && accepted >= max_traces) break;  // executor.py:873 stops after 1001 accepted traces
     }
@@ -641,6 +722,12 @@ int tw_corpus_counts(const tw_corpus* c, int64_t* out6) {
 const char* tw_corpus_string(const tw_corpus* c, int32_t id) {
     if (c == nullptr || id < 0 || (size_t)id >= c->strings.size()) return nullptr;
     return c->strings[(size_t)id].c_str();
+}
+
+const char* tw_corpus_loop_origin(const tw_corpus* c, const char* service) {
+    if (c == nullptr || service == nullptr) return nullptr;
+    auto it = c->loop_origin.find(service);
+    return it == c->loop_origin.end() ? nullptr : it->second.c_str();
 }
 
 int tw_corpus_trace_names(const tw_corpus* c, int32_t* out) {

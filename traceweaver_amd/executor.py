@@ -14,15 +14,16 @@ in libtwgpu.so: native ingest (tw_corpus_*), both passes of every service in one
 accuracy reductions.
 
 Indices 3 (WAP5), 4 (FCFS), 5 (ArrivalOrder) and 7 (vPath) run as host baselines (traceweaver_amd/baselines.py,
-identical to the reference's classes) and add their columns to the same files -- `exps/exp1`'s "3,4,7,10" runs as is.
+identical to the reference's classes, also on load-scaled units) and add their columns to the same files --
+`exps/exp1`'s and `exps/exp5`'s "3,4,7,10" run as they are.
 `--compress_factor N` (N > 1) applies the reference's load scaling (helpers/transforms.py:10-40, executor.py:1086-1097,
 1146-1148) to every service before it is solved: per-service load factor max(1, ceil(N / #replicas)) with the replica
 table read from data/misc/service_to_replica_new.pickle under the project root (executor.py:912), timestamps handed to
 the engine as exact images of the reference's floats (traceweaver_amd/transforms.py).  `--repeat_factor` is accepted and,
 as in the reference (repeat_change_spans never reads it), only shows up in the result file names.
 What it does not do (and says so instead of approximating): the other predictor indices (the older TraceWeaver
-variants 0-2, 6, 8, 9), cache-hit injection (--cache_rate > 0: skip mode), the host baselines together with load
-scaling, --parallel / --instrumented, tar archives (--compressed 1).  For those keep the reference's executor and
+variants 0-2, 6, 8, 9), cache-hit injection (--cache_rate > 0: skip mode), --parallel / --instrumented, tar archives
+(--compressed 1).  For those keep the reference's executor and
 register the predictor.
 The mixture refit between the passes is the deterministic device refit, so figures agree with a reference run to
 within the run-to-run spread the reference itself has (its k-means++ start is drawn from an unseeded RNG,
@@ -89,14 +90,12 @@ def unsupported(args):
         problems.append("--compressed 1")
     if args.cache_rate != 0:
         problems.append("--cache_rate %g (cache-hit injection = skip mode)" % args.cache_rate)
-    if args.compress_factor > 1 and any(i in BASELINES for i in requested(args)):
-        problems.append("--compress_factor > 1 together with the host baselines 3, 4, 5, 7 (only index 10 runs on load-scaled units)")
     if args.parallel or args.instrumented:
         problems.append("--parallel / --instrumented")
     return problems
 
 
-def scale_load(units, args, trace_id):
+def scale_load(units, args, trace_id, corpus):
     """Load scaling of every unit (helpers/transforms.py:10-40) with the per-service factor of executor.py:1086-1097."""
     from . import transforms
     from .ingest import IngestedUnit
@@ -108,10 +107,11 @@ def scale_load(units, args, trace_id):
         replicas = pickle.load(f)
     out = []
     for u in units:
-        if u.service not in replicas:
+        owner = u.service if u.service in replicas else corpus.loop_origin(u.service)   # "...-loop" stand-ins: executor.py:1092-1096
+        if owner not in replicas:
             raise SystemExit("service %s is not in the replica table %s (the reference stops here too, executor.py:1098-1101)" % (u.service, path))
-        factor = transforms.load_factor(args.compress_factor, len(replicas[u.service]))
-        print("Process: %s  replicas: %d  dynamic load factor: %d" % (u.service, len(replicas[u.service]), factor))
+        factor = transforms.load_factor(args.compress_factor, len(replicas[owner]))
+        print("Process: %s  replicas: %d  dynamic load factor: %d" % (u.service, len(replicas[owner]), factor))
         s = transforms.compress_unit(u.arrays, u.true_parent, factor, trace_key=[trace_id(t) for t in u.in_trace])
         out.append(IngestedUnit(s.arrays, s.true_parent, u.in_trace[s.in_perm], u.service, u.in_ep, u.out_eps, u.in_rows[s.in_perm],
                                 [r[p] for r, p in zip(u.out_rows, s.out_perm)], u.process_id))
@@ -139,7 +139,7 @@ def run(args):
     names = corpus.trace_names()
     trace_id = lambda k: corpus.string(names[k])
     if args.compress_factor > 1:                                   # executor.py:1086-1097,1146-1148
-        units = scale_load(units, args, trace_id)
+        units = scale_load(units, args, trace_id, corpus)
     key = lambda row: (trace_id(table["trace"][row]), corpus.string(table["span_id"][row]))
     seen = np.zeros(n_traces, dtype=bool)
     for u in units:

@@ -18,7 +18,7 @@ NODEJS_CALLERS = {"service5": "service3", "service4": "service2", "service2": "s
 
 # executor.py:757-763: --fix value -> (operation name of the roots that are kept, span surgery)
 REFERENCE_FIX = {0: ("init-span", "client_twins"), 1: ("ComposeReview", "reroot"), 2: ("HTTP GET /hotels", None),
-                 3: ("HTTP GET /recommendations", None), 4: ("[Todo] CompleteTodoCommandHandler", None), 5: (None, None)}
+                 3: ("HTTP GET /recommendations", None), 4: ("[Todo] CompleteTodoCommandHandler", None), 5: (None, "rpc_twins")}
 
 
 class IngestedUnit(object):
@@ -59,7 +59,7 @@ class Corpus(object):
         `max_traces` kept (the reference's literal 1001; 0 = no limit).  `fix`: None / "client_twins" (FixSpans,
         nodejs corpora; `callers` = service -> calling service, default the reference's table) / "reroot" (FixSpans2,
         media corpora)."""
-        mode = {None: 0, "none": 0, "client_twins": 1, "reroot": 2}[fix]
+        mode = {None: 0, "none": 0, "client_twins": 1, "reroot": 2, "rpc_twins": 3}[fix]
         if mode == 1:
             callers = NODEJS_CALLERS if callers is None else callers
             k = (ctypes.c_char_p * len(callers))(*[x.encode() for x in callers.keys()])
@@ -87,6 +87,11 @@ class Corpus(object):
 
     def string(self, idx):
         s = self._lib.tw_corpus_string(self._h, int(idx))
+        return s.decode() if s is not None else None
+
+    def loop_origin(self, service):
+        """The service a "...-loop" stand-in was split from by the --fix 5 rewrite (executor.py:386-399), or None."""
+        s = self._lib.tw_corpus_loop_origin(self._h, service.encode())
         return s.decode() if s is not None else None
 
     def trace_names(self):

@@ -227,6 +227,70 @@ def write_jaeger_corpus(directory, seed, n_traces, app=HOTEL_APP, concurrency=1.
 
 
 # ---------------------------------------------------------------------------------------------
+# The shape alibaba-analysis/real-parser.py:308-359 writes and `--fix 5` reads (executor.py:377-448): one record per
+# call under its rpc id ("0.1.2"), a server record in the callee plus -- except for the root -- a client record with the
+# same timestamps in the caller; `requestType` instead of `operationName`, `caller` / `callee`, processID = service
+# name, no `processes` map, millisecond timestamps x 1000.  `cart` calls itself (the reference splits such a callee off
+# as a "...-loop" service) and that self-call calls on; `violations` of the traces break parent-child containment
+# (the reference drops those).
+ALIBABA_APP = {"root": "gw", "calls": {"gw": [("auth",), ("cart", "catalog")], "cart": [("cart",)], "cart/self": [("stock",)],
+                                       "catalog": [("db",)]}}
+
+
+def write_alibaba_corpus(directory, seed, n_traces, app=ALIBABA_APP, concurrency=1.5, mean_service_ms=6.0, sigma=0.5,
+                         violations=0.0, t0_ms=1_655_760_000_000):
+    import json
+    import os
+
+    rng = np.random.default_rng(seed)
+    os.makedirs(directory, exist_ok=True)
+
+    def ln(mean):
+        mu = np.log(mean) - 0.5 * sigma * sigma
+        return max(1, int(rng.lognormal(mu, sigma)))
+
+    def build(service, key, rpc, caller, start, tid, records, bad):
+        """records of the call `rpc` handled by `service` from `start` (ms); returns its end"""
+        cur = start + ln(1.0) - 1
+        for k, stage in enumerate(app["calls"].get(key, [])):
+            stage_end = cur
+            for j, callee in enumerate(stage):
+                child = "%s.%d" % (rpc, sum(len(st) for st in app["calls"][key][:k]) + j + 1)
+                sub = key + "/self" if callee == service else callee
+                stage_end = max(stage_end, build(callee, sub, child, service, cur, tid, records, bad))
+            cur = stage_end
+        end = inner_end = cur + ln(mean_service_ms)
+        if bad and rpc.count(".") == 1 and rpc.endswith(".1"):
+            end += 10_000                                         # recorded longer than the root span waits for it
+        rec = {"traceID": tid, "startTime": int(start) * 1000, "spanID": rpc, "caller": caller, "requestType": "rpc",
+               "callee": service, "interface": "if_" + service, "duration": int(end - start) * 1000,
+               "tags": [{"key": "span.kind", "value": "server"}],
+               "references": [] if "." not in rpc else [{"refType": "CHILD_OF", "traceID": tid, "spanID": rpc.rsplit(".", 1)[0]}],
+               "processID": service}
+        records.append(rec)
+        if "." in rpc:
+            twin = json.loads(json.dumps(rec))
+            twin["tags"][0]["value"] = "client"
+            twin["processID"] = caller
+            records.append(twin)
+        return inner_end
+
+    probe = [build(app["root"], app["root"], "0", "USER", 0, "probe", [], False) for _ in range(16)]
+    mean_resp = float(np.mean(probe))
+    t, paths = t0_ms, []
+    for k in range(n_traces):
+        t += int(rng.exponential(mean_resp / max(concurrency, 1e-9))) + 1
+        tid = "%016x" % (0x2000 + k)
+        records = []
+        build(app["root"], app["root"], "0", "USER", t, tid, records, rng.random() < violations)
+        path = os.path.join(directory, tid + ".json")
+        with open(path, "w") as f:
+            json.dump({"data": [{"traceID": tid, "spans": records}]}, f)
+        paths.append(path)
+    return paths
+
+
+# ---------------------------------------------------------------------------------------------
 # BASELINE.json configs 3-5 as unit sets.
 # nodejs_microservices_with_arbitrary_file_io: 4 services, E in {1, 2, 1, 1}, millisecond-granular
 # timestamps, heavily interleaved requests (SURVEY.md 8(d) C3).

@@ -121,4 +121,5 @@ def compress_unit(arrays, true_parent, factor, trace_key=None):
     fl = [x[in_perm], in_end[in_perm], np.concatenate(out_start), np.concatenate(out_end)]
     (i_s, i_e, o_s, o_e), scale = to_exact_units(fl)
     scaled = UnitArrays(i_s, i_e, arrays.out_off, o_s, o_e, arrays.dag, arrays.key_rank, time_scale=scale)
+    scaled.in_dur = (arrays.in_end - arrays.in_start)[in_perm]                  # the integer durations (the baselines read them)
     return ScaledUnit(scaled, truth, in_perm, out_perm, fl[0], fl[2], factor)
