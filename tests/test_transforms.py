@@ -159,6 +159,22 @@ def _own_refit_keeps_accuracy(lib_path, ds, units):
         assert y >= x - 0.03, "pass 2 with the engine's refit must not fall behind pass 1 (%s: %.3f -> %.3f)" % (d["process"], x, y)
 
 
+def _scaled_stress_units():
+    """Synthetic units (chains, diamonds, fan-outs up to E = 8, light to heavy load, ms-granular ties) after load
+    scaling with factors 1 (float conversion only: time_scale 1, binary64 sums), 2, 3 and 7."""
+    cases = [(1, 400, "chain3", 1.5, 1), (3, 300, "chain3", 8, 1), (5, 300, "diamond", 5, 1), (8, 300, "chain2", 12, 1000),
+             (14, 150, "chain5", 2.5, 1), (16, 100, "mix8", 1.3, 1), (7, 300, "par4", 3, 1)]
+    units, truth = parity.stress_units(cases)
+    out = [transforms.compress_unit(u, tp, f).arrays for u, tp, f in zip(units, truth, (3, 1, 2, 1, 3, 7, 2))]
+    assert sorted({u.time_scale for u in out}) == [2.0 ** -5, 2.0 ** -4, 0.5, 1.0]
+    return out
+
+
+def test_emulated_engine_on_scaled_stress_units(emu_lib):
+    r1, r2, _ = parity.check_units(emu_lib, _scaled_stress_units())
+    assert sum(r["repaired_windows"] for r in r1) > 0          # span consumption across windows on scaled timestamps too
+
+
 def test_emulated_engine_on_scaled_units(emu_lib, oracle):
     ds, units = _engine_vs_oracle(emu_lib, oracle)
     _own_refit_keeps_accuracy(emu_lib, ds, units)
@@ -202,3 +218,9 @@ def test_predictor_protocol_with_float_timestamps(emu_lib, oracle):
 def test_gpu_engine_on_scaled_units(oracle):
     ds, units = _engine_vs_oracle(None, oracle)
     _own_refit_keeps_accuracy(None, ds, units)
+
+
+@pytest.mark.gpu
+def test_gpu_engine_on_scaled_stress_units():
+    r1, r2, _ = parity.check_units(None, _scaled_stress_units())
+    assert sum(r["repaired_windows"] for r in r1) > 0
