@@ -262,16 +262,21 @@ __device__ __forceinline__ double term_gauss(double mean, double used, double lo
 // not inlined: the mixture term is ~1.5k instructions and is called from several places per kernel; keeping one
 // copy keeps the enumeration kernels inside the instruction cache
 __device__ __noinline__ double term_mix(int n, const double* c, double x) {
-    double a[kMaxComp], amax = -dinf();
+    // the per-component terms stay in registers (an array indexed by the loop counter would live in scratch memory:
+    // one store and two loads per component and call); k < kMaxComp = 5
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, amax = -dinf();
     for (int k = 0; k < n; k++) {
         const double y = x * c[k * 4 + 1] - c[k * 4 + 0];  // x_us * prec_chol - mean * prec_chol (k_mix_consts)
         const double lp = y * y;
-        a[k] = (-0.5 * (kLog2Pi + lp) + c[k * 4 + 2]) + c[k * 4 + 3];  // sklearn _estimate_weighted_log_prob
-        if (a[k] > amax) amax = a[k];
+        const double ak = (-0.5 * (kLog2Pi + lp) + c[k * 4 + 2]) + c[k * 4 + 3];  // sklearn _estimate_weighted_log_prob
+        a0 = k == 0 ? ak : a0; a1 = k == 1 ? ak : a1; a2 = k == 2 ? ak : a2; a3 = k == 3 ? ak : a3; a4 = k == 4 ? ak : a4;
+        if (ak > amax) amax = ak;
     }
     double m = 0.0, s = 0.0;  // scipy.special.logsumexp: max split out, log1p of the rest
-    for (int k = 0; k < n; k++) if (a[k] == amax) m += 1.0;
-    for (int k = 0; k < n; k++) s += (a[k] == amax) ? 0.0 : tw_exp(a[k] - amax);
+    for (int k = 0; k < n; k++) {   // (left to the compiler's unroller: rolled, the five values cost 4 more VGPRs and one wave of occupancy in three kernels)
+        const double ak = k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : (k == 3 ? a3 : a4)));
+        if (ak == amax) m += 1.0; else s += tw_exp(ak - amax);   // adding the 0.0 of a maximal component changes nothing: s >= +0.0
+    }
     if (s != 0.0) s = s / m;
     return (tw_log1p(s) + (m == 1.0 ? 0.0 : tw_log(m))) + amax;  // log(1.0) is exactly 0.0
 }
@@ -661,22 +666,43 @@ __device__ void light_leaf(LightCtx<E>& c, bool want_bits) {
         }
     }
     int pos = c.nk < kTopK ? c.nk : kTopK - 1;
+    if constexpr (E <= 6) {
+        // written as selects, not as conditional stores: the optimiser turns "if (k == pos) list[k] = ..." into a store at
+        // a dynamic index, which moves the list from registers into scratch memory (seen in the ISA for E >= 2; as selects
+        // the kernels for E <= 6 are free of scratch memory at unchanged occupancy)
 #pragma unroll
-    for (int k = kTopK - 1; k >= 1; k--) {
-        if (k == pos && (sj > c.ts[k - 1] || (sj == c.ts[k - 1] && tie[k - 1] > 0))) {
-            c.ts[k] = c.ts[k - 1];
+        for (int k = kTopK - 1; k >= 1; k--) {
+            const bool shift = k == pos && (sj > c.ts[k - 1] || (sj == c.ts[k - 1] && tie[k - 1] > 0));
+            c.ts[k] = shift ? c.ts[k - 1] : c.ts[k];
 #pragma unroll
-            for (int e = 0; e < E; e++) c.tidx[k][e] = c.tidx[k - 1][e];
-            pos = k - 1;
+            for (int e = 0; e < E; e++) c.tidx[k][e] = shift ? c.tidx[k - 1][e] : c.tidx[k][e];
+            pos = shift ? k - 1 : pos;
         }
+#pragma unroll
+        for (int k = 0; k < kTopK; k++) {
+            const bool here = k == pos;
+            c.ts[k] = here ? sj : c.ts[k];
+#pragma unroll
+            for (int e = 0; e < E; e++) c.tidx[k][e] = here ? c.x[e] : c.tidx[k][e];
+        }
+    } else {  // 7 and 8 endpoints: 40 list registers more would cost the second wavefront per SIMD
+#pragma unroll
+        for (int k = kTopK - 1; k >= 1; k--) {
+            if (k == pos && (sj > c.ts[k - 1] || (sj == c.ts[k - 1] && tie[k - 1] > 0))) {
+                c.ts[k] = c.ts[k - 1];
+#pragma unroll
+                for (int e = 0; e < E; e++) c.tidx[k][e] = c.tidx[k - 1][e];
+                pos = k - 1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kTopK; k++)
+            if (k == pos) {
+                c.ts[k] = sj;
+#pragma unroll
+                for (int e = 0; e < E; e++) c.tidx[k][e] = c.x[e];
+            }
     }
-#pragma unroll
-    for (int k = 0; k < kTopK; k++)
-        if (k == pos) {
-            c.ts[k] = sj;
-#pragma unroll
-            for (int e = 0; e < E; e++) c.tidx[k][e] = c.x[e];
-        }
     if (c.nk < kTopK) c.nk++;
 }
 
