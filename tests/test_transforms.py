@@ -21,8 +21,16 @@ from conftest import REPO, golden_mixtures
 from traceweaver_amd import transforms
 from traceweaver_amd.engine import Engine, UnitArrays
 
-SCALED = sorted(glob.glob(os.path.join(REPO, "tests", "golden", "refcmp_*.npz")))
-IDS = [os.path.basename(f)[7:-4] for f in SCALED]
+# refcmp_*: the reference's executor with --compress_factor on shipped corpora (gen_golden_compress.py);
+# refsynx_*: the reference's predictor class on load-scaled synthetic units of every DAG shape, both passes
+# (gen_golden_synth_scaled.py)
+SCALED = sorted(glob.glob(os.path.join(REPO, "tests", "golden", "refcmp_*.npz"))) + \
+    sorted(glob.glob(os.path.join(REPO, "tests", "golden", "refsynx_*.npz")))
+IDS = [os.path.basename(f)[:-4].split("_", 1)[1] for f in SCALED]
+
+
+def _synthetic(d):
+    return str(d["dataset"]).startswith("synthetic")
 SCORE_RTOL = 1e-12
 
 
@@ -34,7 +42,7 @@ def scaled_unit(d, oracle):
 
 
 def test_goldens_present():
-    assert len(SCALED) >= 4
+    assert len(SCALED) >= 14 and sum("refsynx_" in f for f in SCALED) >= 7
 
 
 def test_exact_units():
@@ -57,7 +65,7 @@ def test_compress_unit_reproduces_the_reference_inputs(path, oracle):
     d = np.load(path)
     corpus, service = str(d["dataset"]).rsplit("_x", 1)[0], str(d["process"])
     base = os.path.join(REPO, "tests", "golden", "ref_%s__%s.npz" % (corpus, service))
-    if not os.path.exists(base):
+    if _synthetic(d) or not os.path.exists(base):
         pytest.skip("no untransformed golden of this service")
     b = np.load(base)
     svc = oracle.service_from_golden(b)
@@ -100,7 +108,7 @@ def test_oracle_pass1_pinned_on_scaled_runs(case):
         assert np.allclose(p1[kind + "_score"][m], r[m], rtol=SCORE_RTOL, atol=0)
     assert np.array_equal(p1["parent"], d["pass1_parent"])
     own = np.nonzero(p1["chosen"] != d["p0_chosen"])[0]               # the oracle's own selection (ties aside)
-    assert len(own) <= 0.01 * svc.n_in
+    assert len(own) <= (0.2 if int(d["synth"][3]) == 1000 else 0.01) * svc.n_in if _synthetic(d) else len(own) <= 0.01 * svc.n_in
 
 
 def test_integer_sums_would_not_reproduce_the_reference(case, oracle):
@@ -122,10 +130,16 @@ def test_oracle_pass2_given_the_reference_mixtures(case, oracle):
     assert np.array_equal(p2["topk2_idx"], d["p1_topk2_idx"]) and np.array_equal(p2["parent"], d["final_parent"])
     assert p2["cnt_unassigned"] == int(d["cnt_unassigned"])
     assert np.array_equal(p1["leaves"] + p2["leaves"], d["per_span_candidates"])
-    # what the reference's refit does to its own result on this path (hazard, see the module docstring)
     acc1 = (d["pass1_parent"] == d["true_parent"]).all(axis=0).mean()
     acc2 = (d["final_parent"] == d["true_parent"]).all(axis=0).mean()
-    assert acc1 > 0.95 and acc2 < 0.05
+    if _synthetic(d):      # the predictor class with consistent spans: the second pass does what it is meant to
+        assert acc2 >= acc1
+        gaps = oracle.gaps(svc, d["pass1_parent"])                     # traceweaver_v3.py:717-786 on float timestamps
+        q = next(q for q, g in enumerate(gaps) if g is not None and d["mix_n"][q] > 0)
+        n, p = oracle.fit_mixture(gaps[q], n_selected=int(d["mix_n"][q]))
+        assert np.allclose(p[:n, :2], d["mix_p"][q, :n, :2], rtol=1e-9) and np.allclose(p[:n, 2], d["mix_p"][q, :n, 3], rtol=1e-9)
+    else:                  # through the executor: what the reference's refit does to its own result (hazard H13)
+        assert acc1 > 0.95 and acc2 < 0.05
 
 
 def _engine_vs_oracle(lib_path, oracle):
@@ -135,12 +149,15 @@ def _engine_vs_oracle(lib_path, oracle):
     # bit-exact against the oracle with the reference's mixture tables (where the run got that far) ...
     r1, r2, _ = parity.check_units(lib_path, [units[k] for k in full], mixtures=[golden_mixtures(ds[k]) for k in full])
     for k, a, b in zip(full, r1, r2):
+        if _synthetic(ds[k]) and int(ds[k]["synth"][3]) == 1000:
+            continue   # ms-granular: saturated with exact ties that cascade through span consumption; engine == oracle is asserted above
         assert (a["parent"] != ds[k]["pass1_parent"]).any(axis=0).sum() <= 4
         assert (b["parent"] != ds[k]["final_parent"]).any(axis=0).sum() <= 4
     # ... and on every unit with mixtures made from the engine's own gap samples
     r1, r2, _ = parity.check_units(lib_path, units)
     for d, a in zip(ds, r1):   # exact ties (HiGHS stood in for Gurobi when the runs were frozen) are more frequent on the ms-granular corpus
-        assert (a["parent"] != d["pass1_parent"]).any(axis=0).sum() <= 10
+        if not (_synthetic(d) and int(d["synth"][3]) == 1000):
+            assert (a["parent"] != d["pass1_parent"]).any(axis=0).sum() <= 10
     return ds, units
 
 
@@ -155,7 +172,8 @@ def _own_refit_keeps_accuracy(lib_path, ds, units):
     a2 = [e["accuracy"] for e in eng.evaluate()]
     eng.close()
     for d, x, y in zip(ds, a1, a2):
-        assert x == pytest.approx((d["pass1_parent"] == d["true_parent"]).all(axis=0).mean(), abs=0.004)
+        if not (_synthetic(d) and int(d["synth"][3]) == 1000):         # (tie-saturated ms-granular unit: equally good picks differ)
+            assert x == pytest.approx((d["pass1_parent"] == d["true_parent"]).all(axis=0).mean(), abs=0.004)
         assert y >= x - 0.03, "pass 2 with the engine's refit must not fall behind pass 1 (%s: %.3f -> %.3f)" % (d["process"], x, y)
 
 
