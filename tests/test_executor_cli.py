@@ -142,7 +142,7 @@ def test_load_scaling_through_the_command_line(emu_lib, tmp_path):
     assert "needs the replica table" in str(ei.value)
 
 
-def test_alibaba_shape_with_load_scaling(emu_lib, tmp_path):
+def _alibaba_shape_with_load_scaling(lib, tmp_path):
     """The exps/exp5 route on a generated corpus of the Alibaba parser's shape: --fix 5 --compress_factor 3 with a
     replica table; the self-call stand-in takes the replica count of the service it was split from."""
     from traceweaver_amd import executor, synth
@@ -153,8 +153,8 @@ def test_alibaba_shape_with_load_scaling(emu_lib, tmp_path):
     with open(replicas, "wb") as f:
         pickle.dump({"gw": [0], "cart": [0, 1], "catalog": [0, 1, 2]}, f)
     argv = ["--absolute_path", str(tmp_path / "call_graph_0"), "--cache_rate", "0", "--fix", "5", "--results_directory", out,
-            "--test_name", "cg0", "--load_level", "0", "--compress_factor", "3", "--engine_library", emu_lib, "--replicas_file", replicas,
-            "--predictor_indices", "3,4,7,10"]                                  # exps/exp5/run_experiment.sh:58
+            "--test_name", "cg0", "--load_level", "0", "--compress_factor", "3", "--replicas_file", replicas,
+            "--predictor_indices", "3,4,7,10"] + (["--engine_library", lib] if lib else [])   # exps/exp5/run_experiment.sh:58
     acc, per_process, conf = executor.run(executor.parse_args(argv))
     plain = executor.run(executor.parse_args([a if a != "3" else "1" for a in argv]))[0]
     assert os.path.exists(out + "accuracy_cg0_0_3_1_0.0.pickle") and os.path.exists(out + "accuracy_cg0_0_1_1_0.0.pickle")
@@ -162,6 +162,15 @@ def test_alibaba_shape_with_load_scaling(emu_lib, tmp_path):
     method = "MaxScoreBatchSubsetWithSkips"
     assert plain[method] > 90.0 and acc[method] > 90.0 and acc[method + "TopK"] >= acc[method]
     assert list(acc) == ["WAP5", "FCFS", "vPath", method, method + "TopK"] and all(acc[method] > acc[m] for m in ("WAP5", "FCFS", "vPath"))
+
+
+def test_alibaba_shape_with_load_scaling(emu_lib, tmp_path):
+    _alibaba_shape_with_load_scaling(emu_lib, tmp_path)
+
+
+@pytest.mark.gpu
+def test_alibaba_shape_with_load_scaling_gpu(tmp_path):
+    _alibaba_shape_with_load_scaling(None, tmp_path)
 
 
 def test_generated_corpus_end_to_end(emu_lib, tmp_path):
