@@ -36,3 +36,31 @@ def test_missing_library_fails_loudly(tmp_path):
 
     with pytest.raises(ImportError):
         _ffi.load(str(tmp_path / "nope.so"))
+
+
+def test_ctypes_structures_match_the_header(tmp_path):
+    """sizeof / offsetof of every structure that crosses the ABI, as a C compiler sees include/traceweaver_amd.h,
+    against the ctypes declarations the Python side uses."""
+    import subprocess
+
+    from traceweaver_amd import _ffi
+
+    fields = {"tw_batch": ("Batch", ["n_units", "unit_in_off", "key_rank", "in_start", "out_end", "batch_size", "topk", "unit_time_scale"]),
+              "tw_results": ("Results", ["parent", "topk_score", "unit_stats"]),
+              "tw_span_table": ("SpanTable", ["trace", "start", "kind"]),
+              "tw_unit_set": ("UnitSet", ["n_units", "unit_in_off", "out_end", "true_child", "unit_order", "n_traces", "skipped"])}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "traceweaver_amd.h"', 'int main(void) {']
+    for c_name, (_, names) in fields.items():
+        src.append('printf("%s %%zu", sizeof(%s));' % (c_name, c_name))
+        for f in names:
+            src.append('printf(" %%zu", offsetof(%s, %s));' % (c_name, f))
+        src.append('printf("\\n");')
+    src += ["return 0;", "}"]
+    (tmp_path / "abi.c").write_text("\n".join(src))
+    exe = str(tmp_path / "abi")
+    subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(tmp_path / "abi.c"), "-o", exe])
+    for line in subprocess.check_output([exe], text=True).splitlines():
+        c_name, size, *offs = line.split()
+        cls = getattr(_ffi, fields[c_name][0])
+        assert ctypes.sizeof(cls) == int(size), c_name
+        assert [getattr(cls, f).offset for f in fields[c_name][1]] == [int(o) for o in offs], c_name
