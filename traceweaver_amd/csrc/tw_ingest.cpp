@@ -16,6 +16,7 @@
 // caller can translate indices back to (trace id, span id) keys.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <cstdio>
 #include <cstdlib>
@@ -682,10 +683,14 @@ int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths,
     // <= 0: up to 16 parser threads, one per ~64 files (measured on the 256-thread host: 1 thread 0.4 M spans/s, 8 threads 1.0 M, 256 threads 0.13 M)
     const int want = n_threads <= 0 ? std::min(std::min((int)std::thread::hardware_concurrency(), 16), n_paths / 64 + 1) : n_threads;
     const int nt = std::max(1, std::min(want, std::max(n_paths, 1)));
+    const bool timing = getenv("TW_INGEST_TIMING") != nullptr;   // debug aid: phase times on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
     std::vector<std::thread> pool;
     for (int t = 1; t < nt; t++) pool.emplace_back(work);
     work();
     for (auto& th : pool) th.join();
+    if (timing) fprintf(stderr, "tw_corpus_add_files: %d files, %d threads: read+parse+walk %.3f s", n_paths, nt, since());
     // TimeOrder (executor.py:314-318): by the start of the root span, files without one last; ties keep the given order
     std::vector<int> idx((size_t)n_paths);
     for (int i = 0; i < n_paths; i++) idx[(size_t)i] = i;
@@ -709,6 +714,7 @@ int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths,
         if (usable[(size_t)i]) { append_trace(c, T, walked[(size_t)i]); accepted++; } else c->traces_filtered++;
         if (max_traces > 0 && accepted >= max_traces) break;  // executor.py:873 stops after 1001 accepted traces
     }
+    if (timing) fprintf(stderr, ", order+append done at %.3f s\n", since());
     return TW_OK;
 }
 
