@@ -7,16 +7,32 @@ One *step* = one full two-pass reconstruction (TraceWeaverV3.FindAssignments, tr
 of every service unit resident on the GPU: pass 1 (windows, Gaussian parameters, candidate enumeration,
 exact per-window selection, consumption repair) -> per-edge mixture refit -> pass 2 -> accuracy against ground
 truth (device reduction; the parent arrays stay in HBM).  Spans are already in HBM when the timed region starts
-(tw_load_batch is outside it).  Workload: BASELINE.json config 2 shape --
-the six accelerated services of media_microservices (E in {1,1,1,1,2,4}) -- scaled up with the seed-fixed
-synthetic generator in traceweaver_amd/synth.py (the shipped corpus has 1000 requests per service, which a
-GPU finishes in microseconds).  `value` = spans (incoming + outgoing handed to the engine)
-per second over all ranks.  N > 1: one process per GPU, units sharded, no data-path collective; the only
-collectives are the timing barrier / max-reduce (weak scaling: per-GPU work is fixed).
+(tw_load_batch is outside it).  `value` = spans (incoming + outgoing handed to the engine)
+per second over all ranks.
+
+Workloads (--workload):
+  media    BASELINE.json config 2 shape (default, the configuration the metric is quoted on for one GPU): the six
+           accelerated services of media_microservices (E in {1,1,1,1,2,4}) scaled up with the seed-fixed synthetic
+           generator in traceweaver_amd/synth.py (the shipped corpus has 1000 requests per service, which a GPU
+           finishes in microseconds).  Weak scaling: every rank holds its own replicas.
+  nodejs   config 3 shape: nodejs_microservices_with_arbitrary_file_io, 4 services, millisecond-granular, heavily
+           interleaved.  Weak scaling.
+  alibaba  config 4: ONE Alibaba-shape slice (--total-spans, default 1 M engine spans, 15 call graphs, 39 services)
+           sharded per service over the ranks (sharding.shard_units, LPT on measured work), every step ends with the
+           all-gather of the parent arrays (RCCL over xGMI), the path's one exchange step.  Strong
+           scaling: total work is fixed.  With --verify rank 0 also solves the whole slice alone and the gathered
+           parents must equal that result.
+
+N > 1: `python bench.py --gpus N` starts N ranks itself (re-exec under torch.distributed.run on 127.0.0.1); when the
+driver has already started the ranks (RANK / WORLD_SIZE in the environment) --gpus must equal WORLD_SIZE.  One process
+per GPU, rank r -> device LOCAL_RANK; the media / nodejs workloads have no data-path collective (units are
+independent), the only collectives are the timing barrier / max-reduce.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,8 +41,8 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-ALG_BYTES_PER_SPAN_TWO_PASS = 36  # 16 B read per pass + 4 B parent index written
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+ALG_BYTES_PER_SPAN_PER_PASS = 20  # 16 B read (start, end) + 4 B parent index written
 
 
 def parse_args():
@@ -34,14 +50,37 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n-in", type=int, default=100000, help="requests per service unit")
-    ap.add_argument("--replicas", type=int, default=4, help="copies of the 6-service media graph per GPU")
-    ap.add_argument("--concurrency", type=float, default=1.6, help="mean requests in flight per service")
+    ap.add_argument("--workload", default="media", choices=["media", "nodejs", "alibaba"])
+    ap.add_argument("--n-in", type=int, default=100000, help="requests per service unit (media / nodejs)")
+    ap.add_argument("--replicas", type=int, default=4, help="copies of the service graph per GPU (media / nodejs)")
+    ap.add_argument("--concurrency", type=float, default=None, help="mean requests in flight per service (default: 1.6 media, 4 nodejs, 1.3 alibaba)")
+    ap.add_argument("--total-spans", type=int, default=1000000, help="engine spans of the Alibaba-shape slice (whole job)")
+    ap.add_argument("--verify", type=int, default=0, help="alibaba: rank 0 also solves the whole slice alone and compares the gathered parents")
     ap.add_argument("--fit", default="device", choices=["device", "sklearn"], help="mixture refit between the passes")
     ap.add_argument("--cpu-sample", type=int, default=40000, help="requests per service in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--end-to-end", type=int, default=1, help="also time JSON -> ingest -> H2D -> two passes -> parents on the host (rank 0, N = 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for the timing collectives (nccl = RCCL; gloo lets several ranks share one GPU for testing)")
+                    help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU for testing)")
+    ap.add_argument("--lib", default=None, help="TESTING ONLY: path of an alternative build of libtwgpu (the host-emulation "
+                                                "library of tests/hostemu); no GPU is touched then")
     return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script on this node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def fit_mixtures(eng, mode):
@@ -65,27 +104,56 @@ def one_step(eng, mode):
     return t1, t2, res
 
 
-def cpu_baseline(args, seed):
-    """The CPU oracle (a C port of the reference algorithm, 1 thread) on a bounded sample of the same
-    workload: same services, fewer requests per service."""
-    sys.path.insert(0, os.path.join(REPO, "oracle"))
-    import tw_oracle as T
+def make_units(args, seed, n_in=None, replicas=None, total_spans=None):
     from traceweaver_amd import synth
 
-    units, _ = synth.make_workload(seed, args.cpu_sample, services=synth.MEDIA_SERVICES, concurrency=args.concurrency)
+    n_in = args.n_in if n_in is None else n_in
+    replicas = args.replicas if replicas is None else replicas
+    if args.workload == "media":
+        conc = 1.6 if args.concurrency is None else args.concurrency
+        u, t = synth.make_workload(seed, n_in, services=synth.MEDIA_SERVICES, replicas=replicas, concurrency=conc)
+        name = "media_microservices shape (6 services, E in {1,1,1,1,2,4}), %d requests/service x %d replicas per GPU, concurrency %.1f" % (
+            n_in, replicas, conc)
+        return u, t, name
+    if args.workload == "nodejs":
+        conc = 4.0 if args.concurrency is None else args.concurrency
+        u, t = synth.make_nodejs_workload(seed, n_in, concurrency=conc, replicas=replicas)
+        name = "nodejs_microservices_with_arbitrary_file_io shape (4 services, E in {1,2,1,1}, ms-granular), %d requests/service x %d replicas per GPU, concurrency %.1f" % (
+            n_in, replicas, conc)
+        return u, t, name
+    conc = 1.3 if args.concurrency is None else args.concurrency
+    u, t, _ = synth.make_alibaba_workload(10, args.total_spans if total_spans is None else total_spans, concurrency=conc)
+    name = "alibaba_microservices shape, one %d-span slice (15 call graphs, %d services, ms-granular), sharded per service, concurrency %.1f" % (
+        sum(x.n_spans for x in u), len(u), conc)
+    return u, t, name
+
+
+def cpu_baseline(args, seed):
+    """The CPU oracle (a C port of the reference algorithm, 1 thread) on a bounded sample of the same
+    workload: same services, fewer requests per service.  Next to it the record of the reference itself (its
+    Python executor, predictor index 10, HiGHS in place of Gurobi) timed in the build container on a corpus of the
+    same shape: profiles/cpu_reference.json, written by oracle/refrun/time_reference.py -- /root/reference does not
+    exist on the GPU box, so that figure cannot be re-measured there."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import tw_oracle as T
+
+    units, _, _ = make_units(args, seed, n_in=args.cpu_sample, replicas=1, total_spans=min(args.total_spans, 16 * args.cpu_sample))
     spans = sum(u.n_spans for u in units)
     t0 = time.perf_counter()
     for u in units:
         svc = T.Service(u.in_start, u.in_end - u.in_start, u.out_off, u.out_start, u.out_end - u.out_start, u.dag, u.key_rank)
         T.run_service(svc)
     dt = time.perf_counter() - t0
-    return {"value": spans / dt, "unit": "spans/s", "cores": 1, "kind": "port",
-            "sample": "oracle/tw_oracle.c two-pass (sklearn refit) on the same 6 media-shape services at %d requests each "
-                      "(%d spans, %.1f s); the Python reference itself measured 235-342 spans/s on one core (BASELINE.md)"
-                      % (args.cpu_sample, spans, dt)}
+    out = {"value": spans / dt, "unit": "spans/s", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
+           "sample": "oracle/tw_oracle.c two-pass (sklearn refit) on the same %d %s-shape services at %d requests each (%d spans, %.1f s), 1 thread"
+                     % (len(units), args.workload, args.cpu_sample, spans, dt)}
+    ref = os.path.join(REPO, "profiles", "cpu_reference.json")
+    if os.path.exists(ref):
+        out["reference"] = json.load(open(ref))
+    return out
 
 
-def ingest_rate(n_traces=3000, threads=8):
+def ingest_rate(n_traces=3000, threads=8, lib=None):
     """Host side of the chain, informational: Jaeger JSON files -> service units through the native
     loader (tw_corpus_*), files in the page cache.  Not part of `value` (whose inputs are resident in HBM)."""
     import tempfile
@@ -95,7 +163,7 @@ def ingest_rate(n_traces=3000, threads=8):
 
     with tempfile.TemporaryDirectory() as d:
         paths = synth.write_jaeger_corpus(d, 3, n_traces, app=synth.HOTEL_APP)
-        c = Corpus()
+        c = Corpus(lib_path=lib)
         t0 = time.perf_counter()
         counts = c.add_files(paths, first_span=None, max_traces=0, threads=threads)
         units, _, _ = c.units()
@@ -105,14 +173,87 @@ def ingest_rate(n_traces=3000, threads=8):
             "what": "Jaeger JSON (one trace per file) -> span table -> per-service SoA units, native loader"}
 
 
+def end_to_end(device, lib=None, n_traces=20000, threads=None):
+    """What a user of the command line gets, nothing resident beforehand: Jaeger JSON files (page cache) -> native ingest
+    -> tw_load_batch (host -> HBM) -> pass 1 -> refit -> pass 2 -> parent arrays back on the host.  Bounded sample; not
+    `value`."""
+    import tempfile
+
+    from traceweaver_amd import synth
+    from traceweaver_amd.engine import Engine
+    from traceweaver_amd.ingest import Corpus
+
+    threads = threads or min(os.cpu_count() or 8, 16)
+    with tempfile.TemporaryDirectory() as d:
+        paths = synth.write_jaeger_corpus(d, 5, n_traces, app=synth.HOTEL_APP)
+        eng = Engine(device, lib_path=lib)
+        t0 = time.perf_counter()
+        c = Corpus(lib_path=lib)
+        c.add_files(paths, first_span=None, max_traces=0, threads=threads)
+        units, _, _ = c.units()
+        t1 = time.perf_counter()
+        eng.load([u.arrays for u in units])
+        t2 = time.perf_counter()
+        eng.run_pass1()
+        eng.fit_mixtures()
+        eng.run_pass2()
+        parents = eng.results(2, fields=("parent",))
+        t3 = time.perf_counter()
+        spans = sum(u.arrays.n_spans for u in units)
+        acc = float(np.mean([np.all(p["parent"] == u.true_parent, axis=0).mean() for p, u in zip(parents, units)]))
+        eng.close()
+        c.close()
+    return {"value": spans / (t3 - t0), "unit": "spans/s", "spans": spans, "traces": n_traces, "threads": threads, "accuracy": acc,
+            "ingest_s": t1 - t0, "load_s": t2 - t1, "solve_s": t3 - t2,
+            "what": "JSON files -> native ingest (%d threads) -> H2D -> pass 1 -> refit -> pass 2 -> parents on the host; hotel-shape corpus" % threads}
+
+
+def profile_traffic(dominant, spans_rank):
+    """HBM bytes per launch of the dominant kernel group from the newest committed rocprofv3 PMC passes
+    (profiles/collect.sh) -- only if that profile was taken from exactly these kernel sources and this workload."""
+    import glob
+
+    from traceweaver_amd import build as tw_build
+
+    tpaths = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))
+    if not tpaths:
+        return None, None
+    tj = json.load(open(tpaths[-1]))
+    if tj.get("source_digest") != tw_build.source_digest():
+        return None, "profile %s was taken from other kernel sources" % os.path.basename(tpaths[-1])
+    g = tj["groups"].get(dominant)
+    if not g or tj.get("spans_per_launch") != spans_rank:
+        return None, "profile %s holds another workload" % os.path.basename(tpaths[-1])
+    return g["fetch_bytes_x2"] + g["write_bytes"], os.path.basename(tpaths[-1])
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: start one rank per GPU (or let `python bench.py --gpus N` start them)" % (args.gpus, world))
     import torch
 
-    device = local_rank % max(torch.cuda.device_count(), 1)
+    emulated = args.lib is not None and not torch.cuda.is_available()
+    if not emulated:
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            sys.exit("bench.py: no GPU visible (the HIP engine has no CPU fallback)")
+        if args.backend == "nccl" and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > ndev:
+            sys.exit("bench.py: %d ranks on this node but only %d GPU(s) visible" % (int(os.environ.get("LOCAL_WORLD_SIZE", world)), ndev))
+        device = local_rank % ndev
+        torch.cuda.set_device(device)
+    else:
+        device = 0
+        os.environ.setdefault("TW_TILE", "1")
+        os.environ.setdefault("TW_COOP_THREADS", "1")
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -120,86 +261,150 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend="gloo")
-    torch.cuda.set_device(device)
-    red_dev = "cuda" if args.backend == "nccl" else "cpu"
+    red_dev = "cuda" if (args.backend == "nccl" and not emulated) else "cpu"
 
-    from traceweaver_amd import synth
+    from traceweaver_amd import sharding
     from traceweaver_amd.engine import Engine
 
-    units, truth = synth.make_workload(1000 + rank, args.n_in, services=synth.MEDIA_SERVICES, replicas=args.replicas,
-                                       concurrency=args.concurrency)
+    strong = args.workload == "alibaba"
+    all_units, all_truth, wl_name = make_units(args, 1000 + (0 if strong else rank))
+    eng = Engine(device, lib_path=args.lib)
+    if strong:
+        # measured work per unit: leaves enumerated by a pass over the whole slice would need a first run; the static
+        # estimate is spans x endpoints, refined with the measured leaves of the warm-up pass below
+        costs = [sharding.unit_cost(u) for u in all_units]
+        parts = sharding.shard_units(costs, world)
+        mine = parts[rank]
+    else:
+        mine = list(range(len(all_units)))
+    units = [all_units[k] for k in mine]
+    truth = [all_truth[k] for k in mine]
     spans_rank = sum(u.n_spans for u in units)
-    eng = Engine(device)
     eng.load(units)
     eng.set_truth(truth)
 
+    def sync():
+        if not emulated:
+            torch.cuda.synchronize()
+
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+
+    def step():
+        t1, t2, res = one_step(eng, args.fit)
+        gathered = None
+        if strong:  # the exchange step of the sharded slice: parents of every service on every rank
+            local = [r["parent"] for r in eng.results(2, fields=("parent",))]
+            gathered = sharding.gather_parents(local, mine, len(all_units), dist=dist, device=red_dev)
+        return t1, t2, res, gathered
+
+    if strong and world > 1 and args.warmup > 0:
+        # re-balance on measured work: enumerated tuples per unit from a first pass (candidate products span orders of
+        # magnitude, the static estimate does not see them); every rank computes the same partition
+        eng.run_pass1()
+        leaves = np.zeros(len(all_units), dtype=np.float64)
+        for k, r in zip(mine, eng.results(1, fields=("leaves",))):
+            leaves[k] = float(r["leaves"].sum())
+        t = torch.from_numpy(leaves).to(red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        leaves = t.cpu().numpy()
+        costs = [sharding.unit_cost(u, measured_leaves=float(l)) for u, l in zip(all_units, leaves)]
+        parts = sharding.shard_units(costs, world)
+        mine = parts[rank]
+        units = [all_units[k] for k in mine]
+        truth = [all_truth[k] for k in mine]
+        spans_rank = sum(u.n_spans for u in units)
+        eng.load(units)
+        eng.set_truth(truth)
 
     for _ in range(args.warmup):
-        one_step(eng, args.fit)
+        step()
     barrier()
     t0 = time.perf_counter()
-    enum_ms, sel_ms, fit_ms, pass_ms = [], [], [], []
+    enum_ms, sel_ms, fit_ms, pass_ms, rep_ms = [], [], [], [], []
     for _ in range(args.steps):
-        t1, t2, res = one_step(eng, args.fit)
+        t1, t2, res, gathered = step()
         enum_ms += [t1["enumerate"], t2["enumerate"]]
         sel_ms += [t1["select"], t2["select"]]
+        rep_ms += [t1["repair"], t2["repair"]]
         fit_ms += [t2["fit"]]
         pass_ms += [t1["pass"], t2["pass"]]
     barrier()
     dt = time.perf_counter() - t0
+    stats2 = eng.results(2, fields=("unit_stats",))
+    counters = np.array([sum(r[k] for r in stats2) for k in ("budget_windows", "repaired_windows", "n_windows", "cnt_unassigned")], dtype=np.float64)
+    acc_sum = np.array([sum(r["correct"] for r in res), sum(r["n_in"] for r in res)], dtype=np.float64)
+    per_rank_spans = [spans_rank]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        s = torch.tensor([spans_rank], dtype=torch.float64, device=red_dev)
+        s = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        s[rank] = spans_rank
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        spans_total = float(s.item())
-    else:
-        spans_total = float(spans_rank)
-    acc = float(np.mean([r["accuracy"] for r in res]))  # mean of the per-service accuracies, as the reference reports them
+        per_rank_spans = [int(x) for x in s.cpu().tolist()]
+        c = torch.from_numpy(np.concatenate([counters, acc_sum])).to(red_dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        c = c.cpu().numpy()
+        counters, acc_sum = c[:4], c[4:]
+    spans_total = float(sum(per_rank_spans))
+    acc = float(np.mean([r["accuracy"] for r in res])) if not strong else float(acc_sum[0] / max(acc_sum[1], 1))
     host = eng.results(2, fields=("parent",))          # cross-check of the device reduction, outside the timed region
-    assert abs(acc - float(np.mean([synth.accuracy(r["parent"], tp) for r, tp in zip(host, truth)]))) < 1e-12
+    from traceweaver_amd import synth
+
+    host_acc = [synth.accuracy(r["parent"], tp) for r, tp in zip(host, truth)]
+    assert all(abs(a - r["accuracy"]) < 1e-12 for a, r in zip(host_acc, res)), "device accuracy reduction differs from the host's"
+    verified = None
+    if strong:
+        for k, p in zip(mine, host):
+            assert np.array_equal(gathered[k], p["parent"]), "gathered parents differ from the local result"
+        assert all(g is not None for g in gathered), "the gather left a unit out"
+        if args.verify and rank == 0 and world > 1:
+            eng.load(all_units)
+            eng.set_truth(all_truth)
+            one_step(eng, args.fit)
+            alone = eng.results(2, fields=("parent",))
+            verified = all(np.array_equal(g, a["parent"]) for g, a in zip(gathered, alone))
+            assert verified, "sharded result differs from the single-GPU result"
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = spans_total * args.steps / dt
         # dominant kernel group, measured live with HIP events on the engine's stream (tw_get_timing): the
-        # enumeration kernels and the selection kernels run once per pass, the refit once per step
-        groups = {"k_enumerate": float(np.mean(enum_ms)), "k_select": float(np.mean(sel_ms)), "k_fit": float(np.mean(fit_ms))}
+        # enumeration / selection / repair kernels run once per pass, the refit once per step
+        groups = {"k_enumerate": float(np.mean(enum_ms)), "k_select": float(np.mean(sel_ms)), "k_repair": float(np.mean(rep_ms)),
+                  "k_fit": float(np.mean(fit_ms))}
         dominant = max(groups, key=lambda k: groups[k] * (1 if k == "k_fit" else 2))
-        alg_bytes = 20.0 * spans_rank  # per launch: 16 B read + 4 B written per span
+        alg_bytes = float(ALG_BYTES_PER_SPAN_PER_PASS) * spans_rank  # per launch of a per-pass kernel group
         achieved = alg_bytes / (groups[dominant] * 1e-3) / 1e9
-        traffic = None
-        import glob
-        tpaths = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))
-        if tpaths:  # HBM bytes per launch from the newest committed rocprofv3 PMC passes (profiles/collect.sh)
-            tj = json.load(open(tpaths[-1]))
-            g = tj["groups"].get(dominant)
-            if g and tj.get("spans_per_launch") == spans_rank:
-                traffic = g["fetch_bytes_x2"] + g["write_bytes"]
+        traffic, traffic_src = (None, None) if emulated else profile_traffic(dominant, spans_rank)
         out = {
             "metric": "spans/sec reconstructed + assignment accuracy vs ground truth",
             "value": value, "unit": "spans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "int64 timestamps, f64 scores", "data": "synthetic",
-            "config": {"workload": "media_microservices shape (6 services, E in {1,1,1,1,2,4}), %d requests/service x %d "
-                                   "replicas per GPU, concurrency %.1f, two-pass reconstruction, %s mixture refit"
-                                   % (args.n_in, args.replicas, args.concurrency, args.fit),
-                       "spans_per_gpu": spans_rank, "parallelism": "units sharded, %d rank(s)" % world},
+            "config": {"workload": wl_name + ", two-pass reconstruction, %s mixture refit" % args.fit,
+                       "spans_per_gpu": per_rank_spans[0] if len(set(per_rank_spans)) == 1 else per_rank_spans, "spans_total": int(spans_total),
+                       "parallelism": "units sharded, %d rank(s), backend %s" % (world, args.backend if world > 1 else "none")},
             "accuracy": acc,
+            "budget_windows": int(counters[0]), "repaired_windows": int(counters[1]), "windows": int(counters[2]), "unassigned": int(counters[3]),
             "gpu_pass_ms": {"pass1": float(np.mean(pass_ms[0::2])), "pass2": float(np.mean(pass_ms[1::2]))},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": groups[dominant], "algorithmic_bytes_per_launch": alg_bytes,
                          "group_ms_per_launch": groups},
         }
-        if args.cpu_sample > 0:
+        if verified is not None:
+            out["sharded_equals_single_gpu"] = bool(verified)
+        if not emulated and world == 1:
+            out["roofline"]["peak_measured"] = eng.hbm_copy_gbps()
+        if args.cpu_sample > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, 1000)
-            out["ingest"] = ingest_rate()
+            out["ingest"] = ingest_rate(lib=args.lib)
+            if args.end_to_end:
+                out["end_to_end"] = end_to_end(device, lib=args.lib)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -184,6 +184,15 @@ int tw_set_truth(tw_engine *e, const int32_t *true_child, const int32_t *in_trac
  * right under the exact / the top-5 criterion on this engine alone. */
 int tw_evaluate(tw_engine *e, int64_t *per_unit, uint8_t *trace_flags, int64_t *e2e);
 
+/* Measurement aid for the roofline figures (bench.py): rate of a plain 16-B-per-lane streaming copy kernel over
+ * `bytes` of HBM (read + written bytes per second, in GB/s), `iters` launches timed with HIP events. */
+int tw_measure_hbm_copy(tw_engine *e, int64_t bytes, int32_t iters, double *gbps);
+
+/* Page-locked host buffers for the arrays of a tw_batch / tw_results: tw_load_batch and tw_get_results move pinned
+ * memory at the full host-link rate (pageable memory is staged by the runtime at a fraction of it). */
+int tw_host_alloc(int64_t bytes, void **out);
+void tw_host_free(void *p);
+
 /* One-shot convenience for a single unit: load, pass 1, (optional) pass 2 with caller-supplied
  * mixtures, results of the last pass run.  mix_n == NULL => pass 1 only. */
 int tw_assign_service(tw_engine *e, int32_t n_in, const int64_t *in_start, const int64_t *in_end,

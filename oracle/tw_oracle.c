@@ -788,7 +788,7 @@ static void mwis_enumerate(mwis_comp *c) {
 }
 
 static int two_plain_nodes = 2048;  /* the matching relaxation is consulted from this many search nodes on */
-static int two_node_budget = 4096;  /* search nodes per component; beyond it the incumbent is returned */
+static int two_node_budget = 1 << 24;  /* search nodes per component; beyond it the incumbent is returned and the window is reported */
 #define TWO_MATCH_MIN_DEPTH 4       /* ... and only where at least this many in-spans remain below the node */
 #define TWO_PLAIN_NODES two_plain_nodes
 #define TWO_NODE_BUDGET two_node_budget

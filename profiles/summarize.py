@@ -53,6 +53,87 @@ def counter_per_group(path, counter):
     return per, calls
 
 
+SIMDS = 256 * 4  # MI355X: 256 CUs x 4 SIMDs
+XCDS = 8         # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (measured: 19.1 counts per ns of kernel time = 8 x 2.39 GHz)
+
+
+def short(name):
+    n = name.replace("void ", "").replace("tw::", "")
+    for cut in ("(tw::Dev", "(Dev", "(tw::FitDev", "(FitDev"):
+        if cut in n:
+            n = n[:n.index(cut)]
+    return n[:60]
+
+
+def counters_per_kernel(path):
+    """{kernel: {counter: sum over dispatches}} plus per-kernel launch resources from one counter_collection.csv"""
+    per, res = collections.defaultdict(lambda: collections.defaultdict(float)), {}
+    if not os.path.exists(path):
+        return per, res
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        per[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        key = (k, r["Dispatch_Id"])
+        if key not in seen:
+            seen.add(key)
+            per[k]["_dispatches"] += 1
+            per[k]["_ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        res[k] = (int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]), int(r["SGPR_Count"]), int(r["LDS_Block_Size"]), int(r["Scratch_Size"]),
+                  int(r["Workgroup_Size"]))
+    return per, res
+
+
+def counter_report(tag, src, out, rows):
+    """Per-kernel SQ / GRBM counters of the sq1, sq2, grbm passes -> profiles/<tag>_counters.md.  Formulas are the
+    gfx94x derived metrics (ROCm 7.2 ships none for gfx950, MI355X_MICROARCH.md): SQ cycle counters tick in quad-cycles.
+      waves/SIMD   = 4 * SQ_WAVE_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)        mean resident wavefronts per SIMD
+      VALU busy    = 4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE * 1024)         share of SIMD cycles issuing VALU work
+      lanes active = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)         (divergence: 1.0 = all 64 lanes)
+      wait / stall / issue = SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES
+      LDS conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+    """
+    sq1, res = counters_per_kernel(os.path.join(src, tag + "_sq1", tag + "_counter_collection.csv"))
+    sq2, _ = counters_per_kernel(os.path.join(src, tag + "_sq2", tag + "_counter_collection.csv"))
+    grbm, _ = counters_per_kernel(os.path.join(src, tag + "_grbm", tag + "_counter_collection.csv"))
+    if not sq1:
+        return
+    total = sum(float(r["TotalDurationNs"]) for r in rows)
+    with open(os.path.join(out, tag + "_counters.md"), "w") as f:
+        f.write("# %s per-kernel counters (rocprofv3 --pmc, one pass per counter set, same bench command)\n\n" % tag)
+        f.write(counter_report.__doc__.split("Formulas", 1)[1].join(["Formulas", ""]) if False else "")
+        f.write("Formulas (gfx94x derived metrics; SQ cycle counters tick in quad-cycles): waves/SIMD = 4*SQ_WAVE_CYCLES/(cycles*1024) with cycles = GRBM_GUI_ACTIVE/8 (the counter is summed over the 8 XCDs); "
+                "VALU busy = 4*SQ_ACTIVE_INST_VALU/(cycles*1024); lanes = SQ_THREAD_CYCLES_VALU/(64*SQ_ACTIVE_INST_VALU); "
+                "wait / stall / issue = SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES; LDS conflict = "
+                "SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE; VGPR = arch + accumulation registers per lane; scratch in bytes per lane.\n\n")
+        f.write("| kernel | % GPU time | avg us | VGPR | LDS B | scratch | waves launched/call | waves/SIMD | VALU busy | lanes | wait | stall | issue | "
+                "LDS conflict | VALU : SALU : LDS : VMEM rd : VMEM wr insts/wave |\n|" + "---|" * 15 + "\n")
+        for r in rows[:24]:
+            k = short(r["Name"])
+            a, b, g = sq1.get(k), sq2.get(k), grbm.get(k)
+            if not a or a["_dispatches"] == 0:
+                continue
+            n = a["_dispatches"]
+            gui = (g["GRBM_GUI_ACTIVE"] / g["_dispatches"] / XCDS) if g and g["_dispatches"] else float("nan")
+            wc = a["SQ_WAVE_CYCLES"] / n
+            waves = a["SQ_WAVES"] / n
+            v = res.get(k, (0, 0, 0, 0, 0))
+            nb = b["_dispatches"] if b and b["_dispatches"] else float("nan")
+            lanes = (a["SQ_THREAD_CYCLES_VALU"] / (64.0 * a["SQ_ACTIVE_INST_VALU"])) if a.get("SQ_THREAD_CYCLES_VALU") and a["SQ_ACTIVE_INST_VALU"] else float("nan")
+            mix = "-"
+            if b:
+                wv = max(a["SQ_WAVES"] / n, 1.0)
+                mix = "%.0f : %.0f : %.0f : %.0f : %.0f" % (a["SQ_INSTS_VALU"] / n / wv, b["SQ_INSTS_SALU"] / nb / wv, b["SQ_INSTS_LDS"] / nb / wv,
+                                                       b["SQ_INSTS_VMEM_RD"] / nb / wv, b["SQ_INSTS_VMEM_WR"] / nb / wv)
+            conflict = (b["SQ_LDS_BANK_CONFLICT"] / b["SQ_LDS_IDX_ACTIVE"]) if b and b["SQ_LDS_IDX_ACTIVE"] else float("nan")
+            f.write("| `%s` | %.1f | %.1f | %d | %d | %d | %.0f | %.2f | %.3f | %.2f | %.2f | %.2f | %.2f | %.3f | %s |\n" % (
+                k, 100.0 * float(r["TotalDurationNs"]) / total, float(r["AverageNs"]) / 1e3, v[0], v[2], v[3], waves,
+                4.0 * wc / (gui * SIMDS), 4.0 * a["SQ_ACTIVE_INST_VALU"] / n / (gui * SIMDS), lanes,
+                a["SQ_WAIT_ANY"] / max(a["SQ_WAVE_CYCLES"], 1), a["SQ_WAIT_INST_ANY"] / max(a["SQ_WAVE_CYCLES"], 1),
+                a["SQ_ACTIVE_INST_ANY"] / max(a["SQ_WAVE_CYCLES"], 1), conflict, mix))
+    print(open(os.path.join(out, tag + "_counters.md")).read())
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     out = os.path.join(REPO, "profiles")
@@ -68,7 +149,10 @@ def main():
     for r in rows:
         dur[group_of(r["Name"])] += float(r["TotalDurationNs"])
     spans = bench["config"]["spans_per_gpu"]
-    traffic = {"tag": tag, "workload": bench["config"]["workload"], "spans_per_launch": spans, "launch_sets": passes, "groups": {}}
+    digest = os.path.join(src, tag + "_digest.txt")
+    traffic = {"tag": tag, "source_digest": open(digest).read().strip() if os.path.exists(digest) else None,
+               "commit": open(os.path.join(src, tag + "_commit.txt")).read().strip() if os.path.exists(os.path.join(src, tag + "_commit.txt")) else None,
+               "workload": bench["config"]["workload"], "spans_per_launch": spans, "launch_sets": passes, "groups": {}}
     for g in sorted(dur, key=lambda k: -dur[k]):
         n = passes if g in ("k_enumerate", "k_select", "repair") else passes // 2   # per pass / per step
         traffic["groups"][g] = {
@@ -89,6 +173,7 @@ def main():
         for r in rows[:14]:
             f.write("| `%s` | %s | %.1f | %s |\n" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
     print(open(os.path.join(out, tag + "_summary.md")).read())
+    counter_report(tag, src, out, rows)
 
 
 if __name__ == "__main__":

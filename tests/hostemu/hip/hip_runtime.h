@@ -32,6 +32,7 @@
 #define __shared__ static
 #define __launch_bounds__(...)
 
+struct uint4 { unsigned x, y, z, w; };
 struct dim3 {
     unsigned x, y, z;
     dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
@@ -61,6 +62,9 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
 }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorEmu; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+enum { hipHostMallocDefault = 0 };
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorEmu; }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }

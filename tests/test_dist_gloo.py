@@ -144,3 +144,48 @@ def test_shard_units_is_deterministic_and_complete():
         assert parts == sharding.shard_units(costs, world)
         assert sorted(k for p in parts for k in p) == list(range(len(costs)))
     assert sharding.gather_parents([np.zeros((1, 2), np.int32)], [0], 1)[0].shape == (1, 2)
+
+
+def _run_bench(emu_lib, *flags):
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--lib", emu_lib, "--cpu-sample", "0", "--steps", "1", "--warmup", "1"]
+                         + list(flags), capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints the one JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_two_ranks(emu_lib):
+    """`python bench.py --gpus 2` launches its own ranks (torch.distributed.run on 127.0.0.1) -- here over gloo against
+    the host-emulation build of the engine -- and reports the whole job."""
+    one = _run_bench(emu_lib, "--gpus", "1", "--n-in", "1500", "--replicas", "1")
+    two = _run_bench(emu_lib, "--gpus", "2", "--backend", "gloo", "--n-in", "1500", "--replicas", "1")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["spans_total"] == 2 * one["config"]["spans_total"] == 2 * two["config"]["spans_per_gpu"]
+    assert two["budget_windows"] == 0 and 0.9 < two["accuracy"] <= 1.0
+    for key in ("roofline", "gpu_pass_ms", "repaired_windows", "windows"):
+        assert key in two
+
+
+def test_bench_rejects_a_world_size_that_is_not_gpus(emu_lib):
+    import subprocess
+
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--lib", emu_lib, "--gpus", "4", "--cpu-sample", "0"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+
+
+def test_bench_alibaba_slice_sharded_over_two_ranks_equals_one(emu_lib):
+    """BASELINE.json config 4 in small: one Alibaba-shape slice sharded per service (shard_units on measured work) ->
+    engine -> all-gather of the parents; rank 0 re-solves the whole slice alone and the results must be identical."""
+    r = _run_bench(emu_lib, "--gpus", "2", "--backend", "gloo", "--workload", "alibaba", "--total-spans", "30000", "--verify", "1")
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["sharded_equals_single_gpu"] is True
+    assert sum(r["config"]["spans_per_gpu"]) == r["config"]["spans_total"]
+    assert r["budget_windows"] == 0

@@ -59,7 +59,10 @@ def test_heavier_stress_units():
     cases = [(21, 3000, "chain3", 6, 1), (22, 3000, "par2", 8, 1000), (23, 2000, "diamond", 4, 1),
              (24, 5000, "single", 12, 1), (25, 1500, "par4", 2.5, 1), (26, 4000, "chain2", 10, 1000)]
     units, _ = parity.stress_units(cases)
-    parity.check_units(None, units)
+    # ms-granular timestamps at 8-12 requests in flight: saturated with exact ties, the regime where a selection search
+    # can run out of its node budget (the reference's solver takes minutes per window there)
+    r1, r2, _ = parity.check_units(None, units, allow_budget=True)
+    assert sum(r["budget_windows"] for r in r1 + r2) <= 8
 
 
 def test_media_shape_at_scale():
@@ -67,6 +70,7 @@ def test_media_shape_at_scale():
     the oracle plus size-independent properties of the assignment."""
     units, truth = synth.make_workload(7, 60000, services=synth.MEDIA_SERVICES, concurrency=1.6)
     r1, r2, ora = parity.check_units(None, units)
+    assert sum(r["budget_windows"] for r in r1 + r2) == 0           # every selection is a proven optimum
     for u, tp, r in zip(units, truth, r2):
         par = r["parent"]
         assigned = par[0] >= 0
@@ -90,6 +94,8 @@ def test_nodejs_fileio_shape_at_scale():
     comparison with the oracle at 20k requests per service -- exact score ties everywhere."""
     units, truth = synth.make_nodejs_workload(13, 20000, concurrency=4.0)
     r1, r2, _ = parity.check_units(None, units)
+    assert sum(r["budget_windows"] for r in r1 + r2) == 0           # every selection is a proven optimum
+    assert sum(r["repaired_windows"] for r in r1 + r2) > 0
     for u, r in zip(units, r2):
         parity.assert_assignment_properties(u, r["parent"])
 
@@ -113,6 +119,7 @@ def test_alibaba_shape_1m_span_slice():
     res = eng.results(2, fields=("parent", "unit_stats"))
     per = eng.evaluate()
     eng.close()
+    assert sum(r["budget_windows"] for r in res) == 0               # every selection is a proven optimum
     for u, tp, r, ev in zip(units, truth, res, per):
         parity.assert_assignment_properties(u, r["parent"])
         assert ev["correct"] == int(np.all(r["parent"] == tp, axis=0).sum())

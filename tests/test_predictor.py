@@ -77,6 +77,22 @@ def test_end_to_end_reproduces_frozen_reference_run(emu_lib):
     run_frontend_case(emu_lib)
 
 
+def test_second_service_of_a_seeded_run(emu_lib):
+    """One predictor instance, one seed, two services in the executor's order: the second service starts from the RNG
+    state the first one left behind -- which includes the discarded fits the reference runs after its second pass
+    (traceweaver_v3.py:1221-1222) -- and must still reproduce the frozen reference run."""
+    pred = run_frontend_case(emu_lib)
+    d = np.load([f for f in GOLDEN if "hotel_load100__search" in f][0])
+    in_parts, out_parts, graph, truth, out_eps = protocol_inputs(d)
+    ret = pred.FindAssignments("MaxScoreBatchSubsetWithSkips", "search", in_parts, out_parts, False, [], truth, graph)
+    in_spans = list(in_parts.values())[0]
+    parent = np.array([[int(ret[0][ep][s.GetId()][1].rsplit("_", 1)[1]) if ret[0][ep][s.GetId()] != ("NA", "NA") else -1
+                        for s in in_spans] for ep in out_eps])
+    assert np.array_equal(parent, d["final_parent"])
+    assert ret[2] == int(d["not_best_count"]) and ret[5] == int(d["cnt_unassigned"])
+    assert pred.last_stats["budget_windows"] == 0
+
+
 def test_skip_mode_is_rejected_loudly(emu_lib):
     from traceweaver_amd.predictor import TraceWeaverGPU
 

@@ -52,7 +52,7 @@ class Results(ctypes.Structure):
 
 EXPORTS = ["tw_create", "tw_destroy", "tw_last_error", "tw_load_batch", "tw_run_pass1", "tw_get_gaps",
            "tw_set_mixtures", "tw_fit_mixtures", "tw_get_mixtures", "tw_run_pass2", "tw_get_results", "tw_get_gauss_params", "tw_get_timing",
-           "tw_assign_service", "tw_find_order", "tw_set_truth", "tw_evaluate",
+           "tw_assign_service", "tw_find_order", "tw_set_truth", "tw_evaluate", "tw_measure_hbm_copy", "tw_host_alloc", "tw_host_free",
            "tw_corpus_create", "tw_corpus_destroy", "tw_corpus_last_error", "tw_corpus_add_files", "tw_corpus_set_callers", "tw_corpus_counts",
            "tw_corpus_string", "tw_corpus_loop_origin", "tw_corpus_trace_names", "tw_corpus_span_table", "tw_corpus_build_units"]
 
@@ -85,6 +85,10 @@ def load(path=None):
     lib.tw_find_order.argtypes = [vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp]
     lib.tw_set_truth.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.tw_evaluate.argtypes = [vp, vp, vp, vp]
+    lib.tw_measure_hbm_copy.argtypes = [vp, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
+    lib.tw_host_alloc.argtypes = [ctypes.c_int64, ctypes.POINTER(vp)]
+    lib.tw_host_free.argtypes = [vp]
+    lib.tw_host_free.restype = None
     lib.tw_corpus_create.argtypes = [ctypes.POINTER(vp)]
     lib.tw_corpus_destroy.argtypes = [vp]
     lib.tw_corpus_destroy.restype = None
@@ -101,6 +105,6 @@ def load(path=None):
     lib.tw_corpus_span_table.argtypes = [vp, ctypes.POINTER(SpanTable)]
     lib.tw_corpus_build_units.argtypes = [vp, ctypes.POINTER(UnitSet)]
     for name in EXPORTS:
-        if name not in ("tw_destroy", "tw_last_error", "tw_corpus_destroy", "tw_corpus_last_error", "tw_corpus_string", "tw_corpus_loop_origin"):
+        if name not in ("tw_destroy", "tw_last_error", "tw_host_free", "tw_corpus_destroy", "tw_corpus_last_error", "tw_corpus_string", "tw_corpus_loop_origin"):
             getattr(lib, name).restype = ctypes.c_int
     return lib

@@ -15,6 +15,18 @@ SOURCES = ["tw_engine.hip", "tw_kernels.h", "tw_device.h", "tw_fit.h", "tw_eval.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread"]
 
 
+def source_digest():
+    """sha256 over the kernel / engine sources and the ABI header: profiles record it (profiles/summarize.py) so that
+    bench.py only quotes HBM-traffic counters taken from exactly the code that is running."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in [os.path.join(SRC, f) for f in sorted(SOURCES)] + [os.path.join(REPO, "include", "traceweaver_amd.h")]:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True

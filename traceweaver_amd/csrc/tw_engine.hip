@@ -779,6 +779,16 @@ int tw_set_truth(tw_engine* e, const int32_t* true_child, const int32_t* in_trac
     if (e->state < ST_LOADED) return fail(e, TW_ERR_STATE, "tw_set_truth before tw_load_batch");
     if (in_trace != nullptr && n_traces <= 0) return fail(e, TW_ERR_ARG, "in_trace given without n_traces");
     HIPCHK(hipSetDevice(e->device));
+    // k_evaluate indexes trace_bad[] with in_trace and compares parents with true_child: both are checked here, once,
+    // on the host (an out-of-range trace number would be an out-of-bounds store on the device)
+    for (const UnitDev& U : e->units) {
+        const int32_t* t = true_child + U.ie_off;
+        for (int64_t k = 0; k < (int64_t)U.E * U.n_in; k++)
+            if (t[k] < -1 || t[k] >= U.n_in) return fail(e, TW_ERR_ARG, "tw_set_truth: true_child outside [-1, n_in)");
+    }
+    if (in_trace != nullptr)
+        for (int64_t k = 0; k < e->P.n_in_total; k++)
+            if (in_trace[k] < -1 || in_trace[k] >= n_traces) return fail(e, TW_ERR_ARG, "tw_set_truth: in_trace outside [-1, n_traces)");
     int rc;
     if (e->truth == nullptr) {
         rc = dev_alloc(e, &e->truth, e->n_ie); if (rc != TW_OK) return rc;
@@ -829,6 +839,41 @@ int tw_evaluate(tw_engine* e, int64_t* per_unit, uint8_t* trace_flags, int64_t* 
     }
     if (e2e != nullptr) { e2e[0] = (int64_t)h[(size_t)nc - 2]; e2e[1] = (int64_t)h[(size_t)nc - 1]; }
     return TW_OK;
+}
+
+int tw_measure_hbm_copy(tw_engine* e, int64_t bytes, int32_t iters, double* gbps) {
+    if (e == nullptr || gbps == nullptr || bytes < (1 << 20) || iters < 1) return TW_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    void *a = nullptr, *b = nullptr;
+    const size_t n16 = (size_t)bytes / 16;
+    hipError_t s = hipMalloc(&a, n16 * 16);
+    if (s == hipSuccess) s = hipMalloc(&b, n16 * 16);
+    if (s == hipSuccess) s = hipMemsetAsync(a, 1, n16 * 16, e->stream);
+    if (s == hipSuccess) {
+        const unsigned grid = 256 * 8 * 4;  // 32 workgroups of 256 threads per CU
+        hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, e->stream, (const uint4*)a, (uint4*)b, (int64_t)n16);  // warm-up
+        s = hipEventRecord(e->ev[EV_BEGIN], e->stream);
+        for (int k = 0; k < iters; k++) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, e->stream, (const uint4*)a, (uint4*)b, (int64_t)n16);
+        if (s == hipSuccess) s = hipEventRecord(e->ev[EV_END], e->stream);
+        if (s == hipSuccess) s = hipStreamSynchronize(e->stream);
+        float ms = 0.f;
+        if (s == hipSuccess) s = hipEventElapsedTime(&ms, e->ev[EV_BEGIN], e->ev[EV_END]);
+        if (s == hipSuccess) *gbps = 2.0 * (double)(n16 * 16) * iters / ((double)ms * 1e-3) / 1e9;
+    }
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (s != hipSuccess) return fail(e, TW_ERR_DEVICE, std::string("tw_measure_hbm_copy: ") + hipGetErrorString(s));
+    return TW_OK;
+}
+
+int tw_host_alloc(int64_t bytes, void** out) {
+    if (out == nullptr || bytes < 0) return TW_ERR_ARG;
+    *out = nullptr;
+    return hipHostMalloc(out, (size_t)std::max<int64_t>(bytes, 8), hipHostMallocDefault) == hipSuccess ? TW_OK : TW_ERR_DEVICE;
+}
+
+void tw_host_free(void* p) {
+    if (p != nullptr) (void)hipHostFree(p);
 }
 
 /* Debug aid, not part of the public header: sizes of the work lists of the last pass --

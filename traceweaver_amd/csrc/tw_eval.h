@@ -94,6 +94,12 @@ __global__ void __launch_bounds__(kTile) k_evaluate(Dev P, const int32_t* truth,
     }
 }
 
+// Streaming copy, 16 B per lane (tw_measure_hbm_copy): the HBM rate a plain kernel reaches on this device, the
+// measured ceiling quoted next to the 8 TB/s specification in the roofline figures.
+__global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 __global__ void k_count_flags(const uint8_t* a, const uint8_t* b, int64_t n, unsigned long long* out) {  // out[0] += #a[i]==0, out[1] += #b[i]==0
     unsigned long long ca = 0, cb = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

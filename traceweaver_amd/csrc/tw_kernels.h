@@ -1549,56 +1549,55 @@ __device__ inline bool cands_share(const Dev& P, const UnitDev& U, int i, int a,
 
 // Exact selection, canonical procedure (shared with the oracle so that exact ties resolve identically):
 //   node weight 10000 + score (traceweaver_v3.py:1260); nodes with weight <= 0 are never selected; the
-//   window is split into connected components of the span conflict relation; each component is searched
-//   depth-first over its spans in index order, candidates in list order then "none", sums accumulated
-//   left to right; a subtree is cut when acc + upper bound <= best; only strict improvements replace the
-//   incumbent.  The answer is the first optimal selection in that depth-first order and does not depend
-//   on the bound.  Upper bound: the remaining spans cut into groups of <= 3 consecutive spans, every group
-//   solved exactly on its own, cheapest cutting (the sum of the best weights is the all-singletons cutting;
-//   pairs and triples see spans that compete for the same outgoing spans); once a component's search has
-//   visited kPlainNodes nodes, at nodes with >= kMatchMinDepth spans left additionally the matching
-//   relaxation: relax every endpoint but e -- what remains is a maximum-weight bipartite matching between
-//   the remaining spans and the outgoing spans of endpoint e (edge weight = best still-compatible
-//   candidate using that span, a span may stay unmatched), solved with the Hungarian algorithm (exact for
-//   E = 1); endpoints are tried in order and the first one that proves acc + bound <= best cuts the node.
-//   A component whose search exceeds kNodeBudget nodes keeps its incumbent and the window is counted in
-//   unit_stats[4].
+//   window is split into connected components of the span conflict relation; the answer for a component is
+//   the FIRST selection of maximum weight in depth-first order: spans in index order, candidates in list
+//   order then "none", sums accumulated left to right, only strict improvements replace the incumbent.
+//   That selection does not depend on how the tree is searched or bounded, so the oracle (one depth-first
+//   search with an additional matching relaxation) and this engine (many sub-trees at once) agree whenever
+//   both searches complete.  Upper bound of a suffix of the component: the remaining spans cut into groups of
+//   <= 3 consecutive spans, every group solved exactly on its own, cheapest cutting (the sum of the best
+//   weights is the all-singletons cutting; pairs and triples see spans that compete for the same outgoing
+//   spans).
 //
 // Mapping: k_select_fast settles the windows whose best candidates do not clash (one lane per span) and
-// lists the others; k_select_heavy solves a listed window per workgroup (one wavefront), candidate data
-// and the search state in LDS: components of <= kBruteMax spans by complete enumeration spread over the
-// lanes, larger ones by the depth-first search (thread 0) with the grouped bound evaluated by all lanes
-// and the column scans of the Hungarian algorithm spread over the lanes.
-constexpr int kPlainNodes = 2048;    // the matching relaxation is consulted from this many search nodes on ...
-constexpr int kMatchMinDepth = 4;    // ... and only where at least this many spans remain below the node
-constexpr int kNodeBudget = 4096;    // search nodes per component; beyond it the incumbent is returned
-constexpr int kMatchMaxCols = 256;   // widest span-index range one endpoint's relaxation may address
-constexpr int kMaxCols = kMatchMaxCols + kMaxWin + 1;
+// lists the others; k_select_heavy solves a listed window per wavefront, candidate data in LDS: components
+// of <= kBruteMax spans by complete enumeration spread over the lanes, larger ones by select_search: the
+// tree is cut below its first D levels into P >= 4 x lanes sub-trees, the lanes draw sub-trees in
+// depth-first order from a counter and search them independently -- the search stack of a lane is 3 bits
+// per level in registers, the weight above a node and the set of blocked candidates are rebuilt from it
+// when the search returns to a level -- and share only the best weight found so far.  A lane cuts a node
+// when acc + bound <= its own incumbent (an earlier leaf of an earlier or the same sub-tree: ties go to the
+// earlier leaf, as in the sequential search) or when acc + bound < the shared best weight (strictly: a tie
+// with a later sub-tree must survive).  The winner is the largest weight, the smallest sub-tree among equal
+// weights.  A lane that visits more than kNodeBudget / lanes nodes on one component stops; the window then keeps the
+// best selection found and is counted in unit_stats[4] (not proven optimal).
+constexpr int kNodeBudget = 1 << 24; // search nodes per component, shared evenly by the lanes (2^18 per lane of a wavefront)
 constexpr int kBlkWords = (kMaxWin * kTopK + 63) / 64;  // words of a mask over all candidates of a component
 constexpr int kBigWindow = 8;        // windows of at least this many spans are served first by k_select_heavy
 constexpr int kBruteMax = 4;         // components of up to this many spans are solved by complete enumeration (see select_brute)
+constexpr int kStackWords = (kMaxWin + 9) / 10;  // search stack: 3 bits per level, 10 levels per 32-bit word
+constexpr int kPrefixMax = 10;       // levels above the sub-trees: 4 x 256 sub-trees are reached after <= 10 levels of >= 2 choices
 
 // ---- cooperative path: one workgroup per window --------------------------------------------------
 struct SelectLds {
     int32_t idx[kMaxWin][kTopK][kMaxEp];
     double w[kMaxWin][kTopK];  // 10000 + score; <= 0 means not eligible
-    double ub[kMaxWin + 1], accs[kMaxWin + 1];
-    double u[kMaxWin + 1], v[kMaxCols], minv[kMaxCols], cost[kMaxWin][kTopK];
+    double ub[kMaxWin + 1];
     double red_val[kCoop / 64];
-    double best_w, bound, delta;
-    int32_t red_idx[kCoop / 64], col[kMaxWin][kTopK];
-    int16_t p[kMaxCols], way[kMaxCols];
-    uint8_t used[kMaxCols], ncand[kMaxWin], comp[kMaxWin], mem[kMaxWin], ndeg[kMaxWin];
-    int8_t cur[kMaxWin], best[kMaxWin], next[kMaxWin + 1], pick[kMaxWin];
+    int32_t red_idx[kCoop / 64];
+    uint8_t ncand[kMaxWin], comp[kMaxWin], mem[kMaxWin];
+    int8_t pick[kMaxWin];
     uint32_t adj[kMaxWin];  // span conflict relation as bit rows
     uint32_t cmask[kBruteMax][kTopK], celig[kBruteMax];  // select_brute: conflicts among / eligibility of the component's candidates
     unsigned long long g2[kMaxWin], g3[kMaxWin];  // bit patterns of the pair / triple optima of the grouped bound (weights are > 0)
-    // depth-first search: conflicts of candidate k of member x with the candidates of the other members as a bit
-    // mask over (member y, candidate k2) -> bit y*kTopK+k2, and per depth the union of the masks of the choices above
-    unsigned long long cmask3[kMaxWin][kTopK][kBlkWords], blk[kMaxWin + 1][kBlkWords];
-    int cm, d, nodes, entered, state, j0, j1, nrow, ncol_real, budget_hit, base, top, prune;
+    // select_search: conflicts of candidate k of member x with the candidates of the other members as a bit
+    // mask over (member y, candidate k2) -> bit y*kTopK+k2
+    unsigned long long cmask3[kMaxWin][kTopK][kBlkWords];
+    unsigned long long gbest;       // bit pattern of the best weight any lane has found (weights are > 0: the patterns order like the values)
+    unsigned long long win_key;     // reduction of the lanes' results
+    uint32_t win_stack[kStackWords];
+    int cm, budget_hit, next_sub, n_sub, depth0, win_sub;
 };
-enum { SEL_RUN = 0, SEL_NEED_BOUND = 1, SEL_DONE = 2 };
 
 __device__ inline bool lds_share(const SelectLds& L, int E, int b1, int k1, int b2, int k2) {
     for (int e = 0; e < E; e++)
@@ -1606,187 +1605,146 @@ __device__ inline bool lds_share(const SelectLds& L, int E, int b1, int k1, int 
     return false;
 }
 
-// is candidate k of member x blocked by the choices made above depth d?
-__device__ inline bool lds_blocked(const SelectLds& L, int d, int x, int k) {
-    const int bit = x * kTopK + k;
-    return (L.blk[d][bit >> 6] >> (bit & 63)) & 1ull;
+__device__ __forceinline__ int stack_get(const uint32_t (&st)[kStackWords], int d) {
+    const int wd = d / 10, sh = (d % 10) * 3;
+    uint32_t v = 0;
+#pragma unroll
+    for (int q = 0; q < kStackWords; q++) v = q == wd ? st[q] : v;
+    return (int)((v >> sh) & 7u);
+}
+__device__ __forceinline__ void stack_set(uint32_t (&st)[kStackWords], int d, int k) {
+    const int wd = d / 10, sh = (d % 10) * 3;
+#pragma unroll
+    for (int q = 0; q < kStackWords; q++) st[q] = q == wd ? ((st[q] & ~(7u << sh)) | ((uint32_t)k << sh)) : st[q];
 }
 
-// Hungarian algorithm on the graph in L (rows = remaining spans, <= kTopK finite entries per row plus
-// the row's own zero-cost dummy column); every thread of the workgroup takes part.  Result: L.bound = -min cost.
-__device__ void hungarian_coop(SelectLds& L) {
-    const double INF = 1.0e300;
+// Depth-first search of a component of more than kBruteMax spans, sub-trees spread over the lanes (see above).
+// Needs L.cm, L.mem, L.ncand, L.w, L.ub, L.cmask3; writes L.pick of the members.
+__device__ void select_search(SelectLds& L) {
+    static_assert(kBlkWords == 3, "the blocked mask is kept in three registers");
+    static_assert(kTopK + 1 <= 7, "a level's choice must fit 3 bits");
     const int t = threadIdx.x, nt = blockDim.x;
-    const int lane = t & 63, wave = t >> 6, nwave = (nt + 63) >> 6;
-    const int n = L.nrow, m = L.ncol_real + n;
-    for (int j = t; j <= m; j += nt) { L.v[j] = 0.0; L.p[j] = 0; }
-    for (int i = t; i <= n; i += nt) L.u[i] = 0.0;
+    const int cm = L.cm;
+    if (t == 0) {
+        int D = 0, P = 1;
+        while (D < cm - 1 && D < kPrefixMax && P < 4 * nt) { P *= (int)L.ncand[L.mem[D]] + 1; D++; }
+        L.depth0 = D; L.n_sub = P; L.next_sub = 0; L.gbest = 0ull; L.win_key = 0ull; L.win_sub = -1;
+    }
     group_sync();
-    for (int i = 1; i <= n; i++) {
-        for (int j = t; j <= m; j += nt) { L.minv[j] = INF; L.used[j] = 0; L.way[j] = 0; }
-        if (t == 0) L.p[0] = (int16_t)i;
-        int j0 = 0;  // wave-uniform
-        group_sync();
+    const int D = L.depth0, P = L.n_sub;
+    double own_w = 0.0;           // incumbent of this lane: only strict improvements replace it
+    int own_sub = -1;
+    uint32_t own_st[kStackWords], st[kStackWords];
+#pragma unroll
+    for (int q = 0; q < kStackWords; q++) { own_st[q] = 0; st[q] = 0; }
+    int nodes = 0;
+    const int lane_budget = kNodeBudget / nt;
+    bool over = false;
+    while (!over) {
+        const int sub = atomicAdd(&L.next_sub, 1);   // sub-trees are handed out in depth-first order
+        if (sub >= P) break;
+        // the sub-tree's prefix: digit q of `sub` (first member most significant) = candidate, or ncand = "none"
+        double acc = 0.0;
+        unsigned long long b0 = 0, b1 = 0, b2 = 0;
+        bool ok = true;
+        {
+            int rest = sub;
+            int digit[kPrefixMax];
+#pragma unroll
+            for (int q = kPrefixMax - 1; q >= 0; q--) {
+                if (q < D) { const int r = (int)L.ncand[L.mem[q]] + 1; digit[q] = rest % r; rest /= r; } else digit[q] = 0;
+            }
+#pragma unroll
+            for (int q = 0; q < kPrefixMax; q++) {
+                if (q >= D || !ok) continue;
+                const int b = L.mem[q], k = digit[q];
+                stack_set(st, q, k);
+                if (k == (int)L.ncand[b]) continue;   // "none"
+                const double w = L.w[b][k];
+                const int bit = q * kTopK + k;
+                if (!(w > 0.0) || (((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull)) { ok = false; continue; }
+                acc = acc + w;
+                b0 |= L.cmask3[q][k][0]; b1 |= L.cmask3[q][k][1]; b2 |= L.cmask3[q][k][2];
+            }
+        }
+        if (!ok) continue;
+        int d = D;
+        bool entered = true;
         while (true) {
-            if (t == 0) {  // relax the (<= kTopK + 1) finite entries of row i0
-                L.used[j0] = 1;
-                const int i0 = L.p[j0], deg = L.ndeg[i0 - 1];
-                for (int q = 0; q <= deg; q++) {
-                    const int j = q < deg ? L.col[i0 - 1][q] : L.ncol_real + i0;
-                    const double a = q < deg ? L.cost[i0 - 1][q] : 0.0;
-                    if (L.used[j]) continue;
-                    const double cur = a - L.u[i0] - L.v[j];
-                    if (cur < L.minv[j]) { L.minv[j] = cur; L.way[j] = (int16_t)j0; }
-                }
-            }
-            group_sync();
-            // first minimum of minv over the unused columns: per lane (ascending j), then across lanes -- the
-            // smaller column index wins among equal values, exactly like the sequential scan
-            double dv = INF;
-            int dj = 0;
-            for (int j = 1 + t; j <= m; j += nt)
-                if (!L.used[j] && L.minv[j] < dv) { dv = L.minv[j]; dj = j; }
-            for (int off = 32; off >= 1; off >>= 1) {
-                if (off < nt) {
-                    const double ov = __shfl_down(dv, off);
-                    const int oj = __shfl_down(dj, off);
-                    if (ov < dv || (ov == dv && oj != 0 && (dj == 0 || oj < dj))) { dv = ov; dj = oj; }
-                }
-            }
-            if (nwave > 1) {
-                if (lane == 0) { L.red_val[wave] = dv; L.red_idx[wave] = dj; }
-                group_sync();
-                dv = L.red_val[0]; dj = L.red_idx[0];
-                for (int q = 1; q < nwave; q++) {
-                    const double ov = L.red_val[q];
-                    const int oj = L.red_idx[q];
-                    if (ov < dv || (ov == dv && oj != 0 && (dj == 0 || oj < dj))) { dv = ov; dj = oj; }
+            int k = 0;
+            bool up = false;
+            if (entered) {
+                if (++nodes > lane_budget) { over = true; break; }
+                if (d == cm) {
+                    if (acc > own_w) {
+                        own_w = acc; own_sub = sub;
+#pragma unroll
+                        for (int q = 0; q < kStackWords; q++) own_st[q] = st[q];
+                        atomicMax(&L.gbest, (unsigned long long)__double_as_longlong(acc));
+                    }
+                    up = true;
+                } else {
+                    const double bound = acc + L.ub[d];
+                    if (bound <= own_w || bound < __longlong_as_double((long long)L.gbest)) up = true;
                 }
             } else {
-                dv = __shfl(dv, 0);
-                dj = __shfl(dj, 0);
+                k = stack_get(st, d) + 1;   // resume below the choice this level made last
             }
-            const double delta = dv;
-            for (int j = t; j <= m; j += nt) {
-                if (L.used[j]) { L.u[L.p[j]] += delta; L.v[j] -= delta; }
-                else if (L.minv[j] < INF) L.minv[j] -= delta;
+            if (!up) {
+                const int b = L.mem[d], nc = L.ncand[b];
+                bool found = false;
+                for (; k <= nc; k++) {
+                    if (k == nc) { found = true; break; }   // "none"
+                    const double w = L.w[b][k];
+                    if (!(w > 0.0)) continue;
+                    const int bit = d * kTopK + k;
+                    if (((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull) continue;
+                    acc = acc + w;
+                    b0 |= L.cmask3[d][k][0]; b1 |= L.cmask3[d][k][1]; b2 |= L.cmask3[d][k][2];
+                    found = true;
+                    break;
+                }
+                if (found) { stack_set(st, d, k); d++; entered = true; continue; }
+                up = true;
             }
-            j0 = dj;
-            group_sync();
-            if (L.p[j0] == 0) break;
+            // return to the level above: its weight and blocked set are rebuilt from the stack (sums left to right,
+            // exactly the additions the descent made)
+            d--;
+            if (d < D) break;
+            entered = false;
+            acc = 0.0; b0 = 0; b1 = 0; b2 = 0;
+            for (int q = 0; q < d; q++) {
+                const int kq = stack_get(st, q), bq = L.mem[q];
+                if (kq == (int)L.ncand[bq]) continue;
+                acc = acc + L.w[bq][kq];
+                b0 |= L.cmask3[q][kq][0]; b1 |= L.cmask3[q][kq][1]; b2 |= L.cmask3[q][kq][2];
+            }
         }
-        if (t == 0) {
-            int jj = j0;
-            do { const int j1 = L.way[jj]; L.p[jj] = L.p[j1]; jj = j1; } while (jj);
-        }
-        group_sync();
     }
-    if (t == 0) L.bound = L.v[0];  // = -(min cost)
+    if (over) L.budget_hit = 1;
+    // winner: largest weight, smallest sub-tree among equal weights (a lane's own result is already the first leaf of
+    // that weight among its sub-trees, which it visited in increasing order).  Weights are < 2^21 in magnitude only by
+    // construction of the key; the comparison itself is done on (bit pattern of the weight, -sub-tree).
     group_sync();
-}
-
-// matching relaxation for members d..cm-1 given L.cur[0..d): L.prune = 1 as soon as one endpoint proves
-// accs[d] + bound <= best_w.  Columns are addressed directly by span index (no de-duplication: a row may
-// list a column twice, the relax step takes the minimum), so the graph is built by all lanes at once.
-__device__ void match_prunes_coop(SelectLds& L, int E) {
-    const int t = threadIdx.x, nt = blockDim.x;
-    if (t == 0) L.prune = 0;
-    for (int e = 0; e < E; e++) {
-        const int d = L.d, nrow = L.cm - d;
-        if (t == 0) { L.base = 0x7fffffff; L.top = -0x7fffffff - 1; L.nrow = nrow; }
-        for (int r = t; r < nrow; r += nt) L.ndeg[r] = 0;
-        group_sync();
-        for (int r = t; r < nrow; r += nt) {  // one lane per remaining span: compatible candidates in list order
-            const int b = L.mem[d + r];
-            int deg = 0;
-            for (int k = 0; k < L.ncand[b]; k++) {
-                const double w = L.w[b][k];
-                if (!(w > 0.0)) continue;
-                if (lds_blocked(L, d, d + r, k)) continue;
-                const int32_t x = L.idx[b][k][e];
-                atomicMin(&L.base, x);
-                atomicMax(&L.top, x);
-                L.col[r][deg] = x;
-                L.cost[r][deg] = -w;
-                deg++;
-            }
-            L.ndeg[r] = (uint8_t)deg;
-        }
-        group_sync();
-        const int base = L.top < L.base ? 1 : L.base, ncol = L.top < L.base ? 0 : L.top - L.base + 1;
-        if (ncol > kMatchMaxCols) { group_sync(); continue; }  // uniform: range too wide, no bound from this endpoint
-        for (int r = t; r < nrow; r += nt)
-            for (int q = 0; q < L.ndeg[r]; q++) L.col[r][q] = L.col[r][q] - base + 1;
-        if (t == 0) L.ncol_real = ncol;
-        group_sync();
-        hungarian_coop(L);
-        const bool cut = L.accs[L.d] + L.bound <= L.best_w;
-        group_sync();
-        if (cut) { if (t == 0) L.prune = 1; break; }
+    const unsigned long long wbits = own_sub >= 0 ? (unsigned long long)__double_as_longlong(own_w) : 0ull;
+    if (own_sub >= 0) atomicMax(&L.win_key, wbits);
+    group_sync();
+    if (own_sub >= 0 && wbits == L.win_key) atomicMax(&L.win_sub, 0x7fffffff - own_sub);   // smallest sub-tree wins
+    group_sync();
+    if (own_sub >= 0 && wbits == L.win_key && 0x7fffffff - own_sub == L.win_sub) {   // exactly one lane: sub-trees are not shared
+#pragma unroll
+        for (int q = 0; q < kStackWords; q++) L.win_stack[q] = own_st[q];
     }
     group_sync();
-}
-
-// thread 0 advances the depth-first search until it needs the matching bound (SEL_NEED_BOUND) or the
-// component is finished (SEL_DONE)
-__device__ void select_step(SelectLds& L, int E, bool resume_with_bound) {
-    static_assert(kBlkWords == 3, "the blocked mask is kept in three registers");
-    int d = L.d;
-    bool entered = L.entered != 0;
-    const int cm = L.cm;
-    if (resume_with_bound) {
-        if (L.prune) { d--; entered = false; }
-        else { L.next[d] = 0; entered = false; }
-    }
-    // hot state in registers: node counter, incumbent weight, and -- valid after a descent, reloaded after a return --
-    // the weight accumulated above depth d and the candidates blocked at depth d
-    int nodes = L.nodes;
-    double best_w = L.best_w, acc = 0.0;
-    unsigned long long b0 = 0, b1 = 0, b2 = 0;
-    bool have = false;
-    if (entered && d >= 0) { acc = L.accs[d]; b0 = L.blk[d][0]; b1 = L.blk[d][1]; b2 = L.blk[d][2]; have = true; }
-    while (d >= 0) {
-        if (entered) {
-            if (nodes >= kNodeBudget) { L.budget_hit = 1; break; }
-            nodes++;
-            if (d == cm) {
-                if (acc > best_w) { best_w = acc; for (int q = 0; q < cm; q++) L.best[q] = L.cur[q]; }
-                d--; entered = false; have = false; continue;
-            }
-            if (acc + L.ub[d] <= best_w) { d--; entered = false; have = false; continue; }
-            if (nodes > kPlainNodes && cm - d >= kMatchMinDepth) {
-                L.d = d; L.entered = 1; L.state = SEL_NEED_BOUND; L.nodes = nodes; L.best_w = best_w;
-                return;
-            }
-            L.next[d] = 0;
+    if (t == 0) {
+        const bool any = L.win_sub >= 0 && L.win_key != 0ull;
+        for (int q = 0; q < cm; q++) {
+            const int b = L.mem[q];
+            const int k = any ? (int)((L.win_stack[q / 10] >> ((q % 10) * 3)) & 7u) : (int)L.ncand[b];
+            L.pick[b] = (int8_t)(k == (int)L.ncand[b] ? -1 : k);
         }
-        if (!have) { acc = L.accs[d]; b0 = L.blk[d][0]; b1 = L.blk[d][1]; b2 = L.blk[d][2]; have = true; }
-        const int b = L.mem[d], nc = L.ncand[b];
-        int k = entered ? 0 : L.next[d];
-        bool descended = false;
-        for (; k <= nc; k++) {
-            if (k == nc) {  // "none"
-                L.cur[d] = -1; L.next[d] = (int8_t)(nc + 1); L.accs[d + 1] = acc;
-                L.blk[d + 1][0] = b0; L.blk[d + 1][1] = b1; L.blk[d + 1][2] = b2;
-                d++; entered = true; descended = true; break;
-            }
-            const double w = L.w[b][k];
-            if (!(w > 0.0)) continue;
-            const int bit = d * kTopK + k;
-            if (((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull) continue;
-            L.cur[d] = (int8_t)k; L.next[d] = (int8_t)(k + 1);
-            acc = acc + w;
-            L.accs[d + 1] = acc;
-            b0 |= L.cmask3[d][k][0]; b1 |= L.cmask3[d][k][1]; b2 |= L.cmask3[d][k][2];
-            L.blk[d + 1][0] = b0; L.blk[d + 1][1] = b1; L.blk[d + 1][2] = b2;
-            d++; entered = true; descended = true; break;
-        }
-        if (!descended) { L.cur[d] = -1; d--; entered = false; have = false; }
     }
-    L.d = d;
-    L.nodes = nodes;
-    L.best_w = best_w;
-    L.state = SEL_DONE;
+    group_sync();
 }
 
 // Complete enumeration of a component of cm <= kBruteMax spans by all lanes: combination index = the choices
@@ -1941,8 +1899,8 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             int cm = 0;
             for (int b = root; b < m; b++) if (L.comp[b] == root) L.mem[cm++] = (uint8_t)b;
             L.cm = cm;
-            // (the rest prepares the depth-first search of a component too large for complete enumeration)
-            for (int d = 0; d < cm && cm > kBruteMax; d++) { L.cur[d] = -1; L.best[d] = -1; L.g2[d] = 0; L.g3[d] = 0; }
+            // (the rest prepares the search of a component too large for complete enumeration)
+            for (int d = 0; d < cm && cm > kBruteMax; d++) { L.g2[d] = 0; L.g3[d] = 0; }
         }
         group_sync();
         TW_SEL_TICK(3);
@@ -1950,7 +1908,6 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
         {   // conflict masks of the component's candidates (only between members whose candidate lists meet at all)
             const int cm = L.cm;
             for (int q = t; q < cm * kTopK * kBlkWords; q += nt) (&L.cmask3[0][0][0])[q] = 0;
-            for (int q = t; q < kBlkWords; q += nt) L.blk[0][q] = 0;
             group_sync();
             for (int q = t; q < cm * kTopK * cm; q += nt) {
                 const int x = q / (kTopK * cm), k = (q / cm) % kTopK, y = q % cm;
@@ -2000,17 +1957,9 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
                 if (d + 3 <= cm) { const double c3 = __longlong_as_double((long long)L.g3[d]) + L.ub[d + 3]; if (c3 < u) u = c3; }
                 L.ub[d] = u;
             }
-            L.best_w = 0.0; L.nodes = 0; L.d = 0; L.accs[0] = 0.0; L.entered = 1; L.state = SEL_RUN;
-            select_step(L, E, false);
         }
         group_sync();
-        while (L.state == SEL_NEED_BOUND) {
-            match_prunes_coop(L, E);
-            if (t == 0) select_step(L, E, true);
-            group_sync();
-        }
-        if (t == 0) for (int q = 0; q < L.cm; q++) L.pick[L.mem[q]] = L.best[q];
-        group_sync();
+        select_search(L);
         TW_SEL_TICK(5);
     }
     TW_SEL_TICK(6);
@@ -2091,7 +2040,7 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
 #ifdef TW_PROFILE_SEL
         if (threadIdx.x == 0) {
             const unsigned long long dur = (unsigned long long)(wall_clock64() - _w0);
-            atomicMax((unsigned long long*)&P.prof[8], (dur << 24) | ((unsigned long long)(last - first + 1) << 16) | (unsigned long long)(L.nodes & 0xffff));
+            atomicMax((unsigned long long*)&P.prof[8], (dur << 24) | ((unsigned long long)(last - first + 1) << 16) | 0ull);
             atomicAdd((unsigned long long*)&P.prof[9], dur);
         }
 #endif

@@ -50,6 +50,36 @@ def _vp(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None else ctypes.c_void_p(0)
 
 
+class _PinnedPool(object):
+    """Page-locked staging arrays for Engine.load (tw_host_alloc): the concatenation of the units' arrays has to be
+    written somewhere anyway -- written into pinned memory, tw_load_batch moves it at the full host-link rate."""
+
+    def __init__(self, lib):
+        self._lib = lib
+        self._bufs = {}
+
+    def array(self, name, count, dtype):
+        dtype = np.dtype(dtype)
+        need = max(int(count) * dtype.itemsize, 8)
+        buf = self._bufs.get(name)
+        if buf is None or buf[1] < need:
+            if buf is not None:
+                self._lib.tw_host_free(buf[0])
+            p = ctypes.c_void_p(0)
+            cap = need + need // 4
+            if self._lib.tw_host_alloc(cap, ctypes.byref(p)) != 0 or not p.value:
+                raise MemoryError("tw_host_alloc(%d) failed" % cap)
+            buf = (p, cap)
+            self._bufs[name] = buf
+        raw = (ctypes.c_char * need).from_address(buf[0].value)
+        return np.frombuffer(raw, dtype=dtype, count=int(count))
+
+    def close(self):
+        for p, _ in self._bufs.values():
+            self._lib.tw_host_free(p)
+        self._bufs = {}
+
+
 class Engine(object):
     def __init__(self, device=0, lib_path=None):
         self._lib = _ffi.load(lib_path)
@@ -60,9 +90,13 @@ class Engine(object):
         self.units = []
         self._keep = None
         self._n_traces = 0
+        self._pinned = _PinnedPool(self._lib)
+        self.last_load_s = {}
 
     def close(self):
         if self._h:
+            self._keep = None
+            self._pinned.close()
             self._lib.tw_destroy(self._h)
             self._h = ctypes.c_void_p(0)
 
@@ -92,11 +126,13 @@ class Engine(object):
             "unit_in_off": in_off, "unit_E": unit_E, "ep_off": np.array(ep_off, dtype=np.int64),
             "dag": np.concatenate([u.dag.ravel() for u in units]),
             "key_rank": np.concatenate([u.key_rank for u in units]),
-            "in_start": np.concatenate([u.in_start for u in units]),
-            "in_end": np.concatenate([u.in_end for u in units]),
-            "out_start": np.concatenate([u.out_start for u in units]),
-            "out_end": np.concatenate([u.out_end for u in units]),
         }
+        self._keep = None   # views of the pinned buffers of the previous batch
+        n_in_total, n_out_total = int(in_off[-1]), int(base)
+        for name, total in (("in_start", n_in_total), ("in_end", n_in_total), ("out_start", n_out_total), ("out_end", n_out_total)):
+            dst = self._pinned.array(name, total, np.int64)   # the span arrays (16 B per span) go through page-locked memory
+            np.concatenate([getattr(u, name) for u in units], out=dst)
+            arrays[name] = dst
         scaled = [u.time_scale is not None for u in units]
         if any(scaled) and not all(scaled):
             raise ValueError("a batch holds either integer-microsecond units or load-scaled units, not both")
@@ -240,6 +276,12 @@ class Engine(object):
             out.append(dag[p:p + int(e) * int(e)].reshape(int(e), int(e)).copy())
             p += int(e) * int(e)
         return out
+
+    def hbm_copy_gbps(self, nbytes=1 << 30, iters=10):
+        """Measured HBM rate of a plain streaming copy kernel on this device (read + written GB/s)."""
+        g = ctypes.c_double(0.0)
+        self._check(self._lib.tw_measure_hbm_copy(self._h, int(nbytes), int(iters), ctypes.byref(g)))
+        return float(g.value)
 
     def timing(self):
         """ms of the last pass: total, enumerate kernel, select kernel, windows, claim+detect+repair, params."""

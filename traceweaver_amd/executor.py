@@ -65,6 +65,10 @@ def parse_args(argv=None):
     ap.add_argument("--replicas_file", type=q, default=None,
                     help="pickle {service: [replica ids]} for --compress_factor > 1 (default: data/misc/service_to_replica_new.pickle under --project_root, executor.py:912)")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--allow_partial", type=int, default=0, choices=[0, 1],
+                    help="go on when services of the corpus cannot be solved here (skip mode, < 2 requests, cyclic call order); they are "
+                         "recorded under 'left_out' in the confidence_scores pickle.  Default: stop, because the accuracy files would "
+                         "otherwise count those services as right")
     ap.add_argument("--engine_library", type=q, default=None, help=argparse.SUPPRESS)   # tests: host-emulation build
     args = ap.parse_args(argv)
     if args.relative_path is None and args.absolute_path is None:
@@ -135,6 +139,12 @@ def run(args):
           % (counts["traces"], counts["spans"], time.time() - t0, counts["files_rejected"], counts["traces_filtered"], len(units), skipped))
     if not units:
         raise SystemExit("no service of this corpus can be solved (see the counts above)")
+    # `several_callers` is a skip the reference performs itself (executor.py:1126-1128); the others are services the
+    # reference does solve -- leaving them out silently would make the end-to-end figures look better than a reference run
+    lost = {k: v for k, v in skipped.items() if k != "several_callers" and v > 0}
+    if lost and not args.allow_partial:
+        raise SystemExit("%d service(s) of this corpus cannot be solved by the native chain: %s.  Re-run with --allow_partial 1 to "
+                         "solve the others (the result files then record what was left out)." % (sum(lost.values()), lost))
     table = corpus.span_table()
     names = corpus.trace_names()
     trace_id = lambda k: corpus.string(names[k])
@@ -195,6 +205,10 @@ def run(args):
             eng.run_pass2()
             per, _, flags = eng.evaluate(trace_flags=True)
             res = eng.results(2, fields=("parent", "unit_stats"))
+            unproven = sum(r["budget_windows"] for r in res)
+            if unproven:
+                print("WARNING: %d window(s) hit the node budget of the exact selection search: their selection is the best one found, "
+                      "not a proven optimum (DESIGN.md section 6)" % unproven)
             print("--- %s seconds --- (%d services, both passes, refit, accuracy)" % (time.time() - t1, len(units)))
             eng.close()
             for u, ev, r in zip(units, per, res):
@@ -223,6 +237,8 @@ def run(args):
             record(method, parents, {method: bad}, options=all_options if method == "WAP5" else None)
     for k, v in accuracy_overall.items():
         print("End-to-end accuracy for method %s: %.3f%%" % (k, v))
+    if lost:
+        confidence["left_out"] = dict(lost)
 
     os.makedirs(os.path.dirname(args.results_directory) or ".", exist_ok=True)   # the name is used as a prefix, like the reference does
     suffix = "_%s_%s_%s_%s_%s.pickle" % (args.test_name, args.load_level, int(args.compress_factor), int(args.repeat_factor), args.cache_rate)

@@ -14,6 +14,9 @@ Only the no-skip mode of the reference is accelerated (every endpoint has exactl
 incoming span; all BASELINE.json configs).  The cache-hit / skip experiments (exp2) raise
 NotImplementedError here rather than silently falling back to a CPU path.
 """
+import threading
+import warnings
+
 import numpy as np
 
 from . import gmm
@@ -86,16 +89,24 @@ class TraceWeaverGPU(object):
         self.fit = fit
         self.replay_true_fit = replay_true_fit
         self._engine = Engine(device, lib_path=lib_path)
+        self._lock = threading.Lock()   # one engine, one batch at a time: the executor's optional thread pool
+                                        # (executor.py:1015-1023) may call one predictor instance from several threads
         self.last_timing = {}
+        self.last_stats = {}            # counters of the last call, incl. budget_windows (selection not proven optimal)
 
     # ------------------------------------------------------------------------------------------
+    def _replay_true_fit(self, unit, true_parent):
+        """The reference fits every edge on the *true* assignments first and overwrites the result (traceweaver_v3.py:796-818);
+        those fits still draw from numpy's global RNG, so a seeded run only reproduces a seeded reference run with them."""
+        for q in reference_fit_order(unit, unit.key_rank):
+            row = self._gap_row(unit, true_parent, q)
+            if len(row):
+                gmm.fit_edge_sklearn(row)
+
     def _host_refit(self, unit, gaps_pred, true_parent):
         order = reference_fit_order(unit, unit.key_rank)
         if self.replay_true_fit and true_parent is not None:
-            for q in order:  # results are overwritten by the second round, exactly like the reference
-                row = self._gap_row(unit, true_parent, q)
-                if len(row):
-                    gmm.fit_edge_sklearn(row)
+            self._replay_true_fit(unit, true_parent)
         mix_n = np.zeros(unit.nslot, dtype=np.int32)
         mix_p = np.zeros((unit.nslot, gmm.MAX_COMP, 3))
         for q in order:
@@ -122,6 +133,12 @@ class TraceWeaverGPU(object):
     # ------------------------------------------------------------------------------------------
     def FindAssignments(self, method, process, in_span_partitions, out_span_partitions, parallel, instrumented_hops,
                         true_assignments, invocation_graph, true_skips=False, true_dist=False):
+        with self._lock:
+            return self._find_assignments(method, process, in_span_partitions, out_span_partitions, parallel, instrumented_hops,
+                                          true_assignments, invocation_graph, true_skips, true_dist)
+
+    def _find_assignments(self, method, process, in_span_partitions, out_span_partitions, parallel, instrumented_hops,
+                          true_assignments, invocation_graph, true_skips=False, true_dist=False):
         assert len(in_span_partitions) == 1                       # traceweaver_v3.py:1088
         if parallel or true_skips or true_dist or instrumented_hops:
             raise NotImplementedError("TraceWeaverGPU accelerates predictor 10 (MaxScoreBatchSubsetWithSkips) only")
@@ -160,6 +177,19 @@ class TraceWeaverGPU(object):
         eng.run_pass2()
         self.last_timing = {"pass1": t1, "pass2": eng.timing()}
         r2 = eng.results(2)[0]
+        if self.fit == "sklearn" and self.replay_true_fit and true_parent is not None:
+            # ComputeEpPairDistParams5 also runs after the second iteration (`if iterations > 1` sits inside the loop,
+            # traceweaver_v3.py:1221-1222): its results are never used, but it advances numpy's global RNG by one more round
+            # of fits on the true and on the pass-2 assignments -- what the next service of a seeded run starts from
+            self._replay_true_fit(unit, true_parent)
+            for q in reference_fit_order(unit, unit.key_rank):
+                row = self._gap_row(unit, r2["parent"], q)
+                if len(row):
+                    gmm.fit_edge_sklearn(row)
+        self.last_stats = {k: r2[k] for k in ("not_best_count", "cnt_unassigned", "n_windows", "repaired_windows", "budget_windows")}
+        if r2["budget_windows"]:
+            warnings.warn("%d window(s) of service %r hit the node budget of the exact selection search: the selection returned "
+                          "for them is the best one found, not a proven optimum" % (r2["budget_windows"], process))
 
         all_assignments, all_topk_assignments = {}, {}
         for k, ep in enumerate(out_eps):

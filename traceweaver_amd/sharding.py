@@ -10,10 +10,14 @@ latency-bound, so a single all_gather of one padded int32 buffer per rank is use
 import numpy as np
 
 
-def unit_cost(unit, leaves_per_span=None):
-    """Static work estimate: spans x endpoints (enumeration work scales with the candidate product,
-    which is unknown before pass 1; callers may pass a measured leaves-per-span figure)."""
+def unit_cost(unit, leaves_per_span=None, measured_leaves=None):
+    """Work estimate of one unit.  Static: spans x endpoints (what the scans, sorts and per-span kernels cost).
+    Enumeration work scales with the candidate product, which spans four orders of magnitude per span and is unknown
+    before pass 1: callers that have run a pass give `measured_leaves` (sum of tw_results.leaves of the unit, the tuples
+    DfsTraverseX visits, traceweaver_v3.py:302-303), each tuple costing about E score terms."""
     base = unit.n_in * (1 + unit.E)
+    if measured_leaves is not None:
+        return base + float(measured_leaves) * unit.E
     return base * (leaves_per_span if leaves_per_span else 1.0)
 
 
