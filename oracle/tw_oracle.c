@@ -635,16 +635,24 @@ int two_gauss_params(const two_service *s, double *gauss, int32_t max_blocks) {
 }
 
 /* ------------------------------------------------------------------ exact MWIS per window */
+/* Weights of the selection problem.  The reference hands 10000 + score (binary64) to a MILP solver whose optimality
+ * tolerances are ~1e-7; sums of such weights in binary64 depend on the order of the additions in their last bits, so
+ * "the selection of maximum weight" would depend on how a search accumulates and bounds them.  The canonical problem
+ * therefore uses exact integers: w = rint((10000 + score) * 2^32) (resolution 2.3e-10, far below the solver tolerance;
+ * equal scores stay equal).  Sums, bounds and comparisons are then exact and independent of the search order. */
+typedef int64_t two_w;
+static two_w weight_of(double score) { return (two_w)rint((10000.0 + score) * 4294967296.0); }
+
 typedef struct {
     int m;                               /* in-spans in the component */
     int n[TWO_MAX_WIN];                  /* eligible candidate count */
     int kk[TWO_MAX_WIN][TWO_MAX_K];      /* candidate ids */
-    double w[TWO_MAX_WIN][TWO_MAX_K];
+    two_w w[TWO_MAX_WIN][TWO_MAX_K];
     const int32_t *idx[TWO_MAX_WIN][TWO_MAX_K];
-    double ub[TWO_MAX_WIN + 1];
+    two_w ub[TWO_MAX_WIN + 1];
     int E;
     int cur[TWO_MAX_WIN], best[TWO_MAX_WIN];
-    double best_w;
+    two_w best_w;
     int64_t nodes;
     int exhausted;
 } mwis_comp;
@@ -655,7 +663,7 @@ static int shares(int E, const int32_t *a, const int32_t *b) { for (int e = 0; e
  * endpoint but `e`.  What remains is a maximum-weight bipartite matching between the remaining in-spans
  * and the spans of endpoint e, edge weight = best still-compatible candidate of the in-span that uses the
  * span; an in-span may stay unmatched (own dummy column, weight 0).  Solved exactly with the Hungarian
- * algorithm (potentials, shortest augmenting paths; rows have <= K finite entries).  The bound is the
+ * algorithm (integer potentials, shortest augmenting paths; rows have <= K finite entries).  The bound is the
  * minimum over the endpoints; for E = 1 it is the exact optimum of the sub-problem. */
 #define TWO_MAX_RES (TWO_MAX_WIN * TWO_MAX_K)
 #define TWO_MATCH_MAX_COLS 256
@@ -663,17 +671,17 @@ typedef struct {
     int nrow;
     int ndeg[TWO_MAX_WIN];
     int32_t col[TWO_MAX_WIN][TWO_MAX_K]; /* 1-based column ids */
-    double cost[TWO_MAX_WIN][TWO_MAX_K]; /* -weight */
+    two_w cost[TWO_MAX_WIN][TWO_MAX_K];  /* -weight */
 } match_graph;
 
-static double hungarian_min_cost(const match_graph *g, int ncol_real) {
-    const double INF = 1.0e300;
+static two_w hungarian_min_cost(const match_graph *g, int ncol_real) {
+    const two_w INF = INT64_MAX / 4;
     int n = g->nrow, m = ncol_real + n; /* column ncol_real + r is the dummy of row r (cost 0) */
-    double u[TWO_MAX_WIN + 1], v[TWO_MAX_RES + TWO_MAX_WIN + 1], minv[TWO_MAX_RES + TWO_MAX_WIN + 1];
+    two_w u[TWO_MAX_WIN + 1], v[TWO_MAX_RES + TWO_MAX_WIN + 1], minv[TWO_MAX_RES + TWO_MAX_WIN + 1];
     int p[TWO_MAX_RES + TWO_MAX_WIN + 1], way[TWO_MAX_RES + TWO_MAX_WIN + 1];
     unsigned char used[TWO_MAX_RES + TWO_MAX_WIN + 1];
-    for (int j = 0; j <= m; j++) { v[j] = 0.0; p[j] = 0; }
-    for (int i = 0; i <= n; i++) u[i] = 0.0;
+    for (int j = 0; j <= m; j++) { v[j] = 0; p[j] = 0; }
+    for (int i = 0; i <= n; i++) u[i] = 0;
     for (int i = 1; i <= n; i++) {
         p[0] = i;
         int j0 = 0;
@@ -681,12 +689,12 @@ static double hungarian_min_cost(const match_graph *g, int ncol_real) {
         do {
             used[j0] = 1;
             int i0 = p[j0], j1 = 0;
-            double delta = INF;
+            two_w delta = INF;
             for (int t = 0; t <= g->ndeg[i0 - 1]; t++) {
                 int j = t < g->ndeg[i0 - 1] ? g->col[i0 - 1][t] : ncol_real + i0;
-                double a = t < g->ndeg[i0 - 1] ? g->cost[i0 - 1][t] : 0.0;
+                two_w a = t < g->ndeg[i0 - 1] ? g->cost[i0 - 1][t] : 0;
                 if (used[j]) continue;
-                double cur = a - u[i0] - v[j];
+                two_w cur = a - u[i0] - v[j];
                 if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
             }
             for (int j = 1; j <= m; j++) if (!used[j] && minv[j] < delta) { delta = minv[j]; j1 = j; }
@@ -703,7 +711,7 @@ static double hungarian_min_cost(const match_graph *g, int ncol_real) {
 
 /* returns 1 when some endpoint's relaxation already proves acc + bound <= best (endpoints in order, first hit wins) */
 long long two_match_calls = 0, two_match_endpoints = 0;
-static int match_prunes(mwis_comp *c, int d, double acc) {
+static int match_prunes(mwis_comp *c, int d, two_w acc) {
     two_match_calls++;
     for (int e = 0; e < c->E; e++) {
         match_graph g;
@@ -727,33 +735,33 @@ static int match_prunes(mwis_comp *c, int d, double acc) {
         if (ncol > TWO_MATCH_MAX_COLS) continue; /* range too wide for the column arrays: this endpoint gives no bound */
         for (int r = 0; r < g.nrow; r++) for (int t = 0; t < g.ndeg[r]; t++) g.col[r][t] = g.col[r][t] - base + 1;
         two_match_endpoints++;
-        double bnd = -hungarian_min_cost(&g, ncol);
+        two_w bnd = -hungarian_min_cost(&g, ncol);
         if (acc + bnd <= c->best_w) return 1;
     }
     return 0;
 }
 
 /* exact optimum of the in-spans d..d+g-1 taken alone (g <= 3): every combination of one eligible candidate or
- * "none" per in-span whose candidates share no span; weights added left to right */
+ * "none" per in-span whose candidates share no span */
 #define TWO_GROUP 3
-static double group_opt(const mwis_comp *c, int d, int g) {
-    double best = 0.0;
+static two_w group_opt(const mwis_comp *c, int d, int g) {
+    two_w best = 0;
     for (int a = 0; a <= c->n[d]; a++) {
-        double sa = a < c->n[d] ? c->w[d][a] : 0.0;
+        two_w sa = a < c->n[d] ? c->w[d][a] : 0;
         if (g == 1) { if (sa > best) best = sa; continue; }
         for (int b = 0; b <= c->n[d + 1]; b++) {
-            double sb = sa;
+            two_w sb = sa;
             if (b < c->n[d + 1]) {
                 if (a < c->n[d] && shares(c->E, c->idx[d][a], c->idx[d + 1][b])) continue;
-                sb = a < c->n[d] ? sa + c->w[d + 1][b] : c->w[d + 1][b];
+                sb = sa + c->w[d + 1][b];
             }
             if (g == 2) { if (sb > best) best = sb; continue; }
             for (int k = 0; k <= c->n[d + 2]; k++) {
-                double sc = sb;
+                two_w sc = sb;
                 if (k < c->n[d + 2]) {
                     if (a < c->n[d] && shares(c->E, c->idx[d][a], c->idx[d + 2][k])) continue;
                     if (b < c->n[d + 1] && shares(c->E, c->idx[d + 1][b], c->idx[d + 2][k])) continue;
-                    sc = (a < c->n[d] || b < c->n[d + 1]) ? sb + c->w[d + 2][k] : c->w[d + 2][k];
+                    sc = sb + c->w[d + 2][k];
                 }
                 if (sc > best) best = sc;
             }
@@ -763,16 +771,14 @@ static double group_opt(const mwis_comp *c, int d, int g) {
 }
 
 /* Components of up to TWO_BRUTE_MAX in-spans: complete enumeration in depth-first order (candidates in list order,
- * then "none", first in-span most significant), sums accumulated left to right, strict improvements only.  This is
- * what the bounded search below returns whenever its bound is exact in floating point; enumerating removes the
- * dependence on the bound's rounding for the small components (the GPU engine spreads the same enumeration over
- * the lanes of a wavefront). */
+ * then "none", first in-span most significant), strict improvements only (the GPU engine spreads the same
+ * enumeration over the lanes of a wavefront). */
 #define TWO_BRUTE_MAX 4
 static void mwis_enumerate(mwis_comp *c) {
     int ch[TWO_BRUTE_MAX];
     for (int t = 0; t < c->m; t++) ch[t] = 0;
     while (1) {
-        int ok = 1; double sum = 0.0;
+        int ok = 1; two_w sum = 0;
         for (int t = 0; t < c->m && ok; t++) {
             if (ch[t] == c->n[t]) continue; /* none */
             for (int q = 0; q < t && ok; q++) if (ch[q] < c->n[q] && shares(c->E, c->idx[q][ch[q]], c->idx[t][ch[t]])) ok = 0;
@@ -793,7 +799,7 @@ static int two_node_budget = 1 << 24;  /* search nodes per component; beyond it 
 #define TWO_PLAIN_NODES two_plain_nodes
 #define TWO_NODE_BUDGET two_node_budget
 void two_set_search_limits(int plain_nodes, int budget) { two_plain_nodes = plain_nodes; two_node_budget = budget; } /* experiments only */
-static void mwis_dfs(mwis_comp *c, int d, double acc) {
+static void mwis_dfs(mwis_comp *c, int d, two_w acc) {
     if (c->nodes >= TWO_NODE_BUDGET) { c->exhausted = 1; return; }
     c->nodes++;
     if (d == c->m) { if (acc > c->best_w) { c->best_w = acc; memcpy(c->best, c->cur, sizeof(int) * (size_t)c->m); } return; }
@@ -812,10 +818,10 @@ static void mwis_dfs(mwis_comp *c, int d, double acc) {
 
 /* Exact maximum-weight independent set of the window's conflict graph (V3:1252-1281, V3:1395-1419).
  * Canonical procedure (also followed by the GPU engine so that exact ties resolve identically):
- *   nodes with weight 10000+score <= 0 are never selected; the window is split into connected
+ *   weights are the exact integers of weight_of() above; nodes with weight <= 0 are never selected; the window is split into connected
  *   components of the in-span conflict relation; components of <= TWO_BRUTE_MAX in-spans are enumerated
  *   completely (mwis_enumerate), larger ones are searched depth-first over their
- *   in-spans in index order, candidates in list order then "none", sums accumulated left to right,
+ *   in-spans in index order, candidates in list order then "none",
  *   a subtree is cut when acc + upper bound <= best (upper bound = the remaining in-spans cut into
  *   groups of <= 3 consecutive in-spans, each solved exactly on its own, cheapest cutting; once the
  *   component's search has visited TWO_PLAIN_NODES nodes additionally the matching relaxation above),
@@ -831,9 +837,9 @@ static int64_t mwis_window(const two_service *s, int m, const int *ncand, two_ca
         for (int j = 0; j < i; j++) {
             int hit = 0;
             for (int a = 0; a < ncand[i] && !hit; a++) {
-                if (!(10000.0 + cands[i][a].score > 0.0)) continue;
+                if (!(weight_of(cands[i][a].score) > 0)) continue;
                 for (int b = 0; b < ncand[j] && !hit; b++)
-                    if (10000.0 + cands[j][b].score > 0.0 && shares(E, cands[i][a].idx, cands[j][b].idx)) hit = 1;
+                    if (weight_of(cands[j][b].score) > 0 && shares(E, cands[i][a].idx, cands[j][b].idx)) hit = 1;
             }
             if (hit) { int ci = comp[i], cj = comp[j], lo = ci < cj ? ci : cj, hi = ci < cj ? cj : ci; for (int t = 0; t < m; t++) if (comp[t] == hi) comp[t] = lo; }
         }
@@ -845,25 +851,25 @@ static int64_t mwis_window(const two_service *s, int m, const int *ncand, two_ca
             if (comp[i] != root) continue;
             int d = c.m++; members[d] = i; c.n[d] = 0;
             for (int a = 0; a < ncand[i]; a++) {
-                double w = 10000.0 + cands[i][a].score;
-                if (!(w > 0.0)) continue;
+                two_w w = weight_of(cands[i][a].score);
+                if (!(w > 0)) continue;
                 c.kk[d][c.n[d]] = a; c.w[d][c.n[d]] = w; c.idx[d][c.n[d]] = cands[i][a].idx; c.n[d]++;
             }
         }
         /* upper bound of the suffix d..m-1: cut it into groups of 1-3 consecutive in-spans, solve every group
          * exactly on its own (conflicts inside the group only) and take the cheapest cutting */
-        c.ub[c.m] = 0.0;
+        c.ub[c.m] = 0;
         for (int d = c.m - 1; d >= 0; d--) {
-            double u = 0.0;
+            two_w u = 0;
             for (int g = 1; g <= TWO_GROUP && d + g <= c.m; g++) {
-                double cand = group_opt(&c, d, g) + c.ub[d + g];
+                two_w cand = group_opt(&c, d, g) + c.ub[d + g];
                 if (g == 1 || cand < u) u = cand;
             }
             c.ub[d] = u;
         }
         for (int d = 0; d < c.m; d++) { c.cur[d] = -1; c.best[d] = -1; }
-        c.best_w = 0.0;
-        if (c.m <= TWO_BRUTE_MAX) mwis_enumerate(&c); else mwis_dfs(&c, 0, 0.0);
+        c.best_w = 0;
+        if (c.m <= TWO_BRUTE_MAX) mwis_enumerate(&c); else mwis_dfs(&c, 0, 0);
         for (int d = 0; d < c.m; d++) chosen[members[d]] = c.best[d] >= 0 ? c.kk[d][c.best[d]] : -1;
         nodes += c.nodes;
         if (c.exhausted) *budget_hit = 1;

@@ -1548,10 +1548,14 @@ __device__ inline bool cands_share(const Dev& P, const UnitDev& U, int i, int a,
 }
 
 // Exact selection, canonical procedure (shared with the oracle so that exact ties resolve identically):
-//   node weight 10000 + score (traceweaver_v3.py:1260); nodes with weight <= 0 are never selected; the
-//   window is split into connected components of the span conflict relation; the answer for a component is
-//   the FIRST selection of maximum weight in depth-first order: spans in index order, candidates in list
-//   order then "none", sums accumulated left to right, only strict improvements replace the incumbent.
+//   node weight 10000 + score (traceweaver_v3.py:1260) as an exact integer, rint((10000 + score) * 2^32): the
+//   reference hands binary64 weights to a MILP solver with ~1e-7 tolerances, and binary64 sums depend on the order
+//   of the additions in their last bits -- "the selection of maximum weight" would then depend on how a search
+//   accumulates and bounds them; with integers (resolution 2.3e-10, equal scores stay equal) sums, bounds and
+//   comparisons are exact.  Nodes with weight <= 0 are never selected; the window is split into connected
+//   components of the span conflict relation; the answer for a component is the FIRST selection of maximum
+//   weight in depth-first order: spans in index order, candidates in list order then "none", only strict
+//   improvements replace the incumbent.
 //   That selection does not depend on how the tree is searched or bounded, so the oracle (one depth-first
 //   search with an additional matching relaxation) and this engine (many sub-trees at once) agree whenever
 //   both searches complete.  Upper bound of a suffix of the component: the remaining spans cut into groups of
@@ -1571,6 +1575,8 @@ __device__ inline bool cands_share(const Dev& P, const UnitDev& U, int i, int a,
 // with a later sub-tree must survive).  The winner is the largest weight, the smallest sub-tree among equal
 // weights.  A lane that visits more than kNodeBudget / lanes nodes on one component stops; the window then keeps the
 // best selection found and is counted in unit_stats[4] (not proven optimal).
+typedef long long sel_w;
+__device__ __forceinline__ sel_w sel_weight(double score) { return (sel_w)rint((10000.0 + score) * 4294967296.0); }
 constexpr int kNodeBudget = 1 << 24; // search nodes per component, shared evenly by the lanes (2^18 per lane of a wavefront)
 constexpr int kBlkWords = (kMaxWin * kTopK + 63) / 64;  // words of a mask over all candidates of a component
 constexpr int kBigWindow = 8;        // windows of at least this many spans are served first by k_select_heavy
@@ -1581,19 +1587,19 @@ constexpr int kPrefixMax = 10;       // levels above the sub-trees: 4 x 256 sub-
 // ---- cooperative path: one workgroup per window --------------------------------------------------
 struct SelectLds {
     int32_t idx[kMaxWin][kTopK][kMaxEp];
-    double w[kMaxWin][kTopK];  // 10000 + score; <= 0 means not eligible
-    double ub[kMaxWin + 1];
-    double red_val[kCoop / 64];
+    sel_w w[kMaxWin][kTopK];  // sel_weight(score); <= 0 means not eligible
+    sel_w ub[kMaxWin + 1];
+    sel_w red_val[kCoop / 64];
     int32_t red_idx[kCoop / 64];
     uint8_t ncand[kMaxWin], comp[kMaxWin], mem[kMaxWin];
     int8_t pick[kMaxWin];
     uint32_t adj[kMaxWin];  // span conflict relation as bit rows
     uint32_t cmask[kBruteMax][kTopK], celig[kBruteMax];  // select_brute: conflicts among / eligibility of the component's candidates
-    unsigned long long g2[kMaxWin], g3[kMaxWin];  // bit patterns of the pair / triple optima of the grouped bound (weights are > 0)
+    unsigned long long g2[kMaxWin], g3[kMaxWin];  // pair / triple optima of the grouped bound (weights are > 0)
     // select_search: conflicts of candidate k of member x with the candidates of the other members as a bit
     // mask over (member y, candidate k2) -> bit y*kTopK+k2
     unsigned long long cmask3[kMaxWin][kTopK][kBlkWords];
-    unsigned long long gbest;       // bit pattern of the best weight any lane has found (weights are > 0: the patterns order like the values)
+    unsigned long long gbest;       // the best weight any lane has found (weights are > 0)
     unsigned long long win_key;     // reduction of the lanes' results
     uint32_t win_stack[kStackWords];
     int cm, budget_hit, next_sub, n_sub, depth0, win_sub;
@@ -1632,7 +1638,7 @@ __device__ void select_search(SelectLds& L) {
     }
     group_sync();
     const int D = L.depth0, P = L.n_sub;
-    double own_w = 0.0;           // incumbent of this lane: only strict improvements replace it
+    sel_w own_w = 0;              // incumbent of this lane: only strict improvements replace it
     int own_sub = -1;
     uint32_t own_st[kStackWords], st[kStackWords];
 #pragma unroll
@@ -1644,7 +1650,7 @@ __device__ void select_search(SelectLds& L) {
         const int sub = atomicAdd(&L.next_sub, 1);   // sub-trees are handed out in depth-first order
         if (sub >= P) break;
         // the sub-tree's prefix: digit q of `sub` (first member most significant) = candidate, or ncand = "none"
-        double acc = 0.0;
+        sel_w acc = 0;
         unsigned long long b0 = 0, b1 = 0, b2 = 0;
         bool ok = true;
         {
@@ -1660,9 +1666,9 @@ __device__ void select_search(SelectLds& L) {
                 const int b = L.mem[q], k = digit[q];
                 stack_set(st, q, k);
                 if (k == (int)L.ncand[b]) continue;   // "none"
-                const double w = L.w[b][k];
+                const sel_w w = L.w[b][k];
                 const int bit = q * kTopK + k;
-                if (!(w > 0.0) || (((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull)) { ok = false; continue; }
+                if (!(w > 0) || (((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull)) { ok = false; continue; }
                 acc = acc + w;
                 b0 |= L.cmask3[q][k][0]; b1 |= L.cmask3[q][k][1]; b2 |= L.cmask3[q][k][2];
             }
@@ -1680,12 +1686,12 @@ __device__ void select_search(SelectLds& L) {
                         own_w = acc; own_sub = sub;
 #pragma unroll
                         for (int q = 0; q < kStackWords; q++) own_st[q] = st[q];
-                        atomicMax(&L.gbest, (unsigned long long)__double_as_longlong(acc));
+                        atomicMax(&L.gbest, (unsigned long long)acc);
                     }
                     up = true;
                 } else {
-                    const double bound = acc + L.ub[d];
-                    if (bound <= own_w || bound < __longlong_as_double((long long)L.gbest)) up = true;
+                    const sel_w bound = acc + L.ub[d];
+                    if (bound <= own_w || bound < (sel_w)L.gbest) up = true;
                 }
             } else {
                 k = stack_get(st, d) + 1;   // resume below the choice this level made last
@@ -1695,8 +1701,8 @@ __device__ void select_search(SelectLds& L) {
                 bool found = false;
                 for (; k <= nc; k++) {
                     if (k == nc) { found = true; break; }   // "none"
-                    const double w = L.w[b][k];
-                    if (!(w > 0.0)) continue;
+                    const sel_w w = L.w[b][k];
+                    if (!(w > 0)) continue;
                     const int bit = d * kTopK + k;
                     if (((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull) continue;
                     acc = acc + w;
@@ -1707,12 +1713,11 @@ __device__ void select_search(SelectLds& L) {
                 if (found) { stack_set(st, d, k); d++; entered = true; continue; }
                 up = true;
             }
-            // return to the level above: its weight and blocked set are rebuilt from the stack (sums left to right,
-            // exactly the additions the descent made)
+            // return to the level above: its weight and blocked set are rebuilt from the stack
             d--;
             if (d < D) break;
             entered = false;
-            acc = 0.0; b0 = 0; b1 = 0; b2 = 0;
+            acc = 0; b0 = 0; b1 = 0; b2 = 0;
             for (int q = 0; q < d; q++) {
                 const int kq = stack_get(st, q), bq = L.mem[q];
                 if (kq == (int)L.ncand[bq]) continue;
@@ -1723,10 +1728,9 @@ __device__ void select_search(SelectLds& L) {
     }
     if (over) L.budget_hit = 1;
     // winner: largest weight, smallest sub-tree among equal weights (a lane's own result is already the first leaf of
-    // that weight among its sub-trees, which it visited in increasing order).  Weights are < 2^21 in magnitude only by
-    // construction of the key; the comparison itself is done on (bit pattern of the weight, -sub-tree).
+    // that weight among its sub-trees, which it visited in increasing order)
     group_sync();
-    const unsigned long long wbits = own_sub >= 0 ? (unsigned long long)__double_as_longlong(own_w) : 0ull;
+    const unsigned long long wbits = own_sub >= 0 ? (unsigned long long)own_w : 0ull;
     if (own_sub >= 0) atomicMax(&L.win_key, wbits);
     group_sync();
     if (own_sub >= 0 && wbits == L.win_key) atomicMax(&L.win_sub, 0x7fffffff - own_sub);   // smallest sub-tree wins
@@ -1768,17 +1772,17 @@ __device__ void select_brute(SelectLds& L, int E) {
     for (int q = t; q < cm * kTopK * cm; q += nt) {
         const int x = q / (kTopK * cm), k = (q / cm) % kTopK, y = q % cm;
         const int bx = L.mem[x], by = L.mem[y];
-        if (k >= L.ncand[bx] || !(L.w[bx][k] > 0.0)) continue;
+        if (k >= L.ncand[bx] || !(L.w[bx][k] > 0)) continue;
         if (y == x) { atomicOr(&L.celig[x], 1u << k); continue; }
         uint32_t bits = 0;
         for (int k2 = 0; k2 < L.ncand[by]; k2++)
-            if (L.w[by][k2] > 0.0 && lds_share(L, E, bx, k, by, k2)) bits |= 1u << (y * kTopK + k2);
+            if (L.w[by][k2] > 0 && lds_share(L, E, bx, k, by, k2)) bits |= 1u << (y * kTopK + k2);
         if (bits) atomicOr(&L.cmask[x][k], bits);
     }
     group_sync();
     int total = 1;
     for (int x = 0; x < cm; x++) total *= C;
-    double bsum = 0.0;
+    sel_w bsum = 0;
     int bidx = 0x7fffffff;
     for (int q = t; q < total; q += nt) {
         int rest = q;
@@ -1789,21 +1793,21 @@ __device__ void select_brute(SelectLds& L, int E) {
         }
         bool ok = true;
         uint32_t sel = 0, clash = 0;
-        double sum = 0.0;
+        sel_w sum = 0;
 #pragma unroll
         for (int x = 0; x < kBruteMax; x++) {
             if (x < cm && ch[x] != kTopK) {
                 ok = ok && ((L.celig[x] >> ch[x]) & 1u);
                 sel |= 1u << (x * kTopK + ch[x]);
                 clash |= L.cmask[x][ch[x]];
-                sum += L.w[L.mem[x]][ch[x]];  // left to right
+                sum += L.w[L.mem[x]][ch[x]];
             }
         }
         if (ok && (sel & clash) == 0 && sum > bsum) { bsum = sum; bidx = q; }  // own indices increase: the first maximum stays
     }
     for (int off = 32; off >= 1; off >>= 1) {
         if (off < nt) {
-            const double os = __shfl_down(bsum, off);
+            const sel_w os = __shfl_down(bsum, off);
             const int oi = __shfl_down(bidx, off);
             if (os > bsum || (os == bsum && oi < bidx)) { bsum = os; bidx = oi; }
         }
@@ -1819,7 +1823,7 @@ __device__ void select_brute(SelectLds& L, int E) {
     if (t == 0) {
         int rest = bidx;
         for (int x = cm - 1; x >= 0; x--) {
-            const int k = bsum > 0.0 ? rest % C : kTopK;
+            const int k = bsum > 0 ? rest % C : kTopK;
             rest /= C;
             L.pick[L.mem[x]] = (int8_t)(k == kTopK ? -1 : k);
         }
@@ -1851,7 +1855,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
     for (int q = t; q < m * kTopK; q += nt) {
         const int b = q / kTopK, k = q % kTopK;
         const int n = cand_n(P, U, first + b);
-        L.w[b][k] = k < n ? 10000.0 + cand_score(P, U, first + b, k) : 0.0;
+        L.w[b][k] = k < n ? sel_weight(cand_score(P, U, first + b, k)) : 0;
         for (int e = 0; e < E; e++) L.idx[b][k][e] = k < n ? cand_idx(P, U, first + b, k, e) : -1 - q;
         if (k == 0) { L.ncand[b] = (uint8_t)n; L.comp[b] = (uint8_t)b; L.pick[b] = -1; }
     }
@@ -1866,9 +1870,9 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
         if (c >= b) continue;
         bool hit = false;
         for (int ka = 0; ka < L.ncand[b] && !hit; ka++) {
-            if (!(L.w[b][ka] > 0.0)) continue;
+            if (!(L.w[b][ka] > 0)) continue;
             for (int kb = 0; kb < L.ncand[c] && !hit; kb++)
-                if (L.w[c][kb] > 0.0 && lds_share(L, E, b, ka, c, kb)) hit = true;
+                if (L.w[c][kb] > 0 && lds_share(L, E, b, ka, c, kb)) hit = true;
         }
         if (hit) { atomicOr(&L.adj[b], 1u << c); atomicOr(&L.adj[c], 1u << b); }
     }
@@ -1912,9 +1916,9 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             for (int q = t; q < cm * kTopK * cm; q += nt) {
                 const int x = q / (kTopK * cm), k = (q / cm) % kTopK, y = q % cm;
                 const int bx = L.mem[x], by = L.mem[y];
-                if (y == x || !((L.adj[bx] >> by) & 1u) || k >= L.ncand[bx] || !(L.w[bx][k] > 0.0)) continue;
+                if (y == x || !((L.adj[bx] >> by) & 1u) || k >= L.ncand[bx] || !(L.w[bx][k] > 0)) continue;
                 for (int k2 = 0; k2 < L.ncand[by]; k2++)
-                    if (L.w[by][k2] > 0.0 && lds_share(L, E, bx, k, by, k2)) {
+                    if (L.w[by][k2] > 0 && lds_share(L, E, bx, k, by, k2)) {
                         const int bit = y * kTopK + k2;
                         atomicOr(&L.cmask3[x][k][bit >> 6], 1ull << (bit & 63));
                     }
@@ -1924,7 +1928,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             // every group exactly on its own (conflicts inside the group only) and take the cheapest cutting.  It
             // sees spans that compete for the same outgoing spans (one of them must stay unassigned: -10000), which
             // the sum of best weights does not.  All pairs and triples are evaluated at once, one (group, combination)
-            // per lane; weights are positive doubles, so the maximum is taken on their bit patterns.
+            // per lane; weights are positive integers.
             const int cm = L.cm, npair = cm > 1 ? cm - 1 : 0, ntrip = cm > 2 ? cm - 2 : 0;
             constexpr int C = kTopK + 1;  // choices per span: a candidate or "none"
             const int total = npair * C * C + ntrip * C * C * C;
@@ -1933,28 +1937,28 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
                 if (q < npair * C * C) { d = q / (C * C); const int c = q % (C * C); ch[0] = c / C; ch[1] = c % C; ch[2] = kTopK; g = 2; }
                 else { const int r = q - npair * C * C; d = r / (C * C * C); const int c = r % (C * C * C); ch[0] = c / (C * C); ch[1] = (c / C) % C; ch[2] = c % C; g = 3; }
                 bool ok = true;
-                double sum = 0.0;
+                sel_w sum = 0;
                 for (int x = 0; x < g && ok; x++) {
                     if (ch[x] == kTopK) continue;  // "none"
                     const int b = L.mem[d + x];
-                    if (ch[x] >= L.ncand[b] || !(L.w[b][ch[x]] > 0.0)) { ok = false; break; }
+                    if (ch[x] >= L.ncand[b] || !(L.w[b][ch[x]] > 0)) { ok = false; break; }
                     for (int y = 0; y < x && ok; y++)
                         if (ch[y] != kTopK && lds_share(L, E, L.mem[d + y], ch[y], b, ch[x])) ok = false;
-                    sum += L.w[b][ch[x]];  // left to right
+                    sum += L.w[b][ch[x]];
                 }
-                if (ok && sum > 0.0) atomicMax(g == 2 ? &L.g2[d] : &L.g3[d], (unsigned long long)__double_as_longlong(sum));
+                if (ok && sum > 0) atomicMax(g == 2 ? &L.g2[d] : &L.g3[d], (unsigned long long)sum);
             }
         }
         group_sync();
         if (t == 0) {
             const int cm = L.cm;
-            L.ub[cm] = 0.0;
+            L.ub[cm] = 0;
             for (int d = cm - 1; d >= 0; d--) {
-                double mx = 0.0;
+                sel_w mx = 0;
                 for (int k = 0; k < L.ncand[L.mem[d]]; k++) if (L.w[L.mem[d]][k] > mx) mx = L.w[L.mem[d]][k];
-                double u = mx + L.ub[d + 1];
-                if (d + 2 <= cm) { const double c2 = __longlong_as_double((long long)L.g2[d]) + L.ub[d + 2]; if (c2 < u) u = c2; }
-                if (d + 3 <= cm) { const double c3 = __longlong_as_double((long long)L.g3[d]) + L.ub[d + 3]; if (c3 < u) u = c3; }
+                sel_w u = mx + L.ub[d + 1];
+                if (d + 2 <= cm) { const sel_w c2 = (sel_w)L.g2[d] + L.ub[d + 2]; if (c2 < u) u = c2; }
+                if (d + 3 <= cm) { const sel_w c3 = (sel_w)L.g3[d] + L.ub[d + 3]; if (c3 < u) u = c3; }
                 L.ub[d] = u;
             }
         }
@@ -1982,7 +1986,7 @@ __global__ void __launch_bounds__(kTile) k_select_fast(Dev P) {
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
     const int64_t g = U.in_off + i;
-    const bool ok = P.tk_n[g] > 0 && 10000.0 + P.tk_score[tks_index(U, 0, i)] > 0.0;
+    const bool ok = P.tk_n[g] > 0 && sel_weight(P.tk_score[tks_index(U, 0, i)]) > 0;
     P.chosen[g] = ok ? 0 : -1;
     const int w = P.wid[g];
     const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
@@ -1990,7 +1994,7 @@ __global__ void __launch_bounds__(kTile) k_select_fast(Dev P) {
     if (!ok || first >= i) return;
     uint32_t elig = 0;
     for (int j = first; j < i; j++)
-        if (P.tk_n[U.in_off + j] > 0 && 10000.0 + P.tk_score[tks_index(U, 0, j)] > 0.0) elig |= 1u << (j - first);
+        if (P.tk_n[U.in_off + j] > 0 && sel_weight(P.tk_score[tks_index(U, 0, j)]) > 0) elig |= 1u << (j - first);
     bool clash = false;
     for (int e = 0; e < U.E && !clash; e++) {
         const int32_t mine = P.tk_idx[tk_index(U, 0, e, i)];

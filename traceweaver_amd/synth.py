@@ -151,6 +151,10 @@ def accuracy(parent, true_parent):
 # through client spans, stage after stage.
 HOTEL_APP = {"root_op": "HTTP GET /hotels", "root": "frontend",
              "calls": {"frontend": [("search",), ("reservation",), ("profile",)], "search": [("geo",), ("rate",)]}}
+# media_microservices shape: the six services the reference solves there have E in {4, 2, 1, 1, 1, 1}
+MEDIA_APP = {"root_op": "HTTP GET /hotels", "root": "nginx",
+             "calls": {"nginx": [("user", "text", "unique-id", "movie-id")], "text": [("url-shorten", "user-mention")],
+                       "user": [("compose-a",)], "unique-id": [("compose-b",)], "movie-id": [("rating",)], "rating": [("compose-c",)]}}
 FANOUT_APP = {"root_op": "compose", "root": "gateway",
               "calls": {"gateway": [("auth",), ("text", "media", "user")], "text": [("url", "mention")]}}
 
