@@ -2,7 +2,8 @@ import sys, os, ctypes, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from traceweaver_amd import synth
 from traceweaver_amd.engine import Engine
-units, truth = synth.make_workload(1000, 100000, services=synth.MEDIA_SERVICES, replicas=4, concurrency=1.6)
+conc = float(os.environ.get("TW_CONC", "1.6")); n_in = int(os.environ.get("TW_NIN", "100000"))
+units, truth = synth.make_workload(1000, n_in, services=synth.MEDIA_SERVICES, replicas=4, concurrency=conc)
 eng = Engine(0, lib_path=os.environ.get("TW_PROFILE_LIB", "scratch/profsel.so")); eng.load(units)
 lib = eng._lib
 lib.tw_debug_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

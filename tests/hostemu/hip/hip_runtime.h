@@ -189,6 +189,7 @@ inline int __builtin_amdgcn_readfirstlane(int v) {
     return emu_wave ? emu_exchange(v, [&](unsigned long long live) { return __builtin_ffsll((long long)live) - 1; }) : v;
 }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline int __ffs(int x) { return __builtin_ffs(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 using std::max;

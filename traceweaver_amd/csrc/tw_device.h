@@ -79,7 +79,7 @@ struct Dev {
     int32_t* wid;       // window id inside the unit
     int32_t* w_last;    // [in_off + w] last span of window w
     int32_t* unit_nwin; // [n_units]
-    uint8_t* w_dirty;   // [in_off + w] window needs the exact repair walk
+    uint8_t* w_dirty;   // [in_off + w] window was re-solved because an earlier window took one of its candidate spans
     int32_t* w_conf;    // [in_off + w] the spans' best candidates clash: the window is on a selection work list
     int32_t* unit_ndirty;
     int32_t* tk_n;      // candidates found on all spans (top_k_2)
@@ -94,6 +94,9 @@ struct Dev {
     int32_t* c_lo;      // first candidate index (full-list cutoff)
     int32_t* c_hi;      // last candidate index
     uint64_t* c_bits;   // kCandWords words: spans that occur in >= 1 feasible tuple
+    uint64_t* gone;     // kCandWords words: candidate spans taken by earlier windows when the span's current list was computed
+    int64_t* leaves_r;  // per incoming span: tuples of the enumeration on the remaining spans (rep = 1)
+    int32_t* round_changed;  // spans whose set of taken candidate spans changed in the current repair round
     int32_t* parent;
     // per outgoing span
     int32_t* owner;     // smallest window id that speculatively chose the span

@@ -23,6 +23,7 @@ using namespace tw;
 
 namespace {
 
+constexpr int kMaxRepairRounds = 1 << 20;
 enum { ST_EMPTY = 0, ST_LOADED = 1, ST_PASS1 = 2, ST_MIX = 3, ST_PASS2 = 4 };
 enum { EV_BEGIN = 0, EV_PARAMS, EV_ENUM0, EV_ENUM1, EV_WIN, EV_SEL, EV_REPAIR, EV_END, EV_COUNT };
 
@@ -82,6 +83,7 @@ struct tw_engine {
     unsigned long long* key_acc = nullptr;  // [2] scratch of k_key_bits
     unsigned ts_end_bit = 64;               // timestamps differ only below this bit (whole batch)
     double fit_ms = 0.0;
+    int rounds = 0;                         // repair rounds of the last pass
     hipEvent_t ev[EV_COUNT] = {};
     double ms[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -158,17 +160,25 @@ int run_scan(tw_engine* e, typename Tr::T* agg) {
     return TW_OK;
 }
 
+// mode 0: first solve on all spans (per-thread kernel, then the wavefront kernel for the spans it deferred);
+// mode 1: the spans listed by k_detect_gone, without the candidate spans earlier windows took
 template <int E>
-void launch_enumerate(tw_engine* e, int pass) {
+void launch_enumerate(tw_engine* e, int pass, int mode) {
     const Dev& P = e->P;
     const int nt = e->tile_cls_off[E + 1] - e->tile_cls_off[E];
     if (nt == 0) return;
-    hipLaunchKernelGGL((k_enumerate_light<E>), dim3(nt), dim3(e->tile), 0, e->stream, P, pass,
-                       (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
+    if (mode == 0)
+        hipLaunchKernelGGL((k_enumerate_light<E>), dim3(nt), dim3(e->tile), 0, e->stream, P, pass,
+                           (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
     const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
-    const int grid = std::min(cap, 4096);  // persistent wavefronts pulling spans from the class' work list
-    hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), dim3(std::min(e->coop, kHeavyThreads)), 0, e->stream, P, pass);
-    hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), dim3(std::min(e->coop, kHeavyThreads)), 0, e->stream, P, pass);
+    const int grid = std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096);  // persistent wavefronts pulling spans from the class' work list
+    hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), dim3(std::min(e->coop, kHeavyThreads)), 0, e->stream, P, pass, mode);
+    hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), dim3(std::min(e->coop, kHeavyThreads)), 0, e->stream, P, pass, mode);
+}
+
+void launch_enumerate_all(tw_engine* e, int pass, int mode) {
+    launch_enumerate<1>(e, pass, mode); launch_enumerate<2>(e, pass, mode); launch_enumerate<3>(e, pass, mode); launch_enumerate<4>(e, pass, mode);
+    launch_enumerate<5>(e, pass, mode); launch_enumerate<6>(e, pass, mode); launch_enumerate<7>(e, pass, mode); launch_enumerate<8>(e, pass, mode);
 }
 
 // OR of (key ^ first key) and of the keys themselves over a set of index ranges (see k_key_bits)
@@ -258,7 +268,6 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 3, e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t), e->stream));
     HIPCHK(hipMemsetAsync(P.unit_ndirty, 0, sizeof(int32_t) * P.n_units, e->stream));
-    HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
     if (pass == 1) {
         int rc = sort_ends(e);
         if (rc != TW_OK) return rc;
@@ -269,8 +278,7 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
-    launch_enumerate<1>(e, pass); launch_enumerate<2>(e, pass); launch_enumerate<3>(e, pass); launch_enumerate<4>(e, pass);
-    launch_enumerate<5>(e, pass); launch_enumerate<6>(e, pass); launch_enumerate<7>(e, pass); launch_enumerate<8>(e, pass);
+    launch_enumerate_all(e, pass, 0);
     HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
     if (pass == 1) {
         int rc = run_scan<ScanMaxEnd>(e, e->agg_pair);
@@ -282,17 +290,34 @@ int run_pass(tw_engine* e, int pass) {
         rc = run_scan<ScanWinId>(e, e->agg_i32);
         if (rc != TW_OK) return rc;
         hipLaunchKernelGGL(k_window_index, tiles, tb, 0, e->stream, P);
-    } else {
-        HIPCHK(hipMemsetAsync(P.w_dirty, 0, (size_t)P.n_in_total, e->stream));
     }
     HIPCHK(hipEventRecord(e->ev[EV_WIN], e->stream));
     HIPCHK(hipMemsetAsync(P.w_conf, 0, sizeof(int32_t) * (size_t)P.n_in_total, e->stream));
     hipLaunchKernelGGL(k_select_fast, tiles, tb, 0, e->stream, P);
     hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096)), dim3(std::min(e->coop, 64)), 0, e->stream, P);
     HIPCHK(hipEventRecord(e->ev[EV_SEL], e->stream));
-    hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P);
-    hipLaunchKernelGGL(k_detect, tiles, tb, 0, e->stream, P);
-    hipLaunchKernelGGL(k_repair, dim3(P.n_units), dim3(e->coop), 0, e->stream, P, pass);
+    // span consumption: rounds of claim / detect / re-enumerate / re-select until no span's set of taken candidates changes
+    HIPCHK(hipMemsetAsync(P.gone, 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(e->n_ie * kCandWords, 1), e->stream));
+    HIPCHK(hipMemsetAsync(P.w_dirty, 0, (size_t)P.n_in_total, e->stream));
+    e->rounds = 0;
+    for (int round = 0;; round++) {
+        HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
+        hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P);
+        HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
+        HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
+        HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 3, e->stream));
+        HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t), e->stream));
+        HIPCHK(hipMemsetAsync(P.round_changed, 0, sizeof(int32_t), e->stream));
+        hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, e->stream, P, round);
+        int32_t changed = 0;
+        HIPCHK(hipMemcpyAsync(&changed, P.round_changed, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (changed == 0) break;
+        if (round >= kMaxRepairRounds) return fail(e, TW_ERR_DEVICE, "span consumption did not settle (more repair rounds than windows)");
+        e->rounds = round + 1;
+        launch_enumerate_all(e, pass, 1);
+        hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096)), dim3(std::min(e->coop, 64)), 0, e->stream, P);
+    }
     HIPCHK(hipEventRecord(e->ev[EV_REPAIR], e->stream));
     hipLaunchKernelGGL(k_finalize, tiles, tb, 0, e->stream, P);
     if (pass == 1) hipLaunchKernelGGL(k_gaps, tiles, tb, 0, e->stream, P);
@@ -498,6 +523,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.tk_idx, ie * kTopK); ALLOC(P.tkr_idx, ie * kTopK);
     ALLOC(P.tk_score, n_in_total * kTopK); ALLOC(P.tkr_score, n_in_total * kTopK);
     ALLOC(P.c_lo, ie); ALLOC(P.c_hi, ie); ALLOC(P.c_bits, ie * kCandWords); ALLOC(P.parent, ie);
+    ALLOC(P.gone, ie * kCandWords); ALLOC(P.leaves_r, n_in_total); ALLOC(P.round_changed, 1);
     ALLOC(P.owner, n_out_total);
     ALLOC(P.gaps, gaps);
     ALLOC(P.unit_stats, (int64_t)P.n_units * 8); ALLOC(P.err, 1);

@@ -295,204 +295,12 @@ __device__ __forceinline__ double score_term(const Scorer& S, int slot, int64_t 
 
 // ---------------------------------------------------------------------------------------------
 // Candidate enumeration for one incoming span.  E is a compile-time constant so that the index
-// tuple, the heap and the cutoffs live in registers.
+// tuple, the kept lists and the cutoffs live in registers.
 template <int E>
 struct Cand {
     double score;
     int32_t idx[E];
 };
-
-template <int E>
-struct Enumerator {
-    const Dev& P;
-    const UnitDev& U;
-    Scorer S;
-    int64_t in_start, in_end;
-    const int64_t* os[E];  // endpoint segments
-    const int64_t* oe[E];
-    int32_t lo[E], hi[E];
-    Cand<E> heap_store[kTopK + 1];
-    Cand<E>* heap;  // thread-private heap_store by default; the wavefront kernel points it at LDS
-    int nheap;
-    int64_t leaves;
-    uint64_t bits[E][kCandWords];
-
-    __device__ Enumerator(const Dev& p, const UnitDev& u) : P(p), U(u), heap(heap_store) {}
-
-    // FindCutoffs on the full lists (traceweaver_v3.py:182-217): lo = bisect_left(start >= in.start),
-    // hi = bisect_right(start <= min(in.end, start of every successor's hi span)) - 1, reverse topo order.
-    __device__ bool cutoffs(int guess) {
-#pragma unroll
-        for (int e = E - 1; e >= 0; e--) {
-            const int n = (int)(U.ep_off[e + 1] - U.ep_off[e]);
-            int64_t t = in_end;
-#pragma unroll
-            for (int f = e + 1; f < E; f++) {
-                if (!((U.succ_mask[e] >> f) & 1)) continue;
-                const int nf = (int)(U.ep_off[f + 1] - U.ep_off[f]);
-                const int anchor = hi[f] >= 0 ? hi[f] : nf - 1;  // Python's [-1] wrap (hazard H10)
-                const int64_t st = os[f][anchor];
-                if (st < t) t = st;
-            }
-            lo[e] = bound_near<false>(os[e], n, in_start, guess);
-            hi[e] = bound_near<true>(os[e], n, t, lo[e]) - 1;
-        }
-        return true;
-    }
-
-    // Python's (score, [spans]) ordering: score, then the first differing span by start_mus.
-    __device__ bool lt(const Cand<E>& a, const Cand<E>& b) const {
-        if (a.score != b.score) return a.score < b.score;
-#pragma unroll
-        for (int e = 0; e < E; e++)
-            if (a.idx[e] != b.idx[e]) return os[e][a.idx[e]] < os[e][b.idx[e]];
-        return false;
-    }
-    // heapq.heappush followed by heappop when the heap exceeds K (traceweaver_v3.py:305-307),
-    // emulated operation by operation so that ties resolve like CPython's _heapq.
-    __device__ void siftdown(int startpos, int pos) {
-        const Cand<E> item = heap[pos];
-        while (pos > startpos) {
-            const int parent = (pos - 1) >> 1;
-            if (lt(item, heap[parent])) { heap[pos] = heap[parent]; pos = parent; continue; }
-            break;
-        }
-        heap[pos] = item;
-    }
-    __device__ void siftup(int pos) {
-        const int startpos = pos;
-        const Cand<E> item = heap[pos];
-        int child = 2 * pos + 1;
-        while (child < nheap) {
-            const int right = child + 1;
-            if (right < nheap && !lt(heap[child], heap[right])) child = right;
-            heap[pos] = heap[child];
-            pos = child;
-            child = 2 * pos + 1;
-        }
-        heap[pos] = item;
-        siftdown(startpos, pos);
-    }
-    __device__ void push(const Cand<E>& c) {
-        heap[nheap++] = c;
-        siftdown(0, nheap - 1);
-        if (nheap > kTopK) {
-            const Cand<E> last = heap[--nheap];
-            if (nheap > 0) { heap[0] = last; siftup(0); }
-        }
-    }
-    __device__ void reverse(int n) {
-        for (int i = 0, j = n - 1; i < j; i++, j--) { const Cand<E> t = heap[i]; heap[i] = heap[j]; heap[j] = t; }
-    }
-    // list.sort(reverse=True) of CPython for n < 64: reverse, count_run, binary insertion, reverse.
-    __device__ void sort_desc() {
-        const int n = nheap;
-        if (n < 2) return;
-        reverse(n);
-        int run = 2;
-        if (lt(heap[1], heap[0])) {
-            for (int i = 2; i < n; i++, run++) if (!lt(heap[i], heap[i - 1])) break;
-            reverse(run);
-        } else {
-            for (int i = 2; i < n; i++, run++) if (lt(heap[i], heap[i - 1])) break;
-        }
-        for (int start = run; start < n; start++) {
-            int l = 0, r = start;
-            const Cand<E> pivot = heap[start];
-            do {
-                const int p = l + ((r - l) >> 1);
-                if (lt(pivot, heap[p])) r = p; else l = p + 1;
-            } while (l < r);
-            for (int p = start; p > l; p--) heap[p] = heap[p - 1];
-            heap[l] = pivot;
-        }
-        reverse(n);
-    }
-
-    // ScoreAssignmentAsPerInvocationGraph, no-skip branch (traceweaver_v1.py:305-361)
-    __device__ double score(const int32_t* x, const int64_t* xs, const int64_t* xe) const {
-        int last = 0;
-        int64_t last_end = xe[0];
-#pragma unroll
-        for (int e = 1; e < E; e++) if (xe[e] > last_end) { last_end = xe[e]; last = e; }  // first maximum
-        double cost = 0.0;
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int np = U.npred[e];
-            for (int j = 0; j < np; j++) {
-                if (!U.pred_prim[e][j]) continue;
-                const int p = U.pred_list[e][j];
-                cost += score_term(S, slot_prim(E, p, e), xe[p], xs[e]);
-            }
-            if (np == 0) cost += score_term(S, slot_root(E, e), in_start, xs[e]);
-            if (e == last) cost += score_term(S, slot_close(E, e), xe[e], in_end);
-        }
-        return cost;
-    }
-
-    // DfsTraverseX / DfsTraverse3 (traceweaver_v3.py:236-351): endpoints in topological order,
-    // candidates by increasing index, containment in the incoming span, pred.end <= s.start for every
-    // DAG in-edge.  `gone` masks spans consumed by earlier windows (relative to lo[e]); the full-list
-    // cutoffs stay valid because they never exclude a feasible tuple.
-    template <bool kScore, bool kBits>
-    __device__ void dfs(const uint64_t (*gone)[kCandWords]) {
-        int32_t x[E];
-        int64_t xs[E], xe[E];
-        nheap = 0;
-        leaves = 0;
-        if (kBits)
-            for (int e = 0; e < E; e++)
-                for (int w = 0; w < kCandWords; w++) bits[e][w] = 0;
-        int d = 0;
-        x[0] = lo[0] - 1;
-        while (d >= 0) {
-            int c = x[d] + 1;
-            bool found = false;
-            for (; c <= hi[d]; c++) {
-                const int r = c - lo[d];
-                if (gone != nullptr && ((gone[d][r >> 6] >> (r & 63)) & 1)) continue;
-                const int64_t st = os[d][c], en = oe[d][c];
-                if (in_start > st || en > in_end) continue;
-                bool ok = true;
-                for (int p = 0; p < d; p++)
-                    if (((U.pred_mask[d] >> p) & 1) && xe[p] > st) { ok = false; break; }
-                if (ok) { xs[d] = st; xe[d] = en; found = true; break; }
-            }
-            if (!found) { d--; continue; }
-            x[d] = c;
-            if (d == E - 1) {
-                leaves++;
-                if (kBits) {
-#pragma unroll
-                    for (int e = 0; e < E; e++) { const int r = x[e] - lo[e]; bits[e][r >> 6] |= 1ull << (r & 63); }
-                }
-                if (kScore) {
-                    Cand<E> cand;
-                    cand.score = score(x, xs, xe);
-#pragma unroll
-                    for (int e = 0; e < E; e++) cand.idx[e] = x[e];
-                    push(cand);
-                }
-            } else {
-                d++;
-                x[d] = lo[d] - 1;
-            }
-        }
-        if (kScore) sort_desc();
-    }
-};
-
-template <int E>
-__device__ void setup_enumerator(Enumerator<E>& en, const Dev& P, const UnitDev& U, int i, int pass) {
-    en.in_start = P.in_start[U.in_off + i];
-    en.in_end = P.in_end[U.in_off + i];
-#pragma unroll
-    for (int e = 0; e < E; e++) { en.os[e] = P.out_start + U.ep_off[e]; en.oe[e] = P.out_end + U.ep_off[e]; }
-    en.S.pass = pass;
-    en.S.gp = P.gparam + (U.gp_off + (int64_t)(i / P.batch_size) * U.nslot) * 4;
-    en.S.mix_n = P.mix_n + U.slot_off;
-    en.S.mix_c = P.mix_c + (int64_t)U.slot_off * kMaxComp * 4;
-}
 
 // Speculative enumeration on all spans: this *is* top_k_2 (traceweaver_v3.py:1185) and equals top_k
 // (traceweaver_v3.py:1182) for every span none of whose candidates was consumed by an earlier window.
@@ -527,34 +335,22 @@ constexpr int kHeavyThreads = 64;
 #define TW_PROF_FLUSH() do {} while (0)
 #endif
 
-template <int E>
-__device__ void write_result(const Dev& P, const UnitDev& U, int i, int pass, const Enumerator<E>& en) {
-    const int64_t g = U.in_off + i;
-    P.tk_n[g] = en.nheap;
-    P.leaves[g] = en.leaves;
-    P.rep[g] = 0;
-#pragma unroll
-    for (int k = 0; k < kTopK; k++) {
-        if (k >= en.nheap) continue;  // unused entries keep the -1 / NaN pattern they were given at load time
-        P.tk_score[tks_index(U, k, i)] = en.heap[k].score;
-#pragma unroll
-        for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, i)] = en.heap[k].idx[e];
-    }
-    if (pass == 1) {
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            P.c_lo[ie_index(U, e, i)] = en.lo[e];
-            for (int w = 0; w < kCandWords; w++) P.c_bits[ie_index(U, e, i) * kCandWords + w] = en.bits[e][w];
-        }
-    }
-}
-
 // Work list of k_enumerate_heavy<E, W>: the class' slice [heavy_in_off[E], heavy_in_off[E+1]) of heavy_in_unit /
 // heavy_in_idx is filled from the front with the spans whose candidate windows are all <= kNarrow wide (served by
 // the small-LDS instantiation, more wavefronts per CU) and from the back with the others.
 constexpr int kNarrow = 32;
 template <int E>
 __device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narrow, int unit, int i) {
+    const int sn = wave_append(&P.heavy_in_count[E], pred && narrow);
+    const int sw = wave_append(&P.heavy_in_count[kMaxEp + 1 + E], pred && !narrow);
+    if (!pred) return false;
+    const int pos = narrow ? P.heavy_in_off[E] + sn : P.heavy_in_off[E + 1] - 1 - sw;
+    P.heavy_in_unit[pos] = unit;
+    P.heavy_in_idx[pos] = i;
+    return true;
+}
+
+__device__ __forceinline__ bool heavy_append_rt(const Dev& P, int E, bool pred, bool narrow, int unit, int i) {  // E is the same for the whole wavefront
     const int sn = wave_append(&P.heavy_in_count[E], pred && narrow);
     const int sw = wave_append(&P.heavy_in_count[kMaxEp + 1 + E], pred && !narrow);
     if (!pred) return false;
@@ -869,18 +665,18 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
     }
 }
 
-// CPython heap / sort replay on an LDS-resident heap (k_enumerate_heavy, degenerate-tie spans only)
-template <int E>
+// CPython heap / sort replay on an LDS-resident heap (k_enumerate_heavy, degenerate-tie spans only).  Entries hold
+// positions in the staged candidate lists; Python's order on equal scores is start_mus of the first differing span.
+template <int E, int W>
 struct LdsHeap {
     Cand<E>* heap;
     int nheap;
-    const int64_t* out_start;  // P.out_start
-    const UnitDev* U;
+    const int64_t (*ls)[W];  // staged start times [E][W]
     __device__ bool lt(const Cand<E>& a, const Cand<E>& b) const {
         if (a.score != b.score) return a.score < b.score;
 #pragma unroll
         for (int e = 0; e < E; e++)
-            if (a.idx[e] != b.idx[e]) return out_start[U->ep_off[e] + a.idx[e]] < out_start[U->ep_off[e] + b.idx[e]];
+            if (a.idx[e] != b.idx[e]) return ls[e][a.idx[e]] < ls[e][b.idx[e]];
         return false;
     }
     __device__ void siftdown(int startpos, int pos) {
@@ -942,38 +738,56 @@ struct LdsHeap {
     }
 };
 
-// One wavefront per span.  Nothing lives in scratch memory: what is the same for every lane (cut-offs,
-// the prefix being walked, the staged candidate window, the term tables, the replay heap) sits in LDS,
-// what differs per lane (its grid point) sits in registers addressed by compile-time indices.
+// One wavefront per span.  Nothing lives in scratch memory: what is the same for every lane (cut-offs, the prefix
+// being walked, the staged candidates, the term tables, the replay heap) sits in LDS, what differs per lane (its
+// grid point) sits in registers addressed by compile-time indices.
+//
+//   * Only the candidates that can occur in a tuple at all are staged: spans of the cut-off window that lie inside
+//     the incoming span (traceweaver_v3.py:328-333) and -- when a window is re-solved after earlier windows took
+//     spans away (mode 1, traceweaver_v1.py:457-463) -- are still there.  Order is kept; lr[][] maps a staged
+//     position back to the position in the cut-off window.  On the bench workloads two thirds of the raw grid points
+//     fail containment; the enumeration only visits the grid of the staged candidates.
+//   * Every score term is a table look-up: root(in.start -> s.start) and closing(s.end -> in.end) per staged
+//     candidate, and the term of a primary call-order edge (p.end -> s.start, traceweaver_v1.py:345-347) per pair of
+//     staged candidates (as long as the pair tables fit their LDS pool; edges that do not fit are evaluated per tuple).
+//     A term is evaluated once per candidate (pair) instead of once per tuple -- with mixtures (pass 2) a term is
+//     ~1.5k instructions and an 8-endpoint tuple has up to 9 of them.  The tuple score adds the same doubles in the
+//     same order as the reference, so it is bit-identical.
+constexpr int kPairPoolPerEp = 160;   // doubles of pair-term tables per endpoint count (E = 8: 10 KB)
 template <int E, int W>
-__global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass) {
+__global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass, int mode) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     static_assert(W == kNarrow || W == 64 * kCandWords, "one instantiation per half of the work list");
     constexpr bool kWide = W != kNarrow;
     constexpr int kList = kWide ? kMaxEp + 1 + E : E;
+    constexpr int kPool = E > 1 ? kPairPoolPerEp * E : 1;
     __shared__ unsigned long long sbits[kMaxEp][kCandWords];
-    // LDS-staged candidate window of the span: start / end of every candidate outgoing span, and the two
-    // score terms that depend on one span only -- root(in.start -> s.start) and closing(s.end -> in.end)
-    // (traceweaver_v1.py:349-357).  They are evaluated once per candidate instead of once per tuple; the
-    // tuple score adds the same doubles in the same order, so it is bit-identical.
-    __shared__ int64_t ls[E][W], le[E][W];
+    __shared__ int64_t ls[E][W], le[E][W];      // staged candidates: start / end
     __shared__ double troot[E][W], tclose[E][W];
-    __shared__ Cand<E> sheap[kTopK + 1];   // CPython heap replay (degenerate ties only), lane 0
-    __shared__ int32_t keep_idx[kTopK][E];  // index tuples of the kept entries otherwise
-    __shared__ int32_t px[E];               // the prefix the wavefront is walking (same for every lane)
+    __shared__ double tpair[kPool];
+    __shared__ int16_t tp_off[E][E];            // pair table of the j-th in-edge of endpoint e, -1: evaluated per tuple
+    __shared__ uint8_t lr[E][W];                // position of the staged candidate in the cut-off window
+    __shared__ Cand<E> sheap[kTopK + 1];        // CPython heap replay (degenerate ties only), lane 0
+    __shared__ int32_t keep_idx[kTopK][E];      // staged positions of the kept entries otherwise
+    __shared__ int32_t px[E];                   // the prefix the wavefront is walking (staged positions, same for every lane)
     __shared__ int64_t pxs[E], pxe[E];
     const int t = threadIdx.x, nt = blockDim.x;
     const int count = P.heavy_in_count[kList];
-    TW_PROF_DECL();
     int chunk_pos = 0, chunk_end = 0;
+    bool first_chunk = true;
     while (true) {
         // dynamic work distribution: candidate products span four orders of magnitude, a static split leaves
-        // most wavefronts idle behind the few that drew the large spans
+        // most wavefronts idle behind the few that drew the large spans.  The first chunk of a wavefront is its own
+        // (no atomic: thousands of same-address atomics at kernel start serialise at ~20 ns each); later chunks come
+        // from the counter, which starts behind the static ones.
         if (chunk_pos == chunk_end) {
-            if (t == 0) chunk_pos = atomicAdd(&P.heavy_in_next[kList], kWorkChunk);
-            chunk_pos = __shfl(chunk_pos, 0);
+            if (first_chunk) { chunk_pos = (int)blockIdx.x * kWorkChunk; first_chunk = false; }
+            else {
+                if (t == 0) chunk_pos = (int)gridDim.x * kWorkChunk + atomicAdd(&P.heavy_in_next[kList], kWorkChunk);
+                chunk_pos = __shfl(chunk_pos, 0);
+            }
             chunk_end = chunk_pos + kWorkChunk < count ? chunk_pos + kWorkChunk : count;
-            if (chunk_pos >= count) { TW_PROF_FLUSH(); break; }
+            if (chunk_pos >= count) break;
         }
         const int item = chunk_pos++;
         // wave-uniform by construction; telling the compiler so turns every access to the unit descriptor below
@@ -982,10 +796,6 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         const int unit = __builtin_amdgcn_readfirstlane(P.heavy_in_unit[pos]);
         const int i = __builtin_amdgcn_readfirstlane(P.heavy_in_idx[pos]);
         const UnitDev& U = P.units[unit];
-        TW_T0();
-#ifdef TW_PROFILE
-        const long long _tw_item0 = wall_clock64();
-#endif
         const int64_t in_start = P.in_start[U.in_off + i], in_end = P.in_end[U.in_off + i];
         Scorer S;
         S.pass = pass;
@@ -993,12 +803,9 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         S.mix_n = P.mix_n + U.slot_off;
         S.mix_c = P.mix_c + (int64_t)U.slot_off * kMaxComp * 4;
         // cut-offs (FindCutoffs, traceweaver_v3.py:182-217) were computed by k_enumerate_light in pass 1
-        int32_t lo[E], hi[E];
-#pragma unroll
-        for (int e = 0; e < E; e++) { lo[e] = P.c_lo[ie_index(U, e, i)]; hi[e] = P.c_hi[ie_index(U, e, i)]; }
-        // the unit's call-order DAG in registers (it is consulted at every grid point; read from the descriptor in
-        // global memory each of those reads is a scalar load with its own wait): predecessor masks, predecessor
-        // counts, and per endpoint the predecessor list in in_edges() order packed 4 bits each (index | primary << 3)
+        int32_t lo[E], cn[E];   // first span of the cut-off window; number of staged candidates
+        // the unit's call-order DAG in registers: predecessor masks, predecessor counts, and per endpoint the
+        // predecessor list in in_edges() order packed 4 bits each (index | primary << 3)
         uint32_t dag_pm[E], dag_np[E], dag_pl[E];
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -1009,40 +816,83 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             for (int j = 0; j < E; j++) pk |= (j < (int)dag_np[e] ? ((uint32_t)U.pred_list[e][j] | ((uint32_t)U.pred_prim[e][j] << 3)) : 0u) << (4 * j);
             dag_pl[e] = pk;
         }
-        TW_TICK(0);
         for (int k = t; k < kMaxEp * kCandWords; k += nt) (&sbits[0][0])[k] = 0;
+        bool none = false;
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int w = hi[e] - lo[e] + 1;
+        for (int e = 0; e < E; e++) {   // stage the candidates that can occur in a tuple, order kept (ballot prefix sums)
+            lo[e] = P.c_lo[ie_index(U, e, i)];
+            const int w = P.c_hi[ie_index(U, e, i)] - lo[e] + 1;
             const int64_t* os = P.out_start + U.ep_off[e];
             const int64_t* oe = P.out_end + U.ep_off[e];
-            for (int r = t; r < w; r += nt) {
-                const int c = lo[e] + r;
-                ls[e][r] = os[c];
-                le[e][r] = oe[c];
+            const uint64_t* gone = mode == 1 ? P.gone + ie_index(U, e, i) * kCandWords : nullptr;
+            int c = 0;
+            for (int r0 = 0; r0 < w; r0 += nt) {
+                const int r = r0 + t;
+                int64_t st = 0, e2 = 0;
+                bool inside = false;
+                if (r < w) {
+                    st = os[lo[e] + r]; e2 = oe[lo[e] + r];
+                    inside = !(in_start > st || e2 > in_end);
+                    if (inside && gone != nullptr) inside = !((gone[r >> 6] >> (r & 63)) & 1ull);
+                }
+                const unsigned long long m = __ballot(inside);
+                if (inside) {
+                    const int q = c + __popcll(m & ((1ull << t) - 1ull));
+                    ls[e][q] = st; le[e][q] = e2; lr[e][q] = (uint8_t)r;
+                }
+                c += __popcll(m);
             }
+            cn[e] = c;
+            none |= c == 0;
         }
         wave_sync();
+        int64_t leaves = 0;
+        int nout = 0;
+        if (!none) {
         {   // one (candidate span, root | closing) term per lane, all endpoints at once
             int wsum = 0;
 #pragma unroll
-            for (int e = 0; e < E; e++) wsum += hi[e] - lo[e] + 1;
+            for (int e = 0; e < E; e++) wsum += cn[e];
             for (int q = t; q < 2 * wsum; q += nt) {
                 int es = 0, r = q >> 1;
                 bool found = false;
 #pragma unroll
-                for (int e = 0; e < E; e++) {
-                    const int w = hi[e] - lo[e] + 1;
-                    if (!found) { if (r < w) { es = e; found = true; } else r -= w; }
-                }
+                for (int e = 0; e < E; e++)
+                    if (!found) { if (r < cn[e]) { es = e; found = true; } else r -= cn[e]; }
                 const int64_t st = ls[es][r], e2 = le[es][r];
-                if (in_start > st || e2 > in_end) continue;  // not contained: never part of a tuple
                 if (q & 1) tclose[es][r] = score_term(S, slot_close(E, es), e2, in_end);
                 else {
                     bool is_root = false;
 #pragma unroll
                     for (int e = 0; e < E; e++) if (e == es) is_root = dag_np[e] == 0;
                     troot[es][r] = is_root ? score_term(S, slot_root(E, es), in_start, st) : 0.0;
+                }
+            }
+        }
+        if constexpr (E > 1) {   // pair tables of the primary in-edges, in scoring order, while the pool lasts
+            int used = 0;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    if (j >= (int)dag_np[e]) continue;
+                    const uint32_t pj = (dag_pl[e] >> (4 * j)) & 15u;
+                    if (!(pj & 8u)) continue;
+                    const int p = (int)(pj & 7u);
+                    int cp = 0;
+#pragma unroll
+                    for (int q = 0; q < E; q++) if (q == p) cp = cn[q];
+                    const int need = cp * cn[e];
+                    const bool fits = used + need <= kPool;
+                    if (t == 0) tp_off[e][j] = (int16_t)(fits ? used : -1);
+                    if (fits) {
+                        for (int q = t; q < need; q += nt) {
+                            const int a = q / cn[e], b2 = q % cn[e];
+                            const int64_t pend = le[p][a], st = ls[e][b2];
+                            if (pend <= st) tpair[used + q] = score_term(S, slot_prim(E, p, e), pend, st);  // other pairs never occur in a tuple
+                        }
+                        used += need;
+                    }
                 }
             }
         }
@@ -1053,35 +903,51 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         // values) and watch for an equivalence that could matter (between the candidate, the evicted entry
         // or the kept entries).  If one shows up -- millisecond-granular data -- the span is redone with the
         // CPython heap replayed push by push in LDS (second attempt).
-        LdsHeap<E> hp;
-        hp.heap = sheap; hp.nheap = 0; hp.out_start = P.out_start; hp.U = &U;
+        LdsHeap<E, W> hp;
+        hp.heap = sheap; hp.nheap = 0; hp.ls = ls;
         wave_sync();
-        TW_TICK(1);
         double ts[kTopK];
-        int tq[kTopK], tslot[kTopK], nk = 0, seq = -1;
-        int tg[kTopK];
+        int tslot[kTopK], nk = 0;
         bool exact_replay = false, ambiguous = false;
-        int64_t leaves = 0;
         for (int attempt = 0; attempt < 2; attempt++) {
         exact_replay = attempt == 1;
-        hp.nheap = 0; nk = 0; seq = -1; leaves = 0;
+        hp.nheap = 0; nk = 0; leaves = 0;
 #pragma unroll
-        for (int k = 0; k < kTopK; k++) { ts[k] = -dinf(); tq[k] = -1; tg[k] = -1; tslot[k] = k; }
-        // order of the candidate tuple (prefix px[0..L) + grid point gj) against the kept tuple in LDS slot sl
-        // when their scores are equal: +1 candidate greater, -1 smaller, 0 equivalent
-        auto tie_order = [&](int gj, int sl, int Ls) -> int {
-            int gr = gj;
-            int32_t ci[E];
+        for (int k = 0; k < kTopK; k++) { ts[k] = -dinf(); tslot[k] = k; }
+        // Split the endpoints at L: levels 0..L-1 are walked together (every lane the same prefix), the
+        // tuples of levels L..E-1 -- a grid of G = prod cn_e points, in enumeration order -- are spread over
+        // the lanes.  L is the deepest split that still gives the lanes a full wavefront of grid points.
+        int L = E - 1;
+        int G = cn[E - 1];  // < 64 * 128: the grid stops growing once it fills the wavefront
+#pragma unroll
+        for (int e = E - 2; e >= 0; e--)
+            if (L == e + 1 && G < kHeavyThreads) { L = e; G *= cn[e]; }
+        // grid point -> staged positions of the levels L..E-1, last endpoint fastest: divisions by the wave-uniform
+        // counts as multiplications (exact for g * (c - 1) < 2^32)
+        uint32_t magic[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) magic[e] = (uint32_t)((0x100000000ull + (unsigned)cn[e] - 1ull) / (unsigned)cn[e]);
+        auto grid_digits = [&](int g, int32_t (&x)[E]) {
+            uint32_t rest = (uint32_t)g;
 #pragma unroll
             for (int e = E - 1; e >= 0; e--) {
-                if (e >= Ls) { const int w = hi[e] - lo[e] + 1; ci[e] = lo[e] + (int)(gr % w); gr /= w; }
-                else ci[e] = px[e];
+                if (e >= L) {
+                    const uint32_t q = cn[e] == 1 ? rest : __umulhi(rest, magic[e]);
+                    x[e] = (int32_t)(rest - q * (uint32_t)cn[e]);
+                    rest = q;
+                } else x[e] = px[e];
             }
+        };
+        // order of the candidate tuple (prefix px[0..L) + grid point gj) against the kept tuple in LDS slot sl
+        // when their scores are equal: +1 candidate greater, -1 smaller, 0 equivalent
+        auto tie_order = [&](int gj, int sl) -> int {
+            int32_t ci[E];
+            grid_digits(gj, ci);
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 const int32_t ki = keep_idx[sl][e];
                 if (ci[e] != ki) {
-                    const int64_t a = ls[e][ci[e] - lo[e]], b2 = ls[e][ki - lo[e]];
+                    const int64_t a = ls[e][ci[e]], b2 = ls[e][ki];
                     return a > b2 ? 1 : (a < b2 ? -1 : 0);
                 }
             }
@@ -1092,83 +958,64 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             for (int e = 0; e < E; e++) {
                 const int32_t ia = keep_idx[sa][e], ib = keep_idx[sb][e];
                 if (ia != ib) {
-                    const int64_t a = ls[e][ia - lo[e]], b2 = ls[e][ib - lo[e]];
+                    const int64_t a = ls[e][ia], b2 = ls[e][ib];
                     return a > b2 ? 1 : (a < b2 ? -1 : 0);
                 }
             }
             return 0;
         };
-        // Split the endpoints at L: levels 0..L-1 are walked together (every lane the same prefix), the
-        // tuples of levels L..E-1 -- a grid of G = prod w_e points, in enumeration order -- are spread over
-        // the lanes.  L is the deepest split that still gives the lanes a full wavefront of grid points.
-        int L = E - 1;
-        int G = hi[E - 1] - lo[E - 1] + 1;  // < 64 * 128: the grid stops growing once it fills the wavefront
-#pragma unroll
-        for (int e = E - 2; e >= 0; e--)
-            if (L == e + 1 && G < kHeavyThreads) { L = e; G *= (hi[e] - lo[e] + 1); }
         int d = 0;
-        if (L > 0) px[0] = lo[0] - 1;
+        if (L > 0 && t == 0) px[0] = -1;
         wave_sync();
         const bool once = (L == 0);
         while (once || d >= 0) {
             if (L > 0) {  // next feasible prefix, every lane in lockstep (DfsTraverseX order)
-                int hid = 0, lod = 0;
+                int cd = 0;
                 uint32_t pmd = 0;
 #pragma unroll
-                for (int e = 0; e < E; e++) if (e == d) { hid = hi[e]; lod = lo[e]; pmd = dag_pm[e]; }
+                for (int e = 0; e < E; e++) if (e == d) { cd = cn[e]; pmd = dag_pm[e]; }
                 int c = px[d] + 1;
                 bool found = false;
                 int64_t fst = 0, fen = 0;
-                for (; c <= hid; c++) {
-                    const int64_t st = ls[d][c - lod], e2 = le[d][c - lod];
-                    if (in_start > st || e2 > in_end) continue;
+                for (; c < cd; c++) {
+                    const int64_t st = ls[d][c];
                     bool ok = true;
                     for (int p = 0; p < d; p++)
                         if (((pmd >> p) & 1) && pxe[p] > st) { ok = false; break; }
-                    if (ok) { fst = st; fen = e2; found = true; break; }
+                    if (ok) { fst = st; fen = le[d][c]; found = true; break; }
                 }
+                wave_sync();   // every lane has read px[d] before it changes
                 if (!found) { d--; continue; }
-                px[d] = c; pxs[d] = fst; pxe[d] = fen;  // every lane stores the same values
+                if (t == 0) { px[d] = c; pxs[d] = fst; pxe[d] = fen; }
                 if (d < L - 1) {
                     d++;
-                    int lon = 0;
-#pragma unroll
-                    for (int e = 0; e < E; e++) if (e == d) lon = lo[e];
-                    px[d] = lon - 1;
+                    if (t == 0) px[d] = -1;
+                    wave_sync();
                     continue;
                 }
+                wave_sync();
             }
             bool any = false;
-            seq++;
             for (int base = 0; base < G; base += nt) {
-                int g = base + t;
+                const int g = base + t;
                 bool ok = g < G;
                 double score = 0.0;
                 int32_t x[E];
                 int64_t xs[E], xe[E];
-#pragma unroll
-                for (int e = E - 1; e >= 0; e--) {  // mixed-radix digits of the grid point, last endpoint fastest
-                    if (e >= L) {
-                        const int w = hi[e] - lo[e] + 1;
-                        x[e] = lo[e] + (int)(g % w);
-                        g /= w;
-                    } else {
-                        x[e] = px[e]; xs[e] = pxs[e]; xe[e] = pxe[e];
-                    }
-                }
+                grid_digits(ok ? g : 0, x);
 #pragma unroll
                 for (int e = 0; e < E; e++) {
-                    if (e >= L && ok) {
-                        const int64_t st = ls[e][x[e] - lo[e]], e2 = le[e][x[e] - lo[e]];
-                        ok = !(in_start > st || e2 > in_end);
+                    if (e < L) { xs[e] = pxs[e]; xe[e] = pxe[e]; }
+                    else {
+                        const int64_t st = ls[e][x[e]];
 #pragma unroll
                         for (int p = 0; p < e; p++)
                             if (((dag_pm[e] >> p) & 1) && xe[p] > st) ok = false;
-                        xs[e] = st; xe[e] = e2;
+                        xs[e] = st; xe[e] = le[e][x[e]];
                     }
                 }
                 if (ok) {
-                    // ScoreAssignmentAsPerInvocationGraph (traceweaver_v1.py:305-361) with tabulated root / closing terms
+                    // ScoreAssignmentAsPerInvocationGraph (traceweaver_v1.py:305-361) from the term tables
                     int last = 0;
                     int64_t last_end = xe[0];
 #pragma unroll
@@ -1176,25 +1023,28 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
 #pragma unroll
                     for (int e = 0; e < E; e++) {
                         const int np = (int)dag_np[e];
-                        for (int j = 0; j < np; j++) {
+#pragma unroll
+                        for (int j = 0; j < E; j++) {
+                            if (j >= np) continue;
                             const uint32_t pj = (dag_pl[e] >> (4 * j)) & 15u;
                             if (!(pj & 8u)) continue;
                             const int p = (int)(pj & 7u);
                             int64_t pend = 0;
+                            int xp = 0;
 #pragma unroll
-                            for (int q = 0; q < E; q++) if (q == p) pend = xe[q];
-                            score += score_term(S, slot_prim(E, p, e), pend, xs[e]);
+                            for (int q = 0; q < E; q++) if (q == p) { pend = xe[q]; xp = x[q]; }
+                            const int off = E > 1 ? (int)tp_off[e][j] : -1;
+                            score += off >= 0 ? tpair[off + xp * cn[e] + x[e]] : score_term(S, slot_prim(E, p, e), pend, xs[e]);
                         }
-                        if (np == 0) score += troot[e][x[e] - lo[e]];
-                        if (e == last) score += tclose[e][x[e] - lo[e]];
+                        if (np == 0) score += troot[e][x[e]];
+                        if (e == last) score += tclose[e][x[e]];
                     }
-                    if (pass == 1) {
+                    if (pass == 1 && mode == 0) {
 #pragma unroll
                         for (int e = 0; e < E; e++)
-                            if (e >= L) { const int r = x[e] - lo[e]; atomicOr(&sbits[e][r >> 6], 1ull << (r & 63)); }
+                            if (e >= L) { const int r = lr[e][x[e]]; atomicOr(&sbits[e][r >> 6], 1ull << (r & 63)); }
                     }
                 }
-                TW_TICK(2);
                 const unsigned long long feasible = __ballot(ok);
                 leaves += __popcll(feasible);
                 any |= feasible != 0;
@@ -1213,12 +1063,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         if (t == 0) {
                             Cand<E> cand;
                             cand.score = sj;
-                            int gj = base + j;
-#pragma unroll
-                            for (int e = E - 1; e >= 0; e--) {
-                                if (e >= L) { const int w = hi[e] - lo[e] + 1; cand.idx[e] = lo[e] + (int)(gj % w); gj /= w; }
-                                else cand.idx[e] = px[e];
-                            }
+                            grid_digits(base + j, cand.idx);
                             hp.push(cand);
                         }
                     }
@@ -1254,7 +1099,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                                 int sl = 0;
 #pragma unroll
                                 for (int q = 0; q < kTopK; q++) if (q == k) sl = tslot[q];
-                                tie[k] = tie_order(gj, sl, L);
+                                tie[k] = tie_order(gj, sl);
                                 if (tie[k] == 0) ambiguous = true;
                             }
                         }
@@ -1272,37 +1117,33 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         int slot = 0;  // free slot, or the slot of the entry that drops out
 #pragma unroll
                         for (int k = 0; k < kTopK; k++) if (k == lastpos) slot = tslot[k];
-                        int pos = lastpos;
+                        int pos2 = lastpos;
 #pragma unroll
                         for (int k = kTopK - 1; k >= 1; k--) {
-                            if (k == pos && (sj > ts[k - 1] || (sj == ts[k - 1] && tie[k - 1] > 0))) {
-                                ts[k] = ts[k - 1]; tq[k] = tq[k - 1]; tg[k] = tg[k - 1]; tslot[k] = tslot[k - 1];
-                                pos = k - 1;
+                            if (k == pos2 && (sj > ts[k - 1] || (sj == ts[k - 1] && tie[k - 1] > 0))) {
+                                ts[k] = ts[k - 1]; tslot[k] = tslot[k - 1];
+                                pos2 = k - 1;
                             }
                         }
 #pragma unroll
                         for (int k = 0; k < kTopK; k++)
-                            if (k == pos) { ts[k] = sj; tq[k] = seq; tg[k] = gj; tslot[k] = slot; }
+                            if (k == pos2) { ts[k] = sj; tslot[k] = slot; }
                         if (nk < kTopK) nk++;
+                        wave_sync();   // tie_order of this round has read keep_idx[slot] before it is overwritten
                         if (t == 0) {
-                            int gr = gj;
+                            int32_t ci[E];
+                            grid_digits(gj, ci);
 #pragma unroll
-                            for (int e = E - 1; e >= 0; e--) {
-                                if (e >= L) { const int w = hi[e] - lo[e] + 1; keep_idx[slot][e] = lo[e] + (int)(gr % w); gr /= w; }
-                                else keep_idx[slot][e] = px[e];
-                            }
+                            for (int e = 0; e < E; e++) keep_idx[slot][e] = ci[e];
                         }
+                        wave_sync();
                     }
                 }
                 wave_sync();
-                TW_TICK(3);
             }
-            if (t == 0 && any && pass == 1)
+            if (t == 0 && any && pass == 1 && mode == 0)
                 for (int e = 0; e < L; e++) {
-                    int loe = 0;
-#pragma unroll
-                    for (int q = 0; q < E; q++) if (q == e) loe = lo[q];
-                    const int r = px[e] - loe;
+                    const int r = lr[e][px[e]];
                     sbits[e][r >> 6] |= 1ull << (r & 63);
                 }
             if (L == 0) break;
@@ -1328,6 +1169,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             else {
 #pragma unroll
                 for (int k = 0; k < kTopK; k++) {
+                    if (k >= nk) continue;
                     sheap[k].score = ts[k];
                     int sl = 0;
 #pragma unroll
@@ -1337,38 +1179,33 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             }
         }
         wave_sync();
-        {   // results leave through all lanes: one (entry, field) per lane
+        nout = exact_replay ? __shfl(hp.nheap, 0) : nk;
+        }  // !none
+        {   // results leave through all lanes: one (entry, field) per lane; staged positions back to span indices
             const int64_t g = U.in_off + i;
-            const int nout = exact_replay ? __shfl(hp.nheap, 0) : nk;
-            if (t == 0) { P.tk_n[g] = nout; P.leaves[g] = leaves; P.rep[g] = 0; }
+            int32_t* out_n = mode == 1 ? P.tkr_n : P.tk_n;
+            int32_t* out_idx = mode == 1 ? P.tkr_idx : P.tk_idx;
+            double* out_score = mode == 1 ? P.tkr_score : P.tk_score;
+            if (t == 0) { out_n[g] = nout; (mode == 1 ? P.leaves_r : P.leaves)[g] = leaves; P.rep[g] = (uint8_t)mode; }
             for (int q = t; q < kTopK * (E + 1); q += nt) {
                 const int k = q / (E + 1), f = q % (E + 1);
-                if (k >= nout) continue;  // unused entries keep the -1 / NaN pattern they were given at load time
-                if (f == E) P.tk_score[tks_index(U, k, i)] = sheap[k].score;
-                else P.tk_idx[tk_index(U, k, f, i)] = sheap[k].idx[f];
-            }
-            if (pass == 1) {
-                for (int q = t; q < E * (kCandWords + 1); q += nt) {
-                    const int e = q / (kCandWords + 1), f = q % (kCandWords + 1);
+                if (mode == 0 && k >= nout) continue;  // unused entries keep the -1 / NaN pattern they were given at load time
+                if (f == E) out_score[tks_index(U, k, i)] = k < nout ? sheap[k].score : dnan();
+                else {
                     int loe = 0;
 #pragma unroll
-                    for (int x = 0; x < E; x++) if (x == e) loe = lo[x];
-                    if (f == kCandWords) P.c_lo[ie_index(U, e, i)] = loe;
-                    else P.c_bits[ie_index(U, e, i) * kCandWords + f] = sbits[e][f];
+                    for (int x = 0; x < E; x++) if (x == f) loe = lo[x];
+                    out_idx[tk_index(U, k, f, i)] = k < nout ? loe + (int)lr[f][sheap[k].idx[f]] : -1;
+                }
+            }
+            if (pass == 1 && mode == 0) {
+                for (int q = t; q < E * kCandWords; q += nt) {
+                    const int e = q / kCandWords, f = q % kCandWords;
+                    P.c_bits[ie_index(U, e, i) * kCandWords + f] = sbits[e][f];
                 }
             }
         }
         wave_sync();
-        TW_TICK(4);
-#ifdef TW_PROFILE
-        if (t == 0) {
-            const unsigned long long dur = (unsigned long long)(wall_clock64() - _tw_item0);
-            unsigned long long gsz = 1;
-            for (int e = 0; e < E; e++) gsz *= (unsigned long long)(hi[e] - lo[e] + 1 > 0 ? hi[e] - lo[e] + 1 : 0);
-            if (gsz > 0xfffffffffull) gsz = 0xfffffffffull;
-            atomicMax((unsigned long long*)&P.prof[12], (dur << 40) | (gsz << 4) | (unsigned long long)(exact_replay ? 1 : 0) | (unsigned long long)(ambiguous ? 2 : 0));
-        }
-#endif
     }
 }
 
@@ -1519,7 +1356,6 @@ __global__ void k_window_index(Dev P) {  // after the ScanWinId scan: wid curren
     const int64_t g = U.in_off + i;
     const int w = P.wid[g] - P.win_end[g];
     P.wid[g] = w;
-    P.w_dirty[g] = 0;
     if (P.win_end[g]) P.w_last[U.in_off + w] = i;
     if (i == U.n_in - 1) P.unit_nwin[Tl.unit] = w + 1;
 }
@@ -1973,6 +1809,23 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
     TW_SEL_TICK(7);
 }
 
+// Puts window w of the unit on the work list of k_select_heavy (`listed` lanes only; every lane of the wavefront calls).
+// Long windows can take a thousand times longer than short ones: they are listed from the front and served first, the
+// short ones from the back of the same array, so that no long search starts when the kernel is about to drain.
+__device__ __forceinline__ void list_window(const Dev& P, const UnitDev& U, int unit, int w, bool listed) {
+    bool big = false;
+    if (listed) {
+        const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
+        big = P.w_last[U.in_off + w] - first + 1 >= kBigWindow;
+    }
+    const int sb = wave_append(&P.heavy_count[1], big), ss = wave_append(&P.heavy_count[2], listed && !big);
+    if (listed) {
+        const int pos = big ? sb : (int)(P.n_in_total / 2) - ss;
+        P.heavy_unit[pos] = unit;
+        P.heavy_win[pos] = w;
+    }
+}
+
 // Fast path, one lane per incoming span.  When the best candidates (list position 0) of a window's spans
 // use pairwise different outgoing spans, "everybody takes position 0" is the selection the canonical search
 // returns: it is the first leaf of the depth-first order (position 0 is tried first and nothing clashes), its
@@ -2002,17 +1855,8 @@ __global__ void __launch_bounds__(kTile) k_select_fast(Dev P) {
             clash = P.tk_idx[tk_index(U, 0, e, first + __ffs((int)rest) - 1)] == mine;
     }
     // the first lane that finds a clash puts the window on the work list of k_select_heavy
-    // Long windows can take a thousand times longer than short ones: they are listed from the front and served
-    // first, the short ones from the back of the same array, so that no long search starts when the kernel is
-    // about to drain.
     const bool listed = clash && atomicExch(&P.w_conf[U.in_off + w], 1) == 0;
-    const bool big = listed && P.w_last[U.in_off + w] - first + 1 >= kBigWindow;
-    const int sb = wave_append(&P.heavy_count[1], big), ss = wave_append(&P.heavy_count[2], listed && !big);
-    if (listed) {
-        const int pos = big ? sb : (int)(P.n_in_total / 2) - ss;
-        P.heavy_unit[pos] = Tl.unit;
-        P.heavy_win[pos] = w;
-    }
+    list_window(P, U, Tl.unit, w, listed);
 }
 
 __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent workgroups, one deferred window at a time
@@ -2052,10 +1896,19 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
 }
 
 // ---------------------------------------------------------------------------------------------
-// Span consumption (traceweaver_v1.py:457-463).  The reference removes the spans chosen by window w
-// before it enumerates window w+1.  Here every window is first solved on the full lists; a window's
-// result is final unless one of its candidate spans was taken by an earlier window.  k_claim /
-// k_detect find those windows, k_repair re-solves them in window order.
+// Span consumption (traceweaver_v1.py:457-463).  The reference removes the spans chosen by window w before it
+// enumerates window w+1: the candidate list of a span is the top-5 over the tuples that avoid every span taken by an
+// EARLIER window, and a window's selection is a function of its spans' lists.  Here every window is first solved on
+// the full lists (which is top_k_2, traceweaver_v3.py:1185, needed anyway); then rounds of
+//     k_claim        owner[x] = smallest window that currently chooses outgoing span x
+//     k_detect_gone  per span: which of its candidate spans belong to an earlier window now?  If that set differs from
+//                    the one its current list was computed with, the span is listed for k_enumerate_heavy (mode 1:
+//                    those spans are not staged) and its window for k_select_heavy
+// run until no set changes.  At that fixed point every window's selection is the one the sequential walk produces:
+// by induction over the windows, window w's set of taken spans is exact once all earlier windows are final, and the
+// first window never changes.  Windows that do not share candidates (perfect cuts) never interact, chains of
+// size-capped windows settle front to back; all flagged windows of all units are re-solved concurrently by the same
+// wavefront kernels as the first solve.
 __global__ void k_claim(Dev P) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
@@ -2067,153 +1920,41 @@ __global__ void k_claim(Dev P) {
     const int w = P.wid[U.in_off + i];
     for (int e = 0; e < U.E; e++) atomicMin(&P.owner[U.ep_off[e] + cand_idx(P, U, i, c, e)], w);
 }
-__global__ void k_detect(Dev P) {
+
+__global__ void __launch_bounds__(kTile) k_detect_gone(Dev P, int round) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
-    if (i >= U.n_in) return;
-    const int w = P.wid[U.in_off + i];
-    bool dirty = false;
-    for (int e = 0; e < U.E && !dirty; e++) {
-        const int64_t b = ie_index(U, e, i);
-        const int lo = P.c_lo[b];
-        for (int wd = 0; wd < kCandWords && !dirty; wd++) {
-            uint64_t bits = P.c_bits[b * kCandWords + wd];
-            while (bits) {
-                const int r = __ffsll((long long)bits) - 1;
-                bits &= bits - 1;
-                if (P.owner[U.ep_off[e] + lo + 64 * wd + r] < w) { dirty = true; break; }
-            }
-        }
-    }
-    if (dirty) {
-        if (!P.w_dirty[U.in_off + w]) { P.w_dirty[U.in_off + w] = 1; atomicAdd(&P.unit_ndirty[Tl.unit], 1); }
-    }
-}
-
-// Is outgoing span x of endpoint e taken by a span of an earlier window (spans < limit)?  A taker j
-// must contain x: in_start[j] <= start(x) and in_end[j] >= end(x); pm_val (prefix max of in_end)
-// bounds the search from below.
-__device__ bool taken_before(const Dev& P, const UnitDev& U, int e, int x, int limit) {
-    const int64_t xs = P.out_start[U.ep_off[e] + x], xe = P.out_end[U.ep_off[e] + x];
-    int jmax = upper_bound_i64(P.in_start + U.in_off, U.n_in, xs) - 1;
-    if (jmax > limit - 1) jmax = limit - 1;
-    const int jmin = lower_bound_i64(P.pm_val + U.in_off, U.n_in, xe);
-    for (int j = jmax; j >= jmin; j--) {
-        const int c = P.chosen[U.in_off + j];
-        if (c >= 0 && cand_idx(P, U, j, c, e) == x) return true;
-    }
-    return false;
-}
-
-template <int E>
-__device__ void repair_span(const Dev& P, const UnitDev& U, int i, int pass, const uint64_t (*gone)[kCandWords]) {
-    Enumerator<E> en(P, U);
-    setup_enumerator<E>(en, P, U, i, pass);
-    en.cutoffs(i);  // same full-list cutoffs as the speculative run: the masks in `gone` are relative to lo[]
-    en.template dfs<true, false>(gone);
-    const int64_t g = U.in_off + i;
-    P.tkr_n[g] = en.nheap;
-    P.leaves[g] = en.leaves;
-#pragma unroll
-    for (int k = 0; k < kTopK; k++) {
-        P.tkr_score[tks_index(U, k, i)] = k < en.nheap ? en.heap[k].score : dnan();
-#pragma unroll
-        for (int e = 0; e < E; e++) P.tkr_idx[tk_index(U, k, e, i)] = k < en.nheap ? en.heap[k].idx[e] : -1;
-    }
-    __threadfence_block();
-    P.rep[g] = 1;
-}
-
-// One workgroup per unit walks the flagged windows in increasing order.  When window w is visited
-// every earlier window is final, so the set of consumed spans it sees is exact.
-__global__ void __launch_bounds__(kCoop) k_repair(Dev P, int pass) {
-    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    __shared__ int next_w;
-    __shared__ int any_gone;
-    __shared__ uint64_t gone[kMaxWin][kMaxEp][kCandWords];
-    __shared__ SelectLds L;
-    const int u = blockIdx.x;
-    const UnitDev& U = P.units[u];
-    if (P.unit_ndirty[u] == 0) return;
-    const int t = threadIdx.x, nt = blockDim.x, nwin = P.unit_nwin[u];
-    int w = 0;
-    int64_t repaired = 0;
-    TW_SEL_DECL();
-    while (true) {
-        // next flagged window >= w
-        __syncthreads();
-        if (t == 0) next_w = nwin;
-        __syncthreads();
-        for (int base = w; base < nwin; base += nt) {
-            const int k = base + t;
-            if (k < nwin && P.w_dirty[U.in_off + k]) atomicMin(&next_w, k);
-            __syncthreads();
-            if (next_w < nwin) break;
-        }
-        __syncthreads();
-        w = next_w;
-        if (w >= nwin) break;
-        const int last = P.w_last[U.in_off + w];
-        const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
-        const int m = last - first + 1;
-        if (m <= 0 || m > kMaxWin) { w++; continue; }
-        // exact consumed masks of the window's spans
-        for (int k = t; k < m * kMaxEp * kCandWords; k += nt) (&gone[0][0][0])[k] = 0;
-        if (t == 0) any_gone = 0;
-        __syncthreads();
-        for (int k = t; k < m * U.E * 64 * kCandWords; k += nt) {
-            const int r = k % (64 * kCandWords), e = (k / (64 * kCandWords)) % U.E, b = k / (64 * kCandWords * U.E);
-            const int64_t ib = ie_index(U, e, first + b);
-            if (!((P.c_bits[ib * kCandWords + (r >> 6)] >> (r & 63)) & 1)) continue;
-            if (taken_before(P, U, e, P.c_lo[ib] + r, first)) {
-                atomicOr((unsigned long long*)&gone[b][e][r >> 6], 1ull << (r & 63));
-                any_gone = 1;
-            }
-        }
-        __syncthreads();
-        if (any_gone) {
-            for (int b = t; b < m; b += nt) {
-                bool hit = false;
-                for (int e = 0; e < U.E; e++) for (int wd = 0; wd < kCandWords; wd++) hit |= gone[b][e][wd] != 0;
-                if (!hit) continue;
-                switch (U.E) {
-                    case 1: repair_span<1>(P, U, first + b, pass, gone[b]); break;
-                    case 2: repair_span<2>(P, U, first + b, pass, gone[b]); break;
-                    case 3: repair_span<3>(P, U, first + b, pass, gone[b]); break;
-                    case 4: repair_span<4>(P, U, first + b, pass, gone[b]); break;
-                    case 5: repair_span<5>(P, U, first + b, pass, gone[b]); break;
-                    case 6: repair_span<6>(P, U, first + b, pass, gone[b]); break;
-                    case 7: repair_span<7>(P, U, first + b, pass, gone[b]); break;
-                    case 8: repair_span<8>(P, U, first + b, pass, gone[b]); break;
+    const bool live = i < U.n_in;
+    const int64_t g = U.in_off + (live ? i : 0);
+    const int w = P.wid[g];
+    bool changed = false, any = false, narrow = true;
+    if (live) {
+        for (int e = 0; e < U.E; e++) {
+            const int64_t b = ie_index(U, e, i);
+            const int lo = P.c_lo[b];
+            narrow &= P.c_hi[b] - lo + 1 <= kNarrow;
+            for (int wd = 0; wd < kCandWords; wd++) {
+                uint64_t bits = P.c_bits[b * kCandWords + wd], gone = 0;
+                while (bits) {
+                    const int r = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    if (P.owner[U.ep_off[e] + lo + 64 * wd + r] < w) gone |= 1ull << r;
                 }
+                if (gone != P.gone[b * kCandWords + wd]) { P.gone[b * kCandWords + wd] = gone; changed = true; }
+                any |= gone != 0;
             }
-            __threadfence();
-            __syncthreads();
-            select_window_coop(P, U, u, first, m, L TW_SEL_PASS);
-            if (t == 0) repaired++;
-            __threadfence();
-            __syncthreads();
-            // later windows that hold a span chosen here must be re-examined
-            for (int k = t; k < m * U.E; k += nt) {
-                const int b = k / U.E, e = k % U.E, c = P.chosen[U.in_off + first + b];
-                if (c < 0) continue;
-                const int x = cand_idx(P, U, first + b, c, e);
-                const int64_t xs = P.out_start[U.ep_off[e] + x];
-                const int jmax = upper_bound_i64(P.in_start + U.in_off, U.n_in, xs) - 1;
-                for (int j = last + 1; j <= jmax; j++) {
-                    const int64_t ij = ie_index(U, e, j);
-                    const int r = x - P.c_lo[ij];
-                    if (r < 0 || r >= 64 * kCandWords) continue;
-                    if ((P.c_bits[ij * kCandWords + (r >> 6)] >> (r & 63)) & 1) P.w_dirty[U.in_off + P.wid[U.in_off + j]] = 1;
-                }
-            }
-            __threadfence();
         }
-        w++;
+        if (changed && !any) P.rep[g] = 0;   // nothing of this span is taken any more: its list on all spans is its list again
+        if (changed) P.w_dirty[U.in_off + w] = 1;
     }
-    if (t == 0) P.unit_stats[(int64_t)u * 8 + 3] = repaired;
+    heavy_append_rt(P, U.E, changed && any, narrow, Tl.unit, i);
+    // the first lane of a window that sees a change lists the window for k_select_heavy (stamp = round: no reset between rounds)
+    const bool listed = changed && atomicExch(&P.w_conf[U.in_off + w], round + 2) != round + 2;
+    list_window(P, U, Tl.unit, w, listed);
+    const unsigned long long m = __ballot(changed);
+    if (m != 0 && (threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(P.round_changed, __popcll(m));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2224,6 +1965,8 @@ __global__ void k_finalize(Dev P) {
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
     const int c = P.chosen[U.in_off + i];
+    if (P.rep[U.in_off + i]) P.leaves[U.in_off + i] = P.leaves_r[U.in_off + i];   // tuples of the top_k call on the remaining spans
+    if (P.win_end[U.in_off + i] && P.w_dirty[U.in_off + P.wid[U.in_off + i]]) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 8 + 3], 1ull);
     for (int e = 0; e < U.E; e++) P.parent[ie_index(U, e, i)] = c >= 0 ? cand_idx(P, U, i, c, e) : -1;
     if (c != 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 8 + 0], 1ull);  // traceweaver_v3.py:1201-1207
     if (c < 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 8 + 1], 1ull);   // traceweaver_v3.py:1217
