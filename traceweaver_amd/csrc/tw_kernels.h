@@ -753,14 +753,15 @@ struct LdsHeap {
 //     A term is evaluated once per candidate (pair) instead of once per tuple -- with mixtures (pass 2) a term is
 //     ~1.5k instructions and an 8-endpoint tuple has up to 9 of them.  The tuple score adds the same doubles in the
 //     same order as the reference, so it is bit-identical.
-constexpr int kPairPoolPerEp = 160;   // doubles of pair-term tables per endpoint count (E = 8: 10 KB)
+constexpr int kPairPoolPerEp = 160;   // doubles of pair-term tables per endpoint (E <= 4); 2048 doubles (16 KB) for the deep call graphs
+constexpr int kGridTarget = 1024;     // grid points per prefix the split of the endpoints aims at (a prefix step costs about as much as five grid batches)
 template <int E, int W>
 __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass, int mode) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     static_assert(W == kNarrow || W == 64 * kCandWords, "one instantiation per half of the work list");
     constexpr bool kWide = W != kNarrow;
     constexpr int kList = kWide ? kMaxEp + 1 + E : E;
-    constexpr int kPool = E > 1 ? kPairPoolPerEp * E : 1;
+    constexpr int kPool = E > 4 ? 2048 : (E > 1 ? kPairPoolPerEp * E : 1);
     __shared__ unsigned long long sbits[kMaxEp][kCandWords];
     __shared__ int64_t ls[E][W], le[E][W];      // staged candidates: start / end
     __shared__ double troot[E][W], tclose[E][W];
@@ -916,12 +917,17 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         for (int k = 0; k < kTopK; k++) { ts[k] = -dinf(); tslot[k] = k; }
         // Split the endpoints at L: levels 0..L-1 are walked together (every lane the same prefix), the
         // tuples of levels L..E-1 -- a grid of G = prod cn_e points, in enumeration order -- are spread over
-        // the lanes.  L is the deepest split that still gives the lanes a full wavefront of grid points.
+        // the lanes.  L is the deepest split that gives a prefix about kGridTarget grid points (< kGridTarget * 128).
         int L = E - 1;
-        int G = cn[E - 1];  // < 64 * 128: the grid stops growing once it fills the wavefront
+        int G = cn[E - 1];
 #pragma unroll
         for (int e = E - 2; e >= 0; e--)
-            if (L == e + 1 && G < kHeavyThreads) { L = e; G *= cn[e]; }
+            if (L == e + 1 && G * cn[e] <= kGridTarget * 2 && G < kGridTarget) { L = e; G *= cn[e]; }
+        if (G < kHeavyThreads) {   // at least a wavefront of grid points whenever the product allows it
+#pragma unroll
+            for (int e = E - 2; e >= 0; e--)
+                if (L == e + 1 && G < kHeavyThreads) { L = e; G *= cn[e]; }
+        }
         // grid point -> staged positions of the levels L..E-1, last endpoint fastest: divisions by the wave-uniform
         // counts as multiplications (exact for g * (c - 1) < 2^32)
         uint32_t magic[E];
@@ -1408,7 +1414,12 @@ __device__ inline bool cands_share(const Dev& P, const UnitDev& U, int i, int a,
 // when the search returns to a level -- and share only the best weight found so far.  A lane cuts a node
 // when acc + bound <= its own incumbent (an earlier leaf of an earlier or the same sub-tree: ties go to the
 // earlier leaf, as in the sequential search) or when acc + bound < the shared best weight (strictly: a tie
-// with a later sub-tree must survive).  The winner is the largest weight, the smallest sub-tree among equal
+// with a later sub-tree must survive).  Bounds: the grouped bound of the suffix, and a transposition table -- once
+// the sub-tree below a node has been searched, (best weight known then) - (weight above the node) bounds what any
+// other way of reaching the same (depth, blocked candidates of the remaining spans) can still gain; assignments of
+// the spans above that merely permute who took which outgoing span all meet in that one entry (on the test
+// workloads: 4.2e6 -> 1.9e3 nodes for the largest component of the nodejs shape, 8.3e8 -> 2.7e5 on the tie-saturated
+// stress set).  The winner is the largest weight, the smallest sub-tree among equal
 // weights.  A lane that visits more than kNodeBudget / lanes nodes on one component stops; the window then keeps the
 // best selection found and is counted in unit_stats[4] (not proven optimal).
 typedef long long sel_w;
@@ -1418,6 +1429,7 @@ constexpr int kBlkWords = (kMaxWin * kTopK + 63) / 64;  // words of a mask over 
 constexpr int kBigWindow = 8;        // windows of at least this many spans are served first by k_select_heavy
 constexpr int kBruteMax = 4;         // components of up to this many spans are solved by complete enumeration (see select_brute)
 constexpr int kStackWords = (kMaxWin + 9) / 10;  // search stack: 3 bits per level, 10 levels per 32-bit word
+constexpr int kMemoSlots = 256;      // transposition table entries (LDS); a table of 2^20 entries prunes no better on the test workloads
 constexpr int kPrefixMax = 10;       // levels above the sub-trees: 4 x 256 sub-trees are reached after <= 10 levels of >= 2 choices
 
 // ---- cooperative path: one workgroup per window --------------------------------------------------
@@ -1435,6 +1447,12 @@ struct SelectLds {
     // select_search: conflicts of candidate k of member x with the candidates of the other members as a bit
     // mask over (member y, candidate k2) -> bit y*kTopK+k2
     unsigned long long cmask3[kMaxWin][kTopK][kBlkWords];
+    // transposition table of select_search: what can still be gained below a node depends only on its depth and on which
+    // candidates of the remaining spans are blocked, not on how the spans above were assigned
+    unsigned long long mkey[kMemoSlots][kBlkWords];
+    sel_w mval[kMemoSlots];
+    unsigned int mstate[kMemoSlots];   // generation << 2 | (0 empty, 1 being written, 2 valid)
+    unsigned int memo_gen;
     unsigned long long gbest;       // the best weight any lane has found (weights are > 0)
     unsigned long long win_key;     // reduction of the lanes' results
     uint32_t win_stack[kStackWords];
@@ -1471,9 +1489,22 @@ __device__ void select_search(SelectLds& L) {
         int D = 0, P = 1;
         while (D < cm - 1 && D < kPrefixMax && P < 4 * nt) { P *= (int)L.ncand[L.mem[D]] + 1; D++; }
         L.depth0 = D; L.n_sub = P; L.next_sub = 0; L.gbest = 0ull; L.win_key = 0ull; L.win_sub = -1;
+        L.memo_gen++;   // entries of earlier components become stale without a sweep (memo_gen is reset with the states when it wraps)
+        if ((L.memo_gen & 0x3fffffffu) == 0u) { L.memo_gen = 1u; for (int q = 0; q < kMemoSlots; q++) L.mstate[q] = 0u; }
     }
     group_sync();
     const int D = L.depth0, P = L.n_sub;
+    const unsigned int tag_busy = (L.memo_gen << 2) | 1u, tag_ready = (L.memo_gen << 2) | 2u;
+    // key of a node: the blocked candidates of the spans d.. (bits below d * kTopK cleared) with the depth in the low bits
+    auto memo_key = [&](int d, unsigned long long b0, unsigned long long b1, unsigned long long b2, unsigned long long (&k)[kBlkWords]) -> unsigned {
+        const int bit = d * kTopK, wd = bit >> 6;
+        const unsigned long long keep = ~0ull << (bit & 63);
+        k[0] = wd == 0 ? (b0 & keep) : 0ull; k[1] = wd == 1 ? (b1 & keep) : (wd < 1 ? b1 : 0ull); k[2] = wd == 2 ? (b2 & keep) : (wd < 2 ? b2 : 0ull);
+        k[0] |= (unsigned long long)d;   // d >= 1: bits 0..4 belong to the first span and are clear
+        unsigned long long h = (k[0] * 0x9E3779B97F4A7C15ull) ^ (k[1] * 0xC2B2AE3D27D4EB4Full) ^ (k[2] * 0x165667B19E3779F9ull);
+        h ^= h >> 29;
+        return (unsigned)h & (kMemoSlots - 1);
+    };
     sel_w own_w = 0;              // incumbent of this lane: only strict improvements replace it
     int own_sub = -1;
     uint32_t own_st[kStackWords], st[kStackWords];
@@ -1528,6 +1559,21 @@ __device__ void select_search(SelectLds& L) {
                 } else {
                     const sel_w bound = acc + L.ub[d];
                     if (bound <= own_w || bound < (sel_w)L.gbest) up = true;
+                    else if (d >= 1) {   // has the sub-tree below this (depth, blocked set) been searched already?
+                        unsigned long long k[kBlkWords];
+                        const unsigned slot = memo_key(d, b0, b1, b2, k);
+                        for (int pr = 0; pr < 4; pr++) {
+                            const unsigned sl = (slot + pr) & (kMemoSlots - 1);
+                            const unsigned st = ((volatile unsigned int*)L.mstate)[sl];
+                            if ((st >> 2) != (tag_ready >> 2) || (st & 3u) == 0u) break;   // empty: the chain ends here
+                            if (st != tag_ready) continue;
+                            if (L.mkey[sl][0] == k[0] && L.mkey[sl][1] == k[1] && L.mkey[sl][2] == k[2]) {
+                                const sel_w mb = acc + L.mval[sl];
+                                if (mb <= own_w || mb < (sel_w)L.gbest) up = true;
+                                break;
+                            }
+                        }
+                    }
                 }
             } else {
                 k = stack_get(st, d) + 1;   // resume below the choice this level made last
@@ -1548,6 +1594,25 @@ __device__ void select_search(SelectLds& L) {
                 }
                 if (found) { stack_set(st, d, k); d++; entered = true; continue; }
                 up = true;
+                if (d >= 1) {   // every way on from this node has been searched: remember what it can gain at most
+                    unsigned long long kk[kBlkWords];
+                    const unsigned slot = memo_key(d, b0, b1, b2, kk);
+                    const sel_w gb = (sel_w)L.gbest;
+                    const sel_w val = (own_w > gb ? own_w : gb) - acc;
+                    for (int pr = 0; pr < 4; pr++) {
+                        const unsigned sl = (slot + pr) & (kMemoSlots - 1);
+                        const unsigned st0 = ((volatile unsigned int*)L.mstate)[sl];
+                        if ((st0 >> 2) == (tag_ready >> 2) && (st0 & 3u) != 0u) {   // taken: the same node already? then done
+                            if (st0 == tag_ready && L.mkey[sl][0] == kk[0] && L.mkey[sl][1] == kk[1] && L.mkey[sl][2] == kk[2]) break;
+                            continue;
+                        }
+                        if (atomicCAS(&L.mstate[sl], st0, tag_busy) != st0) continue;   // another lane took the slot just now
+                        L.mkey[sl][0] = kk[0]; L.mkey[sl][1] = kk[1]; L.mkey[sl][2] = kk[2]; L.mval[sl] = val;
+                        __threadfence_block();
+                        atomicExch(&L.mstate[sl], tag_ready);
+                        break;
+                    }
+                }
             }
             // return to the level above: its weight and blocked set are rebuilt from the stack
             d--;
@@ -1864,14 +1929,23 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
     __shared__ SelectLds L;
     __shared__ int next_item;
     const int n_big = P.heavy_count[1], count = n_big + P.heavy_count[2];
+    if ((int)blockIdx.x * kWorkChunk >= count) return;   // nothing for this workgroup (the usual case outside heavy load)
+    for (int q = threadIdx.x; q < kMemoSlots; q += blockDim.x) L.mstate[q] = 0u;
+    if (threadIdx.x == 0) L.memo_gen = 0u;
+    group_sync();
     int chunk_pos = 0, chunk_end = 0;
+    bool first_chunk = true;
     TW_SEL_DECL();
     while (true) {
-        if (chunk_pos == chunk_end) {  // dynamic distribution (search effort varies by orders of magnitude), kWorkChunk windows per atomic
-            if (threadIdx.x == 0) next_item = atomicAdd(P.heavy_next, kWorkChunk);
-            group_sync();
-            chunk_pos = next_item;
-            group_sync();
+        if (chunk_pos == chunk_end) {  // dynamic distribution (search effort varies by orders of magnitude), kWorkChunk windows per atomic;
+                                       // the first chunk of a workgroup is its own (no same-address atomic storm at kernel start)
+            if (first_chunk) { chunk_pos = (int)blockIdx.x * kWorkChunk; first_chunk = false; }
+            else {
+                if (threadIdx.x == 0) next_item = (int)gridDim.x * kWorkChunk + atomicAdd(P.heavy_next, kWorkChunk);
+                group_sync();
+                chunk_pos = next_item;
+                group_sync();
+            }
             chunk_end = chunk_pos + kWorkChunk < count ? chunk_pos + kWorkChunk : count;
             if (chunk_pos >= count) { TW_SEL_FLUSH(); break; }
         }
