@@ -980,3 +980,239 @@ int two_gaps(const two_service *s, const int32_t *parent, double *gaps, int32_t 
     }
     return 0;
 }
+
+/* ================================================================== skip mode (exps/exp2)
+ * One pass of TraceWeaverV3.FindAssignments when some endpoint holds fewer outgoing spans than there are incoming
+ * spans (V3:972,1141-1158: `iterations = 1`, `dynamism = True`): every endpoint list ends in a sentinel that stands for
+ * "this request did not call the endpoint" (V3:231-234,321-324); reaching it draws the least-used skip span of the
+ * request's time window (FetchSkipFromWindow V3:820-842), i.e. the skip spans of a window are handed out round robin,
+ * one draw per partial tuple that reaches the sentinel; scores are means of normal *densities* over the scored edges
+ * (V1:133-136,359-360) with (mean, std) from BuildDistributions (V3:108-172), a skipped predecessor being replaced
+ * by the latest of its own non-skipped predecessors, or by the incoming span (V1:264-292,331-343); two candidates that
+ * hold the same skip span at an endpoint conflict (V3:1276-1281); skip spans are never consumed (V1:460-462).
+ *
+ * The executor hands the predictor lists that are no longer sorted after create_cache_hits moved spans in place
+ * (helpers/transforms.py:169-176): windows (two_windows above) and the top_k enumeration walk them as they are; the
+ * top_k_2 enumeration (V3:1185) walks the lists TallySkipSpans has sorted by start in the meantime (V3:968-971):
+ * sorted_perm.  With dynamism the reference scans whole lists (V3:316-320); containment selects the same spans.
+ *
+ * Skip spans are encoded as idx = -(TWO_SKIP_BASE + time_window * TWO_SKIP_STRIDE + position in the window's pool).
+ * Returns 0, or: -3 sizes, -4 window too long, -6 the reference raises here (a tuple that skips every endpoint, H7
+ * V1:261-262; a score tie whose comparison reaches a skip span: str < int; a skipped predecessor all of whose own
+ * predecessors are skipped: max() of a nested list V1:338), -7 a (mean, std) pair the scorer needs is absent (KeyError). */
+#define TWO_SKIP_BASE 1024
+#define TWO_SKIP_STRIDE 128
+typedef struct {
+    const int32_t *sorted_perm; /* [out_off[E]] per endpoint: list position of the k-th span in start order (stable) */
+    int32_t n_tw;
+    const int64_t *tw_start;    /* [n_tw] time windows in start order (V3:976-987) */
+    const int32_t *pool;        /* [E][n_tw] skip spans per (endpoint, time window) (V3:862-916) */
+    const double *dist;         /* [(E+1)][(E+1)][2] mean, std; NaN = no such key; index 0 = the incoming endpoint */
+} two_skip;
+
+typedef struct {
+    const two_service *s; const two_skip *k; const two_graph *g;
+    const uint8_t *const *consumed;   /* NULL entries: nothing consumed */
+    int sorted, count;
+    int wi;                           /* time window of the incoming span */
+    int64_t *fetches;                 /* [E][n_tw] draws so far */
+    int64_t in_start, in_end, leaves;
+    int32_t x[TWO_MAX_E];
+    two_cand heap[TWO_MAX_K + 1]; int nheap, K, err;
+} skip_ctx;
+
+static const double SQRT_2PI = 0x1.40d931ff62706p+1; /* np.sqrt(2*np.pi) */
+static double skip_term(skip_ctx *c, int a, int b, int64_t t1, int64_t t2) { /* GetEpPairCost(normalized=True) V1:117-139 */
+    int E1 = c->s->E + 1;
+    double mean = c->k->dist[((size_t)a * E1 + b) * 2], std = c->k->dist[((size_t)a * E1 + b) * 2 + 1];
+    if (mean != mean) { c->err = -7; return 0.0; }
+    if (std < 1.0e-12) std = 0.001;
+    double y = ((double)(t2 - t1) - mean) / std;
+    return (two_exp(-(y * y) / 2.0) / SQRT_2PI) / std; /* scipy.stats.norm.pdf */
+}
+static int is_skip(int32_t x) { return x <= -TWO_SKIP_BASE; }
+
+/* V1:259-361 with normalized=True */
+static double skip_score(skip_ctx *c) {
+    const two_service *s = c->s; const two_graph *g = c->g;
+    int E = s->E, last = -1, nmap = 0;
+    int64_t last_end = 0;
+    for (int e = 0; e < E; e++) { /* max() over the non-skipped spans keeps the first maximum V1:314 */
+        if (is_skip(c->x[e])) continue;
+        int64_t en = oend(s, e, c->x[e]);
+        if (last < 0 || en > last_end) { last_end = en; last = e; }
+    }
+    if (last < 0) { c->err = -6; return 0.0; } /* AllSkip2: the reference returns a bare 0 and the caller unpacks it (H7) */
+    double cost = 0.0;
+    for (int e = 0; e < E; e++) {
+        if (is_skip(c->x[e])) continue;
+        int64_t st = ostart(s, e, c->x[e]);
+        for (int j = 0; j < g->npred[e]; j++) {
+            if (!g->prim[e][j]) continue;
+            int b = g->pred[e][j];
+            if (is_skip(c->x[b])) {
+                if (g->npred[b] == 0) { cost += skip_term(c, 0, 1 + e, c->in_start, st); nmap++; continue; } /* FindValidAncestor -> None */
+                int lat = -1; int64_t lat_end = 0;
+                for (int q = 0; q < g->npred[b]; q++) {
+                    int a = g->pred[b][q];
+                    if (is_skip(c->x[a])) continue;
+                    int64_t en = oend(s, a, c->x[a]);
+                    if (lat < 0 || en > lat_end) { lat_end = en; lat = a; }
+                }
+                if (lat < 0) { c->err = -6; return 0.0; }
+                cost += skip_term(c, 1 + lat, 1 + e, ostart(s, lat, c->x[lat]), st); nmap++; /* latest[1].start_mus V1:340 */
+                continue;
+            }
+            cost += skip_term(c, 1 + b, 1 + e, oend(s, b, c->x[b]), st); nmap++;
+        }
+        if (g->npred[e] == 0) { cost += skip_term(c, 0, 1 + e, c->in_start, st); nmap++; }
+        if (e == last) { cost += skip_term(c, 1 + e, 0, oend(s, e, c->x[e]), c->in_end); nmap++; }
+    }
+    return cost / (double)nmap;
+}
+
+/* (score, [spans]) order with skip spans: the comparison of two different skip spans is str < str on "None" (neither
+ * less); a skip span against a real one raises in the reference */
+static int skip_lt(skip_ctx *c, const two_cand *a, const two_cand *b) {
+    if (a->score != b->score) return a->score < b->score;
+    for (int e = 0; e < c->s->E; e++)
+        if (a->idx[e] != b->idx[e]) {
+            int sa = is_skip(a->idx[e]), sb = is_skip(b->idx[e]);
+            if (sa && sb) return 0;
+            if (sa || sb) { c->err = -6; return 0; }
+            return ostart(c->s, e, a->idx[e]) < ostart(c->s, e, b->idx[e]);
+        }
+    return 0;
+}
+static void skip_siftdown(skip_ctx *c, two_cand *h, int startpos, int pos) {
+    two_cand item = h[pos];
+    while (pos > startpos) { int parent = (pos - 1) >> 1; if (skip_lt(c, &item, &h[parent])) { h[pos] = h[parent]; pos = parent; continue; } break; }
+    h[pos] = item;
+}
+static void skip_siftup(skip_ctx *c, two_cand *h, int n, int pos) {
+    int startpos = pos, child = 2 * pos + 1;
+    two_cand item = h[pos];
+    while (child < n) { int right = child + 1; if (right < n && !skip_lt(c, &h[child], &h[right])) child = right; h[pos] = h[child]; pos = child; child = 2 * pos + 1; }
+    h[pos] = item;
+    skip_siftdown(c, h, startpos, pos);
+}
+static void skip_push(skip_ctx *c, const two_cand *cand) {
+    c->heap[c->nheap++] = *cand;
+    skip_siftdown(c, c->heap, 0, c->nheap - 1);
+    if (c->nheap > c->K) { two_cand last = c->heap[--c->nheap]; if (c->nheap > 0) { c->heap[0] = last; skip_siftup(c, c->heap, c->nheap, 0); } }
+}
+static void skip_sort_desc(skip_ctx *c, two_cand *a, int n) { /* list.sort(reverse=True), n < 64 */
+    if (n < 2) return;
+    rev(a, n);
+    int run = 2, descending = 0;
+    if (skip_lt(c, &a[1], &a[0])) { descending = 1; for (int i = 2; i < n; i++, run++) if (!skip_lt(c, &a[i], &a[i - 1])) break; }
+    else { for (int i = 2; i < n; i++, run++) if (skip_lt(c, &a[i], &a[i - 1])) break; }
+    if (descending) rev(a, run);
+    for (int start = run; start < n; start++) {
+        int l = 0, r = start; two_cand pivot = a[start];
+        do { int p = l + ((r - l) >> 1); if (skip_lt(c, &pivot, &a[p])) r = p; else l = p + 1; } while (l < r);
+        for (int p = start; p > l; p--) a[p] = a[p - 1];
+        a[l] = pivot;
+    }
+    rev(a, n);
+}
+
+/* DfsTraverseX V3:292-351 with the sentinel branch */
+static void skip_dfs(skip_ctx *c, int e) {
+    const two_service *s = c->s;
+    int E = s->E;
+    if (c->err) return;
+    if (e == E) {
+        if (c->count) c->leaves++;
+        two_cand cand;
+        cand.score = skip_score(c);
+        for (int q = 0; q < E; q++) cand.idx[q] = c->x[q];
+        for (int q = E; q < TWO_MAX_E; q++) cand.idx[q] = -1;
+        skip_push(c, &cand);
+        return;
+    }
+    int64_t m = n_out(s, e);
+    for (int64_t pos = 0; pos < m; pos++) {
+        int64_t x = c->sorted ? c->k->sorted_perm[s->out_off[e] + pos] : pos;
+        if (c->consumed && c->consumed[e] && c->consumed[e][x]) continue;
+        int64_t st = ostart(s, e, x);
+        if (c->in_start > st || oend(s, e, x) > c->in_end) continue;
+        int ok = 1;
+        for (int p = 0; p < e && ok; p++)
+            if (s->dag[p * E + e] && !is_skip(c->x[p]) && oend(s, p, c->x[p]) > st) ok = 0;
+        if (!ok) continue;
+        c->x[e] = (int32_t)x;
+        skip_dfs(c, e + 1);
+    }
+    int32_t pool = c->k->pool[(size_t)e * c->k->n_tw + c->wi];
+    if (pool > 0) { /* FetchSkipFromWindow: least-used first == round robin */
+        int64_t *f = &c->fetches[(size_t)e * c->k->n_tw + c->wi];
+        int pos = (int)(*f % pool);
+        (*f)++;
+        c->x[e] = -(TWO_SKIP_BASE + c->wi * TWO_SKIP_STRIDE + pos);
+        skip_dfs(c, e + 1);
+    }
+}
+
+int two_run_skip(const two_service *s, const two_skip *k, const uint8_t *end_flag, int32_t *topk_n, int32_t *topk_idx, double *topk_score,
+                 int32_t *topk2_n, int32_t *topk2_idx, double *topk2_score, int64_t *leaves, int32_t *chosen, int32_t *parent, int64_t *stats) {
+    int n = s->n_in, E = s->E, K = s->topk;
+    if (E > TWO_MAX_E || K > TWO_MAX_K) return -3;
+    for (int e = 0; e < E; e++) for (int w = 0; w < k->n_tw; w++) if (k->pool[(size_t)e * k->n_tw + w] > TWO_SKIP_STRIDE) return -3;
+    g_time_scale = 1.0;
+    two_graph g; build_graph(s, &g);
+    uint8_t *consumed[TWO_MAX_E];
+    for (int e = 0; e < TWO_MAX_E; e++) consumed[e] = NULL;
+    for (int e = 0; e < E; e++) consumed[e] = (uint8_t *)calloc((size_t)n_out(s, e) + 1, 1);
+    int64_t *fetches = (int64_t *)calloc((size_t)E * (size_t)k->n_tw, sizeof(int64_t));
+    static two_cand batch[TWO_MAX_WIN][TWO_MAX_K];
+    int batch_n[TWO_MAX_WIN], batch_i[TWO_MAX_WIN], nbatch = 0, rc = 0;
+    stats[0] = stats[1] = stats[2] = stats[3] = stats[4] = 0;
+    for (int i = 0; i < E * n; i++) parent[i] = -1;
+    for (int i = 0; i < n && rc == 0; i++) {
+        if (nbatch >= TWO_MAX_WIN) { rc = -4; break; }
+        skip_ctx c; memset(&c, 0, sizeof(c));
+        c.s = s; c.k = k; c.g = &g; c.fetches = fetches; c.in_start = s->in_start[i]; c.in_end = s->in_end[i]; c.K = K;
+        { /* FindWindow V3:827-832: the window with the largest start <= key, first one of equal starts */
+            int64_t best = INT64_MIN; int wi = -1;
+            for (int w = 0; w < k->n_tw; w++) if (k->tw_start[w] <= c.in_start && k->tw_start[w] > best) { best = k->tw_start[w]; wi = w; }
+            if (wi < 0) { rc = -6; break; }
+            c.wi = wi;
+        }
+        for (int call = 0; call < 2 && rc == 0; call++) {
+            c.sorted = call; c.count = !call; c.consumed = call ? NULL : (const uint8_t *const *)consumed;
+            c.nheap = 0; c.leaves = 0; c.err = 0;
+            skip_dfs(&c, 0);
+            if (!c.err) skip_sort_desc(&c, c.heap, c.nheap);
+            if (c.err) { rc = c.err; break; }
+            int32_t *on = call ? topk2_n : topk_n, *oi = call ? topk2_idx : topk_idx; double *os_ = call ? topk2_score : topk_score;
+            on[i] = c.nheap;
+            for (int q = 0; q < K; q++) {
+                os_[(size_t)i * K + q] = q < c.nheap ? c.heap[q].score : NAN;
+                for (int e = 0; e < E; e++) oi[((size_t)i * K + q) * E + e] = q < c.nheap ? c.heap[q].idx[e] : -1;
+            }
+            if (!call) { leaves[i] = c.leaves; memcpy(batch[nbatch], c.heap, sizeof(two_cand) * (size_t)c.nheap); batch_n[nbatch] = c.nheap; batch_i[nbatch] = i; }
+        }
+        if (rc) break;
+        nbatch++;
+        if (end_flag[i]) {
+            int pick[TWO_MAX_WIN], hit = 0;
+            stats[2] += mwis_window(s, nbatch, batch_n, batch, pick, &hit); stats[4] += hit; stats[3] += 1;
+            for (int b = 0; b < nbatch; b++) {
+                int ii = batch_i[b];
+                chosen[ii] = pick[b];
+                if (batch_n[b] < 1 || pick[b] < 0) stats[0] += 1; else if (pick[b] != 0) stats[0] += 1;
+                if (pick[b] < 0) { stats[1] += 1; continue; }
+                for (int e = 0; e < E; e++) {
+                    int32_t x = batch[b][pick[b]].idx[e];
+                    parent[(size_t)e * n + ii] = is_skip(x) ? -2 : x;
+                    if (!is_skip(x)) consumed[e][x] = 1;   /* V1:460-462: skip spans stay */
+                }
+            }
+            nbatch = 0;
+        }
+    }
+    for (int e = 0; e < E; e++) free(consumed[e]);
+    free(fetches);
+    return rc;
+}

@@ -236,3 +236,154 @@ def service_from_golden(d):
 def golden_key_rank(d):
     order = [str(x) for x in d["partition_key_order"]]
     return np.array([order.index(str(e)) for e in d["out_eps"]], dtype=np.int32)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# skip mode (exps/exp2): TallySkipSpans / WaterFill (traceweaver_v3.py:853-989), BuildDistributions (:108-172), one pass
+# with skip spans (two_run_skip in tw_oracle.c).  Literal restatements on index arrays.
+SKIP_BASE, SKIP_STRIDE = 1024, 128
+
+
+class _Skip(ctypes.Structure):
+    _fields_ = [("sorted_perm", ctypes.c_void_p), ("n_tw", ctypes.c_int32), ("tw_start", ctypes.c_void_p), ("pool", ctypes.c_void_p),
+                ("dist", ctypes.c_void_p)]
+
+
+def tally_skip_spans(svc, prior_windows=()):
+    """traceweaver_v3.py:853-989.  Returns (time windows [(start, end, expected)] sorted by start, skip budget [E],
+    skip spans per (endpoint, window) [E, n_windows]).  `prior_windows`: what self.time_windows already held (the
+    reference never clears it between services, hazard H8)."""
+    n, E, B = svc.n_in, svc.E, svc.c.batch_size_mis
+    tw = list(prior_windows)
+    window_start = int(svc.in_start[0])
+    final_end = int(np.max(svc.in_end))
+    for i in range(n):                                              # :976-987
+        if i != 0 and i != n - 1 and i % B == 0:
+            window_end = int(svc.in_end[i])
+            tw.append((window_start, window_end, B))
+            window_start = window_end
+        elif i == n - 1:
+            tw.append((window_start, final_end, B))
+    budget = np.array([n - int(svc.out_off[e + 1] - svc.out_off[e]) for e in range(E)], dtype=np.int64)    # :972
+    keys = sorted(tw, key=lambda x: x[0])                          # WaterFill's window_keys (stable)
+    pool = np.zeros((E, len(tw)), dtype=np.int32)
+    for e in range(E):                                              # TackleMismatch :918-962
+        st = svc.out_start[svc.out_off[e]:svc.out_off[e + 1]]
+        counts = {}
+        for (a, b, _) in tw:
+            counts[(a, b)] = int(((st > a) & (st <= b)).sum())
+        alloc = {k[:2]: 0 for k in tw}
+        skip_budget = int(budget[e])
+        if skip_budget > 0:                                         # WaterFill :862-916
+            nw = len(counts)                                        # len(window_diffs): distinct (start, end) keys
+            index_to_key = {i: k[:2] for i, k in enumerate(keys)}
+            existing = np.zeros(nw)
+            expected = np.zeros(nw)
+            for i in range(nw):
+                existing[i] = counts[index_to_key[i]]
+                expected[i] = keys[i][2]
+            order = np.argsort(existing)[::-1]
+            sorted_existing = existing[order]
+            alloc_v = np.zeros(nw)
+            lam, total_remaining = 0, 0
+            for i in range(nw):
+                lam = (skip_budget + np.sum(sorted_existing[:i + 1])) // (i + 1)
+                total_remaining = (skip_budget + np.sum(sorted_existing[:i + 1])) % (i + 1)
+                if lam <= sorted_existing[i]:
+                    break
+            remaining = 0
+            for i in range(nw):
+                want = max(lam - sorted_existing[i], 0)
+                give = min(want, expected[i] - sorted_existing[i])
+                remaining += want - give
+                alloc_v[order[i]] = give
+            total_remaining += remaining
+            while total_remaining > 0:
+                no_change = True
+                for i in reversed(range(nw)):
+                    if total_remaining > 0 and alloc_v[order[i]] < (expected[i] - sorted_existing[i]):
+                        alloc_v[order[i]] += 1
+                        no_change = False
+                        total_remaining -= 1
+                if no_change:
+                    break
+            for i in range(nw):
+                alloc[index_to_key[i]] = alloc_v[i]
+        for w, k in enumerate(keys):
+            pool[e, w] = max(int(alloc[k[:2]]), 0)       # range(int(negative)) is empty (:950)
+    return keys, budget, pool
+
+
+def build_distributions(svc):
+    """traceweaver_v3.py:108-172: merged time-ordered sweep; every span looks back (no further than the longest request)
+    for its nearest qualifying predecessor and contributes one delay sample to the pair (predecessor's endpoint, own
+    endpoint).  Returns [(E+1), (E+1), 2] (np.mean, np.std), NaN where no sample; index 0 = the incoming endpoint."""
+    E, n = svc.E, svc.n_in
+    rows = [(int(svc.in_start[i]), int(svc.in_end[i] - svc.in_start[i]), 0, True) for i in range(n)]
+    for e in range(E):
+        for x in range(int(svc.out_off[e]), int(svc.out_off[e + 1])):
+            rows.append((int(svc.out_start[x]), int(svc.out_end[x] - svc.out_start[x]), 1 + e, False))
+    rows.sort(key=lambda r: r[0])                                   # list.sort is stable: ties keep [in, ep 0, ep 1, ...] order
+    large = max(int(svc.in_end[i] - svc.in_start[i]) for i in range(n))
+    samples = {}
+    for i, (st, du, ep, server) in enumerate(rows):
+        if not server:                                              # client span :125-150
+            par, ptype = None, None
+            for j in range(i - 1, -1, -1):
+                p = rows[j]
+                if (st + du) - p[0] > large:
+                    break
+                if p[3]:
+                    par, ptype = p, "server"
+                    break
+                if (not p[3]) and p[0] + p[1] < st and p[2] < ep:   # out_ep_order == endpoint index (topological order)
+                    par, ptype = p, "client"
+                    break
+            if par is not None:
+                samples.setdefault((par[2], ep), []).append(st - par[0] if ptype == "server" else st - (par[0] + par[1]))
+        else:                                                       # server span :152-169
+            par = None
+            for j in range(i - 1, -1, -1):
+                p = rows[j]
+                if (st + du) - p[0] > large:
+                    break
+                if (not p[3]) and p[0] + p[1] < st + du:
+                    par = p
+                    break
+            if par is not None:
+                samples.setdefault((par[2], ep), []).append((st + du) - (par[0] + par[1]))
+            samples.setdefault((ep, ep), []).append(du)
+    tab = np.full((E + 1, E + 1, 2), np.nan)
+    for (a, b), v in samples.items():
+        tab[a, b] = (np.mean(v), np.std(v))
+    return tab, large
+
+
+def run_skip(svc, end_flag, keys, pool, dist):
+    """One pass with skip spans (two_run_skip).  Candidate indices: >= 0 a span (position in the list as handed over),
+    <= -SKIP_BASE a skip span -(SKIP_BASE + window * SKIP_STRIDE + position in the window's pool); parent: -2 skip."""
+    n, E, K = svc.n_in, svc.E, svc.topk
+    perm = np.concatenate([np.argsort(svc.out_start[svc.out_off[e]:svc.out_off[e + 1]], kind="stable") for e in range(E)]).astype(np.int32)
+    tw_start = np.array([k[0] for k in keys], dtype=np.int64)
+    pool = np.ascontiguousarray(pool, dtype=np.int32)
+    dist = np.ascontiguousarray(dist, dtype=np.float64)
+    sk = _Skip(_p(perm), len(keys), _p(tw_start), _p(pool), _p(dist))
+    o = {"topk_n": np.zeros(n, np.int32), "topk_idx": np.zeros((n, K, E), np.int32), "topk_score": np.zeros((n, K)),
+         "topk2_n": np.zeros(n, np.int32), "topk2_idx": np.zeros((n, K, E), np.int32), "topk2_score": np.zeros((n, K)),
+         "leaves": np.zeros(n, np.int64), "chosen": np.full(n, -1, np.int32), "parent": np.zeros((E, n), np.int32)}
+    stats = np.zeros(5, np.int64)
+    lib().two_run_skip.restype = ctypes.c_int
+    rc = lib().two_run_skip(ctypes.byref(svc.c), ctypes.byref(sk), _p(end_flag), _p(o["topk_n"]), _p(o["topk_idx"]), _p(o["topk_score"]),
+                            _p(o["topk2_n"]), _p(o["topk2_idx"]), _p(o["topk2_score"]), _p(o["leaves"]), _p(o["chosen"]), _p(o["parent"]), _p(stats))
+    if rc != 0:
+        raise RuntimeError("two_run_skip failed: %d" % rc)
+    o["not_best_count"], o["cnt_unassigned"], o["mwis_nodes"], o["n_windows"], o["budget_windows"] = (int(v) for v in stats)
+    return o
+
+
+def decode_skip(idx):
+    """(index with skips as -2 - pool position, time window or -1) from the raw candidate indices of run_skip."""
+    idx = np.asarray(idx)
+    skip = idx <= -SKIP_BASE
+    code = np.where(skip, -idx - SKIP_BASE, 0)
+    return np.where(skip, -2 - code % SKIP_STRIDE, idx), np.where(skip, code // SKIP_STRIDE, -1)

@@ -61,6 +61,48 @@ def check(lib_path):
     eng.close()
 
 
+def check_find_order_on_reference_runs(lib_path):
+    """FindOrder on the device against the call-order DAGs the reference's own FindOrder (executor.py:214-285) produced
+    in the frozen runs -- all 90 services of the shipped corpora plus the synthetic reference runs -- from the inputs and
+    ground truth of those runs; also with the endpoints in partition-key order, as the executor calls it."""
+    from conftest import GOLDEN, unit_from_golden
+    from traceweaver_amd.engine import UnitArrays
+
+    ds = [np.load(p) for p in GOLDEN]
+    units = [unit_from_golden(d)[1] for d in ds]
+    eng = Engine(0, lib_path=lib_path)
+    dags = eng.find_order(units, [d["true_parent"] for d in ds])
+    checked = 0
+    for d, u, got in zip(ds, units, dags):
+        assert np.array_equal(got, d["dag"]), "%s / %s" % (d["dataset"], d["process"])
+        checked += int(d["dag"].sum() > 0)
+    assert checked >= 10                       # chains, diamonds and the transitive edges of the hotel frontend are among them
+    shuf, truth, want = [], [], []
+    for d, u in zip(ds, units):
+        if u.E < 2:
+            continue
+        keys = [str(x) for x in d["partition_key_order"]]
+        perm = [[str(x) for x in d["out_eps"]].index(k) for k in keys]      # position in topological order of every key
+        n = [int(u.out_off[e + 1] - u.out_off[e]) for e in perm]
+        shuf.append(UnitArrays(u.in_start, u.in_end, np.concatenate([[0], np.cumsum(n)]),
+                               np.concatenate([u.out_start[u.out_off[e]:u.out_off[e + 1]] for e in perm]),
+                               np.concatenate([u.out_end[u.out_off[e]:u.out_off[e + 1]] for e in perm]), np.zeros((u.E, u.E))))
+        truth.append(d["true_parent"][perm])
+        want.append(d["dag"][np.ix_(perm, perm)])
+    for got, w in zip(eng.find_order(shuf, truth), want):
+        assert np.array_equal(got, w)
+    eng.close()
+
+
+def test_find_order_reproduces_the_reference_dags_emulated(emu_lib):
+    check_find_order_on_reference_runs(emu_lib)
+
+
+@pytest.mark.gpu
+def test_find_order_reproduces_the_reference_dags_gpu():
+    check_find_order_on_reference_runs(None)
+
+
 def test_find_order_and_accuracy_emulated(emu_lib):
     check(emu_lib)
 

@@ -1,0 +1,79 @@
+"""Skip mode (exps/exp2: cache hits injected into the hotel `frontend` service, one pass with skip spans): the oracle's
+restatement against runs of the unmodified reference with --cache_rate 0.05 ... 0.3 (oracle/refrun/gen_golden_skip.py ->
+tests/golden/refskip_*.npz).  Pinned: time windows, skip budget, water-filled skip spans per (endpoint, window)
+(traceweaver_v3.py:853-989), the (mean, std) table of BuildDistributions (:108-172, bit for bit), span windows on the
+lists as the predictor receives them (no longer sorted after create_cache_hits), both top-5 lists of every request incl.
+which skip span of which window they hold (:820-842), scores (<= 1e-12 relative: numpy's exp vs fdlibm), tuple counts,
+and the selections / final assignment up to the reference solver's tolerance: the scores are densities of the order of
+1e-4 next to the 10000 offset of the weights (traceweaver_v3.py:1260), so selections whose weights differ by < 1e-6 are
+the same optimum to a MILP solver; the oracle works with exact integers (resolution 2.3e-10) and takes the larger one."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+SKIP_GOLDEN = sorted(glob.glob(os.path.join(REPO, "tests", "golden", "refskip_*__frontend.npz")))
+
+
+def solve(oracle, d):
+    T = oracle
+    svc = T.service_from_golden(d)
+    keys, budget, pool = T.tally_skip_spans(svc)
+    tab, large = T.build_distributions(svc)
+    end_flag, pre, win = T.windows(svc)
+    return svc, keys, budget, pool, tab, large, end_flag, pre, win, T.run_skip(svc, end_flag, keys, pool, tab)
+
+
+def window_weights(chosen, score, end_flag):
+    """per window: (assigned requests, sum of 10000 + score of the chosen candidates)"""
+    out, cnt, w = [], 0, 0.0
+    for i in range(len(chosen)):
+        if chosen[i] >= 0:
+            cnt += 1
+            w += 10000.0 + score[i, chosen[i]]
+        if end_flag[i]:
+            out.append((cnt, w))
+            cnt, w = 0, 0.0
+    return out
+
+
+@pytest.mark.parametrize("path", SKIP_GOLDEN, ids=[os.path.basename(p)[8:-4] for p in SKIP_GOLDEN])
+def test_skip_mode_oracle_reproduces_the_reference(oracle, path):
+    d = np.load(path)
+    T = oracle
+    svc, keys, budget, pool, tab, large, end_flag, pre, win, o = solve(oracle, d)
+    assert int(d["n_passes"]) == 1 and not bool(d["dynamism_at_entry"]) and int(d["time_windows_at_entry"]) == 0
+    assert np.array_equal(np.array(keys), d["time_windows"]) and np.array_equal(budget, d["skip_budget"])
+    assert np.array_equal(pool, d["skip_count"])
+    assert large == int(d["large_delay"])
+    assert np.array_equal(np.isnan(tab), np.isnan(d["dist_table"]))
+    m = ~np.isnan(tab)
+    assert np.array_equal(tab[m], d["dist_table"][m])                     # np.mean / np.std of the same samples in the same order
+    assert np.array_equal(win, d["windows"]) and np.array_equal(pre, d["pre_leaves"])
+    for kind in ("topk", "topk2"):
+        idx, w = T.decode_skip(o[kind + "_idx"])
+        assert np.array_equal(o[kind + "_n"], d["p0_%s_n" % kind])
+        assert np.array_equal(idx, d["p0_%s_idx" % kind]) and np.array_equal(w, d["p0_%s_win" % kind])
+        ref = d["p0_%s_score" % kind]
+        ok = ~np.isnan(ref)
+        assert np.allclose(o[kind + "_score"][ok], ref[ok], rtol=1e-12, atol=0)
+    assert np.array_equal(o["leaves"], d["per_span_candidates"])
+    # selections: identical, or the same optimum within the solver's tolerance (same number of requests assigned)
+    mine = window_weights(o["chosen"], o["topk_score"], end_flag)
+    ref = window_weights(d["p0_chosen"], d["p0_topk_score"], end_flag)
+    for (ca, wa), (cb, wb) in zip(mine, ref):
+        assert ca == cb and abs(wa - wb) < 1e-6 and wa >= wb - 1e-9
+    differing = int((o["chosen"] != d["p0_chosen"]).sum())
+    assert differing <= 0.02 * svc.n_in
+    assert o["cnt_unassigned"] == int(d["cnt_unassigned"])
+    assert (o["parent"] != d["final_parent"]).any(axis=0).sum() <= differing
+    assert abs(o["not_best_count"] - int(d["not_best_count"])) <= differing
+    acc = lambda p: float(np.all(p == d["true_parent"], axis=0).mean())
+    assert abs(acc(o["parent"]) - acc(d["final_parent"])) <= 0.005
+
+
+def test_golden_files_present():
+    assert len(SKIP_GOLDEN) >= 1

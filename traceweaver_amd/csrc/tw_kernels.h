@@ -1407,30 +1407,20 @@ __device__ inline bool cands_share(const Dev& P, const UnitDev& U, int i, int a,
 //
 // Mapping: k_select_fast settles the windows whose best candidates do not clash (one lane per span) and
 // lists the others; k_select_heavy solves a listed window per wavefront, candidate data in LDS: components
-// of <= kBruteMax spans by complete enumeration spread over the lanes, larger ones by select_search: the
-// tree is cut below its first D levels into P >= 4 x lanes sub-trees, the lanes draw sub-trees in
-// depth-first order from a counter and search them independently -- the search stack of a lane is 3 bits
-// per level in registers, the weight above a node and the set of blocked candidates are rebuilt from it
-// when the search returns to a level -- and share only the best weight found so far.  A lane cuts a node
-// when acc + bound <= its own incumbent (an earlier leaf of an earlier or the same sub-tree: ties go to the
-// earlier leaf, as in the sequential search) or when acc + bound < the shared best weight (strictly: a tie
-// with a later sub-tree must survive).  Bounds: the grouped bound of the suffix, and a transposition table -- once
-// the sub-tree below a node has been searched, (best weight known then) - (weight above the node) bounds what any
-// other way of reaching the same (depth, blocked candidates of the remaining spans) can still gain; assignments of
-// the spans above that merely permute who took which outgoing span all meet in that one entry (on the test
-// workloads: 4.2e6 -> 1.9e3 nodes for the largest component of the nodejs shape, 8.3e8 -> 2.7e5 on the tie-saturated
-// stress set).  The winner is the largest weight, the smallest sub-tree among equal
-// weights.  A lane that visits more than kNodeBudget / lanes nodes on one component stops; the window then keeps the
-// best selection found and is counted in unit_stats[4] (not proven optimal).
+// of <= kBruteMax spans by complete enumeration spread over the lanes, larger ones by select_search: a
+// depth-first search in that canonical order by one lane (stack in LDS), cut where weight + bound <= incumbent.
+// Bounds: the grouped bound of the suffix, and a transposition table -- once the sub-tree below a node has been
+// searched, (incumbent then) - (weight above the node) bounds what any other way of reaching the same (depth,
+// blocked candidates of the remaining spans) can still gain; assignments of the spans above that merely permute
+// who took which outgoing span all meet in that one entry.  A component whose search visits more than kNodeBudget
+// nodes keeps the best selection found; the window is counted in unit_stats[4] (not proven optimal).
 typedef long long sel_w;
 __device__ __forceinline__ sel_w sel_weight(double score) { return (sel_w)rint((10000.0 + score) * 4294967296.0); }
-constexpr int kNodeBudget = 1 << 24; // search nodes per component, shared evenly by the lanes (2^18 per lane of a wavefront)
+constexpr int kNodeBudget = 1 << 24; // search nodes per component
 constexpr int kBlkWords = (kMaxWin * kTopK + 63) / 64;  // words of a mask over all candidates of a component
 constexpr int kBigWindow = 8;        // windows of at least this many spans are served first by k_select_heavy
 constexpr int kBruteMax = 4;         // components of up to this many spans are solved by complete enumeration (see select_brute)
-constexpr int kStackWords = (kMaxWin + 9) / 10;  // search stack: 3 bits per level, 10 levels per 32-bit word
 constexpr int kMemoSlots = 256;      // transposition table entries (LDS); a table of 2^20 entries prunes no better on the test workloads
-constexpr int kPrefixMax = 10;       // levels above the sub-trees: 4 x 256 sub-trees are reached after <= 10 levels of >= 2 choices
 
 // ---- cooperative path: one workgroup per window --------------------------------------------------
 struct SelectLds {
@@ -1453,10 +1443,11 @@ struct SelectLds {
     sel_w mval[kMemoSlots];
     unsigned int mstate[kMemoSlots];   // generation << 2 | (0 empty, 1 being written, 2 valid)
     unsigned int memo_gen;
-    unsigned long long gbest;       // the best weight any lane has found (weights are > 0)
-    unsigned long long win_key;     // reduction of the lanes' results
-    uint32_t win_stack[kStackWords];
-    int cm, budget_hit, next_sub, n_sub, depth0, win_sub;
+    sel_w saccs[kMaxWin + 1];                       // search stack: weight above every level,
+    unsigned long long sblk[kMaxWin + 1][kBlkWords];  // candidates blocked at every level,
+    int8_t scur[kMaxWin], sbest[kMaxWin];             // choice per level (ncand = "none"), incumbent
+    int cm, budget_hit;
+    unsigned long long nodes_total;   // search nodes of the window (all lanes), reported in unit_stats[5]
 };
 
 __device__ inline bool lds_share(const SelectLds& L, int E, int b1, int k1, int b2, int k2) {
@@ -1465,188 +1456,101 @@ __device__ inline bool lds_share(const SelectLds& L, int E, int b1, int k1, int 
     return false;
 }
 
-__device__ __forceinline__ int stack_get(const uint32_t (&st)[kStackWords], int d) {
-    const int wd = d / 10, sh = (d % 10) * 3;
-    uint32_t v = 0;
-#pragma unroll
-    for (int q = 0; q < kStackWords; q++) v = q == wd ? st[q] : v;
-    return (int)((v >> sh) & 7u);
-}
-__device__ __forceinline__ void stack_set(uint32_t (&st)[kStackWords], int d, int k) {
-    const int wd = d / 10, sh = (d % 10) * 3;
-#pragma unroll
-    for (int q = 0; q < kStackWords; q++) st[q] = q == wd ? ((st[q] & ~(7u << sh)) | ((uint32_t)k << sh)) : st[q];
-}
-
-// Depth-first search of a component of more than kBruteMax spans, sub-trees spread over the lanes (see above).
+// Depth-first search of a component of more than kBruteMax spans (see above): lane 0 walks the tree in the canonical
+// order with its stack in LDS (weight above every level, blocked candidates at every level: a return costs nothing),
+// cutting a node when weight + bound <= incumbent, the bound being the grouped bound of the suffix or the entry of the
+// transposition table for (depth, blocked candidates of the remaining spans).  With the table the search is a dynamic
+// programme over the sets of taken outgoing spans rather than over the assignments that produce them: the largest
+// component of the heavy-load test workloads takes ~2e3 nodes instead of 4e6 (nodejs shape) / 8e8 (tie-saturated set).
 // Needs L.cm, L.mem, L.ncand, L.w, L.ub, L.cmask3; writes L.pick of the members.
 __device__ void select_search(SelectLds& L) {
     static_assert(kBlkWords == 3, "the blocked mask is kept in three registers");
-    static_assert(kTopK + 1 <= 7, "a level's choice must fit 3 bits");
-    const int t = threadIdx.x, nt = blockDim.x;
+    const int t = threadIdx.x;
     const int cm = L.cm;
     if (t == 0) {
-        int D = 0, P = 1;
-        while (D < cm - 1 && D < kPrefixMax && P < 4 * nt) { P *= (int)L.ncand[L.mem[D]] + 1; D++; }
-        L.depth0 = D; L.n_sub = P; L.next_sub = 0; L.gbest = 0ull; L.win_key = 0ull; L.win_sub = -1;
-        L.memo_gen++;   // entries of earlier components become stale without a sweep (memo_gen is reset with the states when it wraps)
+        L.memo_gen++;   // entries of earlier components become stale without a sweep
         if ((L.memo_gen & 0x3fffffffu) == 0u) { L.memo_gen = 1u; for (int q = 0; q < kMemoSlots; q++) L.mstate[q] = 0u; }
-    }
-    group_sync();
-    const int D = L.depth0, P = L.n_sub;
-    const unsigned int tag_busy = (L.memo_gen << 2) | 1u, tag_ready = (L.memo_gen << 2) | 2u;
-    // key of a node: the blocked candidates of the spans d.. (bits below d * kTopK cleared) with the depth in the low bits
-    auto memo_key = [&](int d, unsigned long long b0, unsigned long long b1, unsigned long long b2, unsigned long long (&k)[kBlkWords]) -> unsigned {
-        const int bit = d * kTopK, wd = bit >> 6;
-        const unsigned long long keep = ~0ull << (bit & 63);
-        k[0] = wd == 0 ? (b0 & keep) : 0ull; k[1] = wd == 1 ? (b1 & keep) : (wd < 1 ? b1 : 0ull); k[2] = wd == 2 ? (b2 & keep) : (wd < 2 ? b2 : 0ull);
-        k[0] |= (unsigned long long)d;   // d >= 1: bits 0..4 belong to the first span and are clear
-        unsigned long long h = (k[0] * 0x9E3779B97F4A7C15ull) ^ (k[1] * 0xC2B2AE3D27D4EB4Full) ^ (k[2] * 0x165667B19E3779F9ull);
-        h ^= h >> 29;
-        return (unsigned)h & (kMemoSlots - 1);
-    };
-    sel_w own_w = 0;              // incumbent of this lane: only strict improvements replace it
-    int own_sub = -1;
-    uint32_t own_st[kStackWords], st[kStackWords];
-#pragma unroll
-    for (int q = 0; q < kStackWords; q++) { own_st[q] = 0; st[q] = 0; }
-    int nodes = 0;
-    const int lane_budget = kNodeBudget / nt;
-    bool over = false;
-    while (!over) {
-        const int sub = atomicAdd(&L.next_sub, 1);   // sub-trees are handed out in depth-first order
-        if (sub >= P) break;
-        // the sub-tree's prefix: digit q of `sub` (first member most significant) = candidate, or ncand = "none"
-        sel_w acc = 0;
+        const unsigned int tag = (L.memo_gen << 2) | 2u;
+        // key of a node: the blocked candidates of the spans d.. (bits below d * kTopK cleared) with the depth in the low bits
+        auto memo_key = [&](int d, unsigned long long b0, unsigned long long b1, unsigned long long b2, unsigned long long (&k)[kBlkWords]) -> unsigned {
+            const int bit = d * kTopK, wd = bit >> 6;
+            const unsigned long long keep = ~0ull << (bit & 63);
+            k[0] = wd == 0 ? (b0 & keep) : 0ull; k[1] = wd == 1 ? (b1 & keep) : (wd < 1 ? b1 : 0ull); k[2] = wd == 2 ? (b2 & keep) : (wd < 2 ? b2 : 0ull);
+            k[0] |= (unsigned long long)d;   // d >= 1: bits 0..4 belong to the first span and are clear
+            unsigned long long h = (k[0] * 0x9E3779B97F4A7C15ull) ^ (k[1] * 0xC2B2AE3D27D4EB4Full) ^ (k[2] * 0x165667B19E3779F9ull);
+            h ^= h >> 29;
+            return (unsigned)h & (kMemoSlots - 1);
+        };
+        sel_w best_w = 0, acc = 0;      // only strict improvements replace the incumbent
         unsigned long long b0 = 0, b1 = 0, b2 = 0;
-        bool ok = true;
-        {
-            int rest = sub;
-            int digit[kPrefixMax];
-#pragma unroll
-            for (int q = kPrefixMax - 1; q >= 0; q--) {
-                if (q < D) { const int r = (int)L.ncand[L.mem[q]] + 1; digit[q] = rest % r; rest /= r; } else digit[q] = 0;
-            }
-#pragma unroll
-            for (int q = 0; q < kPrefixMax; q++) {
-                if (q >= D || !ok) continue;
-                const int b = L.mem[q], k = digit[q];
-                stack_set(st, q, k);
-                if (k == (int)L.ncand[b]) continue;   // "none"
-                const sel_w w = L.w[b][k];
-                const int bit = q * kTopK + k;
-                if (!(w > 0) || (((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull)) { ok = false; continue; }
-                acc = acc + w;
-                b0 |= L.cmask3[q][k][0]; b1 |= L.cmask3[q][k][1]; b2 |= L.cmask3[q][k][2];
-            }
-        }
-        if (!ok) continue;
-        int d = D;
-        bool entered = true;
-        while (true) {
+        for (int q = 0; q < cm; q++) { L.scur[q] = -1; L.sbest[q] = -1; }
+        L.saccs[0] = 0; L.sblk[0][0] = 0; L.sblk[0][1] = 0; L.sblk[0][2] = 0;
+        int d = 0, nodes = 0;
+        bool entered = true, over = false;
+        while (d >= 0) {
             int k = 0;
-            bool up = false;
             if (entered) {
-                if (++nodes > lane_budget) { over = true; break; }
+                if (++nodes > kNodeBudget) { over = true; break; }
                 if (d == cm) {
-                    if (acc > own_w) {
-                        own_w = acc; own_sub = sub;
-#pragma unroll
-                        for (int q = 0; q < kStackWords; q++) own_st[q] = st[q];
-                        atomicMax(&L.gbest, (unsigned long long)acc);
-                    }
-                    up = true;
-                } else {
-                    const sel_w bound = acc + L.ub[d];
-                    if (bound <= own_w || bound < (sel_w)L.gbest) up = true;
-                    else if (d >= 1) {   // has the sub-tree below this (depth, blocked set) been searched already?
-                        unsigned long long k[kBlkWords];
-                        const unsigned slot = memo_key(d, b0, b1, b2, k);
-                        for (int pr = 0; pr < 4; pr++) {
-                            const unsigned sl = (slot + pr) & (kMemoSlots - 1);
-                            const unsigned st = ((volatile unsigned int*)L.mstate)[sl];
-                            if ((st >> 2) != (tag_ready >> 2) || (st & 3u) == 0u) break;   // empty: the chain ends here
-                            if (st != tag_ready) continue;
-                            if (L.mkey[sl][0] == k[0] && L.mkey[sl][1] == k[1] && L.mkey[sl][2] == k[2]) {
-                                const sel_w mb = acc + L.mval[sl];
-                                if (mb <= own_w || mb < (sel_w)L.gbest) up = true;
-                                break;
-                            }
-                        }
-                    }
+                    if (acc > best_w) { best_w = acc; for (int q = 0; q < cm; q++) L.sbest[q] = L.scur[q]; }
+                    d--; entered = false; continue;
                 }
-            } else {
-                k = stack_get(st, d) + 1;   // resume below the choice this level made last
-            }
-            if (!up) {
-                const int b = L.mem[d], nc = L.ncand[b];
-                bool found = false;
-                for (; k <= nc; k++) {
-                    if (k == nc) { found = true; break; }   // "none"
-                    const sel_w w = L.w[b][k];
-                    if (!(w > 0)) continue;
-                    const int bit = d * kTopK + k;
-                    if (((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull) continue;
-                    acc = acc + w;
-                    b0 |= L.cmask3[d][k][0]; b1 |= L.cmask3[d][k][1]; b2 |= L.cmask3[d][k][2];
-                    found = true;
-                    break;
-                }
-                if (found) { stack_set(st, d, k); d++; entered = true; continue; }
-                up = true;
-                if (d >= 1) {   // every way on from this node has been searched: remember what it can gain at most
+                bool cut = acc + L.ub[d] <= best_w;
+                if (!cut && d >= 1) {   // has the sub-tree below this (depth, blocked set) been searched already?
                     unsigned long long kk[kBlkWords];
                     const unsigned slot = memo_key(d, b0, b1, b2, kk);
-                    const sel_w gb = (sel_w)L.gbest;
-                    const sel_w val = (own_w > gb ? own_w : gb) - acc;
                     for (int pr = 0; pr < 4; pr++) {
                         const unsigned sl = (slot + pr) & (kMemoSlots - 1);
-                        const unsigned st0 = ((volatile unsigned int*)L.mstate)[sl];
-                        if ((st0 >> 2) == (tag_ready >> 2) && (st0 & 3u) != 0u) {   // taken: the same node already? then done
-                            if (st0 == tag_ready && L.mkey[sl][0] == kk[0] && L.mkey[sl][1] == kk[1] && L.mkey[sl][2] == kk[2]) break;
-                            continue;
-                        }
-                        if (atomicCAS(&L.mstate[sl], st0, tag_busy) != st0) continue;   // another lane took the slot just now
-                        L.mkey[sl][0] = kk[0]; L.mkey[sl][1] = kk[1]; L.mkey[sl][2] = kk[2]; L.mval[sl] = val;
-                        __threadfence_block();
-                        atomicExch(&L.mstate[sl], tag_ready);
-                        break;
+                        if (L.mstate[sl] != tag) break;   // empty: the chain ends here
+                        if (L.mkey[sl][0] == kk[0] && L.mkey[sl][1] == kk[1] && L.mkey[sl][2] == kk[2]) { cut = acc + L.mval[sl] <= best_w; break; }
                     }
                 }
+                if (cut) { d--; entered = false; continue; }
+            } else {
+                acc = L.saccs[d]; b0 = L.sblk[d][0]; b1 = L.sblk[d][1]; b2 = L.sblk[d][2];
+                k = L.scur[d] + 1;   // resume below the choice this level made last ("none" was stored as ncand)
             }
-            // return to the level above: its weight and blocked set are rebuilt from the stack
-            d--;
-            if (d < D) break;
-            entered = false;
-            acc = 0; b0 = 0; b1 = 0; b2 = 0;
-            for (int q = 0; q < d; q++) {
-                const int kq = stack_get(st, q), bq = L.mem[q];
-                if (kq == (int)L.ncand[bq]) continue;
-                acc = acc + L.w[bq][kq];
-                b0 |= L.cmask3[q][kq][0]; b1 |= L.cmask3[q][kq][1]; b2 |= L.cmask3[q][kq][2];
+            const int b = L.mem[d], nc = L.ncand[b];
+            bool found = false;
+            for (; k <= nc; k++) {
+                if (k == nc) { found = true; break; }   // "none"
+                const sel_w w = L.w[b][k];
+                if (!(w > 0)) continue;
+                const int bit = d * kTopK + k;
+                if (((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull) continue;
+                found = true;
+                break;
             }
+            if (found) {
+                L.scur[d] = (int8_t)k;
+                if (k < nc) { acc = acc + L.w[b][k]; b0 |= L.cmask3[d][k][0]; b1 |= L.cmask3[d][k][1]; b2 |= L.cmask3[d][k][2]; }
+                d++;
+                L.saccs[d] = acc; L.sblk[d][0] = b0; L.sblk[d][1] = b1; L.sblk[d][2] = b2;
+                entered = true;
+                continue;
+            }
+            // every way on from this node has been searched: remember what it can gain at most
+            if (d >= 1) {
+                unsigned long long kk[kBlkWords];
+                const unsigned slot = memo_key(d, b0, b1, b2, kk);
+                for (int pr = 0; pr < 4; pr++) {
+                    const unsigned sl = (slot + pr) & (kMemoSlots - 1);
+                    if (L.mstate[sl] == tag) {
+                        if (L.mkey[sl][0] == kk[0] && L.mkey[sl][1] == kk[1] && L.mkey[sl][2] == kk[2]) { L.mval[sl] = best_w - acc; break; }
+                        continue;
+                    }
+                    L.mkey[sl][0] = kk[0]; L.mkey[sl][1] = kk[1]; L.mkey[sl][2] = kk[2]; L.mval[sl] = best_w - acc;
+                    L.mstate[sl] = tag;
+                    break;
+                }
+            }
+            d--; entered = false;
         }
-    }
-    if (over) L.budget_hit = 1;
-    // winner: largest weight, smallest sub-tree among equal weights (a lane's own result is already the first leaf of
-    // that weight among its sub-trees, which it visited in increasing order)
-    group_sync();
-    const unsigned long long wbits = own_sub >= 0 ? (unsigned long long)own_w : 0ull;
-    if (own_sub >= 0) atomicMax(&L.win_key, wbits);
-    group_sync();
-    if (own_sub >= 0 && wbits == L.win_key) atomicMax(&L.win_sub, 0x7fffffff - own_sub);   // smallest sub-tree wins
-    group_sync();
-    if (own_sub >= 0 && wbits == L.win_key && 0x7fffffff - own_sub == L.win_sub) {   // exactly one lane: sub-trees are not shared
-#pragma unroll
-        for (int q = 0; q < kStackWords; q++) L.win_stack[q] = own_st[q];
-    }
-    group_sync();
-    if (t == 0) {
-        const bool any = L.win_sub >= 0 && L.win_key != 0ull;
+        if (over) L.budget_hit = 1;
+        L.nodes_total += (unsigned long long)nodes;
         for (int q = 0; q < cm; q++) {
-            const int b = L.mem[q];
-            const int k = any ? (int)((L.win_stack[q / 10] >> ((q % 10) * 3)) & 7u) : (int)L.ncand[b];
-            L.pick[b] = (int8_t)(k == (int)L.ncand[b] ? -1 : k);
+            const int bq = L.mem[q], kq = best_w > 0 ? L.sbest[q] : -1;
+            L.pick[bq] = (int8_t)((kq < 0 || kq == (int)L.ncand[bq]) ? -1 : kq);
         }
     }
     group_sync();
@@ -1760,7 +1664,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
         for (int e = 0; e < E; e++) L.idx[b][k][e] = k < n ? cand_idx(P, U, first + b, k, e) : -1 - q;
         if (k == 0) { L.ncand[b] = (uint8_t)n; L.comp[b] = (uint8_t)b; L.pick[b] = -1; }
     }
-    if (t == 0) L.budget_hit = 0;
+    if (t == 0) { L.budget_hit = 0; L.nodes_total = 0ull; }
     for (int b = t; b < m; b += nt) L.adj[b] = 0;
     group_sync();
     TW_SEL_TICK(0);
@@ -1870,6 +1774,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
     TW_SEL_TICK(6);
     for (int b = t; b < m; b += nt) P.chosen[U.in_off + first + b] = L.pick[b];
     if (t == 0 && L.budget_hit) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 4], 1ull);
+    if (t == 0 && L.nodes_total) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 5], L.nodes_total);
     group_sync();
     TW_SEL_TICK(7);
 }
