@@ -20,9 +20,10 @@
  *   - outgoing endpoints in the topological order of the call-order DAG    traceweaver_v1.py:37-39
  *   - every endpoint's spans sorted by (start, end)
  *   - timestamps are int64 microseconds (Jaeger JSON startTime / startTime+duration)
- * Only the no-skip mode of the reference is accelerated: every endpoint must hold exactly as many
- * outgoing spans as the unit has incoming spans (traceweaver_v3.py:972,1141-1158 "equal_eps");
- * anything else is rejected with TW_ERR_UNSUPPORTED.
+ * A batch is either a no-skip batch (every endpoint of every unit holds exactly as many outgoing spans as the unit
+ * has incoming spans, traceweaver_v3.py:972,1141-1158 "equal_eps": two passes with the mixture refit in between) or a
+ * skip-mode batch (tw_batch.skip != NULL; exps/exp2: some requests did not call an endpoint: ONE pass with skip spans,
+ * traceweaver_v3.py:820-989,1155-1156).
  */
 #ifndef TRACEWEAVER_AMD_H
 #define TRACEWEAVER_AMD_H
@@ -38,6 +39,8 @@ extern "C" {
 #define TW_MAX_COMP 5    /* mixture components per edge              traceweaver_v3.py:768  */
 #define TW_MAX_WINDOW 32 /* incoming spans per window (reference cap: 31)    */
 #define TW_CAND_WORDS 2  /* 64-bit words of the per-(span, endpoint) candidate bitmap       */
+#define TW_SKIP_BASE 1024
+#define TW_SKIP_STRIDE 128
 
 typedef enum {
     TW_OK = 0,
@@ -48,8 +51,13 @@ typedef enum {
     TW_ERR_WINDOW_WIDTH = -5, /* an incoming span has > 64*TW_CAND_WORDS candidate spans at one      */
                               /* endpoint (the reference's enumeration is infeasible there too)      */
     TW_ERR_WINDOW_SIZE = -6,  /* a window holds more than TW_MAX_WINDOW incoming spans                */
-    TW_ERR_NAN_PARAMS = -7    /* a 100-span block has a single sample: std = NaN, the reference      */
+    TW_ERR_NAN_PARAMS = -7,   /* a 100-span block has a single sample: std = NaN, the reference      */
                               /* aborts in the solver (SURVEY.md hazard H3)                          */
+    TW_ERR_SKIP_PARAMS = -8,  /* skip mode: the scorer needs a (mean, std) pair BuildDistributions   */
+                              /* did not produce (KeyError in the reference, traceweaver_v1.py:118)  */
+    TW_ERR_SKIP_REFERENCE_RAISES = -9 /* skip mode: the reference raises on this input (a tuple that */
+                              /* skips every endpoint, hazard H7; a score tie whose comparison       */
+                              /* reaches a skip span; a skipped predecessor without a called one)    */
 } tw_status;
 
 typedef struct tw_engine tw_engine;
@@ -85,7 +93,21 @@ typedef struct {
      * accumulate in binary64 left to right as Python's sum() does over floats.  NULL = every unit holds plain
      * int64 microseconds (exact integer sums, as Python does over ints). */
     const double *unit_time_scale; /* [n_units] or NULL */
+    /* Skip mode (NULL = a no-skip batch): one descriptor per unit.  The unit's lists are taken as they are -- after
+     * helpers/transforms.py:153-238 (create_cache_hits) they are no longer sorted, and the reference bisects and walks
+     * them as handed over (traceweaver_v3.py:1115 runs before the sort of :968-971); endpoints may hold fewer spans
+     * than there are incoming spans.  Timestamps must be integer microseconds (unit_time_scale == NULL). */
+    const struct tw_skip_unit *skip;
 } tw_batch;
+
+/* What TallySkipSpans (traceweaver_v3.py:853-989) and BuildDistributions (:108-172) hand the main loop. */
+typedef struct tw_skip_unit {
+    int32_t n_tw;            /* time windows of 30 requests (traceweaver_v3.py:976-987), in start order            */
+    const int64_t *tw_start; /* [n_tw]                                                                              */
+    const int32_t *pool;     /* [E][n_tw] skip spans per (endpoint, window) after water-filling, <= 128             */
+    const double *dist;      /* [(E+1)][(E+1)][2] (mean, std) of the delay between two endpoints' spans, NaN where  */
+                             /* no sample exists; index 0 = the incoming endpoint, 1 + e = outgoing endpoint e      */
+} tw_skip_unit;
 
 /* Copies the batch into HBM (span arrays: 16 B per span).  If `spans_on_device` is non-zero the
  * four span arrays are *device* pointers (already resident, e.g. produced by a device-side loader)
@@ -128,8 +150,9 @@ int tw_run_pass2(tw_engine *e);
 
 /* Results of pass `pass` (1 or 2), host buffers, any pointer may be NULL.  Per-unit arrays are
  * concatenated unit after unit; within a unit [E][n_in] / [TW_TOPK][E][n_in] / [TW_TOPK][n_in].
- *   parent      int32  chosen outgoing-span index per endpoint, -1 = ("NA","NA")
- *   topk_idx    int32  top-5 tuples on *all* spans (top_k_2, traceweaver_v3.py:1185), -1 padded
+ *   parent      int32  chosen outgoing-span index per endpoint, -1 = ("NA","NA"), -2 = ("Skip","Skip")
+ *   topk_idx    int32  top-5 tuples on *all* spans (top_k_2, traceweaver_v3.py:1185), -1 padded; skip mode: a skip span
+ *                      is -(TW_SKIP_BASE + time window * TW_SKIP_STRIDE + position in the window's pool)
  *   topk_score  double their scores (NaN padded)
  *   topk_n      int32  [n_in] number of valid tuples
  *   chosen      int32  [n_in] rank of the chosen tuple in the span's own candidate list, -1 none
@@ -183,6 +206,15 @@ int tw_set_truth(tw_engine *e, const int32_t *true_child, const int32_t *in_trac
  * the trace is wrong (exact / top-5) -- combine across ranks with a MAX all-reduce; e2e[2] (may be NULL) = traces
  * right under the exact / the top-5 criterion on this engine alone. */
 int tw_evaluate(tw_engine *e, int64_t *per_unit, uint8_t *trace_flags, int64_t *e2e);
+
+/* Replaces: the sweep of BuildDistributions (traceweaver_v3.py:120-169).  The spans of one service merged in start
+ * order (stable: incoming spans first, then the endpoints in order): start / dur [n], ep [n] (0 = incoming span,
+ * 1 + e = span of outgoing endpoint e), large_delay = the longest incoming span.  Per span: key_out = a * (E + 1) + b
+ * of the pair its delay sample belongs to (-1: no qualifying predecessor) and the sample in microseconds.  The
+ * (mean, std) per pair are np.mean / np.std of the samples in this order (host, traceweaver_amd/skipmode.py); the
+ * durations of the incoming spans form the pair (0, 0), which the scorer never reads. */
+int tw_build_distributions(tw_engine *e, int64_t n, const int64_t *start, const int64_t *dur, const uint8_t *ep, int64_t large_delay,
+                           int32_t E, int32_t *key_out, int64_t *sample_out);
 
 /* Measurement aid for the roofline figures (bench.py): rate of a plain 16-B-per-lane streaming copy kernel over
  * `bytes` of HBM (read + written bytes per second, in GB/s), `iters` launches timed with HIP events. */

@@ -83,11 +83,38 @@ def test_unsupported_settings_are_refused(emu_lib, tmp_path):
     from traceweaver_amd import executor
 
     base = ["--relative_path", "x", "--fix", "2", "--results_directory", str(tmp_path) + "/", "--engine_library", emu_lib]
-    for extra in (["--cache_rate", "0.3"], ["--cache_rate", "0", "--predictor_indices", "2,10"],
-                  ["--cache_rate", "0", "--parallel", "1"]):
+    for extra in (["--cache_rate", "0", "--predictor_indices", "2,10"], ["--cache_rate", "0", "--parallel", "1"]):
         with pytest.raises(SystemExit) as ei:
             executor.main(base + extra)
         assert "not supported here" in str(ei.value)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/data"), reason="the reference's data directory is not present")
+@pytest.mark.parametrize("rate", ["0.1", "0.3"])
+def test_cache_hit_runs_of_exp2(emu_lib, tmp_path, rate):
+    """exps/exp2/run_experiment.sh: hotel_load150 with --cache_rate R and predictors "3,4,10": cache hits are injected into
+    `frontend` (skip mode, one pass with skip spans), `search` runs the two passes; the figures against the reference run
+    with the same rate (tests/golden/refskip_*)."""
+    import glob
+
+    from traceweaver_amd import executor
+
+    out = str(tmp_path) + "/"
+    executor.main(["--relative_path", "data/hotel_reservation/hotel_load150/", "--compressed", "0", "--cache_rate", rate, "--fix", "2",
+                   "--test_name", "x", "--load_level", "150", "--compress_factor", "1", "--repeat_factor", "1", "--execute_parallel", "0",
+                   "--results_directory", out, "--clear_cache", "1", "--predictor_indices", "3,4,10", "--project_root", REF,
+                   "--engine_library", emu_lib])
+    suffix = "_x_150_1_1_%s.pickle" % float(rate)
+    acc = pickle.load(open(out + "accuracy" + suffix, "rb"))
+    conf = pickle.load(open(out + "confidence_scores" + suffix, "rb"))
+    gold = {str(np.load(p)["process"]): np.load(p) for p in glob.glob(os.path.join(os.path.dirname(GOLDEN[0]), "refskip_hotel_load150_c%s__*.npz" % rate.replace(".", "p")))}
+    g = gold["frontend"]
+    ref_acc = float(np.all(g["final_parent"] == g["true_parent"], axis=0).mean())
+    assert abs(conf["frontend"][0] - ref_acc) <= 0.005 and conf["frontend"][2] == 1000
+    assert abs(conf["frontend"][1] - int(g["not_best_count"])) <= 20
+    method = "MaxScoreBatchSubsetWithSkips"
+    assert abs(acc[method] - float(g["e2e_accuracy"])) < 1.5 and acc[method + "TopK"] >= acc[method]
+    assert acc["FCFS"] < acc[method] and acc["WAP5"] < acc[method]
 
 
 @pytest.mark.skipif(not os.path.isdir(REF + "/data"), reason="the reference's data directory is not present")

@@ -93,15 +93,37 @@ def test_second_service_of_a_seeded_run(emu_lib):
     assert pred.last_stats["budget_windows"] == 0
 
 
-def test_skip_mode_is_rejected_loudly(emu_lib):
+def test_skip_mode_behind_the_protocol(emu_lib):
+    """A service short of outgoing spans (the reference's cache-hit experiment) through FindAssignments: the 6-tuple of a
+    reference run with --cache_rate 0.1, ('Skip', 'Skip') where the predictor decides the endpoint was not called."""
+    import glob
+    import os
+
     from traceweaver_amd.predictor import TraceWeaverGPU
 
-    d = np.load([f for f in GOLDEN if "hotel_load100__search" in f][0])
-    in_parts, out_parts, graph, truth, out_eps = protocol_inputs(d)
-    out_parts[out_eps[0]].pop()
-    with pytest.raises(NotImplementedError):
-        TraceWeaverGPU({}, {}, lib_path=emu_lib).FindAssignments("MaxScoreBatchSubsetWithSkips", "search", in_parts, out_parts,
-                                                                  False, [], truth, graph)
+    path = glob.glob(os.path.join(os.path.dirname(GOLDEN[0]), "refskip_hotel_load150_c0p1__frontend.npz"))[0]
+    d = np.load(path)
+    in_parts, out_parts, graph, _, out_eps = protocol_inputs(d)
+    in_spans = list(in_parts.values())[0]
+    truth = {ep: {} for ep in out_eps}
+    for k, ep in enumerate(out_eps):
+        for i, s in enumerate(in_spans):
+            x = int(d["true_parent"][k, i])
+            truth[ep][s.GetId()] = ("Skip", "Skip") if x == -2 else out_parts[ep][x].GetId()
+    pred = TraceWeaverGPU({}, {}, lib_path=emu_lib)
+    all_asg, all_topk, not_best, n_in, per_span, unassigned = pred.FindAssignments(
+        "MaxScoreBatchSubsetWithSkips", "frontend", in_parts, out_parts, False, [], truth, graph)
+    code = lambda v: -2 if v == ("Skip", "Skip") else (-1 if v == ("NA", "NA") else int(v[1].rsplit("_", 1)[1]))
+    parent = np.array([[code(all_asg[ep][s.GetId()]) for s in in_spans] for ep in out_eps])
+    assert n_in == 1000 and (parent == -2).sum() > 50
+    assert (parent != d["final_parent"]).any(axis=0).sum() <= 20          # up to the reference solver's tolerance (tests/test_skip_oracle.py)
+    assert unassigned == int(d["cnt_unassigned"]) and abs(not_best - int(d["not_best_count"])) <= 20
+    assert [per_span[s.GetId()] for s in in_spans] == d["per_span_candidates"].tolist()
+    for k, ep in enumerate(out_eps):
+        for i, s in enumerate(in_spans):
+            assert [code(v) for v in all_topk[ep][s.GetId()]] == [int(v) if v >= -1 else -2 for v in d["final_topk"][k, i] if v != -1 or False][:len(all_topk[ep][s.GetId()])]
+    ok = np.all(parent == d["true_parent"], axis=0).mean()
+    assert abs(ok - float(np.all(d["final_parent"] == d["true_parent"], axis=0).mean())) <= 0.005
 
 
 def test_device_refit_mode(emu_lib):

@@ -11,7 +11,10 @@ TW_TOPK = 5
 TW_MAX_COMP = 5
 
 STATUS = {0: "TW_OK", -1: "TW_ERR_ARG", -2: "TW_ERR_UNSUPPORTED", -3: "TW_ERR_DEVICE", -4: "TW_ERR_STATE",
-          -5: "TW_ERR_WINDOW_WIDTH", -6: "TW_ERR_WINDOW_SIZE", -7: "TW_ERR_NAN_PARAMS"}
+          -5: "TW_ERR_WINDOW_WIDTH", -6: "TW_ERR_WINDOW_SIZE", -7: "TW_ERR_NAN_PARAMS", -8: "TW_ERR_SKIP_PARAMS",
+          -9: "TW_ERR_SKIP_REFERENCE_RAISES"}
+TW_SKIP_BASE = 1024
+TW_SKIP_STRIDE = 128
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -28,7 +31,12 @@ class Batch(ctypes.Structure):
         ("out_start", ctypes.c_void_p), ("out_end", ctypes.c_void_p),
         ("batch_size", ctypes.c_int32), ("batch_size_mis", ctypes.c_int32), ("topk", ctypes.c_int32),
         ("unit_time_scale", ctypes.c_void_p),
+        ("skip", ctypes.c_void_p),
     ]
+
+
+class SkipUnit(ctypes.Structure):
+    _fields_ = [("n_tw", ctypes.c_int32), ("tw_start", ctypes.c_void_p), ("pool", ctypes.c_void_p), ("dist", ctypes.c_void_p)]
 
 
 class SpanTable(ctypes.Structure):
@@ -52,7 +60,7 @@ class Results(ctypes.Structure):
 
 EXPORTS = ["tw_create", "tw_destroy", "tw_last_error", "tw_load_batch", "tw_run_pass1", "tw_get_gaps",
            "tw_set_mixtures", "tw_fit_mixtures", "tw_get_mixtures", "tw_run_pass2", "tw_get_results", "tw_get_gauss_params", "tw_get_timing",
-           "tw_assign_service", "tw_find_order", "tw_set_truth", "tw_evaluate", "tw_measure_hbm_copy", "tw_host_alloc", "tw_host_free",
+           "tw_assign_service", "tw_find_order", "tw_set_truth", "tw_evaluate", "tw_measure_hbm_copy", "tw_host_alloc", "tw_host_free", "tw_build_distributions",
            "tw_corpus_create", "tw_corpus_destroy", "tw_corpus_last_error", "tw_corpus_add_files", "tw_corpus_set_callers", "tw_corpus_counts",
            "tw_corpus_string", "tw_corpus_loop_origin", "tw_corpus_trace_names", "tw_corpus_span_table", "tw_corpus_build_units"]
 
@@ -86,6 +94,7 @@ def load(path=None):
     lib.tw_set_truth.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.tw_evaluate.argtypes = [vp, vp, vp, vp]
     lib.tw_measure_hbm_copy.argtypes = [vp, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
+    lib.tw_build_distributions.argtypes = [vp, ctypes.c_int64, vp, vp, vp, ctypes.c_int64, ctypes.c_int32, vp, vp]
     lib.tw_host_alloc.argtypes = [ctypes.c_int64, ctypes.POINTER(vp)]
     lib.tw_host_free.argtypes = [vp]
     lib.tw_host_free.restype = None

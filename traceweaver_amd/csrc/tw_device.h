@@ -42,6 +42,7 @@ struct UnitDev {
     uint8_t pred_prim[kMaxEp][kMaxEp];    // 1 <=> that in-edge is primary (scored)
     double tscale;             // microseconds per timestamp unit (tw_batch.unit_time_scale; 1.0 for integer microseconds)
     int32_t float_time;        // timestamps are images of binary64 values: sums of timestamps accumulate in binary64
+    int32_t skip;              // skip-mode unit: lists as handed over (not necessarily sorted), Python's bisect for the cut-offs
 };
 
 struct TileDev {
@@ -275,6 +276,7 @@ __device__ inline double np_sum(const double* a, int n) {
 
 constexpr double kLogSqrt2Pi = 0x1.d67f1c864beb4p-1;  // np.log(np.sqrt(2*np.pi))
 constexpr double kLog2Pi = 0x1.d67f1c864beb4p+0;      // np.log(2*np.pi)
+constexpr double kSqrt2Pi = 0x1.40d931ff62706p+1;     // np.sqrt(2*np.pi)
 
 __host__ __device__ inline int slot_root(int E, int e) { return e; }
 __host__ __device__ inline int slot_prim(int E, int p, int e) { return E + p * E + e; }

@@ -18,6 +18,7 @@
 #include "tw_kernels.h"
 #include "tw_fit.h"
 #include "tw_eval.h"
+#include "tw_skip.h"
 
 using namespace tw;
 
@@ -84,6 +85,10 @@ struct tw_engine {
     unsigned ts_end_bit = 64;               // timestamps differ only below this bit (whole batch)
     double fit_ms = 0.0;
     int rounds = 0;                         // repair rounds of the last pass
+    bool skip_mode = false;                 // skip-mode batch (tw_batch.skip): one pass with skip spans
+    SkipUnitDev* skip_units = nullptr;
+    int32_t* skip_perm = nullptr; int64_t* skip_tw = nullptr; int32_t* skip_pool = nullptr; double* skip_dist = nullptr; long long* skip_fetch = nullptr;
+    int64_t skip_fetch_n = 0;
     hipEvent_t ev[EV_COUNT] = {};
     double ms[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -146,6 +151,9 @@ const char* kernel_error_text(int code) {
         case TW_ERR_WINDOW_WIDTH: return "an incoming span has more candidate spans at one endpoint than the candidate bitmap holds";
         case TW_ERR_WINDOW_SIZE: return "a window holds more than TW_MAX_WINDOW incoming spans";
         case TW_ERR_NAN_PARAMS: return "a parameter block holds a single sample (std = NaN); the reference aborts here (n_in % 100 == 1)";
+        case TW_ERR_SKIP_PARAMS: return "skip mode: the scorer needs a (mean, std) pair that BuildDistributions did not produce (the reference raises KeyError)";
+        case TW_ERR_SKIP_REFERENCE_RAISES: return "skip mode: the reference raises on this input (all endpoints skipped, or a score tie compared through a skip span)";
+        case TW_ERR_ARG: return "skip mode: a request starts before the first time window";
         default: return "kernel reported an error";
     }
 }
@@ -268,11 +276,17 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 3, e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t), e->stream));
     HIPCHK(hipMemsetAsync(P.unit_ndirty, 0, sizeof(int32_t) * P.n_units, e->stream));
-    if (pass == 1) {
+    if (pass == 1 && !e->skip_mode) {
         int rc = sort_ends(e);
         if (rc != TW_OK) return rc;
         const int64_t total = e->n_gp;
         hipLaunchKernelGGL(k_block_params, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, P, total);
+    }
+    if (e->skip_mode) {
+        // ComputeEpPairDistParams3 is not called when an endpoint is short of spans (traceweaver_v3.py:1177-1178); the first
+        // enumeration only serves the candidate sets of the windows (DfsTraverse3), its scores are not used: neutral parameters
+        const int64_t total = e->n_gp;
+        hipLaunchKernelGGL(k_neutral_params, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, P.gparam, total);
     }
     HIPCHK(hipEventRecord(e->ev[EV_PARAMS], e->stream));
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
@@ -292,6 +306,22 @@ int run_pass(tw_engine* e, int pass) {
         hipLaunchKernelGGL(k_window_index, tiles, tb, 0, e->stream, P);
     }
     HIPCHK(hipEventRecord(e->ev[EV_WIN], e->stream));
+    if (e->skip_mode) {   // the reference's loop in its own order, one wavefront per unit (tw_skip.h)
+        HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
+        HIPCHK(hipMemsetAsync(e->skip_fetch, 0, sizeof(long long) * (size_t)std::max<int64_t>(e->skip_fetch_n, 1), e->stream));
+        HIPCHK(hipMemsetAsync(P.w_dirty, 0, (size_t)P.n_in_total, e->stream));
+        hipLaunchKernelGGL(k_skip_walk, dim3(P.n_units), dim3(std::min(e->coop, 64)), 0, e->stream, P, (const SkipUnitDev*)e->skip_units);
+        HIPCHK(hipEventRecord(e->ev[EV_SEL], e->stream));
+        HIPCHK(hipEventRecord(e->ev[EV_REPAIR], e->stream));
+        hipLaunchKernelGGL(k_finalize, tiles, tb, 0, e->stream, P);
+        HIPCHK(hipEventRecord(e->ev[EV_END], e->stream));
+        HIPCHK(hipGetLastError());
+        int32_t kerr0 = 0;
+        HIPCHK(hipMemcpyAsync(&kerr0, P.err, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (kerr0 != 0) return fail(e, kerr0, kernel_error_text(kerr0));
+        return TW_OK;
+    }
     HIPCHK(hipMemsetAsync(P.w_conf, 0, sizeof(int32_t) * (size_t)P.n_in_total, e->stream));
     hipLaunchKernelGGL(k_select_fast, tiles, tb, 0, e->stream, P);
     hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096)), dim3(std::min(e->coop, 64)), 0, e->stream, P);
@@ -412,10 +442,21 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         seg_in[(size_t)u] = (uint32_t)U.in_off;
         const uint8_t* dag = b->dag + dagi;
         for (int k = 0; k <= E; k++) U.ep_off[k] = b->ep_off[epi + k];
+        U.skip = b->skip != nullptr ? 1 : 0;
         for (int k = 0; k < E; k++) {
-            if (U.ep_off[k + 1] - U.ep_off[k] != n)
-                return fail(e, TW_ERR_UNSUPPORTED, "skip mode: an endpoint's span count differs from the number of incoming spans (traceweaver_v3.py:972,1155-1156)");
+            const int64_t m = U.ep_off[k + 1] - U.ep_off[k];
+            if (b->skip == nullptr && m != n)
+                return fail(e, TW_ERR_UNSUPPORTED, "an endpoint's span count differs from the number of incoming spans: a skip-mode unit (traceweaver_v3.py:972,1155-1156) needs tw_batch.skip");
+            if (b->skip != nullptr && (m > n || m < 0)) return fail(e, TW_ERR_ARG, "skip mode: an endpoint holds more spans than there are incoming spans");
             seg_out.push_back((uint32_t)U.ep_off[k]);
+        }
+        if (b->skip != nullptr) {
+            if (b->unit_time_scale != nullptr) return fail(e, TW_ERR_UNSUPPORTED, "skip mode takes integer microseconds");
+            const tw_skip_unit& K = b->skip[u];
+            if (K.n_tw < 1 || !K.tw_start || !K.pool || !K.dist) return fail(e, TW_ERR_ARG, "skip mode: incomplete tw_skip_unit");
+            if (K.n_tw > (0x7fffffff - TW_SKIP_BASE) / TW_SKIP_STRIDE) return fail(e, TW_ERR_ARG, "skip mode: too many time windows");
+            for (int64_t q = 0; q < (int64_t)E * K.n_tw; q++)
+                if (K.pool[q] < 0 || K.pool[q] > TW_SKIP_STRIDE) return fail(e, TW_ERR_ARG, "skip mode: a pool holds more than TW_SKIP_STRIDE skip spans");
         }
         for (int q = 0; q < E; q++) {
             uint8_t pm = 0, sm = 0;
@@ -540,9 +581,52 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(e->seg_gap, (int64_t)seg_gap_h.size()); ALLOC(e->seg_gap_end, (int64_t)seg_gap_end_h.size()); ALLOC(e->seg_gap_dst, (int64_t)seg_gap_dst_h.size());
     e->comp_cap = std::max(std::max(n_in_total, n_out_total), e->n_gap_scored);
     ALLOC(e->comp_a, e->comp_cap); ALLOC(e->comp_b, e->comp_cap);
+    // skip mode: per unit the start-ordered view of every endpoint list (TallySkipSpans sorts the lists in place,
+    // traceweaver_v3.py:968-971; the top_k_2 enumeration walks that order), time windows, pools, (mean, std) table, draw counters
+    e->skip_mode = b->skip != nullptr;
+    std::vector<int32_t> perm_h, pool_h;
+    std::vector<int64_t> tw_h;
+    std::vector<double> dist_h;
+    std::vector<SkipUnitDev> skip_h;
+    std::vector<int64_t> sk_tw_off, sk_pool_off, sk_dist_off;
+    if (e->skip_mode) {
+        perm_h.resize((size_t)n_out_total);
+        for (int u = 0; u < b->n_units; u++) {
+            const UnitDev& U = e->units[(size_t)u];
+            const tw_skip_unit& K = b->skip[u];
+            for (int k = 0; k < U.E; k++) {
+                const int64_t a = U.ep_off[k], m = U.ep_off[k + 1] - a;
+                std::vector<int32_t> idx((size_t)m);
+                for (int64_t q = 0; q < m; q++) idx[(size_t)q] = (int32_t)q;
+                std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return b->out_start[a + x] < b->out_start[a + y]; });
+                std::copy(idx.begin(), idx.end(), perm_h.begin() + a);
+            }
+            sk_tw_off.push_back((int64_t)tw_h.size()); sk_pool_off.push_back((int64_t)pool_h.size()); sk_dist_off.push_back((int64_t)dist_h.size());
+            tw_h.insert(tw_h.end(), K.tw_start, K.tw_start + K.n_tw);
+            pool_h.insert(pool_h.end(), K.pool, K.pool + (int64_t)U.E * K.n_tw);
+            dist_h.insert(dist_h.end(), K.dist, K.dist + (int64_t)(U.E + 1) * (U.E + 1) * 2);
+        }
+        e->skip_fetch_n = (int64_t)pool_h.size();
+        ALLOC(e->skip_units, b->n_units); ALLOC(e->skip_perm, n_out_total); ALLOC(e->skip_tw, (int64_t)tw_h.size());
+        ALLOC(e->skip_pool, (int64_t)pool_h.size()); ALLOC(e->skip_dist, (int64_t)dist_h.size()); ALLOC(e->skip_fetch, e->skip_fetch_n);
+    }
 #undef ALLOC
     rc = arena_commit(e);
     if (rc != TW_OK) return rc;
+    if (e->skip_mode) {
+        for (int u = 0; u < b->n_units; u++) {
+            SkipUnitDev K{};
+            K.perm = e->skip_perm; K.tw_start = e->skip_tw + sk_tw_off[(size_t)u]; K.pool = e->skip_pool + sk_pool_off[(size_t)u];
+            K.dist = e->skip_dist + sk_dist_off[(size_t)u]; K.fetches = e->skip_fetch + sk_pool_off[(size_t)u]; K.n_tw = b->skip[u].n_tw;
+            skip_h.push_back(K);
+        }
+        HIPCHK(hipMemcpyAsync(e->skip_units, skip_h.data(), sizeof(SkipUnitDev) * skip_h.size(), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->skip_perm, perm_h.data(), sizeof(int32_t) * perm_h.size(), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->skip_tw, tw_h.data(), sizeof(int64_t) * tw_h.size(), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->skip_pool, pool_h.data(), sizeof(int32_t) * pool_h.size(), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->skip_dist, dist_h.data(), sizeof(double) * dist_h.size(), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));   // the staging vectors go out of scope
+    }
     HIPCHK(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 16, e->stream));
     HIPCHK(hipMemsetAsync(P.prof + 10, 0xff, sizeof(unsigned long long), e->stream));
     P.units = d_units; P.tiles = d_tiles;
@@ -601,6 +685,7 @@ int tw_run_pass1(tw_engine* e) {
 int tw_get_gaps(tw_engine* e, double* gaps) {
     if (e == nullptr || gaps == nullptr) return TW_ERR_ARG;
     if (e->state != ST_PASS1) return fail(e, TW_ERR_STATE, "tw_get_gaps is valid right after tw_run_pass1");
+    if (e->skip_mode) return fail(e, TW_ERR_STATE, "a skip-mode batch runs one pass (traceweaver_v3.py:1155-1156): there is no refit");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(gaps, e->P.gaps, sizeof(double) * e->n_gaps, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -610,6 +695,7 @@ int tw_get_gaps(tw_engine* e, double* gaps) {
 int tw_set_mixtures(tw_engine* e, const int32_t* mix_n, const double* mix_p) {
     if (e == nullptr || mix_n == nullptr || mix_p == nullptr) return TW_ERR_ARG;
     if (e->state < ST_PASS1) return fail(e, TW_ERR_STATE, "tw_set_mixtures before tw_run_pass1");
+    if (e->skip_mode) return fail(e, TW_ERR_STATE, "a skip-mode batch runs one pass (traceweaver_v3.py:1155-1156): there is no second pass");
     HIPCHK(hipSetDevice(e->device));
     for (int64_t q = 0; q < e->n_slots; q++)
         if (mix_n[q] < 0 || mix_n[q] > TW_MAX_COMP) return fail(e, TW_ERR_ARG, "mixture component count outside [0, TW_MAX_COMP]");
@@ -626,6 +712,7 @@ int tw_set_mixtures(tw_engine* e, const int32_t* mix_n, const double* mix_p) {
 int tw_fit_mixtures(tw_engine* e) {
     if (e == nullptr) return TW_ERR_ARG;
     if (e->state != ST_PASS1) return fail(e, TW_ERR_STATE, "tw_fit_mixtures is valid right after tw_run_pass1");
+    if (e->skip_mode) return fail(e, TW_ERR_STATE, "a skip-mode batch runs one pass (traceweaver_v3.py:1155-1156): there is no refit");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
     size_t bytes = 0;
@@ -810,7 +897,7 @@ int tw_set_truth(tw_engine* e, const int32_t* true_child, const int32_t* in_trac
     for (const UnitDev& U : e->units) {
         const int32_t* t = true_child + U.ie_off;
         for (int64_t k = 0; k < (int64_t)U.E * U.n_in; k++)
-            if (t[k] < -1 || t[k] >= U.n_in) return fail(e, TW_ERR_ARG, "tw_set_truth: true_child outside [-1, n_in)");
+            if (t[k] < (e->skip_mode ? -2 : -1) || t[k] >= U.n_in) return fail(e, TW_ERR_ARG, "tw_set_truth: true_child outside [-1, n_in) (-2 = skipped, skip-mode batches only)");
     }
     if (in_trace != nullptr)
         for (int64_t k = 0; k < e->P.n_in_total; k++)
@@ -864,6 +951,35 @@ int tw_evaluate(tw_engine* e, int64_t* per_unit, uint8_t* trace_flags, int64_t* 
         per_unit[u * 4 + 3] = (int64_t)h[(size_t)u * 4 + 3];
     }
     if (e2e != nullptr) { e2e[0] = (int64_t)h[(size_t)nc - 2]; e2e[1] = (int64_t)h[(size_t)nc - 1]; }
+    return TW_OK;
+}
+
+int tw_build_distributions(tw_engine* e, int64_t n, const int64_t* start, const int64_t* dur, const uint8_t* ep, int64_t large_delay,
+                           int32_t E, int32_t* key_out, int64_t* sample_out) {
+    if (e == nullptr || n <= 0 || !start || !dur || !ep || !key_out || !sample_out || E < 1 || E > TW_MAX_EP) return TW_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    int64_t *d_s = nullptr, *d_d = nullptr, *d_v = nullptr;
+    uint8_t* d_e = nullptr;
+    int32_t* d_k = nullptr;
+    hipError_t s = hipMalloc((void**)&d_s, sizeof(int64_t) * (size_t)n);
+    if (s == hipSuccess) s = hipMalloc((void**)&d_d, sizeof(int64_t) * (size_t)n);
+    if (s == hipSuccess) s = hipMalloc((void**)&d_v, sizeof(int64_t) * (size_t)n);
+    if (s == hipSuccess) s = hipMalloc((void**)&d_e, (size_t)n);
+    if (s == hipSuccess) s = hipMalloc((void**)&d_k, sizeof(int32_t) * (size_t)n);
+    if (s == hipSuccess) s = hipMemcpyAsync(d_s, start, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, e->stream);
+    if (s == hipSuccess) s = hipMemcpyAsync(d_d, dur, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, e->stream);
+    if (s == hipSuccess) s = hipMemcpyAsync(d_e, ep, (size_t)n, hipMemcpyHostToDevice, e->stream);
+    if (s == hipSuccess) {
+        const int threads = e->coop >= 64 ? 256 : e->coop;
+        hipLaunchKernelGGL(k_build_distributions, dim3((unsigned)((n + threads - 1) / threads)), dim3((unsigned)threads), 0, e->stream,
+                           (const int64_t*)d_s, (const int64_t*)d_d, (const uint8_t*)d_e, n, large_delay, (int)E, d_k, d_v);
+        s = hipGetLastError();
+    }
+    if (s == hipSuccess) s = hipMemcpyAsync(key_out, d_k, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream);
+    if (s == hipSuccess) s = hipMemcpyAsync(sample_out, d_v, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream);
+    if (s == hipSuccess) s = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_s); (void)hipFree(d_d); (void)hipFree(d_v); (void)hipFree(d_e); (void)hipFree(d_k);
+    if (s != hipSuccess) return fail(e, TW_ERR_DEVICE, std::string("tw_build_distributions: ") + hipGetErrorString(s));
     return TW_OK;
 }
 

@@ -73,7 +73,10 @@ __global__ void __launch_bounds__(kTile) k_evaluate(Dev P, const int32_t* truth,
         const int n = P.tk_n[g];
         for (int k = 0; k < n && !topk; k++) {
             bool same = true;
-            for (int e = 0; e < U.E && same; e++) same = P.tk_idx[tk_index(U, k, e, i)] == truth[ie_index(U, e, i)];
+            for (int e = 0; e < U.E && same; e++) {
+                const int32_t x = P.tk_idx[tk_index(U, k, e, i)];
+                same = (x <= -TW_SKIP_BASE ? -2 : x) == truth[ie_index(U, e, i)];
+            }
             topk = same;
         }
         if (in_trace != nullptr) {

@@ -566,8 +566,13 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
                 const int64_t st = c.os[f][anchor];
                 if (st < tmax) tmax = st;
             }
-            c.lo[e] = bound_near<false>(c.os[e], n, c.in_start, i);
-            c.hi[e] = bound_near<true>(c.os[e], n, tmax, c.lo[e]) - 1;
+            if (U.skip) {   // lists as handed over, possibly out of order: exactly Python's bisect_left / bisect_right
+                c.lo[e] = lower_bound_i64(c.os[e], n, c.in_start);
+                c.hi[e] = upper_bound_i64(c.os[e], n, tmax) - 1;
+            } else {
+                c.lo[e] = bound_near<false>(c.os[e], n, c.in_start, i);
+                c.hi[e] = bound_near<true>(c.os[e], n, tmax, c.lo[e]) - 1;
+            }
         }
 #pragma unroll
         for (int e = 0; e < E; e++) { P.c_lo[ie_index(U, e, i)] = c.lo[e]; P.c_hi[ie_index(U, e, i)] = c.hi[e]; }
@@ -1946,7 +1951,10 @@ __global__ void k_finalize(Dev P) {
     const int c = P.chosen[U.in_off + i];
     if (P.rep[U.in_off + i]) P.leaves[U.in_off + i] = P.leaves_r[U.in_off + i];   // tuples of the top_k call on the remaining spans
     if (P.win_end[U.in_off + i] && P.w_dirty[U.in_off + P.wid[U.in_off + i]]) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 8 + 3], 1ull);
-    for (int e = 0; e < U.E; e++) P.parent[ie_index(U, e, i)] = c >= 0 ? cand_idx(P, U, i, c, e) : -1;
+    for (int e = 0; e < U.E; e++) {
+        const int32_t x = c >= 0 ? cand_idx(P, U, i, c, e) : -1;
+        P.parent[ie_index(U, e, i)] = x <= -TW_SKIP_BASE ? -2 : x;   // skip spans: ("Skip","Skip")
+    }
     if (c != 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 8 + 0], 1ull);  // traceweaver_v3.py:1201-1207
     if (c < 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 8 + 1], 1ull);   // traceweaver_v3.py:1217
     if (i == 0) P.unit_stats[(int64_t)Tl.unit * 8 + 2] = P.unit_nwin[Tl.unit];

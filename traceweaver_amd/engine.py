@@ -111,9 +111,11 @@ class Engine(object):
             raise EngineError(rc, self._lib.tw_last_error(self._h).decode())
 
     # ------------------------------------------------------------------------------------------
-    def load(self, units, batch_size=100, batch_size_mis=30):
-        """Copy a list of UnitArrays into HBM."""
+    def load(self, units, batch_size=100, batch_size_mis=30, skip=None):
+        """Copy a list of UnitArrays into HBM.  skip: None, or per unit a skipmode.SkipPlan (time windows, skip-span pools,
+        (mean, std) table) -- the batch then runs the reference's one-pass skip mode (run_pass1 only)."""
         self.units = list(units)
+        self.skip_mode = skip is not None
         in_off = np.zeros(len(units) + 1, dtype=np.int64)
         np.cumsum([u.n_in for u in units], out=in_off[1:])
         unit_E = np.array([u.E for u in units], dtype=np.int32)
@@ -137,10 +139,23 @@ class Engine(object):
         if any(scaled) and not all(scaled):
             raise ValueError("a batch holds either integer-microsecond units or load-scaled units, not both")
         arrays["unit_time_scale"] = np.array([u.time_scale for u in units], dtype=np.float64) if all(scaled) else None
+        skip_arr = None
+        if skip is not None:
+            if len(skip) != len(units):
+                raise ValueError("one skip plan per unit")
+            skip_arr = (_ffi.SkipUnit * len(units))()
+            for k, (u, sp) in enumerate(zip(units, skip)):
+                tw = np.ascontiguousarray(sp.tw_start, dtype=np.int64)
+                pool = np.ascontiguousarray(sp.pool, dtype=np.int32).reshape(u.E, len(tw))
+                dist = np.ascontiguousarray(sp.dist, dtype=np.float64).reshape(u.E + 1, u.E + 1, 2)
+                arrays["skip%d" % k] = (tw, pool, dist)
+                skip_arr[k] = _ffi.SkipUnit(len(tw), _vp(tw), _vp(pool), _vp(dist))
+            arrays["skip"] = skip_arr
         self._keep = arrays
         b = _ffi.Batch(len(units), *[_vp(arrays[k]) for k in (
             "unit_in_off", "unit_E", "ep_off", "dag", "key_rank", "in_start", "in_end", "out_start", "out_end")],
-            batch_size, batch_size_mis, _ffi.TW_TOPK, _vp(arrays["unit_time_scale"]))
+            batch_size, batch_size_mis, _ffi.TW_TOPK, _vp(arrays["unit_time_scale"]),
+            ctypes.cast(skip_arr, ctypes.c_void_p) if skip_arr is not None else ctypes.c_void_p(0))
         self._check(self._lib.tw_load_batch(self._h, ctypes.byref(b), 0))
         self._in_off = in_off
         self._ie_off = np.concatenate([[0], np.cumsum([u.n_in * u.E for u in units])]).astype(np.int64)
@@ -276,6 +291,17 @@ class Engine(object):
             out.append(dag[p:p + int(e) * int(e)].reshape(int(e), int(e)).copy())
             p += int(e) * int(e)
         return out
+
+    def build_distributions(self, start, dur, ep, large_delay, E):
+        """The sweep of BuildDistributions (traceweaver_v3.py:120-169) on the device: per span of the merged, start-ordered
+        list the pair index a * (E + 1) + b its delay sample belongs to (-1 none) and the sample."""
+        start = np.ascontiguousarray(start, dtype=np.int64)
+        dur = np.ascontiguousarray(dur, dtype=np.int64)
+        ep = np.ascontiguousarray(ep, dtype=np.uint8)
+        key = np.empty(len(start), dtype=np.int32)
+        val = np.empty(len(start), dtype=np.int64)
+        self._check(self._lib.tw_build_distributions(self._h, len(start), _vp(start), _vp(dur), _vp(ep), int(large_delay), int(E), _vp(key), _vp(val)))
+        return key, val
 
     def hbm_copy_gbps(self, nbytes=1 << 30, iters=10):
         """Measured HBM rate of a plain streaming copy kernel on this device (read + written GB/s)."""

@@ -92,8 +92,6 @@ def unsupported(args):
                         % (args.predictor_indices, sorted(BASELINES), bad))
     if args.compressed:
         problems.append("--compressed 1")
-    if args.cache_rate != 0:
-        problems.append("--cache_rate %g (cache-hit injection = skip mode)" % args.cache_rate)
     if args.parallel or args.instrumented:
         problems.append("--parallel / --instrumented")
     return problems
@@ -150,6 +148,21 @@ def run(args):
     trace_id = lambda k: corpus.string(names[k])
     if args.compress_factor > 1:                                   # executor.py:1086-1097,1146-1148
         units = scale_load(units, args, trace_id, corpus)
+    skip_units = set()
+    if args.cache_rate > 0:                                        # executor.py:1150-1152: only the service named "frontend"
+        from . import skipmode
+        from .ingest import IngestedUnit
+
+        for k, u in enumerate(units):
+            if u.service != "frontend":
+                continue
+            if u.arrays.time_scale is not None:
+                raise SystemExit("--cache_rate with --compress_factor > 1 is not supported (skip mode takes integer microseconds)")
+            print("cache %: ", float(args.cache_rate) * 100)
+            arr, truth, kept = skipmode.cache_hits(u.arrays, u.true_parent, args.cache_rate)
+            units[k] = IngestedUnit(arr, truth, u.in_trace, u.service, u.in_ep, u.out_eps, u.in_rows,
+                                    [r[kept] if e == 0 else r for e, r in enumerate(u.out_rows)], u.process_id)
+            skip_units.add(k)
     key = lambda row: (trace_id(table["trace"][row]), corpus.string(table["span_id"][row]))
     seen = np.zeros(n_traces, dtype=bool)
     for u in units:
@@ -191,20 +204,43 @@ def run(args):
         if index == 10:
             eng = Engine(args.device, lib_path=args.engine_library)
             t1 = time.time()
-            eng.load([u.arrays for u in units])
-            eng.set_truth([u.true_parent for u in units], [u.in_trace for u in units], n_traces)
-            try:
+            plain = [k for k in range(len(units)) if k not in skip_units]
+            per, res = [None] * len(units), [None] * len(units)
+            flags = np.zeros((2, n_traces), dtype=np.uint8)
+            if plain:
+                eng.load([units[k].arrays for k in plain])
+                eng.set_truth([units[k].true_parent for k in plain], [units[k].in_trace for k in plain], n_traces)
+                try:
+                    eng.run_pass1()
+                except EngineError as ex:
+                    if ex.code == -7:   # TW_ERR_NAN_PARAMS, SURVEY.md hazard H3 (e.g. media_load75: 1500 files, 1001 traces kept)
+                        raise SystemExit("%s\nThe reference fails on this input too (scipy.stats.tstd of one batch mean is NaN, "
+                                         "traceweaver_v3.py:611). Keep a multiple-of-100-plus-anything-but-1 number of traces, "
+                                         "e.g. --max_traces 1000." % ex)
+                    raise
+                eng.fit_mixtures()
+                eng.run_pass2()
+                p_, _, f_ = eng.evaluate(trace_flags=True)
+                r_ = eng.results(2, fields=("parent", "unit_stats"))
+                flags = np.maximum(flags, f_)
+                for k, a, b in zip(plain, p_, r_):
+                    per[k], res[k] = a, b
+            if skip_units:   # services short of outgoing spans: the reference's one-pass skip mode (traceweaver_v3.py:1155-1156)
+                from . import skipmode
+
+                sk = sorted(skip_units)
+                plans, windows = [], []
+                for k in sk:   # one predictor object solves the services in turn and never clears its time windows (hazard H8)
+                    plans.append(skipmode.plan(eng, units[k].arrays, prior_windows=windows))
+                    windows = list(plans[-1].windows)
+                eng.load([units[k].arrays for k in sk], skip=plans)
+                eng.set_truth([units[k].true_parent for k in sk], [units[k].in_trace for k in sk], n_traces)
                 eng.run_pass1()
-            except EngineError as ex:
-                if ex.code == -7:   # TW_ERR_NAN_PARAMS, SURVEY.md hazard H3 (e.g. media_load75: 1500 files, 1001 traces kept)
-                    raise SystemExit("%s\nThe reference fails on this input too (scipy.stats.tstd of one batch mean is NaN, "
-                                     "traceweaver_v3.py:611). Keep a multiple-of-100-plus-anything-but-1 number of traces, "
-                                     "e.g. --max_traces 1000." % ex)
-                raise
-            eng.fit_mixtures()
-            eng.run_pass2()
-            per, _, flags = eng.evaluate(trace_flags=True)
-            res = eng.results(2, fields=("parent", "unit_stats"))
+                p_, _, f_ = eng.evaluate(trace_flags=True)
+                r_ = eng.results(1, fields=("parent", "unit_stats"))
+                flags = np.maximum(flags, f_)
+                for k, a, b in zip(sk, p_, r_):
+                    per[k], res[k] = a, b
             unproven = sum(r["budget_windows"] for r in res)
             if unproven:
                 print("WARNING: %d window(s) hit the node budget of the exact selection search: their selection is the best one found, "

@@ -10,9 +10,9 @@ in its predictor table (executor.py:888-900) and everything downstream (accuracy
 plots) runs unchanged -- see INTEGRATION.md.  Spans are only read through `.start_mus`,
 `.duration_mus` and `.GetId()`; (trace_id, span_id) keys never reach the device.
 
-Only the no-skip mode of the reference is accelerated (every endpoint has exactly one outgoing span per
-incoming span; all BASELINE.json configs).  The cache-hit / skip experiments (exp2) raise
-NotImplementedError here rather than silently falling back to a CPU path.
+Services whose endpoints all hold one outgoing span per incoming span run the two passes with the refit in between;
+a service that is short of outgoing spans at some endpoint (the cache-hit experiments, exp2) runs the reference's
+one-pass skip mode (traceweaver_v3.py:820-989,1155-1156; csrc/tw_skip.h): assignments may then be ('Skip', 'Skip').
 """
 import threading
 import warnings
@@ -23,6 +23,7 @@ from . import gmm
 from .engine import Engine, UnitArrays
 
 NA = ("NA", "NA")
+SKIP = ("Skip", "Skip")
 
 
 def pack_unit(in_spans, out_span_partitions, out_eps, invocation_graph):
@@ -93,6 +94,7 @@ class TraceWeaverGPU(object):
                                         # (executor.py:1015-1023) may call one predictor instance from several threads
         self.last_timing = {}
         self.last_stats = {}            # counters of the last call, incl. budget_windows (selection not proven optimal)
+        self._time_windows = []         # the reference never clears self.time_windows between services (SURVEY.md hazard H8)
 
     # ------------------------------------------------------------------------------------------
     def _replay_true_fit(self, unit, true_parent):
@@ -137,6 +139,36 @@ class TraceWeaverGPU(object):
             return self._find_assignments(method, process, in_span_partitions, out_span_partitions, parallel, instrumented_hops,
                                           true_assignments, invocation_graph, true_skips, true_dist)
 
+    def _find_assignments_skip(self, unit, in_ids, out_ids, out_eps, out_span_partitions, true_assignments):
+        from . import skipmode
+
+        if unit.time_scale is not None:
+            raise NotImplementedError("skip mode on load-scaled (float) timestamps")
+        eng = self._engine
+        plan = skipmode.plan(eng, unit, prior_windows=self._time_windows)
+        self._time_windows = list(plan.windows)
+        eng.load([unit], skip=[plan])
+        eng.run_pass1()
+        self.last_timing = {"pass1": eng.timing()}
+        r = eng.results(1)[0]
+        n_in = unit.n_in
+        pick = lambda ids, x: ids[x] if x >= 0 else (SKIP if x <= -2 else NA)
+        all_assignments, all_topk_assignments = {}, {}
+        for k, ep in enumerate(out_eps):
+            par = r["parent"][k]
+            all_assignments[ep] = {in_ids[i]: pick(out_ids[k], int(par[i])) for i in range(n_in)}
+            tk = r["topk_idx"][:, k, :]
+            all_topk_assignments[ep] = {in_ids[i]: [pick(out_ids[k], -2 if tk[j, i] < -1 else int(tk[j, i])) for j in range(int(r["topk_n"][i]))]
+                                        for i in range(n_in)}
+        per_span_candidates = {}
+        for ep in out_span_partitions.keys():                     # traceweaver_v3.py:1096-1098
+            for key in true_assignments[ep].keys():
+                per_span_candidates[key] = 0
+        for i, sid in enumerate(in_ids):
+            per_span_candidates[sid] = int(r["leaves"][i])
+        self.last_stats = {k: r[k] for k in ("not_best_count", "cnt_unassigned", "n_windows", "repaired_windows", "budget_windows")}
+        return all_assignments, all_topk_assignments, r["not_best_count"], n_in, per_span_candidates, r["cnt_unassigned"]
+
     def _find_assignments(self, method, process, in_span_partitions, out_span_partitions, parallel, instrumented_hops,
                           true_assignments, invocation_graph, true_skips=False, true_dist=False):
         assert len(in_span_partitions) == 1                       # traceweaver_v3.py:1088
@@ -147,14 +179,11 @@ class TraceWeaverGPU(object):
         in_ep, in_spans = list(in_span_partitions.items())[0]
         out_eps = list(nx.topological_sort(invocation_graph))     # traceweaver_v1.py:39
         n_in = len(in_spans)
-        for ep in out_eps:
-            if len(out_span_partitions[ep]) != n_in:
-                raise NotImplementedError(
-                    "skip mode (endpoint %r has %d spans for %d incoming spans, traceweaver_v3.py:972) is not "
-                    "accelerated; use the reference predictor for the cache-hit experiments" % (ep, len(out_span_partitions[ep]), n_in))
         unit = pack_unit(in_spans, out_span_partitions, out_eps, invocation_graph)
         in_ids = [s.GetId() for s in in_spans]
         out_ids = [[s.GetId() for s in out_span_partitions[ep]] for ep in out_eps]
+        if any(len(out_span_partitions[ep]) != n_in for ep in out_eps):   # traceweaver_v3.py:972,1155-1156: one pass with skip spans
+            return self._find_assignments_skip(unit, in_ids, out_ids, out_eps, out_span_partitions, true_assignments)
         true_parent = None
         if self.fit == "sklearn" and self.replay_true_fit and true_assignments is not None:
             true_parent = np.full((unit.E, n_in), -1, dtype=np.int64)
