@@ -1040,7 +1040,7 @@ int tw_assign_service(tw_engine* e, int32_t n_in, const int64_t* in_start, const
     tw_batch b;
     b.n_units = 1; b.unit_in_off = in_off; b.unit_E = &E; b.ep_off = out_off; b.dag = dag; b.key_rank = key_rank;
     b.in_start = in_start; b.in_end = in_end; b.out_start = out_start; b.out_end = out_end;
-    b.batch_size = 100; b.batch_size_mis = 30; b.topk = TW_TOPK; b.unit_time_scale = nullptr;
+    b.batch_size = 100; b.batch_size_mis = 30; b.topk = TW_TOPK; b.unit_time_scale = nullptr; b.skip = nullptr;
     int rc = tw_load_batch(e, &b, 0);
     if (rc == TW_OK) rc = tw_run_pass1(e);
     if (rc == TW_OK && mix_n != nullptr) {
