@@ -23,6 +23,12 @@ Workloads (--workload):
            scaling: total work is fixed.  With --verify rank 0 also solves the whole slice alone and the gathered
            parents must equal that result.
 
+  media-split  within-service sharding: ONE media-shape graph whose six services hold --n-in x --replicas requests each;
+           every service is cut at idle moments into one part per rank (sharding.split_points / split_unit), the parts'
+           gap samples are all-gathered between the passes and every rank refits on the union
+           (sharding.refit_split_services), parents are gathered at the end.  Strong scaling; bit-identical to the
+           unsplit run (--verify 1 checks it on rank 0).
+
 N > 1: `python bench.py --gpus N` starts N ranks itself (re-exec under torch.distributed.run on 127.0.0.1); when the
 driver has already started the ranks (RANK / WORLD_SIZE in the environment) --gpus must equal WORLD_SIZE.  One process
 per GPU, rank r -> device LOCAL_RANK; the media / nodejs workloads have no data-path collective (units are
@@ -50,7 +56,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="media", choices=["media", "nodejs", "alibaba"])
+    ap.add_argument("--workload", default="media", choices=["media", "nodejs", "alibaba", "media-split"])
     ap.add_argument("--n-in", type=int, default=100000, help="requests per service unit (media / nodejs)")
     ap.add_argument("--replicas", type=int, default=4, help="copies of the service graph per GPU (media / nodejs)")
     ap.add_argument("--concurrency", type=float, default=None, help="mean requests in flight per service (default: 1.6 media, 4 nodejs, 1.3 alibaba)")
@@ -109,6 +115,12 @@ def make_units(args, seed, n_in=None, replicas=None, total_spans=None):
 
     n_in = args.n_in if n_in is None else n_in
     replicas = args.replicas if replicas is None else replicas
+    if args.workload == "media-split":
+        conc = 1.6 if args.concurrency is None else args.concurrency
+        u, t = synth.make_workload(seed, n_in * replicas, services=synth.MEDIA_SERVICES, replicas=1, concurrency=conc)
+        name = "media_microservices shape, ONE graph (6 services, %d requests each), every service split over the ranks at idle moments, concurrency %.1f" % (
+            n_in * replicas, conc)
+        return u, t, name
     if args.workload == "media":
         conc = 1.6 if args.concurrency is None else args.concurrency
         u, t = synth.make_workload(seed, n_in, services=synth.MEDIA_SERVICES, replicas=replicas, concurrency=conc)
@@ -266,9 +278,22 @@ def main():
     from traceweaver_amd import sharding
     from traceweaver_amd.engine import Engine
 
-    strong = args.workload == "alibaba"
+    strong = args.workload in ("alibaba", "media-split")
+    split = args.workload == "media-split"
     all_units, all_truth, wl_name = make_units(args, 1000 + (0 if strong else rank))
+    whole_units, whole_truth = all_units, all_truth
+    part_service, part_order, part_base = [], [], []
+    if split:   # every service in `world` parts (fewer if it has too few idle block boundaries)
+        parts, ptruth = [], []
+        for sidx, (u, tp) in enumerate(zip(whole_units, whole_truth)):
+            cuts = sharding.split_points(u, world)
+            edges = [0] + cuts + [u.n_in]
+            for k, p in enumerate(sharding.split_unit(u, cuts)):
+                parts.append(p); part_service.append(sidx); part_order.append(k); part_base.append(edges[k])
+                ptruth.append(np.where(tp[:, edges[k]:edges[k + 1]] >= 0, tp[:, edges[k]:edges[k + 1]] - edges[k], -1).astype(np.int32))
+        all_units, all_truth = parts, ptruth
     eng = Engine(device, lib_path=args.lib)
+    fit_eng = Engine(device, lib_path=args.lib) if split else None
     if strong:
         # measured work per unit: leaves enumerated by a pass over the whole slice would need a first run; the static
         # estimate is spans x endpoints, refined with the measured leaves of the warm-up pass below
@@ -294,7 +319,16 @@ def main():
         sync()
 
     def step():
-        t1, t2, res = one_step(eng, args.fit)
+        if split:   # pass 1 -> gap rows of all parts on every rank -> the same refit everywhere -> pass 2
+            eng.run_pass1()
+            t1 = eng.timing()
+            sharding.refit_split_services(eng, fit_eng, mine, part_service, part_order, whole_units, dist=dist, device=red_dev)
+            eng.run_pass2()
+            t2 = eng.timing()
+            t2["fit"] = fit_eng.timing()["fit"]
+            res = eng.evaluate()
+        else:
+            t1, t2, res = one_step(eng, args.fit)
         gathered = None
         if strong:  # the exchange step of the sharded slice: parents of every service on every rank
             local = [r["parent"] for r in eng.results(2, fields=("parent",))]
@@ -362,12 +396,19 @@ def main():
         for k, p in zip(mine, host):
             assert np.array_equal(gathered[k], p["parent"]), "gathered parents differ from the local result"
         assert all(g is not None for g in gathered), "the gather left a unit out"
-        if args.verify and rank == 0 and world > 1:
-            eng.load(all_units)
-            eng.set_truth(all_truth)
+        if args.verify and rank == 0 and (world > 1 or split):
+            eng.load(whole_units)
+            eng.set_truth(whole_truth)
             one_step(eng, args.fit)
             alone = eng.results(2, fields=("parent",))
-            verified = all(np.array_equal(g, a["parent"]) for g, a in zip(gathered, alone))
+            if split:   # stitch the parts of every service
+                stitched = []
+                for sidx in range(len(whole_units)):
+                    ks = sorted((k for k in range(len(all_units)) if part_service[k] == sidx), key=lambda k: part_order[k])
+                    stitched.append(np.concatenate([np.where(gathered[k] >= 0, gathered[k] + part_base[k], -1) for k in ks], axis=1))
+                verified = all(np.array_equal(g, a["parent"]) for g, a in zip(stitched, alone))
+            else:
+                verified = all(np.array_equal(g, a["parent"]) for g, a in zip(gathered, alone))
             assert verified, "sharded result differs from the single-GPU result"
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

@@ -128,6 +128,13 @@ int tw_run_pass1(tw_engine *e);
  * `gaps` holds sum_u nslot_u * n_in_u doubles, unit after unit. */
 int tw_get_gaps(tw_engine *e, double *gaps);
 
+/* The other direction (layout of tw_get_gaps): gap samples for tw_fit_mixtures that were not produced by this engine's
+ * pass 1 -- a service whose requests were solved in parts (on several GPUs) is refitted on the union of the parts'
+ * samples, exactly as the reference fits one mixture per edge over the whole service (traceweaver_v3.py:1221-1222):
+ * load a unit of the service's shape, hand over the gathered rows, tw_fit_mixtures, tw_get_mixtures
+ * (traceweaver_amd/sharding.py).  The fit depends only on the multiset of samples of a row. */
+int tw_set_gaps(tw_engine *e, const double *gaps);
+
 /* Mixtures for pass 2 (the fitted sklearn GaussianMixture objects of traceweaver_v3.py:784-786):
  * mix_n[sum_u nslot_u] components per slot (0 = "(0,0)" fallback, traceweaver_v3.py:765-766),
  * mix_p[sum_u nslot_u][TW_MAX_COMP][3] = weight, mean, precision_cholesky. */

@@ -189,3 +189,80 @@ def test_bench_alibaba_slice_sharded_over_two_ranks_equals_one(emu_lib):
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["sharded_equals_single_gpu"] is True
     assert sum(r["config"]["spans_per_gpu"]) == r["config"]["spans_total"]
     assert r["budget_windows"] == 0
+
+
+def _split_worker(rank, world, port, q, lib_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      TW_TILE="1", TW_COOP_THREADS="1")
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    import torch.distributed as dist
+
+    from traceweaver_amd import sharding, synth
+    from traceweaver_amd.engine import Engine
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    units, _ = synth.make_workload(21, 5000, services=["chain3", "par2"], concurrency=1.6)
+    parts, psvc, pord, pbase = [], [], [], []
+    for s, u in enumerate(units):
+        cuts = sharding.split_points(u, world)
+        for k, p in enumerate(sharding.split_unit(u, cuts)):
+            parts.append(p); psvc.append(s); pord.append(k); pbase.append(([0] + cuts)[k])
+    mine = sharding.shard_units([sharding.unit_cost(p) for p in parts], world)[rank]
+    eng, fit_eng = Engine(0, lib_path=lib_path), Engine(0, lib_path=lib_path)
+    eng.load([parts[k] for k in mine])
+    eng.run_pass1()
+    p1 = [r["parent"] for r in eng.results(1, fields=("parent",))]
+    sharding.refit_split_services(eng, fit_eng, mine, psvc, pord, units, dist=dist)      # all-gather of the gap rows, same fit on every rank
+    eng.run_pass2()
+    p2 = [r["parent"] for r in eng.results(2, fields=("parent",))]
+    full1 = sharding.gather_parents(p1, mine, len(parts), dist=dist)
+    full2 = sharding.gather_parents(p2, mine, len(parts), dist=dist)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, mine, psvc, pbase, [a.tolist() for a in full1], [a.tolist() for a in full2]))
+
+
+def test_one_service_split_over_two_ranks_equals_the_unsplit_run(emu_lib):
+    """Within-service sharding: every service is cut in two at an idle moment on a block boundary, rank r solves its
+    parts, the parts' gap rows are all-gathered between the passes and every rank runs the same device refit on the
+    union; the stitched parent arrays of both passes equal the single-process, unsplit run bit for bit."""
+    from traceweaver_amd import synth
+    from traceweaver_amd.engine import Engine
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q, emu_lib)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    units, _ = synth.make_workload(21, 5000, services=["chain3", "par2"], concurrency=1.6)
+    eng = Engine(0, lib_path=emu_lib)
+    eng.load(units)
+    eng.run_pass1()
+    want1 = [r["parent"] for r in eng.results(1, fields=("parent",))]
+    eng.fit_mixtures()
+    eng.run_pass2()
+    want2 = [r["parent"] for r in eng.results(2, fields=("parent",))]
+    eng.close()
+    _, _, psvc, pbase, _, _ = got[0]
+    assert len(psvc) == 4 and sorted(k for g in got for k in g[1]) == [0, 1, 2, 3] and all(len(g[1]) > 0 for g in got)
+    for rank, mine, _, _, full1, full2 in got:
+        for full, want in ((full1, want1), (full2, want2)):
+            for s in range(len(units)):
+                sub = [np.array(full[k]) for k in range(len(psvc)) if psvc[k] == s]
+                base = [pbase[k] for k in range(len(psvc)) if psvc[k] == s]
+                stitched = np.concatenate([np.where(a >= 0, a + b, -1) for a, b in zip(sub, base)], axis=1)
+                assert np.array_equal(stitched, want[s])
+
+
+def test_bench_media_split_over_two_ranks_equals_one(emu_lib):
+    """bench.py --workload media-split: six services, each cut in two at an idle moment, gap rows all-gathered between the
+    passes, parents gathered at the end; rank 0 re-solves the unsplit services and the stitched result must be identical."""
+    r = _run_bench(emu_lib, "--gpus", "2", "--backend", "gloo", "--workload", "media-split", "--n-in", "1200", "--replicas", "2", "--verify", "1")
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["sharded_equals_single_gpu"] is True
+    assert sum(r["config"]["spans_per_gpu"]) == r["config"]["spans_total"] and min(r["config"]["spans_per_gpu"]) > 0.3 * r["config"]["spans_total"]

@@ -692,6 +692,17 @@ int tw_get_gaps(tw_engine* e, double* gaps) {
     return TW_OK;
 }
 
+int tw_set_gaps(tw_engine* e, const double* gaps) {
+    if (e == nullptr || gaps == nullptr) return TW_ERR_ARG;
+    if (e->state < ST_LOADED) return fail(e, TW_ERR_STATE, "tw_set_gaps before tw_load_batch");
+    if (e->skip_mode) return fail(e, TW_ERR_STATE, "a skip-mode batch runs one pass (traceweaver_v3.py:1155-1156): there is no refit");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->P.gaps, gaps, sizeof(double) * e->n_gaps, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->state = ST_PASS1;
+    return TW_OK;
+}
+
 int tw_set_mixtures(tw_engine* e, const int32_t* mix_n, const double* mix_p) {
     if (e == nullptr || mix_n == nullptr || mix_p == nullptr) return TW_ERR_ARG;
     if (e->state < ST_PASS1) return fail(e, TW_ERR_STATE, "tw_set_mixtures before tw_run_pass1");

@@ -176,6 +176,14 @@ class Engine(object):
         self._check(self._lib.tw_get_gaps(self._h, _vp(g)))
         return [g[self._gap_off[k]:self._gap_off[k + 1]].reshape(u.nslot, u.n_in) for k, u in enumerate(self.units)]
 
+    def set_gaps(self, gaps):
+        """Per unit [nslot, n_in] gap samples (NaN = none) in place of the ones pass 1 produced: the input of fit_mixtures
+        for a service whose requests were solved in parts (traceweaver_amd/sharding.py)."""
+        g = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in gaps]))
+        if len(g) != self._gap_off[-1]:
+            raise ValueError("gap rows do not match the loaded batch")
+        self._check(self._lib.tw_set_gaps(self._h, _vp(g)))
+
     def set_mixtures(self, mix_n, mix_p):
         """mix_n / mix_p: per unit arrays [nslot] int32 and [nslot, 5, 3] (weight, mean, precision_cholesky)."""
         n = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int32).ravel() for a in mix_n]), dtype=np.int32)

@@ -86,3 +86,107 @@ def end_to_end_accuracy(trace_flags, dist=None, device="cpu"):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         flags = t.cpu().numpy()
     return int((flags[0] == 0).sum()), int((flags[1] == 0).sum()), int(flags.shape[1])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# One service on several GPUs (BASELINE.json north_star: "(service, time-window) subproblems ...
+# all-gather ... to stitch").  What couples the requests of a service in the reference:
+#   * windows and span consumption (traceweaver_v3.py:1020-1078, traceweaver_v1.py:457-463): nothing crosses a moment at
+#     which no request is in flight -- every earlier request has ended, so has every call it made (containment), the
+#     candidate sets on both sides are disjoint (a perfect cut, :1024-1039) and no later request can use an earlier span;
+#   * the per-100-request Gaussian parameters of pass 1 (:1173-1178, :580-646): rank slices of the sorted lists -- a cut
+#     at a multiple of 100 requests keeps every block whole, and at an idle moment the first i spans of every endpoint
+#     list are exactly the calls of the first i requests;
+#   * the mixture refit between the passes (:1221-1222): one fit per edge over the gap samples of the whole service --
+#     the one exchange step: the parts' gap rows are all-gathered and every rank runs the same deterministic device fit
+#     on the union (it depends only on the multiset of samples), then hands the table to its parts.
+# So a service is cut at idle moments that fall on block boundaries into parts that are ordinary units; the parts of
+# all services are spread over the ranks like whole services are; results are bit-identical to the unsplit run.
+
+
+def split_points(unit, parts, batch_size=100):
+    """Request indices (multiples of batch_size at which no earlier request is still in flight) nearest to the
+    equal-size targets; fewer than parts - 1 if the service has too few idle block boundaries."""
+    n = unit.n_in
+    if parts <= 1 or n < 2 * batch_size:
+        return []
+    run_max = np.maximum.accumulate(unit.in_end)
+    idx = np.arange(batch_size, n - 1, batch_size)
+    idx = idx[(run_max[idx - 1] < unit.in_start[idx]) & (idx < n - 1)]
+    idx = idx[(n - idx) % batch_size != 1]          # a last block of one request has no variance (hazard H3), in neither part
+    cuts = []
+    for k in range(1, parts):
+        if len(idx) == 0:
+            break
+        c = int(idx[np.argmin(np.abs(idx - k * n / parts))])
+        if c not in cuts and (not cuts or c > cuts[-1]):
+            cuts.append(c)
+    return cuts
+
+
+def split_unit(unit, cuts):
+    """The parts of `unit` between the cut indices as units of their own (views into the same arrays)."""
+    from .engine import UnitArrays
+
+    if unit.time_scale is not None:
+        raise ValueError("load-scaled units are split before scaling")
+    edges = [0] + list(cuts) + [unit.n_in]
+    parts = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        off = np.arange(unit.E + 1, dtype=np.int64) * (b - a)
+        os_ = np.concatenate([unit.out_start[unit.out_off[e] + a:unit.out_off[e] + b] for e in range(unit.E)])
+        oe_ = np.concatenate([unit.out_end[unit.out_off[e] + a:unit.out_off[e] + b] for e in range(unit.E)])
+        if any(int(unit.out_off[e + 1] - unit.out_off[e]) != unit.n_in for e in range(unit.E)):
+            raise ValueError("only no-skip units are split")
+        p = UnitArrays(unit.in_start[a:b], unit.in_end[a:b], off, os_, oe_, unit.dag, unit.key_rank)
+        if a > 0:   # the idle moment: everything before has ended before anything after starts
+            assert unit.in_end[:a].max() < unit.in_start[a] and all(
+                unit.out_end[unit.out_off[e]:unit.out_off[e] + a].max() < unit.out_start[unit.out_off[e] + a] for e in range(unit.E))
+        parts.append(p)
+    return parts
+
+
+def refit_split_services(engine, fit_engine, local_parts, part_service, part_order, service_units, dist=None, device="cpu"):
+    """The exchange step of split services.  `engine` holds this rank's parts (pass 1 done); local_parts = their global
+    part ids, part_service[p] = service of part p, part_order[p] = position of part p inside its service,
+    service_units[s] = the unsplit unit of service s (shape and size only).  Gathers the gap rows of all parts on every
+    rank, fits every service's edges on the union with the device fit (`fit_engine`, any engine of this rank) and sets
+    the tables of the local parts.  Returns {service: (mix_n, mix_p)}."""
+    gaps = engine.gaps()
+    rows = {p: g for p, g in zip(local_parts, gaps)}
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        import torch
+
+        world = dist.get_world_size()
+        head = np.array([[p, g.shape[0], g.shape[1]] for p, g in rows.items()], dtype=np.int64).reshape(-1, 3)
+        body = np.concatenate([g.ravel() for g in rows.values()]) if rows else np.zeros(0)
+        sizes = torch.tensor([head.shape[0], body.shape[0]], dtype=torch.int64, device=device)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes)
+        mh, mb = max(int(s[0]) for s in all_sizes), max(int(s[1]) for s in all_sizes)
+        h = torch.zeros((mh, 3), dtype=torch.int64, device=device)
+        h[:head.shape[0]] = torch.from_numpy(head).to(device)
+        bt = torch.zeros(mb, dtype=torch.float64, device=device)
+        bt[:body.shape[0]] = torch.from_numpy(body).to(device)
+        hs, bs = [torch.zeros_like(h) for _ in range(world)], [torch.zeros_like(bt) for _ in range(world)]
+        dist.all_gather(hs, h)
+        dist.all_gather(bs, bt)       # the gather of gap samples: 8 B per (scored edge, request), RCCL over xGMI with backend "nccl"
+        rows = {}
+        for r in range(world):
+            hr, br, pos = hs[r][:int(all_sizes[r][0])].cpu().numpy(), bs[r].cpu().numpy(), 0
+            for p, a, b in hr:
+                rows[int(p)] = br[pos:pos + int(a) * int(b)].reshape(int(a), int(b)).copy()
+                pos += int(a) * int(b)
+    tables = {}
+    services = sorted({part_service[p] for p in rows})
+    fit_engine.load([service_units[s] for s in services])
+    joined = []
+    for s in services:
+        mine = sorted((p for p in rows if part_service[p] == s), key=lambda p: part_order[p])
+        joined.append(np.concatenate([rows[p] for p in mine], axis=1))
+    fit_engine.set_gaps(joined)
+    fit_engine.fit_mixtures()
+    for s, (mn, mp) in zip(services, fit_engine.mixtures()):
+        tables[s] = (mn.copy(), mp.copy())
+    engine.set_mixtures([tables[part_service[p]][0] for p in local_parts], [tables[part_service[p]][1] for p in local_parts])
+    return tables
