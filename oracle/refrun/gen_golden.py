@@ -407,10 +407,51 @@ def run_dataset(name, rel_dir, fix):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def accuracy_band(names, seeds):
+    """The reference's own run-to-run spread (SURVEY.md hazard H9: its model-selection fits draw from numpy's global RNG):
+    the unmodified reference with several seeds per corpus -> tests/golden/ref_accuracy_band.json
+    {corpus: {"seeds": [...], "e2e": [...], "e2e_topk": [...], "per_service": {service: [...]}}}."""
+    import json
+
+    global SEED
+    path = os.path.join(GOLDEN_DIR, "ref_accuracy_band.json")
+    band = json.load(open(path)) if os.path.exists(path) else {}
+    saved_dir = GOLDEN_DIR
+    for name, rel, fix in DATASETS:
+        if name not in names:
+            continue
+        rec = band.setdefault(name, {"seeds": [], "e2e": [], "e2e_topk": [], "per_service": {}})
+        for seed in seeds:
+            if seed in rec["seeds"]:
+                continue
+            SEED = seed
+            tmp = tempfile.mkdtemp(prefix="twband_")
+            globals()["GOLDEN_DIR"] = tmp
+            try:
+                run_dataset(name, rel, fix)
+                for f in sorted(os.listdir(tmp)):
+                    d = np.load(os.path.join(tmp, f))
+                    acc = float(np.all(d["final_parent"] == d["true_parent"], axis=0).mean())
+                    rec["per_service"].setdefault(str(d["process"]), []).append(acc)
+                    e2e, e2ek = float(d["e2e_accuracy"]), float(d["e2e_topk_accuracy"])
+                rec["seeds"].append(seed); rec["e2e"].append(e2e); rec["e2e_topk"].append(e2ek)
+            finally:
+                globals()["GOLDEN_DIR"] = saved_dir
+                shutil.rmtree(tmp, ignore_errors=True)
+            with open(path, "w") as fh:
+                json.dump(band, fh, indent=1, sort_keys=True)
+            print("band", name, "seed", seed, "e2e", e2e, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--band", nargs="*", default=None, help="corpora to run with several seeds (accuracy only)")
+    ap.add_argument("--seeds", nargs="*", type=int, default=[10, 1, 2, 3, 4])
     args = ap.parse_args()
+    if args.band is not None:
+        accuracy_band(args.band, args.seeds)
+        return
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     for name, rel, fix in DATASETS:
         if args.only and name not in args.only:

@@ -14,6 +14,9 @@ STRESS = [
     (9, 300, "chain3", 4, 1000), (10, 200, "fan6", 2, 1), (11, 257, "single", 1.2, 1), (12, 2, "chain2", 1, 1),
     (13, 513, "par2", 2, 1000), (14, 150, "chain5", 2.5, 1), (15, 120, "mix7", 1.5, 1), (16, 100, "mix8", 1.3, 1),
     (17, 120, "mix8", 1.2, 1000),
+    # deep call graphs with several candidates per endpoint: 10^5-10^6 grid points, up to 2.5e4 feasible tuples per request
+    # (the listed-prefix enumeration of k_enumerate_heavy)
+    (18, 150, "mix7", 3, 1000), (19, 120, "mix8", 2.5, 1000), (20, 200, "fan6", 3, 1),
 ]
 
 

@@ -565,6 +565,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.tk_score, n_in_total * kTopK); ALLOC(P.tkr_score, n_in_total * kTopK);
     ALLOC(P.c_lo, ie); ALLOC(P.c_hi, ie); ALLOC(P.c_bits, ie * kCandWords); ALLOC(P.parent, ie);
     ALLOC(P.gone, ie * kCandWords); ALLOC(P.leaves_r, n_in_total); ALLOC(P.round_changed, 1);
+    ALLOC(P.frontier, (int64_t)4096 * 2 * kFrontierCap);
     ALLOC(P.owner, n_out_total);
     ALLOC(P.gaps, gaps);
     ALLOC(P.unit_stats, (int64_t)P.n_units * 8); ALLOC(P.err, 1);

@@ -760,6 +760,14 @@ struct LdsHeap {
 //     same order as the reference, so it is bit-identical.
 constexpr int kPairPoolPerEp = 160;   // doubles of pair-term tables per endpoint (E <= 4); 2048 doubles (16 KB) for the deep call graphs
 constexpr int kGridTarget = 1024;     // grid points per prefix the split of the endpoints aims at (a prefix step costs about as much as five grid batches)
+// Deep call graphs with many candidates per endpoint (Alibaba shape: 7-8 endpoints x 10-14 candidates = 10^7-10^8 grid
+// points for 10^4-10^5 feasible tuples): walking the prefixes one after the other and testing a dense grid below each
+// leaves most lanes idle (0.1 % of the grid is feasible).  Such a span first builds the list of feasible prefixes of all
+// endpoints but the last, level by level, a wavefront of (prefix, candidate) pairs at a time, order kept by ballot
+// prefix sums (so the list is in the reference's depth-first order); the tuples are then the (prefix, last candidate)
+// pairs, again a wavefront at a time: every test is a lane's own, no prefix is visited twice.
+constexpr long long kFrontierGrid = 1 << 15;   // from this many grid points (staged candidates) on, and E >= 3
+constexpr int kFrontierCap = 1 << 15;          // prefixes per level and wavefront (two buffers of 8 B entries); beyond: the walk
 template <int E, int W>
 __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass, int mode) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
@@ -909,6 +917,59 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         // values) and watch for an equivalence that could matter (between the candidate, the evicted entry
         // or the kept entries).  If one shows up -- millisecond-granular data -- the span is redone with the
         // CPython heap replayed push by push in LDS (second attempt).
+        // feasible prefixes of the endpoints 0..E-2 (see kFrontierGrid), 8 bits per staged position
+        bool use_front = false;
+        int n_front = 0;
+        const unsigned long long* front = nullptr;
+        if constexpr (E >= 3) {
+            long long grid = 1;
+#pragma unroll
+            for (int e = 0; e < E; e++) grid = grid < (1ll << 40) ? grid * cn[e] : grid;
+            if (grid >= kFrontierGrid) {
+                unsigned long long* fa = P.frontier + (size_t)blockIdx.x * 2 * kFrontierCap;
+                unsigned long long* fb = fa + kFrontierCap;
+                for (int c = t; c < cn[0]; c += nt) fa[c] = (unsigned long long)c;
+                int nprev = cn[0];
+                use_front = true;
+                __threadfence_block();
+                wave_sync();
+#pragma unroll
+                for (int d = 1; d < E - 1; d++) {
+                    if (!use_front) continue;
+                    const int cd = cn[d];
+                    const uint32_t md = (uint32_t)((0x100000000ull + (unsigned)cd - 1ull) / (unsigned)cd);
+                    const long long total = (long long)nprev * cd;
+                    int nnext = 0;
+                    for (long long base = 0; base < total; base += nt) {
+                        const long long j = base + t;
+                        bool ok = j < total;
+                        unsigned long long ent = 0;
+                        int c = 0;
+                        if (ok) {
+                            const uint32_t f = cd == 1 ? (uint32_t)j : __umulhi((uint32_t)j, md);
+                            c = (int)((uint32_t)j - f * (uint32_t)cd);
+                            ent = fa[f];
+                            const int64_t st = ls[d][c];
+#pragma unroll
+                            for (int q = 0; q < E - 1; q++)
+                                if (q < d && ((dag_pm[d] >> q) & 1) && le[q][(ent >> (8 * q)) & 255ull] > st) ok = false;
+                        }
+                        const unsigned long long m = __ballot(ok);
+                        const int at = nnext + __popcll(m & ((1ull << t) - 1ull));
+                        if (ok && at < kFrontierCap) fb[at] = ent | ((unsigned long long)c << (8 * d));
+                        nnext += __popcll(m);
+                        if (nnext > kFrontierCap) break;   // uniform
+                    }
+                    if (nnext > kFrontierCap || total >= (1ll << 32)) use_front = false;
+                    unsigned long long* sw = fa; fa = fb; fb = sw;
+                    nprev = nnext;
+                    __threadfence_block();
+                    wave_sync();
+                }
+                front = fa;
+                n_front = nprev;
+            }
+        }
         LdsHeap<E, W> hp;
         hp.heap = sheap; hp.nheap = 0; hp.ls = ls;
         wave_sync();
@@ -933,6 +994,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             for (int e = E - 2; e >= 0; e--)
                 if (L == e + 1 && G < kHeavyThreads) { L = e; G *= cn[e]; }
         }
+        if (use_front) { L = E - 1; G = cn[E - 1]; }   // rows = the listed prefixes, one grid level
         // grid point -> staged positions of the levels L..E-1, last endpoint fastest: divisions by the wave-uniform
         // counts as multiplications (exact for g * (c - 1) < 2^32)
         uint32_t magic[E];
@@ -940,6 +1002,14 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         for (int e = 0; e < E; e++) magic[e] = (uint32_t)((0x100000000ull + (unsigned)cn[e] - 1ull) / (unsigned)cn[e]);
         auto grid_digits = [&](int g, int32_t (&x)[E]) {
             uint32_t rest = (uint32_t)g;
+            if (use_front) {   // g = row * cn[E-1] + last candidate; the row is a listed prefix
+                const uint32_t row = cn[E - 1] == 1 ? rest : __umulhi(rest, magic[E - 1]);
+                x[E - 1] = (int32_t)(rest - row * (uint32_t)cn[E - 1]);
+                const unsigned long long ent = front[row];
+#pragma unroll
+                for (int e = 0; e < E - 1; e++) x[e] = (int32_t)((ent >> (8 * e)) & 255ull);
+                return;
+            }
 #pragma unroll
             for (int e = E - 1; e >= 0; e--) {
                 if (e >= L) {
@@ -978,9 +1048,10 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         int d = 0;
         if (L > 0 && t == 0) px[0] = -1;
         wave_sync();
-        const bool once = (L == 0);
+        const bool once = (L == 0) || use_front;
+        const int Gtot = use_front ? n_front * G : G;
         while (once || d >= 0) {
-            if (L > 0) {  // next feasible prefix, every lane in lockstep (DfsTraverseX order)
+            if (L > 0 && !use_front) {  // next feasible prefix, every lane in lockstep (DfsTraverseX order)
                 int cd = 0;
                 uint32_t pmd = 0;
 #pragma unroll
@@ -1007,17 +1078,19 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                 wave_sync();
             }
             bool any = false;
-            for (int base = 0; base < G; base += nt) {
+            for (int base = 0; base < Gtot; base += nt) {
                 const int g = base + t;
-                bool ok = g < G;
+                bool ok = g < Gtot;
                 double score = 0.0;
                 int32_t x[E];
                 int64_t xs[E], xe[E];
                 grid_digits(ok ? g : 0, x);
 #pragma unroll
                 for (int e = 0; e < E; e++) {
-                    if (e < L) { xs[e] = pxs[e]; xe[e] = pxe[e]; }
-                    else {
+                    if (e < L) {
+                        if (use_front) { xs[e] = ls[e][x[e]]; xe[e] = le[e][x[e]]; }
+                        else { xs[e] = pxs[e]; xe[e] = pxe[e]; }
+                    } else {
                         const int64_t st = ls[e][x[e]];
 #pragma unroll
                         for (int p = 0; p < e; p++)
@@ -1053,7 +1126,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                     if (pass == 1 && mode == 0) {
 #pragma unroll
                         for (int e = 0; e < E; e++)
-                            if (e >= L) { const int r = lr[e][x[e]]; atomicOr(&sbits[e][r >> 6], 1ull << (r & 63)); }
+                            if (e >= L || use_front) { const int r = lr[e][x[e]]; atomicOr(&sbits[e][r >> 6], 1ull << (r & 63)); }
                     }
                 }
                 const unsigned long long feasible = __ballot(ok);
@@ -1152,12 +1225,12 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                 }
                 wave_sync();
             }
-            if (t == 0 && any && pass == 1 && mode == 0)
+            if (t == 0 && any && pass == 1 && mode == 0 && !use_front)
                 for (int e = 0; e < L; e++) {
                     const int r = lr[e][px[e]];
                     sbits[e][r >> 6] |= 1ull << (r & 63);
                 }
-            if (L == 0) break;
+            if (once) break;
         }
         if (attempt == 0) {  // the kept tuples themselves must be pairwise ordered
 #pragma unroll
