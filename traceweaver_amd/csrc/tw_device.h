@@ -97,6 +97,8 @@ struct Dev {
     uint64_t* c_bits;   // kCandWords words: spans that occur in >= 1 feasible tuple
     uint64_t* gone;     // kCandWords words: candidate spans taken by earlier windows when the span's current list was computed
     int64_t* leaves_r;  // per incoming span: tuples of the enumeration on the remaining spans (rep = 1)
+    unsigned long long* frontier_big;  // pool of kFrontierBigSlots longer lists for the spans that outgrow their wavefront's buffers
+    int32_t* frontier_big_next;
     unsigned long long* frontier;  // scratch of k_enumerate_heavy: per wavefront two lists of kFrontierCap feasible prefixes
     int32_t* round_changed;  // spans whose set of taken candidate spans changed in the current repair round
     int32_t* parent;

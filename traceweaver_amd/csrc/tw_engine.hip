@@ -292,6 +292,7 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
+    HIPCHK(hipMemsetAsync(P.frontier_big_next, 0, sizeof(int32_t), e->stream));
     launch_enumerate_all(e, pass, 0);
     HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
     if (pass == 1) {
@@ -345,6 +346,7 @@ int run_pass(tw_engine* e, int pass) {
         if (changed == 0) break;
         if (round >= kMaxRepairRounds) return fail(e, TW_ERR_DEVICE, "span consumption did not settle (more repair rounds than windows)");
         e->rounds = round + 1;
+        HIPCHK(hipMemsetAsync(P.frontier_big_next, 0, sizeof(int32_t), e->stream));
         launch_enumerate_all(e, pass, 1);
         hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096)), dim3(std::min(e->coop, 64)), 0, e->stream, P);
     }
@@ -565,7 +567,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.tk_score, n_in_total * kTopK); ALLOC(P.tkr_score, n_in_total * kTopK);
     ALLOC(P.c_lo, ie); ALLOC(P.c_hi, ie); ALLOC(P.c_bits, ie * kCandWords); ALLOC(P.parent, ie);
     ALLOC(P.gone, ie * kCandWords); ALLOC(P.leaves_r, n_in_total); ALLOC(P.round_changed, 1);
-    ALLOC(P.frontier, (int64_t)4096 * 2 * kFrontierCap);
+    ALLOC(P.frontier, (int64_t)4096 * 2 * kFrontierCap); ALLOC(P.frontier_big, (int64_t)kFrontierBigSlots * 2 * kFrontierBigCap); ALLOC(P.frontier_big_next, 1);
     ALLOC(P.owner, n_out_total);
     ALLOC(P.gaps, gaps);
     ALLOC(P.unit_stats, (int64_t)P.n_units * 8); ALLOC(P.err, 1);

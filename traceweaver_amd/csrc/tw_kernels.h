@@ -767,7 +767,14 @@ constexpr int kGridTarget = 1024;     // grid points per prefix the split of the
 // prefix sums (so the list is in the reference's depth-first order); the tuples are then the (prefix, last candidate)
 // pairs, again a wavefront at a time: every test is a lane's own, no prefix is visited twice.
 constexpr long long kFrontierGrid = 1 << 15;   // from this many grid points (staged candidates) on, and E >= 3
-constexpr int kFrontierCap = 1 << 15;          // prefixes per level and wavefront (two buffers of 8 B entries); beyond: the walk
+#ifndef TW_FRONTIER_CAP
+#define TW_FRONTIER_CAP (1 << 15)
+#define TW_FRONTIER_BIG_CAP (1 << 21)
+#define TW_FRONTIER_BIG_SLOTS 48
+#endif
+constexpr int kFrontierCap = TW_FRONTIER_CAP;          // prefixes per level and wavefront (two buffers of 8 B entries); beyond: a slot of the pool
+constexpr int kFrontierBigCap = TW_FRONTIER_BIG_CAP;       // ... of kFrontierBigSlots lists this long (32 MB a slot); beyond, or none left: the walk
+constexpr int kFrontierBigSlots = TW_FRONTIER_BIG_SLOTS;   // (the host-emulation build of the tests uses tiny sizes so that all three routes are exercised)
 template <int E, int W>
 __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass, int mode) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
@@ -927,47 +934,59 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             for (int e = 0; e < E; e++) grid = grid < (1ll << 40) ? grid * cn[e] : grid;
             if (grid >= kFrontierGrid) {
                 unsigned long long* fa = P.frontier + (size_t)blockIdx.x * 2 * kFrontierCap;
-                unsigned long long* fb = fa + kFrontierCap;
-                for (int c = t; c < cn[0]; c += nt) fa[c] = (unsigned long long)c;
-                int nprev = cn[0];
-                use_front = true;
-                __threadfence_block();
-                wave_sync();
-#pragma unroll
-                for (int d = 1; d < E - 1; d++) {
-                    if (!use_front) continue;
-                    const int cd = cn[d];
-                    const uint32_t md = (uint32_t)((0x100000000ull + (unsigned)cd - 1ull) / (unsigned)cd);
-                    const long long total = (long long)nprev * cd;
-                    int nnext = 0;
-                    for (long long base = 0; base < total; base += nt) {
-                        const long long j = base + t;
-                        bool ok = j < total;
-                        unsigned long long ent = 0;
-                        int c = 0;
-                        if (ok) {
-                            const uint32_t f = cd == 1 ? (uint32_t)j : __umulhi((uint32_t)j, md);
-                            c = (int)((uint32_t)j - f * (uint32_t)cd);
-                            ent = fa[f];
-                            const int64_t st = ls[d][c];
-#pragma unroll
-                            for (int q = 0; q < E - 1; q++)
-                                if (q < d && ((dag_pm[d] >> q) & 1) && le[q][(ent >> (8 * q)) & 255ull] > st) ok = false;
-                        }
-                        const unsigned long long m = __ballot(ok);
-                        const int at = nnext + __popcll(m & ((1ull << t) - 1ull));
-                        if (ok && at < kFrontierCap) fb[at] = ent | ((unsigned long long)c << (8 * d));
-                        nnext += __popcll(m);
-                        if (nnext > kFrontierCap) break;   // uniform
-                    }
-                    if (nnext > kFrontierCap || total >= (1ll << 32)) use_front = false;
-                    unsigned long long* sw = fa; fa = fb; fb = sw;
-                    nprev = nnext;
+                int cap = kFrontierCap;
+                for (int tries = 0; tries < 2; tries++) {
+                    unsigned long long* fb = fa + cap;
+                    for (int c = t; c < cn[0]; c += nt) fa[c] = (unsigned long long)c;
+                    int nprev = cn[0];
+                    use_front = true;
                     __threadfence_block();
                     wave_sync();
+#pragma unroll
+                    for (int d = 1; d < E - 1; d++) {
+                        if (!use_front) continue;
+                        const int cd = cn[d];
+                        const uint32_t md = (uint32_t)((0x100000000ull + (unsigned)cd - 1ull) / (unsigned)cd);
+                        const long long total = (long long)nprev * cd;
+                        int nnext = 0;
+                        for (long long base = 0; base < total; base += nt) {
+                            const long long j = base + t;
+                            bool ok = j < total;
+                            unsigned long long ent = 0;
+                            int c = 0;
+                            if (ok) {
+                                const uint32_t f = cd == 1 ? (uint32_t)j : __umulhi((uint32_t)j, md);
+                                c = (int)((uint32_t)j - f * (uint32_t)cd);
+                                ent = fa[f];
+                                const int64_t st = ls[d][c];
+#pragma unroll
+                                for (int q = 0; q < E - 1; q++)
+                                    if (q < d && ((dag_pm[d] >> q) & 1) && le[q][(ent >> (8 * q)) & 255ull] > st) ok = false;
+                            }
+                            const unsigned long long m = __ballot(ok);
+                            const int at = nnext + __popcll(m & ((1ull << t) - 1ull));
+                            if (ok && at < cap) fb[at] = ent | ((unsigned long long)c << (8 * d));
+                            nnext += __popcll(m);
+                            if (nnext > cap) break;   // uniform
+                        }
+                        if (nnext > cap || total >= (1ll << 32) / 128) use_front = false;
+                        unsigned long long* sw = fa; fa = fb; fb = sw;
+                        nprev = nnext;
+                        __threadfence_block();
+                        wave_sync();
+                    }
+                    front = fa;
+                    n_front = nprev;
+                    if (use_front || tries == 1) break;
+                    // the lists outgrew the wavefront's own buffers: once more in a slot of the pool, if one is left
+                    int slot = 0;
+                    if (t == 0) slot = atomicAdd(P.frontier_big_next, 1);
+                    slot = __shfl(slot, 0);
+                    if (slot >= kFrontierBigSlots) break;
+                    fa = P.frontier_big + (size_t)slot * 2 * kFrontierBigCap;
+                    cap = kFrontierBigCap;
                 }
-                front = fa;
-                n_front = nprev;
+                if (use_front && (long long)n_front * cn[E - 1] >= (1ll << 31) / 128) use_front = false;
             }
         }
         LdsHeap<E, W> hp;

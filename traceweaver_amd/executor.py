@@ -137,8 +137,11 @@ def run(args):
           % (counts["traces"], counts["spans"], time.time() - t0, counts["files_rejected"], counts["traces_filtered"], len(units), skipped))
     if not units:
         raise SystemExit("no service of this corpus can be solved (see the counts above)")
-    # `several_callers` is a skip the reference performs itself (executor.py:1126-1128); the others are services the
-    # reference does solve -- leaving them out silently would make the end-to-end figures look better than a reference run
+    # `several_callers` is a skip the reference performs itself (executor.py:1126-1128).  A service in which some request
+    # lacks a call to an endpoint (`skip_mode`) makes the reference raise KeyError in FindOrder (executor.py:242: GetGroundTruth,
+    # helpers/utils.py:22-32, leaves that request out of true_assignments[ep]) -- the only skip-mode inputs it solves are
+    # the ones --cache_rate makes after FindOrder; `too_small` / `cyclic_order` raise further down (traceweaver_v3.py:1119,
+    # nx.topological_sort).  Leaving such services out silently would make the figures look better than they are: stop
     lost = {k: v for k, v in skipped.items() if k != "several_callers" and v > 0}
     if lost and not args.allow_partial:
         raise SystemExit("%d service(s) of this corpus cannot be solved by the native chain: %s.  Re-run with --allow_partial 1 to "
