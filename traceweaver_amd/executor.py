@@ -65,6 +65,11 @@ def parse_args(argv=None):
     ap.add_argument("--replicas_file", type=q, default=None,
                     help="pickle {service: [replica ids]} for --compress_factor > 1 (default: data/misc/service_to_replica_new.pickle under --project_root, executor.py:912)")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--fit", default="device", choices=["device", "sklearn"],
+                    help="mixture refit between the passes: 'device' = deterministic EM on the GPU, all services in one batch; 'sklearn' = the "
+                         "reference's scikit-learn procedure on the host, service by service in the reference's order with numpy's global RNG "
+                         "seeded by --seed: reproduces a reference run started with np.random.seed(seed) (SURVEY.md hazard H9)")
+    ap.add_argument("--seed", type=int, default=10)
     ap.add_argument("--allow_partial", type=int, default=0, choices=[0, 1],
                     help="go on when services of the corpus cannot be solved here (skip mode, < 2 requests, cyclic call order); they are "
                          "recorded under 'left_out' in the confidence_scores pickle.  Default: stop, because the accuracy files would "
@@ -210,7 +215,21 @@ def run(args):
             plain = [k for k in range(len(units)) if k not in skip_units]
             per, res = [None] * len(units), [None] * len(units)
             flags = np.zeros((2, n_traces), dtype=np.uint8)
-            if plain:
+            if plain and args.fit == "sklearn":   # the reference's own refit, its RNG stream replayed service by service
+                from .predictor import TraceWeaverGPU
+
+                eng.close()
+                pred = TraceWeaverGPU({}, {}, device=args.device, fit="sklearn", lib_path=args.engine_library)
+                np.random.seed(args.seed)
+                for k in plain:
+                    u = units[k]
+                    _, r2 = pred.solve_arrays(u.arrays, u.true_parent, u.service)
+                    pred._engine.set_truth([u.true_parent], [u.in_trace], n_traces)
+                    p_, _, f_ = pred._engine.evaluate(trace_flags=True)
+                    flags = np.maximum(flags, f_)
+                    per[k], res[k] = p_[0], r2
+                eng = pred._engine
+            elif plain:
                 eng.load([units[k].arrays for k in plain])
                 eng.set_truth([units[k].true_parent for k in plain], [units[k].in_trace for k in plain], n_traces)
                 try:

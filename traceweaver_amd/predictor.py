@@ -139,6 +139,41 @@ class TraceWeaverGPU(object):
             return self._find_assignments(method, process, in_span_partitions, out_span_partitions, parallel, instrumented_hops,
                                           true_assignments, invocation_graph, true_skips, true_dist)
 
+    def solve_arrays(self, unit, true_parent=None, process=""):
+        """Both passes of one no-skip service on index arrays (what FindAssignments does between packing and unpacking;
+        traceweaver_amd.executor --fit sklearn calls it service by service).  true_parent [E, n_in] (or None) is only used to
+        replay the reference's discarded fits on the true assignments (fit="sklearn", replay_true_fit).  Returns the result
+        dicts of pass 1 (leaves) and pass 2 (everything)."""
+        if self.fit != "sklearn" or not self.replay_true_fit:
+            true_parent = None
+        eng = self._engine
+        eng.load([unit])
+        eng.run_pass1()
+        t1 = eng.timing()
+        r1 = eng.results(1, fields=("leaves",))[0]
+        if self.fit == "device":
+            eng.fit_mixtures()
+        else:
+            mix_n, mix_p = self._host_refit(unit, eng.gaps()[0], true_parent)
+            eng.set_mixtures([mix_n], [mix_p])
+        eng.run_pass2()
+        self.last_timing = {"pass1": t1, "pass2": eng.timing()}
+        r2 = eng.results(2)[0]
+        if true_parent is not None:
+            # ComputeEpPairDistParams5 also runs after the second iteration (`if iterations > 1` sits inside the loop,
+            # traceweaver_v3.py:1221-1222): its results are never used, but it advances numpy's global RNG by one more round
+            # of fits on the true and on the pass-2 assignments -- what the next service of a seeded run starts from
+            self._replay_true_fit(unit, true_parent)
+            for q in reference_fit_order(unit, unit.key_rank):
+                row = self._gap_row(unit, r2["parent"], q)
+                if len(row):
+                    gmm.fit_edge_sklearn(row)
+        self.last_stats = {k: r2[k] for k in ("not_best_count", "cnt_unassigned", "n_windows", "repaired_windows", "budget_windows")}
+        if r2["budget_windows"]:
+            warnings.warn("%d window(s) of service %r hit the node budget of the exact selection search: the selection returned "
+                          "for them is the best one found, not a proven optimum" % (r2["budget_windows"], process))
+        return r1, r2
+
     def _find_assignments_skip(self, unit, in_ids, out_ids, out_eps, out_span_partitions, true_assignments):
         from . import skipmode
 
@@ -193,32 +228,7 @@ class TraceWeaverGPU(object):
                     true_parent[k, i] = pos.get(true_assignments[ep].get(sid), -1)
             true_parent[:, (true_parent < 0).any(axis=0)] = -1
 
-        eng = self._engine
-        eng.load([unit])
-        eng.run_pass1()
-        t1 = eng.timing()
-        r1 = eng.results(1, fields=("leaves",))[0]
-        if self.fit == "device":
-            eng.fit_mixtures()
-        else:
-            mix_n, mix_p = self._host_refit(unit, eng.gaps()[0], true_parent)
-            eng.set_mixtures([mix_n], [mix_p])
-        eng.run_pass2()
-        self.last_timing = {"pass1": t1, "pass2": eng.timing()}
-        r2 = eng.results(2)[0]
-        if self.fit == "sklearn" and self.replay_true_fit and true_parent is not None:
-            # ComputeEpPairDistParams5 also runs after the second iteration (`if iterations > 1` sits inside the loop,
-            # traceweaver_v3.py:1221-1222): its results are never used, but it advances numpy's global RNG by one more round
-            # of fits on the true and on the pass-2 assignments -- what the next service of a seeded run starts from
-            self._replay_true_fit(unit, true_parent)
-            for q in reference_fit_order(unit, unit.key_rank):
-                row = self._gap_row(unit, r2["parent"], q)
-                if len(row):
-                    gmm.fit_edge_sklearn(row)
-        self.last_stats = {k: r2[k] for k in ("not_best_count", "cnt_unassigned", "n_windows", "repaired_windows", "budget_windows")}
-        if r2["budget_windows"]:
-            warnings.warn("%d window(s) of service %r hit the node budget of the exact selection search: the selection returned "
-                          "for them is the best one found, not a proven optimum" % (r2["budget_windows"], process))
+        r1, r2 = self.solve_arrays(unit, true_parent, process)
 
         all_assignments, all_topk_assignments = {}, {}
         for k, ep in enumerate(out_eps):
