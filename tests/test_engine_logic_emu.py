@@ -169,9 +169,8 @@ def test_lane_threaded_emulation(emu_lib):
     """TW_EMU_LANES=1: workgroups run as host threads, one per lane (64 to a wavefront, 128 per tile, 256 per
     cooperative workgroup), cross-lane operations are rendezvous -- the lane-parallel logic (work-list appends with
     wave-aggregated atomics, ballot prefix sums, block scans, wave reductions, the selection kernels' LDS hand-offs)
-    against the oracle, bit for bit.  Covers the paths whose single-lane LDS writes are already fenced by wave
-    barriers (E <= 2 on microsecond data); the top-5 bookkeeping of the wavefront enumeration kernel relies on
-    lock-step execution between barriers and is outside what this mode can check."""
+    against the oracle, bit for bit -- including the wavefront enumeration kernel (staging by ballot prefix sums, the
+    tuple lists of deep call graphs built with wavefront scans, the top-5 bookkeeping) on a 7-endpoint unit."""
     import subprocess
     import sys
 
@@ -179,12 +178,12 @@ def test_lane_threaded_emulation(emu_lib):
         "import sys, os\n"
         "sys.path[:0] = [%r, %r, %r]\n"
         "import parity\n"
-        "units, _ = parity.stress_units([(6, 200, 'single', 10, 1), (4, 200, 'par2', 6, 1), (11, 130, 'single', 1.2, 1)])\n"
+        "units, _ = parity.stress_units([(6, 200, 'single', 10, 1), (4, 200, 'par2', 6, 1), (11, 130, 'single', 1.2, 1), (18, 30, 'mix7', 3, 1000)])\n"
         "r1, r2, _ = parity.check_units(%r, units)\n"
         "assert sum(r['repaired_windows'] for r in r1) > 0\n"
         "print('lanes ok')\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
          os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"), emu_lib)
     env = dict(os.environ, TW_EMU_LANES="1", TW_TILE="128", TW_COOP_THREADS="256")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "lanes ok" in out.stdout, out.stderr[-2000:]

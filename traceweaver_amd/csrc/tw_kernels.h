@@ -762,10 +762,8 @@ constexpr int kPairPoolPerEp = 160;   // doubles of pair-term tables per endpoin
 constexpr int kGridTarget = 1024;     // grid points per prefix the split of the endpoints aims at (a prefix step costs about as much as five grid batches)
 // Deep call graphs with many candidates per endpoint (Alibaba shape: 7-8 endpoints x 10-14 candidates = 10^7-10^8 grid
 // points for 10^4-10^5 feasible tuples): walking the prefixes one after the other and testing a dense grid below each
-// leaves most lanes idle (0.1 % of the grid is feasible).  Such a span first builds the list of feasible prefixes of all
-// endpoints but the last, level by level, a wavefront of (prefix, candidate) pairs at a time, order kept by ballot
-// prefix sums (so the list is in the reference's depth-first order); the tuples are then the (prefix, last candidate)
-// pairs, again a wavefront at a time: every test is a lane's own, no prefix is visited twice.
+// leaves most lanes idle (0.1 % of the grid is feasible).  Such a span first lists its feasible tuples, level by level
+// (see the kernel), in the reference's depth-first order, and then scores them a wavefront at a time.
 constexpr long long kFrontierGrid = 1 << 15;   // from this many grid points (staged candidates) on, and E >= 3
 #ifndef TW_FRONTIER_CAP
 #define TW_FRONTIER_CAP (1 << 15)
@@ -924,7 +922,10 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         // values) and watch for an equivalence that could matter (between the candidate, the evicted entry
         // or the kept entries).  If one shows up -- millisecond-granular data -- the span is redone with the
         // CPython heap replayed push by push in LDS (second attempt).
-        // feasible prefixes of the endpoints 0..E-2 (see kFrontierGrid), 8 bits per staged position
+        // the feasible tuples as a list (see kFrontierGrid), 8 bits per staged position, built level by level: a prefix may
+        // be followed by exactly the candidates that start no earlier than its latest predecessor ends -- the staged
+        // candidates are in start order, so that is a tail of the list, found by bisection: one lane per prefix, the
+        // children written behind one another (wavefront prefix sum of the counts), depth-first order kept
         bool use_front = false;
         int n_front = 0;
         const unsigned long long* front = nullptr;
@@ -932,9 +933,10 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             long long grid = 1;
 #pragma unroll
             for (int e = 0; e < E; e++) grid = grid < (1ll << 40) ? grid * cn[e] : grid;
-            if (grid >= kFrontierGrid) {
+            if (grid >= kFrontierGrid && !U.skip) {
                 unsigned long long* fa = P.frontier + (size_t)blockIdx.x * 2 * kFrontierCap;
                 int cap = kFrontierCap;
+                const int lane = t & 63;
                 for (int tries = 0; tries < 2; tries++) {
                     unsigned long long* fb = fa + cap;
                     for (int c = t; c < cn[0]; c += nt) fa[c] = (unsigned long long)c;
@@ -943,33 +945,31 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                     __threadfence_block();
                     wave_sync();
 #pragma unroll
-                    for (int d = 1; d < E - 1; d++) {
+                    for (int d = 1; d < E; d++) {
                         if (!use_front) continue;
                         const int cd = cn[d];
-                        const uint32_t md = (uint32_t)((0x100000000ull + (unsigned)cd - 1ull) / (unsigned)cd);
-                        const long long total = (long long)nprev * cd;
                         int nnext = 0;
-                        for (long long base = 0; base < total; base += nt) {
-                            const long long j = base + t;
-                            bool ok = j < total;
-                            unsigned long long ent = 0;
-                            int c = 0;
-                            if (ok) {
-                                const uint32_t f = cd == 1 ? (uint32_t)j : __umulhi((uint32_t)j, md);
-                                c = (int)((uint32_t)j - f * (uint32_t)cd);
-                                ent = fa[f];
-                                const int64_t st = ls[d][c];
+                        for (int base = 0; base < nprev; base += nt) {
+                            const int f = base + t;
+                            const bool valid = f < nprev;
+                            const unsigned long long ent = valid ? fa[f] : 0ull;
+                            int64_t tmin = INT64_MIN;   // the latest end among the predecessors' spans
 #pragma unroll
-                                for (int q = 0; q < E - 1; q++)
-                                    if (q < d && ((dag_pm[d] >> q) & 1) && le[q][(ent >> (8 * q)) & 255ull] > st) ok = false;
-                            }
-                            const unsigned long long m = __ballot(ok);
-                            const int at = nnext + __popcll(m & ((1ull << t) - 1ull));
-                            if (ok && at < cap) fb[at] = ent | ((unsigned long long)c << (8 * d));
-                            nnext += __popcll(m);
+                            for (int q = 0; q < E - 1; q++)
+                                if (q < d && ((dag_pm[d] >> q) & 1)) { const int64_t en = le[q][(ent >> (8 * q)) & 255ull]; tmin = en > tmin ? en : tmin; }
+                            int lo2 = 0, hi2 = cd;
+                            while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (ls[d][mid] < tmin) lo2 = mid + 1; else hi2 = mid; }
+                            const int cnt = valid ? cd - lo2 : 0;
+                            int incl = cnt;
+                            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl(incl, lane >= off ? lane - off : lane); if (lane >= off) incl += v; }
+                            const int total = __shfl(incl, nt - 1 < 63 ? nt - 1 : 63);
+                            const int start = nnext + incl - cnt;
+                            if (nnext + total <= cap)
+                                for (int c = lo2; c < lo2 + cnt; c++) fb[start + (c - lo2)] = ent | ((unsigned long long)c << (8 * d));
+                            nnext += total;
                             if (nnext > cap) break;   // uniform
                         }
-                        if (nnext > cap || total >= (1ll << 32) / 128) use_front = false;
+                        if (nnext > cap) use_front = false;
                         unsigned long long* sw = fa; fa = fb; fb = sw;
                         nprev = nnext;
                         __threadfence_block();
@@ -986,7 +986,6 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                     fa = P.frontier_big + (size_t)slot * 2 * kFrontierBigCap;
                     cap = kFrontierBigCap;
                 }
-                if (use_front && (long long)n_front * cn[E - 1] >= (1ll << 31) / 128) use_front = false;
             }
         }
         LdsHeap<E, W> hp;
@@ -1013,7 +1012,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             for (int e = E - 2; e >= 0; e--)
                 if (L == e + 1 && G < kHeavyThreads) { L = e; G *= cn[e]; }
         }
-        if (use_front) { L = E - 1; G = cn[E - 1]; }   // rows = the listed prefixes, one grid level
+        if (use_front) { L = E; G = 1; }   // the tuples are listed: no walk, no grid
         // grid point -> staged positions of the levels L..E-1, last endpoint fastest: divisions by the wave-uniform
         // counts as multiplications (exact for g * (c - 1) < 2^32)
         uint32_t magic[E];
@@ -1021,12 +1020,10 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         for (int e = 0; e < E; e++) magic[e] = (uint32_t)((0x100000000ull + (unsigned)cn[e] - 1ull) / (unsigned)cn[e]);
         auto grid_digits = [&](int g, int32_t (&x)[E]) {
             uint32_t rest = (uint32_t)g;
-            if (use_front) {   // g = row * cn[E-1] + last candidate; the row is a listed prefix
-                const uint32_t row = cn[E - 1] == 1 ? rest : __umulhi(rest, magic[E - 1]);
-                x[E - 1] = (int32_t)(rest - row * (uint32_t)cn[E - 1]);
-                const unsigned long long ent = front[row];
+            if (use_front) {   // g-th listed tuple
+                const unsigned long long ent = front[rest];
 #pragma unroll
-                for (int e = 0; e < E - 1; e++) x[e] = (int32_t)((ent >> (8 * e)) & 255ull);
+                for (int e = 0; e < E; e++) x[e] = (int32_t)((ent >> (8 * e)) & 255ull);
                 return;
             }
 #pragma unroll
@@ -1068,7 +1065,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         if (L > 0 && t == 0) px[0] = -1;
         wave_sync();
         const bool once = (L == 0) || use_front;
-        const int Gtot = use_front ? n_front * G : G;
+        const int Gtot = use_front ? n_front : G;
         while (once || d >= 0) {
             if (L > 0 && !use_front) {  // next feasible prefix, every lane in lockstep (DfsTraverseX order)
                 int cd = 0;
