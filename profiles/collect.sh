@@ -16,8 +16,8 @@ ARGS="--steps 5 --warmup 1 --cpu-sample 0 $*"
 export TMPDIR=/tmp
 T="timeout 240"
 mkdir -p gpurun_out
-git rev-parse HEAD > gpurun_out/${TAG}_commit.txt 2>/dev/null || cat .git_head 2>/dev/null > gpurun_out/${TAG}_commit.txt || true
-rocprofv3 -L > gpurun_out/${TAG}_counters_available.txt 2>&1 || true
+python -c "from traceweaver_amd import build; print(build.source_digest())" > gpurun_out/${TAG}_digest.txt 2>/dev/null || true
+cp .git_head gpurun_out/${TAG}_commit.txt 2>/dev/null || true
 run_pmc() {  # name, counters...
     local name=$1; shift
     mkdir -p gpurun_out/${TAG}_${name}
@@ -29,7 +29,7 @@ $T rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_sta
 echo "stats: rc $?"
 run_pmc fetch FETCH_SIZE
 run_pmc write WRITE_SIZE
-run_pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU
+run_pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU
 run_pmc sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA
 run_pmc grbm GRBM_GUI_ACTIVE GRBM_COUNT
 # only the summaries travel back (the per-dispatch CSVs of five passes stay under the 64 MiB pull limit)

@@ -931,9 +931,10 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         const unsigned long long* front = nullptr;
         if constexpr (E >= 3) {
             long long grid = 1;
+            uint32_t any_order = 0;   // without call-order constraints every grid point is a tuple: nothing to gain from listing them
 #pragma unroll
-            for (int e = 0; e < E; e++) grid = grid < (1ll << 40) ? grid * cn[e] : grid;
-            if (grid >= kFrontierGrid && !U.skip) {
+            for (int e = 0; e < E; e++) { grid = grid < (1ll << 40) ? grid * cn[e] : grid; any_order |= dag_pm[e]; }
+            if (grid >= kFrontierGrid && any_order != 0 && !U.skip) {
                 unsigned long long* fa = P.frontier + (size_t)blockIdx.x * 2 * kFrontierCap;
                 int cap = kFrontierCap;
                 const int lane = t & 63;
