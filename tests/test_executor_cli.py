@@ -20,7 +20,7 @@ def run_cli(tmp_path, emu_lib, rel, fix, name):
     argv = ["--relative_path", rel, "--compressed", "0", "--cache_rate", "0", "--fix", str(fix), "--test_name", name,
             "--load_level", "100", "--compress_factor", "1", "--repeat_factor", "1", "--execute_parallel", "0",
             "--results_directory", out, "--clear_cache", "1", "--predictor_indices", "10",
-            "--project_root", REF, "--engine_library", emu_lib]
+            "--project_root", REF, "--engine_library", emu_lib, "--fit", "device"]
     executor.main(argv)
     suffix = "_%s_100_1_1_0.0.pickle" % name
     return {k: pickle.load(open(out + k + suffix, "rb")) for k in ("accuracy", "process_acc", "confidence_scores", "bin_acc", "e2e")}

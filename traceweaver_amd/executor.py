@@ -65,10 +65,12 @@ def parse_args(argv=None):
     ap.add_argument("--replicas_file", type=q, default=None,
                     help="pickle {service: [replica ids]} for --compress_factor > 1 (default: data/misc/service_to_replica_new.pickle under --project_root, executor.py:912)")
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--fit", default="device", choices=["device", "sklearn"],
-                    help="mixture refit between the passes: 'device' = deterministic EM on the GPU, all services in one batch; 'sklearn' = the "
-                         "reference's scikit-learn procedure on the host, service by service in the reference's order with numpy's global RNG "
-                         "seeded by --seed: reproduces a reference run started with np.random.seed(seed) (SURVEY.md hazard H9)")
+    ap.add_argument("--fit", default="sklearn", choices=["device", "sklearn"],
+                    help="mixture refit between the passes.  'sklearn' (default: the reference's procedure, traceweaver_v3.py:764-786) = "
+                         "scikit-learn on the host, service by service in the reference's order with numpy's global RNG seeded by --seed: "
+                         "reproduces a reference run started with np.random.seed(seed) (SURVEY.md hazard H9; the passes themselves run on the "
+                         "GPU).  'device' = deterministic EM on the GPU, all services in one batch: fastest, accuracy within the spread the "
+                         "reference itself shows between seeds (up to a few pp on some corpora)")
     ap.add_argument("--seed", type=int, default=10)
     ap.add_argument("--allow_partial", type=int, default=0, choices=[0, 1],
                     help="go on when services of the corpus cannot be solved here (skip mode, < 2 requests, cyclic call order); they are "
