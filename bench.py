@@ -358,12 +358,13 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    enum_ms, sel_ms, fit_ms, pass_ms, rep_ms = [], [], [], [], []
+    enum_ms, sel_ms, fit_ms, pass_ms, rep_ms, rounds = [], [], [], [], [], []
     for _ in range(args.steps):
         t1, t2, res, gathered = step()
         enum_ms += [t1["enumerate"], t2["enumerate"]]
         sel_ms += [t1["select"], t2["select"]]
         rep_ms += [t1["repair"], t2["repair"]]
+        rounds += [t1["rounds"], t2["rounds"]]
         fit_ms += [t2["fit"]]
         pass_ms += [t1["pass"], t2["pass"]]
     barrier()
@@ -431,6 +432,7 @@ def main():
                        "parallelism": "units sharded, %d rank(s), backend %s" % (world, args.backend if world > 1 else "none")},
             "accuracy": acc,
             "budget_windows": int(counters[0]), "repaired_windows": int(counters[1]), "windows": int(counters[2]), "unassigned": int(counters[3]),
+            "repair_rounds_per_pass": float(np.mean(rounds)),
             "gpu_pass_ms": {"pass1": float(np.mean(pass_ms[0::2])), "pass2": float(np.mean(pass_ms[1::2]))},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -828,6 +828,7 @@ int tw_get_timing(tw_engine* e, double* ms, int32_t n) {
     if (e == nullptr || ms == nullptr) return TW_ERR_ARG;
     for (int i = 0; i < n && i < 6; i++) ms[i] = e->ms[i];
     if (n > 6) ms[6] = e->fit_ms;
+    if (n > 7) ms[7] = (double)e->rounds;
     return TW_OK;
 }
 

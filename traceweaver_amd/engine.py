@@ -319,6 +319,6 @@ class Engine(object):
 
     def timing(self):
         """ms of the last pass: total, enumerate kernel, select kernel, windows, claim+detect+repair, params."""
-        ms = np.zeros(7, dtype=np.float64)
-        self._check(self._lib.tw_get_timing(self._h, _vp(ms), 7))
-        return dict(zip(("pass", "enumerate", "select", "windows", "repair", "params", "fit"), ms.tolist()))
+        ms = np.zeros(8, dtype=np.float64)
+        self._check(self._lib.tw_get_timing(self._h, _vp(ms), 8))
+        return dict(zip(("pass", "enumerate", "select", "windows", "repair", "params", "fit", "rounds"), ms.tolist()))
