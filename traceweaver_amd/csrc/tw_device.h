@@ -99,6 +99,7 @@ struct Dev {
     int64_t* leaves_r;  // per incoming span: tuples of the enumeration on the remaining spans (rep = 1)
     unsigned long long* frontier_big;  // pool of kFrontierBigSlots longer lists for the spans that outgrow their wavefront's buffers
     int32_t* frontier_big_next;
+    int32_t* frontier_next;
     unsigned long long* frontier;  // scratch of k_enumerate_heavy: per wavefront two lists of kFrontierCap feasible prefixes
     int32_t* round_changed;  // spans whose set of taken candidate spans changed in the current repair round
     int32_t* parent;

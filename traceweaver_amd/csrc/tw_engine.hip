@@ -38,6 +38,8 @@ int env_int(const char* name, int dflt) {
 struct tw_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t cls_stream[kMaxEp + 1] = {};   // one stream per endpoint count: the enumeration kernels of different classes overlap
+    hipEvent_t cls_ev[kMaxEp + 2] = {};        // [0] fork, [E] class E done
     std::string err;
     int state = ST_EMPTY;
     int tile = kTile;   // incoming spans (threads) per workgroup of the per-span kernels
@@ -170,23 +172,36 @@ int run_scan(tw_engine* e, typename Tr::T* agg) {
 
 // mode 0: first solve on all spans (per-thread kernel, then the wavefront kernel for the spans it deferred);
 // mode 1: the spans listed by k_detect_gone, without the candidate spans earlier windows took
+// The classes (units of one endpoint count) are independent of one another and every class' kernels end in a long tail
+// (work per span spans four orders of magnitude): each class runs on a stream of its own, forked from and joined to the
+// engine's stream by events, so that the tails overlap.  The wide instantiation of a class owns the big-list pool slots
+// together with the narrow one (one counter): no conflict, they only ever add.
 template <int E>
-void launch_enumerate(tw_engine* e, int pass, int mode) {
+void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
     const Dev& P = e->P;
     const int nt = e->tile_cls_off[E + 1] - e->tile_cls_off[E];
     if (nt == 0) return;
+    hipStream_t st = e->cls_stream[E];
+    (void)hipStreamWaitEvent(st, e->cls_ev[0], 0);
     if (mode == 0)
-        hipLaunchKernelGGL((k_enumerate_light<E>), dim3(nt), dim3(e->tile), 0, e->stream, P, pass,
+        hipLaunchKernelGGL((k_enumerate_light<E>), dim3(nt), dim3(e->tile), 0, st, P, pass,
                            (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
     const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
-    const int grid = std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096);  // persistent wavefronts pulling spans from the class' work list
-    hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), dim3(std::min(e->coop, kHeavyThreads)), 0, e->stream, P, pass, mode);
-    hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), dim3(std::min(e->coop, kHeavyThreads)), 0, e->stream, P, pass, mode);
+    const int grid = std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096 / 2);  // persistent wavefronts pulling spans from the class' work list
+    hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), dim3(std::min(e->coop, kHeavyThreads)), 0, st, P, pass, mode);
+    hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), dim3(std::min(e->coop, kHeavyThreads)), 0, st, P, pass, mode);
+    (void)hipEventRecord(e->cls_ev[E], st);
+    used = true;
+    (void)hipStreamWaitEvent(e->stream, e->cls_ev[E], 0);
 }
 
 void launch_enumerate_all(tw_engine* e, int pass, int mode) {
-    launch_enumerate<1>(e, pass, mode); launch_enumerate<2>(e, pass, mode); launch_enumerate<3>(e, pass, mode); launch_enumerate<4>(e, pass, mode);
-    launch_enumerate<5>(e, pass, mode); launch_enumerate<6>(e, pass, mode); launch_enumerate<7>(e, pass, mode); launch_enumerate<8>(e, pass, mode);
+    bool used = false;
+    (void)hipMemsetAsync(e->P.frontier_next, 0, sizeof(int32_t), e->stream);
+    (void)hipMemsetAsync(e->P.frontier_big_next, 0, sizeof(int32_t), e->stream);
+    (void)hipEventRecord(e->cls_ev[0], e->stream);
+    launch_enumerate<1>(e, pass, mode, used); launch_enumerate<2>(e, pass, mode, used); launch_enumerate<3>(e, pass, mode, used); launch_enumerate<4>(e, pass, mode, used);
+    launch_enumerate<5>(e, pass, mode, used); launch_enumerate<6>(e, pass, mode, used); launch_enumerate<7>(e, pass, mode, used); launch_enumerate<8>(e, pass, mode, used);
 }
 
 // OR of (key ^ first key) and of the keys themselves over a set of index ranges (see k_key_bits)
@@ -292,7 +307,6 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
-    HIPCHK(hipMemsetAsync(P.frontier_big_next, 0, sizeof(int32_t), e->stream));
     launch_enumerate_all(e, pass, 0);
     HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
     if (pass == 1) {
@@ -346,7 +360,6 @@ int run_pass(tw_engine* e, int pass) {
         if (changed == 0) break;
         if (round >= kMaxRepairRounds) return fail(e, TW_ERR_DEVICE, "span consumption did not settle (more repair rounds than windows)");
         e->rounds = round + 1;
-        HIPCHK(hipMemsetAsync(P.frontier_big_next, 0, sizeof(int32_t), e->stream));
         launch_enumerate_all(e, pass, 1);
         hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096)), dim3(std::min(e->coop, 64)), 0, e->stream, P);
     }
@@ -383,6 +396,8 @@ int tw_create(int device_id, tw_engine** out) {
     hipError_t s = hipSetDevice(device_id);
     if (s == hipSuccess) s = hipStreamCreate(&e->stream);
     for (int i = 0; i < EV_COUNT && s == hipSuccess; i++) s = hipEventCreate(&e->ev[i]);
+    for (int i = 1; i <= kMaxEp && s == hipSuccess; i++) s = hipStreamCreate(&e->cls_stream[i]);
+    for (int i = 0; i <= kMaxEp + 1 && s == hipSuccess; i++) s = hipEventCreateWithFlags(&e->cls_ev[i], hipEventDisableTiming);
     if (s != hipSuccess) {
         fprintf(stderr, "tw_create: %s\n", hipGetErrorString(s));
         delete e;
@@ -399,6 +414,10 @@ void tw_destroy(tw_engine* e) {
     if (e->arena != nullptr) (void)hipFree(e->arena);
     for (int i = 0; i < EV_COUNT; i++)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    for (int i = 0; i <= kMaxEp + 1; i++)
+        if (e->cls_ev[i]) (void)hipEventDestroy(e->cls_ev[i]);
+    for (int i = 1; i <= kMaxEp; i++)
+        if (e->cls_stream[i]) (void)hipStreamDestroy(e->cls_stream[i]);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -567,7 +586,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.tk_score, n_in_total * kTopK); ALLOC(P.tkr_score, n_in_total * kTopK);
     ALLOC(P.c_lo, ie); ALLOC(P.c_hi, ie); ALLOC(P.c_bits, ie * kCandWords); ALLOC(P.parent, ie);
     ALLOC(P.gone, ie * kCandWords); ALLOC(P.leaves_r, n_in_total); ALLOC(P.round_changed, 1);
-    ALLOC(P.frontier, (int64_t)4096 * 2 * kFrontierCap); ALLOC(P.frontier_big, (int64_t)kFrontierBigSlots * 2 * kFrontierBigCap); ALLOC(P.frontier_big_next, 1);
+    ALLOC(P.frontier, (int64_t)kFrontierSlots * 2 * kFrontierCap); ALLOC(P.frontier_next, 1); ALLOC(P.frontier_big, (int64_t)kFrontierBigSlots * 2 * kFrontierBigCap); ALLOC(P.frontier_big_next, 1);
     ALLOC(P.owner, n_out_total);
     ALLOC(P.gaps, gaps);
     ALLOC(P.unit_stats, (int64_t)P.n_units * 8); ALLOC(P.err, 1);

@@ -772,6 +772,7 @@ constexpr long long kFrontierGrid = 1 << 15;   // from this many grid points (st
 #endif
 constexpr int kFrontierCap = TW_FRONTIER_CAP;          // prefixes per level and wavefront (two buffers of 8 B entries); beyond: a slot of the pool
 constexpr int kFrontierBigCap = TW_FRONTIER_BIG_CAP;       // ... of kFrontierBigSlots lists this long (32 MB a slot); beyond, or none left: the walk
+constexpr int kFrontierSlots = 4096;            // buffer pairs of kFrontierCap entries, claimed by the wavefronts that need one
 constexpr int kFrontierBigSlots = TW_FRONTIER_BIG_SLOTS;   // (the host-emulation build of the tests uses tiny sizes so that all three routes are exercised)
 template <int E, int W>
 __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass, int mode) {
@@ -793,6 +794,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
     const int t = threadIdx.x, nt = blockDim.x;
     const int count = P.heavy_in_count[kList];
     int chunk_pos = 0, chunk_end = 0;
+    int front_slot = -1;   // this wavefront's pair of tuple-list buffers: -1 not claimed yet, -2 none left
     bool first_chunk = true;
     while (true) {
         // dynamic work distribution: candidate products span four orders of magnitude, a static split leaves
@@ -934,8 +936,15 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             uint32_t any_order = 0;   // without call-order constraints every grid point is a tuple: nothing to gain from listing them
 #pragma unroll
             for (int e = 0; e < E; e++) { grid = grid < (1ll << 40) ? grid * cn[e] : grid; any_order |= dag_pm[e]; }
-            if (grid >= kFrontierGrid && any_order != 0 && !U.skip) {
-                unsigned long long* fa = P.frontier + (size_t)blockIdx.x * 2 * kFrontierCap;
+            if (grid >= kFrontierGrid && any_order != 0 && !U.skip && front_slot < 0 && front_slot != -2) {
+                // the first such span of this wavefront claims one of the kFrontierSlots buffer pairs (kernels of several
+                // classes run side by side: the block index does not identify a wavefront across them)
+                if (t == 0) front_slot = atomicAdd(P.frontier_next, 1);
+                front_slot = __shfl(front_slot, 0);
+                if (front_slot >= kFrontierSlots) front_slot = -2;   // none left: this wavefront walks
+            }
+            if (grid >= kFrontierGrid && any_order != 0 && !U.skip && front_slot >= 0) {
+                unsigned long long* fa = P.frontier + (size_t)front_slot * 2 * kFrontierCap;
                 int cap = kFrontierCap;
                 const int lane = t & 63;
                 for (int tries = 0; tries < 2; tries++) {
