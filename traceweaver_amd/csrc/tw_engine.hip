@@ -187,7 +187,7 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
         hipLaunchKernelGGL((k_enumerate_light<E>), dim3(nt), dim3(e->tile), 0, st, P, pass,
                            (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
     const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
-    const int grid = std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096 / 2);  // persistent wavefronts pulling spans from the class' work list
+    const int grid = std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096);  // persistent wavefronts pulling spans from the class' work list
     hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), dim3(std::min(e->coop, kHeavyThreads)), 0, st, P, pass, mode);
     hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), dim3(std::min(e->coop, kHeavyThreads)), 0, st, P, pass, mode);
     (void)hipEventRecord(e->cls_ev[E], st);
