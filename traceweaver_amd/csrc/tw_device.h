@@ -116,6 +116,8 @@ struct Dev {
     int32_t* heavy_in_next;   // [2][kMaxEp+1] next unclaimed entry of each list
     int32_t heavy_in_off[kMaxEp + 2];  // class offsets into heavy_in_unit / heavy_in_idx
     int32_t *heavy_in_unit, *heavy_in_idx;
+    int32_t* heavy_big_count;   // [kMaxEp+1] narrow spans with a long enumeration: served first
+    int32_t *heavy_big_unit, *heavy_big_idx;   // class offsets as heavy_in_off
     int32_t* err;           // first error raised by a kernel (tw_status)
     unsigned long long* prof;  // [16] phase timers of -DTW_PROFILE builds
 };

@@ -307,6 +307,7 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
+    HIPCHK(hipMemsetAsync(P.heavy_big_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
     launch_enumerate_all(e, pass, 0);
     HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
     if (pass == 1) {
@@ -350,6 +351,7 @@ int run_pass(tw_engine* e, int pass) {
         hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P);
         HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
         HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
+        HIPCHK(hipMemsetAsync(P.heavy_big_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
         HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 3, e->stream));
         HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t), e->stream));
         HIPCHK(hipMemsetAsync(P.round_changed, 0, sizeof(int32_t), e->stream));
@@ -592,6 +594,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.unit_stats, (int64_t)P.n_units * 8); ALLOC(P.err, 1);
     ALLOC(e->tile_ids, (int64_t)tile_ids_h.size());
     ALLOC(P.heavy_in_count, 2 * (kMaxEp + 1)); ALLOC(P.heavy_in_next, 2 * (kMaxEp + 1)); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
+    ALLOC(P.heavy_big_count, kMaxEp + 1); ALLOC(P.heavy_big_unit, n_in_total); ALLOC(P.heavy_big_idx, n_in_total);
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
     ALLOC(P.prof, 16); ALLOC(e->key_acc, 2);
     ALLOC(P.heavy_count, 3); ALLOC(P.heavy_next, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);

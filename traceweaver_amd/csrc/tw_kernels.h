@@ -339,11 +339,17 @@ constexpr int kHeavyThreads = 64;
 // heavy_in_idx is filled from the front with the spans whose candidate windows are all <= kNarrow wide (served by
 // the small-LDS instantiation, more wavefronts per CU) and from the back with the others.
 constexpr int kNarrow = 32;
+// Narrow spans whose enumeration is long (product of the staged candidates > kBigProduct) go to a list of their own that
+// the narrow instantiation serves first, one to a wavefront: a persistent kernel ends with its longest item, so the long
+// ones must not start last.
+constexpr int kBigProduct = 768;
 template <int E>
-__device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narrow, int unit, int i) {
-    const int sn = wave_append(&P.heavy_in_count[E], pred && narrow);
+__device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narrow, bool big, int unit, int i) {
+    const int sb = wave_append(&P.heavy_big_count[E], pred && narrow && big);
+    const int sn = wave_append(&P.heavy_in_count[E], pred && narrow && !big);
     const int sw = wave_append(&P.heavy_in_count[kMaxEp + 1 + E], pred && !narrow);
     if (!pred) return false;
+    if (narrow && big) { P.heavy_big_unit[P.heavy_in_off[E] + sb] = unit; P.heavy_big_idx[P.heavy_in_off[E] + sb] = i; return true; }
     const int pos = narrow ? P.heavy_in_off[E] + sn : P.heavy_in_off[E + 1] - 1 - sw;
     P.heavy_in_unit[pos] = unit;
     P.heavy_in_idx[pos] = i;
@@ -600,10 +606,10 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
         for (int e = 0; e < E; e++) {
             int v = 0;
             for (int cx = c.lo[e]; cx <= c.hi[e]; cx++) v += (c.os[e][cx] >= c.in_start && c.oe[e][cx] <= c.in_end) ? 1 : 0;
-            if (prod <= kLightMax) prod *= v;
+            if (prod <= (1ll << 40)) prod *= v;
         }
     }
-    if (heavy_append<E>(P, prod > kLightMax, narrow, T.unit, i)) return;
+    if (heavy_append<E>(P, prod > kLightMax, narrow, prod > kBigProduct, T.unit, i)) return;
     c.nk = 0; c.leaves = 0; c.ambiguous = false;
 #pragma unroll
     for (int k = 0; k < kTopK; k++) c.ts[k] = -dinf();
@@ -648,7 +654,7 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
     // rare (millisecond-granular data): CPython's heapq / list.sort must be replayed push by push.  That needs
     // dynamically indexed per-thread state; keeping it out of this kernel keeps this kernel free of scratch memory
     // (measured: 8x faster) -- the span goes to the wavefront kernel, which replays from LDS.
-    if (heavy_append<E>(P, c.ambiguous, narrow, T.unit, i)) return;
+    if (heavy_append<E>(P, c.ambiguous, narrow, false, T.unit, i)) return;
     const int64_t g = U.in_off + i;
     P.tk_n[g] = c.nk;
     P.leaves[g] = c.leaves;
@@ -792,7 +798,10 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
     __shared__ int32_t px[E];                   // the prefix the wavefront is walking (staged positions, same for every lane)
     __shared__ int64_t pxs[E], pxe[E];
     const int t = threadIdx.x, nt = blockDim.x;
-    const int count = P.heavy_in_count[kList];
+    const int n_big = kWide ? 0 : P.heavy_big_count[E];
+    const int count = n_big + P.heavy_in_count[kList];
+    const int nstatic = (int)gridDim.x * kWorkChunk;
+    if ((int)blockIdx.x >= count) return;   // nothing for this wavefront (its strided static items start at its block index)
     int chunk_pos = 0, chunk_end = 0;
     int front_slot = -1;   // this wavefront's pair of tuple-list buffers: -1 not claimed yet, -2 none left
     bool first_chunk = true;
@@ -804,18 +813,22 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         if (chunk_pos == chunk_end) {
             if (first_chunk) { chunk_pos = (int)blockIdx.x * kWorkChunk; first_chunk = false; }
             else {
-                if (t == 0) chunk_pos = (int)gridDim.x * kWorkChunk + atomicAdd(&P.heavy_in_next[kList], kWorkChunk);
+                if (t == 0) chunk_pos = nstatic + atomicAdd(&P.heavy_in_next[kList], kWorkChunk);
                 chunk_pos = __shfl(chunk_pos, 0);
             }
-            chunk_end = chunk_pos + kWorkChunk < count ? chunk_pos + kWorkChunk : count;
-            if (chunk_pos >= count) break;
+            const int limit = chunk_pos < nstatic ? nstatic : count;   // static chunks are strided over the wavefronts below
+            chunk_end = chunk_pos + kWorkChunk < limit ? chunk_pos + kWorkChunk : limit;
+            if (chunk_pos >= count && chunk_pos >= nstatic) break;
         }
-        const int item = chunk_pos++;
+        int item = chunk_pos++;
+        if (item < nstatic) item = (item % kWorkChunk) * (int)gridDim.x + item / kWorkChunk;   // the long spans at the front: one to a wavefront
+        if (item >= count) continue;
         // wave-uniform by construction; telling the compiler so turns every access to the unit descriptor below
         // into a scalar load (SGPRs, constant cache) instead of 64 lanes loading the same address
-        const int pos = kWide ? P.heavy_in_off[E + 1] - 1 - item : P.heavy_in_off[E] + item;
-        const int unit = __builtin_amdgcn_readfirstlane(P.heavy_in_unit[pos]);
-        const int i = __builtin_amdgcn_readfirstlane(P.heavy_in_idx[pos]);
+        const bool from_big = item < n_big;
+        const int pos = from_big ? P.heavy_in_off[E] + item : (kWide ? P.heavy_in_off[E + 1] - 1 - item : P.heavy_in_off[E] + (item - n_big));
+        const int unit = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_unit : P.heavy_in_unit)[pos]);
+        const int i = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_idx : P.heavy_in_idx)[pos]);
         const UnitDev& U = P.units[unit];
         const int64_t in_start = P.in_start[U.in_off + i], in_end = P.in_end[U.in_off + i];
         Scorer S;
@@ -1938,7 +1951,7 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
     __shared__ SelectLds L;
     __shared__ int next_item;
     const int n_big = P.heavy_count[1], count = n_big + P.heavy_count[2];
-    if ((int)blockIdx.x * kWorkChunk >= count) return;   // nothing for this workgroup (the usual case outside heavy load)
+    if ((int)blockIdx.x >= count) return;   // nothing for this workgroup (the usual case outside heavy load)
     for (int q = threadIdx.x; q < kMemoSlots; q += blockDim.x) L.mstate[q] = 0u;
     if (threadIdx.x == 0) L.memo_gen = 0u;
     group_sync();
@@ -1955,10 +1968,17 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
                 chunk_pos = next_item;
                 group_sync();
             }
-            chunk_end = chunk_pos + kWorkChunk < count ? chunk_pos + kWorkChunk : count;
-            if (chunk_pos >= count) { TW_SEL_FLUSH(); break; }
+            const int limit = chunk_pos < (int)gridDim.x * kWorkChunk ? (int)gridDim.x * kWorkChunk : count;   // static chunks are remapped below
+            chunk_end = chunk_pos + kWorkChunk < limit ? chunk_pos + kWorkChunk : limit;
+            if (chunk_pos >= count && chunk_pos >= (int)gridDim.x * kWorkChunk) { TW_SEL_FLUSH(); break; }
         }
-        const int item = chunk_pos++;
+        int item = chunk_pos++;
+        {   // the static chunks are strided over the workgroups: the long windows at the front of the list go to different
+            // wavefronts instead of four in a row to the same one
+            const int nstatic = (int)gridDim.x * kWorkChunk;
+            if (item < nstatic) item = (item % kWorkChunk) * (int)gridDim.x + item / kWorkChunk;
+            if (item >= count) continue;
+        }
         const int pos = item < n_big ? item : (int)(P.n_in_total / 2) - (item - n_big);
         const int unit = __builtin_amdgcn_readfirstlane(P.heavy_unit[pos]), w = __builtin_amdgcn_readfirstlane(P.heavy_win[pos]);  // wave-uniform: scalar loads below
         const UnitDev& U = P.units[unit];
