@@ -206,6 +206,21 @@ int tw_find_order(tw_engine *e, int32_t n_units, const int64_t *unit_in_off, con
  * (end-to-end) accuracy.  Call after tw_load_batch. */
 int tw_set_truth(tw_engine *e, const int32_t *true_child, const int32_t *in_trace, int64_t n_traces);
 
+/* Replaces: repeat_change_spans (helpers/transforms.py:10-40) -- the load scaling `--compress_factor N` applies to every
+ * service before the predictor runs (executor.py:1086-1097,1146-1148) -- on the RESIDENT span table, so that the load levels
+ * of one corpus (exps/exp5/run_experiment.sh:60-156 runs six per call graph) share one upload.  Needs an integer-microsecond
+ * batch (no unit_time_scale, no skip mode) and tw_set_truth (the requests' own calls pair the spans of a request as the
+ * reference's sort by trace id does, helpers/transforms.py:25-29; every endpoint must hold exactly one call per request,
+ * otherwise TW_ERR_ARG -- the reference asserts).  Per request with load factor f = unit_factor[u] >= 1 (executor.py:1089-1091):
+ * x = in.start / f in binary64, out.start = x + (out.start - in.start), durations kept; every list is re-sorted by
+ * (start, end), ties in the order of trace_rank[n_in_total] (rank of the request's trace id inside its unit; NULL = current
+ * order); truth and trace numbers follow the spans.  The scaled binary64 timestamps are kept exactly, as int64 multiples of
+ * unit_time_scale[u] = 2^-k (written if not NULL; semantics of tw_batch.unit_time_scale).  in_perm[n_in_total] /
+ * out_perm[n_out_total] (may be NULL) = list-local old index of every new position.  Always scales the table as uploaded
+ * (calls do not compound); afterwards the engine is in the state tw_load_batch leaves it in. */
+int tw_scale_load(tw_engine *e, const int32_t *unit_factor, const int32_t *trace_rank, int32_t *in_perm, int32_t *out_perm,
+                  double *unit_time_scale);
+
 /* Replaces: AccuracyForService / TopKAccuracyForService (helpers/utils.py:62-97) and AccuracyEndToEnd /
  * TopKAccuracyEndToEnd (helpers/utils.py:99-145) as reductions over the resident results of the last pass run.
  * per_unit[n_units][4] = requests, requests with every endpoint right, requests whose top-5 list holds the true

@@ -7,11 +7,18 @@ units, truth = synth.make_workload(1000, n_in, services=synth.MEDIA_SERVICES, re
 eng = Engine(0, lib_path=os.environ.get("TW_PROFILE_LIB", "scratch/profsel.so")); eng.load(units)
 lib = eng._lib
 lib.tw_debug_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-eng.run_pass1(); t = eng.timing()
-a = np.zeros(16, dtype=np.uint64); lib.tw_debug_profile(eng._h, ctypes.c_void_p(a.ctypes.data))
-out = np.zeros(10, dtype=np.int32); lib.tw_debug_worklists(eng._h, ctypes.c_void_p(out.ctypes.data))
-names = ["0 load cands", "1 adjacency", "2 components", "3 comp setup", "4 brute", "5 dfs path", "6 loop overhead", "7 write"]
-tot = float(a[:8].sum())
-print("pass1 select ms", t["select"], "windows", out[0])
-for k in range(8): print("%-16s %6.1f%%  per window %8.0f ticks (10 ns)" % (names[k], 100.0*a[k]/tot, a[k]/max(out[0],1)))
-print("longest window: %.1f us, m=%d, nodes(last comp)=%d ; sum of window times / 1792 WGs = %.2f ms" % ((int(a[8]) >> 24) / 100.0, (int(a[8]) >> 16) & 0xff, int(a[8]) & 0xffff, int(a[9]) / 100.0 / 1792 / 1000.0))
+def report(pass_no, t, a, out):
+  names = ["0 load cands", "1 adjacency", "2 components", "3 comp setup", "4 brute", "5 dfs path", "6 loop overhead", "7 write"]
+  tot = float(a[:8].sum())
+  print("pass", pass_no, "select ms", t["select"], "windows", out[0])
+  for k in range(8): print("%-16s %6.1f%%  per window %8.0f ticks (10 ns)" % (names[k], 100.0*a[k]/tot, a[k]/max(out[0],1)))
+  print("longest window: %.1f us, m=%d, nodes(last comp)=%d ; sum of window times / 1792 WGs = %.2f ms" % ((int(a[8]) >> 24) / 100.0, (int(a[8]) >> 16) & 0xff, int(a[8]) & 0xffff, int(a[9]) / 100.0 / 1792 / 1000.0))
+prev = np.zeros(16, dtype=np.uint64)
+for pass_no in (1, 2):
+  if pass_no == 1: eng.run_pass1()
+  else: eng.fit_mixtures(); eng.run_pass2()
+  t = eng.timing()
+  cur = np.zeros(16, dtype=np.uint64); lib.tw_debug_profile(eng._h, ctypes.c_void_p(cur.ctypes.data))
+  a = cur - prev; a[8] = cur[8]; prev = cur
+  out = np.zeros(10, dtype=np.int32); lib.tw_debug_worklists(eng._h, ctypes.c_void_p(out.ctypes.data))
+  report(pass_no, t, a, out)

@@ -10,7 +10,7 @@ SRC = os.path.join(REPO, "traceweaver_amd", "csrc")
 
 
 def build(force=False):
-    deps = [os.path.join(SRC, f) for f in ("tw_engine.hip", "tw_kernels.h", "tw_device.h", "tw_fit.h", "tw_eval.h", "tw_skip.h", "tw_ingest.cpp")]
+    deps = [os.path.join(SRC, f) for f in ("tw_engine.hip", "tw_kernels.h", "tw_device.h", "tw_fit.h", "tw_eval.h", "tw_skip.h", "tw_load.h", "tw_ingest.cpp")]
     deps += [os.path.join(REPO, "include", "traceweaver_amd.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
              os.path.join(HERE, "rocprim", "rocprim.hpp")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):

@@ -19,6 +19,7 @@
 #include "tw_fit.h"
 #include "tw_eval.h"
 #include "tw_skip.h"
+#include "tw_load.h"
 
 using namespace tw;
 
@@ -91,6 +92,10 @@ struct tw_engine {
     SkipUnitDev* skip_units = nullptr;
     int32_t* skip_perm = nullptr; int64_t* skip_tw = nullptr; int32_t* skip_pool = nullptr; double* skip_dist = nullptr; long long* skip_fetch = nullptr;
     int64_t skip_fetch_n = 0;
+    // tw_scale_load: the table as uploaded (kept so that every load level starts from it)
+    int64_t *orig_is = nullptr, *orig_ie = nullptr, *orig_os = nullptr, *orig_oe = nullptr;
+    int32_t *orig_truth = nullptr, *orig_trace = nullptr;
+    bool scaled_upload = false;             // the batch was uploaded with unit_time_scale (already load-scaled by the caller)
     hipEvent_t ev[EV_COUNT] = {};
     double ms[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -144,6 +149,7 @@ int arena_commit(tw_engine* e) {
 void free_all(tw_engine* e) {
     for (void* q : e->allocs) (void)hipFree(q);
     e->allocs.clear();
+    e->orig_is = e->orig_ie = e->orig_os = e->orig_oe = nullptr; e->orig_truth = e->orig_trace = nullptr;
     e->truth = nullptr; e->in_trace = nullptr; e->trace_bad = nullptr; e->eval_counts = nullptr; e->n_traces = 0; e->trace_cap = 0;
     e->state = ST_EMPTY;
 }
@@ -223,6 +229,22 @@ unsigned bit_length(unsigned long long x) {
     unsigned n = 0;
     while (x) { n++; x >>= 1; }
     return n;
+}
+
+// End times of one batch share their upper bits: the sorts of run_pass only look at the bits that differ.
+// All keys must agree above end_bit, so both arrays are measured against the same reference key.
+int measure_end_bits(tw_engine* e) {
+    const Dev& P = e->P;
+    unsigned long long a[2], b[2], first_in = 0, first_out = 0;
+    int rc = key_bits(e, P.in_end, e->seg_in, e->seg_in + 1, P.n_units, P.n_in_total, a);
+    if (rc == TW_OK) rc = key_bits(e, P.out_end, e->seg_out, e->seg_out + 1, e->n_seg_out, P.n_out_total, b);
+    if (rc != TW_OK) return rc;
+    HIPCHK(hipMemcpy(&first_in, P.in_end, sizeof(first_in), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&first_out, P.out_end, sizeof(first_out), hipMemcpyDeviceToHost));
+    e->ts_end_bit = std::max(1u, bit_length(a[0] | b[0] | (first_in ^ first_out)));
+    if (e->ts_end_bit > 63) e->ts_end_bit = 64;  // keys of both signs: full width (sign handling is rocprim's)
+    e->ts_fixed = e->ts_end_bit >= 64 ? 0ull : (first_in >> e->ts_end_bit) << e->ts_end_bit;
+    return TW_OK;
 }
 
 int ensure_sort_tmp(tw_engine* e, size_t bytes) {
@@ -385,6 +407,153 @@ int run_pass(tw_engine* e, int pass) {
 }
 
 }  // namespace
+
+namespace {
+// One stable pass of the (start, end, trace order) sort: keys gathered through the current permutation, pairs sorted
+// on the bits that differ at all.
+template <class Src>
+int load_sort_pass(tw_engine* e, const Src* src, int64_t n, unsigned bits, unsigned long long* ka, unsigned long long* kb, uint32_t** perm, uint32_t** perm_alt) {
+    if (n <= 0 || bits == 0) return TW_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 8192), block = e->coop >= 64 ? 256 : e->coop;
+    if (sizeof(Src) == 8) hipLaunchKernelGGL(k_load_keys64, dim3(grid), dim3(block), 0, e->stream, (const int64_t*)src, (const uint32_t*)*perm, n, ka);
+    else hipLaunchKernelGGL(k_load_keys32, dim3(grid), dim3(block), 0, e->stream, (const int32_t*)src, (const uint32_t*)*perm, n, ka);
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, ka, kb, *perm, *perm_alt, (size_t)n, 0u, bits, e->stream));
+    int rc = ensure_sort_tmp(e, bytes);
+    if (rc != TW_OK) return rc;
+    bytes = e->sort_tmp_bytes;
+    HIPCHK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, ka, kb, *perm, *perm_alt, (size_t)n, 0u, bits, e->stream));
+    std::swap(*perm, *perm_alt);
+    return TW_OK;
+}
+
+// number of low bits in which the int64 values of an array differ (64 if signs differ)
+int differing_bits(tw_engine* e, const int64_t* v, int64_t n, unsigned* bits) {
+    *bits = 0;
+    if (n <= 0) return TW_OK;
+    std::vector<uint32_t> seg = {0u, (uint32_t)n};
+    uint32_t* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, sizeof(uint32_t) * 2));
+    hipError_t st = hipMemcpy(d, seg.data(), sizeof(uint32_t) * 2, hipMemcpyHostToDevice);
+    unsigned long long out[2] = {0, 0};
+    int rc = st == hipSuccess ? key_bits(e, v, d, d + 1, 1, n, out) : TW_ERR_DEVICE;
+    (void)hipFree(d);
+    if (rc != TW_OK) return rc == TW_ERR_DEVICE ? fail(e, TW_ERR_DEVICE, "differing_bits: copy failed") : rc;
+    *bits = std::min(64u, std::max(1u, bit_length(out[0])));
+    return TW_OK;
+}
+}  // namespace
+
+extern "C" int tw_scale_load(tw_engine* e, const int32_t* unit_factor, const int32_t* trace_rank, int32_t* in_perm, int32_t* out_perm, double* unit_time_scale) {
+    if (e == nullptr || unit_factor == nullptr) return TW_ERR_ARG;
+    if (e->state < ST_LOADED) return fail(e, TW_ERR_STATE, "tw_scale_load before tw_load_batch");
+    if (e->skip_mode) return fail(e, TW_ERR_UNSUPPORTED, "load scaling of a skip-mode batch (skip mode takes integer microseconds)");
+    if (e->scaled_upload) return fail(e, TW_ERR_UNSUPPORTED, "the batch was uploaded with unit_time_scale: it is load-scaled already");
+    if (e->truth == nullptr) return fail(e, TW_ERR_STATE, "tw_scale_load needs the requests' own calls (tw_set_truth): helpers/transforms.py:25-29 pairs them by trace id");
+    HIPCHK(hipSetDevice(e->device));
+    Dev& P = e->P;
+    const int64_t n_in = P.n_in_total, n_out = P.n_out_total;
+    for (int u = 0; u < P.n_units; u++)
+        if (unit_factor[u] < 1) return fail(e, TW_ERR_ARG, "tw_scale_load: load factors are integers >= 1 (executor.py:1089-1091)");
+    int rc;
+    const bool has_trace = e->n_traces > 0 && e->in_trace != nullptr;
+    if (e->orig_is == nullptr) {   // first load level: keep the table as uploaded
+        rc = dev_alloc(e, &e->orig_is, n_in); if (rc != TW_OK) return rc;
+        rc = dev_alloc(e, &e->orig_ie, n_in); if (rc != TW_OK) return rc;
+        rc = dev_alloc(e, &e->orig_os, n_out); if (rc != TW_OK) return rc;
+        rc = dev_alloc(e, &e->orig_oe, n_out); if (rc != TW_OK) return rc;
+        rc = dev_alloc(e, &e->orig_truth, e->n_ie); if (rc != TW_OK) return rc;
+        rc = dev_alloc(e, &e->orig_trace, n_in); if (rc != TW_OK) return rc;
+        HIPCHK(hipMemcpyAsync(e->orig_is, P.in_start, sizeof(int64_t) * n_in, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->orig_ie, P.in_end, sizeof(int64_t) * n_in, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->orig_os, P.out_start, sizeof(int64_t) * n_out, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->orig_oe, P.out_end, sizeof(int64_t) * n_out, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->orig_truth, e->truth, sizeof(int32_t) * e->n_ie, hipMemcpyDeviceToDevice, e->stream));
+        if (has_trace) HIPCHK(hipMemcpyAsync(e->orig_trace, e->in_trace, sizeof(int32_t) * n_in, hipMemcpyDeviceToDevice, e->stream));
+    }
+    // scratch of this call (freed on return): binary64 / int64 images, tie ranks, row ids, sort keys and permutations
+    const int64_t n_max = std::max(n_in, n_out);
+    std::vector<void*> tmp;
+    auto scratch = [&](size_t bytes) -> void* { void* q = nullptr; if (hipMalloc(&q, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr; tmp.push_back(q); return q; };
+    struct Free { std::vector<void*>& v; ~Free() { for (void* q : v) (void)hipFree(q); } } free_tmp{tmp};
+    LoadDev L{};
+    L.units = P.units; L.tiles = P.tiles;
+    L.is = e->orig_is; L.ie = e->orig_ie; L.os = e->orig_os; L.oe = e->orig_oe; L.truth = e->orig_truth; L.in_trace = e->orig_trace;
+    L.x = (double*)scratch(8 * n_in); L.xe = (double*)scratch(8 * n_in); L.y = (double*)scratch(8 * n_out); L.ye = (double*)scratch(8 * n_out);
+    L.rank_in = (int32_t*)scratch(4 * n_in); L.rank_out = (int32_t*)scratch(4 * n_out); L.row_in = (int32_t*)scratch(4 * n_in); L.row_out = (int32_t*)scratch(4 * n_out);
+    L.owner_req = (int32_t*)scratch(4 * n_out); L.kmax = (int32_t*)scratch(4 * P.n_units); L.err = (int32_t*)scratch(4);
+    int32_t* d_factor = (int32_t*)scratch(4 * P.n_units); int32_t* d_segbase = (int32_t*)scratch(4 * P.n_units);
+    int32_t* d_rank = trace_rank != nullptr ? (int32_t*)scratch(4 * n_in) : nullptr;
+    unsigned long long *ka = (unsigned long long*)scratch(8 * n_max), *kb = (unsigned long long*)scratch(8 * n_max);
+    uint32_t *perm = (uint32_t*)scratch(4 * n_max), *perm_alt = (uint32_t*)scratch(4 * n_max);
+    uint32_t* perm_in = (uint32_t*)scratch(4 * n_in);
+    int32_t *pos_in = (int32_t*)scratch(4 * n_in), *pos_out = (int32_t*)scratch(4 * n_out);
+    if (!L.x || !L.xe || !L.y || !L.ye || !L.rank_in || !L.rank_out || !L.row_in || !L.row_out || !L.owner_req || !L.kmax || !L.err || !d_factor ||
+        !d_segbase || (trace_rank != nullptr && !d_rank) || !ka || !kb || !perm || !perm_alt || !perm_in || !pos_in || !pos_out)
+        return fail(e, TW_ERR_DEVICE, "tw_scale_load: out of device memory");
+    std::vector<int32_t> segbase_h((size_t)P.n_units);
+    { int32_t acc = 0; for (int u = 0; u < P.n_units; u++) { segbase_h[(size_t)u] = acc; acc += e->units[(size_t)u].E; } }
+    HIPCHK(hipMemcpyAsync(d_factor, unit_factor, sizeof(int32_t) * P.n_units, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d_segbase, segbase_h.data(), sizeof(int32_t) * P.n_units, hipMemcpyHostToDevice, e->stream));
+    if (d_rank != nullptr) HIPCHK(hipMemcpyAsync(d_rank, trace_rank, sizeof(int32_t) * n_in, hipMemcpyHostToDevice, e->stream));
+    L.factor = d_factor; L.seg_base = d_segbase; L.trace_rank = d_rank;
+    HIPCHK(hipMemsetAsync(L.kmax, 0, sizeof(int32_t) * P.n_units, e->stream));
+    HIPCHK(hipMemsetAsync(L.err, 0, sizeof(int32_t), e->stream));
+    HIPCHK(hipMemsetAsync(L.owner_req, 0xff, sizeof(int32_t) * n_out, e->stream));
+    hipLaunchKernelGGL(k_load_scale_in, dim3(P.n_tiles), dim3(e->tile), 0, e->stream, L);
+    hipLaunchKernelGGL(k_load_scale_out, dim3(P.n_tiles), dim3(e->tile), 0, e->stream, L);
+    hipLaunchKernelGGL(k_load_to_int, dim3(P.n_tiles), dim3(e->tile), 0, e->stream, L);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> kmax_h((size_t)P.n_units);
+    int32_t err_h = 0;
+    HIPCHK(hipMemcpyAsync(kmax_h.data(), L.kmax, sizeof(int32_t) * P.n_units, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&err_h, L.err, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (err_h != 0)
+        return fail(e, TW_ERR_ARG, "tw_scale_load: the requests' own calls are not one call per request at every endpoint (helpers/transforms.py:25-29 asserts it), "
+                                   "or the scaled timestamps span too many binades for int64");
+    // stable least-significant-key-first passes: trace order, end, start, list
+    const unsigned grid_in = (unsigned)std::min<int64_t>((n_in + 255) / 256, 8192), grid_out = (unsigned)std::min<int64_t>((n_out + 255) / 256, 8192);
+    const unsigned block = e->coop >= 64 ? 256 : e->coop;
+    int64_t* d_is = const_cast<int64_t*>(P.in_start); int64_t* d_ie = const_cast<int64_t*>(P.in_end);
+    int64_t* d_os = const_cast<int64_t*>(P.out_start); int64_t* d_oe = const_cast<int64_t*>(P.out_end);
+    for (int side = 0; side < 2; side++) {
+        const int64_t n = side == 0 ? n_in : n_out;
+        const int64_t* vs = (const int64_t*)(side == 0 ? L.x : L.y); const int64_t* ve = (const int64_t*)(side == 0 ? L.xe : L.ye);
+        const int32_t* rank = side == 0 ? L.rank_in : L.rank_out; const int32_t* row = side == 0 ? L.row_in : L.row_out;
+        const int nrows = side == 0 ? P.n_units : e->n_seg_out;
+        unsigned bs = 0, be = 0;
+        rc = differing_bits(e, vs, n, &bs); if (rc != TW_OK) return rc;
+        rc = differing_bits(e, ve, n, &be); if (rc != TW_OK) return rc;
+        hipLaunchKernelGGL(k_load_iota, dim3(side == 0 ? grid_in : grid_out), dim3(block), 0, e->stream, perm, n);
+        rc = load_sort_pass(e, rank, n, 32u, ka, kb, &perm, &perm_alt); if (rc != TW_OK) return rc;
+        rc = load_sort_pass(e, ve, n, be, ka, kb, &perm, &perm_alt); if (rc != TW_OK) return rc;
+        rc = load_sort_pass(e, vs, n, bs, ka, kb, &perm, &perm_alt); if (rc != TW_OK) return rc;
+        rc = load_sort_pass(e, row, n, std::max(1u, bit_length((unsigned long long)std::max(nrows - 1, 1))), ka, kb, &perm, &perm_alt); if (rc != TW_OK) return rc;
+        hipLaunchKernelGGL(k_load_place, dim3(side == 0 ? grid_in : grid_out), dim3(block), 0, e->stream, (const uint32_t*)perm, n, vs, ve,
+                           side == 0 ? d_is : d_os, side == 0 ? d_ie : d_oe, side == 0 ? pos_in : pos_out);
+        hipLaunchKernelGGL(k_load_local, dim3(side == 0 ? grid_in : grid_out), dim3(block), 0, e->stream, perm, row, (const uint32_t*)(side == 0 ? e->seg_in : e->seg_out), n);
+        HIPCHK(hipGetLastError());
+        int32_t* host = side == 0 ? in_perm : out_perm;
+        if (host != nullptr) HIPCHK(hipMemcpyAsync(host, perm, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    hipLaunchKernelGGL(k_load_retruth, dim3(P.n_tiles), dim3(e->tile), 0, e->stream, L, (const int32_t*)pos_in, (const int32_t*)pos_out, e->truth,
+                       has_trace ? e->in_trace : nullptr);
+    HIPCHK(hipGetLastError());
+    for (int u = 0; u < P.n_units; u++) {
+        UnitDev& U = e->units[(size_t)u];
+        U.tscale = std::ldexp(1.0, -kmax_h[(size_t)u]);
+        U.float_time = 1;
+        if (unit_time_scale != nullptr) unit_time_scale[u] = U.tscale;
+    }
+    HIPCHK(hipMemcpyAsync(const_cast<UnitDev*>(P.units), e->units.data(), sizeof(UnitDev) * e->units.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    rc = measure_end_bits(e);
+    if (rc != TW_OK) return rc;
+    e->state = ST_LOADED;
+    return TW_OK;
+}
 
 extern "C" {
 
@@ -682,18 +851,9 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipMemsetAsync(P.tk_score, 0xff, sizeof(double) * (size_t)std::max<int64_t>(n_in_total * kTopK, 1), e->stream));
     HIPCHK(hipMemsetAsync(e->mix_n_dev, 0, sizeof(int32_t) * std::max<int64_t>(slots, 1), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    {   // end times of one batch share their upper bits: the sorts of run_pass only look at the bits that differ.
-        // All keys must agree above end_bit, so both arrays are measured against the same reference key.
-        unsigned long long a[2], b[2], first_in = 0, first_out = 0;
-        rc = key_bits(e, d_ie, e->seg_in, e->seg_in + 1, P.n_units, n_in_total, a);
-        if (rc == TW_OK) rc = key_bits(e, d_oe, e->seg_out, e->seg_out + 1, e->n_seg_out, n_out_total, b);
-        if (rc != TW_OK) return rc;
-        HIPCHK(hipMemcpy(&first_in, d_ie, sizeof(first_in), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&first_out, d_oe, sizeof(first_out), hipMemcpyDeviceToHost));
-        e->ts_end_bit = std::max(1u, bit_length(a[0] | b[0] | (first_in ^ first_out)));
-        if (e->ts_end_bit > 63) e->ts_end_bit = 64;  // keys of both signs: full width (sign handling is rocprim's)
-        e->ts_fixed = e->ts_end_bit >= 64 ? 0ull : (first_in >> e->ts_end_bit) << e->ts_end_bit;
-    }
+    e->scaled_upload = b->unit_time_scale != nullptr;
+    rc = measure_end_bits(e);
+    if (rc != TW_OK) return rc;
     e->state = ST_LOADED;
     return TW_OK;
 }

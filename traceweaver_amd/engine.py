@@ -249,6 +249,35 @@ class Engine(object):
         return out
 
     # ------------------------------------------------------------------------------------------
+    def scale_load(self, factors, trace_rank=None):
+        """helpers/transforms.py:10-40 (repeat_change_spans) on the resident table (tw_scale_load): per unit an integer load
+        factor; trace_rank = per unit [n_in] ranks of the requests' trace ids (tie order of the re-sort; None = current
+        order).  Needs set_truth.  Every call scales the table as uploaded.  Returns per unit (in_perm [n_in],
+        [out_perm_e [n_in]] * E, time_scale) -- old index of every new position.  (self.units keeps the arrays as uploaded.)"""
+        f = np.ascontiguousarray(np.asarray(factors, dtype=np.int32))
+        if len(f) != len(self.units):
+            raise ValueError("one load factor per unit")
+        tr = None
+        if trace_rank is not None:
+            tr = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int32).ravel() for a in trace_rank]), dtype=np.int32)
+            if len(tr) != self._in_off[-1]:
+                raise ValueError("trace_rank does not match the loaded batch")
+        n_out = int(sum(int(u.out_off[-1]) for u in self.units))
+        ip = np.zeros(int(self._in_off[-1]), dtype=np.int32)
+        op = np.zeros(n_out, dtype=np.int32)
+        ts = np.zeros(len(self.units), dtype=np.float64)
+        self._check(self._lib.tw_scale_load(self._h, _vp(f), _vp(tr), _vp(ip), _vp(op), _vp(ts)))
+        out, o = [], 0
+        for k, u in enumerate(self.units):
+            a, b = int(self._in_off[k]), int(self._in_off[k + 1])
+            outs = []
+            for e in range(u.E):
+                m = int(u.out_off[e + 1] - u.out_off[e])
+                outs.append(op[o:o + m].copy())
+                o += m
+            out.append((ip[a:b].copy(), outs, float(ts[k])))
+        return out
+
     def set_truth(self, true_parent, in_trace=None, n_traces=0):
         """Ground truth of the loaded batch: per unit [E, n_in] index of the true outgoing span; optionally per
         unit [n_in] trace numbers in [0, n_traces) for the per-trace (end-to-end) accuracy."""

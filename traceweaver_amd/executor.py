@@ -114,17 +114,22 @@ def scale_load(units, args, trace_id, corpus):
         raise SystemExit("--compress_factor %g needs the replica table %s ({service: [replica ids]}, executor.py:912)" % (args.compress_factor, path))
     with open(path, "rb") as f:
         replicas = pickle.load(f)
-    out = []
+    out, factors, ranks = [], [], []
     for u in units:
         owner = u.service if u.service in replicas else corpus.loop_origin(u.service)   # "...-loop" stand-ins: executor.py:1092-1096
         if owner not in replicas:
             raise SystemExit("service %s is not in the replica table %s (the reference stops here too, executor.py:1098-1101)" % (u.service, path))
         factor = transforms.load_factor(args.compress_factor, len(replicas[owner]))
         print("Process: %s  replicas: %d  dynamic load factor: %d" % (u.service, len(replicas[owner]), factor))
-        s = transforms.compress_unit(u.arrays, u.true_parent, factor, trace_key=[trace_id(t) for t in u.in_trace])
+        keys = [trace_id(t) for t in u.in_trace]
+        s = transforms.compress_unit(u.arrays, u.true_parent, factor, trace_key=keys)
+        rank = np.empty(len(keys), dtype=np.int32)
+        rank[np.argsort(np.asarray(keys), kind="stable")] = np.arange(len(keys), dtype=np.int32)
+        factors.append(factor)
+        ranks.append(rank)
         out.append(IngestedUnit(s.arrays, s.true_parent, u.in_trace[s.in_perm], u.service, u.in_ep, u.out_eps, u.in_rows[s.in_perm],
                                 [r[p] for r, p in zip(u.out_rows, s.out_perm)], u.process_id))
-    return out
+    return out, factors, ranks
 
 
 def run(args):
@@ -156,8 +161,10 @@ def run(args):
     table = corpus.span_table()
     names = corpus.trace_names()
     trace_id = lambda k: corpus.string(names[k])
+    resident = None
     if args.compress_factor > 1:                                   # executor.py:1086-1097,1146-1148
-        units = scale_load(units, args, trace_id, corpus)
+        resident = units                                           # the device scales its own copy of the table (tw_scale_load)
+        units, load_factors, trace_ranks = scale_load(units, args, trace_id, corpus)
     skip_units = set()
     if args.cache_rate > 0:                                        # executor.py:1150-1152: only the service named "frontend"
         from . import skipmode
@@ -231,9 +238,20 @@ def run(args):
                     flags = np.maximum(flags, f_)
                     per[k], res[k] = p_[0], r2
                 eng = pred._engine
+            elif plain and resident is not None:
+                # load levels on the resident table: the spans go up once, as ingested; the host transform above only
+                # serves the result files and the baselines (same permutations: tests/test_load_scaling.py)
+                eng.load([resident[k].arrays for k in plain])
+                eng.set_truth([resident[k].true_parent for k in plain], [resident[k].in_trace for k in plain], n_traces)
+                t_scale = time.time()
+                perms = eng.scale_load([load_factors[k] for k in plain], trace_rank=[trace_ranks[k] for k in plain])
+                for k, (ip, _, ts) in zip(plain, perms):
+                    assert ts == units[k].arrays.time_scale and np.array_equal(resident[k].in_trace[ip], units[k].in_trace)
+                print("Load scaling on the device: %.1f ms" % ((time.time() - t_scale) * 1e3))
             elif plain:
                 eng.load([units[k].arrays for k in plain])
                 eng.set_truth([units[k].true_parent for k in plain], [units[k].in_trace for k in plain], n_traces)
+            if plain and args.fit != "sklearn":
                 try:
                     eng.run_pass1()
                 except EngineError as ex:
