@@ -1,18 +1,24 @@
+"""Item / wavefront lifetimes of k_enumerate_heavy<4, 32> on the bench workload (library built with -DTW_PROFILE, path in
+TW_PROFILE_LIB): is the kernel's tail one long item or an uneven split?"""
 import sys, os, ctypes, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from traceweaver_amd import synth
 from traceweaver_amd.engine import Engine
-units, truth = synth.make_workload(1000, 100000, services=["par4"], replicas=4, concurrency=1.6)
+conc = float(os.environ.get("TW_CONC", "1.6")); n_in = int(os.environ.get("TW_NIN", "100000"))
+units, truth = synth.make_workload(1000, n_in, services=synth.MEDIA_SERVICES, replicas=4, concurrency=conc)
 eng = Engine(0, lib_path=os.environ.get("TW_PROFILE_LIB", "scratch/prof.so")); eng.load(units)
 lib = eng._lib
 lib.tw_debug_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-def read():
-    a = np.zeros(16, dtype=np.uint64); lib.tw_debug_profile(eng._h, ctypes.c_void_p(a.ctypes.data)); return a
-eng.run_pass1(); t = eng.timing()
-a = read()
-names = ["a0 load lo/hi", "a1 stage+tab", "a2 score", "a3 insert+sync", "a4 write", "items", "max wave total", "fetch", "lifetime sum", "waves"]
-tot = float(a[0]+a[1]+a[2]+a[3]+a[4]+a[7])
-print("pass1 enum ms", t["enumerate"])
-for k in (0,1,2,3,4,7):
-    print("%-16s %6.1f%%  per item %8.0f ticks" % (names[k], 100.0*a[k]/tot, a[k]/max(a[5],1)))
-print("items", a[5], "waves", a[9], "lifetime/wave ticks", a[8]/max(a[9],1), "sum phases/wave", tot/max(a[9],1))
+prev = np.zeros(16, dtype=np.uint64)
+for pass_no in (1, 2):
+    if pass_no == 1: eng.run_pass1()
+    else: eng.fit_mixtures(); eng.run_pass2()
+    t = eng.timing()
+    cur = np.zeros(16, dtype=np.uint64); lib.tw_debug_profile(eng._h, ctypes.c_void_p(cur.ctypes.data))
+    a = cur - prev; prev = cur.copy()
+    print("pass %d enumerate group %.2f ms; E=4 narrow wavefront kernel: %d items, mean %.1f us, longest %.1f us (%d tuples), items >= 100 us: %d"
+          % (pass_no, t["enumerate"], a[14], a[13] / max(a[14], 1) / 100.0, (int(cur[12]) >> 24) / 100.0, int(cur[12]) & 0xffffff, a[15]))
+    print("   wavefronts with work %d, mean lifetime %.1f us, longest %.1f us; sum of item time / 4096 = %.1f us"
+          % (a[9], a[8] / max(a[9], 1) / 100.0, int(cur[6]) / 100.0, a[13] / 100.0 / 4096))
+    tot = float(a[:5].sum())
+    print("   phases: " + ", ".join("%s %.0f%%" % (n, 100.0 * a[k] / tot) for k, n in enumerate(["stage", "tables", "tuple list", "walk+top5", "results"])))

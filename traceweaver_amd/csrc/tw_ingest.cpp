@@ -341,6 +341,8 @@ struct tw_corpus {
     std::unordered_map<std::string, std::string> caller_of;  // service -> calling service (FixSpans' process_map_1)
     std::unordered_map<std::string, std::string> loop_by_rpc;  // selfLoopMap: rpc id -> stand-in service of a self-call (executor.py:386-399)
     std::unordered_map<std::string, std::string> loop_origin;  // serviceLoopMap: stand-in service -> the service that called itself
+    std::unordered_map<std::string, int64_t> loop_seq;         // rpc id -> number (in time order, over all calls) of the trace that entered it
+    int64_t traces_seen = 0;                                   // traces handed to the --fix 5 rewrite so far
     // last unit set built
     std::vector<int64_t> u_in_off, u_ep_off, u_in_start, u_in_end, u_out_start, u_out_end;
     std::vector<int32_t> u_E, u_key_rank, u_truth, u_in_trace, u_in_row, u_out_row, u_service, u_ep_name, u_in_ep, u_order;
@@ -481,29 +483,58 @@ bool fix_reroot(TraceTmp& T, const std::string& root_op) {
 // ParseSpansJson with first_span == None (executor.py:377-448; the output of alibaba-analysis/real-parser.py, --fix 5):
 // every call is logged twice under one rpc id -- a server record in the callee and a client record with the same
 // timestamps in the caller.  The client record is renamed "<rpc id>.client" and the server record re-pointed at it;
-// a service calling itself gets a stand-in callee "...-loop" (one per rpc id, for the whole corpus: the map lives in
-// the corpus and traces are visited in time order, as the reference does), the client spans below such an rpc id move
-// into the process of their parent span, and a trace in which a child is not contained in its parent is dropped.
+// a service calling itself gets a stand-in callee "...-loop" (one per rpc id, for the whole corpus: the reference keeps
+// the map across traces and visits them in time order), the client spans below such an rpc id move into the process of
+// their parent span, and a trace in which a child is not contained in its parent is dropped.
 // The reference draws the stand-in names at random (helpers/misc.py:17-19); here they are "<callee>@<rpc id>-loop".
-// Returns false when the trace is dropped.
-bool fix_rpc_twins(TraceTmp& T, tw_corpus* c) {
-    auto sanitized = [](const std::string& sid) {
-        return sid.size() >= 7 && sid.compare(sid.size() - 7, 7, ".client") == 0 ? sid.substr(0, sid.size() - 7) : sid;
+//
+// The corpus-wide map is the only thing that ties traces together, and a trace only ever sees the entries made by traces
+// up to itself.  So the rewrite runs in three steps: (1) per trace, any thread: the self-calls it would enter
+// (self_calls); (2) one thread, in time order: enter them, each with the number of its trace (a few entries per corpus);
+// (3) per trace, any thread: the rewrite proper, reading the map as it stood when the trace was reached (entries with a
+// number <= its own).  Same result as the sequential visit, with the per-span work spread over the parser threads.
+std::string sanitized_rpc(const std::string& sid) {
+    return sid.size() >= 7 && sid.compare(sid.size() - 7, 7, ".client") == 0 ? sid.substr(0, sid.size() - 7) : sid;
+}
+
+// step 1: (rpc id, callee) of every self-call in span order, up to the span at which the reference would raise
+void self_calls(const TraceTmp& T, std::vector<std::pair<std::string, std::string>>& out) {
+    out.clear();
+    for (const SpanTmp& s : T.spans) {
+        if (!s.has_caller || !s.has_callee) return;                    // span["caller"] would raise: the trace is dropped there
+        if (s.caller == s.callee) out.emplace_back(s.sid, s.callee);   // (ids are still unsuffixed here: sanitized == sid)
+    }
+}
+
+// step 2 (sequential, in time order)
+void enter_self_calls(tw_corpus* c, const std::vector<std::pair<std::string, std::string>>& calls, int64_t seq) {
+    for (const auto& rc : calls) {
+        const std::string rpc = sanitized_rpc(rc.first);
+        if (c->loop_by_rpc.find(rpc) != c->loop_by_rpc.end()) continue;
+        const std::string name = rc.second + "@" + rpc + "-loop";
+        c->loop_by_rpc.emplace(rpc, name);
+        c->loop_seq[rpc] = seq;
+        c->loop_origin[name] = rc.second;
+    }
+}
+
+// step 3.  Returns false when the trace is dropped.
+bool fix_rpc_twins(TraceTmp& T, const tw_corpus* c, int64_t seq) {
+    auto visible = [&](const std::string& rpc) -> const std::string* {
+        auto it = c->loop_by_rpc.find(rpc);
+        if (it == c->loop_by_rpc.end()) return nullptr;
+        auto sq = c->loop_seq.find(rpc);
+        return sq != c->loop_seq.end() && sq->second <= seq ? &it->second : nullptr;
     };
     for (SpanTmp& s : T.spans) {                                       // step 1
         if (s.kind == 2) s.sid += ".client";
         if (s.kind == 1 && s.refs.size() == 1) s.refs[0].second = s.sid + ".client";
         if (!s.has_caller || !s.has_callee) return false;              // span["caller"] would raise
         if (s.caller == s.callee) {
-            const std::string rpc = sanitized(s.sid);
-            auto it = c->loop_by_rpc.find(rpc);
-            if (it == c->loop_by_rpc.end()) {
-                const std::string name = s.callee + "@" + rpc + "-loop";
-                it = c->loop_by_rpc.emplace(rpc, name).first;
-                c->loop_origin[name] = s.callee;
-            }
-            s.callee = it->second;
-            if (s.kind == 1) s.pid = it->second;
+            const std::string* name = visible(sanitized_rpc(s.sid));   // entered by this trace or an earlier one
+            if (name == nullptr) return false;                         // (cannot happen: step 2 ran for this trace)
+            s.callee = *name;
+            if (s.kind == 1) s.pid = *name;
         }
     }
     const int n = (int)T.spans.size();
@@ -540,7 +571,7 @@ bool fix_rpc_twins(TraceTmp& T, tw_corpus* c) {
         }
     };
     std::function<void(int)> traverse = [&](int v) {                   // traverse_and_update
-        if (c->loop_by_rpc.count(sanitized(T.spans[(size_t)v].sid))) update(v);
+        if (visible(sanitized_rpc(T.spans[(size_t)v].sid)) != nullptr) update(v);
         for (int ch : children[(size_t)v]) traverse(ch);
     };
     traverse(root);
@@ -664,6 +695,7 @@ int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths,
     std::vector<TraceTmp> parsed((size_t)n_paths);
     std::vector<Walked> walked((size_t)n_paths);
     std::vector<char> usable((size_t)n_paths, 0);
+    std::vector<std::vector<std::pair<std::string, std::string>>> loops(fix == TW_FIX_RPC_TWINS ? (size_t)n_paths : 0);
     const std::string fs = first_span ? first_span : "";
     std::atomic<int> next(0);
     auto work = [&]() {  // everything that touches one trace only: read, parse, span surgery, walk
@@ -676,7 +708,7 @@ int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths,
             bool ok = true;
             if (fix == TW_FIX_CLIENT_TWINS) ok = fix_client_twins(T, c->caller_of);
             else if (fix == TW_FIX_REROOT) ok = fix_reroot(T, fs);
-            else if (fix == TW_FIX_RPC_TWINS) continue;   // needs the corpus-wide self-call map: done below, in time order
+            else if (fix == TW_FIX_RPC_TWINS) { self_calls(T, loops[(size_t)i]); continue; }   // the rewrite reads the corpus-wide self-call map: below
             usable[(size_t)i] = ok && walk_trace(T, fs, walked[(size_t)i]);
         }
     };
@@ -707,12 +739,44 @@ int tw_corpus_add_files(tw_corpus* c, const char* const* paths, int32_t n_paths,
         c->files_rejected++;
         if (c->err.empty()) c->err = std::string(paths[i]) + ": " + parsed[(size_t)i].error;
     }
+    std::vector<int64_t> seq_of((size_t)n_paths, -1);
+    if (fix == TW_FIX_RPC_TWINS) {
+        // the self-call map in time order (a few entries), then the rewrite + walk of every trace on the parser threads
+        for (int i : idx) {
+            if (!parsed[(size_t)i].ok) continue;
+            seq_of[(size_t)i] = c->traces_seen++;
+            enter_self_calls(c, loops[(size_t)i], seq_of[(size_t)i]);
+        }
+        std::atomic<int> next2(0);
+        auto rewrite = [&]() {
+            for (int i = next2.fetch_add(1); i < n_paths; i = next2.fetch_add(1)) {
+                TraceTmp& T = parsed[(size_t)i];
+                if (T.ok) usable[(size_t)i] = fix_rpc_twins(T, c, seq_of[(size_t)i]) && walk_trace(T, fs, walked[(size_t)i]);
+            }
+        };
+        std::vector<std::thread> pool2;
+        for (int t = 1; t < nt; t++) pool2.emplace_back(rewrite);
+        rewrite();
+        for (auto& th : pool2) th.join();
+        if (timing) fprintf(stderr, ", rewrite+walk done at %.3f s", since());
+    }
+    int64_t last_seq = -1;
+    bool stopped = false;
     for (int i : idx) {
         TraceTmp& T = parsed[(size_t)i];
         if (!T.ok) continue;
-        if (fix == TW_FIX_RPC_TWINS) usable[(size_t)i] = fix_rpc_twins(T, c) && walk_trace(T, fs, walked[(size_t)i]);
+        last_seq = seq_of[(size_t)i];
         if (usable[(size_t)i]) { append_trace(c, T, walked[(size_t)i]); accepted++; } else c->traces_filtered++;
-        if (max_traces > 0 && accepted >= max_traces) break;  // executor.py:873 stops after 1001 accepted traces
+        if (max_traces > 0 && accepted >= max_traces) { stopped = true; break; }  // executor.py:873 stops after 1001 accepted traces
+    }
+    if (fix == TW_FIX_RPC_TWINS && stopped) {   // the reference never reached the later traces: their self-calls are not in its map
+        for (auto it = c->loop_seq.begin(); it != c->loop_seq.end();) {
+            if (it->second <= last_seq) { ++it; continue; }
+            auto nm = c->loop_by_rpc.find(it->first);
+            if (nm != c->loop_by_rpc.end()) { c->loop_origin.erase(nm->second); c->loop_by_rpc.erase(nm); }
+            it = c->loop_seq.erase(it);
+        }
+        c->traces_seen = last_seq + 1;
     }
     if (timing) fprintf(stderr, ", order+append done at %.3f s\n", since());
     return TW_OK;

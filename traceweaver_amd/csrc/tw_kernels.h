@@ -321,17 +321,24 @@ constexpr int kHeavyThreads = 64;
 // Optional phase timers (build with -DTW_PROFILE; read back through tw_debug_profile): cycles spent by
 // lane 0 of every heavy-enumeration wavefront per phase.  Compiled out by default.
 #ifdef TW_PROFILE
-#define TW_PROF_DECL() long long _tw_t = wall_clock64(), _tw_a0 = 0, _tw_a1 = 0, _tw_a2 = 0, _tw_a3 = 0, _tw_a4 = 0, _tw_items = 0, _tw_fetch = 0, _tw_born = _tw_t
-#define TW_T0() do { const long long _n = wall_clock64(); _tw_fetch += _n - _tw_t; _tw_t = _n; _tw_items++; } while (0)
-#define TW_TICK(k) do { const long long _n = wall_clock64(); _tw_a##k += _n - _tw_t; _tw_t = _n; } while (0)
-#define TW_PROF_FLUSH() do { if (threadIdx.x == 0) { atomicAdd((unsigned long long*)&P.prof[0], (unsigned long long)_tw_a0); atomicAdd((unsigned long long*)&P.prof[1], (unsigned long long)_tw_a1); \
-    atomicAdd((unsigned long long*)&P.prof[2], (unsigned long long)_tw_a2); atomicAdd((unsigned long long*)&P.prof[3], (unsigned long long)_tw_a3); atomicAdd((unsigned long long*)&P.prof[4], (unsigned long long)_tw_a4); \
-    atomicAdd((unsigned long long*)&P.prof[5], (unsigned long long)_tw_items); atomicAdd((unsigned long long*)&P.prof[7], (unsigned long long)_tw_fetch); \
-    atomicAdd((unsigned long long*)&P.prof[8], (unsigned long long)(wall_clock64() - _tw_born)); atomicAdd((unsigned long long*)&P.prof[9], 1ull); atomicMin((unsigned long long*)&P.prof[10], (unsigned long long)_tw_born); atomicMax((unsigned long long*)&P.prof[11], (unsigned long long)_tw_born); atomicMax((unsigned long long*)&P.prof[6], (unsigned long long)(_tw_a0 + _tw_a1 + _tw_a2 + _tw_a3 + _tw_a4)); } } while (0)
+// prof[12] longest item (ticks << 24 | tuples, capped), [13] sum of item ticks, [14] items, [8] sum of wavefront lifetimes,
+// [9] wavefronts that drew work, [6] longest wavefront lifetime, [15] items >= 100 us -- of the narrow E = 4 instantiation
+#define TW_PROF_DECL() const long long _tw_born = wall_clock64(); long long _tw_t = _tw_born, _tw_p = _tw_born, _tw_ph[5] = {0, 0, 0, 0, 0}; const bool _tw_on = (E == 4 && !kWide && mode == 0)
+#define TW_ITEM_BEGIN() do { _tw_t = wall_clock64(); _tw_p = _tw_t; } while (0)
+// phases of an item: [0] stage candidates, [1] term and pair tables, [2] tuple list, [3] walk + top-5, [4] results
+#define TW_PHASE(k) do { const long long _n = wall_clock64(); _tw_ph[k] += _n - _tw_p; _tw_p = _n; } while (0)
+#define TW_ITEM_END(tuples) do { if (_tw_on && threadIdx.x == 0) { const unsigned long long _d = (unsigned long long)(wall_clock64() - _tw_t); \
+    const unsigned long long _l = (unsigned long long)(tuples) > 0xffffffull ? 0xffffffull : (unsigned long long)(tuples); \
+    atomicMax((unsigned long long*)&P.prof[12], (_d << 24) | _l); atomicAdd((unsigned long long*)&P.prof[13], _d); atomicAdd((unsigned long long*)&P.prof[14], 1ull); \
+    if (_d >= 10000ull) atomicAdd((unsigned long long*)&P.prof[15], 1ull); } } while (0)
+#define TW_PROF_FLUSH() do { if (_tw_on && threadIdx.x == 0) { const unsigned long long _d = (unsigned long long)(wall_clock64() - _tw_born); \
+    atomicAdd((unsigned long long*)&P.prof[8], _d); atomicAdd((unsigned long long*)&P.prof[9], 1ull); atomicMax((unsigned long long*)&P.prof[6], _d); \
+    for (int _k = 0; _k < 5; _k++) atomicAdd((unsigned long long*)&P.prof[_k], (unsigned long long)_tw_ph[_k]); } } while (0)
 #else
 #define TW_PROF_DECL() do {} while (0)
-#define TW_T0() do {} while (0)
-#define TW_TICK(k) do {} while (0)
+#define TW_ITEM_BEGIN() do {} while (0)
+#define TW_PHASE(k) do {} while (0)
+#define TW_ITEM_END(tuples) do {} while (0)
 #define TW_PROF_FLUSH() do {} while (0)
 #endif
 
@@ -804,6 +811,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
     if ((int)blockIdx.x >= count) return;   // nothing for this wavefront (its strided static items start at its block index)
     int chunk_pos = 0, chunk_end = 0;
     int front_slot = -1;   // this wavefront's pair of tuple-list buffers: -1 not claimed yet, -2 none left
+    TW_PROF_DECL();
     bool first_chunk = true;
     while (true) {
         // dynamic work distribution: candidate products span four orders of magnitude, a static split leaves
@@ -818,7 +826,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             }
             const int limit = chunk_pos < nstatic ? nstatic : count;   // static chunks are strided over the wavefronts below
             chunk_end = chunk_pos + kWorkChunk < limit ? chunk_pos + kWorkChunk : limit;
-            if (chunk_pos >= count && chunk_pos >= nstatic) break;
+            if (chunk_pos >= count && chunk_pos >= nstatic) { TW_PROF_FLUSH(); break; }
         }
         int item = chunk_pos++;
         if (item < nstatic) item = (item % kWorkChunk) * (int)gridDim.x + item / kWorkChunk;   // the long spans at the front: one to a wavefront
@@ -830,6 +838,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         const int unit = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_unit : P.heavy_in_unit)[pos]);
         const int i = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_idx : P.heavy_in_idx)[pos]);
         const UnitDev& U = P.units[unit];
+        TW_ITEM_BEGIN();
         const int64_t in_start = P.in_start[U.in_off + i], in_end = P.in_end[U.in_off + i];
         Scorer S;
         S.pass = pass;
@@ -852,20 +861,32 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         }
         for (int k = t; k < kMaxEp * kCandWords; k += nt) (&sbits[0][0])[k] = 0;
         bool none = false;
+        // stage the candidates that can occur in a tuple, order kept (ballot prefix sums).  The loads come first, all of
+        // them -- cut-offs of every endpoint, then the first chunk of every window: one memory round trip per step for the
+        // span instead of one per endpoint (the phase is latency-bound: profiles/tools/profile_enumerate.py)
+        int32_t wd[E];
 #pragma unroll
-        for (int e = 0; e < E; e++) {   // stage the candidates that can occur in a tuple, order kept (ballot prefix sums)
-            lo[e] = P.c_lo[ie_index(U, e, i)];
-            const int w = P.c_hi[ie_index(U, e, i)] - lo[e] + 1;
+        for (int e = 0; e < E; e++) { lo[e] = P.c_lo[ie_index(U, e, i)]; wd[e] = P.c_hi[ie_index(U, e, i)]; }
+        int64_t st0[E], en0[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            wd[e] = wd[e] - lo[e] + 1;
+            st0[e] = 0; en0[e] = 0;
+            if (t < wd[e]) { st0[e] = P.out_start[U.ep_off[e] + lo[e] + t]; en0[e] = P.out_end[U.ep_off[e] + lo[e] + t]; }
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int w = wd[e];
             const int64_t* os = P.out_start + U.ep_off[e];
             const int64_t* oe = P.out_end + U.ep_off[e];
             const uint64_t* gone = mode == 1 ? P.gone + ie_index(U, e, i) * kCandWords : nullptr;
             int c = 0;
             for (int r0 = 0; r0 < w; r0 += nt) {
                 const int r = r0 + t;
-                int64_t st = 0, e2 = 0;
+                int64_t st = st0[e], e2 = en0[e];
                 bool inside = false;
                 if (r < w) {
-                    st = os[lo[e] + r]; e2 = oe[lo[e] + r];
+                    if (r0 > 0) { st = os[lo[e] + r]; e2 = oe[lo[e] + r]; }
                     inside = !(in_start > st || e2 > in_end);
                     if (inside && gone != nullptr) inside = !((gone[r >> 6] >> (r & 63)) & 1ull);
                 }
@@ -880,6 +901,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             none |= c == 0;
         }
         wave_sync();
+        TW_PHASE(0);
         int64_t leaves = 0;
         int nout = 0;
         if (!none) {
@@ -941,6 +963,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         // be followed by exactly the candidates that start no earlier than its latest predecessor ends -- the staged
         // candidates are in start order, so that is a tail of the list, found by bisection: one lane per prefix, the
         // children written behind one another (wavefront prefix sum of the counts), depth-first order kept
+        TW_PHASE(1);
         bool use_front = false;
         int n_front = 0;
         const unsigned long long* front = nullptr;
@@ -1014,6 +1037,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         LdsHeap<E, W> hp;
         hp.heap = sheap; hp.nheap = 0; hp.ls = ls;
         wave_sync();
+        TW_PHASE(2);
         double ts[kTopK];
         int tslot[kTopK], nk = 0;
         bool exact_replay = false, ambiguous = false;
@@ -1042,13 +1066,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
 #pragma unroll
         for (int e = 0; e < E; e++) magic[e] = (uint32_t)((0x100000000ull + (unsigned)cn[e] - 1ull) / (unsigned)cn[e]);
         auto grid_digits = [&](int g, int32_t (&x)[E]) {
-            uint32_t rest = (uint32_t)g;
-            if (use_front) {   // g-th listed tuple
-                const unsigned long long ent = front[rest];
-#pragma unroll
-                for (int e = 0; e < E; e++) x[e] = (int32_t)((ent >> (8 * e)) & 255ull);
-                return;
-            }
+            uint32_t rest = (uint32_t)g;   // (listed tuples are read from the list instead, see the batch loop)
 #pragma unroll
             for (int e = E - 1; e >= 0; e--) {
                 if (e >= L) {
@@ -1060,9 +1078,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         };
         // order of the candidate tuple (prefix px[0..L) + grid point gj) against the kept tuple in LDS slot sl
         // when their scores are equal: +1 candidate greater, -1 smaller, 0 equivalent
-        auto tie_order = [&](int gj, int sl) -> int {
-            int32_t ci[E];
-            grid_digits(gj, ci);
+        auto tie_order = [&](const int32_t (&ci)[E], int sl) -> int {
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 const int32_t ki = keep_idx[sl][e];
@@ -1117,13 +1133,23 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                 wave_sync();
             }
             bool any = false;
+            unsigned long long ent_next = use_front && t < Gtot ? front[t] : 0ull;   // listed tuples: one batch ahead of their use
             for (int base = 0; base < Gtot; base += nt) {
                 const int g = base + t;
                 bool ok = g < Gtot;
                 double score = 0.0;
                 int32_t x[E];
                 int64_t xs[E], xe[E];
-                grid_digits(ok ? g : 0, x);
+                if (use_front) {
+#pragma unroll
+                    for (int e = 0; e < E; e++) x[e] = (int32_t)((ent_next >> (8 * e)) & 255ull);
+                    ent_next = g + nt < Gtot ? front[g + nt] : 0ull;
+                } else grid_digits(ok ? g : 0, x);
+                // the lane's tuple as staged positions, 8 bits each: whoever inserts it gets it by shuffle (the listed tuples
+                // live in global memory: reading them again, one lane at a time, cost a round trip per insertion)
+                unsigned long long packed = 0ull;
+#pragma unroll
+                for (int e = 0; e < E; e++) packed |= (unsigned long long)(uint32_t)x[e] << (8 * e);
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     if (e < L) {
@@ -1183,10 +1209,12 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         const int j = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
                         const double sj = __shfl(score, j);
+                        const unsigned long long pj = __shfl(packed, j);
                         if (t == 0) {
                             Cand<E> cand;
                             cand.score = sj;
-                            grid_digits(base + j, cand.idx);
+#pragma unroll
+                            for (int e = 0; e < E; e++) cand.idx[e] = (int32_t)((pj >> (8 * e)) & 255ull);
                             hp.push(cand);
                         }
                     }
@@ -1212,7 +1240,10 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         const int j = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
                         const double sj = __shfl(score, j);
-                        const int gj = base + j;
+                        const unsigned long long pj = __shfl(packed, j);
+                        int32_t cj[E];
+#pragma unroll
+                        for (int e = 0; e < E; e++) cj[e] = (int32_t)((pj >> (8 * e)) & 255ull);
                         // exact order against every kept entry of equal score (rare): greater[k] / equivalence
                         int tie[kTopK];
 #pragma unroll
@@ -1222,7 +1253,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                                 int sl = 0;
 #pragma unroll
                                 for (int q = 0; q < kTopK; q++) if (q == k) sl = tslot[q];
-                                tie[k] = tie_order(gj, sl);
+                                tie[k] = tie_order(cj, sl);
                                 if (tie[k] == 0) ambiguous = true;
                             }
                         }
@@ -1254,10 +1285,8 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         if (nk < kTopK) nk++;
                         wave_sync();   // tie_order of this round has read keep_idx[slot] before it is overwritten
                         if (t == 0) {
-                            int32_t ci[E];
-                            grid_digits(gj, ci);
 #pragma unroll
-                            for (int e = 0; e < E; e++) keep_idx[slot][e] = ci[e];
+                            for (int e = 0; e < E; e++) keep_idx[slot][e] = cj[e];
                         }
                         wave_sync();
                     }
@@ -1287,6 +1316,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         }
         }  // attempt
         wave_sync();
+        TW_PHASE(3);
         if (t == 0) {
             if (exact_replay) hp.sort_desc();
             else {
@@ -1329,6 +1359,8 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             }
         }
         wave_sync();
+        TW_PHASE(4);
+        TW_ITEM_END(leaves);
     }
 }
 
