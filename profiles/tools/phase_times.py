@@ -18,7 +18,7 @@ for lib in sys.argv[1:]:
     eng.close()
 import ctypes
 eng = Engine(0); eng.load(units)
-out = np.zeros(10, dtype=np.int32)
+out = np.zeros(16, dtype=np.int32)
 eng.run_pass1(); eng._lib.tw_debug_worklists(eng._h, ctypes.c_void_p(out.ctypes.data)); print("pass1 worklists: select windows", out[0], "heavy spans by E", out[1:].tolist())
 eng.fit_mixtures(); eng.run_pass2(); eng._lib.tw_debug_worklists(eng._h, ctypes.c_void_p(out.ctypes.data)); print("pass2 worklists: select windows", out[0], "heavy spans by E", out[1:].tolist())
 r = eng.results(2, fields=("unit_stats",)); print("windows total", sum(int(x["n_windows"]) for x in r), "in-spans", sum(u.n_in for u in units))

@@ -21,4 +21,5 @@ for pass_no in (1, 2):
     print("   wavefronts with work %d, mean lifetime %.1f us, longest %.1f us; sum of item time / 4096 = %.1f us"
           % (a[9], a[8] / max(a[9], 1) / 100.0, int(cur[6]) / 100.0, a[13] / 100.0 / 4096))
     tot = float(a[:5].sum())
-    print("   phases: " + ", ".join("%s %.0f%%" % (n, 100.0 * a[k] / tot) for k, n in enumerate(["stage", "tables", "tuple list", "walk+top5", "results"])))
+    print("   phases: " + ", ".join("%s %.0f%%" % (n, 100.0 * a[k] / tot) for k, n in enumerate(os.environ.get("TW_PHASE_NAMES", "stage,tables,tuple list,walk+top5,results").split(","))))
+    print("   longest item: tuple list %.1f us, walk+top5 %.1f us" % (int(cur[7]) / 100.0, int(cur[10]) / 100.0))

@@ -20,5 +20,5 @@ for pass_no in (1, 2):
   t = eng.timing()
   cur = np.zeros(16, dtype=np.uint64); lib.tw_debug_profile(eng._h, ctypes.c_void_p(cur.ctypes.data))
   a = cur - prev; a[8] = cur[8]; prev = cur
-  out = np.zeros(10, dtype=np.int32); lib.tw_debug_worklists(eng._h, ctypes.c_void_p(out.ctypes.data))
+  out = np.zeros(16, dtype=np.int32); lib.tw_debug_worklists(eng._h, ctypes.c_void_p(out.ctypes.data))
   report(pass_no, t, a, out)

@@ -30,6 +30,7 @@
 #define __forceinline__ inline
 #define __noinline__
 #define __shared__ static
+#define HIP_DYNAMIC_SHARED(type, var) static type var[8192];   // (dynamic LDS of a launch: the tests' pools stay below this)
 #define __launch_bounds__(...)
 
 struct uint4 { unsigned x, y, z, w; };

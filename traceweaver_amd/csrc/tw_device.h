@@ -113,11 +113,25 @@ struct Dev {
     int32_t* heavy_next;    // next unclaimed entry of that list
     int32_t *heavy_unit, *heavy_win;
     int32_t* heavy_in_count;  // [2][kMaxEp+1] incoming spans deferred to k_enumerate_heavy per endpoint count E: narrow, wide windows
-    int32_t* heavy_in_next;   // [2][kMaxEp+1] next unclaimed entry of each list
+    int32_t* heavy_in_next;   // [3][kMaxEp+1] next unclaimed entry of each list: narrow, wide, long enumerations (when launched on their own)
     int32_t heavy_in_off[kMaxEp + 2];  // class offsets into heavy_in_unit / heavy_in_idx
     int32_t *heavy_in_unit, *heavy_in_idx;
     int32_t* heavy_big_count;   // [kMaxEp+1] narrow spans with a long enumeration: served first
-    int32_t *heavy_big_unit, *heavy_big_idx;   // class offsets as heavy_in_off
+    int32_t *heavy_big_unit, *heavy_big_idx;   // class offsets heavy_big_off (room for the extra entries of split spans)
+    int32_t heavy_big_off[kMaxEp + 2];
+    // A very long enumeration is cut into parts by the position of the first endpoint's candidate (k_enumerate_light lists one
+    // entry per part); the parts leave their top-5 in a scratch slot each and k_merge_parts combines them.
+    int32_t* heavy_big_part;   // [big list] number of parts | part << 8   (1 = the whole enumeration)
+    int32_t* heavy_big_slot;   // [big list] scratch slot of the part's result
+    int32_t part_off[kMaxEp + 2];   // class offsets into the part scratch and the split-span records (2 slots per extra entry)
+    int32_t* part_used;        // [kMaxEp+1] extra list entries handed out per class
+    int32_t* split_count;      // [kMaxEp+1] split spans per class
+    int32_t *split_unit, *split_idx, *split_slot, *split_parts;   // [part_off region] one record per split span
+    int32_t* part_n;           // [slot] entries | ambiguous << 8
+    int64_t* part_leaves;      // [slot]
+    double* part_score;        // [slot][kTopK]
+    int32_t* part_idx;         // [slot][kTopK][kMaxEp] span indices in the endpoint lists
+    unsigned long long* part_bits;   // [slot][kMaxEp] candidate spans seen in a feasible tuple (narrow windows: one word)
     int32_t* err;           // first error raised by a kernel (tw_status)
     unsigned long long* prof;  // [16] phase timers of -DTW_PROFILE builds
 };

@@ -41,6 +41,8 @@ struct tw_engine {
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[kMaxEp + 1] = {};   // one stream per endpoint count: the enumeration kernels of different classes overlap
     hipEvent_t cls_ev[kMaxEp + 2] = {};        // [0] fork, [E] class E done
+    hipStream_t big_stream[kMaxEp + 1] = {};   // the long enumerations of a class run next to its others
+    hipEvent_t big_ev[kMaxEp + 1] = {};
     std::string err;
     int state = ST_EMPTY;
     int tile = kTile;   // incoming spans (threads) per workgroup of the per-span kernels
@@ -194,8 +196,28 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
                            (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
     const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
     const int grid = std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096);  // persistent wavefronts pulling spans from the class' work list
-    hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), dim3(std::min(e->coop, kHeavyThreads)), 0, st, P, pass, mode);
-    hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), dim3(std::min(e->coop, kHeavyThreads)), 0, st, P, pass, mode);
+    const dim3 hb(std::min(e->coop, kHeavyThreads));
+    const int pool = E > 4 ? 2048 : (E > 1 ? kPairPoolPerEp * E : 1);       // doubles of pair-term tables per wavefront
+    if (mode == 0 && E > 1) {
+        // the long enumerations on a stream of their own, next to the others: few wavefronts, each with room for the tables of
+        // every primary edge (narrow windows: <= 32 x 32 pairs an edge), instead of evaluating the terms tuple by tuple
+        const int big_pool = (E > 4 ? 5 : 3) * kNarrow * kNarrow;
+        hipStream_t sb = e->big_stream[E];
+        (void)hipEventRecord(e->big_ev[E], st);
+        (void)hipStreamWaitEvent(sb, e->big_ev[E], 0);
+        hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(std::min(grid, 1024)), hb, sizeof(double) * (size_t)big_pool, sb, P, pass, mode, 1, big_pool);
+        // the parts of the split spans are combined; the few whose order of equal scores is not decided are listed again
+        // (list emptied first) and enumerated whole
+        (void)hipMemsetAsync(P.heavy_big_count + E, 0, sizeof(int32_t), sb);
+        (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), sb);
+        hipLaunchKernelGGL(k_merge_parts, dim3(64), dim3(std::min(e->coop, 64)), 0, sb, P, pass, E);
+        hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(64), hb, sizeof(double) * (size_t)big_pool, sb, P, pass, mode, 1, big_pool);
+        (void)hipEventRecord(e->big_ev[E], sb);
+        hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 2, pool);
+        (void)hipStreamWaitEvent(st, e->big_ev[E], 0);
+    } else
+        hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 0, pool);
+    hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 0, pool);
     (void)hipEventRecord(e->cls_ev[E], st);
     used = true;
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[E], 0);
@@ -328,8 +350,10 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventRecord(e->ev[EV_PARAMS], e->stream));
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
-    HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
+    HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 3 * (kMaxEp + 1), e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_big_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
+    HIPCHK(hipMemsetAsync(P.part_used, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
+    HIPCHK(hipMemsetAsync(P.split_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
     launch_enumerate_all(e, pass, 0);
     HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
     if (pass == 1) {
@@ -372,7 +396,7 @@ int run_pass(tw_engine* e, int pass) {
         HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
         hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P);
         HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
-        HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
+        HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 3 * (kMaxEp + 1), e->stream));
         HIPCHK(hipMemsetAsync(P.heavy_big_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
         HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 3, e->stream));
         HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t), e->stream));
@@ -569,6 +593,8 @@ int tw_create(int device_id, tw_engine** out) {
     for (int i = 0; i < EV_COUNT && s == hipSuccess; i++) s = hipEventCreate(&e->ev[i]);
     for (int i = 1; i <= kMaxEp && s == hipSuccess; i++) s = hipStreamCreate(&e->cls_stream[i]);
     for (int i = 0; i <= kMaxEp + 1 && s == hipSuccess; i++) s = hipEventCreateWithFlags(&e->cls_ev[i], hipEventDisableTiming);
+    for (int i = 1; i <= kMaxEp && s == hipSuccess; i++) s = hipStreamCreate(&e->big_stream[i]);
+    for (int i = 1; i <= kMaxEp && s == hipSuccess; i++) s = hipEventCreateWithFlags(&e->big_ev[i], hipEventDisableTiming);
     if (s != hipSuccess) {
         fprintf(stderr, "tw_create: %s\n", hipGetErrorString(s));
         delete e;
@@ -589,6 +615,10 @@ void tw_destroy(tw_engine* e) {
         if (e->cls_ev[i]) (void)hipEventDestroy(e->cls_ev[i]);
     for (int i = 1; i <= kMaxEp; i++)
         if (e->cls_stream[i]) (void)hipStreamDestroy(e->cls_stream[i]);
+    for (int i = 1; i <= kMaxEp; i++) {
+        if (e->big_ev[i]) (void)hipEventDestroy(e->big_ev[i]);
+        if (e->big_stream[i]) (void)hipStreamDestroy(e->big_stream[i]);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -762,8 +792,24 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.gaps, gaps);
     ALLOC(P.unit_stats, (int64_t)P.n_units * 8); ALLOC(P.err, 1);
     ALLOC(e->tile_ids, (int64_t)tile_ids_h.size());
-    ALLOC(P.heavy_in_count, 2 * (kMaxEp + 1)); ALLOC(P.heavy_in_next, 2 * (kMaxEp + 1)); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
-    ALLOC(P.heavy_big_count, kMaxEp + 1); ALLOC(P.heavy_big_unit, n_in_total); ALLOC(P.heavy_big_idx, n_in_total);
+    ALLOC(P.heavy_in_count, 2 * (kMaxEp + 1)); ALLOC(P.heavy_in_next, 3 * (kMaxEp + 1)); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
+    {   // long enumerations: a list entry per span plus the extra entries of the split ones (an eighth of the class + 64), two
+        // scratch slots per extra entry
+        int64_t big_total = 0, slots = 0;
+        for (int cls = 0; cls <= kMaxEp; cls++) {
+            const int64_t n_cls = heavy_off_h[cls + 1] - heavy_off_h[cls];
+            const int64_t extra = n_cls > 0 ? n_cls / 8 + 64 : 0;
+            P.heavy_big_off[cls] = (int32_t)big_total; P.part_off[cls] = (int32_t)slots;
+            big_total += n_cls + extra; slots += 2 * extra;
+        }
+        P.heavy_big_off[kMaxEp + 1] = (int32_t)big_total; P.part_off[kMaxEp + 1] = (int32_t)slots;
+        ALLOC(P.heavy_big_count, kMaxEp + 1); ALLOC(P.heavy_big_unit, big_total); ALLOC(P.heavy_big_idx, big_total);
+        ALLOC(P.heavy_big_part, big_total); ALLOC(P.heavy_big_slot, big_total);
+        ALLOC(P.part_used, kMaxEp + 1); ALLOC(P.split_count, kMaxEp + 1);
+        ALLOC(P.split_unit, slots); ALLOC(P.split_idx, slots); ALLOC(P.split_slot, slots); ALLOC(P.split_parts, slots);
+        ALLOC(P.part_n, slots); ALLOC(P.part_leaves, slots); ALLOC(P.part_score, slots * kTopK); ALLOC(P.part_idx, slots * kTopK * kMaxEp);
+        ALLOC(P.part_bits, slots * kMaxEp);
+    }
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
     ALLOC(P.prof, 16); ALLOC(e->key_acc, 2);
     ALLOC(P.heavy_count, 3); ALLOC(P.heavy_next, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);
@@ -1216,7 +1262,8 @@ void tw_host_free(void* p) {
 }
 
 /* Debug aid, not part of the public header: sizes of the work lists of the last pass --
- * out[0] = windows listed for k_select_heavy, out[1 + E] = spans listed for k_enumerate_heavy<E>. */
+ * out[0] = windows listed for k_select_heavy, out[1 + E] = spans listed for k_enumerate_heavy<E> (E <= kMaxEp),
+ * out[2 + kMaxEp] = spans enumerated in parts, out[3 + kMaxEp] = of those, enumerated once more as a whole (out: 4 + kMaxEp ints). */
 int tw_debug_worklists(tw_engine* e, int32_t* out) {
     if (e == nullptr || out == nullptr || e->state < ST_PASS1) return TW_ERR_ARG;
     int32_t sel[3];
@@ -1226,6 +1273,10 @@ int tw_debug_worklists(tw_engine* e, int32_t* out) {
     HIPCHK(hipStreamSynchronize(e->stream));
     out[0] = sel[1] + sel[2];
     for (int k = 0; k <= kMaxEp; k++) out[1 + k] = both[k] + both[kMaxEp + 1 + k];
+    int32_t split[kMaxEp + 1];   // [0] spans listed again after the merge, [E >= 2] split spans of the class
+    HIPCHK(hipMemcpy(split, e->P.split_count, sizeof(split), hipMemcpyDeviceToHost));
+    out[2 + kMaxEp] = 0; out[3 + kMaxEp] = split[0];
+    for (int k = 2; k <= kMaxEp; k++) out[2 + kMaxEp] += split[k];
     return TW_OK;
 }
 

@@ -323,13 +323,13 @@ constexpr int kHeavyThreads = 64;
 #ifdef TW_PROFILE
 // prof[12] longest item (ticks << 24 | tuples, capped), [13] sum of item ticks, [14] items, [8] sum of wavefront lifetimes,
 // [9] wavefronts that drew work, [6] longest wavefront lifetime, [15] items >= 100 us -- of the narrow E = 4 instantiation
-#define TW_PROF_DECL() const long long _tw_born = wall_clock64(); long long _tw_t = _tw_born, _tw_p = _tw_born, _tw_ph[5] = {0, 0, 0, 0, 0}; const bool _tw_on = (E == 4 && !kWide && mode == 0)
-#define TW_ITEM_BEGIN() do { _tw_t = wall_clock64(); _tw_p = _tw_t; } while (0)
+#define TW_PROF_DECL() const long long _tw_born = wall_clock64(); long long _tw_t = _tw_born, _tw_p = _tw_born, _tw_ph[5] = {0, 0, 0, 0, 0}, _tw_it[5] = {0, 0, 0, 0, 0}; const bool _tw_on = (E == 4 && !kWide && mode == 0)
+#define TW_ITEM_BEGIN() do { _tw_t = wall_clock64(); _tw_p = _tw_t; for (int _k = 0; _k < 5; _k++) _tw_it[_k] = 0; } while (0)
 // phases of an item: [0] stage candidates, [1] term and pair tables, [2] tuple list, [3] walk + top-5, [4] results
-#define TW_PHASE(k) do { const long long _n = wall_clock64(); _tw_ph[k] += _n - _tw_p; _tw_p = _n; } while (0)
+#define TW_PHASE(k) do { const long long _n = wall_clock64(); _tw_ph[k] += _n - _tw_p; _tw_it[k] += _n - _tw_p; _tw_p = _n; } while (0)
 #define TW_ITEM_END(tuples) do { if (_tw_on && threadIdx.x == 0) { const unsigned long long _d = (unsigned long long)(wall_clock64() - _tw_t); \
     const unsigned long long _l = (unsigned long long)(tuples) > 0xffffffull ? 0xffffffull : (unsigned long long)(tuples); \
-    atomicMax((unsigned long long*)&P.prof[12], (_d << 24) | _l); atomicAdd((unsigned long long*)&P.prof[13], _d); atomicAdd((unsigned long long*)&P.prof[14], 1ull); \
+    if (atomicMax((unsigned long long*)&P.prof[12], (_d << 24) | _l) < ((_d << 24) | _l)) { P.prof[11] = ((unsigned long long)_tw_it[0] << 48) | ((unsigned long long)_tw_it[1] << 32) | ((unsigned long long)_tw_it[2] << 16) | (unsigned long long)_tw_it[3]; P.prof[10] = (unsigned long long)_tw_it[3]; P.prof[7] = (unsigned long long)_tw_it[2]; } atomicAdd((unsigned long long*)&P.prof[13], _d); atomicAdd((unsigned long long*)&P.prof[14], 1ull); \
     if (_d >= 10000ull) atomicAdd((unsigned long long*)&P.prof[15], 1ull); } } while (0)
 #define TW_PROF_FLUSH() do { if (_tw_on && threadIdx.x == 0) { const unsigned long long _d = (unsigned long long)(wall_clock64() - _tw_born); \
     atomicAdd((unsigned long long*)&P.prof[8], _d); atomicAdd((unsigned long long*)&P.prof[9], 1ull); atomicMax((unsigned long long*)&P.prof[6], _d); \
@@ -349,14 +349,53 @@ constexpr int kNarrow = 32;
 // Narrow spans whose enumeration is long (product of the staged candidates > kBigProduct) go to a list of their own that
 // the narrow instantiation serves first, one to a wavefront: a persistent kernel ends with its longest item, so the long
 // ones must not start last.
-constexpr int kBigProduct = 768;
+#ifndef TW_BIG_PRODUCT
+#define TW_BIG_PRODUCT 768
+#define TW_SPLIT_MIN 4096
+#define TW_SPLIT_GRAIN 2048
+#define TW_GRID_TARGET 1024
+#endif
+constexpr int kBigProduct = TW_BIG_PRODUCT;
+// One wavefront scores ~0.5 tuples per ns when it has a SIMD to itself: a span with 4e4 tuples (one in 1e5 on the bench
+// workload) kept a kernel alive for 1.5 ms that was otherwise done after 0.6 ms.  From kSplitMin contained grid points on, the
+// span is listed kSplitGrain points a part (at most kMaxParts, at most one part per candidate of the first endpoint): part p
+// takes the tuples whose first span is among the p-th share of that endpoint's staged candidates.  (The host-emulation
+// build of the tests sets tiny thresholds so that the route is exercised.)
+constexpr int kSplitMin = TW_SPLIT_MIN, kSplitGrain = TW_SPLIT_GRAIN, kMaxParts = 16;
 template <int E>
-__device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narrow, bool big, int unit, int i) {
-    const int sb = wave_append(&P.heavy_big_count[E], pred && narrow && big);
+__device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narrow, bool big, int unit, int i, long long prod = 0, int first_cands = 0) {
+    const bool isbig = pred && narrow && big;
+    int nparts = 1, slot_base = 0;
+    if (E >= 2 && isbig && prod >= kSplitMin && first_cands >= 2) {
+        long long want = prod / kSplitGrain;
+        want = want > kMaxParts ? kMaxParts : want;
+        nparts = (int)(want > first_cands ? first_cands : want);
+        if (nparts >= 2) {   // the class' budget of extra list entries (two scratch slots go with each)
+            const int old = atomicAdd(&P.part_used[E], nparts - 1);
+            if (old + nparts - 1 > (P.part_off[E + 1] - P.part_off[E]) / 2) nparts = 1;
+            else slot_base = P.part_off[E] + 2 * old;
+        } else nparts = 1;
+    }
+    const bool split = nparts > 1;
+    const int sb = wave_append(&P.heavy_big_count[E], isbig && !split);
     const int sn = wave_append(&P.heavy_in_count[E], pred && narrow && !big);
     const int sw = wave_append(&P.heavy_in_count[kMaxEp + 1 + E], pred && !narrow);
     if (!pred) return false;
-    if (narrow && big) { P.heavy_big_unit[P.heavy_in_off[E] + sb] = unit; P.heavy_big_idx[P.heavy_in_off[E] + sb] = i; return true; }
+    if (split) {
+        const int base = P.heavy_big_off[E] + atomicAdd(&P.heavy_big_count[E], nparts);
+        for (int p = 0; p < nparts; p++) {
+            P.heavy_big_unit[base + p] = unit; P.heavy_big_idx[base + p] = i;
+            P.heavy_big_part[base + p] = nparts | (p << 8); P.heavy_big_slot[base + p] = slot_base + p;
+        }
+        const int k = P.part_off[E] + atomicAdd(&P.split_count[E], 1);
+        P.split_unit[k] = unit; P.split_idx[k] = i; P.split_slot[k] = slot_base; P.split_parts[k] = nparts;
+        return true;
+    }
+    if (isbig) {
+        const int q = P.heavy_big_off[E] + sb;
+        P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1; P.heavy_big_slot[q] = 0;
+        return true;
+    }
     const int pos = narrow ? P.heavy_in_off[E] + sn : P.heavy_in_off[E + 1] - 1 - sw;
     P.heavy_in_unit[pos] = unit;
     P.heavy_in_idx[pos] = i;
@@ -605,6 +644,7 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
     int64_t prod = empty ? 0 : 1;
 #pragma unroll
     for (int e = 0; e < E; e++) if (prod > 0 && prod <= kLightMax) prod *= (c.hi[e] - c.lo[e] + 1);
+    int first_cands = 0;
     if (prod > kLightMax && narrow) {
         // the windows also hold spans that start inside the incoming span but end after it; what the enumeration
         // costs is the product of the *contained* candidates (a third of the raw product on the bench workload)
@@ -614,9 +654,10 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
             int v = 0;
             for (int cx = c.lo[e]; cx <= c.hi[e]; cx++) v += (c.os[e][cx] >= c.in_start && c.oe[e][cx] <= c.in_end) ? 1 : 0;
             if (prod <= (1ll << 40)) prod *= v;
+            if (e == 0) first_cands = v;
         }
     }
-    if (heavy_append<E>(P, prod > kLightMax, narrow, prod > kBigProduct, T.unit, i)) return;
+    if (heavy_append<E>(P, prod > kLightMax, narrow, prod > kBigProduct, T.unit, i, prod, U.skip ? 0 : first_cands)) return;
     c.nk = 0; c.leaves = 0; c.ambiguous = false;
 #pragma unroll
     for (int k = 0; k < kTopK; k++) c.ts[k] = -dinf();
@@ -772,7 +813,7 @@ struct LdsHeap {
 //     ~1.5k instructions and an 8-endpoint tuple has up to 9 of them.  The tuple score adds the same doubles in the
 //     same order as the reference, so it is bit-identical.
 constexpr int kPairPoolPerEp = 160;   // doubles of pair-term tables per endpoint (E <= 4); 2048 doubles (16 KB) for the deep call graphs
-constexpr int kGridTarget = 1024;     // grid points per prefix the split of the endpoints aims at (a prefix step costs about as much as five grid batches)
+constexpr int kGridTarget = TW_GRID_TARGET;     // grid points per prefix the split of the endpoints aims at (a prefix step costs about as much as five grid batches)
 // Deep call graphs with many candidates per endpoint (Alibaba shape: 7-8 endpoints x 10-14 candidates = 10^7-10^8 grid
 // points for 10^4-10^5 feasible tuples): walking the prefixes one after the other and testing a dense grid below each
 // leaves most lanes idle (0.1 % of the grid is feasible).  Such a span first lists its feasible tuples, level by level
@@ -788,16 +829,20 @@ constexpr int kFrontierBigCap = TW_FRONTIER_BIG_CAP;       // ... of kFrontierBi
 constexpr int kFrontierSlots = 4096;            // buffer pairs of kFrontierCap entries, claimed by the wavefronts that need one
 constexpr int kFrontierBigSlots = TW_FRONTIER_BIG_SLOTS;   // (the host-emulation build of the tests uses tiny sizes so that all three routes are exercised)
 template <int E, int W>
-__global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass, int mode) {
+__global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass, int mode, int part, int pool) {
+    // part: 0 = the long enumerations first, then the others (one launch serves both lists); 1 = only the long ones, 2 = only the
+    // others -- two launches side by side, the first with a pair-term pool (dynamic LDS, `pool` doubles) that holds the
+    // tables of every primary edge, which the occupancy of the second cannot afford
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     static_assert(W == kNarrow || W == 64 * kCandWords, "one instantiation per half of the work list");
     constexpr bool kWide = W != kNarrow;
     constexpr int kList = kWide ? kMaxEp + 1 + E : E;
-    constexpr int kPool = E > 4 ? 2048 : (E > 1 ? kPairPoolPerEp * E : 1);
+    constexpr int kNext = kWide ? kMaxEp + 1 + E : E;   // (part 1 has a counter of its own, see below)
+    const int kPool = pool;
     __shared__ unsigned long long sbits[kMaxEp][kCandWords];
     __shared__ int64_t ls[E][W], le[E][W];      // staged candidates: start / end
     __shared__ double troot[E][W], tclose[E][W];
-    __shared__ double tpair[kPool];
+    HIP_DYNAMIC_SHARED(double, tpair)
     __shared__ int16_t tp_off[E][E];            // pair table of the j-th in-edge of endpoint e, -1: evaluated per tuple
     __shared__ uint8_t lr[E][W];                // position of the staged candidate in the cut-off window
     __shared__ Cand<E> sheap[kTopK + 1];        // CPython heap replay (degenerate ties only), lane 0
@@ -805,8 +850,9 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
     __shared__ int32_t px[E];                   // the prefix the wavefront is walking (staged positions, same for every lane)
     __shared__ int64_t pxs[E], pxe[E];
     const int t = threadIdx.x, nt = blockDim.x;
-    const int n_big = kWide ? 0 : P.heavy_big_count[E];
-    const int count = n_big + P.heavy_in_count[kList];
+    const int n_big = (kWide || part == 2) ? 0 : P.heavy_big_count[E];
+    const int count = n_big + (part == 1 ? 0 : P.heavy_in_count[kList]);
+    int32_t* next_counter = &P.heavy_in_next[part == 1 ? 2 * (kMaxEp + 1) + E : kNext];
     const int nstatic = (int)gridDim.x * kWorkChunk;
     if ((int)blockIdx.x >= count) return;   // nothing for this wavefront (its strided static items start at its block index)
     int chunk_pos = 0, chunk_end = 0;
@@ -821,7 +867,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         if (chunk_pos == chunk_end) {
             if (first_chunk) { chunk_pos = (int)blockIdx.x * kWorkChunk; first_chunk = false; }
             else {
-                if (t == 0) chunk_pos = nstatic + atomicAdd(&P.heavy_in_next[kList], kWorkChunk);
+                if (t == 0) chunk_pos = nstatic + atomicAdd(next_counter, kWorkChunk);
                 chunk_pos = __shfl(chunk_pos, 0);
             }
             const int limit = chunk_pos < nstatic ? nstatic : count;   // static chunks are strided over the wavefronts below
@@ -834,9 +880,13 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         // wave-uniform by construction; telling the compiler so turns every access to the unit descriptor below
         // into a scalar load (SGPRs, constant cache) instead of 64 lanes loading the same address
         const bool from_big = item < n_big;
-        const int pos = from_big ? P.heavy_in_off[E] + item : (kWide ? P.heavy_in_off[E + 1] - 1 - item : P.heavy_in_off[E] + (item - n_big));
+        const int pos = from_big ? P.heavy_big_off[E] + item : (kWide ? P.heavy_in_off[E + 1] - 1 - item : P.heavy_in_off[E] + (item - n_big));
         const int unit = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_unit : P.heavy_in_unit)[pos]);
         const int i = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_idx : P.heavy_in_idx)[pos]);
+        // a part of a split enumeration?  (number of parts, which one, where its result goes)
+        const int part_info = from_big ? __builtin_amdgcn_readfirstlane(P.heavy_big_part[pos]) : 1;
+        const int nparts = part_info & 255, part_no = part_info >> 8;
+        const int part_slot = from_big ? __builtin_amdgcn_readfirstlane(P.heavy_big_slot[pos]) : 0;
         const UnitDev& U = P.units[unit];
         TW_ITEM_BEGIN();
         const int64_t in_start = P.in_start[U.in_off + i], in_end = P.in_end[U.in_off + i];
@@ -904,6 +954,9 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         TW_PHASE(0);
         int64_t leaves = 0;
         int nout = 0;
+        int c0_begin = 0, c0_end = cn[0];   // the staged candidates of the first endpoint this wavefront enumerates
+        if (nparts > 1) { c0_begin = (int)((long long)part_no * cn[0] / nparts); c0_end = (int)((long long)(part_no + 1) * cn[0] / nparts); none |= c0_begin == c0_end; }
+        bool part_ambiguous = false;
         if (!none) {
         {   // one (candidate span, root | closing) term per lane, all endpoints at once
             int wsum = 0;
@@ -985,8 +1038,8 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                 const int lane = t & 63;
                 for (int tries = 0; tries < 2; tries++) {
                     unsigned long long* fb = fa + cap;
-                    for (int c = t; c < cn[0]; c += nt) fa[c] = (unsigned long long)c;
-                    int nprev = cn[0];
+                    for (int c = c0_begin + t; c < c0_end; c += nt) fa[c - c0_begin] = (unsigned long long)c;
+                    int nprev = c0_end - c0_begin;
                     use_front = true;
                     __threadfence_block();
                     wave_sync();
@@ -1038,6 +1091,14 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         hp.heap = sheap; hp.nheap = 0; hp.ls = ls;
         wave_sync();
         TW_PHASE(2);
+        // candidate spans that occur in a feasible tuple (pass 1): every lane collects its own in registers and adds them
+        // to the bitmap in LDS once per span -- one same-address LDS atomic per lane, endpoint and BATCH was a fifth of the walk
+        constexpr int kBitWords = (W + 63) / 64;
+        unsigned long long mybits[E][kBitWords];
+#pragma unroll
+        for (int e = 0; e < E; e++)
+#pragma unroll
+            for (int w = 0; w < kBitWords; w++) mybits[e][w] = 0ull;
         double ts[kTopK];
         int tslot[kTopK], nk = 0;
         bool exact_replay = false, ambiguous = false;
@@ -1060,6 +1121,10 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                 if (L == e + 1 && G < kHeavyThreads) { L = e; G *= cn[e]; }
         }
         if (use_front) { L = E; G = 1; }   // the tuples are listed: no walk, no grid
+        // a part walks its share of the first level; if that level is inside the grid (short enumerations only: never with the
+        // production thresholds) the first part takes everything and the others nothing
+        int w0_begin = c0_begin, w0_end = c0_end;
+        if (nparts > 1 && L == 0) { w0_begin = 0; w0_end = part_no == 0 ? cn[0] : 0; }
         // grid point -> staged positions of the levels L..E-1, last endpoint fastest: divisions by the wave-uniform
         // counts as multiplications (exact for g * (c - 1) < 2^32)
         uint32_t magic[E];
@@ -1101,16 +1166,17 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
             return 0;
         };
         int d = 0;
-        if (L > 0 && t == 0) px[0] = -1;
+        if (L > 0 && t == 0) px[0] = w0_begin - 1;
         wave_sync();
         const bool once = (L == 0) || use_front;
-        const int Gtot = use_front ? n_front : G;
+        const int Gtot = use_front ? n_front : (nparts > 1 && L == 0 && w0_end == 0 ? 0 : G);
         while (once || d >= 0) {
             if (L > 0 && !use_front) {  // next feasible prefix, every lane in lockstep (DfsTraverseX order)
                 int cd = 0;
                 uint32_t pmd = 0;
 #pragma unroll
                 for (int e = 0; e < E; e++) if (e == d) { cd = cn[e]; pmd = dag_pm[e]; }
+                if (d == 0) cd = w0_end;
                 int c = px[d] + 1;
                 bool found = false;
                 int64_t fst = 0, fen = 0;
@@ -1191,7 +1257,11 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                     if (pass == 1 && mode == 0) {
 #pragma unroll
                         for (int e = 0; e < E; e++)
-                            if (e >= L || use_front) { const int r = lr[e][x[e]]; atomicOr(&sbits[e][r >> 6], 1ull << (r & 63)); }
+                            if (e >= L || use_front) {
+                                const int r = lr[e][x[e]];
+#pragma unroll
+                                for (int w = 0; w < kBitWords; w++) if ((r >> 6) == w) mybits[e][w] |= 1ull << (r & 63);
+                            }
                     }
                 }
                 const unsigned long long feasible = __ballot(ok);
@@ -1292,7 +1362,9 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                     }
                 }
                 wave_sync();
+                if (nparts > 1 && ambiguous) break;   // (uniform) the span will be enumerated as a whole anyway
             }
+            if (nparts > 1 && ambiguous) break;
             if (t == 0 && any && pass == 1 && mode == 0 && !use_front)
                 for (int e = 0; e < L; e++) {
                     const int r = lr[e][px[e]];
@@ -1311,10 +1383,17 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                         for (int q = 0; q < kTopK; q++) { if (q == a) sa = tslot[q]; if (q == b2) sb = tslot[q]; }
                         if (slot_order(sa, sb) == 0) ambiguous = true;
                     }
+            if (nparts > 1) { part_ambiguous = ambiguous; break; }   // a part cannot replay CPython's heap: the whole span is redone (k_merge_parts)
             if (!ambiguous) break;
             wave_sync();
         }
         }  // attempt
+        if (pass == 1 && mode == 0) {
+#pragma unroll
+            for (int e = 0; e < E; e++)
+#pragma unroll
+                for (int w = 0; w < kBitWords; w++) if (mybits[e][w] != 0ull) atomicOr(&sbits[e][w], mybits[e][w]);
+        }
         wave_sync();
         TW_PHASE(3);
         if (t == 0) {
@@ -1334,6 +1413,21 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         wave_sync();
         nout = exact_replay ? __shfl(hp.nheap, 0) : nk;
         }  // !none
+        if (nparts > 1) {   // a part: its top-5 (span indices), tuple count and candidate bitmap go to the scratch slot
+            if (t == 0) { P.part_n[part_slot] = nout | (part_ambiguous ? 256 : 0); P.part_leaves[part_slot] = leaves; }
+            for (int q = t; q < kTopK * (E + 1); q += nt) {
+                const int k = q / (E + 1), f = q % (E + 1);
+                if (k >= nout) continue;
+                if (f == E) P.part_score[(int64_t)part_slot * kTopK + k] = sheap[k].score;
+                else {
+                    int loe = 0;
+#pragma unroll
+                    for (int x = 0; x < E; x++) if (x == f) loe = lo[x];
+                    P.part_idx[((int64_t)part_slot * kTopK + k) * kMaxEp + f] = loe + (int)lr[f][sheap[k].idx[f]];
+                }
+            }
+            for (int q = t; q < E; q += nt) P.part_bits[(int64_t)part_slot * kMaxEp + q] = sbits[q][0];
+        } else
         {   // results leave through all lanes: one (entry, field) per lane; staged positions back to span indices
             const int64_t g = U.in_off + i;
             int32_t* out_n = mode == 1 ? P.tkr_n : P.tk_n;
@@ -1361,6 +1455,89 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         wave_sync();
         TW_PHASE(4);
         TW_ITEM_END(leaves);
+    }
+}
+
+// Combines the parts of the split spans of the endpoint-count class E (see kSplitMin): the five largest tuples of the union
+// under Python's order of (score, [spans]) -- score, then start_mus of the first differing span -- the sum of the tuple
+// counts and the union of the candidate bitmaps.  The parts partition the tuples by their first span, in enumeration order,
+// and each kept its own five largest, so the five largest of the union are among the kept ones.  Where that order does not
+// decide (two kept tuples of equal score whose first differing spans start together, inside a part or across parts), the
+// reference's result depends on the order of its heap operations: such a span is put back on the class' list (the host has
+// emptied it) and enumerated once more by one wavefront, which replays CPython's heap.  One lane per split span.
+__global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
+    if (*P.err != 0) return;
+    const int n = P.split_count[E];
+    for (int s = (int)(blockIdx.x * blockDim.x + threadIdx.x); s < n; s += (int)(gridDim.x * blockDim.x)) {
+        const int rec = P.part_off[E] + s;
+        const int unit = P.split_unit[rec], i = P.split_idx[rec], slot0 = P.split_slot[rec], nparts = P.split_parts[rec];
+        const UnitDev& U = P.units[unit];
+        bool redo = false;
+        int64_t leaves = 0;
+        int total = 0;
+        unsigned long long bits[kMaxEp];
+        for (int e = 0; e < kMaxEp; e++) bits[e] = 0ull;
+        for (int p = 0; p < nparts; p++) {
+            const int np = P.part_n[slot0 + p];
+            redo |= (np >> 8) != 0;
+            total += np & 255;
+            leaves += P.part_leaves[slot0 + p];
+            for (int e = 0; e < E; e++) bits[e] |= P.part_bits[(int64_t)(slot0 + p) * kMaxEp + e];
+        }
+        const int C = nparts * kTopK;
+        auto valid = [&](int c) { return (c % kTopK) < (P.part_n[slot0 + c / kTopK] & 255); };
+        auto score = [&](int c) { return P.part_score[(int64_t)(slot0 + c / kTopK) * kTopK + c % kTopK]; };
+        auto span = [&](int c, int e) { return P.part_idx[((int64_t)(slot0 + c / kTopK) * kTopK + c % kTopK) * kMaxEp + e]; };
+        auto order = [&](int a, int b) -> int {   // equal scores: +1 a greater, -1 smaller, 0 Python cannot tell
+            for (int e = 0; e < E; e++) {
+                const int ia = span(a, e), ib = span(b, e);
+                if (ia != ib) {
+                    const int64_t sa = P.out_start[U.ep_off[e] + ia], sb = P.out_start[U.ep_off[e] + ib];
+                    return sa > sb ? 1 : (sa < sb ? -1 : 0);
+                }
+            }
+            return 0;
+        };
+        unsigned long long taken[(kMaxParts * kTopK + 63) / 64];
+        for (auto& w : taken) w = 0ull;
+        int pick[kTopK], nout = 0;
+        for (int r = 0; r < kTopK; r++) {
+            int best = -1;
+            for (int c = 0; c < C; c++) {
+                if (!valid(c) || ((taken[c >> 6] >> (c & 63)) & 1ull)) continue;
+                if (best < 0) { best = c; continue; }
+                const double sc = score(c), sb = score(best);
+                if (sc > sb || (sc == sb && order(c, best) > 0)) best = c;
+            }
+            if (best < 0) break;
+            pick[nout++] = best;
+            taken[best >> 6] |= 1ull << (best & 63);
+        }
+        if (nout > 0) {   // does the order decide among everything that reaches the last kept score?
+            const double s_last = score(pick[nout - 1]);
+            for (int a = 0; a < C && !redo; a++) {
+                if (!valid(a) || score(a) < s_last) continue;
+                for (int b = a + 1; b < C; b++)
+                    if (valid(b) && score(b) == score(a) && order(a, b) == 0) { redo = true; break; }
+            }
+        }
+        if (redo) {
+            const int q = P.heavy_big_off[E] + atomicAdd(&P.heavy_big_count[E], 1);
+            P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1; P.heavy_big_slot[q] = 0;
+            atomicAdd(&P.split_count[0], 1);   // (classes start at E = 2: entry 0 counts the spans listed again, for tw_debug_worklists)
+            continue;
+        }
+        const int64_t g = U.in_off + i;
+        P.tk_n[g] = total < kTopK ? total : kTopK;
+        P.leaves[g] = leaves;
+        P.rep[g] = 0;
+        for (int k = 0; k < nout; k++) {   // entries a span does not have keep the -1 / NaN pattern of tw_load_batch
+            P.tk_score[tks_index(U, k, i)] = score(pick[k]);
+            for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, i)] = span(pick[k], e);
+        }
+        if (pass == 1)
+            for (int e = 0; e < E; e++)
+                for (int w = 0; w < kCandWords; w++) P.c_bits[ie_index(U, e, i) * kCandWords + w] = w == 0 ? bits[e] : 0ull;
     }
 }
 
