@@ -189,24 +189,33 @@ def test_lane_threaded_emulation(emu_lib):
     assert out.returncode == 0 and "lanes ok" in out.stdout, out.stderr[-2000:]
 
 
-def test_split_enumerations(emu_lib):
+def test_split_enumerations(emu_lib, monkeypatch):
     """Very long enumerations are cut into parts by the first endpoint's candidate and merged (k_merge_parts).  The
     host-emulation build splits from ~100 grid points on: units without call-order constraints (every grid point a
-    tuple, the prefix walk), chains (the tuple list), microsecond timestamps (the parts decide the order) and
-    millisecond ones (equal scores whose order the parts cannot decide: the span is enumerated once more as a whole).
-    Every unit equals the oracle bit for bit either way (check_units)."""
+    tuple, the prefix walk) and chains (the tuple list).  A span with two candidates of one endpoint that start together
+    is not split (Python's order of tuples may not decide between them); with TW_SPLIT_TWINS=1 it is, so that the
+    merge's way back -- order of equal scores not decided: the span is listed again and enumerated whole -- is reached
+    (millisecond timestamps).  Every unit equals the oracle bit for bit either way (check_units)."""
     from traceweaver_amd.engine import Engine
 
     cases = [(21, 120, "par4", 4, 1), (22, 120, "chain3", 6, 1), (23, 100, "diamond", 5, 1), (24, 120, "par4", 3, 1000), (25, 80, "chain5", 3, 1)]
     units, _ = parity.stress_units(cases)
+
+    def lists():
+        eng = Engine(0, lib_path=emu_lib)
+        seen = []
+        for u in units:
+            eng.load([u])
+            eng.run_pass1()
+            seen.append(eng.worklists())
+        eng.close()
+        return seen
+
     parity.check_units(emu_lib, units, allow_budget=True)
-    eng = Engine(0, lib_path=emu_lib)
-    seen = []
-    for u in units:
-        eng.load([u])
-        eng.run_pass1()
-        seen.append(eng.worklists())
-    eng.close()
+    seen = lists()
     assert all(w["split_spans"] > 0 for w in seen), seen
-    assert seen[0]["split_redone"] < seen[0]["split_spans"]        # mostly decided by the parts
-    assert seen[3]["split_redone"] > 0                             # millisecond granularity: ties the parts cannot order
+    assert all(w["split_redone"] == 0 for w in seen), seen         # no twins, no undecided order
+    monkeypatch.setenv("TW_SPLIT_TWINS", "1")
+    parity.check_units(emu_lib, units, allow_budget=True)
+    forced = lists()
+    assert forced[3]["split_spans"] > seen[3]["split_spans"] and forced[3]["split_redone"] > 0, forced

@@ -124,6 +124,7 @@ struct Dev {
     int32_t* heavy_big_part;   // [big list] number of parts | part << 8   (1 = the whole enumeration)
     int32_t* heavy_big_slot;   // [big list] scratch slot of the part's result
     int32_t part_off[kMaxEp + 2];   // class offsets into the part scratch and the split-span records (2 slots per extra entry)
+    int32_t split_twins;       // debug (TW_SPLIT_TWINS=1): also split spans with twin candidates, so that tests reach the merge's way back
     int32_t* part_used;        // [kMaxEp+1] extra list entries handed out per class
     int32_t* split_count;      // [kMaxEp+1] split spans per class
     int32_t *split_unit, *split_idx, *split_slot, *split_parts;   // [part_off region] one record per split span

@@ -41,8 +41,6 @@ struct tw_engine {
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[kMaxEp + 1] = {};   // one stream per endpoint count: the enumeration kernels of different classes overlap
     hipEvent_t cls_ev[kMaxEp + 2] = {};        // [0] fork, [E] class E done
-    hipStream_t big_stream[kMaxEp + 1] = {};   // the long enumerations of a class run next to its others
-    hipEvent_t big_ev[kMaxEp + 1] = {};
     std::string err;
     int state = ST_EMPTY;
     int tile = kTile;   // incoming spans (threads) per workgroup of the per-span kernels
@@ -198,25 +196,16 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
     const int grid = std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096);  // persistent wavefronts pulling spans from the class' work list
     const dim3 hb(std::min(e->coop, kHeavyThreads));
     const int pool = E > 4 ? 2048 : (E > 1 ? kPairPoolPerEp * E : 1);       // doubles of pair-term tables per wavefront
+    // one launch serves the class' two lists of narrow spans, the long enumerations (and the parts of the split ones) first
+    hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 0, pool);
     if (mode == 0 && E > 1) {
-        // the long enumerations on a stream of their own, next to the others: few wavefronts, each with room for the tables of
-        // every primary edge (narrow windows: <= 32 x 32 pairs an edge), instead of evaluating the terms tuple by tuple
-        const int big_pool = (E > 4 ? 5 : 3) * kNarrow * kNarrow;
-        hipStream_t sb = e->big_stream[E];
-        (void)hipEventRecord(e->big_ev[E], st);
-        (void)hipStreamWaitEvent(sb, e->big_ev[E], 0);
-        hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(std::min(grid, 1024)), hb, sizeof(double) * (size_t)big_pool, sb, P, pass, mode, 1, big_pool);
         // the parts of the split spans are combined; the few whose order of equal scores is not decided are listed again
         // (list emptied first) and enumerated whole
-        (void)hipMemsetAsync(P.heavy_big_count + E, 0, sizeof(int32_t), sb);
-        (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), sb);
-        hipLaunchKernelGGL(k_merge_parts, dim3(64), dim3(std::min(e->coop, 64)), 0, sb, P, pass, E);
-        hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(64), hb, sizeof(double) * (size_t)big_pool, sb, P, pass, mode, 1, big_pool);
-        (void)hipEventRecord(e->big_ev[E], sb);
-        hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 2, pool);
-        (void)hipStreamWaitEvent(st, e->big_ev[E], 0);
-    } else
-        hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 0, pool);
+        (void)hipMemsetAsync(P.heavy_big_count + E, 0, sizeof(int32_t), st);
+        (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), st);
+        hipLaunchKernelGGL(k_merge_parts, dim3(64), dim3(std::min(e->coop, 64)), 0, st, P, pass, E);
+        hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(256), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 1, pool);
+    }
     hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 0, pool);
     (void)hipEventRecord(e->cls_ev[E], st);
     used = true;
@@ -593,8 +582,6 @@ int tw_create(int device_id, tw_engine** out) {
     for (int i = 0; i < EV_COUNT && s == hipSuccess; i++) s = hipEventCreate(&e->ev[i]);
     for (int i = 1; i <= kMaxEp && s == hipSuccess; i++) s = hipStreamCreate(&e->cls_stream[i]);
     for (int i = 0; i <= kMaxEp + 1 && s == hipSuccess; i++) s = hipEventCreateWithFlags(&e->cls_ev[i], hipEventDisableTiming);
-    for (int i = 1; i <= kMaxEp && s == hipSuccess; i++) s = hipStreamCreate(&e->big_stream[i]);
-    for (int i = 1; i <= kMaxEp && s == hipSuccess; i++) s = hipEventCreateWithFlags(&e->big_ev[i], hipEventDisableTiming);
     if (s != hipSuccess) {
         fprintf(stderr, "tw_create: %s\n", hipGetErrorString(s));
         delete e;
@@ -615,10 +602,6 @@ void tw_destroy(tw_engine* e) {
         if (e->cls_ev[i]) (void)hipEventDestroy(e->cls_ev[i]);
     for (int i = 1; i <= kMaxEp; i++)
         if (e->cls_stream[i]) (void)hipStreamDestroy(e->cls_stream[i]);
-    for (int i = 1; i <= kMaxEp; i++) {
-        if (e->big_ev[i]) (void)hipEventDestroy(e->big_ev[i]);
-        if (e->big_stream[i]) (void)hipStreamDestroy(e->big_stream[i]);
-    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -767,6 +750,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     P.n_out_total = n_out_total;
     P.batch_size = b->batch_size;
     P.batch_mis = b->batch_size_mis;
+    P.split_twins = env_int("TW_SPLIT_TWINS", 0);
     int rc;
 #define ALLOC(ptr, count) do { rc = dev_alloc(e, &(ptr), (count)); if (rc != TW_OK) return rc; } while (0)
     e->arena_req.clear();

@@ -649,13 +649,21 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
         // the windows also hold spans that start inside the incoming span but end after it; what the enumeration
         // costs is the product of the *contained* candidates (a third of the raw product on the bench workload)
         prod = 1;
+        bool twins = false;   // two candidates of one endpoint that start together: Python's order of tuples may not decide
 #pragma unroll
         for (int e = 0; e < E; e++) {
             int v = 0;
-            for (int cx = c.lo[e]; cx <= c.hi[e]; cx++) v += (c.os[e][cx] >= c.in_start && c.oe[e][cx] <= c.in_end) ? 1 : 0;
+            int64_t prev = INT64_MIN;
+            for (int cx = c.lo[e]; cx <= c.hi[e]; cx++) {
+                const int64_t st = c.os[e][cx];
+                if (st >= c.in_start && c.oe[e][cx] <= c.in_end) { v++; twins |= st == prev; prev = st; }
+            }
             if (prod <= (1ll << 40)) prod *= v;
             if (e == 0) first_cands = v;
         }
+        // parts are only worth it when they settle the top five among themselves (k_merge_parts): with twins the span would
+        // most likely be enumerated again as a whole (millisecond-granular traces: nearly always)
+        if (twins && !P.split_twins) first_cands = 0;
     }
     if (heavy_append<E>(P, prod > kLightMax, narrow, prod > kBigProduct, T.unit, i, prod, U.skip ? 0 : first_cands)) return;
     c.nk = 0; c.leaves = 0; c.ambiguous = false;
