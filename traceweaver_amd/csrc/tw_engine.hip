@@ -203,7 +203,7 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
         // (list emptied first) and enumerated whole
         (void)hipMemsetAsync(P.heavy_big_count + E, 0, sizeof(int32_t), st);
         (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), st);
-        hipLaunchKernelGGL(k_merge_parts, dim3(64), dim3(std::min(e->coop, 64)), 0, st, P, pass, E);
+        hipLaunchKernelGGL(k_merge_parts, dim3(1024), dim3(std::min(e->coop, 64)), 0, st, P, pass, E);
         hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(256), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 1, pool);
     }
     hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 0, pool);

@@ -1472,80 +1472,94 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
 // and each kept its own five largest, so the five largest of the union are among the kept ones.  Where that order does not
 // decide (two kept tuples of equal score whose first differing spans start together, inside a part or across parts), the
 // reference's result depends on the order of its heap operations: such a span is put back on the class' list (the host has
-// emptied it) and enumerated once more by one wavefront, which replays CPython's heap.  One lane per split span.
+// emptied it) and enumerated once more by one wavefront, which replays CPython's heap.
+// One wavefront per split span: the kept tuples (<= kMaxParts * 5) sit in LDS, every lane ranks one or two of them against
+// all others, and the tuples ranked 0..4 are written by the lanes that hold them.
 __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
     if (*P.err != 0) return;
+    constexpr int kCandMax = kMaxParts * kTopK;
+    __shared__ double sc[kCandMax];
+    __shared__ int32_t sp[kCandMax][kMaxEp];
+    __shared__ int64_t ss[kCandMax][kMaxEp];    // start of the tuple's span at every endpoint
+    __shared__ uint8_t ok[kCandMax], rk[kCandMax];
+    __shared__ int redo_flag;
+    const int t = threadIdx.x, nt = blockDim.x;
     const int n = P.split_count[E];
-    for (int s = (int)(blockIdx.x * blockDim.x + threadIdx.x); s < n; s += (int)(gridDim.x * blockDim.x)) {
+    for (int s = (int)blockIdx.x; s < n; s += (int)gridDim.x) {
         const int rec = P.part_off[E] + s;
         const int unit = P.split_unit[rec], i = P.split_idx[rec], slot0 = P.split_slot[rec], nparts = P.split_parts[rec];
         const UnitDev& U = P.units[unit];
-        bool redo = false;
-        int64_t leaves = 0;
+        const int C = nparts * kTopK;
+        if (t == 0) redo_flag = 0;
+        for (int c = t; c < C; c += nt) {
+            const int slot = slot0 + c / kTopK, k = c % kTopK;
+            const int np = P.part_n[slot];
+            const bool have = k < (np & 255);
+            ok[c] = have ? 1 : 0;
+            sc[c] = have ? P.part_score[(int64_t)slot * kTopK + k] : 0.0;
+            for (int e = 0; e < E; e++) {
+                const int x = have ? P.part_idx[((int64_t)slot * kTopK + k) * kMaxEp + e] : 0;
+                sp[c][e] = x;
+                ss[c][e] = have ? P.out_start[U.ep_off[e] + x] : 0;
+            }
+        }
+        wave_sync();
+        // rank of every kept tuple = number of kept tuples that are greater; an undecided pair matters when it reaches the
+        // fifth place (both ranks are then off by at most the number of such pairs: any one of them within the first five
+        // or straddling it is reported)
+        bool undecided = false;
+        for (int a = t; a < C; a += nt) {
+            if (!ok[a]) { rk[a] = (uint8_t)kCandMax; continue; }
+            int r = 0;
+            bool tie_here = false;
+            for (int b = 0; b < C; b++) {
+                if (b == a || !ok[b]) continue;
+                if (sc[b] > sc[a]) { r++; continue; }
+                if (sc[b] < sc[a]) continue;
+                int o = 0;   // +1: b greater
+                for (int e = 0; e < E; e++)
+                    if (sp[a][e] != sp[b][e]) { o = ss[b][e] > ss[a][e] ? 1 : (ss[b][e] < ss[a][e] ? -1 : 0); break; }
+                if (o > 0) r++;
+                if (o == 0) tie_here = true;
+            }
+            rk[a] = (uint8_t)r;
+            if (tie_here && r <= kTopK) undecided = true;
+        }
         int total = 0;
-        unsigned long long bits[kMaxEp];
-        for (int e = 0; e < kMaxEp; e++) bits[e] = 0ull;
-        for (int p = 0; p < nparts; p++) {
+        long long leaves = 0;
+        for (int p = 0; p < nparts; p++) {   // (<= kMaxParts: every lane the same few loads)
             const int np = P.part_n[slot0 + p];
-            redo |= (np >> 8) != 0;
+            if (np >> 8) undecided = true;
             total += np & 255;
             leaves += P.part_leaves[slot0 + p];
-            for (int e = 0; e < E; e++) bits[e] |= P.part_bits[(int64_t)(slot0 + p) * kMaxEp + e];
         }
-        const int C = nparts * kTopK;
-        auto valid = [&](int c) { return (c % kTopK) < (P.part_n[slot0 + c / kTopK] & 255); };
-        auto score = [&](int c) { return P.part_score[(int64_t)(slot0 + c / kTopK) * kTopK + c % kTopK]; };
-        auto span = [&](int c, int e) { return P.part_idx[((int64_t)(slot0 + c / kTopK) * kTopK + c % kTopK) * kMaxEp + e]; };
-        auto order = [&](int a, int b) -> int {   // equal scores: +1 a greater, -1 smaller, 0 Python cannot tell
-            for (int e = 0; e < E; e++) {
-                const int ia = span(a, e), ib = span(b, e);
-                if (ia != ib) {
-                    const int64_t sa = P.out_start[U.ep_off[e] + ia], sb = P.out_start[U.ep_off[e] + ib];
-                    return sa > sb ? 1 : (sa < sb ? -1 : 0);
-                }
-            }
-            return 0;
-        };
-        unsigned long long taken[(kMaxParts * kTopK + 63) / 64];
-        for (auto& w : taken) w = 0ull;
-        int pick[kTopK], nout = 0;
-        for (int r = 0; r < kTopK; r++) {
-            int best = -1;
-            for (int c = 0; c < C; c++) {
-                if (!valid(c) || ((taken[c >> 6] >> (c & 63)) & 1ull)) continue;
-                if (best < 0) { best = c; continue; }
-                const double sc = score(c), sb = score(best);
-                if (sc > sb || (sc == sb && order(c, best) > 0)) best = c;
-            }
-            if (best < 0) break;
-            pick[nout++] = best;
-            taken[best >> 6] |= 1ull << (best & 63);
-        }
-        if (nout > 0) {   // does the order decide among everything that reaches the last kept score?
-            const double s_last = score(pick[nout - 1]);
-            for (int a = 0; a < C && !redo; a++) {
-                if (!valid(a) || score(a) < s_last) continue;
-                for (int b = a + 1; b < C; b++)
-                    if (valid(b) && score(b) == score(a) && order(a, b) == 0) { redo = true; break; }
-            }
-        }
+        if (undecided) redo_flag = 1;
+        wave_sync();
+        const bool redo = redo_flag != 0;
         if (redo) {
-            const int q = P.heavy_big_off[E] + atomicAdd(&P.heavy_big_count[E], 1);
-            P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1; P.heavy_big_slot[q] = 0;
-            atomicAdd(&P.split_count[0], 1);   // (classes start at E = 2: entry 0 counts the spans listed again, for tw_debug_worklists)
-            continue;
+            if (t == 0) {
+                const int q = P.heavy_big_off[E] + atomicAdd(&P.heavy_big_count[E], 1);
+                P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1; P.heavy_big_slot[q] = 0;
+                atomicAdd(&P.split_count[0], 1);   // (classes start at E = 2: entry 0 counts the spans listed again, for tw_debug_worklists)
+            }
+        } else {
+            const int64_t g = U.in_off + i;
+            if (t == 0) { P.tk_n[g] = total < kTopK ? total : kTopK; P.leaves[g] = leaves; P.rep[g] = 0; }
+            for (int a = t; a < C; a += nt) {   // entries a span does not have keep the -1 / NaN pattern of tw_load_batch
+                const int k = rk[a];
+                if (k >= kTopK) continue;
+                P.tk_score[tks_index(U, k, i)] = sc[a];
+                for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, i)] = sp[a][e];
+            }
+            if (pass == 1)
+                for (int q = t; q < E * kCandWords; q += nt) {
+                    const int e = q / kCandWords, w = q % kCandWords;
+                    unsigned long long bits = 0ull;
+                    if (w == 0) for (int p = 0; p < nparts; p++) bits |= P.part_bits[(int64_t)(slot0 + p) * kMaxEp + e];
+                    P.c_bits[ie_index(U, e, i) * kCandWords + w] = bits;
+                }
         }
-        const int64_t g = U.in_off + i;
-        P.tk_n[g] = total < kTopK ? total : kTopK;
-        P.leaves[g] = leaves;
-        P.rep[g] = 0;
-        for (int k = 0; k < nout; k++) {   // entries a span does not have keep the -1 / NaN pattern of tw_load_batch
-            P.tk_score[tks_index(U, k, i)] = score(pick[k]);
-            for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, i)] = span(pick[k], e);
-        }
-        if (pass == 1)
-            for (int e = 0; e < E; e++)
-                for (int w = 0; w < kCandWords; w++) P.c_bits[ie_index(U, e, i) * kCandWords + w] = w == 0 ? bits[e] : 0ull;
+        wave_sync();
     }
 }
 
