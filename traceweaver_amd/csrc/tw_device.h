@@ -114,6 +114,7 @@ struct Dev {
     int32_t *heavy_unit, *heavy_win;
     int32_t* heavy_in_count;  // [2][kMaxEp+1] incoming spans deferred to k_enumerate_heavy per endpoint count E: narrow, wide windows
     int32_t* heavy_in_next;   // [3][kMaxEp+1] next unclaimed entry of each list: narrow, wide, long enumerations (when launched on their own)
+    uint8_t* span_cls;        // per incoming span: 0 enumerated by its thread of k_enumerate_light, 1 by a wavefront (k_classify)
     int32_t heavy_in_off[kMaxEp + 2];  // class offsets into heavy_in_unit / heavy_in_idx
     int32_t *heavy_in_unit, *heavy_in_idx;
     int32_t* heavy_big_count;   // [kMaxEp+1] narrow spans with a long enumeration: served first

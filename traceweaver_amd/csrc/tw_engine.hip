@@ -189,24 +189,32 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
     if (nt == 0) return;
     hipStream_t st = e->cls_stream[E];
     (void)hipStreamWaitEvent(st, e->cls_ev[0], 0);
-    if (mode == 0)
-        hipLaunchKernelGGL((k_enumerate_light<E>), dim3(nt), dim3(e->tile), 0, st, P, pass,
-                           (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
     const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
     const int grid = std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096);  // persistent wavefronts pulling spans from the class' work list
     const dim3 hb(std::min(e->coop, kHeavyThreads));
     const int pool = E > 4 ? 2048 : (E > 1 ? kPairPoolPerEp * E : 1);       // doubles of pair-term tables per wavefront
-    // one launch serves the class' two lists of narrow spans, the long enumerations (and the parts of the split ones) first
-    hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 0, pool);
-    if (mode == 0 && E > 1) {
-        // the parts of the split spans are combined; the few whose order of equal scores is not decided are listed again
-        // (list emptied first) and enumerated whole
-        (void)hipMemsetAsync(P.heavy_big_count + E, 0, sizeof(int32_t), st);
-        (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), st);
-        hipLaunchKernelGGL(k_merge_parts, dim3(1024), dim3(std::min(e->coop, 64)), 0, st, P, pass, E);
-        hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(256), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 1, pool);
+    const size_t pool_bytes = sizeof(double) * (size_t)pool;
+    // the wavefront kernels of the class: the two lists of narrow spans in one launch, the long enumerations (and the parts of the
+    // split ones) first; the parts of the split spans combined, the few whose order of equal scores is not decided listed again
+    // (list emptied first) and enumerated whole; the wide windows
+    auto wavefront_kernels = [&](hipStream_t q) {
+        hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, pool_bytes, q, P, pass, mode, 0, pool);
+        if (mode == 0 && E > 1) {
+            (void)hipMemsetAsync(P.heavy_big_count + E, 0, sizeof(int32_t), q);
+            (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), q);
+            hipLaunchKernelGGL(k_merge_parts, dim3(1024), dim3(std::min(e->coop, 64)), 0, q, P, pass, E);
+            hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(256), hb, pool_bytes, q, P, pass, mode, 1, pool);
+        }
+        hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), hb, pool_bytes, q, P, pass, mode, 0, pool);
+    };
+    if (mode == 0) {
+        // cut-offs and work lists, the per-thread kernel, the wavefront kernels (which also take the few spans the per-thread kernel
+        // hands over).  Running the last two side by side was measured (second stream of higher priority, i.e. another hardware
+        // queue): the kernels do overlap, the class does not finish earlier -- together they saturate the LDS and issue slots
+        hipLaunchKernelGGL((k_classify<E>), dim3(nt), dim3(e->tile), 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
+        hipLaunchKernelGGL((k_enumerate_light<E>), dim3(nt), dim3(e->tile), 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
     }
-    hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), hb, sizeof(double) * (size_t)pool, st, P, pass, mode, 0, pool);
+    wavefront_kernels(st);
     (void)hipEventRecord(e->cls_ev[E], st);
     used = true;
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[E], 0);
@@ -776,7 +784,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.gaps, gaps);
     ALLOC(P.unit_stats, (int64_t)P.n_units * 8); ALLOC(P.err, 1);
     ALLOC(e->tile_ids, (int64_t)tile_ids_h.size());
-    ALLOC(P.heavy_in_count, 2 * (kMaxEp + 1)); ALLOC(P.heavy_in_next, 3 * (kMaxEp + 1)); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
+    ALLOC(P.heavy_in_count, 2 * (kMaxEp + 1)); ALLOC(P.heavy_in_next, 3 * (kMaxEp + 1)); ALLOC(P.span_cls, n_in_total); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
     {   // long enumerations: a list entry per span plus the extra entries of the split ones (an eighth of the class + 64), two
         // scratch slots per extra entry
         int64_t big_total = 0, slots = 0;

@@ -584,8 +584,13 @@ __device__ void light_dfs(LightCtx<E>& c, bool want_bits) {
     }
 }
 
+// Cut-offs and work lists, one thread per incoming span, ahead of the enumeration kernels: FindCutoffs
+// (traceweaver_v3.py:182-217) in pass 1 (kept in c_lo / c_hi: they depend on timestamps only), then the size of the span's
+// enumeration decides who enumerates it -- this thread's slot in k_enumerate_light (span_cls 0) or a wavefront of
+// k_enumerate_heavy (span_cls 1: listed here).  This kernel holds no LDS, so its 2E dependent searches per span run at full
+// occupancy (inside the per-thread kernel, whose term tables allow two wavefronts per SIMD, they were 40 % of its pass-1 time).
 template <int E>
-__global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
+__global__ void __launch_bounds__(kTile) k_classify(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
     if (*P.err != 0) return;  // e.g. NaN parameters (hazard H3): nothing downstream is meaningful
     const int tile = tile_ids[xcd_tile(blockIdx.x, n_tiles_e)];
     const TileDev T = P.tiles[tile];
@@ -596,10 +601,6 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
     c.U = &U;
     c.in_start = P.in_start[U.in_off + i];
     c.in_end = P.in_end[U.in_off + i];
-    c.S.pass = pass;
-    c.S.gp = P.gparam + (U.gp_off + (int64_t)(i / P.batch_size) * U.nslot) * 4;
-    c.S.mix_n = P.mix_n + U.slot_off;
-    c.S.mix_c = P.mix_c + (int64_t)U.slot_off * kMaxComp * 4;
 #pragma unroll
     for (int e = 0; e < E; e++) { c.os[e] = P.out_start + U.ep_off[e]; c.oe[e] = P.out_end + U.ep_off[e]; }
     // the cut-offs depend on timestamps only: pass 1 computes and keeps them, the wavefront kernel and pass 2
@@ -665,7 +666,37 @@ __global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, cons
         // most likely be enumerated again as a whole (millisecond-granular traces: nearly always)
         if (twins && !P.split_twins) first_cands = 0;
     }
-    if (heavy_append<E>(P, prod > kLightMax, narrow, prod > kBigProduct, T.unit, i, prod, U.skip ? 0 : first_cands)) return;
+    const bool heavy = heavy_append<E>(P, prod > kLightMax, narrow, prod > kBigProduct, T.unit, i, prod, U.skip ? 0 : first_cands);
+    P.span_cls[U.in_off + i] = heavy ? 1 : 0;
+}
+
+template <int E>
+__global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
+    if (*P.err != 0) return;  // e.g. NaN parameters (hazard H3): nothing downstream is meaningful
+    const int tile = tile_ids[xcd_tile(blockIdx.x, n_tiles_e)];
+    const TileDev T = P.tiles[tile];
+    const UnitDev& U = P.units[T.unit];
+    const int i = T.first + threadIdx.x;
+    if (i >= U.n_in) return;
+    if (P.span_cls[U.in_off + i] != 0) return;   // enumerated by a wavefront (k_classify listed it)
+    LightCtx<E> c;
+    c.U = &U;
+    c.in_start = P.in_start[U.in_off + i];
+    c.in_end = P.in_end[U.in_off + i];
+    c.S.pass = pass;
+    c.S.gp = P.gparam + (U.gp_off + (int64_t)(i / P.batch_size) * U.nslot) * 4;
+    c.S.mix_n = P.mix_n + U.slot_off;
+    c.S.mix_c = P.mix_c + (int64_t)U.slot_off * kMaxComp * 4;
+#pragma unroll
+    for (int e = 0; e < E; e++) { c.os[e] = P.out_start + U.ep_off[e]; c.oe[e] = P.out_end + U.ep_off[e]; }
+    bool empty = false, narrow = true;
+#pragma unroll
+    for (int e = 0; e < E; e++) {   // cut-offs: k_classify
+        c.lo[e] = P.c_lo[ie_index(U, e, i)]; c.hi[e] = P.c_hi[ie_index(U, e, i)];
+        const int w = c.hi[e] - c.lo[e] + 1;
+        narrow &= (w <= kNarrow);
+        empty |= (w <= 0);
+    }
     c.nk = 0; c.leaves = 0; c.ambiguous = false;
 #pragma unroll
     for (int k = 0; k < kTopK; k++) c.ts[k] = -dinf();
@@ -838,9 +869,8 @@ constexpr int kFrontierSlots = 4096;            // buffer pairs of kFrontierCap 
 constexpr int kFrontierBigSlots = TW_FRONTIER_BIG_SLOTS;   // (the host-emulation build of the tests uses tiny sizes so that all three routes are exercised)
 template <int E, int W>
 __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass, int mode, int part, int pool) {
-    // part: 0 = the long enumerations first, then the others (one launch serves both lists); 1 = only the long ones, 2 = only the
-    // others -- two launches side by side, the first with a pair-term pool (dynamic LDS, `pool` doubles) that holds the
-    // tables of every primary edge, which the occupancy of the second cannot afford
+    // part: 0 = the class' lists, the long enumerations first (one launch serves both); 1 = only the long ones (the split spans
+    // that k_merge_parts lists again); 2 = only the others.  `pool` = doubles of dynamic LDS for the pair-term tables.
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     static_assert(W == kNarrow || W == 64 * kCandWords, "one instantiation per half of the work list");
     constexpr bool kWide = W != kNarrow;
