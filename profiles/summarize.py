@@ -24,8 +24,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def group_of(name):
     if "k_copy16" in name:
         return "hbm_copy_measurement"   # tw_measure_hbm_copy: the measured ceiling quoted in the bench line, not part of a step
-    if "k_enumerate" in name:
-        return "k_enumerate"
+    if "k_enumerate" in name or "k_classify" in name or "k_merge_parts" in name:
+        return "k_enumerate"   # the group bench.py times between its events: cut-offs / lists, both enumeration kernels, merge of split spans
     if "k_select" in name:
         return "k_select"
     if "k_fit" in name:

@@ -22,3 +22,5 @@ for pass_no in (1, 2):
   a = cur - prev; a[8] = cur[8]; prev = cur
   out = np.zeros(16, dtype=np.int32); lib.tw_debug_worklists(eng._h, ctypes.c_void_p(out.ctypes.data))
   report(pass_no, t, a, out)
+  st = eng.results(pass_no, fields=("unit_stats",))
+  print("   search nodes (all windows): %d" % sum(int(r["search_nodes"]) for r in st))
