@@ -3,7 +3,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from traceweaver_amd import synth
 from traceweaver_amd.engine import Engine
 conc = float(os.environ.get("TW_CONC", "1.6")); n_in = int(os.environ.get("TW_NIN", "100000"))
-units, truth = synth.make_workload(1000, n_in, services=synth.MEDIA_SERVICES, replicas=4, concurrency=conc)
+if os.environ.get("TW_WORKLOAD") == "nodejs": units, truth = synth.make_nodejs_workload(1000, n_in, concurrency=conc, replicas=4)
+else: units, truth = synth.make_workload(1000, n_in, services=synth.MEDIA_SERVICES, replicas=4, concurrency=conc)
 eng = Engine(0, lib_path=os.environ.get("TW_PROFILE_LIB", "scratch/profsel.so")); eng.load(units)
 lib = eng._lib
 lib.tw_debug_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -9,20 +9,24 @@ OUT = os.path.join(HERE, "_build", "libtwgpu_emu.so")
 SRC = os.path.join(REPO, "traceweaver_amd", "csrc")
 
 
-def build(force=False):
+def build(force=False, production=False):
+    """production=True: the thresholds of the HIP build (long enumerations from 768 tuples, split from 4096 grid points, tuple lists
+    of 2^15 entries) instead of the tiny ones that make the small test units take every route."""
+    out = OUT.replace("libtwgpu_emu.so", "libtwgpu_emu_prod.so") if production else OUT
     deps = [os.path.join(SRC, f) for f in ("tw_engine.hip", "tw_kernels.h", "tw_device.h", "tw_fit.h", "tw_eval.h", "tw_skip.h", "tw_load.h", "tw_ingest.cpp")]
     deps += [os.path.join(REPO, "include", "traceweaver_amd.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
              os.path.join(HERE, "rocprim", "rocprim.hpp")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
-        return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.check_call([
-        "g++", "-x", "c++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    small = [] if production else [
         "-DTW_BIG_PRODUCT=40", "-DTW_SPLIT_MIN=96", "-DTW_SPLIT_GRAIN=24", "-DTW_GRID_TARGET=16",   # enumerations are split from ~100 grid points on, prefixes walked
-        "-DTW_FRONTIER_CAP=512", "-DTW_FRONTIER_BIG_CAP=8192", "-DTW_FRONTIER_BIG_SLOTS=3",   # small lists: own buffers, pool slots and the walk all occur in the tests
-        "-I", HERE, "-I", os.path.join(REPO, "include"), "-I", SRC, os.path.join(SRC, "tw_engine.hip"),
-        "-x", "c++", os.path.join(SRC, "tw_ingest.cpp"), "-pthread", "-o", OUT])
-    return OUT
+        "-DTW_FRONTIER_CAP=512", "-DTW_FRONTIER_BIG_CAP=8192", "-DTW_FRONTIER_BIG_SLOTS=3"]   # small lists: own buffers, pool slots and the walk all occur in the tests
+    subprocess.check_call(
+        ["g++", "-x", "c++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas"] + small +
+        ["-I", HERE, "-I", os.path.join(REPO, "include"), "-I", SRC, os.path.join(SRC, "tw_engine.hip"),
+         "-x", "c++", os.path.join(SRC, "tw_ingest.cpp"), "-pthread", "-o", out])
+    return out
 
 
 if __name__ == "__main__":

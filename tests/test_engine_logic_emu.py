@@ -198,7 +198,8 @@ def test_split_enumerations(emu_lib, monkeypatch):
     (millisecond timestamps).  Every unit equals the oracle bit for bit either way (check_units)."""
     from traceweaver_amd.engine import Engine
 
-    cases = [(21, 120, "par4", 4, 1), (22, 120, "chain3", 6, 1), (23, 100, "diamond", 5, 1), (24, 120, "par4", 3, 1000), (25, 80, "chain5", 3, 1)]
+    cases = [(21, 120, "par4", 4, 1), (22, 120, "chain3", 6, 1), (23, 100, "diamond", 5, 1), (24, 120, "par4", 3, 1000), (25, 80, "chain5", 3, 1),
+             (32, 80, "par4", 12, 1), (33, 120, "chain2", 20, 1)]   # the last two: windows wider than 32 candidates (the other instantiation)
     units, _ = parity.stress_units(cases)
 
     def lists():
@@ -219,3 +220,13 @@ def test_split_enumerations(emu_lib, monkeypatch):
     parity.check_units(emu_lib, units, allow_budget=True)
     forced = lists()
     assert forced[3]["split_spans"] > seen[3]["split_spans"] and forced[3]["split_redone"] > 0, forced
+
+
+def test_stress_units_with_production_thresholds(emu_lib):
+    """The default host-emulation build uses tiny list thresholds so that small units take every route -- which also means
+    that there every wavefront-enumerated span counts as a long one.  Here the same source is built with the thresholds of
+    the HIP library: the class' lists hold long, ordinary and wide-window spans side by side, as on the GPU."""
+    from tests.hostemu.build_emu import build
+
+    units, _ = parity.stress_units(parity.STRESS)
+    parity.check_units(build(production=True), units, allow_budget=True)

@@ -122,7 +122,7 @@ struct Dev {
     int32_t heavy_big_off[kMaxEp + 2];
     // A very long enumeration is cut into parts by the position of the first endpoint's candidate (k_enumerate_light lists one
     // entry per part); the parts leave their top-5 in a scratch slot each and k_merge_parts combines them.
-    int32_t* heavy_big_part;   // [big list] number of parts | part << 8   (1 = the whole enumeration)
+    int32_t* heavy_big_part;   // [big list] number of parts | part << 8 | wide windows << 24   (1 = the whole enumeration)
     int32_t* heavy_big_slot;   // [big list] scratch slot of the part's result
     int32_t part_off[kMaxEp + 2];   // class offsets into the part scratch and the split-span records (2 slots per extra entry)
     int32_t split_twins;       // debug (TW_SPLIT_TWINS=1): also split spans with twin candidates, so that tests reach the merge's way back
@@ -133,7 +133,7 @@ struct Dev {
     int64_t* part_leaves;      // [slot]
     double* part_score;        // [slot][kTopK]
     int32_t* part_idx;         // [slot][kTopK][kMaxEp] span indices in the endpoint lists
-    unsigned long long* part_bits;   // [slot][kMaxEp] candidate spans seen in a feasible tuple (narrow windows: one word)
+    unsigned long long* part_bits;   // [slot][kMaxEp][kCandWords] candidate spans seen in a feasible tuple
     int32_t* err;           // first error raised by a kernel (tw_status)
     unsigned long long* prof;  // [16] phase timers of -DTW_PROFILE builds
 };

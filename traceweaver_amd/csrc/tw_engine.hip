@@ -199,13 +199,15 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
     // (list emptied first) and enumerated whole; the wide windows
     auto wavefront_kernels = [&](hipStream_t q) {
         hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, pool_bytes, q, P, pass, mode, 0, pool);
+        hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), hb, pool_bytes, q, P, pass, mode, 0, pool);
         if (mode == 0 && E > 1) {
             (void)hipMemsetAsync(P.heavy_big_count + E, 0, sizeof(int32_t), q);
-            (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), q);
             hipLaunchKernelGGL(k_merge_parts, dim3(1024), dim3(std::min(e->coop, 64)), 0, q, P, pass, E);
+            (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), q);
             hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(256), hb, pool_bytes, q, P, pass, mode, 1, pool);
+            (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), q);
+            hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(64), hb, pool_bytes, q, P, pass, mode, 1, pool);
         }
-        hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), hb, pool_bytes, q, P, pass, mode, 0, pool);
     };
     if (mode == 0) {
         // cut-offs and work lists, the per-thread kernel, the wavefront kernels (which also take the few spans the per-thread kernel
@@ -800,7 +802,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         ALLOC(P.part_used, kMaxEp + 1); ALLOC(P.split_count, kMaxEp + 1);
         ALLOC(P.split_unit, slots); ALLOC(P.split_idx, slots); ALLOC(P.split_slot, slots); ALLOC(P.split_parts, slots);
         ALLOC(P.part_n, slots); ALLOC(P.part_leaves, slots); ALLOC(P.part_score, slots * kTopK); ALLOC(P.part_idx, slots * kTopK * kMaxEp);
-        ALLOC(P.part_bits, slots * kMaxEp);
+        ALLOC(P.part_bits, slots * kMaxEp * kCandWords);
     }
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
     ALLOC(P.prof, 16); ALLOC(e->key_acc, 2);

@@ -364,7 +364,8 @@ constexpr int kBigProduct = TW_BIG_PRODUCT;
 constexpr int kSplitMin = TW_SPLIT_MIN, kSplitGrain = TW_SPLIT_GRAIN, kMaxParts = 16;
 template <int E>
 __device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narrow, bool big, int unit, int i, long long prod = 0, int first_cands = 0) {
-    const bool isbig = pred && narrow && big;
+    const bool isbig = pred && big;   // narrow or wide windows: the list entry says which instantiation takes it
+    const int wide_flag = narrow ? 0 : 1 << 24;
     int nparts = 1, slot_base = 0;
     if (E >= 2 && isbig && prod >= kSplitMin && first_cands >= 2) {
         long long want = prod / kSplitGrain;
@@ -379,21 +380,21 @@ __device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narro
     const bool split = nparts > 1;
     const int sb = wave_append(&P.heavy_big_count[E], isbig && !split);
     const int sn = wave_append(&P.heavy_in_count[E], pred && narrow && !big);
-    const int sw = wave_append(&P.heavy_in_count[kMaxEp + 1 + E], pred && !narrow);
+    const int sw = wave_append(&P.heavy_in_count[kMaxEp + 1 + E], pred && !narrow && !big);
     if (!pred) return false;
     if (split) {
         const int base = P.heavy_big_off[E] + atomicAdd(&P.heavy_big_count[E], nparts);
         for (int p = 0; p < nparts; p++) {
             P.heavy_big_unit[base + p] = unit; P.heavy_big_idx[base + p] = i;
-            P.heavy_big_part[base + p] = nparts | (p << 8); P.heavy_big_slot[base + p] = slot_base + p;
+            P.heavy_big_part[base + p] = nparts | (p << 8) | wide_flag; P.heavy_big_slot[base + p] = slot_base + p;
         }
         const int k = P.part_off[E] + atomicAdd(&P.split_count[E], 1);
-        P.split_unit[k] = unit; P.split_idx[k] = i; P.split_slot[k] = slot_base; P.split_parts[k] = nparts;
+        P.split_unit[k] = unit; P.split_idx[k] = i; P.split_slot[k] = slot_base; P.split_parts[k] = nparts | wide_flag;
         return true;
     }
     if (isbig) {
         const int q = P.heavy_big_off[E] + sb;
-        P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1; P.heavy_big_slot[q] = 0;
+        P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | wide_flag; P.heavy_big_slot[q] = 0;
         return true;
     }
     const int pos = narrow ? P.heavy_in_off[E] + sn : P.heavy_in_off[E + 1] - 1 - sw;
@@ -646,7 +647,7 @@ __global__ void __launch_bounds__(kTile) k_classify(Dev P, int pass, const int32
 #pragma unroll
     for (int e = 0; e < E; e++) if (prod > 0 && prod <= kLightMax) prod *= (c.hi[e] - c.lo[e] + 1);
     int first_cands = 0;
-    if (prod > kLightMax && narrow) {
+    if (prod > kLightMax) {
         // the windows also hold spans that start inside the incoming span but end after it; what the enumeration
         // costs is the product of the *contained* candidates (a third of the raw product on the bench workload)
         prod = 1;
@@ -888,7 +889,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
     __shared__ int32_t px[E];                   // the prefix the wavefront is walking (staged positions, same for every lane)
     __shared__ int64_t pxs[E], pxe[E];
     const int t = threadIdx.x, nt = blockDim.x;
-    const int n_big = (kWide || part == 2) ? 0 : P.heavy_big_count[E];
+    const int n_big = part == 2 ? 0 : P.heavy_big_count[E];   // (both instantiations walk the list of long enumerations; each takes its own)
     const int count = n_big + (part == 1 ? 0 : P.heavy_in_count[kList]);
     int32_t* next_counter = &P.heavy_in_next[part == 1 ? 2 * (kMaxEp + 1) + E : kNext];
     const int nstatic = (int)gridDim.x * kWorkChunk;
@@ -918,12 +919,13 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
         // wave-uniform by construction; telling the compiler so turns every access to the unit descriptor below
         // into a scalar load (SGPRs, constant cache) instead of 64 lanes loading the same address
         const bool from_big = item < n_big;
-        const int pos = from_big ? P.heavy_big_off[E] + item : (kWide ? P.heavy_in_off[E + 1] - 1 - item : P.heavy_in_off[E] + (item - n_big));
+        const int pos = from_big ? P.heavy_big_off[E] + item : (kWide ? P.heavy_in_off[E + 1] - 1 - (item - n_big) : P.heavy_in_off[E] + (item - n_big));
         const int unit = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_unit : P.heavy_in_unit)[pos]);
         const int i = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_idx : P.heavy_in_idx)[pos]);
         // a part of a split enumeration?  (number of parts, which one, where its result goes)
         const int part_info = from_big ? __builtin_amdgcn_readfirstlane(P.heavy_big_part[pos]) : 1;
-        const int nparts = part_info & 255, part_no = part_info >> 8;
+        if (from_big && (((part_info >> 24) & 1) != 0) != kWide) continue;   // the other instantiation's
+        const int nparts = part_info & 255, part_no = (part_info >> 8) & 0xffff;
         const int part_slot = from_big ? __builtin_amdgcn_readfirstlane(P.heavy_big_slot[pos]) : 0;
         const UnitDev& U = P.units[unit];
         TW_ITEM_BEGIN();
@@ -1464,7 +1466,7 @@ __global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pa
                     P.part_idx[((int64_t)part_slot * kTopK + k) * kMaxEp + f] = loe + (int)lr[f][sheap[k].idx[f]];
                 }
             }
-            for (int q = t; q < E; q += nt) P.part_bits[(int64_t)part_slot * kMaxEp + q] = sbits[q][0];
+            for (int q = t; q < E * kCandWords; q += nt) P.part_bits[((int64_t)part_slot * kMaxEp + q / kCandWords) * kCandWords + q % kCandWords] = sbits[q / kCandWords][q % kCandWords];
         } else
         {   // results leave through all lanes: one (entry, field) per lane; staged positions back to span indices
             const int64_t g = U.in_off + i;
@@ -1517,7 +1519,8 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
     const int n = P.split_count[E];
     for (int s = (int)blockIdx.x; s < n; s += (int)gridDim.x) {
         const int rec = P.part_off[E] + s;
-        const int unit = P.split_unit[rec], i = P.split_idx[rec], slot0 = P.split_slot[rec], nparts = P.split_parts[rec];
+        const int unit = P.split_unit[rec], i = P.split_idx[rec], slot0 = P.split_slot[rec];
+        const int nparts = P.split_parts[rec] & 255, wide_bit = P.split_parts[rec] & (1 << 24);
         const UnitDev& U = P.units[unit];
         const int C = nparts * kTopK;
         if (t == 0) redo_flag = 0;
@@ -1569,7 +1572,7 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
         if (redo) {
             if (t == 0) {
                 const int q = P.heavy_big_off[E] + atomicAdd(&P.heavy_big_count[E], 1);
-                P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1; P.heavy_big_slot[q] = 0;
+                P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | wide_bit; P.heavy_big_slot[q] = 0;
                 atomicAdd(&P.split_count[0], 1);   // (classes start at E = 2: entry 0 counts the spans listed again, for tw_debug_worklists)
             }
         } else {
@@ -1585,7 +1588,7 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
                 for (int q = t; q < E * kCandWords; q += nt) {
                     const int e = q / kCandWords, w = q % kCandWords;
                     unsigned long long bits = 0ull;
-                    if (w == 0) for (int p = 0; p < nparts; p++) bits |= P.part_bits[(int64_t)(slot0 + p) * kMaxEp + e];
+                    for (int p = 0; p < nparts; p++) bits |= P.part_bits[((int64_t)(slot0 + p) * kMaxEp + e) * kCandWords + w];
                     P.c_bits[ie_index(U, e, i) * kCandWords + w] = bits;
                 }
         }
