@@ -185,6 +185,43 @@ def ingest_rate(n_traces=3000, threads=8, lib=None):
             "what": "Jaeger JSON (one trace per file) -> span table -> per-service SoA units, native loader"}
 
 
+def load_levels(device, lib=None, n_in=50000, factors=(2, 3, 5)):
+    """Load levels of one corpus (exps/exp5 runs six per call graph): the reference's --compress_factor transform
+    (helpers/transforms.py:10-40) on the span table resident in HBM (tw_scale_load) against host transform + upload."""
+    import time
+
+    import numpy as np
+
+    from traceweaver_amd import synth, transforms
+    from traceweaver_amd.engine import Engine
+
+    units, truth = synth.make_workload(77, n_in, services=synth.MEDIA_SERVICES, replicas=2, concurrency=1.2)
+    spans = int(sum(u.n_in * (1 + u.E) for u in units))
+    eng = Engine(device, lib_path=lib)
+    t0 = time.perf_counter()
+    eng.load(units)
+    eng.set_truth(truth)
+    t_up = time.perf_counter() - t0
+    eng.scale_load([factors[0]] * len(units))                                  # (first call: keeps the table as uploaded)
+    t0 = time.perf_counter()
+    for f in factors:
+        eng.scale_load([f] * len(units))
+    t_dev = (time.perf_counter() - t0) / len(factors)
+    t0 = time.perf_counter()
+    host = [transforms.compress_unit(u, tp, factors[-1]) for u, tp in zip(units, truth)]
+    t_host = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref = Engine(device, lib_path=lib)
+    ref.load([h.arrays for h in host])
+    t_reload = time.perf_counter() - t0
+    eng.run_pass1(); ref.run_pass1()
+    same = all(np.array_equal(a["parent"], b["parent"]) for a, b in zip(eng.results(1, fields=("parent",)), ref.results(1, fields=("parent",))))
+    eng.close(); ref.close()
+    return {"spans": spans, "levels": list(factors), "device_s_per_level": t_dev, "host_transform_s_per_level": t_host,
+            "upload_s": t_up, "reload_s_per_level": t_reload, "same_assignments": bool(same),
+            "what": "media shape, %d spans: one upload, then tw_scale_load per level (incl. permutations back to the host) vs numpy transform + upload per level" % spans}
+
+
 def end_to_end(device, lib=None, n_traces=20000, threads=None):
     """What a user of the command line gets, nothing resident beforehand: Jaeger JSON files (page cache) -> native ingest
     -> tw_load_batch (host -> HBM) -> pass 1 -> refit -> pass 2 -> parent arrays back on the host.  Bounded sample; not
@@ -448,6 +485,7 @@ def main():
             out["ingest"] = ingest_rate(lib=args.lib)
             if args.end_to_end:
                 out["end_to_end"] = end_to_end(device, lib=args.lib)
+                out["load_levels"] = load_levels(device, lib=args.lib)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
