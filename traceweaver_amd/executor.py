@@ -21,13 +21,15 @@ identical to the reference's classes, also on load-scaled units) and add their c
 table read from data/misc/service_to_replica_new.pickle under the project root (executor.py:912), timestamps handed to
 the engine as exact images of the reference's floats (traceweaver_amd/transforms.py).  `--repeat_factor` is accepted and,
 as in the reference (repeat_change_spans never reads it), only shows up in the result file names.
+`--cache_rate r` (r > 0, exps/exp2) injects cache hits into the service named "frontend" like the reference
+(executor.py:1150-1152, helpers/transforms.py:153-238 = traceweaver_amd/skipmode.py) and solves it in skip mode on the device.
 What it does not do (and says so instead of approximating): the other predictor indices (the older TraceWeaver
-variants 0-2, 6, 8, 9), cache-hit injection (--cache_rate > 0: skip mode), --parallel / --instrumented, tar archives
-(--compressed 1).  For those keep the reference's executor and
-register the predictor.
-The mixture refit between the passes is the deterministic device refit, so figures agree with a reference run to
-within the run-to-run spread the reference itself has (its k-means++ start is drawn from an unseeded RNG,
-SURVEY.md hazard H9), not digit for digit.
+variants 0-2, 6, 8, 9), --cache_rate together with --compress_factor > 1, --parallel / --instrumented, tar archives
+(--compressed 1).  For those keep the reference's executor and register the predictor.
+The mixture refit between the passes is the reference's own procedure by default (`--fit sklearn`: scikit-learn on the
+host, numpy's global RNG seeded by --seed and replayed service by service, so a seeded run reproduces a seeded reference
+run); `--fit device` uses the deterministic batched device refit, whose figures agree with a reference run to within the
+run-to-run spread the reference itself has (its k-means++ start is drawn from an unseeded RNG, SURVEY.md hazard H9).
 """
 import argparse
 import os

@@ -66,9 +66,22 @@ class Corpus(object):
             v = (ctypes.c_char_p * len(callers))(*[x.encode() for x in callers.values()])
             if self._lib.tw_corpus_set_callers(self._h, k, v, len(callers)) != 0:
                 raise RuntimeError("tw_corpus_set_callers failed")
-        paths = [os.fsencode(p) for p in paths]
-        arr = (ctypes.c_char_p * len(paths))(*paths)
-        rc = self._lib.tw_corpus_add_files(self._h, arr, len(paths), first_span.encode() if first_span else None, int(max_traces), int(threads), mode)
+        # the path array without a Python object per path: one NUL-separated text, pointers computed from the separators
+        n = len(paths)
+        if all(isinstance(p, str) for p in paths):
+            blob = os.fsencode("\0".join(paths)) + b"\0"
+        else:
+            blob = b"\0".join(os.fsencode(p) for p in paths) + b"\0"
+        ends = np.flatnonzero(np.frombuffer(blob, dtype=np.uint8) == 0)
+        if n == 0 or len(ends) != n:
+            if n:
+                raise ValueError("a path holds a NUL character")
+            ends = np.zeros(0, dtype=np.int64)
+        base = ctypes.cast(ctypes.c_char_p(blob), ctypes.c_void_p).value or 0
+        addr = np.empty(max(n, 1), dtype=np.uint64)
+        addr[:n] = base + np.concatenate(([0], ends[:-1] + 1)).astype(np.uint64) if n else 0
+        arr = ctypes.cast(ctypes.c_void_p(addr.ctypes.data), ctypes.POINTER(ctypes.c_char_p))
+        rc = self._lib.tw_corpus_add_files(self._h, arr, n, first_span.encode() if first_span else None, int(max_traces), int(threads), mode)
         if rc != 0:
             raise RuntimeError("tw_corpus_add_files failed: %d" % rc)
         return self.counts()
