@@ -65,6 +65,7 @@ def parse_args():
     ap.add_argument("--fit", default="device", choices=["device", "sklearn"], help="mixture refit between the passes")
     ap.add_argument("--cpu-sample", type=int, default=40000, help="requests per service in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--end-to-end", type=int, default=1, help="also time JSON -> ingest -> H2D -> two passes -> parents on the host (rank 0, N = 1)")
+    ap.add_argument("--host-traces", default="20000,15000", help="traces of the hotel- and the Alibaba-shape JSON corpus of the ingest / end-to-end legs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU for testing)")
     ap.add_argument("--lib", default=None, help="TESTING ONLY: path of an alternative build of libtwgpu (the host-emulation "
@@ -503,7 +504,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, 1000)
             import tempfile
 
-            for kind, n_traces, tag in (("hotel", 20000, ""), ("alibaba", 15000, "_alibaba")):   # each corpus is written once
+            n_hotel, n_ali = (int(x) for x in args.host_traces.split(","))
+            for kind, n_traces, tag in (("hotel", n_hotel, ""), ("alibaba", n_ali, "_alibaba")):   # each corpus is written once
                 with tempfile.TemporaryDirectory() as d:
                     corpus = _corpus(kind, d, n_traces)
                     out["ingest" + tag] = ingest_rate(lib=args.lib, kind=kind, n_traces=n_traces, corpus=corpus)

@@ -266,3 +266,97 @@ def test_alibaba_parser_shape_matches_the_reference_inputs(emu_lib, tmp_path, na
         order = [str(x) for x in g["partition_key_order"]]
         assert a.key_rank.tolist() == [order.index(str(e)) for e in g["out_eps"]]
     c.close()
+
+
+def _snapshot(c):
+    """Everything a corpus hands out, with names resolved to text (string ids are handles)."""
+    table = c.span_table()
+    units, skipped, n_traces = c.units()
+    names = [c.string(i) for i in c.trace_names()]
+    cols = {k: (table[k].tolist() if k not in ("span_id", "service", "op_name") else [c.string(i) for i in table[k]]) for k in table}
+    us = [(u.service, u.in_ep, u.out_eps, u.arrays.in_start.tolist(), u.arrays.in_end.tolist(), u.arrays.out_off.tolist(),
+           u.arrays.out_start.tolist(), u.arrays.out_end.tolist(), u.arrays.dag.tolist(), u.arrays.key_rank.tolist(),
+           u.true_parent.tolist(), u.in_trace.tolist(), u.in_rows.tolist(), [r.tolist() for r in u.out_rows], u.process_id) for u in units]
+    raw_ids = (table["service"].tolist(), table["op_name"].tolist(), table["span_id"].tolist())
+    return names, cols, us, skipped, n_traces, c.counts(), raw_ids
+
+
+@pytest.mark.parametrize("shape", ["hotel", "alibaba"])
+def test_parser_thread_count_changes_nothing(emu_lib, tmp_path, shape):
+    """Rows, units and even the string ids are the same for 1, 3 and 8 parser threads (names are interned by one thread in
+    trace order, whichever thread parsed the trace), and for the file list in any order."""
+    if shape == "hotel":
+        paths, fix = synth.write_jaeger_corpus(str(tmp_path), 11, 400, app=synth.HOTEL_APP, concurrency=2.5), None
+    else:
+        paths, fix = synth.write_alibaba_corpus(str(tmp_path), 11, 400, concurrency=1.5, violations=0.02), "rpc_twins"
+    snaps = []
+    for threads, order in ((1, paths), (3, paths), (8, paths)):
+        c = Corpus(lib_path=emu_lib)
+        c.add_files(order, first_span=None, max_traces=0, threads=threads, fix=fix)
+        snaps.append(_snapshot(c))
+        c.close()
+    assert snaps[0] == snaps[1] == snaps[2]
+    assert snaps[0][4] > 300 and len(snaps[0][2]) >= 2
+    # two calls on one corpus append (rows and trace numbers continue)
+    c = Corpus(lib_path=emu_lib)
+    c.add_files(paths[:150], first_span=None, max_traces=0, threads=2, fix=fix)
+    first = c.counts()
+    c.add_files(paths[150:], first_span=None, max_traces=0, threads=4, fix=fix)
+    both = c.counts()
+    assert both["files"] == len(paths) and both["spans"] > first["spans"] and both["traces"] > first["traces"]
+    table = c.span_table()
+    assert all(c.string(i) is not None for i in table["span_id"][[0, first["spans"] - 1, first["spans"], both["spans"] - 1]])
+    assert c.string(int(c.trace_names()[-1])) is not None and c.string(both["strings"] + (1 << 30)) is None
+    c.close()
+
+
+def test_scanner_escapes_numbers_and_duplicates(emu_lib, tmp_path):
+    """The paths of the scanner a generated corpus never takes: escaped keys and values (decoded like json.load does),
+    numbers of 19 digits and in exponent notation, values the loader does not read (nested, escaped, unicode), a span id
+    that occurs twice (the later record wins, as in the reference's dict), unknown keys before and after the known ones."""
+    def span(sid, op, start, dur, kind, pid, refs, tid="t\\u0031", extra=""):
+        return ('{"x\\"y": {"deep": [1, 2.5e3, "a\\\\b\\"c", null, true, {"k": "\\ud83d\\ude00"}]}, "traceID": "%s", "sp\\u0061nID": "%s", %s'
+                '"operationName": "%s", "references": [%s], "startTime": %s, "duration": %s, '
+                '"tags": [{"key": "http.url", "type": "string", "value": "a\\\\\\"b"}, {"key": "span.kind", "value": "%s"}], "logs": [{"fields": [{"key": "e", "value": "\\\\"}]}], '
+                '"processID": "%s", "warnings": null}') % (tid, sid, extra, op, ", ".join('{"refType": "CHILD_OF", "traceID": "%s", "spanID": "%s"}' % (tid, r) for r in refs), start, dur, kind, pid)
+    docs = []
+    for n in range(40):
+        t0 = 1655760000000000 + 5000 * n
+        tid = "t%d" % n
+        spans = [span("a", "GET /x\\ty", t0, "3.0e3" if n % 2 else 3000, "server", "p1", [], tid=tid),
+                 span("b", "call", t0 + 10, 100, "client", "p1", ["a"], tid=tid),
+                 span("c", "old", t0 + 1, 1, "server", "p2", ["b"], tid=tid),            # shadowed by the next record with the same id
+                 span("c", "h\\u00e9llo", t0 + 20, 50, "server", "p2", ["b"], tid=tid)]
+        docs.append('{"total": 0, "data": [{"spans": [%s], "processes": {"p1": {"tags": [], "serviceName": "front"}, "p2": {"serviceName": "b\\u0061ck"}}, "traceID": "%s"}], "errors": null}'
+                    % (", ".join(spans), tid))
+    big = '{"data": [{"traceID": "big", "spans": [%s], "processes": {"p1": {"serviceName": "front"}}}]}' % span("r", "GET /x\\ty", 9223372036854775807, 1, "server", "p1", [], tid="big")
+    paths = []
+    for n, text in enumerate(docs + [big]):
+        json.loads(text)                                  # the fixtures are valid JSON
+        p = tmp_path / ("%03d.json" % n)
+        p.write_text(text)
+        paths.append(str(p))
+    c = Corpus(lib_path=emu_lib)
+    counts = c.add_files(paths, first_span="GET /x\ty", max_traces=0, threads=2)
+    assert counts["files_rejected"] == 0 and counts["traces"] == 41 and counts["spans"] == 40 * 3 + 1, (counts, c.first_error())
+    table = c.span_table()
+    ops = {c.string(i) for i in table["op_name"]}
+    assert ops == {"GET /x\ty", "call", "héllo"} and {c.string(i) for i in table["service"]} == {"front", "back"}
+    assert int(table["start"].max()) == 9223372036854775807 and set(table["duration"].tolist()) == {3000, 100, 50, 1}
+    assert {c.string(i) for i in c.trace_names()} == {"t%d" % n for n in range(40)} | {"big"}
+    units, skipped, _ = c.units()
+    assert units == [] and skipped["skip_mode"] == 1      # the lone root of "big" makes no call: 41 requests, 40 calls
+    c.close()
+    c = Corpus(lib_path=emu_lib)
+    c.add_files(paths[:-1], first_span="GET /x\ty", max_traces=0, threads=3)
+    units, skipped, _ = c.units()
+    assert [u.service for u in units] == ["front"] and units[0].out_eps == ["back"] and units[0].arrays.n_in == 40
+    assert np.array_equal(units[0].arrays.out_start - units[0].arrays.in_start, np.full(40, 10))
+    assert np.array_equal(units[0].true_parent, np.arange(40)[None, :])
+    c.close()
+    bad = tmp_path / "bad.json"
+    bad.write_text(docs[0].replace('"a\\\\\\"b"', '"a\\qb"'))          # a malformed escape in a value nobody reads still rejects the file
+    c = Corpus(lib_path=emu_lib)
+    counts = c.add_files([str(bad)], first_span=None, max_traces=0)
+    assert counts["files_rejected"] == 1 and "bad escape" in c.first_error()
+    c.close()
