@@ -262,14 +262,16 @@ int tw_assign_service(tw_engine *e, int32_t n_in, const int64_t *in_start, const
  * GetGroundTruth (helpers/utils.py:22-32), FindOrder + nx.topological_sort (executor.py:214-285,
  * traceweaver_v1.py:37-39), FixSpans / FixSpans2 (executor.py:505-537,542-645) and the rewrite of the Alibaba parser
  * output (executor.py:377-448).  Names are interned: every *_name / service / span_id field below is a string id for
- * tw_corpus_string(). */
+ * tw_corpus_string().  String ids are handles, not indices of one dense table: service / operation / endpoint names
+ * count up from 0 (in order of first use, traces in time order -- the same for any number of parser threads), trace
+ * ids are 2^29 + trace number, span ids 2^30 + span-table row (unique per trace: stored, never looked up). */
 typedef struct tw_corpus tw_corpus;
 int tw_corpus_create(tw_corpus **out);
 void tw_corpus_destroy(tw_corpus *c);
 const char *tw_corpus_last_error(const tw_corpus *c);   /* first file that failed to parse, if any */
 
 /* Parses one-trace-per-file Jaeger JSON ({"data":[{"traceID","spans":[...],"processes":{...}}]}, or the
- * requestType shape of alibaba-analysis/real-parser.py:308-359), n_threads parser threads (<= 0: up to 16),
+ * requestType shape of alibaba-analysis/real-parser.py:308-359), n_threads parser threads (<= 0: up to 32, one per 64 files),
  * orders the traces by the start of their root span and adds those whose root operation is `first_span`
  * (NULL / "" = any; executor.py:757-763,841) until max_traces (> 0; the reference stops at 1001,
  * executor.py:873) traces are held.  Files that do not parse or break an assumption the reference asserts on
@@ -299,7 +301,8 @@ const char *tw_corpus_loop_origin(const tw_corpus *c, const char *service);
 /* The static service -> caller map of TW_FIX_CLIENT_TWINS. */
 int tw_corpus_set_callers(tw_corpus *c, const char *const *service, const char *const *caller, int32_t n);
 
-/* out6 = spans held, traces held, files seen, files that failed to parse, traces filtered out, strings. */
+/* out6 = spans held, traces held, files seen, files that failed to parse, traces filtered out, strings (names + trace
+ * ids + span ids held).  tw_corpus_string returns NULL for an id that names nothing. */
 int tw_corpus_counts(const tw_corpus *c, int64_t *out6);
 const char *tw_corpus_string(const tw_corpus *c, int32_t id);
 int tw_corpus_trace_names(const tw_corpus *c, int32_t *out);   /* string id of the traceID of trace 0 .. traces-1 */

@@ -14,6 +14,14 @@
 //
 // Strings never reach the GPU: every name is interned, units carry string ids and span-table rows so that the
 // caller can translate indices back to (trace id, span id) keys.
+//
+// Work per call of tw_corpus_add_files, one crew of parser threads throughout: (1) per trace, any thread: read, scan
+// (keys and compared values are views of the file's text, nothing the loader does not read is copied), span surgery,
+// tree walk, the trace's names numbered in the thread's own name table; (2) one thread: time order, trace limit, first
+// row of every accepted trace, names interned in trace order (a few per trace; ids do not depend on the thread count);
+// (3) per trace, the thread that parsed it: rows written, parse structures released (no two threads meet in one
+// allocator arena); (4) one thread, streaming over the new rows: per-service row lists.  tw_corpus_build_units builds
+// the services side by side.  Measured: profiles/r02b_ingest_sweep.json.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
