@@ -58,7 +58,11 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="media", choices=["media", "nodejs", "alibaba", "media-split"])
     ap.add_argument("--n-in", type=int, default=100000, help="requests per service unit (media / nodejs)")
-    ap.add_argument("--replicas", type=int, default=4, help="copies of the service graph per GPU (media / nodejs)")
+    ap.add_argument("--replicas", type=int, default=None,
+                    help="copies of the service graph per GPU (media / nodejs).  Default: 16 for the media workload -- a resident batch "
+                         "of 25.6 M spans (0.4 GB of timestamps in 288 GB of HBM); the kernels' tails (one 25-span window, one 4e4-tuple "
+                         "span) do not grow with the batch: 4.9e8 spans/s at 4 replicas, 6.1e8 at 8, 6.8e8 at 16, 7.1e8 at 32 "
+                         "(profiles/r02d_batch_sweep.json) -- 4 for the others")
     ap.add_argument("--concurrency", type=float, default=None, help="mean requests in flight per service (default: 1.6 media, 4 nodejs, 1.3 alibaba)")
     ap.add_argument("--total-spans", type=int, default=1000000, help="engine spans of the Alibaba-shape slice (whole job)")
     ap.add_argument("--verify", type=int, default=0, help="alibaba: rank 0 also solves the whole slice alone and compares the gathered parents")
@@ -68,6 +72,10 @@ def parse_args():
     ap.add_argument("--host-traces", default="20000,15000", help="traces of the hotel- and the Alibaba-shape JSON corpus of the ingest / end-to-end legs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU for testing)")
+    ap.add_argument("--sync", default="torch", choices=["torch", "engine"],
+                    help="torch: torch.cuda.synchronize() around the timed region (the bench contract).  engine (N = 1 only): no torch "
+                         "import -- every C-ABI call returns with its stream synchronised; what profiles/collect.sh uses, so that its "
+                         "rocprofv3 passes do not spend a minute each importing torch on a fresh box")
     ap.add_argument("--lib", default=None, help="TESTING ONLY: path of an alternative build of libtwgpu (the host-emulation "
                                                 "library of tests/hostemu); no GPU is touched then")
     return ap.parse_args()
@@ -115,7 +123,8 @@ def make_units(args, seed, n_in=None, replicas=None, total_spans=None):
     from traceweaver_amd import synth
 
     n_in = args.n_in if n_in is None else n_in
-    replicas = args.replicas if replicas is None else replicas
+    if replicas is None:
+        replicas = args.replicas if args.replicas is not None else (16 if args.workload == "media" else 4)
     if args.workload == "media-split":
         conc = 1.6 if args.concurrency is None else args.concurrency
         u, t = synth.make_workload(seed, n_in * replicas, services=synth.MEDIA_SERVICES, replicas=1, concurrency=conc)
@@ -307,10 +316,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: start one rank per GPU (or let `python bench.py --gpus N` start them)" % (args.gpus, world))
-    import torch
+    no_torch = world == 1 and args.sync == "engine"
+    if no_torch:
+        torch = None
+        emulated = False
+        device = 0
+    else:
+        import torch
 
-    emulated = args.lib is not None and not torch.cuda.is_available()
-    if not emulated:
+        emulated = args.lib is not None and not torch.cuda.is_available()
+    if no_torch:
+        pass
+    elif not emulated:
         ndev = torch.cuda.device_count()
         if ndev < 1:
             sys.exit("bench.py: no GPU visible (the HIP engine has no CPU fallback)")
@@ -366,7 +383,7 @@ def main():
     eng.set_truth(truth)
 
     def sync():
-        if not emulated:
+        if not emulated and not no_torch:
             torch.cuda.synchronize()
 
     def barrier():

@@ -1,0 +1,45 @@
+"""Builds libtwgpu with alternative compile-time settings side by side (scratch/variants/<name>.so; scratch/ is not
+tracked but travels to the GPU box), so that one gpurun call can time all of them with batch_sweep.py --lib.
+The settings only move resources (registers per thread, LDS per workgroup): every variant computes the same results.
+
+    python profiles/tools/build_variants.py [name ...]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+from traceweaver_amd import build as B  # noqa: E402
+
+WPE = lambda n: "__attribute__((amdgpu_waves_per_eu(%d)))" % n  # noqa: E731
+SMALL_TAB = "((E)==1?0:(E)==2?4:(E)==3?3:(E)==4?2:2)"
+MID_TAB = "((E)==1?0:(E)==2?6:(E)==3?4:(E)==4?3:2)"
+
+VARIANTS = {
+    "base": [],
+    "memo64": ["-DTW_MEMO_SLOTS=64"],
+    "memo32": ["-DTW_MEMO_SLOTS=32"],
+    "light3": ["-DTW_LIGHT_ATTR=" + WPE(3), "-DTW_LIGHT_TABW(E)=" + MID_TAB],
+    "light4": ["-DTW_LIGHT_ATTR=" + WPE(4), "-DTW_LIGHT_TABW(E)=" + SMALL_TAB],
+    "light4reg": ["-DTW_LIGHT_ATTR=" + WPE(4)],
+    "heavy3": ["-DTW_HEAVY_ATTR=" + WPE(3)],
+    "heavy4": ["-DTW_HEAVY_ATTR=" + WPE(4)],
+}
+
+
+def build(name):
+    out = os.path.join(REPO, "scratch", "variants", name + ".so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = ["/opt/rocm/bin/hipcc"] + B.FLAGS + VARIANTS[name] + ["-I", os.path.join(REPO, "include"), "-I", B.SRC,
+                                                                os.path.join(B.SRC, "tw_engine.hip"), os.path.join(B.SRC, "tw_ingest.cpp"), "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return name, r.returncode, r.stderr[-2000:]
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(VARIANTS)
+    with ThreadPoolExecutor(4) as ex:
+        for name, rc, err in ex.map(build, names):
+            print(name, rc, err if rc else "")

@@ -1,7 +1,7 @@
 # bench lines of the load regimes (+ rocprofv3 kernel stats where asked): bash profiles/tools/regimes.sh <tag> [stats]
 export TMPDIR=/tmp
 TAG=${1:-r02}
-for W in "base:" "alibaba:--workload alibaba" "c4:--concurrency 4 --n-in 20000" "nodejs:--workload nodejs --n-in 20000" "c8:--concurrency 8 --n-in 5000"; do
+for W in "base:" "alibaba:--workload alibaba" "c4:--concurrency 4 --n-in 20000 --replicas 4" "nodejs:--workload nodejs --n-in 20000" "c8:--concurrency 8 --n-in 5000 --replicas 4"; do
   tag=${W%%:*}; args=${W#*:}
   if [ "${2:-}" = "stats" ]; then
     mkdir -p gpurun_out/${TAG}_$tag

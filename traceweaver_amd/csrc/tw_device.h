@@ -109,9 +109,11 @@ struct Dev {
     double* gaps;
     const int64_t* gs_off;  // [n_units]
     int64_t* unit_stats;    // [n_units][8]
-    int32_t* heavy_count;   // [3] windows whose best candidates clash (work list of k_select_heavy): -, long ones (front), short ones (back)
-    int32_t* heavy_next;    // next unclaimed entry of that list
+    int32_t* heavy_count;   // [4] windows whose best candidates clash: [1] long ones (front of the list of k_select_heavy), [2] middle ones
+                            // (its back), [0] windows of <= kBruteMax spans (list of k_select_tiny), [3] next unclaimed entry of that list
+    int32_t* heavy_next;    // next unclaimed entry of the list of k_select_heavy
     int32_t *heavy_unit, *heavy_win;
+    int32_t *tiny_unit, *tiny_win;   // work list of k_select_tiny
     int32_t* heavy_in_count;  // [2][kMaxEp+1] incoming spans deferred to k_enumerate_heavy per endpoint count E: narrow, wide windows
     int32_t* heavy_in_next;   // [3][kMaxEp+1] next unclaimed entry of each list: narrow, wide, long enumerations (when launched on their own)
     uint8_t* span_cls;        // per incoming span: 0 enumerated by its thread of k_enumerate_light, 1 by a wavefront (k_classify)

@@ -231,6 +231,21 @@ void launch_enumerate_all(tw_engine* e, int pass, int mode) {
     launch_enumerate<5>(e, pass, mode, used); launch_enumerate<6>(e, pass, mode, used); launch_enumerate<7>(e, pass, mode, used); launch_enumerate<8>(e, pass, mode, used);
 }
 
+// The listed windows: those of up to kBruteMax spans (nearly all of them) by k_select_tiny, whose workgroups hold 1 KB of LDS
+// and fill the SIMDs; the others by k_select_heavy (22 KB of LDS: seven wavefronts per CU), which ends with its longest
+// search -- on a stream of its own (an idle class stream, forked from and joined to the engine's stream by events), so
+// that the many short windows run beside that tail instead of before it.
+void launch_select_listed(tw_engine* e) {
+    const Dev& P = e->P;
+    const dim3 wave(std::min(e->coop, 64));
+    (void)hipEventRecord(e->cls_ev[0], e->stream);
+    (void)hipStreamWaitEvent(e->cls_stream[1], e->cls_ev[0], 0);
+    hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096)), wave, 0, e->cls_stream[1], P);
+    (void)hipEventRecord(e->cls_ev[1], e->cls_stream[1]);
+    hipLaunchKernelGGL(k_select_tiny, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 8192)), wave, 0, e->stream, P);
+    (void)hipStreamWaitEvent(e->stream, e->cls_ev[1], 0);
+}
+
 // OR of (key ^ first key) and of the keys themselves over a set of index ranges (see k_key_bits)
 int key_bits(tw_engine* e, const void* keys, const uint32_t* seg_begin, const uint32_t* seg_end, int nseg, int64_t total,
              unsigned long long out[2]) {
@@ -331,7 +346,7 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
     HIPCHK(hipMemsetAsync(P.err, 0, sizeof(int32_t), e->stream));
     HIPCHK(hipMemsetAsync(P.unit_stats, 0, sizeof(int64_t) * 8 * P.n_units, e->stream));
-    HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 3, e->stream));
+    HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 4, e->stream));
     HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t), e->stream));
     HIPCHK(hipMemsetAsync(P.unit_ndirty, 0, sizeof(int32_t) * P.n_units, e->stream));
     if (pass == 1 && !e->skip_mode) {
@@ -385,7 +400,7 @@ int run_pass(tw_engine* e, int pass) {
     }
     HIPCHK(hipMemsetAsync(P.w_conf, 0, sizeof(int32_t) * (size_t)P.n_in_total, e->stream));
     hipLaunchKernelGGL(k_select_fast, tiles, tb, 0, e->stream, P);
-    hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096)), dim3(std::min(e->coop, 64)), 0, e->stream, P);
+    launch_select_listed(e);
     HIPCHK(hipEventRecord(e->ev[EV_SEL], e->stream));
     // span consumption: rounds of claim / detect / re-enumerate / re-select until no span's set of taken candidates changes
     HIPCHK(hipMemsetAsync(P.gone, 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(e->n_ie * kCandWords, 1), e->stream));
@@ -397,7 +412,7 @@ int run_pass(tw_engine* e, int pass) {
         HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
         HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 3 * (kMaxEp + 1), e->stream));
         HIPCHK(hipMemsetAsync(P.heavy_big_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
-        HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 3, e->stream));
+        HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 4, e->stream));
         HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t), e->stream));
         HIPCHK(hipMemsetAsync(P.round_changed, 0, sizeof(int32_t), e->stream));
         hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, e->stream, P, round);
@@ -408,7 +423,7 @@ int run_pass(tw_engine* e, int pass) {
         if (round >= kMaxRepairRounds) return fail(e, TW_ERR_DEVICE, "span consumption did not settle (more repair rounds than windows)");
         e->rounds = round + 1;
         launch_enumerate_all(e, pass, 1);
-        hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096)), dim3(std::min(e->coop, 64)), 0, e->stream, P);
+        launch_select_listed(e);
     }
     HIPCHK(hipEventRecord(e->ev[EV_REPAIR], e->stream));
     hipLaunchKernelGGL(k_finalize, tiles, tb, 0, e->stream, P);
@@ -806,7 +821,8 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     }
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
     ALLOC(P.prof, 16); ALLOC(e->key_acc, 2);
-    ALLOC(P.heavy_count, 3); ALLOC(P.heavy_next, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);
+    ALLOC(P.heavy_count, 4); ALLOC(P.heavy_next, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);
+    ALLOC(P.tiny_unit, n_in_total / 2 + 1); ALLOC(P.tiny_win, n_in_total / 2 + 1);
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
     ALLOC(e->gaps_sorted, gaps); ALLOC(e->fit_models, slots * kMaxComp * kModelStride);
@@ -1260,12 +1276,12 @@ void tw_host_free(void* p) {
  * out[2 + kMaxEp] = spans enumerated in parts, out[3 + kMaxEp] = of those, enumerated once more as a whole (out: 4 + kMaxEp ints). */
 int tw_debug_worklists(tw_engine* e, int32_t* out) {
     if (e == nullptr || out == nullptr || e->state < ST_PASS1) return TW_ERR_ARG;
-    int32_t sel[3];
+    int32_t sel[4];
     HIPCHK(hipMemcpyAsync(sel, e->P.heavy_count, sizeof(sel), hipMemcpyDeviceToHost, e->stream));
     int32_t both[2 * (kMaxEp + 1)];
     HIPCHK(hipMemcpyAsync(both, e->P.heavy_in_count, sizeof(both), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    out[0] = sel[1] + sel[2];
+    out[0] = sel[0] + sel[1] + sel[2];
     for (int k = 0; k <= kMaxEp; k++) out[1 + k] = both[k] + both[kMaxEp + 1 + k];
     int32_t split[kMaxEp + 1];   // [0] spans listed again after the merge, [E >= 2] split spans of the class
     HIPCHK(hipMemcpy(split, e->P.split_count, sizeof(split), hipMemcpyDeviceToHost));

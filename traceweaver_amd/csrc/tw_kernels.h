@@ -440,8 +440,11 @@ struct LightCtx {
 // every endpoint, in LDS) instead of being evaluated at every tuple that contains the span; wider endpoints fall
 // back to evaluating at the tree level where the span is chosen.  The tuple score adds the same doubles in the
 // same order, so it is bit-identical.
+#ifndef TW_LIGHT_TABW
+#define TW_LIGHT_TABW(E) ((E) == 1 ? 0 : (E) == 2 ? 8 : (E) == 3 ? 6 : (E) == 4 ? 5 : (E) == 5 ? 4 : (E) == 6 ? 3 : 2)
+#endif
 template <int E>
-__host__ __device__ constexpr int light_tab_width() { return E == 1 ? 0 : E == 2 ? 8 : E == 3 ? 6 : E == 4 ? 5 : E == 5 ? 4 : E == 6 ? 3 : 2; }
+__host__ __device__ constexpr int light_tab_width() { return TW_LIGHT_TABW(E); }
 
 // order of the current tuple c.x against kept tuple k when the scores are equal: +1 greater, -1 smaller, 0 equivalent
 template <int E>
@@ -671,8 +674,11 @@ __global__ void __launch_bounds__(kTile) k_classify(Dev P, int pass, const int32
     P.span_cls[U.in_off + i] = heavy ? 1 : 0;
 }
 
+#ifndef TW_LIGHT_ATTR
+#define TW_LIGHT_ATTR
+#endif
 template <int E>
-__global__ void __launch_bounds__(kTile) k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
+__global__ void __launch_bounds__(kTile) TW_LIGHT_ATTR k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
     if (*P.err != 0) return;  // e.g. NaN parameters (hazard H3): nothing downstream is meaningful
     const int tile = tile_ids[xcd_tile(blockIdx.x, n_tiles_e)];
     const TileDev T = P.tiles[tile];
@@ -852,6 +858,16 @@ struct LdsHeap {
 //     A term is evaluated once per candidate (pair) instead of once per tuple -- with mixtures (pass 2) a term is
 //     ~1.5k instructions and an 8-endpoint tuple has up to 9 of them.  The tuple score adds the same doubles in the
 //     same order as the reference, so it is bit-identical.
+// Registers of the wavefront kernel: up to four endpoints it is held to 168 VGPRs -- three wavefronts per SIMD instead of the
+// two its 232 allow (measured on the default workload: enumeration group 2.57 -> 2.39 ms per launch at 6.4 M spans, 8.70 -> 8.08 ms
+// at 25.6 M; profiles/r02d_variants.jsonl).  The deep call graphs keep their registers (256 VGPRs: a cap would spill).
+#ifndef TW_HEAVY_ATTR
+#ifdef __HIPCC__
+#define TW_HEAVY_ATTR __attribute__((amdgpu_waves_per_eu(E <= 4 ? 3 : 1)))
+#else
+#define TW_HEAVY_ATTR
+#endif
+#endif
 constexpr int kPairPoolPerEp = 160;   // doubles of pair-term tables per endpoint (E <= 4); 2048 doubles (16 KB) for the deep call graphs
 constexpr int kGridTarget = TW_GRID_TARGET;     // grid points per prefix the split of the endpoints aims at (a prefix step costs about as much as five grid batches)
 // Deep call graphs with many candidates per endpoint (Alibaba shape: 7-8 endpoints x 10-14 candidates = 10^7-10^8 grid
@@ -869,7 +885,7 @@ constexpr int kFrontierBigCap = TW_FRONTIER_BIG_CAP;       // ... of kFrontierBi
 constexpr int kFrontierSlots = 4096;            // buffer pairs of kFrontierCap entries, claimed by the wavefronts that need one
 constexpr int kFrontierBigSlots = TW_FRONTIER_BIG_SLOTS;   // (the host-emulation build of the tests uses tiny sizes so that all three routes are exercised)
 template <int E, int W>
-__global__ void __launch_bounds__(kHeavyThreads) k_enumerate_heavy(Dev P, int pass, int mode, int part, int pool) {
+__global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy(Dev P, int pass, int mode, int part, int pool) {
     // part: 0 = the class' lists, the long enumerations first (one launch serves both); 1 = only the long ones (the split spans
     // that k_merge_parts lists again); 2 = only the others.  `pool` = doubles of dynamic LDS for the pair-term tables.
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
@@ -1801,37 +1817,48 @@ constexpr int kNodeBudget = 1 << 24; // search nodes per component
 constexpr int kBlkWords = (kMaxWin * kTopK + 63) / 64;  // words of a mask over all candidates of a component
 constexpr int kBigWindow = 8;        // windows of at least this many spans are served first by k_select_heavy
 constexpr int kBruteMax = 4;         // components of up to this many spans are solved by complete enumeration (see select_brute)
-constexpr int kMemoSlots = 256;      // transposition table entries (LDS); a table of 2^20 entries prunes no better on the test workloads
+#ifndef TW_MEMO_SLOTS
+#define TW_MEMO_SLOTS 256
+#endif
+constexpr int kMemoSlots = TW_MEMO_SLOTS;      // transposition table entries (LDS); a table of 2^20 entries prunes no better on the test workloads
 
 // ---- cooperative path: one workgroup per window --------------------------------------------------
-struct SelectLds {
-    int32_t idx[kMaxWin][kTopK][kMaxEp];
-    sel_w w[kMaxWin][kTopK];  // sel_weight(score); <= 0 means not eligible
-    sel_w ub[kMaxWin + 1];
+// MW = spans a window may hold; SEARCH = false leaves out what only select_search needs (windows of <= kBruteMax spans
+// have no larger component: k_select_tiny, 1 KB instead of 22 KB of LDS per wavefront)
+template <int MW, bool SEARCH>
+struct SelectLdsT {
+    static constexpr bool kSearch = SEARCH;
+    static constexpr int kS = SEARCH ? MW : 1, kSlots = SEARCH ? kMemoSlots : 1;
+    int32_t idx[MW][kTopK][kMaxEp];
+    sel_w w[MW][kTopK];  // sel_weight(score); <= 0 means not eligible
+    sel_w ub[kS + 1];
     sel_w red_val[kCoop / 64];
     int32_t red_idx[kCoop / 64];
-    uint8_t ncand[kMaxWin], comp[kMaxWin], mem[kMaxWin];
-    int8_t pick[kMaxWin];
-    uint32_t adj[kMaxWin];  // span conflict relation as bit rows
+    uint8_t ncand[MW], comp[MW], mem[MW];
+    int8_t pick[MW];
+    uint32_t adj[MW];  // span conflict relation as bit rows
     uint32_t cmask[kBruteMax][kTopK], celig[kBruteMax];  // select_brute: conflicts among / eligibility of the component's candidates
-    unsigned long long g2[kMaxWin], g3[kMaxWin];  // pair / triple optima of the grouped bound (weights are > 0)
+    unsigned long long g2[kS], g3[kS];  // pair / triple optima of the grouped bound (weights are > 0)
     // select_search: conflicts of candidate k of member x with the candidates of the other members as a bit
     // mask over (member y, candidate k2) -> bit y*kTopK+k2
-    unsigned long long cmask3[kMaxWin][kTopK][kBlkWords];
+    unsigned long long cmask3[kS][kTopK][kBlkWords];
     // transposition table of select_search: what can still be gained below a node depends only on its depth and on which
     // candidates of the remaining spans are blocked, not on how the spans above were assigned
-    unsigned long long mkey[kMemoSlots][kBlkWords];
-    sel_w mval[kMemoSlots];
-    unsigned int mstate[kMemoSlots];   // generation << 2 | (0 empty, 1 being written, 2 valid)
+    unsigned long long mkey[kSlots][kBlkWords];
+    sel_w mval[kSlots];
+    unsigned int mstate[kSlots];   // generation << 2 | (0 empty, 1 being written, 2 valid)
     unsigned int memo_gen;
-    sel_w saccs[kMaxWin + 1];                       // search stack: weight above every level,
-    unsigned long long sblk[kMaxWin + 1][kBlkWords];  // candidates blocked at every level,
-    int8_t scur[kMaxWin], sbest[kMaxWin];             // choice per level (ncand = "none"), incumbent
+    sel_w saccs[kS + 1];                       // search stack: weight above every level,
+    unsigned long long sblk[kS + 1][kBlkWords];  // candidates blocked at every level,
+    int8_t scur[kS], sbest[kS];             // choice per level (ncand = "none"), incumbent
     int cm, budget_hit;
     unsigned long long nodes_total;   // search nodes of the window (all lanes), reported in unit_stats[5]
 };
+typedef SelectLdsT<kMaxWin, true> SelectLds;
+typedef SelectLdsT<kBruteMax, false> SelectLdsTiny;
 
-__device__ inline bool lds_share(const SelectLds& L, int E, int b1, int k1, int b2, int k2) {
+template <class LDS>
+__device__ inline bool lds_share(const LDS& L, int E, int b1, int k1, int b2, int k2) {
     for (int e = 0; e < E; e++)
         if (L.idx[b1][k1][e] == L.idx[b2][k2][e]) return true;
     return false;
@@ -1943,7 +1970,8 @@ __device__ void select_search(SelectLds& L) {
 // largest sum, the smallest index among equal sums, and must beat the empty selection (sum 0) strictly.  The
 // canonical search visits at most 1 + 6 + ... + 6^4 = 1555 < kNodeBudget nodes on such a component, so it always
 // completes and returns this very selection.
-__device__ void select_brute(SelectLds& L, int E) {
+template <class LDS>
+__device__ void select_brute(LDS& L, int E) {
     const int t = threadIdx.x, nt = blockDim.x;
     const int lane = t & 63, wave = t >> 6, nwave = (nt + 63) >> 6;
     constexpr int C = kTopK + 1;
@@ -2035,7 +2063,8 @@ __device__ long long g_sel_acc[8];
 #define TW_SEL_ARG
 #define TW_SEL_PASS
 #endif
-__device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int first, int m, SelectLds& L TW_SEL_ARG) {
+template <class LDS>
+__device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int first, int m, LDS& L TW_SEL_ARG) {
     const int t = threadIdx.x, nt = blockDim.x, E = U.E;
     TW_SEL_T0();
     for (int q = t; q < m * kTopK; q += nt) {
@@ -2095,6 +2124,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
         group_sync();
         TW_SEL_TICK(3);
         if (L.cm <= kBruteMax) { select_brute(L, E); TW_SEL_TICK(4); continue; }  // uniform: cm is in LDS and stable here
+        if constexpr (LDS::kSearch) {
         {   // conflict masks of the component's candidates (only between members whose candidate lists meet at all)
             const int cm = L.cm;
             for (int q = t; q < cm * kTopK * kBlkWords; q += nt) (&L.cmask3[0][0][0])[q] = 0;
@@ -2151,6 +2181,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
         group_sync();
         select_search(L);
         TW_SEL_TICK(5);
+        }
     }
     TW_SEL_TICK(6);
     for (int b = t; b < m; b += nt) P.chosen[U.in_off + first + b] = L.pick[b];
@@ -2160,17 +2191,24 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
     TW_SEL_TICK(7);
 }
 
-// Puts window w of the unit on the work list of k_select_heavy (`listed` lanes only; every lane of the wavefront calls).
-// Long windows can take a thousand times longer than short ones: they are listed from the front and served first, the
-// short ones from the back of the same array, so that no long search starts when the kernel is about to drain.
+// Puts window w of the unit on a work list (`listed` lanes only; every lane of the wavefront calls): windows of up to
+// kBruteMax spans -- nearly all -- on the list of k_select_tiny, the others on the list of k_select_heavy.  There, long windows
+// can take a thousand times longer than short ones: they are listed from the front and served first, the short ones from the
+// back of the same array, so that no long search starts when the kernel is about to drain.
 __device__ __forceinline__ void list_window(const Dev& P, const UnitDev& U, int unit, int w, bool listed) {
-    bool big = false;
+    bool big = false, tiny = false;
     if (listed) {
         const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
-        big = P.w_last[U.in_off + w] - first + 1 >= kBigWindow;
+        const int m = P.w_last[U.in_off + w] - first + 1;
+        big = m >= kBigWindow;
+        tiny = m <= kBruteMax;
     }
-    const int sb = wave_append(&P.heavy_count[1], big), ss = wave_append(&P.heavy_count[2], listed && !big);
-    if (listed) {
+    const int sb = wave_append(&P.heavy_count[1], big), ss = wave_append(&P.heavy_count[2], listed && !big && !tiny);
+    const int st = wave_append(&P.heavy_count[0], tiny);
+    if (tiny) {
+        P.tiny_unit[st] = unit;
+        P.tiny_win[st] = w;
+    } else if (listed) {
         const int pos = big ? sb : (int)(P.n_in_total / 2) - ss;
         P.heavy_unit[pos] = unit;
         P.heavy_win[pos] = w;
@@ -2259,6 +2297,35 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
             atomicAdd((unsigned long long*)&P.prof[9], dur);
         }
 #endif
+    }
+}
+
+// The listed windows of up to kBruteMax spans: every component is solved by complete enumeration (select_brute), so the
+// workgroup needs neither the search stack nor the transposition table -- 1 KB of LDS, and the SIMDs fill up (the full kernel
+// is limited to seven wavefronts per CU by its 22 KB, and what it does is latency-bound).  Same procedure, same results.
+__global__ void __launch_bounds__(64) k_select_tiny(Dev P) {  // persistent workgroups, one listed window at a time
+    if (*P.err != 0) return;
+    __shared__ SelectLdsTiny L;
+    __shared__ int next_item;
+    const int count = P.heavy_count[0];
+    if ((int)blockIdx.x * kWorkChunk >= count) return;
+    int chunk_pos = (int)blockIdx.x * kWorkChunk, chunk_end = chunk_pos + kWorkChunk;   // the first chunk of a workgroup is its own
+    TW_SEL_DECL();
+    while (true) {
+        if (chunk_pos == chunk_end) {
+            if (threadIdx.x == 0) next_item = (int)gridDim.x * kWorkChunk + atomicAdd(&P.heavy_count[3], kWorkChunk);
+            group_sync();
+            chunk_pos = next_item;
+            group_sync();
+            chunk_end = chunk_pos + kWorkChunk;
+        }
+        if (chunk_pos >= count) { TW_SEL_FLUSH(); break; }
+        const int item = chunk_pos++;
+        const int unit = __builtin_amdgcn_readfirstlane(P.tiny_unit[item]), w = __builtin_amdgcn_readfirstlane(P.tiny_win[item]);
+        const UnitDev& U = P.units[unit];
+        const int last = P.w_last[U.in_off + w];
+        const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
+        select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS);
     }
 }
 
