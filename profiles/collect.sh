@@ -27,9 +27,11 @@ run_pmc() {  # name, counters...
     $T rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/${TAG}_${name} -o ${TAG} -- python bench.py $ARGS > gpurun_out/${TAG}_${name}.log 2>&1
     echo "${name}: rc $?"
 }
+if [ -z "${SKIP_STATS:-}" ]; then   # (a later call that only adds counter passes to a set keeps the first call's stats)
 mkdir -p gpurun_out/${TAG}_stats
 $T rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -o ${TAG} -- python bench.py $ARGS > gpurun_out/${TAG}_stats.log 2>&1
 echo "stats: rc $?"
+fi
 for p in $PASSES; do
     case $p in
     fetch) run_pmc fetch FETCH_SIZE;;

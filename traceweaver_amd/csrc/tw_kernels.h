@@ -858,15 +858,13 @@ struct LdsHeap {
 //     A term is evaluated once per candidate (pair) instead of once per tuple -- with mixtures (pass 2) a term is
 //     ~1.5k instructions and an 8-endpoint tuple has up to 9 of them.  The tuple score adds the same doubles in the
 //     same order as the reference, so it is bit-identical.
-// Registers of the wavefront kernel: up to four endpoints it is held to 168 VGPRs -- three wavefronts per SIMD instead of the
-// two its 232 allow (measured on the default workload: enumeration group 2.57 -> 2.39 ms per launch at 6.4 M spans, 8.70 -> 8.08 ms
-// at 25.6 M; profiles/r02d_variants.jsonl).  The deep call graphs keep their registers (256 VGPRs: a cap would spill).
+// Registers of the wavefront kernel.  Measured and not adopted (profiles/r02d_variants.jsonl, profiles/r02d_spill_traffic.md):
+// -DTW_HEAVY_ATTR='__attribute__((amdgpu_waves_per_eu(3)))' holds it to 168 VGPRs -- three wavefronts per SIMD instead of the two
+// its 232 registers allow (E = 4) -- and the enumeration group does get 7 % faster (2.57 -> 2.39 ms per launch at 6.4 M spans,
+// 8.70 -> 8.08 ms at 25.6 M), but the 256 B per lane it then spills are written back to HBM: 2.4 GB per launch at 25.6 M spans,
+// five times everything else the group writes.  The registers have to go by restructuring (cold paths out of line), not by a cap.
 #ifndef TW_HEAVY_ATTR
-#ifdef __HIPCC__
-#define TW_HEAVY_ATTR __attribute__((amdgpu_waves_per_eu(E <= 4 ? 3 : 1)))
-#else
 #define TW_HEAVY_ATTR
-#endif
 #endif
 constexpr int kPairPoolPerEp = 160;   // doubles of pair-term tables per endpoint (E <= 4); 2048 doubles (16 KB) for the deep call graphs
 constexpr int kGridTarget = TW_GRID_TARGET;     // grid points per prefix the split of the endpoints aims at (a prefix step costs about as much as five grid batches)
