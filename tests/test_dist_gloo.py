@@ -266,3 +266,41 @@ def test_bench_media_split_over_two_ranks_equals_one(emu_lib):
     r = _run_bench(emu_lib, "--gpus", "2", "--backend", "gloo", "--workload", "media-split", "--n-in", "1200", "--replicas", "2", "--verify", "1")
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["sharded_equals_single_gpu"] is True
     assert sum(r["config"]["spans_per_gpu"]) == r["config"]["spans_total"] and min(r["config"]["spans_per_gpu"]) > 0.3 * r["config"]["spans_total"]
+
+
+def test_bench_sync_engine_needs_no_torch(emu_lib):
+    """`bench.py --sync engine` (what profiles/collect.sh runs under rocprofv3): the same line as the default route,
+    from a process that never imports torch (every C-ABI call returns with its stream synchronised)."""
+    import subprocess
+
+    a = _run_bench(emu_lib, "--n-in", "600", "--replicas", "1")
+    b = _run_bench(emu_lib, "--n-in", "600", "--replicas", "1", "--sync", "engine")
+    for k in ("accuracy", "windows", "unassigned", "budget_windows", "n_gpus"):
+        assert a[k] == b[k], k
+    assert a["config"] == b["config"]
+    code = ("import sys, runpy\n"
+            "sys.argv = ['bench.py', '--lib', %r, '--cpu-sample', '0', '--steps', '1', '--warmup', '0', '--n-in', '300', '--replicas', '1', '--sync', 'engine']\n"
+            "runpy.run_path(%r, run_name='__main__')\n"
+            "assert 'torch' not in sys.modules, 'torch was imported'\n") % (emu_lib, os.path.join(REPO, "bench.py"))
+    env = dict(os.environ, TW_TILE="1", TW_COOP_THREADS="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+
+
+def test_bench_default_batch_is_sixteen_replicas():
+    """The default workload of `python bench.py`: 16 replicas of the media graph (profiles/r02d_batch_sweep.json); the other
+    workloads keep 4."""
+    sys.path.insert(0, REPO)
+    import bench
+
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        args = bench.parse_args()
+        assert args.replicas is None and args.workload == "media" and args.n_in == 100000
+    finally:
+        sys.argv = old
+    import inspect
+
+    src = inspect.getsource(bench.make_units)
+    assert "16 if args.workload == \"media\" else 4" in src
