@@ -14,7 +14,8 @@ Workloads (--workload):
   media    BASELINE.json config 2 shape (default, the configuration the metric is quoted on for one GPU): the six
            accelerated services of media_microservices (E in {1,1,1,1,2,4}) scaled up with the seed-fixed synthetic
            generator in traceweaver_amd/synth.py (the shipped corpus has 1000 requests per service, which a GPU
-           finishes in microseconds).  Weak scaling: every rank holds its own replicas.
+           finishes in microseconds): by default 16 replicas of the graph x 100 000 requests per service = 25.6 M spans
+           resident per GPU.  Weak scaling: every rank holds its own replicas.
   nodejs   config 3 shape: nodejs_microservices_with_arbitrary_file_io, 4 services, millisecond-granular, heavily
            interleaved.  Weak scaling.
   alibaba  config 4: ONE Alibaba-shape slice (--total-spans, default 1 M engine spans, 15 call graphs, 39 services)
