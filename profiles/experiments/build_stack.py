@@ -1,6 +1,6 @@
 """Builds HEAD and HEAD + the patches of this directory, cumulatively, side by side:
 
-    scratch/variants/s0_head.so, s1_select_mid.so, s2_dense_terms.so, s3_segmented_lists.so, s4_select_big.so, s5_light3.so (= s4 with other resources)
+    scratch/variants/s0_head.so, s1_select_mid.so, s2_dense_terms.so, s3_segmented_lists.so, s4_select_big.so, s5_conflict_lanes.so, s6_light3.so (= s5 with other resources)
 
 (scratch/ is not tracked but travels to the GPU box).  The patches are applied to copies of the sources under a temporary
 directory; the working tree is not touched.  Then, in one gpurun call:  bash profiles/experiments/run_stack.sh
@@ -18,7 +18,8 @@ sys.path.insert(0, REPO)
 from traceweaver_amd import build as B  # noqa: E402
 
 STACK = [("s0_head", None), ("s1_select_mid", "select_mid_instantiation.patch"), ("s2_dense_terms", "dense_mixture_terms.patch"),
-         ("s3_segmented_lists", "segmented_selection_lists.patch"), ("s4_select_big", "select_big_instantiation.patch")]
+         ("s3_segmented_lists", "segmented_selection_lists.patch"), ("s4_select_big", "select_big_instantiation.patch"),
+         ("s5_conflict_lanes", "conflict_relation_lanes.patch")]
 
 
 def main():
@@ -36,7 +37,7 @@ def main():
     # the top of the stack once more with the per-thread kernels capped to 168 VGPRs and narrower term tables (three wavefronts
     # per SIMD; neutral without the dense term evaluation, r02d_variants.jsonl `light3` -- the terms that fall off the table were
     # what it cost)
-    jobs.append(("s5_light3", jobs[-1][1], ["-DTW_LIGHT_ATTR=__attribute__((amdgpu_waves_per_eu(3)))",
+    jobs.append(("s6_light3", jobs[-1][1], ["-DTW_LIGHT_ATTR=__attribute__((amdgpu_waves_per_eu(3)))",
                                             "-DTW_LIGHT_TABW(E)=((E)==1?8:(E)==2?6:(E)==3?4:(E)==4?3:2)"]))
     os.makedirs(os.path.join(REPO, "scratch", "variants"), exist_ok=True)
 
@@ -48,7 +49,7 @@ def main():
         r = subprocess.run(cmd, capture_output=True, text=True)
         return name, r.returncode, r.stderr[-1500:]
 
-    with ThreadPoolExecutor(6) as ex:
+    with ThreadPoolExecutor(7) as ex:
         for name, rc, err in ex.map(build, jobs):
             print(name, "ok" if rc == 0 else "FAILED\n" + err)
     shutil.rmtree(tmp, ignore_errors=True)
