@@ -60,6 +60,7 @@ struct Dev {
     const UnitDev* units;
     const TileDev* tiles;
     int32_t n_units, n_tiles;
+    int32_t tile_spans;        // incoming spans per tile (workgroup size of the per-span kernels)
     int64_t n_in_total, n_out_total;
     int32_t batch_size, batch_mis;
     // spans (SoA, 16 B per span)
@@ -109,11 +110,16 @@ struct Dev {
     double* gaps;
     const int64_t* gs_off;  // [n_units]
     int64_t* unit_stats;    // [n_units][8]
-    int32_t* heavy_count;   // [4] windows whose best candidates clash: [1] long ones (front of the list of k_select_heavy), [2] middle ones
-                            // (its back), [0] windows of <= kBruteMax spans (list of k_select_tiny), [3] next unclaimed entry of that list
-    int32_t* heavy_next;    // next unclaimed entry of the list of k_select_heavy
+    // Windows whose best candidates clash, listed by k_select_fast / k_detect_gone: four lists (0 windows of <= kBruteMax spans for
+    // k_select_tiny; 1 long, 2 middle and 3 very long ones for the three instantiations of k_select_heavy), each cut into kSelSeg
+    // segments by tile range with a counter of its own on a cache line of its own (same-address atomics serialise: one counter per
+    // list kept k_select_fast at 1.4 ms for 150 k wavefronts).  heavy_count[(list * kSelSeg + segment) * kCtrStride]; segment s owns
+    // the positions [first tile of s, first tile of s + 1) * tile_spans of tiny_* (short windows from the front of the segment, very
+    // long ones from its back) and of heavy_* (long ones from the front, middle ones from the back).
+    int32_t* heavy_count;
+    int32_t* heavy_next;    // [4] next unclaimed item of every list
     int32_t *heavy_unit, *heavy_win;
-    int32_t *tiny_unit, *tiny_win;   // work list of k_select_tiny
+    int32_t *tiny_unit, *tiny_win;
     int32_t* heavy_in_count;  // [2][kMaxEp+1] incoming spans deferred to k_enumerate_heavy per endpoint count E: narrow, wide windows
     int32_t* heavy_in_next;   // [3][kMaxEp+1] next unclaimed entry of each list: narrow, wide, long enumerations (when launched on their own)
     uint8_t* span_cls;        // per incoming span: 0 enumerated by its thread of k_enumerate_light, 1 by a wavefront (k_classify)

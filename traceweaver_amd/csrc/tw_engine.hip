@@ -232,18 +232,28 @@ void launch_enumerate_all(tw_engine* e, int pass, int mode) {
 }
 
 // The listed windows: those of up to kBruteMax spans (nearly all of them) by k_select_tiny, whose workgroups hold 1 KB of LDS
-// and fill the SIMDs; the others by k_select_heavy (22 KB of LDS: seven wavefronts per CU), which ends with its longest
-// search -- on a stream of its own (an idle class stream, forked from and joined to the engine's stream by events), so
-// that the many short windows run beside that tail instead of before it.
+// and fill the SIMDs; the middle ones (up to kBigWindow - 1 spans: one-word masks, 7 KB) and the long ones (22 KB: seven
+// wavefronts per CU, ends with its longest search) by the two instantiations of k_select_heavy -- each on an idle class
+// stream of its own, forked from and joined to the engine's stream by events, so that the many short windows run
+// beside the long searches' tail instead of before it.
 void launch_select_listed(tw_engine* e) {
     const Dev& P = e->P;
     const dim3 wave(std::min(e->coop, 64));
+    const dim3 grid((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096));
     (void)hipEventRecord(e->cls_ev[0], e->stream);
     (void)hipStreamWaitEvent(e->cls_stream[1], e->cls_ev[0], 0);
-    hipLaunchKernelGGL(k_select_heavy, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096)), wave, 0, e->cls_stream[1], P);
+    hipLaunchKernelGGL((k_select_heavy<SelectLds, 3>), grid, wave, 0, e->cls_stream[1], P);      // the longest searches first
     (void)hipEventRecord(e->cls_ev[1], e->cls_stream[1]);
+    (void)hipStreamWaitEvent(e->cls_stream[2], e->cls_ev[0], 0);
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsBig, 1>), grid, wave, 0, e->cls_stream[2], P);
+    (void)hipEventRecord(e->cls_ev[2], e->cls_stream[2]);
+    (void)hipStreamWaitEvent(e->cls_stream[3], e->cls_ev[0], 0);
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsMid, 2>), grid, wave, 0, e->cls_stream[3], P);
+    (void)hipEventRecord(e->cls_ev[3], e->cls_stream[3]);
     hipLaunchKernelGGL(k_select_tiny, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 8192)), wave, 0, e->stream, P);
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[1], 0);
+    (void)hipStreamWaitEvent(e->stream, e->cls_ev[2], 0);
+    (void)hipStreamWaitEvent(e->stream, e->cls_ev[3], 0);
 }
 
 // OR of (key ^ first key) and of the keys themselves over a set of index ranges (see k_key_bits)
@@ -346,8 +356,8 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
     HIPCHK(hipMemsetAsync(P.err, 0, sizeof(int32_t), e->stream));
     HIPCHK(hipMemsetAsync(P.unit_stats, 0, sizeof(int64_t) * 8 * P.n_units, e->stream));
-    HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 4, e->stream));
-    HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t), e->stream));
+    HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 4 * kSelSeg * kCtrStride, e->stream));
+    HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t) * 4, e->stream));
     HIPCHK(hipMemsetAsync(P.unit_ndirty, 0, sizeof(int32_t) * P.n_units, e->stream));
     if (pass == 1 && !e->skip_mode) {
         int rc = sort_ends(e);
@@ -412,8 +422,8 @@ int run_pass(tw_engine* e, int pass) {
         HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
         HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 3 * (kMaxEp + 1), e->stream));
         HIPCHK(hipMemsetAsync(P.heavy_big_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
-        HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 4, e->stream));
-        HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t), e->stream));
+        HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 4 * kSelSeg * kCtrStride, e->stream));
+        HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t) * 4, e->stream));
         HIPCHK(hipMemsetAsync(P.round_changed, 0, sizeof(int32_t), e->stream));
         hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, e->stream, P, round);
         int32_t changed = 0;
@@ -771,6 +781,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     P = Dev{};
     P.n_units = b->n_units;
     P.n_tiles = (int32_t)e->tiles.size();
+    P.tile_spans = e->tile;
     P.n_in_total = n_in_total;
     P.n_out_total = n_out_total;
     P.batch_size = b->batch_size;
@@ -821,8 +832,9 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     }
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
     ALLOC(P.prof, 16); ALLOC(e->key_acc, 2);
-    ALLOC(P.heavy_count, 4); ALLOC(P.heavy_next, 1); ALLOC(P.heavy_unit, n_in_total / 2 + 1); ALLOC(P.heavy_win, n_in_total / 2 + 1);
-    ALLOC(P.tiny_unit, n_in_total / 2 + 1); ALLOC(P.tiny_win, n_in_total / 2 + 1);
+    const int64_t sel_cap = (int64_t)P.n_tiles * e->tile + 1;   // every segment of the selection lists has room for all windows of its tiles
+    ALLOC(P.heavy_count, 4 * kSelSeg * kCtrStride); ALLOC(P.heavy_next, 4); ALLOC(P.heavy_unit, sel_cap); ALLOC(P.heavy_win, sel_cap);
+    ALLOC(P.tiny_unit, sel_cap); ALLOC(P.tiny_win, sel_cap);
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
     ALLOC(e->gaps_sorted, gaps); ALLOC(e->fit_models, slots * kMaxComp * kModelStride);
@@ -1276,12 +1288,13 @@ void tw_host_free(void* p) {
  * out[2 + kMaxEp] = spans enumerated in parts, out[3 + kMaxEp] = of those, enumerated once more as a whole (out: 4 + kMaxEp ints). */
 int tw_debug_worklists(tw_engine* e, int32_t* out) {
     if (e == nullptr || out == nullptr || e->state < ST_PASS1) return TW_ERR_ARG;
-    int32_t sel[4];
-    HIPCHK(hipMemcpyAsync(sel, e->P.heavy_count, sizeof(sel), hipMemcpyDeviceToHost, e->stream));
+    static int32_t sel_all[4 * kSelSeg * kCtrStride];
+    HIPCHK(hipMemcpyAsync(sel_all, e->P.heavy_count, sizeof(sel_all), hipMemcpyDeviceToHost, e->stream));
     int32_t both[2 * (kMaxEp + 1)];
     HIPCHK(hipMemcpyAsync(both, e->P.heavy_in_count, sizeof(both), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    out[0] = sel[0] + sel[1] + sel[2];
+    out[0] = 0;
+    for (int k = 0; k < 4 * kSelSeg; k++) out[0] += sel_all[k * kCtrStride];
     for (int k = 0; k <= kMaxEp; k++) out[1 + k] = both[k] + both[kMaxEp + 1 + k];
     int32_t split[kMaxEp + 1];   // [0] spans listed again after the merge, [E >= 2] split spans of the class
     HIPCHK(hipMemcpy(split, e->P.split_count, sizeof(split), hipMemcpyDeviceToHost));

@@ -441,7 +441,7 @@ struct LightCtx {
 // back to evaluating at the tree level where the span is chosen.  The tuple score adds the same doubles in the
 // same order, so it is bit-identical.
 #ifndef TW_LIGHT_TABW
-#define TW_LIGHT_TABW(E) ((E) == 1 ? 0 : (E) == 2 ? 8 : (E) == 3 ? 6 : (E) == 4 ? 5 : (E) == 5 ? 4 : (E) == 6 ? 3 : 2)
+#define TW_LIGHT_TABW(E) ((E) == 1 ? 8 : (E) == 2 ? 8 : (E) == 3 ? 6 : (E) == 4 ? 5 : (E) == 5 ? 4 : (E) == 6 ? 3 : 2)
 #endif
 template <int E>
 __host__ __device__ constexpr int light_tab_width() { return TW_LIGHT_TABW(E); }
@@ -677,6 +677,26 @@ __global__ void __launch_bounds__(kTile) k_classify(Dev P, int pass, const int32
 #ifndef TW_LIGHT_ATTR
 #define TW_LIGHT_ATTR
 #endif
+// position of the n-th set bit of m (n < popcount(m)): six halvings
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const unsigned long long low = m & ((1ull << w) - 1ull);
+        const int c = __popcll(low);
+        if (n >= c) { n -= c; m >>= w; pos += w; } else m = low;
+    }
+    return pos;
+}
+
+// a term of pass 2 from the gap itself (score_term computes x = (double)(t2 - t1) and then exactly this)
+__device__ __forceinline__ double score_term_mix_x(const Scorer& S, int slot, double x) {
+    const int n = S.mix_n[slot];
+    const double* c = S.mix_c + (int64_t)slot * kMaxComp * 4;
+    if (n <= 0) return term_gauss(c[0], c[1], c[2], x);
+    return term_mix(n, c, x);
+}
+
 template <int E>
 __global__ void __launch_bounds__(kTile) TW_LIGHT_ATTR k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
     if (*P.err != 0) return;  // e.g. NaN parameters (hazard H3): nothing downstream is meaningful
@@ -684,22 +704,27 @@ __global__ void __launch_bounds__(kTile) TW_LIGHT_ATTR k_enumerate_light(Dev P, 
     const TileDev T = P.tiles[tile];
     const UnitDev& U = P.units[T.unit];
     const int i = T.first + threadIdx.x;
-    if (i >= U.n_in) return;
-    if (P.span_cls[U.in_off + i] != 0) return;   // enumerated by a wavefront (k_classify listed it)
+    constexpr int Wt = light_tab_width<E>();
+    // pass 2 with a term table: the lanes without a span of their own stay for the table (its mixture terms are evaluated by
+    // all lanes of the wavefront, see below); otherwise they leave here
+    const bool dense = Wt > 0 && pass == 2;
+    bool mine = i < U.n_in;
+    if (mine && P.span_cls[U.in_off + i] != 0) mine = false;   // enumerated by a wavefront (k_classify listed it)
+    if (!mine && !dense) return;
     LightCtx<E> c;
     c.U = &U;
-    c.in_start = P.in_start[U.in_off + i];
-    c.in_end = P.in_end[U.in_off + i];
+    c.in_start = mine ? P.in_start[U.in_off + i] : 0;
+    c.in_end = mine ? P.in_end[U.in_off + i] : 0;
     c.S.pass = pass;
-    c.S.gp = P.gparam + (U.gp_off + (int64_t)(i / P.batch_size) * U.nslot) * 4;
+    c.S.gp = P.gparam + (U.gp_off + (int64_t)((mine ? i : 0) / P.batch_size) * U.nslot) * 4;
     c.S.mix_n = P.mix_n + U.slot_off;
     c.S.mix_c = P.mix_c + (int64_t)U.slot_off * kMaxComp * 4;
 #pragma unroll
     for (int e = 0; e < E; e++) { c.os[e] = P.out_start + U.ep_off[e]; c.oe[e] = P.out_end + U.ep_off[e]; }
-    bool empty = false, narrow = true;
+    bool empty = !mine, narrow = true;
 #pragma unroll
     for (int e = 0; e < E; e++) {   // cut-offs: k_classify
-        c.lo[e] = P.c_lo[ie_index(U, e, i)]; c.hi[e] = P.c_hi[ie_index(U, e, i)];
+        c.lo[e] = mine ? P.c_lo[ie_index(U, e, i)] : 0; c.hi[e] = mine ? P.c_hi[ie_index(U, e, i)] : -1;
         const int w = c.hi[e] - c.lo[e] + 1;
         narrow &= (w <= kNarrow);
         empty |= (w <= 0);
@@ -712,22 +737,77 @@ __global__ void __launch_bounds__(kTile) TW_LIGHT_ATTR k_enumerate_light(Dev P, 
 #pragma unroll
         for (int w = 0; w < kCandWords; w++) c.bits[e][w] = 0;
     {   // term table of this thread: [endpoint][candidate][root, closing], one LDS column per thread
-        constexpr int Wt = light_tab_width<E>();
-        __shared__ double tab[(Wt > 0 ? E * Wt * 2 : 1) * kTile];
+        constexpr int NC = Wt > 0 ? E * Wt * 2 : 1;   // cells per thread
+        static_assert(NC <= 64, "a thread's cells are counted in one 64-bit mask");
+        __shared__ double tab[NC * kTile];
         c.tab = tab + threadIdx.x;
         c.tab_stride = blockDim.x;
-        if (!empty) {
+        if (!dense) {
+            if (!empty) {
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                int r = 0;  // rows = the first Wt *contained* candidates (the others never occur in a tuple)
-                for (int cx = c.lo[e]; cx <= c.hi[e] && r < Wt; cx++) {
-                    const int64_t st = c.os[e][cx], en = c.oe[e][cx];
-                    if (c.in_start > st || en > c.in_end) continue;
-                    c.tab[(e * Wt + r) * 2 * c.tab_stride] = U.npred[e] == 0 ? score_term(c.S, slot_root(E, e), c.in_start, st) : 0.0;
-                    c.tab[((e * Wt + r) * 2 + 1) * c.tab_stride] = score_term(c.S, slot_close(E, e), en, c.in_end);
-                    r++;
+                for (int e = 0; e < E; e++) {
+                    int r = 0;  // rows = the first Wt *contained* candidates (the others never occur in a tuple)
+                    for (int cx = c.lo[e]; cx <= c.hi[e] && r < Wt; cx++) {
+                        const int64_t st = c.os[e][cx], en = c.oe[e][cx];
+                        if (c.in_start > st || en > c.in_end) continue;
+                        c.tab[(e * Wt + r) * 2 * c.tab_stride] = U.npred[e] == 0 ? score_term(c.S, slot_root(E, e), c.in_start, st) : 0.0;
+                        c.tab[((e * Wt + r) * 2 + 1) * c.tab_stride] = score_term(c.S, slot_close(E, e), en, c.in_end);
+                        r++;
+                    }
                 }
             }
+        } else if constexpr (Wt > 0) {
+            // Pass 2: a mixture term is ~1.5 k instructions and a thread has 2-20 of them -- built thread by thread, a wavefront
+            // runs as long as its thread with the most candidates (lanes active: 0.16-0.27).  Instead every thread only writes the
+            // *gaps* into its cells; one ballot per cell says which lanes use it; then the wavefront evaluates the used cells of an
+            // endpoint 64 at a time, item g = the n-th user of cell k (prefix sums over the ballots), whoever owns it.  Same function
+            // on the same binary64 gap: the table holds the same numbers.
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            const int nl = (int)blockDim.x - 64 * wv < 64 ? (int)blockDim.x - 64 * wv : 64;   // lanes of this wavefront (64 unless the emulation runs narrower workgroups)
+            unsigned long long used = 0;
+            if (!empty) {
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    int r = 0;
+                    for (int cx = c.lo[e]; cx <= c.hi[e] && r < Wt; cx++) {
+                        const int64_t st = c.os[e][cx], en = c.oe[e][cx];
+                        if (c.in_start > st || en > c.in_end) continue;
+                        const int cell = (e * Wt + r) * 2;
+                        if (U.npred[e] == 0) { c.tab[cell * c.tab_stride] = (double)(st - c.in_start); used |= 1ull << cell; }
+                        else c.tab[cell * c.tab_stride] = 0.0;
+                        c.tab[(cell + 1) * c.tab_stride] = (double)(c.in_end - en);
+                        used |= 1ull << (cell + 1);
+                        r++;
+                    }
+                }
+            }
+            wave_sync();
+            // endpoint by endpoint: the ballots and their prefix sums are wave-uniform and indexed by compile-time constants only --
+            // they live in scalar registers, the table's LDS footprint stays what it was
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                constexpr int C = 2 * Wt;   // cells of one endpoint
+                unsigned long long users[C];
+                int first[C + 1];
+                first[0] = 0;
+#pragma unroll
+                for (int k = 0; k < C; k++) {
+                    users[k] = __ballot((int)((used >> (e * C + k)) & 1ull));
+                    first[k + 1] = first[k] + __popcll(users[k]);
+                }
+                for (int g = lane; g < first[C]; g += nl) {
+                    int k = 0, base = 0;
+                    unsigned long long mk = users[0];
+#pragma unroll
+                    for (int j = 1; j < C; j++)
+                        if (g >= first[j]) { k = j; mk = users[j]; base = first[j]; }
+                    const int owner = nth_set_bit(mk, g - base);
+                    double* cellp = tab + (size_t)(e * C + k) * blockDim.x + (size_t)(wv * 64 + owner);
+                    *cellp = score_term_mix_x(c.S, (k & 1) ? slot_close(E, e) : slot_root(E, e), *cellp);
+                }
+            }
+            wave_sync();
+            if (!mine) return;
         }
     }
     if (!empty) light_dfs<E, 0>(c, pass == 1);
@@ -1814,6 +1894,7 @@ __device__ __forceinline__ sel_w sel_weight(double score) { return (sel_w)rint((
 constexpr int kNodeBudget = 1 << 24; // search nodes per component
 constexpr int kBlkWords = (kMaxWin * kTopK + 63) / 64;  // words of a mask over all candidates of a component
 constexpr int kBigWindow = 8;        // windows of at least this many spans are served first by k_select_heavy
+constexpr int kHugeWindow = 16;      // ... and from this many on by the instantiation with the full LDS layout (three-word masks)
 constexpr int kBruteMax = 4;         // components of up to this many spans are solved by complete enumeration (see select_brute)
 #ifndef TW_MEMO_SLOTS
 #define TW_MEMO_SLOTS 256
@@ -1827,6 +1908,7 @@ template <int MW, bool SEARCH>
 struct SelectLdsT {
     static constexpr bool kSearch = SEARCH;
     static constexpr int kS = SEARCH ? MW : 1, kSlots = SEARCH ? kMemoSlots : 1;
+    static constexpr int kW = SEARCH ? (MW * kTopK + 63) / 64 : 1;   // words of a mask over all candidates of a component
     int32_t idx[MW][kTopK][kMaxEp];
     sel_w w[MW][kTopK];  // sel_weight(score); <= 0 means not eligible
     sel_w ub[kS + 1];
@@ -1839,21 +1921,23 @@ struct SelectLdsT {
     unsigned long long g2[kS], g3[kS];  // pair / triple optima of the grouped bound (weights are > 0)
     // select_search: conflicts of candidate k of member x with the candidates of the other members as a bit
     // mask over (member y, candidate k2) -> bit y*kTopK+k2
-    unsigned long long cmask3[kS][kTopK][kBlkWords];
+    unsigned long long cmask3[kS][kTopK][kW];
     // transposition table of select_search: what can still be gained below a node depends only on its depth and on which
     // candidates of the remaining spans are blocked, not on how the spans above were assigned
-    unsigned long long mkey[kSlots][kBlkWords];
+    unsigned long long mkey[kSlots][kW];
     sel_w mval[kSlots];
     unsigned int mstate[kSlots];   // generation << 2 | (0 empty, 1 being written, 2 valid)
     unsigned int memo_gen;
     sel_w saccs[kS + 1];                       // search stack: weight above every level,
-    unsigned long long sblk[kS + 1][kBlkWords];  // candidates blocked at every level,
+    unsigned long long sblk[kS + 1][kW];  // candidates blocked at every level,
     int8_t scur[kS], sbest[kS];             // choice per level (ncand = "none"), incumbent
     int cm, budget_hit;
     unsigned long long nodes_total;   // search nodes of the window (all lanes), reported in unit_stats[5]
 };
 typedef SelectLdsT<kMaxWin, true> SelectLds;
 typedef SelectLdsT<kBruteMax, false> SelectLdsTiny;
+typedef SelectLdsT<kHugeWindow, true> SelectLdsBig;   // windows of kBigWindow <= m < kHugeWindow spans: two-word masks, 12 KB
+typedef SelectLdsT<kBigWindow, true> SelectLdsMid;   // windows of kBruteMax < m < kBigWindow spans: one-word masks, 7 KB
 
 template <class LDS>
 __device__ inline bool lds_share(const LDS& L, int E, int b1, int k1, int b2, int k2) {
@@ -1869,8 +1953,10 @@ __device__ inline bool lds_share(const LDS& L, int E, int b1, int k1, int b2, in
 // programme over the sets of taken outgoing spans rather than over the assignments that produce them: the largest
 // component of the heavy-load test workloads takes ~2e3 nodes instead of 4e6 (nodejs shape) / 8e8 (tie-saturated set).
 // Needs L.cm, L.mem, L.ncand, L.w, L.ub, L.cmask3; writes L.pick of the members.
-__device__ void select_search(SelectLds& L) {
-    static_assert(kBlkWords == 3, "the blocked mask is kept in three registers");
+template <class LDS>
+__device__ void select_search(LDS& L) {
+    constexpr int W = LDS::kW;   // words of the blocked mask: kept in up to three registers, the unused ones are constant zero
+    static_assert(W >= 1 && W <= 3 && kBlkWords == 3, "the blocked mask is kept in three registers");
     const int t = threadIdx.x;
     const int cm = L.cm;
     if (t == 0) {
@@ -1887,10 +1973,16 @@ __device__ void select_search(SelectLds& L) {
             h ^= h >> 29;
             return (unsigned)h & (kMemoSlots - 1);
         };
+        auto key_eq = [&](unsigned sl, const unsigned long long (&k)[kBlkWords]) -> bool {
+            bool eq = L.mkey[sl][0] == k[0];
+            if constexpr (W > 1) eq = eq && L.mkey[sl][1] == k[1];
+            if constexpr (W > 2) eq = eq && L.mkey[sl][2] == k[2];
+            return eq;
+        };
         sel_w best_w = 0, acc = 0;      // only strict improvements replace the incumbent
         unsigned long long b0 = 0, b1 = 0, b2 = 0;
         for (int q = 0; q < cm; q++) { L.scur[q] = -1; L.sbest[q] = -1; }
-        L.saccs[0] = 0; L.sblk[0][0] = 0; L.sblk[0][1] = 0; L.sblk[0][2] = 0;
+        L.saccs[0] = 0; L.sblk[0][0] = 0; if constexpr (W > 1) L.sblk[0][1] = 0; if constexpr (W > 2) L.sblk[0][2] = 0;
         int d = 0, nodes = 0;
         bool entered = true, over = false;
         while (d >= 0) {
@@ -1908,12 +2000,12 @@ __device__ void select_search(SelectLds& L) {
                     for (int pr = 0; pr < 4; pr++) {
                         const unsigned sl = (slot + pr) & (kMemoSlots - 1);
                         if (L.mstate[sl] != tag) break;   // empty: the chain ends here
-                        if (L.mkey[sl][0] == kk[0] && L.mkey[sl][1] == kk[1] && L.mkey[sl][2] == kk[2]) { cut = acc + L.mval[sl] <= best_w; break; }
+                        if (key_eq(sl, kk)) { cut = acc + L.mval[sl] <= best_w; break; }
                     }
                 }
                 if (cut) { d--; entered = false; continue; }
             } else {
-                acc = L.saccs[d]; b0 = L.sblk[d][0]; b1 = L.sblk[d][1]; b2 = L.sblk[d][2];
+                acc = L.saccs[d]; b0 = L.sblk[d][0]; if constexpr (W > 1) b1 = L.sblk[d][1]; if constexpr (W > 2) b2 = L.sblk[d][2];
                 k = L.scur[d] + 1;   // resume below the choice this level made last ("none" was stored as ncand)
             }
             const int b = L.mem[d], nc = L.ncand[b];
@@ -1929,9 +2021,9 @@ __device__ void select_search(SelectLds& L) {
             }
             if (found) {
                 L.scur[d] = (int8_t)k;
-                if (k < nc) { acc = acc + L.w[b][k]; b0 |= L.cmask3[d][k][0]; b1 |= L.cmask3[d][k][1]; b2 |= L.cmask3[d][k][2]; }
+                if (k < nc) { acc = acc + L.w[b][k]; b0 |= L.cmask3[d][k][0]; if constexpr (W > 1) b1 |= L.cmask3[d][k][1]; if constexpr (W > 2) b2 |= L.cmask3[d][k][2]; }
                 d++;
-                L.saccs[d] = acc; L.sblk[d][0] = b0; L.sblk[d][1] = b1; L.sblk[d][2] = b2;
+                L.saccs[d] = acc; L.sblk[d][0] = b0; if constexpr (W > 1) L.sblk[d][1] = b1; if constexpr (W > 2) L.sblk[d][2] = b2;
                 entered = true;
                 continue;
             }
@@ -1942,10 +2034,10 @@ __device__ void select_search(SelectLds& L) {
                 for (int pr = 0; pr < 4; pr++) {
                     const unsigned sl = (slot + pr) & (kMemoSlots - 1);
                     if (L.mstate[sl] == tag) {
-                        if (L.mkey[sl][0] == kk[0] && L.mkey[sl][1] == kk[1] && L.mkey[sl][2] == kk[2]) { L.mval[sl] = best_w - acc; break; }
+                        if (key_eq(sl, kk)) { L.mval[sl] = best_w - acc; break; }
                         continue;
                     }
-                    L.mkey[sl][0] = kk[0]; L.mkey[sl][1] = kk[1]; L.mkey[sl][2] = kk[2]; L.mval[sl] = best_w - acc;
+                    L.mkey[sl][0] = kk[0]; if constexpr (W > 1) L.mkey[sl][1] = kk[1]; if constexpr (W > 2) L.mkey[sl][2] = kk[2]; L.mval[sl] = best_w - acc;
                     L.mstate[sl] = tag;
                     break;
                 }
@@ -2078,6 +2170,24 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
     TW_SEL_TICK(0);
     // span conflict relation: b ~ c iff an eligible candidate of b shares an outgoing span with an eligible
     // candidate of c; one lane per pair
+    // (a lane's chain of dependent LDS reads is what this phase costs: with few pairs the candidates of a pair are spread over
+    // the lanes as well -- a window of four spans has 6 pairs for 64 lanes and up to 25 x E comparisons per pair)
+    if (m * (m - 1) / 2 * kTopK * kTopK <= 4 * nt) {   // one (pair, candidate, candidate) per lane
+        for (int q = t; q < m * m * kTopK * kTopK; q += nt) {
+            const int kb = q % kTopK, ka = (q / kTopK) % kTopK, c = (q / (kTopK * kTopK)) % m, b = q / (kTopK * kTopK * m);
+            if (c >= b || ka >= L.ncand[b] || kb >= L.ncand[c] || !(L.w[b][ka] > 0) || !(L.w[c][kb] > 0)) continue;
+            if (lds_share(L, E, b, ka, c, kb)) { atomicOr(&L.adj[b], 1u << c); atomicOr(&L.adj[c], 1u << b); }
+        }
+    } else if (m * (m - 1) / 2 * kTopK <= 4 * nt) {   // one (pair, candidate) per lane
+        for (int q = t; q < m * m * kTopK; q += nt) {
+            const int ka = q % kTopK, c = (q / kTopK) % m, b = q / (kTopK * m);
+            if (c >= b || ka >= L.ncand[b] || !(L.w[b][ka] > 0)) continue;
+            bool hit = false;
+            for (int kb = 0; kb < L.ncand[c] && !hit; kb++)
+                if (L.w[c][kb] > 0 && lds_share(L, E, b, ka, c, kb)) hit = true;
+            if (hit) { atomicOr(&L.adj[b], 1u << c); atomicOr(&L.adj[c], 1u << b); }
+        }
+    } else
     for (int q = t; q < m * m; q += nt) {
         const int b = q / m, c = q % m;
         if (c >= b) continue;
@@ -2125,7 +2235,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
         if constexpr (LDS::kSearch) {
         {   // conflict masks of the component's candidates (only between members whose candidate lists meet at all)
             const int cm = L.cm;
-            for (int q = t; q < cm * kTopK * kBlkWords; q += nt) (&L.cmask3[0][0][0])[q] = 0;
+            for (int q = t; q < cm * kTopK * LDS::kW; q += nt) (&L.cmask3[0][0][0])[q] = 0;
             group_sync();
             for (int q = t; q < cm * kTopK * cm; q += nt) {
                 const int x = q / (kTopK * cm), k = (q / cm) % kTopK, y = q % cm;
@@ -2193,24 +2303,47 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
 // kBruteMax spans -- nearly all -- on the list of k_select_tiny, the others on the list of k_select_heavy.  There, long windows
 // can take a thousand times longer than short ones: they are listed from the front and served first, the short ones from the
 // back of the same array, so that no long search starts when the kernel is about to drain.
+constexpr int kSelSeg = 32;      // segments of the selection work lists (one counter each)
+constexpr int kCtrStride = 32;   // ints between two counters: a cache line each
+__device__ __forceinline__ int sel_first_tile(int s, int n_tiles) { return (int)(((long long)s * n_tiles + kSelSeg - 1) / kSelSeg); }  // segment s = tiles [this, next)
+__device__ __forceinline__ int32_t* sel_counter(const Dev& P, int list, int s) { return P.heavy_count + (list * kSelSeg + s) * kCtrStride; }
+// (called by the per-span kernels, one workgroup per tile: blockIdx.x is the tile)
 __device__ __forceinline__ void list_window(const Dev& P, const UnitDev& U, int unit, int w, bool listed) {
-    bool big = false, tiny = false;
+    int cls = -1;   // 0 short (<= kBruteMax), 1 long (kBigWindow ..), 2 middle, 3 very long (kHugeWindow ..)
     if (listed) {
         const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
         const int m = P.w_last[U.in_off + w] - first + 1;
-        big = m >= kBigWindow;
-        tiny = m <= kBruteMax;
+        cls = m <= kBruteMax ? 0 : (m < kBigWindow ? 2 : (m < kHugeWindow ? 1 : 3));
     }
-    const int sb = wave_append(&P.heavy_count[1], big), ss = wave_append(&P.heavy_count[2], listed && !big && !tiny);
-    const int st = wave_append(&P.heavy_count[0], tiny);
-    if (tiny) {
-        P.tiny_unit[st] = unit;
-        P.tiny_win[st] = w;
-    } else if (listed) {
-        const int pos = big ? sb : (int)(P.n_in_total / 2) - ss;
-        P.heavy_unit[pos] = unit;
-        P.heavy_win[pos] = w;
+    const int s = (int)((long long)blockIdx.x * kSelSeg / gridDim.x);
+    const int s0 = wave_append(sel_counter(P, 0, s), cls == 0), s1 = wave_append(sel_counter(P, 1, s), cls == 1);
+    const int s2 = wave_append(sel_counter(P, 2, s), cls == 2), s3 = wave_append(sel_counter(P, 3, s), cls == 3);
+    if (!listed) return;
+    const int base = sel_first_tile(s, (int)gridDim.x) * P.tile_spans, end = sel_first_tile(s + 1, (int)gridDim.x) * P.tile_spans;
+    // two arrays, each filled from both ends of the segment: short windows and very long ones share tiny_*, long and middle ones heavy_*
+    // (a segment has room for every window of its tiles)
+    int32_t *au = (cls == 0 || cls == 3) ? P.tiny_unit : P.heavy_unit, *aw = (cls == 0 || cls == 3) ? P.tiny_win : P.heavy_win;
+    const int pos = cls == 0 ? base + s0 : (cls == 1 ? base + s1 : (cls == 2 ? end - 1 - s2 : end - 1 - s3));
+    au[pos] = unit;
+    aw[pos] = w;
+}
+
+// Consumers: the segment counts of one list as prefix sums in LDS (first[kSelSeg] = the list's size), and the position of item i
+struct SelSegs { int first[kSelSeg + 1]; };
+__device__ __forceinline__ void sel_segments(const Dev& P, int list, SelSegs& G) {
+    for (int s = threadIdx.x; s < kSelSeg; s += blockDim.x) G.first[s + 1] = *sel_counter(P, list, s);
+    group_sync();
+    if (threadIdx.x == 0) {
+        G.first[0] = 0;
+        for (int s = 0; s < kSelSeg; s++) G.first[s + 1] += G.first[s];
     }
+    group_sync();
+}
+__device__ __forceinline__ int sel_position(const Dev& P, const SelSegs& G, int item, bool from_back) {
+    int lo = 0, hi = kSelSeg - 1;   // the segment with first[s] <= item < first[s + 1]
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (G.first[mid] <= item) lo = mid; else hi = mid - 1; }
+    const int off = item - G.first[lo];
+    return from_back ? sel_first_tile(lo + 1, P.n_tiles) * P.tile_spans - 1 - off : sel_first_tile(lo, P.n_tiles) * P.tile_spans + off;
 }
 
 // Fast path, one lane per incoming span.  When the best candidates (list position 0) of a window's spans
@@ -2246,11 +2379,17 @@ __global__ void __launch_bounds__(kTile) k_select_fast(Dev P) {
     list_window(P, U, Tl.unit, w, listed);
 }
 
+// LIST 1: the long windows (kBigWindow .. kHugeWindow - 1 spans; front of the segments of heavy_*; two-word masks, 12 KB of LDS),
+// LIST 2: the middle ones (back of those segments; one word, 7 KB: 21 wavefronts per CU), LIST 3: the very long ones (back of the
+// segments of tiny_*; the full layout: 22 KB, 7 wavefronts per CU)
+template <class LDS, int LIST>
 __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent workgroups, one deferred window at a time
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    __shared__ SelectLds L;
+    __shared__ LDS L;
     __shared__ int next_item;
-    const int n_big = P.heavy_count[1], count = n_big + P.heavy_count[2];
+    __shared__ SelSegs G;
+    sel_segments(P, LIST, G);
+    const int count = G.first[kSelSeg];
     if ((int)blockIdx.x >= count) return;   // nothing for this workgroup (the usual case outside heavy load)
     for (int q = threadIdx.x; q < kMemoSlots; q += blockDim.x) L.mstate[q] = 0u;
     if (threadIdx.x == 0) L.memo_gen = 0u;
@@ -2263,7 +2402,7 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
                                        // the first chunk of a workgroup is its own (no same-address atomic storm at kernel start)
             if (first_chunk) { chunk_pos = (int)blockIdx.x * kWorkChunk; first_chunk = false; }
             else {
-                if (threadIdx.x == 0) next_item = (int)gridDim.x * kWorkChunk + atomicAdd(P.heavy_next, kWorkChunk);
+                if (threadIdx.x == 0) next_item = (int)gridDim.x * kWorkChunk + atomicAdd(&P.heavy_next[LIST], kWorkChunk);
                 group_sync();
                 chunk_pos = next_item;
                 group_sync();
@@ -2279,8 +2418,9 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
             if (item < nstatic) item = (item % kWorkChunk) * (int)gridDim.x + item / kWorkChunk;
             if (item >= count) continue;
         }
-        const int pos = item < n_big ? item : (int)(P.n_in_total / 2) - (item - n_big);
-        const int unit = __builtin_amdgcn_readfirstlane(P.heavy_unit[pos]), w = __builtin_amdgcn_readfirstlane(P.heavy_win[pos]);  // wave-uniform: scalar loads below
+        const int pos = sel_position(P, G, item, LIST != 1);
+        const int32_t *au = LIST == 3 ? P.tiny_unit : P.heavy_unit, *aw = LIST == 3 ? P.tiny_win : P.heavy_win;
+        const int unit = __builtin_amdgcn_readfirstlane(au[pos]), w = __builtin_amdgcn_readfirstlane(aw[pos]);  // wave-uniform: scalar loads below
         const UnitDev& U = P.units[unit];
         const int last = P.w_last[U.in_off + w];
         const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
@@ -2305,13 +2445,15 @@ __global__ void __launch_bounds__(64) k_select_tiny(Dev P) {  // persistent work
     if (*P.err != 0) return;
     __shared__ SelectLdsTiny L;
     __shared__ int next_item;
-    const int count = P.heavy_count[0];
+    __shared__ SelSegs G;
+    sel_segments(P, 0, G);
+    const int count = G.first[kSelSeg];
     if ((int)blockIdx.x * kWorkChunk >= count) return;
     int chunk_pos = (int)blockIdx.x * kWorkChunk, chunk_end = chunk_pos + kWorkChunk;   // the first chunk of a workgroup is its own
     TW_SEL_DECL();
     while (true) {
         if (chunk_pos == chunk_end) {
-            if (threadIdx.x == 0) next_item = (int)gridDim.x * kWorkChunk + atomicAdd(&P.heavy_count[3], kWorkChunk);
+            if (threadIdx.x == 0) next_item = (int)gridDim.x * kWorkChunk + atomicAdd(&P.heavy_next[0], kWorkChunk);
             group_sync();
             chunk_pos = next_item;
             group_sync();
@@ -2319,7 +2461,8 @@ __global__ void __launch_bounds__(64) k_select_tiny(Dev P) {  // persistent work
         }
         if (chunk_pos >= count) { TW_SEL_FLUSH(); break; }
         const int item = chunk_pos++;
-        const int unit = __builtin_amdgcn_readfirstlane(P.tiny_unit[item]), w = __builtin_amdgcn_readfirstlane(P.tiny_win[item]);
+        const int pos = sel_position(P, G, item, false);
+        const int unit = __builtin_amdgcn_readfirstlane(P.tiny_unit[pos]), w = __builtin_amdgcn_readfirstlane(P.tiny_win[pos]);
         const UnitDev& U = P.units[unit];
         const int last = P.w_last[U.in_off + w];
         const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
