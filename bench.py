@@ -99,21 +99,25 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def fit_mixtures(eng, mode):
+def fit_mixtures(eng, mode, unit_ids=None, seed=0):
+    """The refit between the passes.  "device": the reference's procedure on the GPU (csrc/tw_fit.h), every unit drawing its
+    k-means++ seeds from an MT19937 stream of its own (seed + global unit id), so that a unit's result does not depend on
+    which units share its GPU; "sklearn": scikit-learn on the host (cross-check)."""
     from traceweaver_amd import gmm
 
     if mode == "device":
-        eng.fit_mixtures()
+        ids = range(len(eng.units)) if unit_ids is None else unit_ids
+        eng.fit_mixtures(unit_seeds=[seed + int(k) for k in ids])
         return
     gaps = eng.gaps()
     fitted = [gmm.fit_unit(g) for g in gaps]
     eng.set_mixtures([f[0] for f in fitted], [f[1] for f in fitted])
 
 
-def one_step(eng, mode):
+def one_step(eng, mode, unit_ids=None):
     eng.run_pass1()
     t1 = eng.timing()
-    fit_mixtures(eng, mode)
+    fit_mixtures(eng, mode, unit_ids)
     eng.run_pass2()
     t2 = eng.timing()
     res = eng.evaluate()  # accuracy vs ground truth as a device reduction (helpers/utils.py:62-97); parents stay in HBM
@@ -403,7 +407,7 @@ def main():
             t2["fit"] = fit_eng.timing()["fit"]
             res = eng.evaluate()
         else:
-            t1, t2, res = one_step(eng, args.fit)
+            t1, t2, res = one_step(eng, args.fit, mine)
         gathered = None
         if strong:  # the exchange step of the sharded slice: parents of every service on every rank
             local = [r["parent"] for r in eng.results(2, fields=("parent",))]

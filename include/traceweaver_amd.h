@@ -55,9 +55,12 @@ typedef enum {
                               /* aborts in the solver (SURVEY.md hazard H3)                          */
     TW_ERR_SKIP_PARAMS = -8,  /* skip mode: the scorer needs a (mean, std) pair BuildDistributions   */
                               /* did not produce (KeyError in the reference, traceweaver_v1.py:118)  */
-    TW_ERR_SKIP_REFERENCE_RAISES = -9 /* skip mode: the reference raises on this input (a tuple that */
+    TW_ERR_SKIP_REFERENCE_RAISES = -9, /* skip mode: the reference raises on this input (a tuple that */
                               /* skips every endpoint, hazard H7; a score tie whose comparison       */
                               /* reaches a skip span; a skipped predecessor without a called one)    */
+    TW_ERR_FIT = -10          /* refit: every model-selection fit of an edge raised in scikit-learn  */
+                              /* (covariance <= 0), so the reference's np.argmin([]) raises too      */
+                              /* (traceweaver_v3.py:777-780)                                         */
 } tw_status;
 
 typedef struct tw_engine tw_engine;
@@ -132,7 +135,8 @@ int tw_get_gaps(tw_engine *e, double *gaps);
  * pass 1 -- a service whose requests were solved in parts (on several GPUs) is refitted on the union of the parts'
  * samples, exactly as the reference fits one mixture per edge over the whole service (traceweaver_v3.py:1221-1222):
  * load a unit of the service's shape, hand over the gathered rows, tw_fit_mixtures, tw_get_mixtures
- * (traceweaver_amd/sharding.py).  The fit depends only on the multiset of samples of a row. */
+ * (traceweaver_amd/sharding.py).  The fit depends on the samples of a row *in request order* (k-means++ seeding): parts that are
+ * consecutive stretches of the service's requests are concatenated in that order. */
 int tw_set_gaps(tw_engine *e, const double *gaps);
 
 /* Mixtures for pass 2 (the fitted sklearn GaussianMixture objects of traceweaver_v3.py:784-786):
@@ -140,13 +144,28 @@ int tw_set_gaps(tw_engine *e, const double *gaps);
  * mix_p[sum_u nslot_u][TW_MAX_COMP][3] = weight, mean, precision_cholesky. */
 int tw_set_mixtures(tw_engine *e, const int32_t *mix_n, const double *mix_p);
 
-/* Device-side alternative to tw_get_gaps + host fit + tw_set_mixtures: refits every scored edge on the
- * GPU from the pass-1 gap samples (ComputeEpPairDistParams5, traceweaver_v3.py:764-786): 1..min(5,
- * #unique) component 1-D mixtures by EM (tol 1e-3, <= 100 iterations, reg_covar 1e-6 as scikit-learn's
- * defaults), smallest BIC wins.  The reference's k-means++ start drawn from an unseeded global RNG
- * (not reproducible, SURVEY.md hazard H9) is replaced by a deterministic start from the equal-count
- * buckets of the sorted samples; see traceweaver_amd/csrc/tw_fit.h. */
+/* Device-side alternative to tw_get_gaps + host fit + tw_set_mixtures: the reference's refit of every scored edge
+ * (ComputeEpPairDistParams5, traceweaver_v3.py:764-786) on the GPU, from the pass-1 gap samples: for n = 1..min(5, #unique)
+ * `GaussianMixture(n, covariance_type="diag").fit` -- k-means++ seeding on the samples in request order, Lloyd, EM (tol 1e-3,
+ * <= 100 iterations, reg_covar 1e-6) --, the n of smallest BIC among the fits that did not raise, then the full-covariance
+ * refit with `random_state=100`; see traceweaver_amd/csrc/tw_fit.h.  The only randomness are the uniforms the k-means++
+ * seeding draws: 1, 3, 7, 10, 13 doubles for n = 1..5, n after n per edge (TW_FIT_ROW_TAPE = 34 for a row with >= 5 distinct
+ * samples), independent of the data.
+ *
+ * tw_fit_mixtures draws them from the engine's own MT19937 (numpy's RandomState algorithm; tw_set_fit_seed reseeds it,
+ * tw_create seeds it with 0; one 34-double block per slot and call): the reference's procedure on *a* random stream, as
+ * the reference itself runs it unseeded (SURVEY.md hazard H9).  tw_fit_mixtures_seeded gives every unit a stream of its own,
+ * MT19937(unit_seed[u]): a unit's fit is then the same whichever units share its batch (services sharded over GPUs).
+ * tw_fit_mixtures_tape takes them from the caller: slot q reads tape[slot_off[q] ...], as many doubles as its fits draw
+ * (tw_fit_rows tells: max_n[q] = min(5, #unique) of the row, 0 for a row without samples or an unscored slot; the fits of
+ * a row draw 1, 4, 11, 21, 34 doubles for max_n = 1..5).  Handing over the doubles numpy's global RNG produces at that point
+ * of a seeded reference run makes the refit the one of that run (traceweaver_amd/predictor.py). */
+#define TW_FIT_ROW_TAPE 34
 int tw_fit_mixtures(tw_engine *e);
+int tw_fit_mixtures_seeded(tw_engine *e, const uint32_t *unit_seed);
+int tw_set_fit_seed(tw_engine *e, uint32_t seed);
+int tw_fit_rows(tw_engine *e, int32_t *max_n);
+int tw_fit_mixtures_tape(tw_engine *e, const double *tape, int64_t tape_len, const int64_t *slot_off);
 
 /* The mixture tables currently resident (layout of tw_set_mixtures). */
 int tw_get_mixtures(tw_engine *e, int32_t *mix_n, double *mix_p);

@@ -188,6 +188,7 @@ inline unsigned long long __ballot(int pred) {
 }
 template <class T> inline T __shfl(T v, int src) { return emu_wave ? emu_exchange(v, [&](unsigned long long) { return src; }) : v; }
 template <class T> inline T __shfl_down(T v, int off) { return emu_wave ? emu_exchange(v, [&](unsigned long long) { return emu_lane + off; }) : v; }
+template <class T> inline T __shfl_up(T v, int off) { return emu_wave ? emu_exchange(v, [&](unsigned long long) { return emu_lane - off; }) : v; }
 template <class T> inline T __shfl_xor(T v, int m) { return emu_wave ? emu_exchange(v, [&](unsigned long long) { return emu_lane ^ m; }) : v; }
 inline int __builtin_amdgcn_readfirstlane(int v) {
     return emu_wave ? emu_exchange(v, [&](unsigned long long live) { return __builtin_ffsll((long long)live) - 1; }) : v;

@@ -245,7 +245,7 @@ def test_one_service_split_over_two_ranks_equals_the_unsplit_run(emu_lib):
     eng.load(units)
     eng.run_pass1()
     want1 = [r["parent"] for r in eng.results(1, fields=("parent",))]
-    eng.fit_mixtures()
+    eng.fit_mixtures(unit_seeds=[0, 1])     # refit_split_services: service s draws from MT19937(seed + s)
     eng.run_pass2()
     want2 = [r["parent"] for r in eng.results(2, fields=("parent",))]
     eng.close()

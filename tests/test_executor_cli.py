@@ -1,7 +1,8 @@
 """The reference's command line (executor.py:38-74) on the native chain: JSON directory -> ingest -> both passes ->
 accuracy -> the reference's result files.  CPU tier through the host-emulation build; the figures are compared
-with the frozen reference run of the same corpus (accuracy within the reference's own run-to-run spread, the
-pass-independent parts exactly)."""
+with the frozen reference run of the same corpus: the default refit (`--fit device --seed 10`) is the reference's
+procedure on the reference's RNG stream, so the run reproduces the frozen run (np.random.seed(10)) -- per service to
+the few requests whose window optimum is not unique, end to end to 0.25 pp."""
 import os
 import pickle
 
@@ -37,9 +38,9 @@ def test_hotel_run_matches_the_frozen_reference_run(emu_lib, tmp_path):
     for svc, (acc, not_best, n) in got["confidence_scores"].items():
         g = gold[svc]
         ref_acc = float(np.all(g["final_parent"] == g["true_parent"], axis=0).mean())
-        assert n == len(g["in_start"]) and abs(acc - ref_acc) < 0.015 and abs(not_best - int(g["not_best_count"])) <= 15
+        assert n == len(g["in_start"]) and abs(acc - ref_acc) <= 4.0 / n and abs(not_best - int(g["not_best_count"])) <= 4
     ref_e2e = float(gold["frontend"]["e2e_accuracy"])
-    assert abs(got["accuracy"][method] - ref_e2e) < 1.5 and got["accuracy"][method + "TopK"] >= got["accuracy"][method]
+    assert abs(got["accuracy"][method] - ref_e2e) <= 0.25 and got["accuracy"][method + "TopK"] >= got["accuracy"][method]
     assert [p for p, _, _ in got["bin_acc"][method]] == [10.0 * (b + 1) for b in range(10)]
     true_traces, pred_traces = got["e2e"][method]
     assert len(true_traces) == len(pred_traces) == 1000
@@ -59,9 +60,9 @@ def test_corpora_that_need_span_surgery(emu_lib, tmp_path, name, rel, fix, n_ser
     for svc, (acc, not_best, n) in got["confidence_scores"].items():
         g = gold[svc]
         ref_acc = float(np.all(g["final_parent"] == g["true_parent"], axis=0).mean())
-        assert n == len(g["in_start"]) and abs(acc - ref_acc) < 0.03, (svc, acc, ref_acc)
+        assert n == len(g["in_start"]) and abs(acc - ref_acc) <= 4.0 / n, (svc, acc, ref_acc)
     ref_e2e = float(next(iter(gold.values()))["e2e_accuracy"])
-    assert abs(got["accuracy"]["MaxScoreBatchSubsetWithSkips"] - ref_e2e) < 3.0
+    assert abs(got["accuracy"]["MaxScoreBatchSubsetWithSkips"] - ref_e2e) <= 0.25
 
 
 def _all_corpora():
@@ -75,8 +76,9 @@ def test_end_to_end_accuracy_tracks_the_reference_on_every_corpus(emu_lib, tmp_p
     got = run_cli(tmp_path, emu_lib, "data/" + rel + "/", fix, name)
     g = np.load([p for p in GOLDEN if "ref_%s__" % name in p][0])
     method = "MaxScoreBatchSubsetWithSkips"
-    assert abs(got["accuracy"][method] - float(g["e2e_accuracy"])) < 3.5
-    assert abs(got["accuracy"][method + "TopK"] - float(g["e2e_topk_accuracy"])) < 1.5
+    assert int(g["seed"]) == 10   # run_cli's default --seed
+    assert abs(got["accuracy"][method] - float(g["e2e_accuracy"])) <= 0.25
+    assert abs(got["accuracy"][method + "TopK"] - float(g["e2e_topk_accuracy"])) <= 0.1
 
 
 @pytest.mark.skipif(not os.path.isdir(REF + "/data"), reason="the reference's data directory is not present")
@@ -84,10 +86,10 @@ def test_end_to_end_accuracy_tracks_the_reference_on_every_corpus(emu_lib, tmp_p
                                                                                 "nodeio_0.2", "nodeio_1")],
                          ids=["hotel_load100", "hotel_load150", "media_load100", "node_load150", "nodeio_0.2", "nodeio_1"])
 def test_fit_sklearn_reproduces_the_seeded_reference_run(emu_lib, tmp_path, name, rel, fix):
-    """--fit sklearn --seed 10: the reference's own refit with its RNG stream replayed service by service -- the command
-    line then reproduces the frozen reference run (np.random.seed(10)) of the corpus: per-service accuracy to within the
-    few requests whose window optimum is not unique, end-to-end accuracy to +-0.25 pp (SURVEY.md hazard H9; with the
-    deterministic device refit the figures differ by up to a few pp, as the reference's own do between seeds)."""
+    """--fit sklearn --seed 10 (the cross-check of the default): scikit-learn itself on the host where the device refit
+    runs otherwise, the RNG stream replayed service by service -- the command line reproduces the frozen reference run
+    (np.random.seed(10)) of the corpus: per-service accuracy to within the few requests whose window optimum is not unique,
+    end-to-end accuracy to +-0.25 pp (SURVEY.md hazard H9)."""
     from traceweaver_amd import executor
 
     out = str(tmp_path) + "/"
@@ -116,12 +118,14 @@ def _band():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF + "/data"), reason="the reference's data directory is not present")
-@pytest.mark.parametrize("name,seed_pos", [("hotel_load100", 3), ("nodeio_1", 2), ("nodeio_1", 1), ("node_load150", 3), ("media_load125", 4)])
+@pytest.mark.parametrize("name,seed_pos", [("hotel_load100", 3), ("nodeio_1", 2), ("nodeio_1", 1), ("node_load150", 3), ("media_load125", 4),
+                                           ("media_load150", 0), ("media_load150", 3)])
 def test_seeded_runs_sit_in_the_references_multi_seed_band(emu_lib, tmp_path, name, seed_pos):
     """tests/golden/ref_accuracy_band.json holds the end-to-end accuracy of the unmodified reference for five values of
     np.random.seed per corpus (oracle/refrun/gen_golden.py --band): its refit draws from the global RNG (hazard H9), so its
     own figure moves by up to 4 pp between seeds.  The command line with the same seed lands on the same figure (the
-    extremes of the band included); the deterministic device refit lands within 2 pp of the band."""
+    extremes of the band included) -- with the device refit (default) and with scikit-learn on the host.  The batched mode
+    draws from another stream (the engine's MT19937, one block per slot): one more sample of the same spread."""
     band = _band()[name]
     rel, fix = next((c[1], c[2]) for c in _all_corpora() if c[0] == name)
     from traceweaver_amd import executor
@@ -136,12 +140,14 @@ def test_seeded_runs_sit_in_the_references_multi_seed_band(emu_lib, tmp_path, na
         return pickle.load(open(out + "accuracy_%s_100_1_1_0.0.pickle" % name, "rb"))
 
     method = "MaxScoreBatchSubsetWithSkips"
-    acc = run("sklearn", band["seeds"][seed_pos])
-    assert abs(acc[method] - band["e2e"][seed_pos]) <= 0.25
-    assert abs(acc[method + "TopK"] - band["e2e_topk"][seed_pos]) <= 0.25
+    for fit in ("device", "sklearn") if seed_pos in (1, 3) else ("device",):
+        acc = run(fit, band["seeds"][seed_pos])
+        assert abs(acc[method] - band["e2e"][seed_pos]) <= 0.25, fit
+        assert abs(acc[method + "TopK"] - band["e2e_topk"][seed_pos]) <= 0.25, fit
     if seed_pos == 3:
-        dev = run("device", 0)
-        assert min(band["e2e"]) - 2.0 <= dev[method] <= max(band["e2e"]) + 2.0
+        spread = max(band["e2e"]) - min(band["e2e"])
+        dev = run("device-batch", 0)
+        assert min(band["e2e"]) - max(spread, 0.5) <= dev[method] <= max(band["e2e"]) + max(spread, 0.5)
 
 
 def test_unsupported_settings_are_refused(emu_lib, tmp_path):

@@ -49,12 +49,12 @@ def protocol_inputs(d):
     return {str(d["in_ep"]): in_spans}, parts, g, truth, out_eps
 
 
-def run_frontend_case(lib_path):
+def run_frontend_case(lib_path, fit="device"):
     from traceweaver_amd.predictor import TraceWeaverGPU
 
     d = np.load([f for f in GOLDEN if "hotel_load100__frontend" in f][0])
     in_parts, out_parts, graph, truth, out_eps = protocol_inputs(d)
-    pred = TraceWeaverGPU({}, {}, fit="sklearn", lib_path=lib_path)
+    pred = TraceWeaverGPU({}, {}, fit=fit, lib_path=lib_path)
     np.random.seed(int(d["seed"]))  # executor.py seeds through create_cache_hits (transforms.py:155) for "frontend"
     ret = pred.FindAssignments("MaxScoreBatchSubsetWithSkips", "frontend", in_parts, out_parts, False, [], truth, graph)
     all_asg, all_topk, not_best, n_in, per_span, unassigned = ret
@@ -73,15 +73,19 @@ def run_frontend_case(lib_path):
     return pred
 
 
-def test_end_to_end_reproduces_frozen_reference_run(emu_lib):
-    run_frontend_case(emu_lib)
+@pytest.mark.parametrize("fit", ["device", "sklearn"])
+def test_end_to_end_reproduces_frozen_reference_run(emu_lib, fit):
+    """The refit between the passes on the device (the reference's procedure fed numpy's draws) and, as the cross-check,
+    with scikit-learn itself on the host: either way the 6-tuple of the frozen reference run."""
+    run_frontend_case(emu_lib, fit)
 
 
-def test_second_service_of_a_seeded_run(emu_lib):
+@pytest.mark.parametrize("fit", ["device", "sklearn"])
+def test_second_service_of_a_seeded_run(emu_lib, fit):
     """One predictor instance, one seed, two services in the executor's order: the second service starts from the RNG
     state the first one left behind -- which includes the discarded fits the reference runs after its second pass
     (traceweaver_v3.py:1221-1222) -- and must still reproduce the frozen reference run."""
-    pred = run_frontend_case(emu_lib)
+    pred = run_frontend_case(emu_lib, fit)
     d = np.load([f for f in GOLDEN if "hotel_load100__search" in f][0])
     in_parts, out_parts, graph, truth, out_eps = protocol_inputs(d)
     ret = pred.FindAssignments("MaxScoreBatchSubsetWithSkips", "search", in_parts, out_parts, False, [], truth, graph)
@@ -126,13 +130,14 @@ def test_skip_mode_behind_the_protocol(emu_lib):
     assert abs(ok - float(np.all(d["final_parent"] == d["true_parent"], axis=0).mean())) <= 0.005
 
 
-def test_device_refit_mode(emu_lib):
-    """fit="device": same protocol, deterministic EM on the device between the passes."""
+def test_unseeded_run(emu_lib):
+    """Without a seed the draws are whatever numpy's global RNG holds, like in the reference: still the same procedure."""
     from traceweaver_amd.predictor import TraceWeaverGPU
 
     d = np.load([f for f in GOLDEN if "hotel_load100__search" in f][0])
     in_parts, out_parts, graph, truth, out_eps = protocol_inputs(d)
-    ret = TraceWeaverGPU({}, {}, fit="device", lib_path=emu_lib).FindAssignments(
+    np.random.seed(None)
+    ret = TraceWeaverGPU({}, {}, fit="device", replay_true_fit=False, lib_path=emu_lib).FindAssignments(
         "MaxScoreBatchSubsetWithSkips", "search", in_parts, out_parts, False, [], truth, graph)
     in_spans = list(in_parts.values())[0]
     ok = sum(all(ret[0][ep][s.GetId()] == truth[ep][s.GetId()] for ep in out_eps) for s in in_spans)

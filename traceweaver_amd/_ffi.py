@@ -59,7 +59,7 @@ class Results(ctypes.Structure):
 
 
 EXPORTS = ["tw_create", "tw_destroy", "tw_last_error", "tw_load_batch", "tw_run_pass1", "tw_get_gaps", "tw_set_gaps",
-           "tw_set_mixtures", "tw_fit_mixtures", "tw_get_mixtures", "tw_run_pass2", "tw_get_results", "tw_get_gauss_params", "tw_get_timing",
+           "tw_set_mixtures", "tw_fit_mixtures", "tw_fit_mixtures_seeded", "tw_set_fit_seed", "tw_fit_rows", "tw_fit_mixtures_tape", "tw_get_mixtures", "tw_run_pass2", "tw_get_results", "tw_get_gauss_params", "tw_get_timing",
            "tw_assign_service", "tw_find_order", "tw_set_truth", "tw_evaluate", "tw_measure_hbm_copy", "tw_host_alloc", "tw_host_free", "tw_build_distributions", "tw_scale_load",
            "tw_corpus_create", "tw_corpus_destroy", "tw_corpus_last_error", "tw_corpus_add_files", "tw_corpus_set_callers", "tw_corpus_counts",
            "tw_corpus_string", "tw_corpus_loop_origin", "tw_corpus_trace_names", "tw_corpus_span_table", "tw_corpus_build_units"]
@@ -86,6 +86,10 @@ def load(path=None):
     lib.tw_set_mixtures.argtypes = [vp, vp, vp]
     lib.tw_run_pass2.argtypes = [vp]
     lib.tw_fit_mixtures.argtypes = [vp]
+    lib.tw_fit_mixtures_seeded.argtypes = [vp, vp]
+    lib.tw_set_fit_seed.argtypes = [vp, ctypes.c_uint32]
+    lib.tw_fit_rows.argtypes = [vp, vp]
+    lib.tw_fit_mixtures_tape.argtypes = [vp, vp, ctypes.c_int64, vp]
     lib.tw_get_mixtures.argtypes = [vp, vp, vp]
     lib.tw_get_results.argtypes = [vp, ctypes.c_int, ctypes.POINTER(Results)]
     lib.tw_get_gauss_params.argtypes = [vp, vp]

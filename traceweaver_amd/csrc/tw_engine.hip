@@ -34,6 +34,37 @@ int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// MT19937 as numpy's RandomState runs it (the published reference algorithm of Matsumoto & Nishimura; seeding of an integer
+// seed = init_genrand, `random_sample` = (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53): `Mt19937(s).random_sample()` yields the
+// doubles of `np.random.RandomState(s).random_sample()`.  Used for the k-means++ draws of the mixture refit (tw_fit.h).
+struct Mt19937 {
+    uint32_t mt[624];
+    int idx = 624;
+    explicit Mt19937(uint32_t seed = 0u) {
+        mt[0] = seed;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; i++) {
+                const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+                mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    double random_sample() {
+        const uint32_t a = next() >> 5, b = next() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+};
+
 }  // namespace
 
 struct tw_engine {
@@ -71,6 +102,12 @@ struct tw_engine {
     double* fit_models = nullptr;
     double* fit_uval = nullptr;
     int32_t *fit_ustart = nullptr, *fit_row_n = nullptr, *fit_row_uniq = nullptr;
+    double *fit_tape = nullptr, *fit_tape100 = nullptr;   // uniforms of the k-means++ seedings: model-selection fits / the refit (MT19937(100))
+    int64_t* fit_tape_off = nullptr;
+    int64_t fit_tape_cap = 0;
+    bool fit_prepared = false;              // the gap rows of the resident pass-1 result are sorted and run-length compressed
+    std::vector<int32_t> fit_max_n;         // per slot min(5, #unique), 0 = nothing to fit (host copy, tw_fit_rows)
+    Mt19937 fit_rng;                        // stream of tw_fit_mixtures (tw_set_fit_seed)
     int32_t* slot_unit = nullptr;
     int32_t* tile_ids = nullptr;            // tiles grouped by the unit's endpoint count
     int32_t tile_cls_off[kMaxEp + 2] = {};  // class E owns tile_ids[tile_cls_off[E] .. tile_cls_off[E+1])
@@ -839,6 +876,8 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
     ALLOC(e->gaps_sorted, gaps); ALLOC(e->fit_models, slots * kMaxComp * kModelStride);
     ALLOC(e->fit_uval, gaps); ALLOC(e->fit_ustart, gaps); ALLOC(e->fit_row_n, slots); ALLOC(e->fit_row_uniq, slots);
+    ALLOC(e->fit_tape, slots * kFitRowTape); ALLOC(e->fit_tape_off, slots); ALLOC(e->fit_tape100, kMaxComp * 13);
+    e->fit_tape_cap = slots * kFitRowTape;
     ALLOC(e->slot_unit, slots); ALLOC(e->slot_scored, slots);
     ALLOC(e->seg_gap, (int64_t)seg_gap_h.size()); ALLOC(e->seg_gap_end, (int64_t)seg_gap_end_h.size()); ALLOC(e->seg_gap_dst, (int64_t)seg_gap_dst_h.size());
     e->comp_cap = std::max(std::max(n_in_total, n_out_total), e->n_gap_scored);
@@ -931,6 +970,7 @@ int tw_run_pass1(tw_engine* e) {
     if (e->state < ST_LOADED) return fail(e, TW_ERR_STATE, "tw_run_pass1 before tw_load_batch");
     HIPCHK(hipSetDevice(e->device));
     const int rc = run_pass(e, 1);
+    e->fit_prepared = false;
     if (rc == TW_OK) e->state = ST_PASS1;
     return rc;
 }
@@ -952,6 +992,7 @@ int tw_set_gaps(tw_engine* e, const double* gaps) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->P.gaps, gaps, sizeof(double) * e->n_gaps, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    e->fit_prepared = false;
     e->state = ST_PASS1;
     return TW_OK;
 }
@@ -973,12 +1014,20 @@ int tw_set_mixtures(tw_engine* e, const int32_t* mix_n, const double* mix_p) {
     return TW_OK;
 }
 
-int tw_fit_mixtures(tw_engine* e) {
-    if (e == nullptr) return TW_ERR_ARG;
-    if (e->state != ST_PASS1) return fail(e, TW_ERR_STATE, "tw_fit_mixtures is valid right after tw_run_pass1");
-    if (e->skip_mode) return fail(e, TW_ERR_STATE, "a skip-mode batch runs one pass (traceweaver_v3.py:1155-1156): there is no refit");
-    HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
+namespace {
+
+FitDev fit_dev(tw_engine* e) {
+    FitDev F{};
+    F.units = e->P.units; F.n_units = e->P.n_units; F.n_slots = e->n_slots; F.gaps = e->P.gaps; F.sorted = e->gaps_sorted;
+    F.gs_off = e->P.gs_off; F.slot_unit = e->slot_unit; F.slot_scored = e->slot_scored; F.models = e->fit_models; F.mix_n = e->mix_n_dev; F.mix_p = e->mix_p_dev;
+    F.uval = e->fit_uval; F.ustart = e->fit_ustart; F.row_n = e->fit_row_n; F.row_uniq = e->fit_row_uniq;
+    F.tape = e->fit_tape; F.tape_off = e->fit_tape_off; F.tape100 = e->fit_tape100; F.err = e->P.err;
+    return F;
+}
+
+// Sorts every scored gap row and turns it into (value, multiplicity) runs; idempotent per pass-1 result.
+int fit_prepare(tw_engine* e) {
+    if (e->fit_prepared) return TW_OK;
     size_t bytes = 0;
     const unsigned size = (unsigned)e->n_gaps, nseg = (unsigned)e->n_gap_rows;
     // gap samples are non-negative integers (and NaN = 0x7ff8...0) stored as doubles: their low mantissa bits
@@ -1001,24 +1050,138 @@ int tw_fit_mixtures(tw_engine* e) {
                             e->seg_gap_dst, (int)nseg, e->n_gap_scored, begin_bit, 64, 0ull);
         if (rcs != TW_OK) return rcs;
     }
-    FitDev F{};
-    F.units = e->P.units; F.n_units = e->P.n_units; F.n_slots = e->n_slots; F.sorted = e->gaps_sorted;
-    F.gs_off = e->P.gs_off; F.slot_unit = e->slot_unit; F.slot_scored = e->slot_scored; F.models = e->fit_models; F.mix_n = e->mix_n_dev; F.mix_p = e->mix_p_dev;
-    F.uval = e->fit_uval; F.ustart = e->fit_ustart; F.row_n = e->fit_row_n; F.row_uniq = e->fit_row_uniq;
+    FitDev F = fit_dev(e);
     hipLaunchKernelGGL(k_fit_compress, dim3((unsigned)e->n_slots), dim3(e->coop), 0, e->stream, F);
-    hipLaunchKernelGGL(k_fit_em, dim3((unsigned)(e->n_slots * kMaxComp)), dim3(e->coop >= 64 ? kFitThreads : e->coop), 0, e->stream, F);
+    HIPCHK(hipGetLastError());
+    e->fit_prepared = true;
+    return TW_OK;
+}
+
+// The fits themselves; the tape and the slots' offsets are resident in e->fit_tape / e->fit_tape_off.
+int fit_run(tw_engine* e) {
+    static const std::vector<double> tape100 = [] {   // GaussianMixture(n, random_state=100): a fresh MT19937(100) per fit
+        std::vector<double> t((size_t)kMaxComp * 13, 0.0);
+        for (int k = 1; k <= kMaxComp; k++) {
+            Mt19937 r(100u);
+            for (int j = 0; j < fit_draws(k); j++) t[(size_t)(k - 1) * 13 + j] = r.random_sample();
+        }
+        return t;
+    }();
+    HIPCHK(hipMemcpyAsync(e->fit_tape100, tape100.data(), sizeof(double) * tape100.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->P.err, 0, sizeof(int32_t), e->stream));
+    FitDev F = fit_dev(e);
+    const int threads = e->coop >= 64 ? kFitThreads : e->coop;
+    hipLaunchKernelGGL(k_fit_gmm<false>, dim3((unsigned)(e->n_slots * kMaxComp)), dim3(threads), 0, e->stream, F);
     hipLaunchKernelGGL(k_fit_select, dim3((unsigned)((e->n_slots + 63) / 64)), dim3(64), 0, e->stream, F);
+    hipLaunchKernelGGL(k_fit_gmm<true>, dim3((unsigned)e->n_slots), dim3(threads), 0, e->stream, F);
     const int64_t total = e->n_slots * kMaxComp;
     hipLaunchKernelGGL(k_mix_consts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, (const double*)e->mix_p_dev, (const int32_t*)e->mix_n_dev, (const int32_t*)e->slot_unit, e->P.units, e->mix_c_dev, total);
     HIPCHK(hipEventRecord(e->ev[EV_END], e->stream));
     HIPCHK(hipGetLastError());
+    int32_t kerr = 0;
+    HIPCHK(hipMemcpyAsync(&kerr, e->P.err, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     float f = 0.f;
     HIPCHK(hipEventElapsedTime(&f, e->ev[EV_BEGIN], e->ev[EV_END]));
     e->fit_ms = f;
+    if (kerr != 0)
+        return fail(e, kerr, "refit: every model-selection fit of an edge ended in a covariance <= 0 (scikit-learn's ValueError); the reference "
+                             "raises there as well (np.argmin of an empty list, traceweaver_v3.py:777-780)");
     e->state = ST_MIX;
     return TW_OK;
 }
+
+int fit_check_state(tw_engine* e, const char* who) {
+    if (e->state != ST_PASS1) return fail(e, TW_ERR_STATE, std::string(who) + " is valid right after tw_run_pass1");
+    if (e->skip_mode) return fail(e, TW_ERR_STATE, "a skip-mode batch runs one pass (traceweaver_v3.py:1155-1156): there is no refit");
+    return TW_OK;
+}
+
+}  // namespace
+
+int tw_set_fit_seed(tw_engine* e, uint32_t seed) {
+    if (e == nullptr) return TW_ERR_ARG;
+    e->fit_rng = Mt19937(seed);
+    return TW_OK;
+}
+
+int tw_fit_rows(tw_engine* e, int32_t* max_n) {
+    if (e == nullptr || max_n == nullptr) return TW_ERR_ARG;
+    int rc = fit_check_state(e, "tw_fit_rows");
+    if (rc != TW_OK) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    rc = fit_prepare(e);
+    if (rc != TW_OK) return rc;
+    std::vector<int32_t> uniq((size_t)e->n_slots);
+    HIPCHK(hipMemcpyAsync(uniq.data(), e->fit_row_uniq, sizeof(int32_t) * e->n_slots, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->fit_max_n.assign((size_t)e->n_slots, 0);
+    for (int64_t q = 0; q < e->n_slots; q++) max_n[q] = e->fit_max_n[(size_t)q] = std::min<int32_t>(uniq[(size_t)q], kMaxComp);
+    return TW_OK;
+}
+
+int tw_fit_mixtures_tape(tw_engine* e, const double* tape, int64_t tape_len, const int64_t* slot_off) {
+    if (e == nullptr || tape == nullptr || slot_off == nullptr || tape_len < 0) return TW_ERR_ARG;
+    int rc = fit_check_state(e, "tw_fit_mixtures_tape");
+    if (rc != TW_OK) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->fit_prepared || e->fit_max_n.size() != (size_t)e->n_slots) {
+        std::vector<int32_t> tmp((size_t)e->n_slots);
+        rc = tw_fit_rows(e, tmp.data());
+        if (rc != TW_OK) return rc;
+    }
+    static const int need[kMaxComp + 1] = {0, 1, 4, 11, 21, 34};
+    for (int64_t q = 0; q < e->n_slots; q++) {
+        const int m = e->fit_max_n[(size_t)q];
+        if (m > 0 && (slot_off[q] < 0 || slot_off[q] + need[m] > tape_len))
+            return fail(e, TW_ERR_ARG, "tw_fit_mixtures_tape: the tape does not hold the draws of slot " + std::to_string(q));
+    }
+    HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
+    if (tape_len > e->fit_tape_cap) {
+        double* p = nullptr;
+        rc = dev_alloc(e, &p, tape_len);
+        if (rc != TW_OK) return rc;
+        e->fit_tape = p;
+        e->fit_tape_cap = tape_len;
+    }
+    HIPCHK(hipMemcpyAsync(e->fit_tape, tape, sizeof(double) * (size_t)std::max<int64_t>(tape_len, 0), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->fit_tape_off, slot_off, sizeof(int64_t) * e->n_slots, hipMemcpyHostToDevice, e->stream));
+    return fit_run(e);
+}
+
+int tw_fit_mixtures_seeded(tw_engine* e, const uint32_t* unit_seed) {
+    if (e == nullptr) return TW_ERR_ARG;
+    int rc = fit_check_state(e, "tw_fit_mixtures");
+    if (rc != TW_OK) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
+    rc = fit_prepare(e);
+    if (rc != TW_OK) return rc;
+    // one block of 34 uniforms per slot: no look at the rows needed, no host round trip.  With unit seeds every unit draws from
+    // a stream of its own, so its fit does not depend on which other units share the batch (sharded runs);
+    // otherwise all slots draw from the engine's stream in slot order.
+    static thread_local std::vector<double> tape;
+    static thread_local std::vector<int64_t> off;
+    tape.resize((size_t)e->n_slots * kFitRowTape);
+    off.resize((size_t)e->n_slots);
+    for (int64_t q = 0; q < e->n_slots; q++) off[(size_t)q] = q * kFitRowTape;
+    if (unit_seed == nullptr) {
+        for (size_t i = 0; i < tape.size(); i++) tape[i] = e->fit_rng.random_sample();
+    } else {
+        for (size_t u = 0; u < e->units.size(); u++) {
+            Mt19937 r(unit_seed[u]);
+            const size_t lo = (size_t)e->units[u].slot_off * kFitRowTape, hi = lo + (size_t)e->units[u].nslot * kFitRowTape;
+            for (size_t i = lo; i < hi; i++) tape[i] = r.random_sample();
+        }
+    }
+    if ((int64_t)tape.size() > e->fit_tape_cap) return fail(e, TW_ERR_STATE, "tw_fit_mixtures: tape buffer smaller than the batch");
+    HIPCHK(hipMemcpyAsync(e->fit_tape, tape.data(), sizeof(double) * tape.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->fit_tape_off, off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));   // (the host vectors are reused by the next call)
+    return fit_run(e);
+}
+
+int tw_fit_mixtures(tw_engine* e) { return tw_fit_mixtures_seeded(e, nullptr); }
 
 int tw_get_mixtures(tw_engine* e, int32_t* mix_n, double* mix_p) {
     if (e == nullptr || mix_n == nullptr || mix_p == nullptr) return TW_ERR_ARG;

@@ -1,22 +1,31 @@
-// tw_fit.h -- device-side refit of the per-edge delay mixtures between the two passes
-// (ComputeEpPairDistParams5, traceweaver_v3.py:764-786).
+// tw_fit.h -- device-side refit of the per-edge delay mixtures between the two passes: the reference's procedure,
+// ComputeEpPairDistParams5 (traceweaver_v3.py:764-786), for every scored edge of every unit at once.
 //
-// The reference fits, per scored edge, 1..min(5, #unique) one-dimensional Gaussian mixtures with
-// scikit-learn (k-means++ initialisation drawn from numpy's *unseeded* global RNG), keeps the
-// component count with the smallest BIC and refits it.  That procedure is not reproducible run to run
-// (SURVEY.md hazard H9: +-1 pp end-to-end accuracy between identical runs), so there is no bit-level
-// target to hit.  The device refit keeps the model family, the EM iteration, its stopping rule
-// (|delta mean log-likelihood| < 1e-3, <= 100 iterations, reg_covar 1e-6) and the BIC selection, and
-// replaces the random initialisation by a deterministic one: the k equal-count buckets of the sorted
-// samples.  One workgroup runs one (edge, k) fit start to finish, so every reduction has a fixed
-// order and the result is a pure function of the samples.
+//     for n in 1..min(5, #unique):  GaussianMixture(n, covariance_type="diag").fit(x)      V3:772-779  (numpy's global RNG)
+//     n_selected = the n with the smallest BIC among the fits that did not raise            V3:780
+//     GaussianMixture(n_selected, random_state=100).fit(x)            (full covariance)     V3:784-785
 //
-// Gaps are integer microseconds, so a row of 10^5 samples holds only 10^2..10^4 distinct values:
-// k_fit_compress turns every sorted row into (value, multiplicity) runs once, and all EM sums run over
-// the runs with the multiplicity as weight (the same sums, grouped by value).
+// GaussianMixture.fit (scikit-learn, third-party; restated from its published algorithm, oracle/tw_refit.py is the CPU
+// restatement pinned against scikit-learn itself) = KMeans(n, n_init=1) labels -- k-means++ seeding on the mean-centred
+// samples *in the order of the requests*, then Lloyd iterations -- one-hot responsibilities, an M step, then EM until the
+// mean log-likelihood moves by less than 1e-3 (<= 100 iterations), reg_covar 1e-6; a covariance <= 0 is scikit-learn's
+// ValueError, which the reference skips (V3:777-779).
 //
-// traceweaver_amd/gmm.py::fit_edge_sklearn keeps the reference procedure for comparison; pass 2 is
-// bit-exact against the oracle for *any* mixture table (tests feed the fitted tables to both).
+// Randomness: the only random draws are the k-means++ seeds -- one uniform for the first centre (`choice(n, p)`), then
+// 2 + int(ln n) per further centre -- 1, 3, 7, 10, 13 doubles for n = 1..5, independent of the data.  They come from a
+// *tape* of uniforms: either handed over by the host (the doubles numpy's global MT19937 would have produced at that point
+// of a seeded reference run: tw_fit_mixtures_tape) or drawn by the library from its own MT19937 (tw_fit_mixtures).  The
+// refit of the selected count uses the first doubles of MT19937 seeded with 100, as `random_state=100` does.
+//
+// Gaps are integer microseconds (or integer multiples of 2^-k for load-scaled units), so a row of 10^5 samples holds only
+// 10^2..10^4 distinct values: k_fit_compress turns every sorted row into (value, multiplicity) runs once; Lloyd and EM run
+// over the runs with the multiplicity as weight (the same sums, grouped by value).  Only the k-means++ seeding, whose
+// sampling walks a cumulative sum in request order, reads the unsorted row.  Sums of samples are exact in binary64 (integers
+// below 2^53), so the mean that centres the samples is bit-identical to numpy's; sums of products are not, and differ from
+// scikit-learn's BLAS sums in their last bits like scikit-learn's own results differ between machines.
+//
+// One workgroup runs one (edge, n) fit start to finish: every reduction has a fixed order, the result is a pure
+// function of (samples in request order, tape).
 #pragma once
 #include "tw_device.h"
 
@@ -24,17 +33,27 @@ namespace tw {
 
 constexpr int kFitThreads = 512;
 constexpr int kFitWaves = kFitThreads / 64;
-constexpr int kFitStats = 3 * kMaxComp + 1;  // per component: nk, sum r*(x-c), sum r*(x-c)^2; + log-likelihood
-constexpr int kFitMaxIter = 100;
-constexpr double kFitTol = 1.0e-3;
-constexpr double kFitRegCovar = 1.0e-6;
-constexpr int kModelStride = 1 + 3 * kMaxComp;  // bic, w[5], mu[5], var[5]
+constexpr int kFitStats = 3 * kMaxComp + 2;
+constexpr int kFitMaxIter = 100;          // GaussianMixture(max_iter=100)
+constexpr double kFitTol = 1.0e-3;        // GaussianMixture(tol=1e-3)
+constexpr double kFitRegCovar = 1.0e-6;   // GaussianMixture(reg_covar=1e-6)
+constexpr int kKmMaxIter = 300;           // KMeans(max_iter=300)
+constexpr double kKmTol = 1.0e-4;         // KMeans(tol=1e-4), times the variance of the samples
+constexpr double kEps10 = 10.0 * 2.220446049250313e-16;
+constexpr int kModelStride = 1 + 3 * kMaxComp;  // bic (inf = the fit raised), w[5], mu[5], precision_cholesky[5]
+constexpr int kFitMaxTrials = 3;          // 2 + int(ln 5)
+constexpr int kFitRowTape = 34;           // 1 + 3 + 7 + 10 + 13 doubles: the model-selection fits of one row
+
+__host__ __device__ inline int fit_trials(int k) { return k < 3 ? 2 : 3; }                    // 2 + int(ln k), k = 1..5
+__host__ __device__ inline int fit_draws(int k) { return 1 + (k - 1) * fit_trials(k); }       // 1, 3, 7, 10, 13
+__host__ __device__ inline int fit_tape_pos(int k) { return k == 1 ? 0 : k == 2 ? 1 : k == 3 ? 4 : k == 4 ? 11 : 21; }
 
 struct FitDev {
     const UnitDev* units;
     int32_t n_units;
     int64_t n_slots;
-    const double* sorted;   // gap rows sorted ascending, NaN (dropped) last; row q of unit u at gs_off[u] + q*n_in
+    const double* gaps;     // gap rows in request order, NaN = dropped; row q of unit u at gs_off[u] + q*n_in
+    const double* sorted;   // the rows sorted ascending, NaN last (same offsets)
     const int64_t* gs_off;
     const int32_t* slot_unit;  // [n_slots] owning unit
     const uint8_t* slot_scored;  // [n_slots] 1 <=> the slot is a scored edge (its gap row is sorted and fitted)
@@ -45,6 +64,10 @@ struct FitDev {
     double* models;         // [n_slots][kMaxComp][kModelStride]
     int32_t* mix_n;         // [n_slots]
     double* mix_p;          // [n_slots][kMaxComp][3] weight, mean, precision_cholesky
+    const double* tape;     // uniforms of the model-selection fits
+    const int64_t* tape_off;  // [n_slots] first double of the row's fits (n = 1, 2, ... behind one another)
+    const double* tape100;  // [kMaxComp][13] draws of the refit with n components: MT19937(100)
+    int32_t* err;
 };
 
 // deterministic block reduction of `cnt` doubles per thread: lanes of a wavefront by shuffles (fixed
@@ -133,149 +156,484 @@ __global__ void __launch_bounds__(kCoop) k_fit_compress(FitDev F) {
     if (t == 0) { F.row_n[q] = n_sh; F.row_uniq[q] = carry_sh; }
 }
 
-__global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
+// sklearn.metrics.pairwise._euclidean_distances(c, X, squared=True) for one feature: ((-2 (c x)) + c c) + x x, clipped at 0
+__device__ __forceinline__ double fit_dist(double c, double x) {
+    double d = -2.0 * (c * x);
+    d += c * c;
+    d += x * x;
+    return d > 0.0 ? d : 0.0;
+}
+// label of a centred sample under Lloyd's rule: first minimum of c^2 - 2 x c (the strict `<` scan of _update_chunk_dense)
+__device__ __forceinline__ int fit_label(const double* cen, int k, double x) {
+    double best = cen[0] * cen[0] + (-2.0) * (x * cen[0]);
+    int lab = 0;
+#pragma unroll
+    for (int j = 1; j < kMaxComp; j++) {
+        if (j < k) {
+            const double d = cen[j] * cen[j] + (-2.0) * (x * cen[j]);
+            if (d < best) { best = d; lab = j; }
+        }
+    }
+    return lab;
+}
+
+// One workgroup per (row, component count): GaussianMixture(k).fit(row).  kFull = false: the model-selection fits
+// (diagonal covariance, draws from the row's tape, result = BIC + parameters in F.models); kFull = true: the refit of the
+// selected count (full covariance, draws of MT19937(100), result = the row of the mixture table).
+template <bool kFull>
+__global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
     __shared__ double sh[kFitStats * kFitWaves];
-    __shared__ double par[3 * kMaxComp];  // w, mu, var
-    const int64_t q = blockIdx.x / kMaxComp;
-    const int k = (int)(blockIdx.x % kMaxComp) + 1;
+    __shared__ double par[3 * kMaxComp];              // weights, means, covariances
+    __shared__ double cen[kMaxComp], cen_prev[kMaxComp];
+    __shared__ double seg[kFitMaxTrials][kFitWaves];  // per trial candidate: sum over a wavefront's stretch of the row of the closest squared distances
+    __shared__ double cand[kFitMaxTrials][kFitWaves]; // first crossing found by each wavefront (NaN = none)
+    __shared__ double lastv[kFitWaves];
+    __shared__ int32_t lasti[kFitWaves], cnt_w[kFitWaves];
+    const int64_t q = kFull ? (int64_t)blockIdx.x : (int64_t)(blockIdx.x / kMaxComp);
+    const int k = kFull ? F.mix_n[q] : (int)(blockIdx.x % kMaxComp) + 1;
     const int t = threadIdx.x, nt = blockDim.x;
+    const int W = nt < 64 ? nt : 64, lane = t & 63, wave = t >> 6, nwave = (nt + 63) >> 6;
     const UnitDev& U = F.units[F.slot_unit[q]];
-    const int64_t row = F.gs_off[F.slot_unit[q]] + (q - U.slot_off) * (int64_t)U.n_in;
+    const int n_all = U.n_in;
+    const int64_t row = F.gs_off[F.slot_unit[q]] + (q - U.slot_off) * (int64_t)n_all;
+    const double* xr = F.gaps + row;      // request order
     const double* xv = F.uval + row;      // distinct values, ascending
     const int32_t* xa = F.ustart + row;   // first index of each value in the sorted row
-    double* model = F.models + (q * kMaxComp + (k - 1)) * kModelStride;
+    double* model = kFull ? nullptr : F.models + (q * kMaxComp + (k - 1)) * kModelStride;
     const int n = F.row_n[q], uniq = F.row_uniq[q];
-    if (!F.slot_scored[q] || n == 0 || k > uniq || k > kMaxComp) {
-        if (t == 0) model[0] = dinf();
+    if (!F.slot_scored[q] || n == 0 || k < 1 || k > uniq || k > kMaxComp) {
+        if (!kFull && t == 0) model[0] = dinf();
         return;
     }
-    // every per-thread array below is indexed by compile-time constants only (loops over the components are
-    // unrolled to kMaxComp and predicated with j < k), so nothing spills to scratch memory
-    // initialisation: equal-count buckets of the sorted samples -- sample i belongs to bucket floor(i*k/n),
-    // i.e. bucket c owns the index range [ceil(c*n/k), ceil((c+1)*n/k))
-    double b2[2 * kMaxComp];
-#pragma unroll
-    for (int c = 0; c < 2 * kMaxComp; c++) b2[c] = 0.0;
-    for (int r = t; r < uniq; r += nt) {
-        const int64_t a = xa[r], b = r + 1 < uniq ? xa[r + 1] : n;
-        const double xi = xv[r];
-#pragma unroll
-        for (int c = 0; c < kMaxComp; c++) {
-            if (c < k) {
-                const int64_t lo = ((int64_t)c * n + k - 1) / k, hi = ((int64_t)(c + 1) * n + k - 1) / k;
-                const int64_t ov = (b < hi ? b : hi) - (a > lo ? a : lo);
-                if (ov > 0) { b2[c] += (double)ov; b2[kMaxComp + c] += (double)ov * xi; }
+    const double* tape = kFull ? F.tape100 + (k - 1) * 13 : F.tape + F.tape_off[q] + fit_tape_pos(k);
+    const double dn = (double)n;
+
+    // ---- mean and variance of the samples (exact sum: integers below 2^53)
+    double mv[2] = {0.0, 0.0};
+    for (int r = t; r < uniq; r += nt) mv[0] += xv[r] * (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
+    block_reduce<1>(reinterpret_cast<double(&)[1]>(mv[0]), sh);
+    const double mean = mv[0] / dn;
+    for (int r = t; r < uniq; r += nt) { const double d = xv[r] - mean; mv[1] += (d * d) * (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]); }
+    block_reduce<1>(reinterpret_cast<double(&)[1]>(mv[1]), sh);
+    const double km_tol = mv[1] / dn * kKmTol;
+
+    // ---- k-means++ seeding (sklearn.cluster._kmeans._kmeans_plusplus) on the centred samples in request order.
+    // Every wavefront owns one stretch of the row and walks it in strips of 64 samples.
+    const int strips = (n_all + W - 1) / W, strips_w = (strips + nwave - 1) / nwave;
+    const int s_lo = wave * strips_w * W, s_hi = (s_lo + strips_w * W) < n_all ? (s_lo + strips_w * W) : n_all;
+    if (k > 1) {
+        // the first centre: sample number floor(u n) of the valid samples
+        int64_t cid = (int64_t)(tape[0] * dn);
+        if (cid > n - 1) cid = n - 1;
+        {   // valid samples per stretch, the last valid sample
+            int c = 0, li = -1;
+            double lv = 0.0;
+            for (int b = s_lo; b < s_hi; b += W) {
+                const int i = b + lane;
+                const double x = i < s_hi ? xr[i] : dnan();
+                const bool ok = x == x;
+                c += ok ? 1 : 0;
+                if (ok) { li = i; lv = x; }
+            }
+            for (int off = 32; off >= 1; off >>= 1) {
+                if (off < W) {
+                    c += __shfl_down(c, off);
+                    const int oi = __shfl_down(li, off);
+                    const double ov = __shfl_down(lv, off);
+                    if (oi > li) { li = oi; lv = ov; }
+                }
+            }
+            if (lane == 0) { cnt_w[wave] = c; lasti[wave] = li; lastv[wave] = lv; }
+        }
+        __syncthreads();
+        double x_last = 0.0;
+        { int li = -1; for (int w = 0; w < nwave; w++) if (lasti[w] > li) { li = lasti[w]; x_last = lastv[w]; } }
+        x_last -= mean;
+        {
+            int64_t before = 0;
+            int w0 = 0;
+            for (; w0 < nwave - 1 && before + cnt_w[w0] <= cid; w0++) before += cnt_w[w0];
+            if (wave == w0) {  // (wave-uniform branch) walk the stretch to the cid-th valid sample
+                int64_t seen = before;
+                for (int b = s_lo; b < s_hi; b += W) {
+                    const int i = b + lane;
+                    const double x = i < s_hi ? xr[i] : dnan();
+                    const unsigned long long okm = __ballot(x == x);
+                    const int c = __popcll(okm);
+                    if (seen + c > cid) {
+                        const int rank = (int)(cid - seen);  // the rank-th set bit of okm
+                        const bool mine = (x == x) && __popcll(okm & ((1ull << lane) - 1ull)) == rank;
+                        if (mine) cen[0] = x - mean;
+                        break;
+                    }
+                    seen += c;
+                }
             }
         }
-    }
-    block_reduce<2 * kMaxComp>(b2, sh);
-    if (t == 0) {
-#pragma unroll
-        for (int j = 0; j < kMaxComp; j++) if (j < k) { par[j] = b2[j] / (double)n; par[kMaxComp + j] = b2[kMaxComp + j] / b2[j]; }
-    }
-    __syncthreads();
-    double b1[kMaxComp];
-#pragma unroll
-    for (int c = 0; c < kMaxComp; c++) b1[c] = 0.0;
-    for (int r = t; r < uniq; r += nt) {
-        const int64_t a = xa[r], b = r + 1 < uniq ? xa[r + 1] : n;
-        const double xi = xv[r];
-#pragma unroll
-        for (int c = 0; c < kMaxComp; c++) {
-            if (c < k) {
-                const int64_t lo = ((int64_t)c * n + k - 1) / k, hi = ((int64_t)(c + 1) * n + k - 1) / k;
-                const int64_t ov = (b < hi ? b : hi) - (a > lo ? a : lo);
-                const double d = xi - par[kMaxComp + c];
-                if (ov > 0) b1[c] += (double)ov * (d * d);
+        __syncthreads();
+        // closest squared distances to the first centre: their sums per stretch
+        {
+            double a = 0.0;
+            const double c0 = cen[0];
+            for (int b = s_lo; b < s_hi; b += W) {
+                const int i = b + lane;
+                const double x = i < s_hi ? xr[i] : dnan();
+                if (x == x) a += fit_dist(c0, x - mean);
             }
+            for (int off = 32; off >= 1; off >>= 1) if (off < W) a += __shfl_down(a, off);
+            if (lane == 0) seg[0][wave] = a;
         }
-    }
-    block_reduce<kMaxComp>(b1, sh);
-    if (t == 0) {
+        __syncthreads();
+        const int trials = fit_trials(k);
+        int tp = 1;
+        for (int c = 1; c < k; c++) {
+            double pot = 0.0, base = 0.0;
+            for (int w = 0; w < nwave; w++) { if (w == wave) base = pot; pot += seg[0][w]; }
+            double target[kFitMaxTrials];
 #pragma unroll
-        for (int j = 0; j < kMaxComp; j++) if (j < k) par[2 * kMaxComp + j] = b1[j] / (par[j] * (double)n) + kFitRegCovar;
+            for (int j = 0; j < kFitMaxTrials; j++) target[j] = j < trials ? tape[tp + j] * pot : 0.0;
+            tp += trials;
+            // pass A: np.searchsorted(cumsum(closest), target) -- the first sample whose running sum reaches the target
+            {
+                bool found[kFitMaxTrials] = {false, false, false};
+                double fv[kFitMaxTrials] = {0.0, 0.0, 0.0};
+                double run = base;
+                for (int b = s_lo; b < s_hi; b += W) {
+                    const int i = b + lane;
+                    const double x = i < s_hi ? xr[i] : dnan();
+                    const bool ok = x == x;
+                    const double xc = x - mean;
+                    double v = 0.0;
+                    if (ok) {
+                        v = fit_dist(cen[0], xc);
+#pragma unroll
+                        for (int j = 1; j < kMaxComp - 1; j++) if (j < c) { const double d = fit_dist(cen[j], xc); if (d < v) v = d; }
+                    }
+                    double s = v;  // inclusive scan over the lanes
+                    for (int off = 1; off < W; off <<= 1) { const double o = __shfl_up(s, off); if (lane >= off) s += o; }
+                    const double cum = run + s;
+#pragma unroll
+                    for (int j = 0; j < kFitMaxTrials; j++) {
+                        if (j < trials && !found[j]) {
+                            const unsigned long long m = __ballot(ok && cum >= target[j]);
+                            if (m) { found[j] = true; fv[j] = __shfl(xc, __ffsll((long long)m) - 1); }
+                        }
+                    }
+                    run += __shfl(s, W - 1);
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int j = 0; j < kFitMaxTrials; j++) cand[j][wave] = found[j] ? fv[j] : dnan();
+                }
+            }
+            __syncthreads();
+            double cv[kFitMaxTrials];
+#pragma unroll
+            for (int j = 0; j < kFitMaxTrials; j++) {
+                cv[j] = x_last;  // np.clip(candidate_ids, None, n - 1): a target beyond the last running sum
+                for (int w = nwave - 1; w >= 0; w--) { const double v = cand[j][w]; if (v == v) cv[j] = v; }
+            }
+            __syncthreads();
+            // pass B: the potential of every candidate = sum of min(closest, distance to the candidate)
+            {
+                double a[kFitMaxTrials] = {0.0, 0.0, 0.0};
+                for (int b = s_lo; b < s_hi; b += W) {
+                    const int i = b + lane;
+                    const double x = i < s_hi ? xr[i] : dnan();
+                    if (x == x) {
+                        const double xc = x - mean;
+                        double v = fit_dist(cen[0], xc);
+#pragma unroll
+                        for (int j = 1; j < kMaxComp - 1; j++) if (j < c) { const double d = fit_dist(cen[j], xc); if (d < v) v = d; }
+#pragma unroll
+                        for (int j = 0; j < kFitMaxTrials; j++) if (j < trials) { const double d = fit_dist(cv[j], xc); a[j] += d < v ? d : v; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kFitMaxTrials; j++) {
+                    for (int off = 32; off >= 1; off >>= 1) if (off < W) a[j] += __shfl_down(a[j], off);
+                    if (lane == 0) seg[j][wave] = a[j];
+                }
+            }
+            __syncthreads();
+            int best = 0;
+            double bp = 0.0;
+#pragma unroll
+            for (int j = 0; j < kFitMaxTrials; j++) {
+                if (j < trials) {
+                    double p = 0.0;
+                    for (int w = 0; w < nwave; w++) p += seg[j][w];
+                    if (j == 0 || p < bp) { bp = p; best = j; }   // np.argmin: the first minimum
+                }
+            }
+            const double keep = seg[best][wave];
+            __syncthreads();
+            if (lane == 0) seg[0][wave] = keep;
+            if (t == 0) cen[c] = cv[best];
+            __syncthreads();
+        }
+
+        // ---- Lloyd iterations (_kmeans_single_lloyd) over the runs
+        bool strict = false;
+        for (int it = 0; it < kKmMaxIter; it++) {
+            double v[2 * kMaxComp + 1];
+#pragma unroll
+            for (int j = 0; j < 2 * kMaxComp + 1; j++) v[j] = 0.0;
+            for (int r = t; r < uniq; r += nt) {
+                const double xc = xv[r] - mean;
+                const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
+                const int lab = fit_label(cen, k, xc);
+                if (it == 0 || fit_label(cen_prev, k, xc) != lab) v[2 * kMaxComp] = 1.0;   // labels != labels_old
+#pragma unroll
+                for (int j = 0; j < kMaxComp; j++) if (j == lab) { v[j] += cw; v[kMaxComp + j] += xc * cw; }
+            }
+            block_reduce<2 * kMaxComp + 1>(v, sh);
+            bool any_empty = false;
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) if (j < k && v[j] == 0.0) any_empty = true;
+            if (any_empty) {
+                // _relocate_empty_clusters_dense: the samples farthest from their centres found the empty clusters (one sample each,
+                // labels untouched).  Rare (never on the reference's corpora); thread 0 walks the runs.
+                if (t == 0) {
+                    int taken_run[kMaxComp], taken_cnt[kMaxComp], ntaken = 0;
+                    for (int e = 0; e < k; e++) {
+                        if (v[e] != 0.0) continue;
+                        int fr = -1;
+                        double fd = -1.0;
+                        for (int r = 0; r < uniq; r++) {
+                            int used = 0;
+                            for (int z = 0; z < ntaken; z++) if (taken_run[z] == r) used = taken_cnt[z];
+                            if ((r + 1 < uniq ? xa[r + 1] : n) - xa[r] <= used) continue;
+                            const double xc = xv[r] - mean;
+                            const double d0 = xc - cen[fit_label(cen, k, xc)];
+                            if (d0 * d0 > fd) { fd = d0 * d0; fr = r; }
+                        }
+                        if (fr < 0) break;
+                        bool again = false;
+                        for (int z = 0; z < ntaken; z++) if (taken_run[z] == fr) { taken_cnt[z]++; again = true; }
+                        if (!again) { taken_run[ntaken] = fr; taken_cnt[ntaken] = 1; ntaken++; }
+                        const double xc = xv[fr] - mean;
+                        const int old = fit_label(cen, k, xc);
+                        sh[old] = 1.0;  // (marker only; the sums are adjusted below)
+                        v[kMaxComp + old] -= xc; v[old] -= 1.0;
+                        v[kMaxComp + e] = xc; v[e] = 1.0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < kMaxComp; j++) { par[j] = v[j]; par[kMaxComp + j] = v[kMaxComp + j]; }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < kMaxComp; j++) { v[j] = par[j]; v[kMaxComp + j] = par[kMaxComp + j]; }
+                __syncthreads();
+            }
+            double shift = 0.0;
+            double nc[kMaxComp];
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) {
+                nc[j] = 0.0;
+                if (j < k) {
+                    nc[j] = v[kMaxComp + j] * (1.0 / v[j]);   // _average_centers: the sum times the reciprocal of the weight
+                    const double d = nc[j] - cen[j];
+                    const double s = sqrt(d * d);               // _center_shift, then (center_shift ** 2).sum()
+                    shift += s * s;
+                }
+            }
+            __syncthreads();
+            if (t == 0) {
+#pragma unroll
+                for (int j = 0; j < kMaxComp; j++) if (j < k) { cen_prev[j] = cen[j]; cen[j] = nc[j]; }
+            }
+            __syncthreads();
+            if (v[2 * kMaxComp] == 0.0) { strict = true; break; }
+            if (shift <= km_tol) break;
+        }
+        // the labels KMeans returns: those of the last assignment (strict convergence) or a fresh one under the final centres
+        if (strict) {
+            __syncthreads();
+            if (t == 0) {
+#pragma unroll
+                for (int j = 0; j < kMaxComp; j++) if (j < k) cen[j] = cen_prev[j];
+            }
+            __syncthreads();
+        }
+    } else {
+        if (t == 0) cen[0] = 0.0;
+        __syncthreads();
     }
-    __syncthreads();
-    // EM over the runs, multiplicity as weight
-    double prev_lb = -dinf();
-    for (int iter = 0; iter <= kFitMaxIter; iter++) {
-        double lw[kMaxComp], mu[kMaxComp], iv[kMaxComp], v[kFitStats];
+
+    // ---- GaussianMixture._initialize: one-hot responsibilities of the k-means labels, then the M step
+    bool failed = false;
+    {
+        double v[3 * kMaxComp];
+#pragma unroll
+        for (int j = 0; j < 3 * kMaxComp; j++) v[j] = 0.0;
+        for (int r = t; r < uniq; r += nt) {
+            const double x = xv[r];
+            const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
+            const int lab = k > 1 ? fit_label(cen, k, x - mean) : 0;
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) if (j == lab) { v[j] += cw; v[kMaxComp + j] += cw * x; v[2 * kMaxComp + j] += cw * (x * x); }
+        }
+        block_reduce<3 * kMaxComp>(v, sh);
+        double mu[kMaxComp], nk[kMaxComp];
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) { nk[j] = v[j] + kEps10; mu[j] = j < k ? v[kMaxComp + j] / nk[j] : 0.0; }
+        if (kFull) {
+            double c2[kMaxComp];
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) c2[j] = 0.0;
+            for (int r = t; r < uniq; r += nt) {
+                const double x = xv[r];
+                const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
+                const int lab = k > 1 ? fit_label(cen, k, x - mean) : 0;
+#pragma unroll
+                for (int j = 0; j < kMaxComp; j++) if (j == lab) { const double d = x - mu[j]; c2[j] += cw * (d * d); }
+            }
+            block_reduce<kMaxComp>(c2, sh);
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) v[2 * kMaxComp + j] = c2[j] / nk[j] + kFitRegCovar;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) v[2 * kMaxComp + j] = (v[2 * kMaxComp + j] / nk[j] - mu[j] * mu[j]) + kFitRegCovar;
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) if (j < k && !(v[2 * kMaxComp + j] > 0.0)) failed = true;
+        if (t == 0) {
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) if (j < k) { par[j] = nk[j] / dn; par[kMaxComp + j] = mu[j]; par[2 * kMaxComp + j] = v[2 * kMaxComp + j]; }
+        }
+        __syncthreads();
+    }
+
+    // ---- EM (BaseMixture.fit_predict); the last round only scores the final parameters (bic() re-scores)
+    double lower = -dinf();
+    bool last = false;
+    for (int iter = 0; iter <= kFitMaxIter && !failed; iter++) {
+        if (iter == kFitMaxIter) last = true;
+        double lw[kMaxComp], mu[kMaxComp], pc[kMaxComp], a0[kMaxComp], a1[kMaxComp], a2[kMaxComp], v[kFitStats];
 #pragma unroll
         for (int j = 0; j < kMaxComp; j++) {
+            lw[j] = -dinf(); mu[j] = 0.0; pc[j] = 0.0; a0[j] = 0.0; a1[j] = 0.0; a2[j] = 0.0;
             if (j < k) {
                 mu[j] = par[kMaxComp + j];
-                iv[j] = 1.0 / par[2 * kMaxComp + j];
-                lw[j] = log(par[j]) - 0.5 * (kLog2Pi + log(par[2 * kMaxComp + j]));
-            } else { mu[j] = 0.0; iv[j] = 0.0; lw[j] = -dinf(); }
+                pc[j] = 1.0 / sqrt(par[2 * kMaxComp + j]);   // _compute_precision_cholesky
+                lw[j] = tw_log(par[j]);
+                if (kFull) { a0[j] = mu[j] * pc[j]; }
+                else { const double prec = pc[j] * pc[j]; a0[j] = (mu[j] * mu[j]) * prec; a1[j] = mu[j] * prec; a2[j] = prec; }
+                a2[j] = kFull ? 0.0 : a2[j];
+            }
         }
+        double ld[kMaxComp];
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) ld[j] = j < k ? tw_log(pc[j]) : 0.0;
 #pragma unroll
         for (int c = 0; c < kFitStats; c++) v[c] = 0.0;
         for (int r = t; r < uniq; r += nt) {
-            const double xi = xv[r];
+            const double x = xv[r];
             const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
-            double lp[kMaxComp], mx = -dinf();
+            double wl[kMaxComp], mx = -dinf();
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) {
+                wl[j] = -dinf();
                 if (j < k) {
-                    const double d = xi - mu[j];
-                    lp[j] = lw[j] - 0.5 * d * d * iv[j];
-                    if (lp[j] > mx) mx = lp[j];
+                    double lp;
+                    if (kFull) { const double y = x * pc[j] - a0[j]; lp = y * y; }                       // _estimate_log_gaussian_prob, "full"
+                    else lp = (a0[j] - 2.0 * (x * a1[j])) + (x * x) * a2[j];                             // ... "diag"
+                    wl[j] = (-0.5 * (kLog2Pi + lp) + ld[j]) + lw[j];
+                    if (wl[j] > mx) mx = wl[j];
                 }
             }
             double s = 0.0;
 #pragma unroll
-            for (int j = 0; j < kMaxComp; j++) if (j < k) { lp[j] = exp(lp[j] - mx); s += lp[j]; }
-            v[3 * kMaxComp] += cw * (mx + log(s));
-            const double inv = cw / s;
+            for (int j = 0; j < kMaxComp; j++) if (j < k) s += tw_exp(wl[j] - mx);
+            const double lpn = tw_log(s) + mx;   // scipy.special.logsumexp
+            v[3 * kMaxComp] += cw * lpn;
+            if (!last) {
 #pragma unroll
-            for (int j = 0; j < kMaxComp; j++) {
-                if (j < k) {
-                    const double r2 = lp[j] * inv, d = xi - mu[j];
-                    v[j] += r2;
-                    v[kMaxComp + j] += r2 * d;
-                    v[2 * kMaxComp + j] += r2 * d * d;
+                for (int j = 0; j < kMaxComp; j++) {
+                    if (j < k) {
+                        const double rj = tw_exp(wl[j] - lpn) * cw;   // resp = exp(log_resp)
+                        v[j] += rj;
+                        v[kMaxComp + j] += rj * x;
+                        if (kFull) { const double d = x - mu[j]; (void)d; }
+                        else v[2 * kMaxComp + j] += rj * (x * x);
+                    }
                 }
             }
         }
         block_reduce<kFitStats>(v, sh);
-        const double lb = v[3 * kMaxComp] / (double)n;  // mean log-likelihood under the current parameters
-        // last round only evaluates the likelihood of the final parameters (sklearn's bic() re-scores)
-        const bool stop = (iter == kFitMaxIter) || (fabs(lb - prev_lb) < kFitTol);
-        if (stop) {
-            if (t == 0) {
-                model[0] = -2.0 * lb * (double)n + (double)(3 * k - 1) * log((double)n);
+        const double lb = v[3 * kMaxComp] / dn;
+        if (last) { lower = lb; break; }
+        double nk[kMaxComp], nm[kMaxComp], nks = 0.0;
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) { nk[j] = 0.0; nm[j] = 0.0; if (j < k) { nk[j] = v[j] + kEps10; nm[j] = v[kMaxComp + j] / nk[j]; nks += nk[j]; } }
+        double cov[kMaxComp];
+        if (kFull) {   // covariances around the *new* means: a second sweep with the same responsibilities
+            double c2[kMaxComp];
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) c2[j] = 0.0;
+            for (int r = t; r < uniq; r += nt) {
+                const double x = xv[r];
+                const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
+                double wl[kMaxComp], mx = -dinf();
 #pragma unroll
                 for (int j = 0; j < kMaxComp; j++) {
-                    model[1 + j] = j < k ? par[j] : 0.0;
-                    model[1 + kMaxComp + j] = j < k ? par[kMaxComp + j] : 0.0;
-                    model[1 + 2 * kMaxComp + j] = j < k ? par[2 * kMaxComp + j] : 1.0;
+                    wl[j] = -dinf();
+                    if (j < k) {
+                        const double y = x * pc[j] - a0[j];
+                        wl[j] = (-0.5 * (kLog2Pi + y * y) + ld[j]) + lw[j];
+                        if (wl[j] > mx) mx = wl[j];
+                    }
                 }
-            }
-            return;
-        }
-        prev_lb = lb;
-        __syncthreads();
-        if (t == 0) {  // M step (shifted moments: c = previous mean of the component)
-            double ws = 0.0;
+                double s = 0.0;
 #pragma unroll
-            for (int j = 0; j < kMaxComp; j++) {
-                if (j < k) {
-                    const double nk = v[j] + 10.0 * 2.220446049250313e-16;
-                    const double dm = v[kMaxComp + j] / nk;
-                    par[j] = nk / (double)n;
-                    par[kMaxComp + j] = mu[j] + dm;
-                    par[2 * kMaxComp + j] = v[2 * kMaxComp + j] / nk - dm * dm + kFitRegCovar;
-                    ws += par[j];
-                }
-            }
+                for (int j = 0; j < kMaxComp; j++) if (j < k) s += tw_exp(wl[j] - mx);
+                const double lpn = tw_log(s) + mx;
 #pragma unroll
-            for (int j = 0; j < kMaxComp; j++) if (j < k) par[j] /= ws;
+                for (int j = 0; j < kMaxComp; j++) if (j < k) { const double d = x - nm[j]; c2[j] += (tw_exp(wl[j] - lpn) * cw) * (d * d); }
+            }
+            block_reduce<kMaxComp>(c2, sh);
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) cov[j] = c2[j] / nk[j] + kFitRegCovar;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) cov[j] = j < k ? (v[2 * kMaxComp + j] / nk[j] - nm[j] * nm[j]) + kFitRegCovar : 1.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) if (j < k && !(cov[j] > 0.0)) failed = true;
+        __syncthreads();
+        if (t == 0) {
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) if (j < k) { par[j] = nk[j] / nks; par[kMaxComp + j] = nm[j]; par[2 * kMaxComp + j] = cov[j]; }
         }
         __syncthreads();
+        const double change = lb - lower;
+        lower = lb;
+        if (fabs(change) < kFitTol) last = true;   // converged: one more sweep scores the parameters just set
+    }
+    if (t != 0) return;
+    if (kFull) {
+        if (failed) { atomicCAS(F.err, 0, (int)TW_ERR_FIT); return; }
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) {
+            F.mix_p[(q * kMaxComp + j) * 3 + 0] = j < k ? par[j] : 0.0;
+            F.mix_p[(q * kMaxComp + j) * 3 + 1] = j < k ? par[kMaxComp + j] : 0.0;
+            F.mix_p[(q * kMaxComp + j) * 3 + 2] = j < k ? 1.0 / sqrt(par[2 * kMaxComp + j]) : 0.0;
+        }
+    } else {
+        model[0] = failed ? dinf() : -2.0 * lower * dn + (double)(3 * k - 1) * tw_log(dn);   // GaussianMixture.bic
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) {
+            model[1 + j] = j < k ? par[j] : 0.0;
+            model[1 + kMaxComp + j] = j < k ? par[kMaxComp + j] : 0.0;
+            model[1 + 2 * kMaxComp + j] = j < k ? 1.0 / sqrt(par[2 * kMaxComp + j]) : 0.0;
+        }
     }
 }
 
-// smallest BIC wins (first minimum, like np.argmin over n = 1..5)
+// n_selected = n_comps[argmin(bic)] over the fits that did not raise (first minimum, V3:780).  A row without samples keeps
+// n = 0 (the reference stores (0, 0) and scores with a sigma = 0.001 Gaussian, V3:765-766); a row all of whose fits raised
+// makes the reference raise too (argmin of an empty list): TW_ERR_FIT.
 __global__ void k_fit_select(FitDev F) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= F.n_slots) return;
@@ -286,15 +644,11 @@ __global__ void k_fit_select(FitDev F) {
         if (b < bic) { bic = b; best = k; }
     }
     F.mix_n[q] = best + 1;
-    for (int j = 0; j < kMaxComp; j++) {
-        double w = 0.0, mu = 0.0, pc = 0.0;
-        if (best >= 0 && j <= best) {
-            const double* m = F.models + (q * kMaxComp + best) * kModelStride;
-            w = m[1 + j]; mu = m[1 + kMaxComp + j]; pc = 1.0 / sqrt(m[1 + 2 * kMaxComp + j]);
-        }
-        F.mix_p[(q * kMaxComp + j) * 3 + 0] = w;
-        F.mix_p[(q * kMaxComp + j) * 3 + 1] = mu;
-        F.mix_p[(q * kMaxComp + j) * 3 + 2] = pc;
+    if (best < 0 && F.slot_scored[q] && F.row_n[q] > 0) atomicCAS(F.err, 0, (int)TW_ERR_FIT);
+    for (int j = 0; j < kMaxComp; j++) {   // (rows without samples; the others are written by the refit)
+        F.mix_p[(q * kMaxComp + j) * 3 + 0] = 0.0;
+        F.mix_p[(q * kMaxComp + j) * 3 + 1] = 0.0;
+        F.mix_p[(q * kMaxComp + j) * 3 + 2] = 0.0;
     }
 }
 

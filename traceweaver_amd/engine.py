@@ -192,9 +192,36 @@ class Engine(object):
             raise ValueError("mixture tables do not match the loaded batch")
         self._check(self._lib.tw_set_mixtures(self._h, _vp(n), _vp(p)))
 
-    def fit_mixtures(self):
-        """Device-side refit of every scored edge from the pass-1 gap samples (see csrc/tw_fit.h)."""
-        self._check(self._lib.tw_fit_mixtures(self._h))
+    FIT_ROW_DRAWS = (0, 1, 4, 11, 21, 34)   # uniforms the model-selection fits of a row draw, by min(5, #unique)
+
+    def fit_mixtures(self, tape=None, slot_off=None, seed=None, unit_seeds=None):
+        """The reference's refit of every scored edge on the device, from the pass-1 gap samples (csrc/tw_fit.h).
+        Without a tape the k-means++ draws come from the engine's own MT19937 (`seed` reseeds it first) or, with
+        `unit_seeds`, from one MT19937 per unit (a unit's fit then does not depend on its batch); with (tape, slot_off) --
+        per unit arrays of offsets [nslot] into one tape -- from the caller (see fit_rows)."""
+        if unit_seeds is not None:
+            sd = np.ascontiguousarray(unit_seeds, dtype=np.uint32)
+            if len(sd) != len(self.units):
+                raise ValueError("one seed per unit")
+            self._check(self._lib.tw_fit_mixtures_seeded(self._h, _vp(sd)))
+            return
+        if tape is None:
+            if seed is not None:
+                self._check(self._lib.tw_set_fit_seed(self._h, int(seed)))
+            self._check(self._lib.tw_fit_mixtures(self._h))
+            return
+        t = np.ascontiguousarray(tape, dtype=np.float64)
+        o = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int64).ravel() for a in slot_off]), dtype=np.int64)
+        if len(o) != self._slot_off[-1]:
+            raise ValueError("tape offsets do not match the loaded batch")
+        self._check(self._lib.tw_fit_mixtures_tape(self._h, _vp(t), len(t), _vp(o)))
+
+    def fit_rows(self):
+        """Per unit [nslot]: min(5, #distinct samples) of every gap row of the pass-1 result (0 = nothing to fit) -- the
+        number of model-selection fits of that edge, hence the uniforms they draw (FIT_ROW_DRAWS)."""
+        m = np.empty(int(self._slot_off[-1]), dtype=np.int32)
+        self._check(self._lib.tw_fit_rows(self._h, _vp(m)))
+        return [m[self._slot_off[k]:self._slot_off[k + 1]] for k in range(len(self.units))]
 
     def mixtures(self):
         """Per unit (mix_n [nslot], mix_p [nslot, 5, 3]) currently resident on the device."""

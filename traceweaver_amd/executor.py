@@ -26,10 +26,14 @@ as in the reference (repeat_change_spans never reads it), only shows up in the r
 What it does not do (and says so instead of approximating): the other predictor indices (the older TraceWeaver
 variants 0-2, 6, 8, 9), --cache_rate together with --compress_factor > 1, --parallel / --instrumented, tar archives
 (--compressed 1).  For those keep the reference's executor and register the predictor.
-The mixture refit between the passes is the reference's own procedure by default (`--fit sklearn`: scikit-learn on the
-host, numpy's global RNG seeded by --seed and replayed service by service, so a seeded run reproduces a seeded reference
-run); `--fit device` uses the deterministic batched device refit, whose figures agree with a reference run to within the
-run-to-run spread the reference itself has (its k-means++ start is drawn from an unseeded RNG, SURVEY.md hazard H9).
+The mixture refit between the passes is the reference's own procedure (traceweaver_v3.py:764-786) on the GPU (csrc/tw_fit.h).
+`--fit device` (default) feeds its k-means++ seedings the doubles numpy's global RNG would hand scikit-learn at that point of
+a reference run started with np.random.seed(--seed), service by service in the reference's order -- incl. the reseeding
+np.random.seed(10) the reference performs when it reaches the service named "frontend" (create_cache_hits runs for it at
+every cache rate, executor.py:1150-1152, helpers/transforms.py:155) -- so a seeded run reproduces a seeded reference run;
+`--fit sklearn` runs scikit-learn itself on the host at the same place (cross-check); `--fit device-batch` solves all
+services in one batch with draws from the engine's own MT19937(--seed): the same procedure on another random stream, as an
+unseeded reference run is (SURVEY.md hazard H9).
 """
 import argparse
 import os
@@ -67,12 +71,12 @@ def parse_args(argv=None):
     ap.add_argument("--replicas_file", type=q, default=None,
                     help="pickle {service: [replica ids]} for --compress_factor > 1 (default: data/misc/service_to_replica_new.pickle under --project_root, executor.py:912)")
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--fit", default="sklearn", choices=["device", "sklearn"],
-                    help="mixture refit between the passes.  'sklearn' (default: the reference's procedure, traceweaver_v3.py:764-786) = "
-                         "scikit-learn on the host, service by service in the reference's order with numpy's global RNG seeded by --seed: "
-                         "reproduces a reference run started with np.random.seed(seed) (SURVEY.md hazard H9; the passes themselves run on the "
-                         "GPU).  'device' = deterministic EM on the GPU, all services in one batch: fastest, accuracy within the spread the "
-                         "reference itself shows between seeds (up to a few pp on some corpora)")
+    ap.add_argument("--fit", default="device", choices=["device", "device-batch", "sklearn"],
+                    help="mixture refit between the passes: the reference's procedure (traceweaver_v3.py:764-786) in every case.  'device' "
+                         "(default) = on the GPU, service by service in the reference's order, k-means++ draws replayed from numpy's global "
+                         "RNG seeded by --seed: reproduces a reference run started with np.random.seed(seed) (SURVEY.md hazard H9).  "
+                         "'sklearn' = scikit-learn on the host at the same place (cross-check; the passes still run on the GPU).  "
+                         "'device-batch' = all services in one batch, draws from the engine's own MT19937(seed): fastest")
     ap.add_argument("--seed", type=int, default=10)
     ap.add_argument("--allow_partial", type=int, default=0, choices=[0, 1],
                     help="go on when services of the corpus cannot be solved here (skip mode, < 2 requests, cyclic call order); they are "
@@ -226,14 +230,18 @@ def run(args):
             plain = [k for k in range(len(units)) if k not in skip_units]
             per, res = [None] * len(units), [None] * len(units)
             flags = np.zeros((2, n_traces), dtype=np.uint8)
-            if plain and args.fit == "sklearn":   # the reference's own refit, its RNG stream replayed service by service
+            if plain and args.fit in ("sklearn", "device"):   # the reference's RNG stream replayed service by service
+                from . import skipmode
                 from .predictor import TraceWeaverGPU
 
                 eng.close()
-                pred = TraceWeaverGPU({}, {}, device=args.device, fit="sklearn", lib_path=args.engine_library)
+                pred = TraceWeaverGPU({}, {}, device=args.device, fit=args.fit, lib_path=args.engine_library)
                 np.random.seed(args.seed)
-                for k in plain:
-                    u = units[k]
+                for k, u in enumerate(units):
+                    if u.service == "frontend":   # executor.py:1150-1152: create_cache_hits reseeds (and draws) at every cache rate
+                        skipmode.cache_hit_draws(u.arrays.n_in, args.cache_rate)
+                    if k in skip_units:
+                        continue                  # one pass, no refit: no draws (traceweaver_v3.py:1155-1156,1221)
                     _, r2 = pred.solve_arrays(u.arrays, u.true_parent, u.service)
                     pred._engine.set_truth([u.true_parent], [u.in_trace], n_traces)
                     p_, _, f_ = pred._engine.evaluate(trace_flags=True)
@@ -253,7 +261,7 @@ def run(args):
             elif plain:
                 eng.load([units[k].arrays for k in plain])
                 eng.set_truth([units[k].true_parent for k in plain], [units[k].in_trace for k in plain], n_traces)
-            if plain and args.fit != "sklearn":
+            if plain and args.fit == "device-batch":
                 try:
                     eng.run_pass1()
                 except EngineError as ex:
@@ -262,7 +270,7 @@ def run(args):
                                          "traceweaver_v3.py:611). Keep a multiple-of-100-plus-anything-but-1 number of traces, "
                                          "e.g. --max_traces 1000." % ex)
                     raise
-                eng.fit_mixtures()
+                eng.fit_mixtures(seed=args.seed)
                 eng.run_pass2()
                 p_, _, f_ = eng.evaluate(trace_flags=True)
                 r_ = eng.results(2, fields=("parent", "unit_stats"))

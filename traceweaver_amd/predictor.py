@@ -80,11 +80,14 @@ def reference_fit_order(unit, partition_keys_rank):
 
 
 class TraceWeaverGPU(object):
-    def __init__(self, all_spans, all_processes, device=0, fit="sklearn", replay_true_fit=True, lib_path=None):
-        """fit = "sklearn": the reference's scikit-learn refit between the passes (host), in the reference's
-        call order; with `replay_true_fit` the (discarded) fits on the *true* assignments are replayed too,
-        because they advance numpy's global RNG (traceweaver_v3.py:796-818) -- a seeded run then reproduces
-        a seeded reference run.  fit = "device": deterministic EM on the GPU (csrc/tw_fit.h)."""
+    def __init__(self, all_spans, all_processes, device=0, fit="device", replay_true_fit=True, lib_path=None):
+        """The refit between the passes is the reference's procedure (traceweaver_v3.py:764-786) either way; its only
+        randomness -- the k-means++ draws of the model-selection fits -- comes from numpy's global RNG, consumed in the
+        reference's call order.  fit = "device" (default): the fits run on the GPU (csrc/tw_fit.h) on a tape of exactly
+        the doubles scikit-learn would draw; fit = "sklearn": scikit-learn itself on the host (cross-check).  With
+        `replay_true_fit` the draws of the fits the reference discards (on the *true* assignments, and the round it runs
+        again after the second pass, traceweaver_v3.py:796-818,1221-1222) are consumed too -- a seeded run then
+        reproduces a seeded reference run, and leaves the RNG where the reference leaves it for the next service."""
         self.all_spans = all_spans
         self.all_processes = all_processes
         self.fit = fit
@@ -104,6 +107,26 @@ class TraceWeaverGPU(object):
             row = self._gap_row(unit, true_parent, q)
             if len(row):
                 gmm.fit_edge_sklearn(row)
+
+    def _advance_rng(self, unit, parent):
+        """Consumes the uniforms the reference's fits on `parent` would draw (fit = "device": their results are never used).
+        Per edge with samples: n = 1..min(5, #unique) fits of 1, 3, 7, 10, 13 draws; the refit has its own seeded RNG."""
+        for q in reference_fit_order(unit, unit.key_rank):
+            row = self._gap_row(unit, parent, q)
+            if len(row):
+                np.random.random_sample(Engine.FIT_ROW_DRAWS[min(len(np.unique(row)), gmm.MAX_COMP)])
+
+    def _device_refit(self, unit, true_parent):
+        eng = self._engine
+        if self.replay_true_fit and true_parent is not None:
+            self._advance_rng(unit, true_parent)
+        max_n = eng.fit_rows()[0]
+        off = np.zeros(unit.nslot, dtype=np.int64)
+        pos = 0
+        for q in reference_fit_order(unit, unit.key_rank):
+            off[q] = pos
+            pos += Engine.FIT_ROW_DRAWS[int(max_n[q])]
+        eng.fit_mixtures(tape=np.random.random_sample(pos), slot_off=[off])
 
     def _host_refit(self, unit, gaps_pred, true_parent):
         order = reference_fit_order(unit, unit.key_rank)
@@ -144,7 +167,7 @@ class TraceWeaverGPU(object):
         traceweaver_amd.executor --fit sklearn calls it service by service).  true_parent [E, n_in] (or None) is only used to
         replay the reference's discarded fits on the true assignments (fit="sklearn", replay_true_fit).  Returns the result
         dicts of pass 1 (leaves) and pass 2 (everything)."""
-        if self.fit != "sklearn" or not self.replay_true_fit:
+        if not self.replay_true_fit:
             true_parent = None
         eng = self._engine
         eng.load([unit])
@@ -152,7 +175,7 @@ class TraceWeaverGPU(object):
         t1 = eng.timing()
         r1 = eng.results(1, fields=("leaves",))[0]
         if self.fit == "device":
-            eng.fit_mixtures()
+            self._device_refit(unit, true_parent)
         else:
             mix_n, mix_p = self._host_refit(unit, eng.gaps()[0], true_parent)
             eng.set_mixtures([mix_n], [mix_p])
@@ -163,11 +186,15 @@ class TraceWeaverGPU(object):
             # ComputeEpPairDistParams5 also runs after the second iteration (`if iterations > 1` sits inside the loop,
             # traceweaver_v3.py:1221-1222): its results are never used, but it advances numpy's global RNG by one more round
             # of fits on the true and on the pass-2 assignments -- what the next service of a seeded run starts from
-            self._replay_true_fit(unit, true_parent)
-            for q in reference_fit_order(unit, unit.key_rank):
-                row = self._gap_row(unit, r2["parent"], q)
-                if len(row):
-                    gmm.fit_edge_sklearn(row)
+            if self.fit == "device":
+                self._advance_rng(unit, true_parent)
+                self._advance_rng(unit, r2["parent"])
+            else:
+                self._replay_true_fit(unit, true_parent)
+                for q in reference_fit_order(unit, unit.key_rank):
+                    row = self._gap_row(unit, r2["parent"], q)
+                    if len(row):
+                        gmm.fit_edge_sklearn(row)
         self.last_stats = {k: r2[k] for k in ("not_best_count", "cnt_unassigned", "n_windows", "repaired_windows", "budget_windows")}
         if r2["budget_windows"]:
             warnings.warn("%d window(s) of service %r hit the node budget of the exact selection search: the selection returned "
@@ -220,7 +247,7 @@ class TraceWeaverGPU(object):
         if any(len(out_span_partitions[ep]) != n_in for ep in out_eps):   # traceweaver_v3.py:972,1155-1156: one pass with skip spans
             return self._find_assignments_skip(unit, in_ids, out_ids, out_eps, out_span_partitions, true_assignments)
         true_parent = None
-        if self.fit == "sklearn" and self.replay_true_fit and true_assignments is not None:
+        if self.replay_true_fit and true_assignments is not None:
             true_parent = np.full((unit.E, n_in), -1, dtype=np.int64)
             for k, ep in enumerate(out_eps):
                 pos = {sid: j for j, sid in enumerate(out_ids[k])}

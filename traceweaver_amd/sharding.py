@@ -98,8 +98,8 @@ def end_to_end_accuracy(trace_flags, dist=None, device="cpu"):
 #     at a multiple of 100 requests keeps every block whole, and at an idle moment the first i spans of every endpoint
 #     list are exactly the calls of the first i requests;
 #   * the mixture refit between the passes (:1221-1222): one fit per edge over the gap samples of the whole service --
-#     the one exchange step: the parts' gap rows are all-gathered and every rank runs the same deterministic device fit
-#     on the union (it depends only on the multiset of samples), then hands the table to its parts.
+#     the one exchange step: the parts' gap rows are all-gathered and every rank runs the same device fit on the union
+#     (rows joined in request order, the same seeded draws on every rank), then hands the table to its parts.
 # So a service is cut at idle moments that fall on block boundaries into parts that are ordinary units; the parts of
 # all services are spread over the ranks like whole services are; results are bit-identical to the unsplit run.
 
@@ -146,12 +146,12 @@ def split_unit(unit, cuts):
     return parts
 
 
-def refit_split_services(engine, fit_engine, local_parts, part_service, part_order, service_units, dist=None, device="cpu"):
+def refit_split_services(engine, fit_engine, local_parts, part_service, part_order, service_units, dist=None, device="cpu", seed=0):
     """The exchange step of split services.  `engine` holds this rank's parts (pass 1 done); local_parts = their global
     part ids, part_service[p] = service of part p, part_order[p] = position of part p inside its service,
     service_units[s] = the unsplit unit of service s (shape and size only).  Gathers the gap rows of all parts on every
     rank, fits every service's edges on the union with the device fit (`fit_engine`, any engine of this rank) and sets
-    the tables of the local parts.  Returns {service: (mix_n, mix_p)}."""
+    the tables of the local parts; the draws of service s come from MT19937(seed + s).  Returns {service: (mix_n, mix_p)}."""
     gaps = engine.gaps()
     rows = {p: g for p, g in zip(local_parts, gaps)}
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
@@ -185,7 +185,7 @@ def refit_split_services(engine, fit_engine, local_parts, part_service, part_ord
         mine = sorted((p for p in rows if part_service[p] == s), key=lambda p: part_order[p])
         joined.append(np.concatenate([rows[p] for p in mine], axis=1))
     fit_engine.set_gaps(joined)
-    fit_engine.fit_mixtures()
+    fit_engine.fit_mixtures(unit_seeds=[seed + s for s in services])   # one stream per service: every rank, and the unsplit run, draw the same
     for s, (mn, mp) in zip(services, fit_engine.mixtures()):
         tables[s] = (mn.copy(), mp.copy())
     engine.set_mixtures([tables[part_service[p]][0] for p in local_parts], [tables[part_service[p]][1] for p in local_parts])

@@ -26,6 +26,19 @@ class SkipPlan(object):
         self.large_delay = large_delay
 
 
+def cache_hit_draws(n, cache_rate, seed=10):
+    """The RNG side of create_cache_hits (helpers/transforms.py:155,197-203): numpy's global RNG is reseeded with 10 and
+    int(cache_rate * n) exponentials (unused) and as many indices without replacement, weights exp(-0.001 * index), are drawn
+    -- for the service named "frontend" at every cache rate (executor.py:1150-1152), also 0 (then only the reseeding
+    happens).  Returns the requests that become cache hits."""
+    np.random.seed(seed)                                                  # transforms.py:155
+    size = int(cache_rate * n)
+    np.random.exponential(scale=1 / 0.001, size=size)                     # drawn and not used (transforms.py:197)
+    p = np.asarray(np.exp(-0.001 * np.arange(n))).astype("float64")
+    p = p / np.sum(p)
+    return np.random.choice(np.arange(n), size=size, replace=False, p=p)
+
+
 def cache_hits(unit, true_parent, cache_rate, seed=10):
     """create_cache_hits (helpers/transforms.py:153-238): a fraction `cache_rate` of the requests, drawn without
     replacement with weights exp(-0.001 * index) from numpy's global RNG seeded with 10, lose their call to the FIRST
@@ -34,12 +47,7 @@ def cache_hits(unit, true_parent, cache_rate, seed=10):
     longer sorted.  Returns (unit as the predictor receives it, true_parent with -2 = ('Skip','Skip'), which spans of
     the first endpoint are kept)."""
     n, E = unit.n_in, unit.E
-    np.random.seed(seed)                                                  # transforms.py:155
-    size = int(cache_rate * n)
-    np.random.exponential(scale=1 / 0.001, size=size)                     # drawn and not used (transforms.py:197)
-    p = np.asarray(np.exp(-0.001 * np.arange(n))).astype("float64")
-    p = p / np.sum(p)
-    hit = np.random.choice(np.arange(n), size=size, replace=False, p=p)
+    hit = cache_hit_draws(n, cache_rate, seed)
     hit_mask = np.zeros(n, dtype=bool)
     hit_mask[hit] = True
     in_end = unit.in_end.copy()
