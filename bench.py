@@ -69,6 +69,10 @@ def parse_args():
     ap.add_argument("--verify", type=int, default=0, help="alibaba: rank 0 also solves the whole slice alone and compares the gathered parents")
     ap.add_argument("--fit", default="device", choices=["device", "sklearn"], help="mixture refit between the passes")
     ap.add_argument("--cpu-sample", type=int, default=40000, help="requests per service in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--regimes", type=int, default=1,
+                    help="default workload at N = 1 only: after the timed step loop, 3 steps each of the harder single-GPU regimes "
+                         "(config 3 shape, the config 4 slice on one GPU, media shape at concurrency 4 and 8) on the same engine, "
+                         "reported under `regimes` with their own roofline blocks")
     ap.add_argument("--end-to-end", type=int, default=1, help="also time JSON -> ingest -> H2D -> two passes -> parents on the host (rank 0, N = 1)")
     ap.add_argument("--host-traces", default="20000,15000", help="traces of the hotel- and the Alibaba-shape JSON corpus of the ingest / end-to-end legs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -153,6 +157,51 @@ def make_units(args, seed, n_in=None, replicas=None, total_spans=None):
     name = "alibaba_microservices shape, one %d-span slice (15 call graphs, %d services, ms-granular), sharded per service, concurrency %.1f" % (
         sum(x.n_spans for x in u), len(u), conc)
     return u, t, name
+
+
+REGIMES = [   # (key, workload, overrides): BASELINE.json configs 3 and 4 on one GPU, and the media shape at higher load
+    ("config3_nodejs", "nodejs", {"n_in": 20000, "replicas": 4}),
+    ("config4_alibaba_1gpu", "alibaba", {}),
+    ("media_concurrency4", "media", {"n_in": 20000, "replicas": 4, "concurrency": 4.0}),
+    ("media_concurrency8", "media", {"n_in": 5000, "replicas": 4, "concurrency": 8.0}),
+]
+
+
+def run_regimes(args, eng, steps=3):
+    """The harder single-GPU regimes next to the headline one, same engine, same step (two passes + refit + accuracy),
+    one warm-up step then `steps` timed ones each."""
+    import copy
+
+    out = {}
+    for key, workload, over in REGIMES:
+        a = copy.copy(args)
+        a.workload = workload
+        a.concurrency = over.get("concurrency")
+        units, truth, name = make_units(a, 1000, n_in=over.get("n_in"), replicas=over.get("replicas"))
+        spans = int(sum(u.n_spans for u in units))
+        eng.load(units)
+        eng.set_truth(truth)
+        one_step(eng, "device")
+        t0 = time.perf_counter()
+        en, se, rp, ft, rounds = [], [], [], [], []
+        for _ in range(steps):
+            t1, t2, res = one_step(eng, "device")
+            en += [t1["enumerate"], t2["enumerate"]]; se += [t1["select"], t2["select"]]; rp += [t1["repair"], t2["repair"]]
+            ft.append(t2["fit"]); rounds += [t1["rounds"], t2["rounds"]]
+        dt = (time.perf_counter() - t0) / steps
+        stats = eng.results(2, fields=("unit_stats",))
+        groups = {"k_enumerate": float(np.mean(en)), "k_select": float(np.mean(se)), "k_repair": float(np.mean(rp)), "k_fit": float(np.mean(ft))}
+        dominant = max(groups, key=lambda k: groups[k] * (1 if k == "k_fit" else 2))
+        achieved = ALG_BYTES_PER_SPAN_PER_PASS * spans / (groups[dominant] * 1e-3) / 1e9
+        n_req = sum(u.n_in for u in units)
+        out[key] = {"workload": name, "spans": spans, "value": spans / dt, "unit": "spans/s", "ms_per_step": dt * 1e3, "steps": steps,
+                    "accuracy": float(sum(r["accuracy"] * u.n_in for r, u in zip(res, units)) / n_req),
+                    "budget_windows": int(sum(r["budget_windows"] for r in stats)), "repaired_windows": int(sum(r["repaired_windows"] for r in stats)),
+                    "repair_rounds_per_pass": float(np.mean(rounds)),
+                    "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": achieved / HBM_PEAK_GBPS, "kernel_ms": groups[dominant], "group_ms_per_launch": groups,
+                                 "algorithmic_bytes_per_launch": float(ALG_BYTES_PER_SPAN_PER_PASS * spans), "traffic": None}}
+    return out
 
 
 def cpu_baseline(args, seed):
@@ -522,6 +571,8 @@ def main():
             out["sharded_equals_single_gpu"] = bool(verified)
         if not emulated and world == 1:
             out["roofline"]["peak_measured"] = eng.hbm_copy_gbps()
+        if args.regimes and world == 1 and not emulated and args.workload == "media" and args.concurrency is None:
+            out["regimes"] = run_regimes(args, eng)
         if args.cpu_sample > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, 1000)
             import tempfile

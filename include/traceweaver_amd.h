@@ -153,7 +153,7 @@ int tw_set_mixtures(tw_engine *e, const int32_t *mix_n, const double *mix_p);
  * samples), independent of the data.
  *
  * tw_fit_mixtures draws them from the engine's own MT19937 (numpy's RandomState algorithm; tw_set_fit_seed reseeds it,
- * tw_create seeds it with 0; one 34-double block per slot and call): the reference's procedure on *a* random stream, as
+ * tw_create seeds it with 0, tw_load_batch restarts it; one 34-double block per slot and call): the reference's procedure on *a* random stream, as
  * the reference itself runs it unseeded (SURVEY.md hazard H9).  tw_fit_mixtures_seeded gives every unit a stream of its own,
  * MT19937(unit_seed[u]): a unit's fit is then the same whichever units share its batch (services sharded over GPUs).
  * tw_fit_mixtures_tape takes them from the caller: slot q reads tape[slot_off[q] ...], as many doubles as its fits draw

@@ -102,12 +102,14 @@ struct tw_engine {
     double* fit_models = nullptr;
     double* fit_uval = nullptr;
     int32_t *fit_ustart = nullptr, *fit_row_n = nullptr, *fit_row_uniq = nullptr;
+    double* fit_dbg = nullptr;
     double *fit_tape = nullptr, *fit_tape100 = nullptr;   // uniforms of the k-means++ seedings: model-selection fits / the refit (MT19937(100))
     int64_t* fit_tape_off = nullptr;
     int64_t fit_tape_cap = 0;
     bool fit_prepared = false;              // the gap rows of the resident pass-1 result are sorted and run-length compressed
     std::vector<int32_t> fit_max_n;         // per slot min(5, #unique), 0 = nothing to fit (host copy, tw_fit_rows)
-    Mt19937 fit_rng;                        // stream of tw_fit_mixtures (tw_set_fit_seed)
+    Mt19937 fit_rng;                        // stream of tw_fit_mixtures (tw_set_fit_seed; restarted by every tw_load_batch)
+    uint32_t fit_seed = 0;
     int32_t* slot_unit = nullptr;
     int32_t* tile_ids = nullptr;            // tiles grouped by the unit's endpoint count
     int32_t tile_cls_off[kMaxEp + 2] = {};  // class E owns tile_ids[tile_cls_off[E] .. tile_cls_off[E+1])
@@ -687,6 +689,8 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     if (b->topk != TW_TOPK) return fail(e, TW_ERR_UNSUPPORTED, "topk must be 5 (traceweaver_v3.py:1109)");
     if (b->batch_size <= 0 || b->batch_size_mis <= 0) return fail(e, TW_ERR_ARG, "batch sizes must be positive");
     free_all(e);
+    e->fit_rng = Mt19937(e->fit_seed);   // a batch's refit does not depend on what the engine solved before
+    e->fit_prepared = false;
     e->units.assign((size_t)b->n_units, UnitDev{});
     e->tiles.clear();
     e->gs_off_h.assign((size_t)b->n_units, 0);
@@ -878,6 +882,9 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(e->fit_uval, gaps); ALLOC(e->fit_ustart, gaps); ALLOC(e->fit_row_n, slots); ALLOC(e->fit_row_uniq, slots);
     ALLOC(e->fit_tape, slots * kFitRowTape); ALLOC(e->fit_tape_off, slots); ALLOC(e->fit_tape100, kMaxComp * 13);
     e->fit_tape_cap = slots * kFitRowTape;
+#ifdef TW_FIT_DEBUG
+    ALLOC(e->fit_dbg, slots * kMaxComp * 16);
+#endif
     ALLOC(e->slot_unit, slots); ALLOC(e->slot_scored, slots);
     ALLOC(e->seg_gap, (int64_t)seg_gap_h.size()); ALLOC(e->seg_gap_end, (int64_t)seg_gap_end_h.size()); ALLOC(e->seg_gap_dst, (int64_t)seg_gap_dst_h.size());
     e->comp_cap = std::max(std::max(n_in_total, n_out_total), e->n_gap_scored);
@@ -1021,7 +1028,7 @@ FitDev fit_dev(tw_engine* e) {
     F.units = e->P.units; F.n_units = e->P.n_units; F.n_slots = e->n_slots; F.gaps = e->P.gaps; F.sorted = e->gaps_sorted;
     F.gs_off = e->P.gs_off; F.slot_unit = e->slot_unit; F.slot_scored = e->slot_scored; F.models = e->fit_models; F.mix_n = e->mix_n_dev; F.mix_p = e->mix_p_dev;
     F.uval = e->fit_uval; F.ustart = e->fit_ustart; F.row_n = e->fit_row_n; F.row_uniq = e->fit_row_uniq;
-    F.tape = e->fit_tape; F.tape_off = e->fit_tape_off; F.tape100 = e->fit_tape100; F.err = e->P.err;
+    F.tape = e->fit_tape; F.tape_off = e->fit_tape_off; F.tape100 = e->fit_tape100; F.err = e->P.err; F.dbg = e->fit_dbg;
     return F;
 }
 
@@ -1101,6 +1108,7 @@ int fit_check_state(tw_engine* e, const char* who) {
 
 int tw_set_fit_seed(tw_engine* e, uint32_t seed) {
     if (e == nullptr) return TW_ERR_ARG;
+    e->fit_seed = seed;
     e->fit_rng = Mt19937(seed);
     return TW_OK;
 }
@@ -1449,6 +1457,19 @@ void tw_host_free(void* p) {
 /* Debug aid, not part of the public header: sizes of the work lists of the last pass --
  * out[0] = windows listed for k_select_heavy, out[1 + E] = spans listed for k_enumerate_heavy<E> (E <= kMaxEp),
  * out[2 + kMaxEp] = spans enumerated in parts, out[3 + kMaxEp] = of those, enumerated once more as a whole (out: 4 + kMaxEp ints). */
+/* Debug aid, not part of the public header: the model-selection fits of the last refit, [n_slots][5][16] = BIC (inf = raised),
+ * weights[5], means[5], precision_cholesky[5]. */
+extern "C" int tw_debug_fit_models(tw_engine* e, double* out) {
+    if (e == nullptr || out == nullptr) return TW_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(out, e->fit_models, sizeof(double) * e->n_slots * kMaxComp * kModelStride, hipMemcpyDeviceToHost, e->stream));
+#ifdef TW_FIT_DEBUG
+    HIPCHK(hipMemcpyAsync(out + e->n_slots * kMaxComp * kModelStride, e->fit_dbg, sizeof(double) * e->n_slots * kMaxComp * 16, hipMemcpyDeviceToHost, e->stream));
+#endif
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TW_OK;
+}
+
 int tw_debug_worklists(tw_engine* e, int32_t* out) {
     if (e == nullptr || out == nullptr || e->state < ST_PASS1) return TW_ERR_ARG;
     static int32_t sel_all[4 * kSelSeg * kCtrStride];

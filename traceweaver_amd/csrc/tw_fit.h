@@ -68,6 +68,7 @@ struct FitDev {
     const int64_t* tape_off;  // [n_slots] first double of the row's fits (n = 1, 2, ... behind one another)
     const double* tape100;  // [kMaxComp][13] draws of the refit with n components: MT19937(100)
     int32_t* err;
+    double* dbg;            // -DTW_FIT_DEBUG: [n_slots][kMaxComp][16] k-means++ centres, Lloyd centres, iteration counts
 };
 
 // deterministic block reduction of `cnt` doubles per thread: lanes of a wavefront by shuffles (fixed
@@ -184,13 +185,14 @@ template <bool kFull>
 __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
     __shared__ double sh[kFitStats * kFitWaves];
     __shared__ double par[3 * kMaxComp];              // weights, means, covariances
-    __shared__ double cen[kMaxComp], cen_prev[kMaxComp];
+    __shared__ double cen[kMaxComp];
     __shared__ double seg[kFitMaxTrials][kFitWaves];  // per trial candidate: sum over a wavefront's stretch of the row of the closest squared distances
     __shared__ double cand[kFitMaxTrials][kFitWaves]; // first crossing found by each wavefront (NaN = none)
     __shared__ double lastv[kFitWaves];
     __shared__ int32_t lasti[kFitWaves], cnt_w[kFitWaves];
-    const int64_t q = kFull ? (int64_t)blockIdx.x : (int64_t)(blockIdx.x / kMaxComp);
-    const int k = kFull ? F.mix_n[q] : (int)(blockIdx.x % kMaxComp) + 1;
+    // model selection: the fits with the most components first (they run longest)
+    const int64_t q = kFull ? (int64_t)blockIdx.x : (int64_t)(blockIdx.x % F.n_slots);
+    const int k = kFull ? F.mix_n[q] : kMaxComp - (int)(blockIdx.x / F.n_slots);
     const int t = threadIdx.x, nt = blockDim.x;
     const int W = nt < 64 ? nt : 64, lane = t & 63, wave = t >> 6, nwave = (nt + 63) >> 6;
     const UnitDev& U = F.units[F.slot_unit[q]];
@@ -373,17 +375,29 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
             __syncthreads();
         }
 
-        // ---- Lloyd iterations (_kmeans_single_lloyd) over the runs
+#ifdef TW_FIT_DEBUG
+        if (!kFull && t == 0) for (int j = 0; j < k; j++) F.dbg[(q * kMaxComp + (k - 1)) * 16 + j] = cen[j] + mean;
+        int dbg_it = 0;
+#endif
+        // ---- Lloyd iterations (_kmeans_single_lloyd) over the runs.  Every thread holds the centres in registers: the sums
+        // come back from the reduction to all threads, so all compute the same update.
+        double cc[kMaxComp], cp[kMaxComp];
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) { cc[j] = j < k ? cen[j] : 0.0; cp[j] = 0.0; }
         bool strict = false;
         for (int it = 0; it < kKmMaxIter; it++) {
+#ifdef TW_FIT_DEBUG
+            dbg_it = it + 1;
+#endif
             double v[2 * kMaxComp + 1];
 #pragma unroll
             for (int j = 0; j < 2 * kMaxComp + 1; j++) v[j] = 0.0;
             for (int r = t; r < uniq; r += nt) {
                 const double xc = xv[r] - mean;
                 const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
-                const int lab = fit_label(cen, k, xc);
-                if (it == 0 || fit_label(cen_prev, k, xc) != lab) v[2 * kMaxComp] = 1.0;   // labels != labels_old
+                const int lab = fit_label(cc, k, xc);
+                const int old = it == 0 ? -1 : fit_label(cp, k, xc);
+                if (old != lab) v[2 * kMaxComp] += 1.0;   // labels != labels_old
 #pragma unroll
                 for (int j = 0; j < kMaxComp; j++) if (j == lab) { v[j] += cw; v[kMaxComp + j] += xc * cw; }
             }
@@ -405,7 +419,11 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
                             for (int z = 0; z < ntaken; z++) if (taken_run[z] == r) used = taken_cnt[z];
                             if ((r + 1 < uniq ? xa[r + 1] : n) - xa[r] <= used) continue;
                             const double xc = xv[r] - mean;
-                            const double d0 = xc - cen[fit_label(cen, k, xc)];
+                            const int lb = fit_label(cc, k, xc);
+                            double cl = cc[0];
+#pragma unroll
+                            for (int j = 1; j < kMaxComp; j++) if (j == lb) cl = cc[j];
+                            const double d0 = xc - cl;
                             if (d0 * d0 > fd) { fd = d0 * d0; fr = r; }
                         }
                         if (fr < 0) break;
@@ -413,10 +431,12 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
                         for (int z = 0; z < ntaken; z++) if (taken_run[z] == fr) { taken_cnt[z]++; again = true; }
                         if (!again) { taken_run[ntaken] = fr; taken_cnt[ntaken] = 1; ntaken++; }
                         const double xc = xv[fr] - mean;
-                        const int old = fit_label(cen, k, xc);
-                        sh[old] = 1.0;  // (marker only; the sums are adjusted below)
-                        v[kMaxComp + old] -= xc; v[old] -= 1.0;
-                        v[kMaxComp + e] = xc; v[e] = 1.0;
+                        const int old = fit_label(cc, k, xc);
+#pragma unroll
+                        for (int j = 0; j < kMaxComp; j++) {
+                            if (j == old) { v[kMaxComp + j] -= xc; v[j] -= 1.0; }
+                            if (j == e) { v[kMaxComp + j] = xc; v[j] = 1.0; }
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < kMaxComp; j++) { par[j] = v[j]; par[kMaxComp + j] = v[kMaxComp + j]; }
@@ -427,105 +447,107 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
                 __syncthreads();
             }
             double shift = 0.0;
-            double nc[kMaxComp];
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) {
-                nc[j] = 0.0;
                 if (j < k) {
-                    nc[j] = v[kMaxComp + j] * (1.0 / v[j]);   // _average_centers: the sum times the reciprocal of the weight
-                    const double d = nc[j] - cen[j];
-                    const double s = sqrt(d * d);               // _center_shift, then (center_shift ** 2).sum()
-                    shift += s * s;
+                    const double nc = v[kMaxComp + j] * (1.0 / v[j]);   // _average_centers: the sum times the reciprocal of the weight
+                    const double d = nc - cc[j];
+                    const double sd = sqrt(d * d);                      // _center_shift, then (center_shift ** 2).sum()
+                    shift += sd * sd;
+                    cp[j] = cc[j];
+                    cc[j] = nc;
                 }
             }
-            __syncthreads();
-            if (t == 0) {
-#pragma unroll
-                for (int j = 0; j < kMaxComp; j++) if (j < k) { cen_prev[j] = cen[j]; cen[j] = nc[j]; }
-            }
-            __syncthreads();
             if (v[2 * kMaxComp] == 0.0) { strict = true; break; }
             if (shift <= km_tol) break;
         }
         // the labels KMeans returns: those of the last assignment (strict convergence) or a fresh one under the final centres
-        if (strict) {
-            __syncthreads();
-            if (t == 0) {
+        __syncthreads();
+        if (t == 0) {
 #pragma unroll
-                for (int j = 0; j < kMaxComp; j++) if (j < k) cen[j] = cen_prev[j];
-            }
-            __syncthreads();
+            for (int j = 0; j < kMaxComp; j++) if (j < k) cen[j] = strict ? cp[j] : cc[j];
         }
+        __syncthreads();
+#ifdef TW_FIT_DEBUG
+        if (!kFull && t == 0) {
+            for (int j = 0; j < k; j++) F.dbg[(q * kMaxComp + (k - 1)) * 16 + 5 + j] = cen[j] + mean;
+            F.dbg[(q * kMaxComp + (k - 1)) * 16 + 10] = (double)dbg_it;
+            F.dbg[(q * kMaxComp + (k - 1)) * 16 + 11] = strict ? 1.0 : 0.0;
+            F.dbg[(q * kMaxComp + (k - 1)) * 16 + 12] = km_tol;
+        }
+#endif
     } else {
         if (t == 0) cen[0] = 0.0;
         __syncthreads();
     }
 
-    // ---- GaussianMixture._initialize: one-hot responsibilities of the k-means labels, then the M step
+    // ---- GaussianMixture._initialize: one-hot responsibilities of the k-means labels, then the M step.  From here on the
+    // parameters live in registers: every reduction hands its sums to all threads, all compute the same update.
     bool failed = false;
+    double pw[kMaxComp], pm[kMaxComp], pv[kMaxComp];   // weights, means, covariances
     {
+        double cc[kMaxComp];
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) cc[j] = j < k ? cen[j] : 0.0;
         double v[3 * kMaxComp];
 #pragma unroll
         for (int j = 0; j < 3 * kMaxComp; j++) v[j] = 0.0;
         for (int r = t; r < uniq; r += nt) {
             const double x = xv[r];
             const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
-            const int lab = k > 1 ? fit_label(cen, k, x - mean) : 0;
+            const int lab = k > 1 ? fit_label(cc, k, x - mean) : 0;
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) if (j == lab) { v[j] += cw; v[kMaxComp + j] += cw * x; v[2 * kMaxComp + j] += cw * (x * x); }
         }
         block_reduce<3 * kMaxComp>(v, sh);
-        double mu[kMaxComp], nk[kMaxComp];
 #pragma unroll
-        for (int j = 0; j < kMaxComp; j++) { nk[j] = v[j] + kEps10; mu[j] = j < k ? v[kMaxComp + j] / nk[j] : 0.0; }
-        if (kFull) {
+        for (int j = 0; j < kMaxComp; j++) {
+            const double nk = v[j] + kEps10;
+            pw[j] = nk / dn;
+            pm[j] = j < k ? v[kMaxComp + j] / nk : 0.0;
+            pv[j] = (v[2 * kMaxComp + j] / nk - pm[j] * pm[j]) + kFitRegCovar;   // _estimate_gaussian_covariances_diag
+        }
+        if (kFull) {   // _estimate_gaussian_covariances_full: squared deviations from the means
             double c2[kMaxComp];
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) c2[j] = 0.0;
             for (int r = t; r < uniq; r += nt) {
                 const double x = xv[r];
                 const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
-                const int lab = k > 1 ? fit_label(cen, k, x - mean) : 0;
+                const int lab = k > 1 ? fit_label(cc, k, x - mean) : 0;
 #pragma unroll
-                for (int j = 0; j < kMaxComp; j++) if (j == lab) { const double d = x - mu[j]; c2[j] += cw * (d * d); }
+                for (int j = 0; j < kMaxComp; j++) if (j == lab) { const double d = x - pm[j]; c2[j] += cw * (d * d); }
             }
             block_reduce<kMaxComp>(c2, sh);
 #pragma unroll
-            for (int j = 0; j < kMaxComp; j++) v[2 * kMaxComp + j] = c2[j] / nk[j] + kFitRegCovar;
-        } else {
-#pragma unroll
-            for (int j = 0; j < kMaxComp; j++) v[2 * kMaxComp + j] = (v[2 * kMaxComp + j] / nk[j] - mu[j] * mu[j]) + kFitRegCovar;
+            for (int j = 0; j < kMaxComp; j++) pv[j] = c2[j] / (v[j] + kEps10) + kFitRegCovar;
         }
 #pragma unroll
-        for (int j = 0; j < kMaxComp; j++) if (j < k && !(v[2 * kMaxComp + j] > 0.0)) failed = true;
-        if (t == 0) {
-#pragma unroll
-            for (int j = 0; j < kMaxComp; j++) if (j < k) { par[j] = nk[j] / dn; par[kMaxComp + j] = mu[j]; par[2 * kMaxComp + j] = v[2 * kMaxComp + j]; }
-        }
-        __syncthreads();
+        for (int j = 0; j < kMaxComp; j++) if (j < k && !(pv[j] > 0.0)) failed = true;
     }
 
-    // ---- EM (BaseMixture.fit_predict); the last round only scores the final parameters (bic() re-scores)
+    // ---- EM (BaseMixture.fit_predict); the last round only scores the final parameters (bic() re-scores).
+    // Responsibilities as exp(wl - max) / sum (scikit-learn: exp(wl - logsumexp), the same number up to rounding): one
+    // exponential per component and sample.  The full-covariance M step takes its moments around the previous means
+    // (exact algebra of sum r (x - new mean)^2; the shift of a mean per iteration is small against the spread).
     double lower = -dinf();
     bool last = false;
     for (int iter = 0; iter <= kFitMaxIter && !failed; iter++) {
         if (iter == kFitMaxIter) last = true;
-        double lw[kMaxComp], mu[kMaxComp], pc[kMaxComp], a0[kMaxComp], a1[kMaxComp], a2[kMaxComp], v[kFitStats];
+        double a0[kMaxComp], a1[kMaxComp], a2[kMaxComp], cst[kMaxComp], v[kFitStats];
 #pragma unroll
         for (int j = 0; j < kMaxComp; j++) {
-            lw[j] = -dinf(); mu[j] = 0.0; pc[j] = 0.0; a0[j] = 0.0; a1[j] = 0.0; a2[j] = 0.0;
+            a0[j] = 0.0; a1[j] = 0.0; a2[j] = 0.0; cst[j] = 0.0;
             if (j < k) {
-                mu[j] = par[kMaxComp + j];
-                pc[j] = 1.0 / sqrt(par[2 * kMaxComp + j]);   // _compute_precision_cholesky
-                lw[j] = tw_log(par[j]);
-                if (kFull) { a0[j] = mu[j] * pc[j]; }
-                else { const double prec = pc[j] * pc[j]; a0[j] = (mu[j] * mu[j]) * prec; a1[j] = mu[j] * prec; a2[j] = prec; }
-                a2[j] = kFull ? 0.0 : a2[j];
+                const double pc = 1.0 / sqrt(pv[j]);   // _compute_precision_cholesky
+                if (kFull) { a0[j] = pm[j] * pc; a1[j] = pc; }
+                else { const double prec = pc * pc; a0[j] = (pm[j] * pm[j]) * prec; a1[j] = pm[j] * prec; a2[j] = prec; }
+                cst[j] = log(pc);
             }
         }
-        double ld[kMaxComp];
+        double lwt[kMaxComp];
 #pragma unroll
-        for (int j = 0; j < kMaxComp; j++) ld[j] = j < k ? tw_log(pc[j]) : 0.0;
+        for (int j = 0; j < kMaxComp; j++) lwt[j] = j < k ? log(pw[j]) : 0.0;
 #pragma unroll
         for (int c = 0; c < kFitStats; c++) v[c] = 0.0;
         for (int r = t; r < uniq; r += nt) {
@@ -537,26 +559,26 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
                 wl[j] = -dinf();
                 if (j < k) {
                     double lp;
-                    if (kFull) { const double y = x * pc[j] - a0[j]; lp = y * y; }                       // _estimate_log_gaussian_prob, "full"
+                    if (kFull) { const double y = x * a1[j] - a0[j]; lp = y * y; }                       // _estimate_log_gaussian_prob, "full"
                     else lp = (a0[j] - 2.0 * (x * a1[j])) + (x * x) * a2[j];                             // ... "diag"
-                    wl[j] = (-0.5 * (kLog2Pi + lp) + ld[j]) + lw[j];
+                    wl[j] = (-0.5 * (kLog2Pi + lp) + cst[j]) + lwt[j];
                     if (wl[j] > mx) mx = wl[j];
                 }
             }
             double s = 0.0;
 #pragma unroll
-            for (int j = 0; j < kMaxComp; j++) if (j < k) s += tw_exp(wl[j] - mx);
-            const double lpn = tw_log(s) + mx;   // scipy.special.logsumexp
-            v[3 * kMaxComp] += cw * lpn;
+            for (int j = 0; j < kMaxComp; j++) { wl[j] = j < k ? exp(wl[j] - mx) : 0.0; s += wl[j]; }
+            v[3 * kMaxComp] += cw * (log(s) + mx);   // scipy.special.logsumexp
             if (!last) {
+                const double inv = cw / s;
 #pragma unroll
                 for (int j = 0; j < kMaxComp; j++) {
                     if (j < k) {
-                        const double rj = tw_exp(wl[j] - lpn) * cw;   // resp = exp(log_resp)
+                        const double rj = wl[j] * inv;
+                        const double d = kFull ? x - pm[j] : x;
                         v[j] += rj;
-                        v[kMaxComp + j] += rj * x;
-                        if (kFull) { const double d = x - mu[j]; (void)d; }
-                        else v[2 * kMaxComp + j] += rj * (x * x);
+                        v[kMaxComp + j] += rj * d;
+                        v[2 * kMaxComp + j] += rj * (d * d);
                     }
                 }
             }
@@ -564,49 +586,21 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
         block_reduce<kFitStats>(v, sh);
         const double lb = v[3 * kMaxComp] / dn;
         if (last) { lower = lb; break; }
-        double nk[kMaxComp], nm[kMaxComp], nks = 0.0;
+        double nks = 0.0;
 #pragma unroll
-        for (int j = 0; j < kMaxComp; j++) { nk[j] = 0.0; nm[j] = 0.0; if (j < k) { nk[j] = v[j] + kEps10; nm[j] = v[kMaxComp + j] / nk[j]; nks += nk[j]; } }
-        double cov[kMaxComp];
-        if (kFull) {   // covariances around the *new* means: a second sweep with the same responsibilities
-            double c2[kMaxComp];
-#pragma unroll
-            for (int j = 0; j < kMaxComp; j++) c2[j] = 0.0;
-            for (int r = t; r < uniq; r += nt) {
-                const double x = xv[r];
-                const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
-                double wl[kMaxComp], mx = -dinf();
-#pragma unroll
-                for (int j = 0; j < kMaxComp; j++) {
-                    wl[j] = -dinf();
-                    if (j < k) {
-                        const double y = x * pc[j] - a0[j];
-                        wl[j] = (-0.5 * (kLog2Pi + y * y) + ld[j]) + lw[j];
-                        if (wl[j] > mx) mx = wl[j];
-                    }
-                }
-                double s = 0.0;
-#pragma unroll
-                for (int j = 0; j < kMaxComp; j++) if (j < k) s += tw_exp(wl[j] - mx);
-                const double lpn = tw_log(s) + mx;
-#pragma unroll
-                for (int j = 0; j < kMaxComp; j++) if (j < k) { const double d = x - nm[j]; c2[j] += (tw_exp(wl[j] - lpn) * cw) * (d * d); }
+        for (int j = 0; j < kMaxComp; j++) {
+            if (j < k) {
+                const double nk = v[j] + kEps10;
+                const double m1 = v[kMaxComp + j] / nk;
+                pw[j] = nk;
+                nks += nk;
+                pv[j] = (v[2 * kMaxComp + j] / nk - m1 * m1) + kFitRegCovar;
+                pm[j] = kFull ? pm[j] + m1 : m1;
+                if (!(pv[j] > 0.0)) failed = true;
             }
-            block_reduce<kMaxComp>(c2, sh);
-#pragma unroll
-            for (int j = 0; j < kMaxComp; j++) cov[j] = c2[j] / nk[j] + kFitRegCovar;
-        } else {
-#pragma unroll
-            for (int j = 0; j < kMaxComp; j++) cov[j] = j < k ? (v[2 * kMaxComp + j] / nk[j] - nm[j] * nm[j]) + kFitRegCovar : 1.0;
         }
 #pragma unroll
-        for (int j = 0; j < kMaxComp; j++) if (j < k && !(cov[j] > 0.0)) failed = true;
-        __syncthreads();
-        if (t == 0) {
-#pragma unroll
-            for (int j = 0; j < kMaxComp; j++) if (j < k) { par[j] = nk[j] / nks; par[kMaxComp + j] = nm[j]; par[2 * kMaxComp + j] = cov[j]; }
-        }
-        __syncthreads();
+        for (int j = 0; j < kMaxComp; j++) if (j < k) pw[j] /= nks;
         const double change = lb - lower;
         lower = lb;
         if (fabs(change) < kFitTol) last = true;   // converged: one more sweep scores the parameters just set
@@ -616,17 +610,17 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
         if (failed) { atomicCAS(F.err, 0, (int)TW_ERR_FIT); return; }
 #pragma unroll
         for (int j = 0; j < kMaxComp; j++) {
-            F.mix_p[(q * kMaxComp + j) * 3 + 0] = j < k ? par[j] : 0.0;
-            F.mix_p[(q * kMaxComp + j) * 3 + 1] = j < k ? par[kMaxComp + j] : 0.0;
-            F.mix_p[(q * kMaxComp + j) * 3 + 2] = j < k ? 1.0 / sqrt(par[2 * kMaxComp + j]) : 0.0;
+            F.mix_p[(q * kMaxComp + j) * 3 + 0] = j < k ? pw[j] : 0.0;
+            F.mix_p[(q * kMaxComp + j) * 3 + 1] = j < k ? pm[j] : 0.0;
+            F.mix_p[(q * kMaxComp + j) * 3 + 2] = j < k ? 1.0 / sqrt(pv[j]) : 0.0;
         }
     } else {
-        model[0] = failed ? dinf() : -2.0 * lower * dn + (double)(3 * k - 1) * tw_log(dn);   // GaussianMixture.bic
+        model[0] = failed ? dinf() : -2.0 * lower * dn + (double)(3 * k - 1) * log(dn);   // GaussianMixture.bic
 #pragma unroll
         for (int j = 0; j < kMaxComp; j++) {
-            model[1 + j] = j < k ? par[j] : 0.0;
-            model[1 + kMaxComp + j] = j < k ? par[kMaxComp + j] : 0.0;
-            model[1 + 2 * kMaxComp + j] = j < k ? 1.0 / sqrt(par[2 * kMaxComp + j]) : 0.0;
+            model[1 + j] = j < k ? pw[j] : 0.0;
+            model[1 + kMaxComp + j] = j < k ? pm[j] : 0.0;
+            model[1 + 2 * kMaxComp + j] = j < k ? 1.0 / sqrt(pv[j]) : 0.0;
         }
     }
 }
