@@ -12,7 +12,8 @@ SOURCES = ["tw_engine.hip", "tw_kernels.h", "tw_device.h", "tw_fit.h", "tw_eval.
 
 # -ffp-contract=off: scores are chains of plain IEEE double operations in the reference's order;
 # an FMA would change the last bit and with it the resolution of exact ties (DESIGN.md "Scores").
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
+         "-DTW_FIT_SEED_ATTR=__attribute__((amdgpu_waves_per_eu(4)))"]
 
 
 def source_digest():

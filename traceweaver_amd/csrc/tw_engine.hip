@@ -102,7 +102,7 @@ struct tw_engine {
     double* fit_models = nullptr;
     double* fit_uval = nullptr;
     int32_t *fit_ustart = nullptr, *fit_row_n = nullptr, *fit_row_uniq = nullptr;
-    double* fit_dbg = nullptr;
+    double* fit_centres = nullptr;
     double *fit_tape = nullptr, *fit_tape100 = nullptr;   // uniforms of the k-means++ seedings: model-selection fits / the refit (MT19937(100))
     int64_t* fit_tape_off = nullptr;
     int64_t fit_tape_cap = 0;
@@ -882,9 +882,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(e->fit_uval, gaps); ALLOC(e->fit_ustart, gaps); ALLOC(e->fit_row_n, slots); ALLOC(e->fit_row_uniq, slots);
     ALLOC(e->fit_tape, slots * kFitRowTape); ALLOC(e->fit_tape_off, slots); ALLOC(e->fit_tape100, kMaxComp * 13);
     e->fit_tape_cap = slots * kFitRowTape;
-#ifdef TW_FIT_DEBUG
-    ALLOC(e->fit_dbg, slots * kMaxComp * 16);
-#endif
+    ALLOC(e->fit_centres, slots * kMaxComp * (kMaxComp + 1));
     ALLOC(e->slot_unit, slots); ALLOC(e->slot_scored, slots);
     ALLOC(e->seg_gap, (int64_t)seg_gap_h.size()); ALLOC(e->seg_gap_end, (int64_t)seg_gap_end_h.size()); ALLOC(e->seg_gap_dst, (int64_t)seg_gap_dst_h.size());
     e->comp_cap = std::max(std::max(n_in_total, n_out_total), e->n_gap_scored);
@@ -1028,7 +1026,7 @@ FitDev fit_dev(tw_engine* e) {
     F.units = e->P.units; F.n_units = e->P.n_units; F.n_slots = e->n_slots; F.gaps = e->P.gaps; F.sorted = e->gaps_sorted;
     F.gs_off = e->P.gs_off; F.slot_unit = e->slot_unit; F.slot_scored = e->slot_scored; F.models = e->fit_models; F.mix_n = e->mix_n_dev; F.mix_p = e->mix_p_dev;
     F.uval = e->fit_uval; F.ustart = e->fit_ustart; F.row_n = e->fit_row_n; F.row_uniq = e->fit_row_uniq;
-    F.tape = e->fit_tape; F.tape_off = e->fit_tape_off; F.tape100 = e->fit_tape100; F.err = e->P.err; F.dbg = e->fit_dbg;
+    F.tape = e->fit_tape; F.tape_off = e->fit_tape_off; F.tape100 = e->fit_tape100; F.err = e->P.err; F.centres = e->fit_centres;
     return F;
 }
 
@@ -1078,9 +1076,11 @@ int fit_run(tw_engine* e) {
     HIPCHK(hipMemsetAsync(e->P.err, 0, sizeof(int32_t), e->stream));
     FitDev F = fit_dev(e);
     const int threads = e->coop >= 64 ? kFitThreads : e->coop;
-    hipLaunchKernelGGL(k_fit_gmm<false>, dim3((unsigned)(e->n_slots * kMaxComp)), dim3(threads), 0, e->stream, F);
+    hipLaunchKernelGGL(k_fit_seed<false>, dim3((unsigned)(e->n_slots * (kMaxComp - 1))), dim3(threads), 0, e->stream, F);
+    hipLaunchKernelGGL(k_fit_em<false>, dim3((unsigned)(e->n_slots * kMaxComp)), dim3(threads), 0, e->stream, F);
     hipLaunchKernelGGL(k_fit_select, dim3((unsigned)((e->n_slots + 63) / 64)), dim3(64), 0, e->stream, F);
-    hipLaunchKernelGGL(k_fit_gmm<true>, dim3((unsigned)e->n_slots), dim3(threads), 0, e->stream, F);
+    hipLaunchKernelGGL(k_fit_seed<true>, dim3((unsigned)e->n_slots), dim3(threads), 0, e->stream, F);
+    hipLaunchKernelGGL(k_fit_em<true>, dim3((unsigned)e->n_slots), dim3(threads), 0, e->stream, F);
     const int64_t total = e->n_slots * kMaxComp;
     hipLaunchKernelGGL(k_mix_consts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, (const double*)e->mix_p_dev, (const int32_t*)e->mix_n_dev, (const int32_t*)e->slot_unit, e->P.units, e->mix_c_dev, total);
     HIPCHK(hipEventRecord(e->ev[EV_END], e->stream));
@@ -1463,9 +1463,7 @@ extern "C" int tw_debug_fit_models(tw_engine* e, double* out) {
     if (e == nullptr || out == nullptr) return TW_ERR_ARG;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(out, e->fit_models, sizeof(double) * e->n_slots * kMaxComp * kModelStride, hipMemcpyDeviceToHost, e->stream));
-#ifdef TW_FIT_DEBUG
-    HIPCHK(hipMemcpyAsync(out + e->n_slots * kMaxComp * kModelStride, e->fit_dbg, sizeof(double) * e->n_slots * kMaxComp * 16, hipMemcpyDeviceToHost, e->stream));
-#endif
+
     HIPCHK(hipStreamSynchronize(e->stream));
     return TW_OK;
 }

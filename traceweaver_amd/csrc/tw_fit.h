@@ -68,7 +68,7 @@ struct FitDev {
     const int64_t* tape_off;  // [n_slots] first double of the row's fits (n = 1, 2, ... behind one another)
     const double* tape100;  // [kMaxComp][13] draws of the refit with n components: MT19937(100)
     int32_t* err;
-    double* dbg;            // -DTW_FIT_DEBUG: [n_slots][kMaxComp][16] k-means++ centres, Lloyd centres, iteration counts
+    double* centres;        // [n_slots][kMaxComp][1 + kMaxComp] k-means start of every fit: mean of the samples, final centres (centred)
 };
 
 // deterministic block reduction of `cnt` doubles per thread: lanes of a wavefront by shuffles (fixed
@@ -178,55 +178,89 @@ __device__ __forceinline__ int fit_label(const double* cen, int k, double x) {
     return lab;
 }
 
-// One workgroup per (row, component count): GaussianMixture(k).fit(row).  kFull = false: the model-selection fits
-// (diagonal covariance, draws from the row's tape, result = BIC + parameters in F.models); kFull = true: the refit of the
-// selected count (full covariance, draws of MT19937(100), result = the row of the mixture table).
+// k_fit_seed holds no mixture arithmetic: built to 128 registers, two workgroups per CU hide the latency of its walks
+#ifndef TW_FIT_SEED_ATTR
+#define TW_FIT_SEED_ATTR
+#endif
+constexpr int kRunCache = 4096;   // runs of a row kept in LDS (value + multiplicity = 48 KB) by the iterating kernels; longer rows read the rest from global memory
+constexpr int kSeedBlocks = 16;   // a wavefront's stretch of the row is summed in this many blocks (k_fit_seed)
+
+struct FitRow {
+    int64_t q, row;
+    int k, n_all, n, uniq;
+    bool live;
+};
+// Which (row, component count) a workgroup serves.  Model selection: the fits with the most components first (they run
+// longest), `skip1` leaves k = 1 out (k-means of one cluster is no work); refit: k = the selected count.
 template <bool kFull>
-__global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
-    __shared__ double sh[kFitStats * kFitWaves];
-    __shared__ double par[3 * kMaxComp];              // weights, means, covariances
+__device__ __forceinline__ FitRow fit_row(const FitDev& F, bool skip1) {
+    FitRow R;
+    R.q = kFull ? (int64_t)blockIdx.x : (int64_t)(blockIdx.x % F.n_slots);
+    R.k = kFull ? F.mix_n[R.q] : kMaxComp - (int)(blockIdx.x / F.n_slots);
+    const UnitDev& U = F.units[F.slot_unit[R.q]];
+    R.n_all = U.n_in;
+    R.row = F.gs_off[F.slot_unit[R.q]] + (R.q - U.slot_off) * (int64_t)R.n_all;
+    R.n = F.row_n[R.q];
+    R.uniq = F.row_uniq[R.q];
+    R.live = F.slot_scored[R.q] && R.n > 0 && R.k >= (skip1 ? 2 : 1) && R.k <= R.uniq && R.k <= kMaxComp;
+    return R;
+}
+
+// One workgroup per (row, component count >= 2): the k-means start of GaussianMixture(k).fit(row) --
+// KMeans(k, n_init=1): k-means++ seeding on the mean-centred samples in request order, then Lloyd over the runs.  Leaves the
+// mean and the final centres in F.centres.  Few registers (no mixture arithmetic): several workgroups per CU hide the
+// latency of the walks over the row.
+template <bool kFull>
+__global__ void __launch_bounds__(kFitThreads) TW_FIT_SEED_ATTR k_fit_seed(FitDev F) {
+    __shared__ double sh[(2 * kMaxComp + 1) * kFitWaves];
     __shared__ double cen[kMaxComp];
-    __shared__ double seg[kFitMaxTrials][kFitWaves];  // per trial candidate: sum over a wavefront's stretch of the row of the closest squared distances
-    __shared__ double cand[kFitMaxTrials][kFitWaves]; // first crossing found by each wavefront (NaN = none)
+    __shared__ double blk[kFitWaves][kSeedBlocks];    // closest squared distances summed per block of a wavefront's stretch
+    __shared__ double cand[kFitMaxTrials][kFitWaves]; // candidate found by each wavefront (NaN = none)
     __shared__ double lastv[kFitWaves];
     __shared__ int32_t lasti[kFitWaves], cnt_w[kFitWaves];
-    // model selection: the fits with the most components first (they run longest)
-    const int64_t q = kFull ? (int64_t)blockIdx.x : (int64_t)(blockIdx.x % F.n_slots);
-    const int k = kFull ? F.mix_n[q] : kMaxComp - (int)(blockIdx.x / F.n_slots);
+    __shared__ double par[2 * kMaxComp];
+    __shared__ double run_x[kRunCache];
+    __shared__ int32_t run_c[kRunCache];
+    const FitRow R = fit_row<kFull>(F, true);
+    if (!R.live) return;
+    const int k = R.k, n = R.n, uniq = R.uniq, n_all = R.n_all;
+    const int64_t q = R.q;
     const int t = threadIdx.x, nt = blockDim.x;
     const int W = nt < 64 ? nt : 64, lane = t & 63, wave = t >> 6, nwave = (nt + 63) >> 6;
-    const UnitDev& U = F.units[F.slot_unit[q]];
-    const int n_all = U.n_in;
-    const int64_t row = F.gs_off[F.slot_unit[q]] + (q - U.slot_off) * (int64_t)n_all;
-    const double* xr = F.gaps + row;      // request order
-    const double* xv = F.uval + row;      // distinct values, ascending
-    const int32_t* xa = F.ustart + row;   // first index of each value in the sorted row
-    double* model = kFull ? nullptr : F.models + (q * kMaxComp + (k - 1)) * kModelStride;
-    const int n = F.row_n[q], uniq = F.row_uniq[q];
-    if (!F.slot_scored[q] || n == 0 || k < 1 || k > uniq || k > kMaxComp) {
-        if (!kFull && t == 0) model[0] = dinf();
-        return;
-    }
+    const double* xr = F.gaps + R.row;      // request order
+    const double* xv = F.uval + R.row;      // distinct values, ascending
+    const int32_t* xa = F.ustart + R.row;   // first index of each value in the sorted row
     const double* tape = kFull ? F.tape100 + (k - 1) * 13 : F.tape + F.tape_off[q] + fit_tape_pos(k);
     const double dn = (double)n;
+    for (int r = t; r < uniq && r < kRunCache; r += nt) { run_x[r] = xv[r]; run_c[r] = (r + 1 < uniq ? xa[r + 1] : n) - xa[r]; }
+    __syncthreads();
+#define RUN_X(r) ((r) < kRunCache ? run_x[r] : xv[r])
+#define RUN_C(r) ((double)((r) < kRunCache ? run_c[r] : ((r) + 1 < uniq ? xa[(r) + 1] : n) - xa[r]))
 
     // ---- mean and variance of the samples (exact sum: integers below 2^53)
-    double mv[2] = {0.0, 0.0};
-    for (int r = t; r < uniq; r += nt) mv[0] += xv[r] * (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
-    block_reduce<1>(reinterpret_cast<double(&)[1]>(mv[0]), sh);
+    double mv[1] = {0.0};
+    for (int r = t; r < uniq; r += nt) mv[0] += RUN_X(r) * RUN_C(r);
+    block_reduce<1>(mv, sh);
     const double mean = mv[0] / dn;
-    for (int r = t; r < uniq; r += nt) { const double d = xv[r] - mean; mv[1] += (d * d) * (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]); }
-    block_reduce<1>(reinterpret_cast<double(&)[1]>(mv[1]), sh);
-    const double km_tol = mv[1] / dn * kKmTol;
+    mv[0] = 0.0;
+    for (int r = t; r < uniq; r += nt) { const double d = RUN_X(r) - mean; mv[0] += (d * d) * RUN_C(r); }
+    block_reduce<1>(mv, sh);
+    const double km_tol = mv[0] / dn * kKmTol;
 
     // ---- k-means++ seeding (sklearn.cluster._kmeans._kmeans_plusplus) on the centred samples in request order.
-    // Every wavefront owns one stretch of the row and walks it in strips of 64 samples.
+    // Every wavefront owns one stretch of the row, cut into kSeedBlocks blocks of whole strips of 64 samples.
     const int strips = (n_all + W - 1) / W, strips_w = (strips + nwave - 1) / nwave;
+    const int strips_b = (strips_w + kSeedBlocks - 1) / kSeedBlocks;
     const int s_lo = wave * strips_w * W, s_hi = (s_lo + strips_w * W) < n_all ? (s_lo + strips_w * W) : n_all;
-    if (k > 1) {
-        // the first centre: sample number floor(u n) of the valid samples
-        int64_t cid = (int64_t)(tape[0] * dn);
-        if (cid > n - 1) cid = n - 1;
+    // the first centre: sample number floor(u n) of the valid samples
+    int64_t cid = (int64_t)(tape[0] * dn);
+    if (cid > n - 1) cid = n - 1;
+    double x_last = 0.0;
+    if (n == n_all) {   // no dropped samples (the usual case): positions are indices
+        if (t == 0) cen[0] = xr[cid] - mean;
+        x_last = xr[n_all - 1] - mean;
+        __syncthreads();
+    } else {
         {   // valid samples per stretch, the last valid sample
             int c = 0, li = -1;
             double lv = 0.0;
@@ -248,238 +282,244 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
             if (lane == 0) { cnt_w[wave] = c; lasti[wave] = li; lastv[wave] = lv; }
         }
         __syncthreads();
-        double x_last = 0.0;
         { int li = -1; for (int w = 0; w < nwave; w++) if (lasti[w] > li) { li = lasti[w]; x_last = lastv[w]; } }
         x_last -= mean;
-        {
-            int64_t before = 0;
-            int w0 = 0;
-            for (; w0 < nwave - 1 && before + cnt_w[w0] <= cid; w0++) before += cnt_w[w0];
-            if (wave == w0) {  // (wave-uniform branch) walk the stretch to the cid-th valid sample
-                int64_t seen = before;
-                for (int b = s_lo; b < s_hi; b += W) {
-                    const int i = b + lane;
-                    const double x = i < s_hi ? xr[i] : dnan();
-                    const unsigned long long okm = __ballot(x == x);
-                    const int c = __popcll(okm);
-                    if (seen + c > cid) {
-                        const int rank = (int)(cid - seen);  // the rank-th set bit of okm
-                        const bool mine = (x == x) && __popcll(okm & ((1ull << lane) - 1ull)) == rank;
-                        if (mine) cen[0] = x - mean;
-                        break;
-                    }
-                    seen += c;
-                }
-            }
-        }
-        __syncthreads();
-        // closest squared distances to the first centre: their sums per stretch
-        {
-            double a = 0.0;
-            const double c0 = cen[0];
+        int64_t before = 0;
+        int w0 = 0;
+        for (; w0 < nwave - 1 && before + cnt_w[w0] <= cid; w0++) before += cnt_w[w0];
+        if (wave == w0) {  // (wave-uniform branch) walk the stretch to the cid-th valid sample
+            int64_t seen = before;
             for (int b = s_lo; b < s_hi; b += W) {
                 const int i = b + lane;
                 const double x = i < s_hi ? xr[i] : dnan();
-                if (x == x) a += fit_dist(c0, x - mean);
+                const unsigned long long okm = __ballot(x == x);
+                const int c = __popcll(okm);
+                if (seen + c > cid) {
+                    const int rank = (int)(cid - seen);  // the rank-th set bit of okm
+                    const bool mine = (x == x) && __popcll(okm & ((1ull << lane) - 1ull)) == rank;
+                    if (mine) cen[0] = x - mean;
+                    break;
+                }
+                seen += c;
             }
-            for (int off = 32; off >= 1; off >>= 1) if (off < W) a += __shfl_down(a, off);
-            if (lane == 0) seg[0][wave] = a;
         }
-        __syncthreads();
-        const int trials = fit_trials(k);
-        int tp = 1;
-        for (int c = 1; c < k; c++) {
-            double pot = 0.0, base = 0.0;
-            for (int w = 0; w < nwave; w++) { if (w == wave) base = pot; pot += seg[0][w]; }
-            double target[kFitMaxTrials];
-#pragma unroll
-            for (int j = 0; j < kFitMaxTrials; j++) target[j] = j < trials ? tape[tp + j] * pot : 0.0;
-            tp += trials;
-            // pass A: np.searchsorted(cumsum(closest), target) -- the first sample whose running sum reaches the target
-            {
-                bool found[kFitMaxTrials] = {false, false, false};
-                double fv[kFitMaxTrials] = {0.0, 0.0, 0.0};
-                double run = base;
-                for (int b = s_lo; b < s_hi; b += W) {
-                    const int i = b + lane;
-                    const double x = i < s_hi ? xr[i] : dnan();
-                    const bool ok = x == x;
-                    const double xc = x - mean;
-                    double v = 0.0;
-                    if (ok) {
-                        v = fit_dist(cen[0], xc);
-#pragma unroll
-                        for (int j = 1; j < kMaxComp - 1; j++) if (j < c) { const double d = fit_dist(cen[j], xc); if (d < v) v = d; }
-                    }
-                    double s = v;  // inclusive scan over the lanes
-                    for (int off = 1; off < W; off <<= 1) { const double o = __shfl_up(s, off); if (lane >= off) s += o; }
-                    const double cum = run + s;
-#pragma unroll
-                    for (int j = 0; j < kFitMaxTrials; j++) {
-                        if (j < trials && !found[j]) {
-                            const unsigned long long m = __ballot(ok && cum >= target[j]);
-                            if (m) { found[j] = true; fv[j] = __shfl(xc, __ffsll((long long)m) - 1); }
-                        }
-                    }
-                    run += __shfl(s, W - 1);
-                }
-                if (lane == 0) {
-#pragma unroll
-                    for (int j = 0; j < kFitMaxTrials; j++) cand[j][wave] = found[j] ? fv[j] : dnan();
-                }
-            }
-            __syncthreads();
-            double cv[kFitMaxTrials];
-#pragma unroll
-            for (int j = 0; j < kFitMaxTrials; j++) {
-                cv[j] = x_last;  // np.clip(candidate_ids, None, n - 1): a target beyond the last running sum
-                for (int w = nwave - 1; w >= 0; w--) { const double v = cand[j][w]; if (v == v) cv[j] = v; }
-            }
-            __syncthreads();
-            // pass B: the potential of every candidate = sum of min(closest, distance to the candidate)
-            {
-                double a[kFitMaxTrials] = {0.0, 0.0, 0.0};
-                for (int b = s_lo; b < s_hi; b += W) {
-                    const int i = b + lane;
-                    const double x = i < s_hi ? xr[i] : dnan();
-                    if (x == x) {
-                        const double xc = x - mean;
-                        double v = fit_dist(cen[0], xc);
-#pragma unroll
-                        for (int j = 1; j < kMaxComp - 1; j++) if (j < c) { const double d = fit_dist(cen[j], xc); if (d < v) v = d; }
-#pragma unroll
-                        for (int j = 0; j < kFitMaxTrials; j++) if (j < trials) { const double d = fit_dist(cv[j], xc); a[j] += d < v ? d : v; }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < kFitMaxTrials; j++) {
-                    for (int off = 32; off >= 1; off >>= 1) if (off < W) a[j] += __shfl_down(a[j], off);
-                    if (lane == 0) seg[j][wave] = a[j];
-                }
-            }
-            __syncthreads();
-            int best = 0;
-            double bp = 0.0;
-#pragma unroll
-            for (int j = 0; j < kFitMaxTrials; j++) {
-                if (j < trials) {
-                    double p = 0.0;
-                    for (int w = 0; w < nwave; w++) p += seg[j][w];
-                    if (j == 0 || p < bp) { bp = p; best = j; }   // np.argmin: the first minimum
-                }
-            }
-            const double keep = seg[best][wave];
-            __syncthreads();
-            if (lane == 0) seg[0][wave] = keep;
-            if (t == 0) cen[c] = cv[best];
-            __syncthreads();
-        }
-
-#ifdef TW_FIT_DEBUG
-        if (!kFull && t == 0) for (int j = 0; j < k; j++) F.dbg[(q * kMaxComp + (k - 1)) * 16 + j] = cen[j] + mean;
-        int dbg_it = 0;
-#endif
-        // ---- Lloyd iterations (_kmeans_single_lloyd) over the runs.  Every thread holds the centres in registers: the sums
-        // come back from the reduction to all threads, so all compute the same update.
-        double cc[kMaxComp], cp[kMaxComp];
-#pragma unroll
-        for (int j = 0; j < kMaxComp; j++) { cc[j] = j < k ? cen[j] : 0.0; cp[j] = 0.0; }
-        bool strict = false;
-        for (int it = 0; it < kKmMaxIter; it++) {
-#ifdef TW_FIT_DEBUG
-            dbg_it = it + 1;
-#endif
-            double v[2 * kMaxComp + 1];
-#pragma unroll
-            for (int j = 0; j < 2 * kMaxComp + 1; j++) v[j] = 0.0;
-            for (int r = t; r < uniq; r += nt) {
-                const double xc = xv[r] - mean;
-                const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
-                const int lab = fit_label(cc, k, xc);
-                const int old = it == 0 ? -1 : fit_label(cp, k, xc);
-                if (old != lab) v[2 * kMaxComp] += 1.0;   // labels != labels_old
-#pragma unroll
-                for (int j = 0; j < kMaxComp; j++) if (j == lab) { v[j] += cw; v[kMaxComp + j] += xc * cw; }
-            }
-            block_reduce<2 * kMaxComp + 1>(v, sh);
-            bool any_empty = false;
-#pragma unroll
-            for (int j = 0; j < kMaxComp; j++) if (j < k && v[j] == 0.0) any_empty = true;
-            if (any_empty) {
-                // _relocate_empty_clusters_dense: the samples farthest from their centres found the empty clusters (one sample each,
-                // labels untouched).  Rare (never on the reference's corpora); thread 0 walks the runs.
-                if (t == 0) {
-                    int taken_run[kMaxComp], taken_cnt[kMaxComp], ntaken = 0;
-                    for (int e = 0; e < k; e++) {
-                        if (v[e] != 0.0) continue;
-                        int fr = -1;
-                        double fd = -1.0;
-                        for (int r = 0; r < uniq; r++) {
-                            int used = 0;
-                            for (int z = 0; z < ntaken; z++) if (taken_run[z] == r) used = taken_cnt[z];
-                            if ((r + 1 < uniq ? xa[r + 1] : n) - xa[r] <= used) continue;
-                            const double xc = xv[r] - mean;
-                            const int lb = fit_label(cc, k, xc);
-                            double cl = cc[0];
-#pragma unroll
-                            for (int j = 1; j < kMaxComp; j++) if (j == lb) cl = cc[j];
-                            const double d0 = xc - cl;
-                            if (d0 * d0 > fd) { fd = d0 * d0; fr = r; }
-                        }
-                        if (fr < 0) break;
-                        bool again = false;
-                        for (int z = 0; z < ntaken; z++) if (taken_run[z] == fr) { taken_cnt[z]++; again = true; }
-                        if (!again) { taken_run[ntaken] = fr; taken_cnt[ntaken] = 1; ntaken++; }
-                        const double xc = xv[fr] - mean;
-                        const int old = fit_label(cc, k, xc);
-#pragma unroll
-                        for (int j = 0; j < kMaxComp; j++) {
-                            if (j == old) { v[kMaxComp + j] -= xc; v[j] -= 1.0; }
-                            if (j == e) { v[kMaxComp + j] = xc; v[j] = 1.0; }
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < kMaxComp; j++) { par[j] = v[j]; par[kMaxComp + j] = v[kMaxComp + j]; }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < kMaxComp; j++) { v[j] = par[j]; v[kMaxComp + j] = par[kMaxComp + j]; }
-                __syncthreads();
-            }
-            double shift = 0.0;
-#pragma unroll
-            for (int j = 0; j < kMaxComp; j++) {
-                if (j < k) {
-                    const double nc = v[kMaxComp + j] * (1.0 / v[j]);   // _average_centers: the sum times the reciprocal of the weight
-                    const double d = nc - cc[j];
-                    const double sd = sqrt(d * d);                      // _center_shift, then (center_shift ** 2).sum()
-                    shift += sd * sd;
-                    cp[j] = cc[j];
-                    cc[j] = nc;
-                }
-            }
-            if (v[2 * kMaxComp] == 0.0) { strict = true; break; }
-            if (shift <= km_tol) break;
-        }
-        // the labels KMeans returns: those of the last assignment (strict convergence) or a fresh one under the final centres
-        __syncthreads();
-        if (t == 0) {
-#pragma unroll
-            for (int j = 0; j < kMaxComp; j++) if (j < k) cen[j] = strict ? cp[j] : cc[j];
-        }
-        __syncthreads();
-#ifdef TW_FIT_DEBUG
-        if (!kFull && t == 0) {
-            for (int j = 0; j < k; j++) F.dbg[(q * kMaxComp + (k - 1)) * 16 + 5 + j] = cen[j] + mean;
-            F.dbg[(q * kMaxComp + (k - 1)) * 16 + 10] = (double)dbg_it;
-            F.dbg[(q * kMaxComp + (k - 1)) * 16 + 11] = strict ? 1.0 : 0.0;
-            F.dbg[(q * kMaxComp + (k - 1)) * 16 + 12] = km_tol;
-        }
-#endif
-    } else {
-        if (t == 0) cen[0] = 0.0;
         __syncthreads();
     }
+    const int trials = fit_trials(k);
+    int tp = 1;
+    for (int c = 1; c < k; c++) {
+        double cc[kMaxComp - 1];
+#pragma unroll
+        for (int j = 0; j < kMaxComp - 1; j++) cc[j] = j < c ? cen[j] : 0.0;
+        // pass A1: the closest squared distances summed per block of the row (request order); eight strips' loads in flight
+        for (int bi = 0; bi < kSeedBlocks; bi++) {
+            const int b_lo = s_lo + bi * strips_b * W, b_hi = (b_lo + strips_b * W) < s_hi ? (b_lo + strips_b * W) : s_hi;
+            double a = 0.0;
+            for (int b = b_lo; b < b_hi; b += 8 * W) {
+                double x8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int i = b + u * W + lane; x8[u] = i < b_hi ? xr[i] : dnan(); }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (x8[u] == x8[u]) {
+                        const double xc = x8[u] - mean;
+                        double v = fit_dist(cc[0], xc);
+#pragma unroll
+                        for (int j = 1; j < kMaxComp - 1; j++) if (j < c) { const double d = fit_dist(cc[j], xc); if (d < v) v = d; }
+                        a += v;
+                    }
+                }
+            }
+            for (int off = 32; off >= 1; off >>= 1) if (off < W) a += __shfl_down(a, off);
+            if (lane == 0) blk[wave][bi] = a;
+        }
+        __syncthreads();
+        double pot = 0.0, base = 0.0, mine_sum = 0.0;
+        for (int w = 0; w < nwave; w++) {
+            double sw = 0.0;
+            for (int bi = 0; bi < kSeedBlocks; bi++) sw += blk[w][bi];
+            if (w == wave) { base = pot; mine_sum = sw; }
+            pot += sw;
+        }
+        const double next = base + mine_sum;
+        // pass A2: np.searchsorted(cumsum(closest), target) -- the first sample whose running sum reaches the target lies in the
+        // stretch, and there in the block, whose range of running sums holds the target: that block is walked with the running sum
+#pragma unroll
+        for (int j = 0; j < kFitMaxTrials; j++) {
+            double found = dnan();
+            if (j < trials) {
+                const double target = tape[tp + j] * pot;
+                if ((wave == 0 && target <= next) || (target > base && target <= next)) {   // (wave-uniform)
+                    double run = base;
+                    int bi = 0;
+                    for (; bi < kSeedBlocks - 1 && run + blk[wave][bi] < target; bi++) run += blk[wave][bi];
+                    const int b_lo = s_lo + bi * strips_b * W, b_hi = (b_lo + strips_b * W) < s_hi ? (b_lo + strips_b * W) : s_hi;
+                    double lastx = dnan();
+                    for (int b = b_lo; b < b_hi; b += W) {
+                        const int i = b + lane;
+                        const double x = i < b_hi ? xr[i] : dnan();
+                        const bool ok = x == x;
+                        const double xc = x - mean;
+                        double v = 0.0;
+                        if (ok) {
+                            v = fit_dist(cc[0], xc);
+#pragma unroll
+                            for (int jj = 1; jj < kMaxComp - 1; jj++) if (jj < c) { const double d = fit_dist(cc[jj], xc); if (d < v) v = d; }
+                        }
+                        double sc = v;  // inclusive scan over the lanes
+                        for (int off = 1; off < W; off <<= 1) { const double o = __shfl_up(sc, off); if (lane >= off) sc += o; }
+                        const unsigned long long m = __ballot(ok && run + sc >= target);
+                        if (m) { found = __shfl(xc, __ffsll((long long)m) - 1); break; }
+                        const unsigned long long okm = __ballot(ok);
+                        if (okm) lastx = __shfl(xc, 63 - __clzll((long long)okm));
+                        run += __shfl(sc, W - 1);
+                    }
+                    if (!(found == found)) found = lastx;   // (rounding: the walk's sum fell short of the target)
+                    if (!(found == found)) found = x_last;
+                }
+            }
+            if (lane == 0) cand[j][wave] = found;
+        }
+        tp += trials;
+        __syncthreads();
+        double cv[kFitMaxTrials];
+#pragma unroll
+        for (int j = 0; j < kFitMaxTrials; j++) {
+            cv[j] = x_last;  // np.clip(candidate_ids, None, n - 1): a target beyond the last running sum
+            for (int w = nwave - 1; w >= 0; w--) { const double v = cand[j][w]; if (v == v) cv[j] = v; }
+        }
+        // pass B: the potential of every candidate = sum of min(closest, distance to the candidate) -- over the runs
+        // (the same terms grouped by value)
+        double a[kFitMaxTrials] = {0.0, 0.0, 0.0};
+        for (int r = t; r < uniq; r += nt) {
+            const double xc = RUN_X(r) - mean;
+            const double cw = RUN_C(r);
+            double v = fit_dist(cc[0], xc);
+#pragma unroll
+            for (int j = 1; j < kMaxComp - 1; j++) if (j < c) { const double d = fit_dist(cc[j], xc); if (d < v) v = d; }
+#pragma unroll
+            for (int j = 0; j < kFitMaxTrials; j++) if (j < trials) { const double d = fit_dist(cv[j], xc); a[j] += cw * (d < v ? d : v); }
+        }
+        block_reduce<kFitMaxTrials>(a, sh);
+        double bp = a[0], bc = cv[0];   // np.argmin: the first minimum
+        if (trials > 1 && a[1] < bp) { bp = a[1]; bc = cv[1]; }
+        if (trials > 2 && a[2] < bp) { bp = a[2]; bc = cv[2]; }
+        if (t == 0) cen[c] = bc;
+        __syncthreads();
+    }
+
+    // ---- Lloyd iterations (_kmeans_single_lloyd) over the runs.  Every thread holds the centres in registers: the sums
+    // come back from the reduction to all threads, so all compute the same update.
+    double cc[kMaxComp], cp[kMaxComp];
+#pragma unroll
+    for (int j = 0; j < kMaxComp; j++) { cc[j] = j < k ? cen[j] : 0.0; cp[j] = 0.0; }
+    bool strict = false;
+    for (int it = 0; it < kKmMaxIter; it++) {
+        double v[2 * kMaxComp + 1];
+#pragma unroll
+        for (int j = 0; j < 2 * kMaxComp + 1; j++) v[j] = 0.0;
+        for (int r = t; r < uniq; r += nt) {
+            const double xc = RUN_X(r) - mean;
+            const double cw = RUN_C(r);
+            const int lab = fit_label(cc, k, xc);
+            const int old = it == 0 ? -1 : fit_label(cp, k, xc);
+            if (old != lab) v[2 * kMaxComp] += 1.0;   // labels != labels_old
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) if (j == lab) { v[j] += cw; v[kMaxComp + j] += xc * cw; }
+        }
+        block_reduce<2 * kMaxComp + 1>(v, sh);
+        bool any_empty = false;
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) if (j < k && v[j] == 0.0) any_empty = true;
+        if (any_empty) {
+            // _relocate_empty_clusters_dense: the samples farthest from their centres found the empty clusters (one sample each,
+            // labels untouched).  Rare (never on the reference's corpora); thread 0 walks the runs.
+            if (t == 0) {
+                int taken_run[kMaxComp], taken_cnt[kMaxComp], ntaken = 0;
+                for (int e = 0; e < k; e++) {
+                    if (v[e] != 0.0) continue;
+                    int fr = -1;
+                    double fd = -1.0;
+                    for (int r = 0; r < uniq; r++) {
+                        int used = 0;
+                        for (int z = 0; z < ntaken; z++) if (taken_run[z] == r) used = taken_cnt[z];
+                        if ((r + 1 < uniq ? xa[r + 1] : n) - xa[r] <= used) continue;
+                        const double xc = xv[r] - mean;
+                        const int lb = fit_label(cc, k, xc);
+                        double cl = cc[0];
+#pragma unroll
+                        for (int j = 1; j < kMaxComp; j++) if (j == lb) cl = cc[j];
+                        const double d0 = xc - cl;
+                        if (d0 * d0 > fd) { fd = d0 * d0; fr = r; }
+                    }
+                    if (fr < 0) break;
+                    bool again = false;
+                    for (int z = 0; z < ntaken; z++) if (taken_run[z] == fr) { taken_cnt[z]++; again = true; }
+                    if (!again) { taken_run[ntaken] = fr; taken_cnt[ntaken] = 1; ntaken++; }
+                    const double xc = xv[fr] - mean;
+                    const int old = fit_label(cc, k, xc);
+#pragma unroll
+                    for (int j = 0; j < kMaxComp; j++) {
+                        if (j == old) { v[kMaxComp + j] -= xc; v[j] -= 1.0; }
+                        if (j == e) { v[kMaxComp + j] = xc; v[j] = 1.0; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kMaxComp; j++) { par[j] = v[j]; par[kMaxComp + j] = v[kMaxComp + j]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) { v[j] = par[j]; v[kMaxComp + j] = par[kMaxComp + j]; }
+            __syncthreads();
+        }
+        double shift = 0.0;
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) {
+            if (j < k) {
+                const double nc = v[kMaxComp + j] * (1.0 / v[j]);   // _average_centers: the sum times the reciprocal of the weight
+                const double d = nc - cc[j];
+                const double sd = sqrt(d * d);                      // _center_shift, then (center_shift ** 2).sum()
+                shift += sd * sd;
+                cp[j] = cc[j];
+                cc[j] = nc;
+            }
+        }
+        if (v[2 * kMaxComp] == 0.0) { strict = true; break; }
+        if (shift <= km_tol) break;
+    }
+    // the labels KMeans returns: those of the last assignment (strict convergence) or a fresh one under the final centres
+    if (t == 0) {
+        double* out = F.centres + (q * kMaxComp + (k - 1)) * (kMaxComp + 1);
+        out[0] = mean;
+#pragma unroll
+        for (int j = 0; j < kMaxComp; j++) out[1 + j] = strict ? cp[j] : cc[j];
+    }
+}
+
+// One workgroup per (row, component count): GaussianMixture(k).fit(row) from the k-means labels on.  kFull = false: the
+// model-selection fits (diagonal covariance; result = BIC + parameters in F.models); kFull = true: the refit of the
+// selected count (full covariance; result = the row of the mixture table).
+template <bool kFull>
+__global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
+    __shared__ double sh[kFitStats * kFitWaves];
+    __shared__ double run_x[kRunCache];
+    __shared__ int32_t run_c[kRunCache];
+    const FitRow R = fit_row<kFull>(F, false);
+    const int k = R.k, n = R.n, uniq = R.uniq;
+    const int64_t q = R.q;
+    const int t = threadIdx.x, nt = blockDim.x;
+    double* model = kFull ? nullptr : F.models + (q * kMaxComp + (k - 1)) * kModelStride;
+    if (!R.live) {
+        if (!kFull && t == 0 && k >= 1 && k <= kMaxComp) model[0] = dinf();
+        return;
+    }
+    const double* xv = F.uval + R.row;      // distinct values, ascending
+    const int32_t* xa = F.ustart + R.row;   // first index of each value in the sorted row
+    const double dn = (double)n;
+    const double* seed = F.centres + (q * kMaxComp + (k - 1)) * (kMaxComp + 1);
+    const double mean = k > 1 ? seed[0] : 0.0;
+    for (int r = t; r < uniq && r < kRunCache; r += nt) { run_x[r] = xv[r]; run_c[r] = (r + 1 < uniq ? xa[r + 1] : n) - xa[r]; }
+    __syncthreads();
 
     // ---- GaussianMixture._initialize: one-hot responsibilities of the k-means labels, then the M step.  From here on the
     // parameters live in registers: every reduction hands its sums to all threads, all compute the same update.
@@ -488,13 +528,13 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
     {
         double cc[kMaxComp];
 #pragma unroll
-        for (int j = 0; j < kMaxComp; j++) cc[j] = j < k ? cen[j] : 0.0;
+        for (int j = 0; j < kMaxComp; j++) cc[j] = (k > 1 && j < k) ? seed[1 + j] : 0.0;
         double v[3 * kMaxComp];
 #pragma unroll
         for (int j = 0; j < 3 * kMaxComp; j++) v[j] = 0.0;
         for (int r = t; r < uniq; r += nt) {
-            const double x = xv[r];
-            const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
+            const double x = RUN_X(r);
+            const double cw = RUN_C(r);
             const int lab = k > 1 ? fit_label(cc, k, x - mean) : 0;
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) if (j == lab) { v[j] += cw; v[kMaxComp + j] += cw * x; v[2 * kMaxComp + j] += cw * (x * x); }
@@ -512,8 +552,8 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) c2[j] = 0.0;
             for (int r = t; r < uniq; r += nt) {
-                const double x = xv[r];
-                const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
+                const double x = RUN_X(r);
+                const double cw = RUN_C(r);
                 const int lab = k > 1 ? fit_label(cc, k, x - mean) : 0;
 #pragma unroll
                 for (int j = 0; j < kMaxComp; j++) if (j == lab) { const double d = x - pm[j]; c2[j] += cw * (d * d); }
@@ -551,8 +591,8 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
 #pragma unroll
         for (int c = 0; c < kFitStats; c++) v[c] = 0.0;
         for (int r = t; r < uniq; r += nt) {
-            const double x = xv[r];
-            const double cw = (double)((r + 1 < uniq ? xa[r + 1] : n) - xa[r]);
+            const double x = RUN_X(r);
+            const double cw = RUN_C(r);
             double wl[kMaxComp], mx = -dinf();
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) {
@@ -624,6 +664,9 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_gmm(FitDev F) {
         }
     }
 }
+
+#undef RUN_X
+#undef RUN_C
 
 // n_selected = n_comps[argmin(bic)] over the fits that did not raise (first minimum, V3:780).  A row without samples keeps
 // n = 0 (the reference stores (0, 0) and scores with a sigma = 0.001 Gaussian, V3:765-766); a row all of whose fits raised
