@@ -641,7 +641,11 @@ int two_gauss_params(const two_service *s, double *gauss, int32_t max_blocks) {
  * therefore uses exact integers: w = rint((10000 + score) * 2^32) (resolution 2.3e-10, far below the solver tolerance;
  * equal scores stay equal).  Sums, bounds and comparisons are then exact and independent of the search order. */
 typedef int64_t two_w;
-static two_w weight_of(double score) { return (two_w)rint((10000.0 + score) * 4294967296.0); }
+/* weights <= 0 are never selected: 0 stands for all of them (the conversion of a double beyond the int64 range is undefined) */
+static two_w weight_of(double score) {
+    const double w = (10000.0 + score) * 4294967296.0;
+    return w > 0.5 ? (two_w)rint(w) : 0;
+}
 
 typedef struct {
     int m;                               /* in-spans in the component */

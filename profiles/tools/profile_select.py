@@ -13,7 +13,8 @@ def report(pass_no, t, a, out):
   tot = float(a[:8].sum())
   print("pass", pass_no, "select ms", t["select"], "windows", out[0])
   for k in range(8): print("%-16s %6.1f%%  per window %8.0f ticks (10 ns)" % (names[k], 100.0*a[k]/tot, a[k]/max(out[0],1)))
-  print("longest window: %.1f us, m=%d, nodes(last comp)=%d ; sum of window times / 1792 WGs = %.2f ms" % ((int(a[8]) >> 24) / 100.0, (int(a[8]) >> 16) & 0xff, int(a[8]) & 0xffff, int(a[9]) / 100.0 / 1792 / 1000.0))
+  print("   longest window: search %.1f us, of it matching bound %.1f us in %d calls, %d nodes, E=%d" % (int(cur[10]) / 100.0, int(cur[11]) / 100.0, int(cur[12]), int(cur[13]), int(cur[14])))
+  print("longest window: %.1f us, m=%d, search nodes / 16 = %d ; sum of window times / 1792 WGs = %.2f ms" % ((int(a[8]) >> 24) / 100.0, (int(a[8]) >> 16) & 0xff, int(a[8]) & 0xffff, int(a[9]) / 100.0 / 1792 / 1000.0))
 prev = np.zeros(16, dtype=np.uint64)
 for pass_no in (1, 2):
   if pass_no == 1: eng.run_pass1()

@@ -21,7 +21,8 @@ def build(force=False, production=False):
     os.makedirs(os.path.dirname(out), exist_ok=True)
     small = [] if production else [
         "-DTW_BIG_PRODUCT=40", "-DTW_SPLIT_MIN=96", "-DTW_SPLIT_GRAIN=24", "-DTW_GRID_TARGET=16",   # enumerations are split from ~100 grid points on, prefixes walked
-        "-DTW_FRONTIER_CAP=512", "-DTW_FRONTIER_BIG_CAP=8192", "-DTW_FRONTIER_BIG_SLOTS=3"]   # small lists: own buffers, pool slots and the walk all occur in the tests
+        "-DTW_FRONTIER_CAP=512", "-DTW_FRONTIER_BIG_CAP=8192", "-DTW_FRONTIER_BIG_SLOTS=3",   # small lists: own buffers, pool slots and the walk all occur in the tests
+        "-DTW_MATCH_NODES_1=48", "-DTW_MATCH_NODES=256"]   # the selection search consults the matching relaxation early
     subprocess.check_call(
         ["g++", "-x", "c++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas"] + small +
         ["-I", HERE, "-I", os.path.join(REPO, "include"), "-I", SRC, os.path.join(SRC, "tw_engine.hip"),

@@ -1890,7 +1890,13 @@ __device__ inline bool cands_share(const Dev& P, const UnitDev& U, int i, int a,
 // who took which outgoing span all meet in that one entry.  A component whose search visits more than kNodeBudget
 // nodes keeps the best selection found; the window is counted in unit_stats[4] (not proven optimal).
 typedef long long sel_w;
-__device__ __forceinline__ sel_w sel_weight(double score) { return (sel_w)rint((10000.0 + score) * 4294967296.0); }
+// (a weight <= 0 is never selected, so everything from there down is 0: the conversion of a double beyond the int64 range is
+// undefined -- a mixture component collapsed onto one sample value scores a candidate a few hundred microseconds off at
+// -10^11 -- and on gfx950 comes out as a small *positive* number)
+__device__ __forceinline__ sel_w sel_weight(double score) {
+    const double w = (10000.0 + score) * 4294967296.0;
+    return w > 0.5 ? (sel_w)rint(w) : 0;
+}
 constexpr int kNodeBudget = 1 << 24; // search nodes per component
 constexpr int kBlkWords = (kMaxWin * kTopK + 63) / 64;  // words of a mask over all candidates of a component
 constexpr int kBigWindow = 8;        // windows of at least this many spans are served first by k_select_heavy
@@ -1899,6 +1905,19 @@ constexpr int kBruteMax = 4;         // components of up to this many spans are 
 #ifndef TW_MEMO_SLOTS
 #define TW_MEMO_SLOTS 256
 #endif
+// select_search consults the matching relaxation from this many nodes of a component on: early for one endpoint, where the
+// bound is the exact optimum of the sub-problem (the search stops backtracking: measured on the nodejs shape, 164 774 nodes ->
+// a few hundred), late otherwise (one consultation costs as much as ~50 plain nodes and a second endpoint's constraint is
+// what the relaxation drops: 2 506 -> 2 356 nodes on the longest two-endpoint window) -- there it is what ends tie-saturated
+// searches that would otherwise run into the node budget ...
+#ifndef TW_MATCH_NODES_1
+#define TW_MATCH_NODES_1 2048
+#endif
+#ifndef TW_MATCH_NODES
+#define TW_MATCH_NODES 32768
+#endif
+constexpr int kMatchNodes1 = TW_MATCH_NODES_1, kMatchNodes = TW_MATCH_NODES;
+constexpr int kMatchMinDepth = 4;    // ... at nodes with at least this many spans below
 constexpr int kMemoSlots = TW_MEMO_SLOTS;      // transposition table entries (LDS); a table of 2^20 entries prunes no better on the test workloads
 
 // ---- cooperative path: one workgroup per window --------------------------------------------------
@@ -1933,6 +1952,14 @@ struct SelectLdsT {
     int8_t scur[kS], sbest[kS];             // choice per level (ncand = "none"), incumbent
     int cm, budget_hit;
     unsigned long long nodes_total;   // search nodes of the window (all lanes), reported in unit_stats[5]
+#ifdef TW_PROFILE_SEL
+    long long pt[6];
+#endif
+    // matching relaxation (select_match_prunes): columns = outgoing spans of one endpoint addressed by index - base, then
+    // one "unassigned" column per row
+    static constexpr int kCols = SEARCH ? MW * 4 : 1;   // (candidates of a component lie close together: its spans overlap in time)
+    sel_w hu[kS + 1], hv[kCols + 1], hminv[kCols + 1];
+    uint8_t hp[kCols + 1], hway[kCols + 1], hused[kCols + 1], htouch[kCols + 1];
 };
 typedef SelectLdsT<kMaxWin, true> SelectLds;
 typedef SelectLdsT<kBruteMax, false> SelectLdsTiny;
@@ -1946,6 +1973,94 @@ __device__ inline bool lds_share(const LDS& L, int E, int b1, int k1, int b2, in
     return false;
 }
 
+// Matching relaxation of the sub-problem "spans d..cm-1 of the component, given the candidates blocked so far" (one lane):
+// keep the constraint of one endpoint only -- no outgoing span of endpoint e twice -- and drop the others.  What remains is
+// a maximum-weight bipartite matching between the remaining spans and the outgoing spans of e, edge weight = the weight of
+// the span's still-eligible candidate that uses it; a span may stay unassigned (a column of its own, weight 0).  Solved
+// exactly by shortest augmenting paths with integer potentials (the Hungarian method; rows have <= kTopK + 1 entries, only
+// the columns an augmentation touched are visited).  For one endpoint the bound is the exact optimum of the sub-problem; it is what
+// ends the searches of windows in which more spans compete than outgoing spans are left -- the grouped bound of the
+// suffix cannot see that.  (Any valid bound leaves the answer, the first selection of maximum weight in depth-first order,
+// what it is.)
+constexpr sel_w kNoBound = 0x1fffffffffffffffLL;   // select_match_bound: the endpoint's indices do not fit the column arrays
+template <class LDS>
+__device__ sel_w select_match_bound(LDS& L, int e, int d, unsigned long long b0, unsigned long long b1, unsigned long long b2) {
+    constexpr int NC = LDS::kCols;
+    const sel_w INF = kNoBound;
+    const int cm = L.cm, nrow = cm - d;
+    auto eligible = [&](int dd, int k) -> bool {
+        const int b = L.mem[dd];
+        if (k >= L.ncand[b] || !(L.w[b][k] > 0)) return false;
+        const int bit = dd * kTopK + k;
+        return !(((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull);
+    };
+    {
+        int32_t base = 0x7fffffff, top = -0x7fffffff - 1;
+        for (int r = 0; r < nrow; r++)
+            for (int k = 0; k < kTopK; k++)
+                if (eligible(d + r, k)) { const int32_t x = L.idx[L.mem[d + r]][k][e]; base = x < base ? x : base; top = x > top ? x : top; }
+        if (top < base) { top = 0; base = 1; }
+        const long long span = (long long)top - base + 1;
+        if (span + nrow > NC - 1) return kNoBound;   // indices too far apart for the column arrays (ids are bytes): this endpoint gives no bound
+        const int ncol = (int)span;       // columns 1..ncol: outgoing spans; ncol + 1 + r: span r stays unassigned
+        for (int j = 0; j <= ncol + nrow; j++) { L.hv[j] = 0; L.hp[j] = 0; L.hminv[j] = INF; L.hused[j] = 0; }
+        for (int i = 0; i <= nrow; i++) L.hu[i] = 0;
+        for (int i = 1; i <= nrow; i++) {
+            L.hp[0] = (uint8_t)i;
+            int j0 = 0, ntouch = 0;
+            do {
+                L.hused[j0] = 1;
+                const int i0 = L.hp[j0], dd = d + i0 - 1, b = L.mem[dd];
+                const sel_w ui = L.hu[i0];
+                for (int k = 0; k <= kTopK; k++) {   // the row's edges: its eligible candidates, then "unassigned"
+                    int j;
+                    sel_w a;
+                    if (k < kTopK) {
+                        if (!eligible(dd, k)) continue;
+                        j = L.idx[b][k][e] - base + 1;
+                        a = -L.w[b][k];
+                    } else { j = ncol + i0; a = 0; }
+                    if (L.hused[j]) continue;
+                    const sel_w cur = a - ui - L.hv[j];
+                    if (cur < L.hminv[j]) {
+                        if (L.hminv[j] == INF) L.htouch[ntouch++] = (uint8_t)j;
+                        L.hminv[j] = cur;
+                        L.hway[j] = (uint8_t)j0;
+                    }
+                }
+                sel_w delta = INF;
+                int j1 = 0;
+                for (int q = 0; q < ntouch; q++) {
+                    const int j = L.htouch[q];
+                    if (!L.hused[j] && L.hminv[j] < delta) { delta = L.hminv[j]; j1 = j; }
+                }
+                // (every row has its "unassigned" column, so an unused touched column always exists)
+                L.hu[L.hp[0]] += delta;
+                L.hv[0] -= delta;
+                for (int q = 0; q < ntouch; q++) {
+                    const int j = L.htouch[q];
+                    if (L.hused[j]) { L.hu[L.hp[j]] += delta; L.hv[j] -= delta; }
+                    else L.hminv[j] -= delta;
+                }
+                j0 = j1;
+            } while (L.hp[j0] != 0);
+            do { const int j1 = L.hway[j0]; L.hp[j0] = L.hp[j1]; j0 = j1; } while (j0);
+            for (int q = 0; q < ntouch; q++) { const int j = L.htouch[q]; L.hminv[j] = INF; L.hused[j] = 0; }
+            L.hused[0] = 0;
+        }
+        return L.hv[0];   // = -(minimum cost) = maximum weight of the relaxed sub-problem
+    }
+}
+// true when for some endpoint weight above + bound <= incumbent: nothing below the node can improve on it
+template <class LDS>
+__device__ bool select_match_prunes(LDS& L, int E, int d, sel_w acc, sel_w best_w, unsigned long long b0, unsigned long long b1, unsigned long long b2) {
+    for (int e = 0; e < E; e++) {
+        const sel_w bound = select_match_bound(L, e, d, b0, b1, b2);
+        if (bound != kNoBound && acc + bound <= best_w) return true;
+    }
+    return false;
+}
+
 // Depth-first search of a component of more than kBruteMax spans (see above): lane 0 walks the tree in the canonical
 // order with its stack in LDS (weight above every level, blocked candidates at every level: a return costs nothing),
 // cutting a node when weight + bound <= incumbent, the bound being the grouped bound of the suffix or the entry of the
@@ -1954,7 +2069,7 @@ __device__ inline bool lds_share(const LDS& L, int E, int b1, int k1, int b2, in
 // component of the heavy-load test workloads takes ~2e3 nodes instead of 4e6 (nodejs shape) / 8e8 (tie-saturated set).
 // Needs L.cm, L.mem, L.ncand, L.w, L.ub, L.cmask3; writes L.pick of the members.
 template <class LDS>
-__device__ void select_search(LDS& L) {
+__device__ void select_search(LDS& L, int E) {
     constexpr int W = LDS::kW;   // words of the blocked mask: kept in up to three registers, the unused ones are constant zero
     static_assert(W >= 1 && W <= 3 && kBlkWords == 3, "the blocked mask is kept in three registers");
     const int t = threadIdx.x;
@@ -1979,18 +2094,37 @@ __device__ void select_search(LDS& L) {
             if constexpr (W > 2) eq = eq && L.mkey[sl][2] == k[2];
             return eq;
         };
+#ifdef TW_PROFILE_SEL
+        const long long _s0 = wall_clock64();
+#endif
         sel_w best_w = 0, acc = 0;      // only strict improvements replace the incumbent
         unsigned long long b0 = 0, b1 = 0, b2 = 0;
         for (int q = 0; q < cm; q++) { L.scur[q] = -1; L.sbest[q] = -1; }
         L.saccs[0] = 0; L.sblk[0][0] = 0; if constexpr (W > 1) L.sblk[0][1] = 0; if constexpr (W > 2) L.sblk[0][2] = 0;
         int d = 0, nodes = 0;
         bool entered = true, over = false;
+        // One endpoint: a search that is still running after kMatchNodes1 nodes asks for the optimum of the whole component (one
+        // matching) and from then on only looks for the first selection in depth-first order that reaches it: the incumbent is
+        // floored at optimum - 1, every node is tested with the exact bound of its sub-problem, so the walk descends without
+        // backtracking past a node that cannot reach the optimum, and ends at the first leaf that does.
+        int exact = 0;   // 0 not asked yet, 1 known, -1 not available (indices too far apart)
         while (d >= 0) {
             int k = 0;
             if (entered) {
                 if (++nodes > kNodeBudget) { over = true; break; }
+                if (E == 1 && exact == 0 && nodes > kMatchNodes1) {
+                    const sel_w opt = select_match_bound(L, 0, 0, 0ull, 0ull, 0ull);
+                    exact = opt == kNoBound ? -1 : 1;
+                    if (exact == 1) {
+                        if (best_w >= opt) break;   // the incumbent is the first selection of that weight in depth-first order
+                        best_w = opt - 1;
+                    }
+                }
                 if (d == cm) {
-                    if (acc > best_w) { best_w = acc; for (int q = 0; q < cm; q++) L.sbest[q] = L.scur[q]; }
+                    if (acc > best_w) {
+                        best_w = acc; for (int q = 0; q < cm; q++) L.sbest[q] = L.scur[q];
+                        if (exact == 1) break;      // the optimum, first in depth-first order
+                    }
                     d--; entered = false; continue;
                 }
                 bool cut = acc + L.ub[d] <= best_w;
@@ -2002,6 +2136,15 @@ __device__ void select_search(LDS& L) {
                         if (L.mstate[sl] != tag) break;   // empty: the chain ends here
                         if (key_eq(sl, kk)) { cut = acc + L.mval[sl] <= best_w; break; }
                     }
+                }
+                // from kMatchNodes nodes on the matching relaxation is consulted as well (where enough spans remain below)
+#ifdef TW_PROFILE_SEL
+                const long long _m0 = wall_clock64();
+#endif
+                if (!cut && (E == 1 ? exact == 1 : nodes > kMatchNodes) && cm - d >= kMatchMinDepth) { cut = select_match_prunes(L, E, d, acc, best_w, b0, b1, b2);
+#ifdef TW_PROFILE_SEL
+                    L.pt[1] += wall_clock64() - _m0; L.pt[2] += 1;
+#endif
                 }
                 if (cut) { d--; entered = false; continue; }
             } else {
@@ -2044,7 +2187,13 @@ __device__ void select_search(LDS& L) {
             }
             d--; entered = false;
         }
+#ifdef TW_PROFILE_SEL
+        L.pt[0] += wall_clock64() - _s0; L.pt[3] += nodes;
+#endif
         if (over) L.budget_hit = 1;
+#ifdef TW_SEARCH_TRACE
+        if (nodes > TW_SEARCH_TRACE) printf("search: component of %d spans, %d nodes\n", cm, nodes);
+#endif
         L.nodes_total += (unsigned long long)nodes;
         for (int q = 0; q < cm; q++) {
             const int bq = L.mem[q], kq = best_w > 0 ? L.sbest[q] : -1;
@@ -2165,6 +2314,9 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
         if (k == 0) { L.ncand[b] = (uint8_t)n; L.comp[b] = (uint8_t)b; L.pick[b] = -1; }
     }
     if (t == 0) { L.budget_hit = 0; L.nodes_total = 0ull; }
+#ifdef TW_PROFILE_SEL
+    if (t == 0) for (int q = 0; q < 6; q++) L.pt[q] = 0;
+#endif
     for (int b = t; b < m; b += nt) L.adj[b] = 0;
     group_sync();
     TW_SEL_TICK(0);
@@ -2287,7 +2439,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             }
         }
         group_sync();
-        select_search(L);
+        select_search(L, E);
         TW_SEL_TICK(5);
         }
     }
@@ -2431,8 +2583,9 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
 #ifdef TW_PROFILE_SEL
         if (threadIdx.x == 0) {
             const unsigned long long dur = (unsigned long long)(wall_clock64() - _w0);
-            atomicMax((unsigned long long*)&P.prof[8], (dur << 24) | ((unsigned long long)(last - first + 1) << 16) | 0ull);
+            atomicMax((unsigned long long*)&P.prof[8], (dur << 24) | ((unsigned long long)(last - first + 1) << 16) | (L.nodes_total >> 4 > 0xffffull ? 0xffffull : L.nodes_total >> 4));
             atomicAdd((unsigned long long*)&P.prof[9], dur);
+            if ((dur << 24) >= (P.prof[8] & ~0xffffffull)) { P.prof[10] = (unsigned long long)L.pt[0]; P.prof[11] = (unsigned long long)L.pt[1]; P.prof[12] = (unsigned long long)L.pt[2]; P.prof[13] = (unsigned long long)L.pt[3]; P.prof[14] = (unsigned long long)U.E; }
         }
 #endif
     }
