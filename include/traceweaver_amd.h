@@ -101,7 +101,17 @@ typedef struct {
      * them as handed over (traceweaver_v3.py:1115 runs before the sort of :968-971); endpoints may hold fewer spans
      * than there are incoming spans.  Timestamps must be integer microseconds (unit_time_scale == NULL). */
     const struct tw_skip_unit *skip;
+    /* Parts of a service (NULL = every unit is a whole service).  A service solved in parts -- consecutive stretches of its
+     * requests, cut at PerfectCuts (traceweaver_v3.py:1024-1039), one unit each, e.g. on several GPUs -- must get the windows
+     * of the unsplit run.  CreateWindows2 (:1056-1076) treats the service's first and last request specially: the first one
+     * is counted twice towards the size cap (current_count starts at 1, a request after a cut starts at 0), the last one is
+     * never tested for a PerfectCut.  unit_part[u] bit 0 (TW_PART_AFTER_CUT): the unit's first request follows a cut -- its
+     * first window is counted like a window after a PerfectCut; bit 1 (TW_PART_BEFORE_CUT): a cut follows the unit's last
+     * request -- that request is tested for a PerfectCut like any inner one. */
+    const uint8_t *unit_part;   /* [n_units] or NULL */
 } tw_batch;
+#define TW_PART_AFTER_CUT 1
+#define TW_PART_BEFORE_CUT 2
 
 /* What TallySkipSpans (traceweaver_v3.py:853-989) and BuildDistributions (:108-172) hand the main loop. */
 typedef struct tw_skip_unit {

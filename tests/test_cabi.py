@@ -45,7 +45,7 @@ def test_ctypes_structures_match_the_header(tmp_path):
 
     from traceweaver_amd import _ffi
 
-    fields = {"tw_batch": ("Batch", ["n_units", "unit_in_off", "key_rank", "in_start", "out_end", "batch_size", "topk", "unit_time_scale"]),
+    fields = {"tw_batch": ("Batch", ["n_units", "unit_in_off", "key_rank", "in_start", "out_end", "batch_size", "topk", "unit_time_scale", "skip", "unit_part"]),
               "tw_results": ("Results", ["parent", "topk_score", "unit_stats"]),
               "tw_span_table": ("SpanTable", ["trace", "start", "kind"]),
               "tw_unit_set": ("UnitSet", ["n_units", "unit_in_off", "out_end", "true_child", "unit_order", "n_traces", "skipped"])}

@@ -230,3 +230,53 @@ def test_stress_units_with_production_thresholds(emu_lib):
 
     units, _ = parity.stress_units(parity.STRESS)
     parity.check_units(build(production=True), units, allow_budget=True)
+
+
+def _two_bursts(seed, n_half, shape, concurrency):
+    """A service whose requests come in two bursts with an idle moment in between (no request in flight at request n_half)."""
+    from traceweaver_amd import synth
+    from traceweaver_amd.engine import UnitArrays
+
+    a, _ = synth.make_unit(seed, n_half, shape=shape, concurrency=concurrency)
+    b, _ = synth.make_unit(seed + 1, n_half, shape=shape, concurrency=concurrency, t0_us=int(a.in_end.max()) + 10_000_000)
+    assert np.array_equal(a.dag, b.dag)
+    off = np.arange(a.E + 1, dtype=np.int64) * (2 * n_half)
+    os_ = np.concatenate([np.concatenate([a.out_start[a.out_off[e]:a.out_off[e + 1]], b.out_start[b.out_off[e]:b.out_off[e + 1]]]) for e in range(a.E)])
+    oe_ = np.concatenate([np.concatenate([a.out_end[a.out_off[e]:a.out_off[e + 1]], b.out_end[b.out_off[e]:b.out_off[e + 1]]]) for e in range(a.E)])
+    return UnitArrays(np.concatenate([a.in_start, b.in_start]), np.concatenate([a.in_end, b.in_end]), off, os_, oe_, a.dag, a.key_rank)
+
+
+# (seeds at which the parts, loaded as whole services, get other windows -- and at 67 / 75 / 62 other assignments -- than the unsplit run)
+@pytest.mark.parametrize("seed,shape,conc", [(66, "single", 8.0), (67, "single", 12.0), (75, "single", 12.0), (62, "par2", 6.0), (65, "chain2", 7.0)])
+def test_split_service_with_windows_at_the_size_cap(emu_lib, seed, shape, conc):
+    """Within-service sharding (sharding.split_unit) when the windows reach the 30-request cap right after the cut: the
+    reference's window state machine counts the service's first request twice and never tests its last one for a
+    PerfectCut (traceweaver_v3.py:1056-1076); a part that continues after a cut / is followed by one must not repeat that
+    (tw_batch.unit_part) -- windows and pass-1 assignments of the stitched parts equal the unsplit run."""
+    from traceweaver_amd import sharding
+    from traceweaver_amd.engine import Engine
+
+    unit = _two_bursts(seed, 200, shape, conc)
+    cuts = sharding.split_points(unit, 2)
+    assert cuts == [200]
+    parts = sharding.split_unit(unit, cuts)
+    assert [p.part for p in parts] == [2, 1]
+    eng = Engine(0, lib_path=emu_lib)
+    eng.load([unit])
+    eng.run_pass1()
+    whole = eng.results(1)[0]
+    eng.load(parts)
+    eng.run_pass1()
+    ra, rb = eng.results(1)
+    for p in parts:
+        p.part = 0
+    eng.load(parts)
+    eng.run_pass1()
+    xa, xb = eng.results(1)
+    eng.close()
+    assert not np.array_equal(np.concatenate([xa["window_end"], xb["window_end"]]), whole["window_end"])   # the case is one that needs the flags
+    assert whole["window_end"][199] == 1 and int(whole["window_end"].sum()) < 100     # long windows on both sides of the cut
+    assert np.array_equal(np.concatenate([ra["window_end"], rb["window_end"]]), whole["window_end"])
+    stitched = np.concatenate([ra["parent"], np.where(rb["parent"] >= 0, rb["parent"] + 200, -1)], axis=1)
+    assert np.array_equal(stitched, whole["parent"])
+    assert np.array_equal(np.concatenate([ra["leaves"], rb["leaves"]]), whole["leaves"])

@@ -32,6 +32,7 @@ class Batch(ctypes.Structure):
         ("batch_size", ctypes.c_int32), ("batch_size_mis", ctypes.c_int32), ("topk", ctypes.c_int32),
         ("unit_time_scale", ctypes.c_void_p),
         ("skip", ctypes.c_void_p),
+        ("unit_part", ctypes.c_void_p),
     ]
 
 

@@ -706,6 +706,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         U.in_off = b->unit_in_off[u];
         U.tscale = b->unit_time_scale != nullptr ? b->unit_time_scale[u] : 1.0;
         U.float_time = b->unit_time_scale != nullptr ? 1 : 0;
+        U.part = b->unit_part != nullptr ? (int32_t)b->unit_part[u] : 0;
         {
             int ex = 0;
             if (!(U.tscale > 0.0) || std::frexp(U.tscale, &ex) != 0.5) return fail(e, TW_ERR_ARG, "unit_time_scale must be a positive power of two");
@@ -1493,7 +1494,7 @@ int tw_assign_service(tw_engine* e, int32_t n_in, const int64_t* in_start, const
     tw_batch b;
     b.n_units = 1; b.unit_in_off = in_off; b.unit_E = &E; b.ep_off = out_off; b.dag = dag; b.key_rank = key_rank;
     b.in_start = in_start; b.in_end = in_end; b.out_start = out_start; b.out_end = out_end;
-    b.batch_size = 100; b.batch_size_mis = 30; b.topk = TW_TOPK; b.unit_time_scale = nullptr; b.skip = nullptr;
+    b.batch_size = 100; b.batch_size_mis = 30; b.topk = TW_TOPK; b.unit_time_scale = nullptr; b.skip = nullptr; b.unit_part = nullptr;
     int rc = tw_load_batch(e, &b, 0);
     if (rc == TW_OK) rc = tw_run_pass1(e);
     if (rc == TW_OK && mix_n != nullptr) {

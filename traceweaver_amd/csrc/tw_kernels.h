@@ -1786,7 +1786,7 @@ __global__ void k_perfect_cut(Dev P) {
     if (i >= U.n_in) return;
     const int64_t g = U.in_off + i;
     uint8_t cut = 0;
-    if (i >= 1 && i <= U.n_in - 2) {
+    if (i >= 1 && (i <= U.n_in - 2 || (U.part & TW_PART_BEFORE_CUT))) {   // (the service's last request is never tested: traceweaver_v3.py:1059)
         const int prev = P.pm_idx[g - 1];
         if (P.pm_val[g - 1] <= P.in_end[g]) {
             bool disjoint = true;
@@ -1820,10 +1820,10 @@ __global__ void k_window_flags(Dev P) {
     const int64_t g = U.in_off + i;
     const int n = U.n_in, B = P.batch_mis;
     bool end = (i == n - 1);
-    if (!end && P.pc[g + 1]) end = true;  // pc is 0 outside [1, n-2]
+    if (!end && P.pc[g + 1]) end = true;  // pc is 0 outside [1, n-2] (n-1 for a part that a cut follows)
     if (!end && i >= 1) {
         const int s = P.seg[g];
-        const int d = i - s - (s == 0 ? B - 1 : B);
+        const int d = i - s - ((s == 0 && !(U.part & TW_PART_AFTER_CUT)) ? B - 1 : B);   // (the service's first request counts twice: current_count starts at 1)
         if (d >= 0 && d % B == 0 && !P.pc[g]) end = true;
     }
     P.win_end[g] = end ? 1 : 0;

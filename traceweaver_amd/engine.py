@@ -21,10 +21,14 @@ class UnitArrays(object):
     """Structure-of-arrays form of one unit: endpoints in topological order of the call-order DAG
     (traceweaver_v1.py:37-39), every span list sorted by (start, end) (executor.py:1112)."""
 
-    def __init__(self, in_start, in_end, out_off, out_start, out_end, dag, key_rank=None, time_scale=None):
+    AFTER_CUT, BEFORE_CUT = 1, 2   # tw_batch.unit_part
+
+    def __init__(self, in_start, in_end, out_off, out_start, out_end, dag, key_rank=None, time_scale=None, part=0):
         # time_scale: None = int64 microseconds.  A power of two = the timestamps are exact images of binary64
         # values in units of time_scale microseconds (load-scaled units, traceweaver_amd.transforms).
         self.time_scale = None if time_scale is None else float(time_scale)
+        # part: the unit is a stretch of a service's requests between cuts (sharding.split_unit): AFTER_CUT / BEFORE_CUT
+        self.part = int(part)
         self.in_start = np.ascontiguousarray(in_start, dtype=np.int64)
         self.in_end = np.ascontiguousarray(in_end, dtype=np.int64)
         self.out_off = np.ascontiguousarray(out_off, dtype=np.int64)
@@ -139,6 +143,7 @@ class Engine(object):
         if any(scaled) and not all(scaled):
             raise ValueError("a batch holds either integer-microsecond units or load-scaled units, not both")
         arrays["unit_time_scale"] = np.array([u.time_scale for u in units], dtype=np.float64) if all(scaled) else None
+        arrays["unit_part"] = np.array([u.part for u in units], dtype=np.uint8) if any(u.part for u in units) else None
         skip_arr = None
         if skip is not None:
             if len(skip) != len(units):
@@ -155,7 +160,7 @@ class Engine(object):
         b = _ffi.Batch(len(units), *[_vp(arrays[k]) for k in (
             "unit_in_off", "unit_E", "ep_off", "dag", "key_rank", "in_start", "in_end", "out_start", "out_end")],
             batch_size, batch_size_mis, _ffi.TW_TOPK, _vp(arrays["unit_time_scale"]),
-            ctypes.cast(skip_arr, ctypes.c_void_p) if skip_arr is not None else ctypes.c_void_p(0))
+            ctypes.cast(skip_arr, ctypes.c_void_p) if skip_arr is not None else ctypes.c_void_p(0), _vp(arrays["unit_part"]))
         self._check(self._lib.tw_load_batch(self._h, ctypes.byref(b), 0))
         self._in_off = in_off
         self._ie_off = np.concatenate([[0], np.cumsum([u.n_in * u.E for u in units])]).astype(np.int64)

@@ -138,7 +138,8 @@ def split_unit(unit, cuts):
         oe_ = np.concatenate([unit.out_end[unit.out_off[e] + a:unit.out_off[e] + b] for e in range(unit.E)])
         if any(int(unit.out_off[e + 1] - unit.out_off[e]) != unit.n_in for e in range(unit.E)):
             raise ValueError("only no-skip units are split")
-        p = UnitArrays(unit.in_start[a:b], unit.in_end[a:b], off, os_, oe_, unit.dag, unit.key_rank)
+        part = (UnitArrays.AFTER_CUT if a > 0 else 0) | (UnitArrays.BEFORE_CUT if b < unit.n_in else 0)
+        p = UnitArrays(unit.in_start[a:b], unit.in_end[a:b], off, os_, oe_, unit.dag, unit.key_rank, part=part)
         if a > 0:   # the idle moment: everything before has ended before anything after starts
             assert unit.in_end[:a].max() < unit.in_start[a] and all(
                 unit.out_end[unit.out_off[e]:unit.out_off[e] + a].max() < unit.out_start[unit.out_off[e] + a] for e in range(unit.E))
