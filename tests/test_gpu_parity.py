@@ -16,6 +16,24 @@ from traceweaver_amd import _ffi, synth
 pytestmark = pytest.mark.gpu
 
 
+def tie_spans(path):
+    """Incoming spans of a frozen run that lie in a window whose optimum is proven not unique (tests/golden/tie_windows.json,
+    written by tests/golden/make_tie_windows.py): only there may an exact selection differ from the frozen run's."""
+    import json
+
+    with open(os.path.join(os.path.dirname(path), "tie_windows.json")) as f:
+        t = json.load(f).get(os.path.basename(path)[:-4], {"pass1": [], "pass2": []})
+    return set(t["pass1"]), set(t["pass2"])
+
+
+def assert_differs_only_in_tie_windows(path, d, r1, r2):
+    t1, t2 = tie_spans(path)
+    d1 = set(np.flatnonzero((r1["parent"] != d["pass1_parent"]).any(axis=0)).tolist())
+    d2 = set(np.flatnonzero((r2["parent"] != d["final_parent"]).any(axis=0)).tolist())
+    assert d1 <= t1, "pass 1 differs from the frozen reference run outside the tied windows: %s" % sorted(d1 - t1)
+    assert d2 <= t2, "pass 2 differs from the frozen reference run outside the tied windows: %s" % sorted(d2 - t2)
+
+
 def test_native_library_present():
     assert os.path.exists(_ffi.DEFAULT_LIB), "libtwgpu.so must be prebuilt in-tree (python -c 'import __graft_entry__ as g; g.build()')"
 
@@ -25,12 +43,11 @@ def test_reference_corpora(path):
     d = np.load(path)
     svc, unit = unit_from_golden(d)
     r1, r2, _ = parity.check_units(None, [unit], mixtures=[golden_mixtures(d)])
-    # identical to the frozen reference run except inside the (rare) windows whose optimum is not unique
-    # -- tests/test_oracle_golden.py proves those are exact ties.  The ms-granular heavy-load units are
+    # identical to the frozen reference run except inside the (rare) windows whose optimum is proven not to be unique
+    # (16 of the 90 runs hold one; tests/golden/tie_windows.json).  The ms-granular heavy-load units are
     # saturated with ties that cascade through span consumption; for them only engine == oracle is asserted.
     if not str(d["dataset"]).startswith("synthetic"):
-        assert (r1[0]["parent"] != d["pass1_parent"]).any(axis=0).sum() <= 4
-        assert (r2[0]["parent"] != d["final_parent"]).any(axis=0).sum() <= 4
+        assert_differs_only_in_tie_windows(path, d, r1[0], r2[0])
         assert r2[0]["cnt_unassigned"] == int(d["cnt_unassigned"])
     assert np.array_equal(r1[0]["leaves"] + r2[0]["leaves"], d["per_span_candidates"])
     ref = d["p1_topk2_score"]
@@ -43,10 +60,9 @@ def test_all_corpora_in_one_batch():
     ds = [np.load(p) for p in GOLDEN]
     units = [unit_from_golden(d)[1] for d in ds]
     r1, r2, _ = parity.check_units(None, units, mixtures=[golden_mixtures(d) for d in ds])
-    for d, a, b in zip(ds, r1, r2):
+    for path, d, a, b in zip(GOLDEN, ds, r1, r2):
         if not str(d["dataset"]).startswith("synthetic"):
-            assert (a["parent"] != d["pass1_parent"]).any(axis=0).sum() <= 4
-            assert (b["parent"] != d["final_parent"]).any(axis=0).sum() <= 4
+            assert_differs_only_in_tie_windows(path, d, a, b)
 
 
 def test_stress_units():

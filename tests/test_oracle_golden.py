@@ -120,3 +120,20 @@ def test_gap_samples_and_final_refit(case, oracle):
         if checked >= 3:
             break
     assert checked > 0
+
+
+def test_tie_window_list_is_current(case):
+    """tests/golden/tie_windows.json (what the GPU tier accepts as differences from the frozen runs) holds exactly the tied
+    windows this module proves."""
+    import json
+    import os
+
+    d, svc, end_flag, pre, win, g, p1, p2 = case
+    if str(d["dataset"]).startswith("synthetic"):
+        pytest.skip("tie-saturated synthetic unit: compared with the oracle only")
+    name = "ref_%s__%s" % (str(d["dataset"]), str(d["process"]))
+    with open(os.path.join(os.path.dirname(GOLDEN[0]), "tie_windows.json")) as f:
+        listed = json.load(f)
+    t = listed.get(name, {"pass1": [], "pass2": []})
+    assert sorted(int(i) for i in _tie_windows(d, 0, p1, win)) == t["pass1"]
+    assert sorted(int(i) for i in _tie_windows(d, 1, p2, win)) == t["pass2"]
