@@ -14,7 +14,7 @@ TAG=${1:-r02}
 shift || true
 # --sync engine: bench.py without torch (N = 1; every C-ABI call returns synchronised) -- a fresh box spends a minute or
 # two on its first `import torch`, once per pass
-ARGS="--steps 5 --warmup 1 --cpu-sample 0 --sync engine $*"
+ARGS="--steps 5 --warmup 1 --cpu-sample 0 --regimes 0 --sync engine $*"
 PASSES=${PASSES:-"fetch write sq1 sq2 grbm"}
 export TMPDIR=/tmp
 T="timeout ${PASS_TIMEOUT:-240}"

@@ -116,7 +116,6 @@ struct tw_engine {
     uint32_t *seg_gap = nullptr, *seg_gap_end = nullptr, *seg_gap_dst = nullptr;
     unsigned long long *comp_a = nullptr, *comp_b = nullptr;  // composite keys of sort_rows
     int64_t comp_cap = 0, n_gap_scored = 0;
-    unsigned long long ts_fixed = 0;        // the bits all end times share above ts_end_bit
     int32_t *truth = nullptr, *in_trace = nullptr;  // tw_set_truth
     uint8_t* trace_bad = nullptr;           // [2][n_traces]
     unsigned long long* eval_counts = nullptr;  // [n_units][4] + [2]
@@ -124,7 +123,6 @@ struct tw_engine {
     uint8_t* slot_scored = nullptr;
     int64_t n_gap_rows = 0;
     unsigned long long* key_acc = nullptr;  // [2] scratch of k_key_bits
-    unsigned ts_end_bit = 64;               // timestamps differ only below this bit (whole batch)
     double fit_ms = 0.0;
     int rounds = 0;                         // repair rounds of the last pass
     bool skip_mode = false;                 // skip-mode batch (tw_batch.skip): one pass with skip spans
@@ -316,22 +314,6 @@ unsigned bit_length(unsigned long long x) {
     return n;
 }
 
-// End times of one batch share their upper bits: the sorts of run_pass only look at the bits that differ.
-// All keys must agree above end_bit, so both arrays are measured against the same reference key.
-int measure_end_bits(tw_engine* e) {
-    const Dev& P = e->P;
-    unsigned long long a[2], b[2], first_in = 0, first_out = 0;
-    int rc = key_bits(e, P.in_end, e->seg_in, e->seg_in + 1, P.n_units, P.n_in_total, a);
-    if (rc == TW_OK) rc = key_bits(e, P.out_end, e->seg_out, e->seg_out + 1, e->n_seg_out, P.n_out_total, b);
-    if (rc != TW_OK) return rc;
-    HIPCHK(hipMemcpy(&first_in, P.in_end, sizeof(first_in), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&first_out, P.out_end, sizeof(first_out), hipMemcpyDeviceToHost));
-    e->ts_end_bit = std::max(1u, bit_length(a[0] | b[0] | (first_in ^ first_out)));
-    if (e->ts_end_bit > 63) e->ts_end_bit = 64;  // keys of both signs: full width (sign handling is rocprim's)
-    e->ts_fixed = e->ts_end_bit >= 64 ? 0ull : (first_in >> e->ts_end_bit) << e->ts_end_bit;
-    return TW_OK;
-}
-
 int ensure_sort_tmp(tw_engine* e, size_t bytes) {
     if (bytes > e->sort_tmp_bytes) {
         void* q = nullptr;
@@ -380,13 +362,17 @@ int sort_rows(tw_engine* e, const Key* keys, Key* out, unsigned size, const uint
     return TW_OK;
 }
 
+// (no-skip batches: every endpoint list holds one span per incoming span, all lists sorted by (start, end).  The counters
+// borrow two per-span words that the pass writes only later: the window ids and the owner words)
 int sort_ends(tw_engine* e) {
     const Dev& P = e->P;
-    int rc = sort_rows(e, P.in_end, P.in_end_sorted, (unsigned)P.n_in_total, e->seg_in, e->seg_in + 1, e->seg_in, P.n_units, P.n_in_total,
-                       0, e->ts_end_bit, e->ts_fixed);
-    if (rc != TW_OK) return rc;
-    return sort_rows(e, P.out_end, P.out_end_sorted, (unsigned)P.n_out_total, e->seg_out, e->seg_out + 1, e->seg_out, e->n_seg_out,
-                     P.n_out_total, 0, e->ts_end_bit, e->ts_fixed);
+    const dim3 tiles(P.n_tiles), tb(e->tile);
+    HIPCHK(hipMemsetAsync(P.wid, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(P.n_in_total, 1), e->stream));
+    HIPCHK(hipMemsetAsync(P.owner, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(P.n_out_total, 1), e->stream));
+    hipLaunchKernelGGL(k_rank_ends, tiles, tb, 0, e->stream, P, P.wid, P.owner);
+    hipLaunchKernelGGL(k_place_ends, tiles, tb, 0, e->stream, P, (const int32_t*)P.wid, (const int32_t*)P.owner);
+    HIPCHK(hipGetLastError());
+    return TW_OK;
 }
 
 int run_pass(tw_engine* e, int pass) {
@@ -636,8 +622,6 @@ extern "C" int tw_scale_load(tw_engine* e, const int32_t* unit_factor, const int
     }
     HIPCHK(hipMemcpyAsync(const_cast<UnitDev*>(P.units), e->units.data(), sizeof(UnitDev) * e->units.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    rc = measure_end_bits(e);
-    if (rc != TW_OK) return rc;
     e->state = ST_LOADED;
     return TW_OK;
 }
@@ -965,8 +949,6 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipMemsetAsync(e->mix_n_dev, 0, sizeof(int32_t) * std::max<int64_t>(slots, 1), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->scaled_upload = b->unit_time_scale != nullptr;
-    rc = measure_end_bits(e);
-    if (rc != TW_OK) return rc;
     e->state = ST_LOADED;
     return TW_OK;
 }

@@ -153,6 +153,39 @@ __global__ void k_rows_unpack(const unsigned long long* comp, const uint32_t* se
 }
 
 // ---------------------------------------------------------------------------------------------
+// End times of every list in ascending order (the rank-aligned arrays of ComputeEpPairDistParams3, traceweaver_v3.py:590-646,
+// `sorted(...)` of the ends).  The lists are sorted by (start, end), so their ends are nearly sorted: span j > i ends before
+// span i only if it started while i was in flight.  Rank = index + (later spans that end earlier) - (earlier spans that end
+// later): one thread per span walks forward over the spans that start before it ends -- as many as are in flight with it --
+// and counts; 16 B per span read once, 8 B written, 4 B of counter: a device-wide radix sort of the same keys took five
+// read + write passes (43 % of the HBM traffic of a step in round 2).  Ties keep their order (equal values: same array).
+__device__ __forceinline__ void rank_list(const int64_t* st, const int64_t* en, int n, int i, int32_t* delta) {
+    const int64_t a = en[i];
+    int cnt = 0;
+    for (int j = i + 1; j < n && st[j] < a; j++)
+        if (en[j] < a) { cnt++; atomicAdd(&delta[j], -1); }
+    if (cnt) atomicAdd(&delta[i], cnt);
+}
+__global__ void k_rank_ends(Dev P, int32_t* d_in, int32_t* d_out) {   // both zeroed
+    const TileDev Tl = P.tiles[blockIdx.x];
+    const UnitDev& U = P.units[Tl.unit];
+    const int i = Tl.first + threadIdx.x;
+    if (i >= U.n_in) return;
+    rank_list(P.in_start + U.in_off, P.in_end + U.in_off, U.n_in, i, d_in + U.in_off);
+    for (int e = 0; e < U.E; e++)
+        rank_list(P.out_start + U.ep_off[e], P.out_end + U.ep_off[e], (int)(U.ep_off[e + 1] - U.ep_off[e]), i, d_out + U.ep_off[e]);
+}
+__global__ void k_place_ends(Dev P, const int32_t* d_in, const int32_t* d_out) {
+    const TileDev Tl = P.tiles[blockIdx.x];
+    const UnitDev& U = P.units[Tl.unit];
+    const int i = Tl.first + threadIdx.x;
+    if (i >= U.n_in) return;
+    P.in_end_sorted[U.in_off + i + d_in[U.in_off + i]] = P.in_end[U.in_off + i];
+    for (int e = 0; e < U.E; e++)
+        P.out_end_sorted[U.ep_off[e] + i + d_out[U.ep_off[e] + i]] = P.out_end[U.ep_off[e] + i];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Pass-1 Gaussian parameters: one thread per (unit, 100-span block, slot).
 // mean = (sum t2 - sum t1)/n over rank-aligned sorted arrays, std = sqrt(ceil(n/10)) * tstd(batch means).
 __global__ void k_block_params(Dev P, int64_t total) {
