@@ -436,6 +436,8 @@ def main():
     eng.load(units)
     eng.set_truth(truth)
 
+    on_device = dist is not None and red_dev == "cuda"   # collectives on the engine's device buffers (sharding.*_device)
+
     def sync():
         if not emulated and not no_torch:
             torch.cuda.synchronize()
@@ -450,7 +452,10 @@ def main():
         if split:   # pass 1 -> gap rows of all parts on every rank -> the same refit everywhere -> pass 2
             eng.run_pass1()
             t1 = eng.timing()
-            sharding.refit_split_services(eng, fit_eng, mine, part_service, part_order, whole_units, dist=dist, device=red_dev)
+            if on_device:   # the gap rows are gathered from / joined in / refitted from device memory (RCCL on the engine's buffers)
+                sharding.refit_split_services_device(eng, fit_eng, parts, all_units, part_service, part_order, whole_units, dist)
+            else:
+                sharding.refit_split_services(eng, fit_eng, mine, part_service, part_order, whole_units, dist=dist, device=red_dev)
             eng.run_pass2()
             t2 = eng.timing()
             t2["fit"] = fit_eng.timing()["fit"]
@@ -458,7 +463,9 @@ def main():
         else:
             t1, t2, res = one_step(eng, args.fit, mine)
         gathered = None
-        if strong:  # the exchange step of the sharded slice: parents of every service on every rank
+        if strong and on_device:   # the exchange step on the engine's own buffer: one ncclAllGather, parents on the host of rank 0 only
+            gathered = sharding.gather_parents_device(eng, parts, all_units, dist, host_ranks=(0,))
+        elif strong:  # (gloo / one process) the same exchange through host memory
             local = [r["parent"] for r in eng.results(2, fields=("parent",))]
             gathered = sharding.gather_parents(local, mine, len(all_units), dist=dist, device=red_dev)
         return t1, t2, res, gathered
@@ -521,10 +528,11 @@ def main():
     host_acc = [synth.accuracy(r["parent"], tp) for r, tp in zip(host, truth)]
     assert all(abs(a - r["accuracy"]) < 1e-12 for a, r in zip(host_acc, res)), "device accuracy reduction differs from the host's"
     verified = None
-    if strong:
+    if strong and gathered is not None:
         for k, p in zip(mine, host):
             assert np.array_equal(gathered[k], p["parent"]), "gathered parents differ from the local result"
         assert all(g is not None for g in gathered), "the gather left a unit out"
+    if strong:
         if args.verify and rank == 0 and (world > 1 or split):
             eng.load(whole_units)
             eng.set_truth(whole_truth)

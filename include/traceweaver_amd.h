@@ -149,6 +149,24 @@ int tw_get_gaps(tw_engine *e, double *gaps);
  * consecutive stretches of the service's requests are concatenated in that order. */
 int tw_set_gaps(tw_engine *e, const double *gaps);
 
+/* The engine's own device buffers of the two exchange steps of a sharded run, so that a collective
+ * (ncclAllGather = RCCL over xGMI) works on them in place -- no copy through host memory:
+ *   parent  int32 [sum_u E_u * n_in_u]          parent indices of the last pass run, unit after unit, [E][n_in] per unit
+ *                                               (the layout of tw_results.parent)
+ *   gaps    double [sum_u nslot_u * n_in_u]     gap rows of the pass-1 assignment (the layout of tw_get_gaps)
+ * Valid until the next tw_load_batch; every entry point returns with the engine's stream synchronised, so the buffers
+ * are complete when the caller reads them.  tw_set_gaps_device is tw_set_gaps with a device pointer (the gathered rows
+ * of a split service stay in HBM on their way into the refit). */
+typedef struct {
+    void *parent;
+    int64_t parent_count;
+    void *gaps;
+    int64_t gaps_count;
+    int32_t device;
+} tw_device_view;
+int tw_device_buffers(tw_engine *e, tw_device_view *out);
+int tw_set_gaps_device(tw_engine *e, const double *dev_gaps);
+
 /* Mixtures for pass 2 (the fitted sklearn GaussianMixture objects of traceweaver_v3.py:784-786):
  * mix_n[sum_u nslot_u] components per slot (0 = "(0,0)" fallback, traceweaver_v3.py:765-766),
  * mix_p[sum_u nslot_u][TW_MAX_COMP][3] = weight, mean, precision_cholesky. */

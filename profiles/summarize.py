@@ -30,7 +30,7 @@ def group_of(name):
         return "k_select"
     if "k_fit" in name:
         return "k_fit"
-    if "rocprim" in name or "k_rows_" in name or "k_key_bits" in name:
+    if "rocprim" in name or "k_rows_" in name or "k_key_bits" in name or "k_rank_ends" in name or "k_place_ends" in name:
         return "sort"
     if "k_block_params" in name:
         return "params"

@@ -985,6 +985,27 @@ int tw_set_gaps(tw_engine* e, const double* gaps) {
     return TW_OK;
 }
 
+int tw_device_buffers(tw_engine* e, tw_device_view* out) {
+    if (e == nullptr || out == nullptr) return TW_ERR_ARG;
+    if (e->state < ST_LOADED) return fail(e, TW_ERR_STATE, "tw_device_buffers before tw_load_batch");
+    out->parent = e->P.parent; out->parent_count = e->n_ie;
+    out->gaps = e->P.gaps; out->gaps_count = e->n_gaps;
+    out->device = e->device;
+    return TW_OK;
+}
+
+int tw_set_gaps_device(tw_engine* e, const double* dev_gaps) {
+    if (e == nullptr || dev_gaps == nullptr) return TW_ERR_ARG;
+    if (e->state < ST_LOADED) return fail(e, TW_ERR_STATE, "tw_set_gaps_device before tw_load_batch");
+    if (e->skip_mode) return fail(e, TW_ERR_STATE, "a skip-mode batch runs one pass (traceweaver_v3.py:1155-1156): there is no refit");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->P.gaps, dev_gaps, sizeof(double) * e->n_gaps, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->fit_prepared = false;
+    e->state = ST_PASS1;
+    return TW_OK;
+}
+
 int tw_set_mixtures(tw_engine* e, const int32_t* mix_n, const double* mix_p) {
     if (e == nullptr || mix_n == nullptr || mix_p == nullptr) return TW_ERR_ARG;
     if (e->state < ST_PASS1) return fail(e, TW_ERR_STATE, "tw_set_mixtures before tw_run_pass1");

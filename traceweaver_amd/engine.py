@@ -189,6 +189,24 @@ class Engine(object):
             raise ValueError("gap rows do not match the loaded batch")
         self._check(self._lib.tw_set_gaps(self._h, _vp(g)))
 
+    class _DeviceArray(object):
+        """A device buffer of the engine as the CUDA array interface describes it (torch.as_tensor takes it without a copy)."""
+
+        def __init__(self, ptr, count, typestr):
+            self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": (int(count),), "typestr": typestr, "version": 2}
+
+    def device_views(self):
+        """(parent, gaps): the engine's device buffers of the two exchange steps (tw_device_buffers) as objects with
+        `__cuda_array_interface__` -- int32 [sum E * n_in] parent indices of the last pass run, float64 gap rows of pass 1;
+        `torch.as_tensor(view, device="cuda")` wraps them in place for an all-gather over RCCL (sharding.py)."""
+        v = _ffi.DeviceView()
+        self._check(self._lib.tw_device_buffers(self._h, ctypes.byref(v)))
+        return (Engine._DeviceArray(v.parent or 0, v.parent_count, "<i4"), Engine._DeviceArray(v.gaps or 0, v.gaps_count, "<f8"))
+
+    def set_gaps_device(self, ptr):
+        """set_gaps with a device pointer (int): the gathered rows stay in HBM."""
+        self._check(self._lib.tw_set_gaps_device(self._h, ctypes.c_void_p(int(ptr))))
+
     def set_mixtures(self, mix_n, mix_p):
         """mix_n / mix_p: per unit arrays [nslot] int32 and [nslot, 5, 3] (weight, mean, precision_cholesky)."""
         n = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int32).ravel() for a in mix_n]), dtype=np.int32)

@@ -72,6 +72,38 @@ def gather_parents(local_parents, local_ids, n_units, dist=None, device="cpu"):
     return out
 
 
+def gather_parents_device(engine, rank_units, all_units, dist, host_ranks=(0,)):
+    """The final exchange step on the engine's own device buffer (tw_device_buffers): ONE all-gather (ncclAllGather = RCCL over
+    xGMI with backend "nccl") of the parent indices as they lie in HBM, 4 B per outgoing span -- no copy through host memory
+    on the way in, and the gathered arrays come back to the host only on `host_ranks` (the rank that stitches the
+    end-to-end traces).  rank_units[r] = ids of the units rank r holds, in the order it loaded them (the partition every
+    rank computes, shard_units); all_units = the units (shapes only).  Returns the list of parent arrays [E, n] per unit on
+    the host ranks, None elsewhere."""
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [sum(all_units[k].E * all_units[k].n_in for k in ids) for ids in rank_units]
+    width = max(sizes)
+    view, _ = engine.device_views()
+    local = torch.as_tensor(view, device="cuda")                       # the engine's buffer, in place
+    assert local.numel() == sizes[rank]
+    if local.numel() < width:                                            # ranks hold different numbers of spans: pad on the device
+        local = torch.cat([local, torch.zeros(width - local.numel(), dtype=torch.int32, device=local.device)])
+    out = torch.empty(world * width, dtype=torch.int32, device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    if host_ranks is not None and rank not in host_ranks:
+        return None
+    host = out.cpu().numpy()
+    res = [None] * len(all_units)
+    for r, ids in enumerate(rank_units):
+        pos = r * width
+        for k in ids:
+            u = all_units[k]
+            res[k] = host[pos:pos + u.E * u.n_in].reshape(u.E, u.n_in).copy()
+            pos += u.E * u.n_in
+    return res
+
+
 def end_to_end_accuracy(trace_flags, dist=None, device="cpu"):
     """AccuracyEndToEnd / TopKAccuracyEndToEnd (helpers/utils.py:99-145) when the services of a trace were solved
     on different ranks: a trace is right iff no rank saw a wrong span of it.  `trace_flags` = the [2, n_traces]
@@ -145,6 +177,47 @@ def split_unit(unit, cuts):
                 unit.out_end[unit.out_off[e]:unit.out_off[e] + a].max() < unit.out_start[unit.out_off[e] + a] for e in range(unit.E))
         parts.append(p)
     return parts
+
+
+def refit_split_services_device(engine, fit_engine, rank_parts, parts, part_service, part_order, service_units, dist, seed=0):
+    """refit_split_services on device memory: the gap rows of the local parts are all-gathered from the engine's own buffer
+    (tw_device_buffers; ncclAllGather = RCCL over xGMI), the rows of every service are joined in request order on the
+    device and handed to the refit without leaving HBM (tw_set_gaps_device); only the fitted tables (a few hundred bytes per
+    edge) travel to the host, to be set on the local parts.  rank_parts[r] = part ids on rank r in load order; parts = all
+    parts (shapes only)."""
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [sum(parts[p].nslot * parts[p].n_in for p in ids) for ids in rank_parts]
+    width = max(sizes)
+    _, view = engine.device_views()
+    local = torch.as_tensor(view, device="cuda")
+    assert local.numel() == sizes[rank]
+    if local.numel() < width:
+        local = torch.cat([local, torch.zeros(width - local.numel(), dtype=torch.float64, device=local.device)])
+    out = torch.empty(world * width, dtype=torch.float64, device=local.device)
+    dist.all_gather_into_tensor(out, local)      # the gather of gap samples: 8 B per (scored edge, request)
+    rows = {}
+    for r, ids in enumerate(rank_parts):
+        pos = r * width
+        for p in ids:
+            n = parts[p].nslot * parts[p].n_in
+            rows[p] = out[pos:pos + n].view(parts[p].nslot, parts[p].n_in)
+            pos += n
+    services = sorted({part_service[p] for p in rows})
+    fit_engine.load([service_units[s] for s in services])
+    joined = []
+    for s in services:
+        mine = sorted((p for p in rows if part_service[p] == s), key=lambda p: part_order[p])
+        joined.append(torch.cat([rows[p] for p in mine], dim=1).reshape(-1))
+    flat = torch.cat(joined).contiguous()
+    torch.cuda.synchronize()
+    fit_engine.set_gaps_device(flat.data_ptr())
+    fit_engine.fit_mixtures(unit_seeds=[seed + s for s in services])
+    tables = {s: (mn.copy(), mp.copy()) for s, (mn, mp) in zip(services, fit_engine.mixtures())}
+    local_parts = rank_parts[rank]
+    engine.set_mixtures([tables[part_service[p]][0] for p in local_parts], [tables[part_service[p]][1] for p in local_parts])
+    return tables
 
 
 def refit_split_services(engine, fit_engine, local_parts, part_service, part_order, service_units, dist=None, device="cpu", seed=0):
