@@ -24,6 +24,12 @@ Workloads (--workload):
            scaling: total work is fixed.  With --verify rank 0 also solves the whole slice alone and the gathered
            parents must equal that result.
 
+  alibaba-full  config 5: the 15 Alibaba-shape call graphs (--total-spans engine spans in all) at the six load levels of
+           exps/exp5 (compress factors 1 ... 15000; a service's load factor is max(1, ceil(factor / #replicas)),
+           executor.py:1089-1097, replica table generated with the corpus): the services are sharded over the ranks and
+           uploaded ONCE; every step scales the resident table to each level in turn (tw_scale_load), solves it and
+           gathers the parents (RCCL on the engine's buffers).  Strong scaling; value = spans x levels per second.
+
   media-split  within-service sharding: ONE media-shape graph whose six services hold --n-in x --replicas requests each;
            every service is cut at idle moments into one part per rank (sharding.split_points / split_unit), the parts'
            gap samples are all-gathered between the passes and every rank refits on the union
@@ -57,7 +63,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="media", choices=["media", "nodejs", "alibaba", "media-split"])
+    ap.add_argument("--workload", default="media", choices=["media", "nodejs", "alibaba", "alibaba-full", "media-split"])
+    ap.add_argument("--levels", default="1,200,1000,4000,10000,15000",
+                    help="alibaba-full: the --compress_factor values every call graph is solved at (exps/exp5/run_experiment.sh:60-156)")
     ap.add_argument("--n-in", type=int, default=100000, help="requests per service unit (media / nodejs)")
     ap.add_argument("--replicas", type=int, default=None,
                     help="copies of the service graph per GPU (media / nodejs).  Default: 16 for the media workload -- a resident batch "
@@ -152,8 +160,13 @@ def make_units(args, seed, n_in=None, replicas=None, total_spans=None):
         name = "nodejs_microservices_with_arbitrary_file_io shape (4 services, E in {1,2,1,1}, ms-granular), %d requests/service x %d replicas per GPU, concurrency %.1f" % (
             n_in, replicas, conc)
         return u, t, name
-    conc = 1.3 if args.concurrency is None else args.concurrency
+    full = args.workload == "alibaba-full"
+    conc = (1.0 if full else 1.3) if args.concurrency is None else args.concurrency
     u, t, _ = synth.make_alibaba_workload(10, args.total_spans if total_spans is None else total_spans, concurrency=conc)
+    if full:
+        name = "alibaba_microservices shape, full matrix: 15 call graphs (%d services, %d spans, ms-granular) x %d load levels (compress factors %s), sharded per service, concurrency %.1f at level 1" % (
+            len(u), sum(x.n_spans for x in u), len(args.levels.split(",")), args.levels, conc)
+        return u, t, name
     name = "alibaba_microservices shape, one %d-span slice (15 call graphs, %d services, ms-granular), sharded per service, concurrency %.1f" % (
         sum(x.n_spans for x in u), len(u), conc)
     return u, t, name
@@ -406,8 +419,9 @@ def main():
     from traceweaver_amd import sharding
     from traceweaver_amd.engine import Engine
 
-    strong = args.workload in ("alibaba", "media-split")
+    strong = args.workload in ("alibaba", "alibaba-full", "media-split")
     split = args.workload == "media-split"
+    full = args.workload == "alibaba-full"
     all_units, all_truth, wl_name = make_units(args, 1000 + (0 if strong else rank))
     whole_units, whole_truth = all_units, all_truth
     part_service, part_order, part_base = [], [], []
@@ -448,7 +462,24 @@ def main():
             dist.barrier()
         sync()
 
+    levels, level_factors = [None], {}
+    if full:   # exp5's load levels: per-service load factor from the replica table (executor.py:1089-1097)
+        from traceweaver_amd import synth, transforms
+
+        levels = [float(x) for x in args.levels.split(",")]
+        replicas_all = synth.alibaba_replicas(10, len(all_units))
+        level_factors = {f: [transforms.load_factor(f, r) for r in replicas_all] for f in levels}
+
     def step():
+        """One step = every load level in turn (one for the workloads without levels): list of (t1, t2, res, gathered)."""
+        out = []
+        for f in levels:
+            if f is not None:   # the resident table, as uploaded, scaled to this level (helpers/transforms.py:10-40 on the device)
+                eng.scale_load([level_factors[f][k] for k in mine])
+            out.append(step_level())
+        return out
+
+    def step_level():
         if split:   # pass 1 -> gap rows of all parts on every rank -> the same refit everywhere -> pass 2
             eng.run_pass1()
             t1 = eng.timing()
@@ -495,13 +526,14 @@ def main():
     t0 = time.perf_counter()
     enum_ms, sel_ms, fit_ms, pass_ms, rep_ms, rounds = [], [], [], [], [], []
     for _ in range(args.steps):
-        t1, t2, res, gathered = step()
-        enum_ms += [t1["enumerate"], t2["enumerate"]]
-        sel_ms += [t1["select"], t2["select"]]
-        rep_ms += [t1["repair"], t2["repair"]]
-        rounds += [t1["rounds"], t2["rounds"]]
-        fit_ms += [t2["fit"]]
-        pass_ms += [t1["pass"], t2["pass"]]
+        per_level = step()
+        for t1, t2, res, gathered in per_level:
+            enum_ms += [t1["enumerate"], t2["enumerate"]]
+            sel_ms += [t1["select"], t2["select"]]
+            rep_ms += [t1["repair"], t2["repair"]]
+            rounds += [t1["rounds"], t2["rounds"]]
+            fit_ms += [t2["fit"]]
+            pass_ms += [t1["pass"], t2["pass"]]
     barrier()
     dt = time.perf_counter() - t0
     stats2 = eng.results(2, fields=("unit_stats",))
@@ -520,13 +552,22 @@ def main():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         c = c.cpu().numpy()
         counters, acc_sum = c[:4], c[4:]
-    spans_total = float(sum(per_rank_spans))
+    spans_total = float(sum(per_rank_spans)) * len(levels)   # every level is a reconstruction of all spans
+    acc_levels = []
+    if full:
+        lv = np.array([[sum(r["correct"] for r in lr[2]), sum(r["n_in"] for r in lr[2])] for lr in per_level], dtype=np.float64)
+        if world > 1:
+            tl = torch.from_numpy(lv).to(red_dev)
+            dist.all_reduce(tl, op=dist.ReduceOp.SUM)
+            lv = tl.cpu().numpy()
+        acc_levels = [float(a / max(b, 1)) for a, b in lv]
     acc = float(np.mean([r["accuracy"] for r in res])) if not strong else float(acc_sum[0] / max(acc_sum[1], 1))
     host = eng.results(2, fields=("parent",))          # cross-check of the device reduction, outside the timed region
     from traceweaver_amd import synth
 
-    host_acc = [synth.accuracy(r["parent"], tp) for r, tp in zip(host, truth)]
-    assert all(abs(a - r["accuracy"]) < 1e-12 for a, r in zip(host_acc, res)), "device accuracy reduction differs from the host's"
+    if not full:   # (a scaled table is re-sorted on the device together with its ground truth: the host's copy is in upload order)
+        host_acc = [synth.accuracy(r["parent"], tp) for r, tp in zip(host, truth)]
+        assert all(abs(a - r["accuracy"]) < 1e-12 for a, r in zip(host_acc, res)), "device accuracy reduction differs from the host's"
     verified = None
     if strong and gathered is not None:
         for k, p in zip(mine, host):
@@ -536,6 +577,13 @@ def main():
         if args.verify and rank == 0 and (world > 1 or split):
             eng.load(whole_units)
             eng.set_truth(whole_truth)
+            for li, f in enumerate(levels[:-1]):   # (the last level's result is compared below)
+                eng.scale_load(level_factors[f])
+                one_step(eng, args.fit)
+                assert all(np.array_equal(g, a["parent"]) for g, a in zip(per_level[li][3], eng.results(2, fields=("parent",)))), \
+                    "sharded result differs from the single-GPU result at load level %g" % f
+            if full:
+                eng.scale_load(level_factors[levels[-1]])
             one_step(eng, args.fit)
             alone = eng.results(2, fields=("parent",))
             if split:   # stitch the parts of every service
@@ -567,6 +615,7 @@ def main():
                        "spans_per_gpu": per_rank_spans[0] if len(set(per_rank_spans)) == 1 else per_rank_spans, "spans_total": int(spans_total),
                        "parallelism": "units sharded, %d rank(s), backend %s" % (world, args.backend if world > 1 else "none")},
             "accuracy": acc,
+            **({"accuracy_by_level": dict(zip(args.levels.split(","), acc_levels))} if full else {}),
             "budget_windows": int(counters[0]), "repaired_windows": int(counters[1]), "windows": int(counters[2]), "unassigned": int(counters[3]),
             "repair_rounds_per_pass": float(np.mean(rounds)),
             "gpu_pass_ms": {"pass1": float(np.mean(pass_ms[0::2])), "pass2": float(np.mean(pass_ms[1::2]))},

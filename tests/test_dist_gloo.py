@@ -260,6 +260,34 @@ def test_one_service_split_over_two_ranks_equals_the_unsplit_run(emu_lib):
                 assert np.array_equal(stitched, want[s])
 
 
+def test_bench_alibaba_full_matrix_over_two_ranks_equals_one(emu_lib):
+    """BASELINE.json config 5 in small: the 15 call graphs at several of exp5's load levels -- services sharded over two ranks,
+    uploaded once, scaled on the resident table per level (tw_scale_load with the per-service factor of the replica table),
+    parents gathered per level; rank 0 re-solves every level alone and the results must be identical."""
+    r = _run_bench(emu_lib, "--gpus", "2", "--backend", "gloo", "--workload", "alibaba-full", "--total-spans", "24000",
+                   "--levels", "1,4000,15000", "--verify", "1")
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["sharded_equals_single_gpu"] is True
+    assert r["config"]["spans_total"] == 3 * sum(r["config"]["spans_per_gpu"])
+    assert list(r["accuracy_by_level"]) == ["1", "4000", "15000"] and all(0.8 < a <= 1.0 for a in r["accuracy_by_level"].values())
+    assert r["budget_windows"] == 0
+
+
+def test_generated_corpus_comes_with_its_replica_table(tmp_path):
+    """synth.write_alibaba_corpus(project_root=...) writes data/misc/service_to_replica_new.pickle ({service: [replica ids]},
+    executor.py:912) for the services of the corpus: exp5's six compress factors then scale a service by 1 ... 6."""
+    import pickle
+
+    from traceweaver_amd import synth, transforms
+
+    d = tmp_path / "data" / "alibaba_microservices" / "call_graph_data" / "call_graph_0"
+    synth.write_alibaba_corpus(str(d), 5, 20, project_root=str(tmp_path))
+    table = pickle.load(open(tmp_path / "data" / "misc" / "service_to_replica_new.pickle", "rb"))
+    assert set(table) == {"gw", "auth", "cart", "catalog", "stock", "db"}
+    for f in synth.EXP5_COMPRESS_FACTORS:
+        assert all(1 <= transforms.load_factor(f, len(v)) <= 6 for v in table.values())
+    assert all(transforms.load_factor(1, len(v)) == 1 for v in table.values())
+
+
 def test_bench_media_split_over_two_ranks_equals_one(emu_lib):
     """bench.py --workload media-split: six services, each cut in two at an idle moment, gap rows all-gathered between the
     passes, parents gathered at the end; rank 0 re-solves the unsplit services and the stitched result must be identical."""

@@ -242,7 +242,10 @@ ALIBABA_APP = {"root": "gw", "calls": {"gw": [("auth",), ("cart", "catalog")], "
 
 
 def write_alibaba_corpus(directory, seed, n_traces, app=ALIBABA_APP, concurrency=1.5, mean_service_ms=6.0, sigma=0.5,
-                         violations=0.0, t0_ms=1_655_760_000_000):
+                         violations=0.0, t0_ms=1_655_760_000_000, project_root=None):
+    """One trace per JSON file in the output format of the reference's alibaba-analysis parser.  With `project_root` the
+    replica table the executor reads for --compress_factor > 1 (data/misc/service_to_replica_new.pickle, executor.py:912) is
+    written too, one entry per service of the app (alibaba_replicas)."""
     import json
     import os
 
@@ -291,6 +294,9 @@ def write_alibaba_corpus(directory, seed, n_traces, app=ALIBABA_APP, concurrency
         with open(path, "w") as f:
             json.dump({"data": [{"traceID": tid, "spans": records}]}, f)
         paths.append(path)
+    if project_root is not None:
+        names = sorted({app["root"]} | {c for stages in app["calls"].values() for st in stages for c in st})
+        write_replica_table(project_root, dict(zip(names, alibaba_replicas(seed, len(names)))))
     return paths
 
 
@@ -308,6 +314,30 @@ ALIBABA_GRAPHS = [
     ["mix8", "par2"], ["chain2", "chain2", "single"], ["par2", "par2", "single"], ["diamond", "chain3"],
     ["fan6", "par4"], ["chain3", "par2", "single"], ["single", "single", "par4", "chain2"],
 ]
+
+
+# exps/exp5/run_experiment.sh:60-156: every call graph is run at six --compress_factor values; the load factor of a service is
+# max(1, ceil(compress_factor / #replicas)) (executor.py:1089-1097, data/misc/service_to_replica_new.pickle)
+EXP5_COMPRESS_FACTORS = (1, 200, 1000, 4000, 10000, 15000)
+
+
+def alibaba_replicas(seed, n_services, max_factor=6):
+    """Replica counts for the services of a generated Alibaba-shape corpus (the table of the real corpus is not shipped):
+    between 15000 / max_factor and 15000, so that exp5's six compress factors scale a service's load by 1 ... max_factor."""
+    rng = np.random.default_rng(seed)
+    return [int(x) for x in rng.integers(int(np.ceil(15000 / max_factor)), 15001, size=n_services)]
+
+
+def write_replica_table(project_root, replicas):
+    """data/misc/service_to_replica_new.pickle = {service: [replica ids]} (executor.py:912) under `project_root`."""
+    import os
+    import pickle
+
+    path = os.path.join(project_root, "data", "misc", "service_to_replica_new.pickle")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "wb") as f:
+        pickle.dump({name: list(range(int(n))) for name, n in replicas.items()}, f)
+    return path
 
 
 def make_nodejs_workload(seed, n_in_per_unit, concurrency=4.0, replicas=1):
