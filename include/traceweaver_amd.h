@@ -268,6 +268,25 @@ int tw_set_truth(tw_engine *e, const int32_t *true_child, const int32_t *in_trac
 int tw_scale_load(tw_engine *e, const int32_t *unit_factor, const int32_t *trace_rank, int32_t *in_perm, int32_t *out_perm,
                   double *unit_time_scale);
 
+/* The reference's baseline predictors on the resident table (executor.py:888-900 indices 3, 4, 7 -- what
+ * exps/exp1 and exps/exp5 run next to predictor 10), see traceweaver_amd/csrc/tw_baselines.h.  parent_out in the layout of
+ * tw_results.parent.  No-skip batches only (the lists of a skip-mode batch are not sorted: TW_ERR_UNSUPPORTED).
+ *   tw_run_baseline(TW_BASELINE_FCFS)   algorithms/fcfs.py:10-26: request i takes the i-th call of every endpoint.
+ *   tw_run_baseline(TW_BASELINE_VPATH)  algorithms/vpath.py:48-89; needs tw_set_truth (a returning call is followed to the request
+ *                                        it truly belongs to, as the reference does through the trace id).
+ *   WAP5 (algorithms/wap5.py:257-351) in two steps, because its delay samples accumulate per callee *name* over the services of
+ *   a run (the class keeps them; the names live on the host): tw_wap5_delays returns per (unit, endpoint) -- [n_units][TW_MAX_EP] --
+ *   the sum (in the unit's timestamp units) and the number of the delay samples of BuildDistributions (:257-275) and the longest
+ *   request per unit; the caller adds them up per name in service order, takes the means (statistics.mean: exact) and hands them,
+ *   in microseconds, to tw_wap5_parents, which runs ScoreParents (:282-316).  -2 = several calls were given to the request:
+ *   the reference's accuracy counts that as wrong (helpers/utils.py:68-73).  call_request (may be NULL; layout of out_start):
+ *   the request every call was given to, -1 = none -- the reference's list-valued assignment is its inverse. */
+#define TW_BASELINE_FCFS 4
+#define TW_BASELINE_VPATH 7
+int tw_run_baseline(tw_engine *e, int kind, int32_t *parent_out);
+int tw_wap5_delays(tw_engine *e, int64_t *delay_sum, int32_t *delay_cnt, int64_t *unit_maxdur);
+int tw_wap5_parents(tw_engine *e, const double *mean, int32_t *parent_out, int32_t *call_request);
+
 /* Replaces: AccuracyForService / TopKAccuracyForService (helpers/utils.py:62-97) and AccuracyEndToEnd /
  * TopKAccuracyEndToEnd (helpers/utils.py:99-145) as reductions over the resident results of the last pass run.
  * per_unit[n_units][4] = requests, requests with every endpoint right, requests whose top-5 list holds the true

@@ -66,7 +66,7 @@ class Results(ctypes.Structure):
 
 EXPORTS = ["tw_create", "tw_destroy", "tw_last_error", "tw_load_batch", "tw_run_pass1", "tw_get_gaps", "tw_set_gaps",
            "tw_device_buffers", "tw_set_gaps_device", "tw_set_mixtures", "tw_fit_mixtures", "tw_fit_mixtures_seeded", "tw_set_fit_seed", "tw_fit_rows", "tw_fit_mixtures_tape", "tw_get_mixtures", "tw_run_pass2", "tw_get_results", "tw_get_gauss_params", "tw_get_timing",
-           "tw_assign_service", "tw_find_order", "tw_set_truth", "tw_evaluate", "tw_measure_hbm_copy", "tw_host_alloc", "tw_host_free", "tw_build_distributions", "tw_scale_load",
+           "tw_assign_service", "tw_find_order", "tw_set_truth", "tw_evaluate", "tw_measure_hbm_copy", "tw_host_alloc", "tw_host_free", "tw_build_distributions", "tw_scale_load", "tw_run_baseline", "tw_wap5_delays", "tw_wap5_parents",
            "tw_corpus_create", "tw_corpus_destroy", "tw_corpus_last_error", "tw_corpus_add_files", "tw_corpus_set_callers", "tw_corpus_counts",
            "tw_corpus_string", "tw_corpus_loop_origin", "tw_corpus_trace_names", "tw_corpus_span_table", "tw_corpus_build_units"]
 
@@ -88,6 +88,9 @@ def load(path=None):
     lib.tw_run_pass1.argtypes = [vp]
     lib.tw_get_gaps.argtypes = [vp, vp]
     lib.tw_set_gaps.argtypes = [vp, vp]
+    lib.tw_run_baseline.argtypes = [vp, ctypes.c_int, vp]
+    lib.tw_wap5_delays.argtypes = [vp, vp, vp, vp]
+    lib.tw_wap5_parents.argtypes = [vp, vp, vp, vp]
     lib.tw_device_buffers.argtypes = [vp, ctypes.POINTER(DeviceView)]
     lib.tw_set_gaps_device.argtypes = [vp, vp]
     lib.tw_scale_load.argtypes = [vp, vp, vp, vp, vp, vp]

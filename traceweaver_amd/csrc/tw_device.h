@@ -40,6 +40,7 @@ struct UnitDev {
     uint8_t npred[kMaxEp];
     uint8_t pred_list[kMaxEp][kMaxEp];    // predecessors in networkx in_edges() order
     uint8_t pred_prim[kMaxEp][kMaxEp];    // 1 <=> that in-edge is primary (scored)
+    uint8_t key_rank[kMaxEp];             // rank of the endpoint in the partition-key order (tw_batch.key_rank)
     double tscale;             // microseconds per timestamp unit (tw_batch.unit_time_scale; 1.0 for integer microseconds)
     int32_t float_time;        // timestamps are images of binary64 values: sums of timestamps accumulate in binary64
     int32_t part;              // tw_batch.unit_part: bit 0 the first request follows a cut, bit 1 a cut follows the last request

@@ -20,6 +20,7 @@
 #include "tw_eval.h"
 #include "tw_skip.h"
 #include "tw_load.h"
+#include "tw_baselines.h"
 
 using namespace tw;
 
@@ -736,6 +737,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
                 if (dag[q * E + p]) sm |= (uint8_t)(1u << p);
             }
             U.pred_mask[q] = pm;
+            U.key_rank[q] = (uint8_t)b->key_rank[epi + q];
             U.succ_mask[q] = sm;
             U.npred[q] = (uint8_t)np;
             // networkx in_edges(): predecessors in partition-key (insertion) order, executor.py:223-236
@@ -1461,6 +1463,117 @@ void tw_host_free(void* p) {
 /* Debug aid, not part of the public header: sizes of the work lists of the last pass --
  * out[0] = windows listed for k_select_heavy, out[1 + E] = spans listed for k_enumerate_heavy<E> (E <= kMaxEp),
  * out[2 + kMaxEp] = spans enumerated in parts, out[3 + kMaxEp] = of those, enumerated once more as a whole (out: 4 + kMaxEp ints). */
+namespace {
+
+struct BaseScratch {   // device scratch of one baseline call
+    std::vector<void*> ptrs;
+    ~BaseScratch() { for (void* p : ptrs) (void)hipFree(p); }
+    void* raw(int64_t count, size_t elem, int fill) {
+        void* p = nullptr;
+        const size_t bytes = elem * (size_t)std::max<int64_t>(count, 1);
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        (void)hipMemset(p, fill, bytes);
+        return p;
+    }
+};
+
+int base_check(tw_engine* e, const char* who) {
+    if (e->state < ST_LOADED) return fail(e, TW_ERR_STATE, std::string(who) + " before tw_load_batch");
+    if (e->skip_mode) return fail(e, TW_ERR_UNSUPPORTED, std::string(who) + ": the lists of a skip-mode batch are not sorted; the host baselines serve it (traceweaver_amd/baselines.py)");
+    return TW_OK;
+}
+
+}  // namespace
+
+int tw_run_baseline(tw_engine* e, int kind, int32_t* parent_out) {
+    if (e == nullptr || parent_out == nullptr) return TW_ERR_ARG;
+    if (kind != TW_BASELINE_FCFS && kind != TW_BASELINE_VPATH) return fail(e, TW_ERR_ARG, "tw_run_baseline: kind is TW_BASELINE_FCFS or TW_BASELINE_VPATH (WAP5: tw_wap5_delays / tw_wap5_parents)");
+    int rc = base_check(e, "tw_run_baseline");
+    if (rc != TW_OK) return rc;
+    if (kind == TW_BASELINE_VPATH && e->truth == nullptr) return fail(e, TW_ERR_STATE, "vPath follows a returning call to its request (vpath.py:42-46,81-84): tw_set_truth first");
+    HIPCHK(hipSetDevice(e->device));
+    const Dev& P = e->P;
+    const dim3 tiles(P.n_tiles), tb(e->tile);
+    BaseScratch S;
+    BaseDev B{};
+    B.truth = e->truth;
+    B.parent = (int32_t*)S.raw(e->n_ie, sizeof(int32_t), 0);
+    if (B.parent == nullptr) return fail(e, TW_ERR_DEVICE, "tw_run_baseline: out of device memory");
+    if (kind == TW_BASELINE_FCFS) {
+        hipLaunchKernelGGL(k_base_fcfs, tiles, tb, 0, e->stream, P, B);
+    } else {
+        B.count = (int32_t*)S.raw(e->n_ie, sizeof(int32_t), 0);
+        B.unit_maxdur = (int64_t*)S.raw(P.n_units, sizeof(int64_t), 0);
+        B.owner = (int32_t*)S.raw(P.n_out_total, sizeof(int32_t), 0x7f);
+        int32_t *d_in = (int32_t*)S.raw(P.n_in_total, sizeof(int32_t), 0), *d_out = (int32_t*)S.raw(P.n_out_total, sizeof(int32_t), 0);
+        int32_t *inv_in = (int32_t*)S.raw(P.n_in_total, sizeof(int32_t), 0), *inv_out = (int32_t*)S.raw(P.n_out_total, sizeof(int32_t), 0);
+        if (B.count == nullptr || B.unit_maxdur == nullptr || B.owner == nullptr || d_in == nullptr || d_out == nullptr || inv_in == nullptr || inv_out == nullptr)
+            return fail(e, TW_ERR_DEVICE, "tw_run_baseline: out of device memory");
+        B.in_rank_inv = inv_in; B.out_rank_inv = inv_out;
+        HIPCHK(hipDeviceSynchronize());   // (the fills above ran on the null stream)
+        hipLaunchKernelGGL(k_rank_ends, tiles, tb, 0, e->stream, P, d_in, d_out);
+        hipLaunchKernelGGL(k_place_ends, tiles, tb, 0, e->stream, P, (const int32_t*)d_in, (const int32_t*)d_out);
+        hipLaunchKernelGGL(k_base_rank_inverse, tiles, tb, 0, e->stream, P, (const int32_t*)d_in, (const int32_t*)d_out, inv_in, inv_out);
+        hipLaunchKernelGGL(k_base_prepare, tiles, tb, 0, e->stream, P, B);
+        hipLaunchKernelGGL(k_base_vpath, tiles, tb, 0, e->stream, P, B);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(parent_out, B.parent, sizeof(int32_t) * e->n_ie, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TW_OK;
+}
+
+int tw_wap5_delays(tw_engine* e, int64_t* delay_sum, int32_t* delay_cnt, int64_t* unit_maxdur) {
+    if (e == nullptr || delay_sum == nullptr || delay_cnt == nullptr) return TW_ERR_ARG;
+    int rc = base_check(e, "tw_wap5_delays");
+    if (rc != TW_OK) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    const Dev& P = e->P;
+    const dim3 tiles(P.n_tiles), tb(e->tile);
+    BaseScratch S;
+    BaseDev B{};
+    B.parent = (int32_t*)S.raw(e->n_ie, sizeof(int32_t), 0); B.count = (int32_t*)S.raw(e->n_ie, sizeof(int32_t), 0);
+    B.unit_maxdur = (int64_t*)S.raw(P.n_units, sizeof(int64_t), 0);
+    B.delay_sum = (long long*)S.raw((int64_t)P.n_units * kMaxEp, sizeof(long long), 0); B.delay_cnt = (int32_t*)S.raw((int64_t)P.n_units * kMaxEp, sizeof(int32_t), 0);
+    if (B.parent == nullptr || B.count == nullptr || B.unit_maxdur == nullptr || B.delay_sum == nullptr || B.delay_cnt == nullptr)
+        return fail(e, TW_ERR_DEVICE, "tw_wap5_delays: out of device memory");
+    HIPCHK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(k_base_prepare, tiles, tb, 0, e->stream, P, B);
+    hipLaunchKernelGGL(k_wap5_delays, tiles, tb, 0, e->stream, P, B);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(delay_sum, B.delay_sum, sizeof(int64_t) * P.n_units * kMaxEp, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(delay_cnt, B.delay_cnt, sizeof(int32_t) * P.n_units * kMaxEp, hipMemcpyDeviceToHost, e->stream));
+    if (unit_maxdur != nullptr) HIPCHK(hipMemcpyAsync(unit_maxdur, B.unit_maxdur, sizeof(int64_t) * P.n_units, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TW_OK;
+}
+
+int tw_wap5_parents(tw_engine* e, const double* mean, int32_t* parent_out, int32_t* call_request) {
+    if (e == nullptr || mean == nullptr || parent_out == nullptr) return TW_ERR_ARG;
+    int rc = base_check(e, "tw_wap5_parents");
+    if (rc != TW_OK) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    const Dev& P = e->P;
+    const dim3 tiles(P.n_tiles), tb(e->tile);
+    BaseScratch S;
+    BaseDev B{};
+    B.parent = (int32_t*)S.raw(e->n_ie, sizeof(int32_t), 0xff); B.count = (int32_t*)S.raw(e->n_ie, sizeof(int32_t), 0);
+    double* mean_d = (double*)S.raw((int64_t)P.n_units * kMaxEp, sizeof(double), 0);
+    B.call_request = (int32_t*)S.raw(P.n_out_total, sizeof(int32_t), 0xff);
+    if (B.parent == nullptr || B.count == nullptr || mean_d == nullptr || B.call_request == nullptr) return fail(e, TW_ERR_DEVICE, "tw_wap5_parents: out of device memory");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyAsync(mean_d, mean, sizeof(double) * P.n_units * kMaxEp, hipMemcpyHostToDevice, e->stream));
+    B.mean = mean_d;
+    hipLaunchKernelGGL(k_wap5_parents, tiles, tb, 0, e->stream, P, B);
+    hipLaunchKernelGGL(k_wap5_finish, tiles, tb, 0, e->stream, P, B);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(parent_out, B.parent, sizeof(int32_t) * e->n_ie, hipMemcpyDeviceToHost, e->stream));
+    if (call_request != nullptr) HIPCHK(hipMemcpyAsync(call_request, B.call_request, sizeof(int32_t) * (size_t)P.n_out_total, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TW_OK;
+}
+
 /* Debug aid, not part of the public header: the model-selection fits of the last refit, [n_slots][5][16] = BIC (inf = raised),
  * weights[5], means[5], precision_cholesky[5]. */
 extern "C" int tw_debug_fit_models(tw_engine* e, double* out) {

@@ -365,6 +365,55 @@ class Engine(object):
             return out
         return (out, (int(e2e[0]), int(e2e[1])), flags) if trace_flags else (out, (int(e2e[0]), int(e2e[1])))
 
+    # ------------------------------------------------------------------------------------------
+    def baseline(self, kind):
+        """The reference's FCFS ("FCFS", algorithms/fcfs.py) or vPath ("vPath", algorithms/vpath.py; needs set_truth) on the
+        resident table (tw_run_baseline).  Per unit parent [E, n_in] int32, -1 = ("NA", "NA")."""
+        code = {"FCFS": 4, "vPath": 7}[kind]
+        par = np.empty(int(self._ie_off[-1]), dtype=np.int32)
+        self._check(self._lib.tw_run_baseline(self._h, code, _vp(par)))
+        return [par[int(self._ie_off[k]):int(self._ie_off[k + 1])].reshape(u.E, u.n_in) for k, u in enumerate(self.units)]
+
+    def wap5(self, ep_names, state=None):
+        """The reference's WAP5 (algorithms/wap5.py:257-351) on the resident table: tw_wap5_delays -> the delay samples
+        added up per callee name in service order (the reference keeps one predictor object for a run; `state` = the dict
+        {name: [sum in microseconds, count]} carried from batch to batch) -> tw_wap5_parents.  ep_names: per unit the
+        endpoint names in the unit's endpoint order.  Returns (per unit parent [E, n_in]: -1 none, -2 several calls for one
+        request -- counted as wrong like the reference does --, state, per unit options[e][i] = the calls given to request i,
+        the reference's list-valued assignment)."""
+        from fractions import Fraction
+
+        state = {} if state is None else state
+        nu = len(self.units)
+        sums = np.zeros((nu, _ffi.TW_MAX_EP), dtype=np.int64)
+        cnts = np.zeros((nu, _ffi.TW_MAX_EP), dtype=np.int32)
+        self._check(self._lib.tw_wap5_delays(self._h, _vp(sums), _vp(cnts), None))
+        mean = np.zeros((nu, _ffi.TW_MAX_EP), dtype=np.float64)
+        for k, u in enumerate(self.units):
+            scale = Fraction(1) if u.time_scale is None else Fraction(u.time_scale)
+            for e in np.argsort(u.key_rank, kind="stable"):   # for out_ep in out_span_partitions.keys()
+                st = state.setdefault(ep_names[k][int(e)], [Fraction(0), 0])
+                st[0] += int(sums[k, e]) * scale
+                st[1] += int(cnts[k, e])
+                if st[1] == 0:
+                    raise ValueError("WAP5: no delay sample for endpoint %r (statistics.mean of an empty list raises in the reference)" % ep_names[k][int(e)])
+                mean[k, e] = float(st[0] / st[1])               # statistics.mean: exact, rounded once
+        par = np.empty(int(self._ie_off[-1]), dtype=np.int32)
+        req = np.empty(int(sum(int(u.out_off[-1]) for u in self.units)), dtype=np.int32)
+        self._check(self._lib.tw_wap5_parents(self._h, _vp(mean), _vp(par), _vp(req)))
+        options, o = [], 0
+        for u in self.units:
+            per = []
+            for e in range(u.E):
+                m = int(u.out_off[e + 1] - u.out_off[e])
+                lists = [[] for _ in range(u.n_in)]
+                for x in np.flatnonzero(req[o:o + m] >= 0):
+                    lists[int(req[o + x])].append(int(x))
+                per.append(lists)
+                o += m
+            options.append(per)
+        return [par[int(self._ie_off[k]):int(self._ie_off[k + 1])].reshape(u.E, u.n_in) for k, u in enumerate(self.units)], state, options
+
     def find_order(self, units, true_parent):
         """executor.py:214-285 (FindOrder) on the device for units that need not be loaded (endpoints in any
         order): per unit the uint8 [E, E] call-order relation implied by the true assignments."""

@@ -13,8 +13,9 @@ reference pickles its own Span objects there).  Everything between reading the d
 in libtwgpu.so: native ingest (tw_corpus_*), both passes of every service in one batch, device refit, device
 accuracy reductions.
 
-Indices 3 (WAP5), 4 (FCFS), 5 (ArrivalOrder) and 7 (vPath) run as host baselines (traceweaver_amd/baselines.py,
-identical to the reference's classes, also on load-scaled units) and add their columns to the same files --
+Indices 3 (WAP5), 4 (FCFS) and 7 (vPath) run on the resident table as well (csrc/tw_baselines.h; identical to the
+reference's classes, also on load-scaled units; skip-mode services and index 5, ArrivalOrder, as host code:
+traceweaver_amd/baselines.py) and add their columns to the same files --
 `exps/exp1`'s and `exps/exp5`'s "3,4,7,10" run as they are.
 `--compress_factor N` (N > 1) applies the reference's load scaling (helpers/transforms.py:10-40, executor.py:1086-1097,
 1146-1148) to every service before it is solved: per-service load factor max(1, ceil(N / #replicas)) with the replica
@@ -307,21 +308,32 @@ def run(args):
             record(METHOD, [r["parent"] for r in res], {METHOD: flags[0], METHOD + "TopK": flags[1]})
         else:
             method = BASELINES[index]
-            wap5, all_options = baselines.WAP5(), []               # one instance for the run: its state leaks across services
-            fn = {"FCFS": lambda u: baselines.fcfs(u.arrays), "ArrivalOrder": lambda u: baselines.arrival_order(u.arrays),
-                  "vPath": lambda u: baselines.vpath(u.arrays, u.true_parent), "WAP5": None}[method]
-            parents, bad = [], np.zeros(n_traces, dtype=np.uint8)
-            for u in units:
-                if method == "WAP5":
-                    all_options.append(wap5.assign(u.arrays, u.out_eps))
-                    par = baselines.WAP5.parent(u.arrays, all_options[-1])
+            parents, bad, all_options = [], np.zeros(n_traces, dtype=np.uint8), []
+            on_device = method in ("FCFS", "vPath", "WAP5") and not skip_units
+            if on_device:   # on the resident table (csrc/tw_baselines.h); skip-mode services (unsorted lists) and ArrivalOrder: host
+                eng_b = Engine(args.device, lib_path=args.engine_library)
+                eng_b.load([u.arrays for u in units])
+                eng_b.set_truth([u.true_parent for u in units])
+                if method == "WAP5":   # one predictor object for the run: delay samples accumulate per callee name over the services
+                    parents, _, all_options = eng_b.wap5([u.out_eps for u in units])
                 else:
-                    par = fn(u)
+                    parents = eng_b.baseline(method)
+                eng_b.close()
+            else:
+                wap5 = baselines.WAP5()                                # one instance for the run: its state leaks across services
+                fn = {"FCFS": lambda u: baselines.fcfs(u.arrays), "ArrivalOrder": lambda u: baselines.arrival_order(u.arrays),
+                      "vPath": lambda u: baselines.vpath(u.arrays, u.true_parent), "WAP5": None}[method]
+                for u in units:
+                    if method == "WAP5":
+                        all_options.append(wap5.assign(u.arrays, u.out_eps))
+                        parents.append(baselines.WAP5.parent(u.arrays, all_options[-1]))
+                    else:
+                        parents.append(fn(u))
+            for u, par in zip(units, parents):
                 ok = np.all(par == u.true_parent, axis=0)
                 print("Accuracy for service %s: %.3f%%\n" % (u.service, ok.mean() * 100))
                 accuracy_per_process[(method, u.process_id)] = float(ok.mean())
                 bad[u.in_trace[~ok]] = 1
-                parents.append(par)
             record(method, parents, {method: bad}, options=all_options if method == "WAP5" else None)
     for k, v in accuracy_overall.items():
         print("End-to-end accuracy for method %s: %.3f%%" % (k, v))
