@@ -124,7 +124,8 @@ typedef struct tw_skip_unit {
 
 /* Copies the batch into HBM (span arrays: 16 B per span).  If `spans_on_device` is non-zero the
  * four span arrays are *device* pointers (already resident, e.g. produced by a device-side loader)
- * and are copied device-to-device; the small descriptor arrays are always host pointers. */
+ * and are copied device-to-device; the small descriptor arrays are always host pointers.  A skip-mode batch
+ * (tw_batch.skip) takes host span arrays only: TW_ERR_UNSUPPORTED otherwise. */
 int tw_load_batch(tw_engine *e, const tw_batch *b, int spans_on_device);
 
 /* Pass 1 (traceweaver_v3.py:1159-1219, iteration 0): windows (CreateWindows2, :1020-1078),

@@ -672,6 +672,8 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipSetDevice(e->device));
     if (b->n_units <= 0) return fail(e, TW_ERR_ARG, "n_units must be positive");
     if (b->topk != TW_TOPK) return fail(e, TW_ERR_UNSUPPORTED, "topk must be 5 (traceweaver_v3.py:1109)");
+    if (b->skip != nullptr && spans_on_device)   // the start-ordered views and the pool checks of a skip-mode batch are built on the host
+        return fail(e, TW_ERR_UNSUPPORTED, "a skip-mode batch takes its span arrays from host memory (spans_on_device = 0)");
     if (b->batch_size <= 0 || b->batch_size_mis <= 0) return fail(e, TW_ERR_ARG, "batch sizes must be positive");
     free_all(e);
     e->fit_rng = Mt19937(e->fit_seed);   // a batch's refit does not depend on what the engine solved before

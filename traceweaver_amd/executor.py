@@ -183,7 +183,7 @@ def run(args):
             if u.arrays.time_scale is not None:
                 raise SystemExit("--cache_rate with --compress_factor > 1 is not supported (skip mode takes integer microseconds)")
             print("cache %: ", float(args.cache_rate) * 100)
-            arr, truth, kept = skipmode.cache_hits(u.arrays, u.true_parent, args.cache_rate)
+            arr, truth, kept = skipmode.cache_hits(u.arrays, u.true_parent, args.cache_rate, in_trace=u.in_trace)
             units[k] = IngestedUnit(arr, truth, u.in_trace, u.service, u.in_ep, u.out_eps, u.in_rows,
                                     [r[kept] if e == 0 else r for e, r in enumerate(u.out_rows)], u.process_id)
             skip_units.add(k)
@@ -283,9 +283,12 @@ def run(args):
 
                 sk = sorted(skip_units)
                 plans, windows = [], []
-                for k in sk:   # one predictor object solves the services in turn and never clears its time windows (hazard H8)
-                    plans.append(skipmode.plan(eng, units[k].arrays, prior_windows=windows))
-                    windows = list(plans[-1].windows)
+                for k, u in enumerate(units):   # one predictor object solves the services in turn and never clears its time windows:
+                    if k in skip_units:         # those of every earlier service, skip budget or not, are still in it (hazard H8)
+                        plans.append(skipmode.plan(eng, u.arrays, prior_windows=windows))
+                        windows = list(plans[-1].windows)
+                    elif u.arrays.time_scale is None:
+                        windows = windows + skipmode.time_windows(u.arrays)
                 eng.load([units[k].arrays for k in sk], skip=plans)
                 eng.set_truth([units[k].true_parent for k in sk], [units[k].in_trace for k in sk], n_traces)
                 eng.run_pass1()

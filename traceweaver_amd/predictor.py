@@ -256,6 +256,10 @@ class TraceWeaverGPU(object):
             true_parent[:, (true_parent < 0).any(axis=0)] = -1
 
         r1, r2 = self.solve_arrays(unit, true_parent, process)
+        if unit.time_scale is None:   # TallySkipSpans runs for every service (traceweaver_v3.py:1141): its windows stay in the predictor (hazard H8)
+            from . import skipmode
+
+            self._time_windows = self._time_windows + skipmode.time_windows(unit)
 
         all_assignments, all_topk_assignments = {}, {}
         for k, ep in enumerate(out_eps):

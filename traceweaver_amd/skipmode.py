@@ -39,7 +39,7 @@ def cache_hit_draws(n, cache_rate, seed=10):
     return np.random.choice(np.arange(n), size=size, replace=False, p=p)
 
 
-def cache_hits(unit, true_parent, cache_rate, seed=10):
+def cache_hits(unit, true_parent, cache_rate, seed=10, in_trace=None):
     """create_cache_hits (helpers/transforms.py:153-238): a fraction `cache_rate` of the requests, drawn without
     replacement with weights exp(-0.001 * index) from numpy's global RNG seeded with 10, lose their call to the FIRST
     endpoint (topological order): that span is deleted, the request is shortened by its duration and the request's
@@ -47,6 +47,14 @@ def cache_hits(unit, true_parent, cache_rate, seed=10):
     longer sorted.  Returns (unit as the predictor receives it, true_parent with -2 = ('Skip','Skip'), which spans of
     the first endpoint are kept)."""
     n, E = unit.n_in, unit.E
+    tp0 = np.asarray(true_parent)
+    # adjust_spans (transforms.py:170-180) moves every span that shares the request's trace id; on index arrays that is the
+    # request's own call per endpoint -- which needs every request to have exactly one (a corpus with repeated calls per
+    # trace, or a request that already lacks a call, is not what this restatement covers: say so instead of moving the wrong span)
+    if in_trace is not None and len(np.unique(in_trace)) != len(in_trace):
+        raise ValueError("cache_hits: several requests of one trace at this service (create_cache_hits shifts by trace id)")
+    if (tp0 < 0).any():
+        raise ValueError("cache_hits: a request without a call to some endpoint (create_cache_hits assumes one call per request and endpoint)")
     hit = cache_hit_draws(n, cache_rate, seed)
     hit_mask = np.zeros(n, dtype=bool)
     hit_mask[hit] = True
@@ -74,14 +82,20 @@ def cache_hits(unit, true_parent, cache_rate, seed=10):
     return out, tp, keep0
 
 
+def time_windows(unit):
+    """The 30-request time windows TallySkipSpans appends to the predictor's list for *every* service it solves, skip budget
+    or not (traceweaver_v3.py:1141, :976-987): [(start, end, 30)]."""
+    n = unit.n_in
+    cut = np.arange(BATCH_MIS, n - 1, BATCH_MIS)                          # i % 30 == 0, i != 0, i != n - 1
+    edges = np.concatenate([[unit.in_start[0]], unit.in_end[cut], [np.max(unit.in_end)]]).astype(np.int64)
+    return [(int(a), int(b), BATCH_MIS) for a, b in zip(edges[:-1], edges[1:])]
+
+
 def tally_skip_spans(unit, prior_windows=()):
     """TallySkipSpans (traceweaver_v3.py:853-989).  prior_windows: the windows of services the same predictor object
     solved before (the reference never clears self.time_windows, SURVEY.md hazard H8)."""
     n, E = unit.n_in, unit.E
-    tw = list(prior_windows)
-    cut = np.arange(BATCH_MIS, n - 1, BATCH_MIS)                          # i % 30 == 0, i != 0, i != n - 1
-    edges = np.concatenate([[unit.in_start[0]], unit.in_end[cut], [np.max(unit.in_end)]]).astype(np.int64)
-    tw += [(int(a), int(b), BATCH_MIS) for a, b in zip(edges[:-1], edges[1:])]
+    tw = list(prior_windows) + time_windows(unit)
     keys = sorted(tw, key=lambda w: w[0])
     budget = np.array([n - int(unit.out_off[e + 1] - unit.out_off[e]) for e in range(E)], dtype=np.int64)
     pool = np.zeros((E, len(keys)), dtype=np.int32)
