@@ -24,6 +24,12 @@ CASES = [
     ("single_c10", 43, 330, "single", 10, 1),
     ("chain2_c8_ms", 44, 260, "chain2", 8, 1000),
     ("diamond_c3", 45, 240, "diamond", 3, 1),
+    # 1000-request units at 6-8 requests in flight: size-capped windows with span consumption at the scale of a shipped corpus
+    # (the reference takes 10-40 minutes each)
+    ("chain3_c6_1k", 51, 1000, "chain3", 6, 1),
+    ("par2_c7_1k", 52, 1000, "par2", 7, 1),
+    ("single_c8_1k", 53, 1000, "single", 8, 1),
+    ("chain2_c6_ms_1k", 54, 1000, "chain2", 6, 1000),
 ]
 
 
