@@ -25,11 +25,14 @@ CASES = [
     ("chain2_c8_ms", 44, 260, "chain2", 8, 1000),
     ("diamond_c3", 45, 240, "diamond", 3, 1),
     # 1000-request units at 6-8 requests in flight: size-capped windows with span consumption at the scale of a shipped corpus
-    # (the reference takes 10-40 minutes each)
+    # (the reference takes 10 s to a few minutes each)
     ("chain3_c6_1k", 51, 1000, "chain3", 6, 1),
     ("par2_c7_1k", 52, 1000, "par2", 7, 1),
     ("single_c8_1k", 53, 1000, "single", 8, 1),
     ("chain2_c6_ms_1k", 54, 1000, "chain2", 6, 1000),
+    ("chain3_c9_1k", 55, 1000, "chain3", 9, 1),
+    ("par4_c4_1k", 56, 1000, "par4", 4, 1),
+    ("single_c14_ms_1k", 57, 1000, "single", 14, 1000),
 ]
 
 
