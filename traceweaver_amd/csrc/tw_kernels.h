@@ -1950,6 +1950,11 @@ constexpr int kBruteMax = 4;         // components of up to this many spans are 
 #define TW_MATCH_NODES 32768
 #endif
 constexpr int kMatchNodes1 = TW_MATCH_NODES_1, kMatchNodes = TW_MATCH_NODES;
+#ifndef TW_MEMO_MIN_BELOW
+#define TW_MEMO_MIN_BELOW 3
+#endif
+constexpr int kMemoMinBelow = TW_MEMO_MIN_BELOW;   // the transposition table is consulted / written only at nodes with more spans than this below: a sub-tree of the
+// last levels costs less than a probe and a store (measured, nodejs shape: select 13.1 ms with 0, 10.5 with 3, 58.9 with 6; media shape unchanged)
 constexpr int kMatchMinDepth = 4;    // ... at nodes with at least this many spans below
 constexpr int kMemoSlots = TW_MEMO_SLOTS;      // transposition table entries (LDS); a table of 2^20 entries prunes no better on the test workloads
 
@@ -2161,7 +2166,7 @@ __device__ void select_search(LDS& L, int E) {
                     d--; entered = false; continue;
                 }
                 bool cut = acc + L.ub[d] <= best_w;
-                if (!cut && d >= 1) {   // has the sub-tree below this (depth, blocked set) been searched already?
+                if (!cut && d >= 1 && cm - d > kMemoMinBelow) {   // has the sub-tree below this (depth, blocked set) been searched already?
                     unsigned long long kk[kBlkWords];
                     const unsigned slot = memo_key(d, b0, b1, b2, kk);
                     for (int pr = 0; pr < 4; pr++) {
@@ -2204,7 +2209,7 @@ __device__ void select_search(LDS& L, int E) {
                 continue;
             }
             // every way on from this node has been searched: remember what it can gain at most
-            if (d >= 1) {
+            if (d >= 1 && cm - d > kMemoMinBelow) {
                 unsigned long long kk[kBlkWords];
                 const unsigned slot = memo_key(d, b0, b1, b2, kk);
                 for (int pr = 0; pr < 4; pr++) {
