@@ -1,11 +1,11 @@
 # bench lines of the load regimes (+ rocprofv3 kernel stats where asked): bash profiles/tools/regimes.sh <tag> [stats]
 export TMPDIR=/tmp
 TAG=${1:-r02}
-for W in "base:" "alibaba:--workload alibaba" "c4:--concurrency 4 --n-in 20000 --replicas 4" "nodejs:--workload nodejs --n-in 20000" "c8:--concurrency 8 --n-in 5000 --replicas 4"; do
+for W in "alibaba:--workload alibaba" "c4:--concurrency 4 --n-in 20000 --replicas 4" "nodejs:--workload nodejs --n-in 20000" "c8:--concurrency 8 --n-in 5000 --replicas 4"; do
   tag=${W%%:*}; args=${W#*:}
   if [ "${2:-}" = "stats" ]; then
     mkdir -p gpurun_out/${TAG}_$tag
-    timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_$tag -o p -- python bench.py $args --cpu-sample 0 --steps 2 --warmup 1 > gpurun_out/${TAG}_$tag.log 2>&1
+    timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_$tag -o p -- python bench.py $args --cpu-sample 0 --regimes 0 --sync engine --steps 2 --warmup 1 > gpurun_out/${TAG}_$tag.log 2>&1
     echo $tag rc $?
     rm -f gpurun_out/${TAG}_$tag/p_kernel_trace.csv gpurun_out/${TAG}_$tag/p_agent_info.csv
     head -8 gpurun_out/${TAG}_$tag/p_kernel_stats.csv | cut -c1-150
