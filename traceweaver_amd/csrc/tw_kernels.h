@@ -1956,6 +1956,16 @@ constexpr int kMatchNodes1 = TW_MATCH_NODES_1, kMatchNodes = TW_MATCH_NODES;
 constexpr int kMemoMinBelow = TW_MEMO_MIN_BELOW;   // the transposition table is consulted / written only at nodes with more spans than this below: a sub-tree of the
 // last levels costs less than a probe and a store (measured, nodejs shape: select 13.1 ms with 0, 10.5 with 3, 58.9 with 6; media shape unchanged)
 constexpr int kMatchMinDepth = 4;    // ... at nodes with at least this many spans below
+// The table lives in the LDS layout of the window class, and the layouts of the small classes are mostly table: 64 entries
+// for windows of up to 16 spans let more workgroups share a CU (media shape, x16: select 3.64 -> 3.01 ms; 32 / 128 entries
+// the same within noise), while the 17..32-span layout needs its 256 (128: one nodejs window grows to 190 ms; 512 .. 2048:
+// the per-window sweep of the table costs more than it prunes, media select 3.6 -> 3.9 ms).
+#ifndef TW_MEMO_MID
+#define TW_MEMO_MID 64     // windows of up to 8 spans
+#endif
+#ifndef TW_MEMO_BIG
+#define TW_MEMO_BIG 64     // 9..16 spans
+#endif
 constexpr int kMemoSlots = TW_MEMO_SLOTS;      // transposition table entries (LDS); a table of 2^20 entries prunes no better on the test workloads
 
 // ---- cooperative path: one workgroup per window --------------------------------------------------
@@ -1964,7 +1974,8 @@ constexpr int kMemoSlots = TW_MEMO_SLOTS;      // transposition table entries (L
 template <int MW, bool SEARCH>
 struct SelectLdsT {
     static constexpr bool kSearch = SEARCH;
-    static constexpr int kS = SEARCH ? MW : 1, kSlots = SEARCH ? kMemoSlots : 1;
+    // transposition table entries by layout (TW_MEMO_MID / TW_MEMO_BIG: the windows of 5-7 and 8-15 spans)
+    static constexpr int kS = SEARCH ? MW : 1, kSlots = !SEARCH ? 1 : (MW <= 8 ? TW_MEMO_MID : (MW <= 16 ? TW_MEMO_BIG : kMemoSlots));
     static constexpr int kW = SEARCH ? (MW * kTopK + 63) / 64 : 1;   // words of a mask over all candidates of a component
     int32_t idx[MW][kTopK][kMaxEp];
     sel_w w[MW][kTopK];  // sel_weight(score); <= 0 means not eligible
@@ -2114,7 +2125,7 @@ __device__ void select_search(LDS& L, int E) {
     const int cm = L.cm;
     if (t == 0) {
         L.memo_gen++;   // entries of earlier components become stale without a sweep
-        if ((L.memo_gen & 0x3fffffffu) == 0u) { L.memo_gen = 1u; for (int q = 0; q < kMemoSlots; q++) L.mstate[q] = 0u; }
+        if ((L.memo_gen & 0x3fffffffu) == 0u) { L.memo_gen = 1u; for (int q = 0; q < LDS::kSlots; q++) L.mstate[q] = 0u; }
         const unsigned int tag = (L.memo_gen << 2) | 2u;
         // key of a node: the blocked candidates of the spans d.. (bits below d * kTopK cleared) with the depth in the low bits
         auto memo_key = [&](int d, unsigned long long b0, unsigned long long b1, unsigned long long b2, unsigned long long (&k)[kBlkWords]) -> unsigned {
@@ -2124,7 +2135,7 @@ __device__ void select_search(LDS& L, int E) {
             k[0] |= (unsigned long long)d;   // d >= 1: bits 0..4 belong to the first span and are clear
             unsigned long long h = (k[0] * 0x9E3779B97F4A7C15ull) ^ (k[1] * 0xC2B2AE3D27D4EB4Full) ^ (k[2] * 0x165667B19E3779F9ull);
             h ^= h >> 29;
-            return (unsigned)h & (kMemoSlots - 1);
+            return (unsigned)h & (LDS::kSlots - 1);
         };
         auto key_eq = [&](unsigned sl, const unsigned long long (&k)[kBlkWords]) -> bool {
             bool eq = L.mkey[sl][0] == k[0];
@@ -2170,7 +2181,7 @@ __device__ void select_search(LDS& L, int E) {
                     unsigned long long kk[kBlkWords];
                     const unsigned slot = memo_key(d, b0, b1, b2, kk);
                     for (int pr = 0; pr < 4; pr++) {
-                        const unsigned sl = (slot + pr) & (kMemoSlots - 1);
+                        const unsigned sl = (slot + pr) & (LDS::kSlots - 1);
                         if (L.mstate[sl] != tag) break;   // empty: the chain ends here
                         if (key_eq(sl, kk)) { cut = acc + L.mval[sl] <= best_w; break; }
                     }
@@ -2213,7 +2224,7 @@ __device__ void select_search(LDS& L, int E) {
                 unsigned long long kk[kBlkWords];
                 const unsigned slot = memo_key(d, b0, b1, b2, kk);
                 for (int pr = 0; pr < 4; pr++) {
-                    const unsigned sl = (slot + pr) & (kMemoSlots - 1);
+                    const unsigned sl = (slot + pr) & (LDS::kSlots - 1);
                     if (L.mstate[sl] == tag) {
                         if (key_eq(sl, kk)) { L.mval[sl] = best_w - acc; break; }
                         continue;
@@ -2581,7 +2592,7 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
     sel_segments(P, LIST, G);
     const int count = G.first[kSelSeg];
     if ((int)blockIdx.x >= count) return;   // nothing for this workgroup (the usual case outside heavy load)
-    for (int q = threadIdx.x; q < kMemoSlots; q += blockDim.x) L.mstate[q] = 0u;
+    for (int q = threadIdx.x; q < LDS::kSlots; q += blockDim.x) L.mstate[q] = 0u;
     if (threadIdx.x == 0) L.memo_gen = 0u;
     group_sync();
     int chunk_pos = 0, chunk_end = 0;
