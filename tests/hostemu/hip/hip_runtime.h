@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#define TW_HOST_EMULATION 1   // tw_kernels.h: lane arrays (LaneArr) are plain arrays here
 #define __global__
 #define __device__
 #define __host__

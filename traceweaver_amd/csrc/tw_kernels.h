@@ -1996,9 +1996,6 @@ struct SelectLdsT {
     sel_w mval[kSlots];
     unsigned int mstate[kSlots];   // generation << 2 | (0 empty, 1 being written, 2 valid)
     unsigned int memo_gen;
-    sel_w saccs[kS + 1];                       // search stack: weight above every level,
-    unsigned long long sblk[kS + 1][kW];  // candidates blocked at every level,
-    int8_t scur[kS], sbest[kS];             // choice per level (ncand = "none"), incumbent
     int cm, budget_hit;
     unsigned long long nodes_total;   // search nodes of the window (all lanes), reported in unit_stats[5]
 #ifdef TW_PROFILE_SEL
@@ -2110,10 +2107,53 @@ __device__ bool select_match_prunes(LDS& L, int E, int d, sel_w acc, sel_w best_
     return false;
 }
 
-// Depth-first search of a component of more than kBruteMax spans (see above): lane 0 walks the tree in the canonical
-// order with its stack in LDS (weight above every level, blocked candidates at every level: a return costs nothing),
-// cutting a node when weight + bound <= incumbent, the bound being the grouped bound of the suffix or the entry of the
-// transposition table for (depth, blocked candidates of the remaining spans).  With the table the search is a dynamic
+// ---- a small array held across the lanes of one vector register --------------------------------------------------
+// Element q lives in lane q; a read at a wave-uniform index is one v_readlane per 32 bits with its result in scalar
+// registers, a write a compare and a select.  select_search keeps everything it indexes by depth this way: a walk whose every step
+// waits for a chain of LDS loads in one lane (1.5 us per node, measured) becomes scalar code next to the register file.
+// (The host emulation of the tests has no lanes to spread over: there every emulated lane holds the whole array.)
+#ifdef TW_HOST_EMULATION
+template <class T>
+struct LaneArr {
+    T v[64];
+    template <class F> void load(int n, F f) { for (int q = 0; q < 64; q++) v[q] = q < n ? f(q) : T(0); }
+    void fill(T x) { for (int q = 0; q < 64; q++) v[q] = x; }
+    T get(int i) const { return v[i]; }
+    void set(int i, T x) { v[i] = x; }
+    template <class F> void store(int n, F f) const { if (threadIdx.x == 0) for (int q = 0; q < n; q++) f(q, v[q]); }
+};
+#else
+template <class T>
+struct LaneArr {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "one or two registers per lane");
+    T v;
+    template <class F> __device__ __forceinline__ void load(int n, F f) { v = (int)threadIdx.x < n ? f((int)threadIdx.x) : T(0); }
+    __device__ __forceinline__ void fill(T x) { v = x; }
+    __device__ __forceinline__ T get(int i) const {
+        if constexpr (sizeof(T) == 4) return (T)__builtin_amdgcn_readlane((int)v, i);
+        else {
+            const unsigned long long x = (unsigned long long)v;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, i), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), i);
+            return (T)(((unsigned long long)hi << 32) | lo);
+        }
+    }
+    __device__ __forceinline__ void set(int i, T x) { v = (int)threadIdx.x == i ? x : v; }   // (a compare and a select per register)
+    template <class F> __device__ __forceinline__ void store(int n, F f) const { if ((int)threadIdx.x < n) f((int)threadIdx.x, v); }
+};
+#endif
+// the value of the first active lane, for what the wavefront computed in one lane (or read from LDS at a uniform address)
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ long long uni(long long x) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)x), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)x >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// Depth-first search of a component of more than kBruteMax spans (see above): the wavefront walks the tree in the
+// canonical order as one scalar thread of control -- all lanes take every branch together -- with what it indexes by depth
+// in lane arrays (LaneArr: lane q <-> depth q): the spans' weights, eligibility and conflict masks, the suffix bound, and the
+// stack (weight above every level, blocked candidates at every level: a return costs nothing).  A node is cut when weight +
+// bound <= incumbent, the bound being the grouped bound of the suffix or the entry of the transposition table (LDS, lane 0)
+// for (depth, blocked candidates of the remaining spans).  With the table the search is a dynamic
 // programme over the sets of taken outgoing spans rather than over the assignments that produce them: the largest
 // component of the heavy-load test workloads takes ~2e3 nodes instead of 4e6 (nodejs shape) / 8e8 (tie-saturated set).
 // Needs L.cm, L.mem, L.ncand, L.w, L.ub, L.cmask3; writes L.pick of the members.
@@ -2121,108 +2161,147 @@ template <class LDS>
 __device__ void select_search(LDS& L, int E) {
     constexpr int W = LDS::kW;   // words of the blocked mask: kept in up to three registers, the unused ones are constant zero
     static_assert(W >= 1 && W <= 3 && kBlkWords == 3, "the blocked mask is kept in three registers");
+    static_assert(kMaxWin < 64 && kTopK <= 8, "one lane per depth, one bit per candidate");
+    typedef unsigned long long ull;
     const int t = threadIdx.x;
-    const int cm = L.cm;
+    const int cm = uni(L.cm);
+    // per depth: the member's candidates
+    LaneArr<sel_w> wv[kTopK], ubv;
+    LaneArr<ull> cmk[kTopK][W];
+    LaneArr<int> elig, ncv;
+#pragma unroll
+    for (int k = 0; k < kTopK; k++) {
+        wv[k].load(cm, [&](int q) { const int b = L.mem[q]; return (k < (int)L.ncand[b] && L.w[b][k] > 0) ? L.w[b][k] : (sel_w)0; });
+#pragma unroll
+        for (int w = 0; w < W; w++) cmk[k][w].load(cm, [&](int q) { return L.cmask3[q][k][w]; });
+    }
+    elig.load(cm, [&](int q) { const int b = L.mem[q]; int m = 0; for (int k = 0; k < (int)L.ncand[b]; k++) if (L.w[b][k] > 0) m |= 1 << k; return m; });
+    ncv.load(cm, [&](int q) { return (int)L.ncand[L.mem[q]]; });
+    ubv.load(cm + 1, [&](int q) { return L.ub[q]; });
+    // the stack, the choice per level (ncand = "none") and the incumbent
+    LaneArr<sel_w> sacc;
+    LaneArr<ull> sb[W];
+    LaneArr<int> cur, best;
+    sacc.fill(0); cur.fill(-1); best.fill(-1);
+#pragma unroll
+    for (int w = 0; w < W; w++) sb[w].fill(0ull);
+    int gen = 0;
     if (t == 0) {
         L.memo_gen++;   // entries of earlier components become stale without a sweep
         if ((L.memo_gen & 0x3fffffffu) == 0u) { L.memo_gen = 1u; for (int q = 0; q < LDS::kSlots; q++) L.mstate[q] = 0u; }
-        const unsigned int tag = (L.memo_gen << 2) | 2u;
-        // key of a node: the blocked candidates of the spans d.. (bits below d * kTopK cleared) with the depth in the low bits
-        auto memo_key = [&](int d, unsigned long long b0, unsigned long long b1, unsigned long long b2, unsigned long long (&k)[kBlkWords]) -> unsigned {
-            const int bit = d * kTopK, wd = bit >> 6;
-            const unsigned long long keep = ~0ull << (bit & 63);
-            k[0] = wd == 0 ? (b0 & keep) : 0ull; k[1] = wd == 1 ? (b1 & keep) : (wd < 1 ? b1 : 0ull); k[2] = wd == 2 ? (b2 & keep) : (wd < 2 ? b2 : 0ull);
-            k[0] |= (unsigned long long)d;   // d >= 1: bits 0..4 belong to the first span and are clear
-            unsigned long long h = (k[0] * 0x9E3779B97F4A7C15ull) ^ (k[1] * 0xC2B2AE3D27D4EB4Full) ^ (k[2] * 0x165667B19E3779F9ull);
-            h ^= h >> 29;
-            return (unsigned)h & (LDS::kSlots - 1);
-        };
-        auto key_eq = [&](unsigned sl, const unsigned long long (&k)[kBlkWords]) -> bool {
-            bool eq = L.mkey[sl][0] == k[0];
-            if constexpr (W > 1) eq = eq && L.mkey[sl][1] == k[1];
-            if constexpr (W > 2) eq = eq && L.mkey[sl][2] == k[2];
-            return eq;
-        };
+        gen = (int)L.memo_gen;
+    }
+    const unsigned int tag = ((unsigned)uni(gen) << 2) | 2u;
+    // key of a node: the blocked candidates of the spans d.. (bits below d * kTopK cleared) with the depth in the low bits
+    auto memo_key = [&](int d, ull b0, ull b1, ull b2, ull (&k)[kBlkWords]) -> unsigned {
+        const int bit = d * kTopK, wd = bit >> 6;
+        const ull keep = ~0ull << (bit & 63);
+        k[0] = wd == 0 ? (b0 & keep) : 0ull; k[1] = wd == 1 ? (b1 & keep) : (wd < 1 ? b1 : 0ull); k[2] = wd == 2 ? (b2 & keep) : (wd < 2 ? b2 : 0ull);
+        k[0] |= (ull)d;   // d >= 1: bits 0..4 belong to the first span and are clear
+        ull h = (k[0] * 0x9E3779B97F4A7C15ull) ^ (k[1] * 0xC2B2AE3D27D4EB4Full) ^ (k[2] * 0x165667B19E3779F9ull);
+        h ^= h >> 29;
+        return (unsigned)h & (LDS::kSlots - 1);
+    };
+    auto key_eq = [&](unsigned sl, const ull (&k)[kBlkWords]) -> bool {
+        bool eq = L.mkey[sl][0] == k[0];
+        if constexpr (W > 1) eq = eq && L.mkey[sl][1] == k[1];
+        if constexpr (W > 2) eq = eq && L.mkey[sl][2] == k[2];
+        return eq;
+    };
+    // the kTopK blocked bits of depth d (they may straddle two words)
+    auto blocked_at = [&](int d, ull b0, ull b1, ull b2) -> unsigned {
+        const int bit = d * kTopK, wd = bit >> 6, sh = bit & 63;
+        const ull lo = wd == 0 ? b0 : (wd == 1 ? b1 : b2), hi = wd == 0 ? b1 : (wd == 1 ? b2 : 0ull);
+        ull x = lo >> sh;
+        if (sh > 64 - kTopK) x |= hi << (64 - sh);
+        return (unsigned)x & ((1u << kTopK) - 1u);
+    };
 #ifdef TW_PROFILE_SEL
-        const long long _s0 = wall_clock64();
+    const long long _s0 = wall_clock64();
 #endif
-        sel_w best_w = 0, acc = 0;      // only strict improvements replace the incumbent
-        unsigned long long b0 = 0, b1 = 0, b2 = 0;
-        for (int q = 0; q < cm; q++) { L.scur[q] = -1; L.sbest[q] = -1; }
-        L.saccs[0] = 0; L.sblk[0][0] = 0; if constexpr (W > 1) L.sblk[0][1] = 0; if constexpr (W > 2) L.sblk[0][2] = 0;
-        int d = 0, nodes = 0;
-        bool entered = true, over = false;
-        // One endpoint: a search that is still running after kMatchNodes1 nodes asks for the optimum of the whole component (one
-        // matching) and from then on only looks for the first selection in depth-first order that reaches it: the incumbent is
-        // floored at optimum - 1, every node is tested with the exact bound of its sub-problem, so the walk descends without
-        // backtracking past a node that cannot reach the optimum, and ends at the first leaf that does.
-        int exact = 0;   // 0 not asked yet, 1 known, -1 not available (indices too far apart)
-        while (d >= 0) {
-            int k = 0;
-            if (entered) {
-                if (++nodes > kNodeBudget) { over = true; break; }
-                if (E == 1 && exact == 0 && nodes > kMatchNodes1) {
-                    const sel_w opt = select_match_bound(L, 0, 0, 0ull, 0ull, 0ull);
-                    exact = opt == kNoBound ? -1 : 1;
-                    if (exact == 1) {
-                        if (best_w >= opt) break;   // the incumbent is the first selection of that weight in depth-first order
-                        best_w = opt - 1;
-                    }
+    sel_w best_w = 0, acc = 0;      // only strict improvements replace the incumbent
+    ull b0 = 0, b1 = 0, b2 = 0;
+    int d = 0, nodes = 0;
+    bool entered = true, over = false;
+    // One endpoint: a search that is still running after kMatchNodes1 nodes asks for the optimum of the whole component (one
+    // matching) and from then on only looks for the first selection in depth-first order that reaches it: the incumbent is
+    // floored at optimum - 1, every node is tested with the exact bound of its sub-problem, so the walk descends without
+    // backtracking past a node that cannot reach the optimum, and ends at the first leaf that does.
+    int exact = 0;   // 0 not asked yet, 1 known, -1 not available (indices too far apart)
+    while (d >= 0) {
+        int k = 0;
+        if (entered) {
+            if (++nodes > kNodeBudget) { over = true; break; }
+            if (E == 1 && exact == 0 && nodes > kMatchNodes1) {
+                sel_w opt = 0;
+                if (t == 0) opt = select_match_bound(L, 0, 0, 0ull, 0ull, 0ull);   // (the matching runs in one lane, on LDS)
+                opt = uni(opt);
+                exact = opt == kNoBound ? -1 : 1;
+                if (exact == 1) {
+                    if (best_w >= opt) break;   // the incumbent is the first selection of that weight in depth-first order
+                    best_w = opt - 1;
                 }
-                if (d == cm) {
-                    if (acc > best_w) {
-                        best_w = acc; for (int q = 0; q < cm; q++) L.sbest[q] = L.scur[q];
-                        if (exact == 1) break;      // the optimum, first in depth-first order
-                    }
-                    d--; entered = false; continue;
+            }
+            if (d == cm) {
+                if (acc > best_w) {
+                    best_w = acc; best = cur;
+                    if (exact == 1) break;      // the optimum, first in depth-first order
                 }
-                bool cut = acc + L.ub[d] <= best_w;
-                if (!cut && d >= 1 && cm - d > kMemoMinBelow) {   // has the sub-tree below this (depth, blocked set) been searched already?
-                    unsigned long long kk[kBlkWords];
-                    const unsigned slot = memo_key(d, b0, b1, b2, kk);
+                d--; entered = false; continue;
+            }
+            bool cut = acc + ubv.get(d) <= best_w;
+            if (!cut && d >= 1 && cm - d > kMemoMinBelow) {   // has the sub-tree below this (depth, blocked set) been searched already?
+                ull kk[kBlkWords];
+                const unsigned slot = memo_key(d, b0, b1, b2, kk);
+                int hit = 0;
+                if (t == 0)
                     for (int pr = 0; pr < 4; pr++) {
                         const unsigned sl = (slot + pr) & (LDS::kSlots - 1);
                         if (L.mstate[sl] != tag) break;   // empty: the chain ends here
-                        if (key_eq(sl, kk)) { cut = acc + L.mval[sl] <= best_w; break; }
+                        if (key_eq(sl, kk)) { hit = acc + L.mval[sl] <= best_w; break; }
                     }
-                }
-                // from kMatchNodes nodes on the matching relaxation is consulted as well (where enough spans remain below)
+                cut = uni(hit) != 0;
+            }
+            // from kMatchNodes nodes on the matching relaxation is consulted as well (where enough spans remain below)
+            if (!cut && (E == 1 ? exact == 1 : nodes > kMatchNodes) && cm - d >= kMatchMinDepth) {
 #ifdef TW_PROFILE_SEL
                 const long long _m0 = wall_clock64();
 #endif
-                if (!cut && (E == 1 ? exact == 1 : nodes > kMatchNodes) && cm - d >= kMatchMinDepth) { cut = select_match_prunes(L, E, d, acc, best_w, b0, b1, b2);
+                int hit = 0;
+                if (t == 0) hit = select_match_prunes(L, E, d, acc, best_w, b0, b1, b2);
+                cut = uni(hit) != 0;
 #ifdef TW_PROFILE_SEL
-                    L.pt[1] += wall_clock64() - _m0; L.pt[2] += 1;
+                if (t == 0) { L.pt[1] += wall_clock64() - _m0; L.pt[2] += 1; }
 #endif
-                }
-                if (cut) { d--; entered = false; continue; }
-            } else {
-                acc = L.saccs[d]; b0 = L.sblk[d][0]; if constexpr (W > 1) b1 = L.sblk[d][1]; if constexpr (W > 2) b2 = L.sblk[d][2];
-                k = L.scur[d] + 1;   // resume below the choice this level made last ("none" was stored as ncand)
             }
-            const int b = L.mem[d], nc = L.ncand[b];
-            bool found = false;
-            for (; k <= nc; k++) {
-                if (k == nc) { found = true; break; }   // "none"
-                const sel_w w = L.w[b][k];
-                if (!(w > 0)) continue;
-                const int bit = d * kTopK + k;
-                if (((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull) continue;
-                found = true;
-                break;
+            if (cut) { d--; entered = false; continue; }
+        } else {
+            acc = sacc.get(d); b0 = sb[0].get(d); if constexpr (W > 1) b1 = sb[1].get(d); if constexpr (W > 2) b2 = sb[2].get(d);
+            k = cur.get(d) + 1;   // resume below the choice this level made last ("none" was stored as ncand)
+        }
+        // the next choice of this level: its first eligible, unblocked candidate from k on, then "none"
+        const int nc = ncv.get(d);
+        const unsigned open = k < kTopK ? ((unsigned)elig.get(d) & ~blocked_at(d, b0, b1, b2) & (~0u << k)) : 0u;
+        if (open != 0u) k = __ffs((int)open) - 1;
+        else if (k <= nc) k = nc;
+        else k = -1;
+        if (k >= 0) {
+            cur.set(d, k);
+            if (k < nc) {
+#pragma unroll
+                for (int c = 0; c < kTopK; c++)
+                    if (c == k) { acc = acc + wv[c].get(d); b0 |= cmk[c][0].get(d); if constexpr (W > 1) b1 |= cmk[c][1].get(d); if constexpr (W > 2) b2 |= cmk[c][2].get(d); }
             }
-            if (found) {
-                L.scur[d] = (int8_t)k;
-                if (k < nc) { acc = acc + L.w[b][k]; b0 |= L.cmask3[d][k][0]; if constexpr (W > 1) b1 |= L.cmask3[d][k][1]; if constexpr (W > 2) b2 |= L.cmask3[d][k][2]; }
-                d++;
-                L.saccs[d] = acc; L.sblk[d][0] = b0; if constexpr (W > 1) L.sblk[d][1] = b1; if constexpr (W > 2) L.sblk[d][2] = b2;
-                entered = true;
-                continue;
-            }
-            // every way on from this node has been searched: remember what it can gain at most
-            if (d >= 1 && cm - d > kMemoMinBelow) {
-                unsigned long long kk[kBlkWords];
-                const unsigned slot = memo_key(d, b0, b1, b2, kk);
+            d++;
+            sacc.set(d, acc); sb[0].set(d, b0); if constexpr (W > 1) sb[1].set(d, b1); if constexpr (W > 2) sb[2].set(d, b2);
+            entered = true;
+            continue;
+        }
+        // every way on from this node has been searched: remember what it can gain at most
+        if (d >= 1 && cm - d > kMemoMinBelow) {
+            ull kk[kBlkWords];
+            const unsigned slot = memo_key(d, b0, b1, b2, kk);
+            if (t == 0)
                 for (int pr = 0; pr < 4; pr++) {
                     const unsigned sl = (slot + pr) & (LDS::kSlots - 1);
                     if (L.mstate[sl] == tag) {
@@ -2233,9 +2312,10 @@ __device__ void select_search(LDS& L, int E) {
                     L.mstate[sl] = tag;
                     break;
                 }
-            }
-            d--; entered = false;
         }
+        d--; entered = false;
+    }
+    if (t == 0) {
 #ifdef TW_PROFILE_SEL
         L.pt[0] += wall_clock64() - _s0; L.pt[3] += nodes;
 #endif
@@ -2244,11 +2324,12 @@ __device__ void select_search(LDS& L, int E) {
         if (nodes > TW_SEARCH_TRACE) printf("search: component of %d spans, %d nodes\n", cm, nodes);
 #endif
         L.nodes_total += (unsigned long long)nodes;
-        for (int q = 0; q < cm; q++) {
-            const int bq = L.mem[q], kq = best_w > 0 ? L.sbest[q] : -1;
-            L.pick[bq] = (int8_t)((kq < 0 || kq == (int)L.ncand[bq]) ? -1 : kq);
-        }
     }
+    best.store(cm, [&](int q, int kq) {
+        const int bq = L.mem[q];
+        if (!(best_w > 0)) kq = -1;
+        L.pick[bq] = (int8_t)((kq < 0 || kq == (int)L.ncand[bq]) ? -1 : kq);
+    });
     group_sync();
 }
 
