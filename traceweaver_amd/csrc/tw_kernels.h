@@ -1992,9 +1992,11 @@ struct SelectLdsT {
     unsigned long long cmask3[kS][kTopK][kW];
     // transposition table of select_search: what can still be gained below a node depends only on its depth and on which
     // candidates of the remaining spans are blocked, not on how the spans above were assigned
-    unsigned long long mkey[kSlots][kW];
-    sel_w mval[kSlots];
-    unsigned int mstate[kSlots];   // generation << 2 | (0 empty, 1 being written, 2 valid)
+    struct Memo {      // one entry: read whole by a probe (independent loads, one wait)
+        unsigned long long key[kW];
+        sel_w val;
+        unsigned int state;   // generation << 2 | (0 empty, 2 valid)
+    } memo[kSlots];
     unsigned int memo_gen;
     int cm, budget_hit;
     unsigned long long nodes_total;   // search nodes of the window (all lanes), reported in unit_stats[5]
@@ -2034,11 +2036,14 @@ __device__ sel_w select_match_bound(LDS& L, int e, int d, unsigned long long b0,
     constexpr int NC = LDS::kCols;
     const sel_w INF = kNoBound;
     const int cm = L.cm, nrow = cm - d;
-    auto eligible = [&](int dd, int k) -> bool {
+    auto eligible = [&L, b0, b1, b2](int dd, int k) -> bool {   // (the masks by value: selected as values, not through pointers to them)
         const int b = L.mem[dd];
         if (k >= L.ncand[b] || !(L.w[b][k] > 0)) return false;
         const int bit = dd * kTopK + k;
-        return !(((bit < 64 ? b0 : bit < 128 ? b1 : b2) >> (bit & 63)) & 1ull);
+        unsigned long long w = b2;
+        if (bit < 128) w = b1;
+        if (bit < 64) w = b0;
+        return !((w >> (bit & 63)) & 1ull);
     };
     {
         int32_t base = 0x7fffffff, top = -0x7fffffff - 1;
@@ -2188,7 +2193,7 @@ __device__ void select_search(LDS& L, int E) {
     int gen = 0;
     if (t == 0) {
         L.memo_gen++;   // entries of earlier components become stale without a sweep
-        if ((L.memo_gen & 0x3fffffffu) == 0u) { L.memo_gen = 1u; for (int q = 0; q < LDS::kSlots; q++) L.mstate[q] = 0u; }
+        if ((L.memo_gen & 0x3fffffffu) == 0u) { L.memo_gen = 1u; for (int q = 0; q < LDS::kSlots; q++) L.memo[q].state = 0u; }
         gen = (int)L.memo_gen;
     }
     const unsigned int tag = ((unsigned)uni(gen) << 2) | 2u;
@@ -2202,10 +2207,10 @@ __device__ void select_search(LDS& L, int E) {
         h ^= h >> 29;
         return (unsigned)h & (LDS::kSlots - 1);
     };
-    auto key_eq = [&](unsigned sl, const ull (&k)[kBlkWords]) -> bool {
-        bool eq = L.mkey[sl][0] == k[0];
-        if constexpr (W > 1) eq = eq && L.mkey[sl][1] == k[1];
-        if constexpr (W > 2) eq = eq && L.mkey[sl][2] == k[2];
+    auto key_eq = [&](const typename LDS::Memo& en, const ull (&k)[kBlkWords]) -> bool {
+        bool eq = en.key[0] == k[0];
+        if constexpr (W > 1) eq = eq && en.key[1] == k[1];
+        if constexpr (W > 2) eq = eq && en.key[2] == k[2];
         return eq;
     };
     // the kTopK blocked bits of depth d (they may straddle two words)
@@ -2256,9 +2261,9 @@ __device__ void select_search(LDS& L, int E) {
                 int hit = 0;
                 if (t == 0)
                     for (int pr = 0; pr < 4; pr++) {
-                        const unsigned sl = (slot + pr) & (LDS::kSlots - 1);
-                        if (L.mstate[sl] != tag) break;   // empty: the chain ends here
-                        if (key_eq(sl, kk)) { hit = acc + L.mval[sl] <= best_w; break; }
+                        const typename LDS::Memo en = L.memo[(slot + pr) & (LDS::kSlots - 1)];
+                        if (en.state != tag) break;   // empty: the chain ends here
+                        if (key_eq(en, kk)) { hit = acc + en.val <= best_w; break; }
                     }
                 cut = uni(hit) != 0;
             }
@@ -2303,13 +2308,13 @@ __device__ void select_search(LDS& L, int E) {
             const unsigned slot = memo_key(d, b0, b1, b2, kk);
             if (t == 0)
                 for (int pr = 0; pr < 4; pr++) {
-                    const unsigned sl = (slot + pr) & (LDS::kSlots - 1);
-                    if (L.mstate[sl] == tag) {
-                        if (key_eq(sl, kk)) { L.mval[sl] = best_w - acc; break; }
+                    typename LDS::Memo& en = L.memo[(slot + pr) & (LDS::kSlots - 1)];
+                    if (en.state == tag) {
+                        if (key_eq(en, kk)) { en.val = best_w - acc; break; }
                         continue;
                     }
-                    L.mkey[sl][0] = kk[0]; if constexpr (W > 1) L.mkey[sl][1] = kk[1]; if constexpr (W > 2) L.mkey[sl][2] = kk[2]; L.mval[sl] = best_w - acc;
-                    L.mstate[sl] = tag;
+                    en.key[0] = kk[0]; if constexpr (W > 1) en.key[1] = kk[1]; if constexpr (W > 2) en.key[2] = kk[2]; en.val = best_w - acc;
+                    en.state = tag;
                     break;
                 }
         }
@@ -2673,7 +2678,7 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
     sel_segments(P, LIST, G);
     const int count = G.first[kSelSeg];
     if ((int)blockIdx.x >= count) return;   // nothing for this workgroup (the usual case outside heavy load)
-    for (int q = threadIdx.x; q < LDS::kSlots; q += blockDim.x) L.mstate[q] = 0u;
+    for (int q = threadIdx.x; q < LDS::kSlots; q += blockDim.x) L.memo[q].state = 0u;
     if (threadIdx.x == 0) L.memo_gen = 0u;
     group_sync();
     int chunk_pos = 0, chunk_end = 0;

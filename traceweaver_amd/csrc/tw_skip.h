@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(64) k_skip_walk(Dev P, const SkipUnitDev* skip
     const SkipUnitDev& K = skip[unit];
     const int E = U.E;
     TW_SEL_DECL();
-    for (int q = t; q < SelectLds::kSlots; q += nt) L.mstate[q] = 0u;
+    for (int q = t; q < SelectLds::kSlots; q += nt) L.memo[q].state = 0u;
     if (t == 0) { L.memo_gen = 0u; S.err = 0; S.window_first = 0; }
     group_sync();
     for (int i = 0; i < U.n_in; i++) {
