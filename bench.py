@@ -386,15 +386,20 @@ def main():
     no_torch = world == 1 and args.sync == "engine"
     if no_torch:
         torch = None
-        emulated = False
+        # (no torch to ask for a GPU: the host-emulation build of the tests is known by its file name)
+        emulated = args.lib is not None and os.path.basename(args.lib).endswith("_emu.so")
         device = 0
     else:
         import torch
 
         emulated = args.lib is not None and not torch.cuda.is_available()
-    if no_torch:
+    if emulated:
+        device = 0
+        os.environ.setdefault("TW_TILE", "1")
+        os.environ.setdefault("TW_COOP_THREADS", "1")
+    elif no_torch:
         pass
-    elif not emulated:
+    else:
         ndev = torch.cuda.device_count()
         if ndev < 1:
             sys.exit("bench.py: no GPU visible (the HIP engine has no CPU fallback)")
@@ -402,10 +407,6 @@ def main():
             sys.exit("bench.py: %d ranks on this node but only %d GPU(s) visible" % (int(os.environ.get("LOCAL_WORLD_SIZE", world)), ndev))
         device = local_rank % ndev
         torch.cuda.set_device(device)
-    else:
-        device = 0
-        os.environ.setdefault("TW_TILE", "1")
-        os.environ.setdefault("TW_COOP_THREADS", "1")
     dist = None
     if world > 1:
         import torch.distributed as dist
