@@ -77,6 +77,8 @@ def parse_args():
     ap.add_argument("--verify", type=int, default=0, help="alibaba: rank 0 also solves the whole slice alone and compares the gathered parents")
     ap.add_argument("--fit", default="device", choices=["device", "sklearn"], help="mixture refit between the passes")
     ap.add_argument("--cpu-sample", type=int, default=40000, help="requests per service in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=256, help="CPU baseline: also the sample in min(this, host cores) processes at once (1 = skip)")
+    ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--regimes", type=int, default=1,
                     help="default workload at N = 1 only: after the timed step loop, 3 steps each of the harder single-GPU regimes "
                          "(config 3 shape, the config 4 slice on one GPU, media shape at concurrency 4 and 8) on the same engine, "
@@ -217,25 +219,62 @@ def run_regimes(args, eng, steps=3):
     return out
 
 
+def _cpu_sample(args, seed):
+    """One run of the CPU oracle over the sample: (spans, seconds, services)."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import tw_oracle as T
+
+    units, _, _ = make_units(args, seed, n_in=args.cpu_sample, replicas=1, total_spans=min(args.total_spans, 16 * args.cpu_sample))
+    spans = sum(u.n_spans for u in units)
+    from threadpoolctl import threadpool_limits
+
+    t0 = time.perf_counter()
+    with threadpool_limits(limits=1):   # "1 thread" includes the BLAS / OpenMP pools under the refit
+        for u in units:
+            svc = T.Service(u.in_start, u.in_end - u.in_start, u.out_off, u.out_start, u.out_end - u.out_start, u.dag, u.key_rank)
+            T.run_service(svc)
+    return spans, time.perf_counter() - t0, len(units)
+
+
+def cpu_all_cores(args, seed):
+    """The same sample in one process per host core at once (every process its own copy of the sample: the services of a
+    run are independent, which is how a CPU deployment of the port would use the box): aggregate spans / slowest process."""
+    procs = max(1, min(os.cpu_count() or 1, args.cpu_procs))
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "1", "--cpu-sample", str(args.cpu_sample), "--workload", args.workload,
+           "--total-spans", str(args.total_spans)] + (["--concurrency", str(args.concurrency)] if args.concurrency is not None else [])
+    t0 = time.perf_counter()
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")   # one core per process (the refit's BLAS / OpenMP pools)
+    ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(procs)]
+    rows = []
+    deadline = time.perf_counter() + 240.0
+    for p in ps:
+        try:
+            out, _ = p.communicate(timeout=max(1.0, deadline - time.perf_counter()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            continue
+        if p.returncode == 0 and out.strip():
+            rows.append(json.loads(out.strip().split("\n")[-1]))
+    if len(rows) < procs:   # a process failed or ran out of time: no figure rather than a flattering one
+        return {"value": None, "cores": procs, "what": "%d of %d processes finished within 240 s" % (len(rows), procs)}
+    slowest = max(r["seconds"] for r in rows)
+    return {"value": sum(r["spans"] for r in rows) / slowest, "unit": "spans/s", "cores": len(rows), "slowest_process_s": slowest,
+            "wall_s": time.perf_counter() - t0, "what": "%d processes, each the whole sample" % len(rows)}
+
+
 def cpu_baseline(args, seed):
     """The CPU oracle (a C port of the reference algorithm, 1 thread) on a bounded sample of the same
     workload: same services, fewer requests per service.  Next to it the record of the reference itself (its
     Python executor, predictor index 10, HiGHS in place of Gurobi) timed in the build container on a corpus of the
     same shape: profiles/cpu_reference.json, written by oracle/refrun/time_reference.py -- /root/reference does not
     exist on the GPU box, so that figure cannot be re-measured there."""
-    sys.path.insert(0, os.path.join(REPO, "oracle"))
-    import tw_oracle as T
-
-    units, _, _ = make_units(args, seed, n_in=args.cpu_sample, replicas=1, total_spans=min(args.total_spans, 16 * args.cpu_sample))
-    spans = sum(u.n_spans for u in units)
-    t0 = time.perf_counter()
-    for u in units:
-        svc = T.Service(u.in_start, u.in_end - u.in_start, u.out_off, u.out_start, u.out_end - u.out_start, u.dag, u.key_rank)
-        T.run_service(svc)
-    dt = time.perf_counter() - t0
+    spans, dt, n_units = _cpu_sample(args, seed)
     out = {"value": spans / dt, "unit": "spans/s", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
            "sample": "oracle/tw_oracle.c two-pass (sklearn refit) on the same %d %s-shape services at %d requests each (%d spans, %.1f s), 1 thread"
-                     % (len(units), args.workload, args.cpu_sample, spans, dt)}
+                     % (n_units, args.workload, args.cpu_sample, spans, dt)}
+    if args.cpu_procs > 1:
+        out["all_cores"] = cpu_all_cores(args, seed)
     ref = os.path.join(REPO, "profiles", "cpu_reference.json")
     if os.path.exists(ref):
         out["reference"] = json.load(open(ref))
@@ -374,6 +413,10 @@ def profile_traffic(dominant, spans_rank):
 
 def main():
     args = parse_args()
+    if args.cpu_worker:   # a process of cpu_all_cores
+        spans, dt, _ = _cpu_sample(args, 1000)
+        print(json.dumps({"spans": spans, "seconds": dt}))
+        return
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -332,3 +332,20 @@ def test_bench_default_batch_is_sixteen_replicas():
 
     src = inspect.getsource(bench.make_units)
     assert "16 if args.workload == \"media\" else 4" in src
+
+
+def test_cpu_baseline_all_cores_runs_the_sample_once_per_process():
+    """bench.py's cpu_baseline: the single-process figure and, next to it, the same sample in several processes at once."""
+    sys.path.insert(0, REPO)
+    import bench
+
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py", "--cpu-sample", "300", "--cpu-procs", "2"]
+        args = bench.parse_args()
+    finally:
+        sys.argv = old
+    r = bench.cpu_baseline(args, 1000)
+    assert r["cores"] == 1 and r["value"] > 0
+    a = r["all_cores"]
+    assert a["cores"] == 2 and a["value"] > 0 and a["slowest_process_s"] > 0
