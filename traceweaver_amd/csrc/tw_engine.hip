@@ -113,6 +113,10 @@ struct tw_engine {
     uint32_t fit_seed = 0;
     int32_t* slot_unit = nullptr;
     int32_t* tile_ids = nullptr;            // tiles grouped by the unit's endpoint count
+    // The small counters of a pass in one block, so that a pass (and a repair round) starts with one fill instead of a dozen:
+    // [work-list counters .. frontier cursors] are what a repair round resets, the whole block what a pass resets.
+    int32_t* ctr = nullptr;
+    int64_t ctr_round_ints = 0, ctr_pass_ints = 0;
     int32_t tile_cls_off[kMaxEp + 2] = {};  // class E owns tile_ids[tile_cls_off[E] .. tile_cls_off[E+1])
     uint32_t *seg_gap = nullptr, *seg_gap_end = nullptr, *seg_gap_dst = nullptr;
     unsigned long long *comp_a = nullptr, *comp_b = nullptr;  // composite keys of sort_rows
@@ -262,8 +266,7 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
 
 void launch_enumerate_all(tw_engine* e, int pass, int mode) {
     bool used = false;
-    (void)hipMemsetAsync(e->P.frontier_next, 0, sizeof(int32_t), e->stream);
-    (void)hipMemsetAsync(e->P.frontier_big_next, 0, sizeof(int32_t), e->stream);
+    // (the frontier cursors were reset with the counter block of the pass / the repair round)
     (void)hipEventRecord(e->cls_ev[0], e->stream);
     launch_enumerate<1>(e, pass, mode, used); launch_enumerate<2>(e, pass, mode, used); launch_enumerate<3>(e, pass, mode, used); launch_enumerate<4>(e, pass, mode, used);
     launch_enumerate<5>(e, pass, mode, used); launch_enumerate<6>(e, pass, mode, used); launch_enumerate<7>(e, pass, mode, used); launch_enumerate<8>(e, pass, mode, used);
@@ -380,11 +383,7 @@ int run_pass(tw_engine* e, int pass) {
     const Dev& P = e->P;
     const dim3 tiles(P.n_tiles), tb(e->tile);
     HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
-    HIPCHK(hipMemsetAsync(P.err, 0, sizeof(int32_t), e->stream));
-    HIPCHK(hipMemsetAsync(P.unit_stats, 0, sizeof(int64_t) * 8 * P.n_units, e->stream));
-    HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 4 * kSelSeg * kCtrStride, e->stream));
-    HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t) * 4, e->stream));
-    HIPCHK(hipMemsetAsync(P.unit_ndirty, 0, sizeof(int32_t) * P.n_units, e->stream));
+    HIPCHK(hipMemsetAsync(e->ctr, 0, sizeof(int32_t) * (size_t)e->ctr_pass_ints, e->stream));   // error flag, statistics, every work-list counter
     if (pass == 1 && !e->skip_mode) {
         int rc = sort_ends(e);
         if (rc != TW_OK) return rc;
@@ -399,11 +398,6 @@ int run_pass(tw_engine* e, int pass) {
     }
     HIPCHK(hipEventRecord(e->ev[EV_PARAMS], e->stream));
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
-    HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
-    HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 3 * (kMaxEp + 1), e->stream));
-    HIPCHK(hipMemsetAsync(P.heavy_big_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
-    HIPCHK(hipMemsetAsync(P.part_used, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
-    HIPCHK(hipMemsetAsync(P.split_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
     launch_enumerate_all(e, pass, 0);
     HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
     if (pass == 1) {
@@ -445,12 +439,7 @@ int run_pass(tw_engine* e, int pass) {
     for (int round = 0;; round++) {
         HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
         hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P);
-        HIPCHK(hipMemsetAsync(P.heavy_in_count, 0, sizeof(int32_t) * 2 * (kMaxEp + 1), e->stream));
-        HIPCHK(hipMemsetAsync(P.heavy_in_next, 0, sizeof(int32_t) * 3 * (kMaxEp + 1), e->stream));
-        HIPCHK(hipMemsetAsync(P.heavy_big_count, 0, sizeof(int32_t) * (kMaxEp + 1), e->stream));
-        HIPCHK(hipMemsetAsync(P.heavy_count, 0, sizeof(int32_t) * 4 * kSelSeg * kCtrStride, e->stream));
-        HIPCHK(hipMemsetAsync(P.heavy_next, 0, sizeof(int32_t) * 4, e->stream));
-        HIPCHK(hipMemsetAsync(P.round_changed, 0, sizeof(int32_t), e->stream));
+        HIPCHK(hipMemsetAsync(e->ctr, 0, sizeof(int32_t) * (size_t)e->ctr_round_ints, e->stream));   // work lists, round_changed, frontier cursors
         hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, e->stream, P, round);
         int32_t changed = 0;
         HIPCHK(hipMemcpyAsync(&changed, P.round_changed, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
@@ -830,19 +819,18 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(e->mix_n_dev, slots); ALLOC(e->mix_p_dev, slots * kMaxComp * 3); ALLOC(e->mix_c_dev, slots * kMaxComp * 4);
     ALLOC(P.pm_val, n_in_total); ALLOC(P.pm_idx, n_in_total); ALLOC(P.pc, n_in_total + 1); ALLOC(P.seg, n_in_total);
     ALLOC(P.win_end, n_in_total); ALLOC(P.wid, n_in_total); ALLOC(P.w_last, n_in_total);
-    ALLOC(P.unit_nwin, P.n_units); ALLOC(P.w_dirty, n_in_total); ALLOC(P.w_conf, n_in_total); ALLOC(P.unit_ndirty, P.n_units);
+    ALLOC(P.unit_nwin, P.n_units); ALLOC(P.w_dirty, n_in_total); ALLOC(P.w_conf, n_in_total);
     ALLOC(P.tk_n, n_in_total); ALLOC(P.leaves, n_in_total); ALLOC(P.chosen, n_in_total); ALLOC(P.rep, n_in_total);
     ALLOC(P.tkr_n, n_in_total);
     ALLOC(P.tk_idx, ie * kTopK); ALLOC(P.tkr_idx, ie * kTopK);
     ALLOC(P.tk_score, n_in_total * kTopK); ALLOC(P.tkr_score, n_in_total * kTopK);
     ALLOC(P.c_lo, ie); ALLOC(P.c_hi, ie); ALLOC(P.c_bits, ie * kCandWords); ALLOC(P.parent, ie);
-    ALLOC(P.gone, ie * kCandWords); ALLOC(P.leaves_r, n_in_total); ALLOC(P.round_changed, 1);
-    ALLOC(P.frontier, (int64_t)kFrontierSlots * 2 * kFrontierCap); ALLOC(P.frontier_next, 1); ALLOC(P.frontier_big, (int64_t)kFrontierBigSlots * 2 * kFrontierBigCap); ALLOC(P.frontier_big_next, 1);
+    ALLOC(P.gone, ie * kCandWords); ALLOC(P.leaves_r, n_in_total);
+    ALLOC(P.frontier, (int64_t)kFrontierSlots * 2 * kFrontierCap); ALLOC(P.frontier_big, (int64_t)kFrontierBigSlots * 2 * kFrontierBigCap);
     ALLOC(P.owner, n_out_total);
     ALLOC(P.gaps, gaps);
-    ALLOC(P.unit_stats, (int64_t)P.n_units * 8); ALLOC(P.err, 1);
     ALLOC(e->tile_ids, (int64_t)tile_ids_h.size());
-    ALLOC(P.heavy_in_count, 2 * (kMaxEp + 1)); ALLOC(P.heavy_in_next, 3 * (kMaxEp + 1)); ALLOC(P.span_cls, n_in_total); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
+    ALLOC(P.span_cls, n_in_total); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
     {   // long enumerations: a list entry per span plus the extra entries of the split ones (an eighth of the class + 64), two
         // scratch slots per extra entry
         int64_t big_total = 0, slots = 0;
@@ -853,9 +841,8 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
             big_total += n_cls + extra; slots += 2 * extra;
         }
         P.heavy_big_off[kMaxEp + 1] = (int32_t)big_total; P.part_off[kMaxEp + 1] = (int32_t)slots;
-        ALLOC(P.heavy_big_count, kMaxEp + 1); ALLOC(P.heavy_big_unit, big_total); ALLOC(P.heavy_big_idx, big_total);
+        ALLOC(P.heavy_big_unit, big_total); ALLOC(P.heavy_big_idx, big_total);
         ALLOC(P.heavy_big_part, big_total); ALLOC(P.heavy_big_slot, big_total);
-        ALLOC(P.part_used, kMaxEp + 1); ALLOC(P.split_count, kMaxEp + 1);
         ALLOC(P.split_unit, slots); ALLOC(P.split_idx, slots); ALLOC(P.split_slot, slots); ALLOC(P.split_parts, slots);
         ALLOC(P.part_n, slots); ALLOC(P.part_leaves, slots); ALLOC(P.part_score, slots * kTopK); ALLOC(P.part_idx, slots * kTopK * kMaxEp);
         ALLOC(P.part_bits, slots * kMaxEp * kCandWords);
@@ -863,7 +850,26 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
     ALLOC(P.prof, 16); ALLOC(e->key_acc, 2);
     const int64_t sel_cap = (int64_t)P.n_tiles * e->tile + 1;   // every segment of the selection lists has room for all windows of its tiles
-    ALLOC(P.heavy_count, 4 * kSelSeg * kCtrStride); ALLOC(P.heavy_next, 4); ALLOC(P.heavy_unit, sel_cap); ALLOC(P.heavy_win, sel_cap);
+    {   // the counter block (every array on a 128-byte line of its own: their atomics come from different kernels)
+        int64_t at = 0;
+        auto take = [&](int64_t ints) { const int64_t o = at; at += (ints + 31) / 32 * 32; return o; };
+        const int64_t o_hc = take(4 * kSelSeg * kCtrStride), o_hn = take(4), o_ic = take(2 * (kMaxEp + 1)), o_in = take(3 * (kMaxEp + 1)), o_bc = take(kMaxEp + 1),
+                      o_rc = take(1), o_fn = take(1), o_fb = take(1);
+        e->ctr_round_ints = at;
+        const int64_t o_pu = take(kMaxEp + 1), o_sc = take(kMaxEp + 1), o_err = take(1), o_nd = take(P.n_units), o_us = take((int64_t)P.n_units * 16);
+        e->ctr_pass_ints = at;
+        auto place = [=](void* q) {
+            Dev& D = e->P;
+            int32_t* c = e->ctr = (int32_t*)q;
+            D.heavy_count = c + o_hc; D.heavy_next = c + o_hn; D.heavy_in_count = c + o_ic; D.heavy_in_next = c + o_in; D.heavy_big_count = c + o_bc;
+            D.round_changed = c + o_rc; D.frontier_next = c + o_fn; D.frontier_big_next = c + o_fb;
+            D.part_used = c + o_pu; D.split_count = c + o_sc; D.err = c + o_err; D.unit_ndirty = c + o_nd;
+            D.unit_stats = (int64_t*)(c + o_us);
+        };
+        if (e->arena_open) e->arena_req.emplace_back(place, ((size_t)at * sizeof(int32_t) + 255) / 256 * 256);   // (placed by arena_commit, like the rest)
+        else { ALLOC(e->ctr, at); place(e->ctr); }
+    }
+    ALLOC(P.heavy_unit, sel_cap); ALLOC(P.heavy_win, sel_cap);
     ALLOC(P.tiny_unit, sel_cap); ALLOC(P.tiny_win, sel_cap);
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
