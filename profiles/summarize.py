@@ -162,6 +162,34 @@ def enumerate_wall(trace_path):
     return sum(spans) / len(spans), sum(spans[0::2]) / max(len(spans[0::2]), 1), sum(spans[1::2]) / max(len(spans[1::2]), 1)
 
 
+def timeline(trace_path):
+    """Kernels of the enumeration and selection groups of the last launch set in the trace (pass 2 of the last step), in start
+    order: (short name, queue, start offset us, duration us) -- which kernels overlap and which one ends the group."""
+    if not os.path.exists(trace_path):
+        return None
+    rows = sorted(csv.DictReader(open(trace_path)), key=lambda r: int(r["Start_Timestamp"]))
+    last_enum = max((i for i, r in enumerate(rows) if group_of(r["Kernel_Name"]) == "k_enumerate"
+                     and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 200000), default=None)
+    if last_enum is None:
+        return None
+    t_end = int(rows[last_enum]["Start_Timestamp"])
+    # walk back to the start of that launch set: the first enumeration kernel after the previous selection
+    first = last_enum
+    while first > 0 and not (group_of(rows[first - 1]["Kernel_Name"]) == "k_select" and int(rows[first - 1]["End_Timestamp"]) < t_end - 1000000):
+        first -= 1
+    out, t0 = [], None
+    for r in rows[first:]:
+        g = group_of(r["Kernel_Name"])
+        if g not in ("k_enumerate", "k_select"):
+            if g in ("repair", "other") and out and any(x[0].startswith("k_select") for x in out):
+                break
+            continue
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        t0 = s if t0 is None else t0
+        out.append((short(r["Kernel_Name"]), r.get("Queue_Id", ""), (s - t0) / 1e3, (e - s) / 1e3))
+    return out
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     out = os.path.join(REPO, "profiles")
@@ -206,6 +234,13 @@ def main():
                     "durations; the wall-clock span of a launch set in the kernel trace is **%.2f ms** (pass 1: %.2f, pass 2: %.2f), the HIP events of "
                     "`bench.py` around the same launches read %.2f ms (`roofline.kernel_ms`).\n" % (
                         wall[0], wall[1], wall[2], bench.get("roofline", {}).get("kernel_ms", float("nan"))))
+        tl = timeline(os.path.join(src, tag + "_stats", tag + "_kernel_trace.csv"))
+        if tl:
+            f.write("\nTimeline of the last launch set (pass 2 of the last step), enumeration then selection; kernels on different queues overlap:\n\n"
+                    "| kernel | queue | start us | duration us |\n|---|---|---|---|\n")
+            for name, q, st, du in tl:
+                if du >= 20.0:
+                    f.write("| `%s` | %s | %.0f | %.0f |\n" % (name[:60], q, st, du))
         f.write("\nTop kernels (rocprofv3 --stats):\n\n| kernel | calls | avg us | % |\n|---|---|---|---|\n")
         for r in rows[:14]:
             f.write("| `%s` | %s | %.1f | %s |\n" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from traceweaver_amd import synth
 from traceweaver_amd.engine import Engine
 conc = float(os.environ.get("TW_CONC", "1.6")); n_in = int(os.environ.get("TW_NIN", "100000"))
-units, truth = synth.make_workload(1000, n_in, services=synth.MEDIA_SERVICES, replicas=4, concurrency=conc)
+units, truth = synth.make_workload(1000, n_in, services=synth.MEDIA_SERVICES, replicas=int(os.environ.get("TW_REPLICAS", "4")), concurrency=conc)
 eng = Engine(0, lib_path=os.environ.get("TW_PROFILE_LIB", "scratch/prof.so")); eng.load(units)
 lib = eng._lib
 lib.tw_debug_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

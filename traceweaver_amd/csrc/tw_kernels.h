@@ -346,7 +346,7 @@ struct Cand {
 // costly part) run in parallel, the heap is then fed in enumeration order (wave-uniform pushes) so that
 // ties resolve exactly as in the sequential reference.
 #ifndef TW_LIGHT_MAX
-#define TW_LIGHT_MAX 48
+#define TW_LIGHT_MAX 64
 #endif
 constexpr int kLightMax = TW_LIGHT_MAX;  // largest candidate product the per-thread kernel enumerates itself
 constexpr int kHeavyThreads = 64;
@@ -466,6 +466,12 @@ struct LightCtx {
     double troot[E], tclose[E];  // root / closing term of the span currently chosen at each level
     double* tab;               // this thread's column of the workgroup's LDS term table (stride = workgroup size)
     int tab_stride;
+    // the tabulated candidates themselves are staged next to their terms: (start, end) as offsets from in_start in LDS, the
+    // position in the window a byte each in a register -- the tree below re-reads a level's candidates for every prefix,
+    // and from global memory that was the kernel's time (1 032 VMEM reads per wavefront at E = 4, 54 % of cycles waiting)
+    int32_t* so;               // this thread's column of the offset table, same stride
+    uint64_t cxo[E];           // cx - lo of the staged candidates of every endpoint
+    int nst[E];                // how many are staged (<= light_tab_width<E>())
 };
 
 // Terms that depend on one outgoing span only -- root(in.start -> s.start) and closing(s.end -> in.end),
@@ -474,7 +480,7 @@ struct LightCtx {
 // back to evaluating at the tree level where the span is chosen.  The tuple score adds the same doubles in the
 // same order, so it is bit-identical.
 #ifndef TW_LIGHT_TABW
-#define TW_LIGHT_TABW(E) ((E) == 1 ? 8 : (E) == 2 ? 8 : (E) == 3 ? 6 : (E) == 4 ? 5 : (E) == 5 ? 4 : (E) == 6 ? 3 : 2)
+#define TW_LIGHT_TABW(E) ((E) == 1 ? 5 : (E) == 2 ? 5 : (E) == 3 ? 4 : (E) == 4 ? 3 : 2)   // 24 B of LDS per (endpoint, candidate) and thread
 #endif
 template <int E>
 __host__ __device__ constexpr int light_tab_width() { return TW_LIGHT_TABW(E); }
@@ -592,31 +598,51 @@ __device__ void light_leaf(LightCtx<E>& c, bool want_bits) {
 }
 
 template <int E, int D>
+__device__ void light_dfs(LightCtx<E>& c, bool want_bits);
+// candidate cx = [st, en] (contained in the incoming span; r = its rank among the contained spans of endpoint D)
+template <int E, int D>
+__device__ __forceinline__ void light_visit(LightCtx<E>& c, bool want_bits, int cx, int64_t st, int64_t en, int r) {
+    const UnitDev& U = *c.U;
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < D; p++)
+        if (((U.pred_mask[D] >> p) & 1) && c.xe[p] > st) ok = false;
+    if (!ok) return;
+    c.x[D] = cx; c.xs[D] = st; c.xe[D] = en;
+    constexpr int Wt = light_tab_width<E>();
+    if (r < Wt) {
+        c.troot[D] = c.tab[(D * Wt + r) * 2 * c.tab_stride];
+        c.tclose[D] = c.tab[((D * Wt + r) * 2 + 1) * c.tab_stride];
+    } else {
+        c.troot[D] = U.npred[D] == 0 ? score_term(c.S, slot_root(E, D), c.in_start, st) : 0.0;
+        c.tclose[D] = score_term(c.S, slot_close(E, D), en, c.in_end);
+    }
+    light_dfs<E, D + 1>(c, want_bits);
+}
+template <int E, int D>
 __device__ void light_dfs(LightCtx<E>& c, bool want_bits) {
     if constexpr (D == E) {
         light_leaf<E>(c, want_bits);
     } else {
-        const UnitDev& U = *c.U;
-        int r = -1;  // rank of the candidate among the contained spans of this endpoint = its row in the term table
-        for (int cx = c.lo[D]; cx <= c.hi[D]; cx++) {
-            const int64_t st = c.os[D][cx], en = c.oe[D][cx];
-            if (c.in_start > st || en > c.in_end) continue;
-            r++;
-            bool ok = true;
-#pragma unroll
-            for (int p = 0; p < D; p++)
-                if (((U.pred_mask[D] >> p) & 1) && c.xe[p] > st) ok = false;
-            if (!ok) continue;
-            c.x[D] = cx; c.xs[D] = st; c.xe[D] = en;
-            constexpr int Wt = light_tab_width<E>();
-            if (r < Wt) {
-                c.troot[D] = c.tab[(D * Wt + r) * 2 * c.tab_stride];
-                c.tclose[D] = c.tab[((D * Wt + r) * 2 + 1) * c.tab_stride];
-            } else {
-                c.troot[D] = U.npred[D] == 0 ? score_term(c.S, slot_root(E, D), c.in_start, st) : 0.0;
-                c.tclose[D] = score_term(c.S, slot_close(E, D), en, c.in_end);
+        constexpr int Wt = light_tab_width<E>();
+        const int ns = c.nst[D];
+        int cx = c.lo[D] - 1;
+        for (int r = 0;; r++) {   // (one call site below: the tree is instantiated once per level, not once per route to it)
+            int64_t st, en;
+            if (r < ns) {   // a staged candidate: from LDS
+                cx = c.lo[D] + (int)((c.cxo[D] >> (8 * r)) & 255ull);
+                st = c.in_start + c.so[(D * Wt + r) * 2 * c.tab_stride];
+                en = c.in_start + c.so[((D * Wt + r) * 2 + 1) * c.tab_stride];
+            } else {        // the window may hold more contained spans than the table: the rest as they lie in global memory
+                if (ns < Wt) break;
+                bool found = false;
+                for (cx = cx + 1; cx <= c.hi[D]; cx++) {
+                    st = c.os[D][cx]; en = c.oe[D][cx];
+                    if (!(c.in_start > st || en > c.in_end)) { found = true; break; }
+                }
+                if (!found) break;
             }
-            light_dfs<E, D + 1>(c, want_bits);
+            light_visit<E, D>(c, want_bits, cx, st, en, r);
         }
     }
 }
@@ -703,7 +729,9 @@ __global__ void __launch_bounds__(kTile) k_classify(Dev P, int pass, const int32
         // most likely be enumerated again as a whole (millisecond-granular traces: nearly always)
         if (twins && !P.split_twins) first_cands = 0;
     }
-    const bool heavy = heavy_append<E>(P, prod > kLightMax, narrow, prod > kBigProduct, T.unit, i, prod, U.skip ? 0 : first_cands);
+    // (the per-thread kernel stages its candidates as 32-bit offsets from in_start: a span longer than that is not for it)
+    const bool long_span = c.in_end - c.in_start >= (1ll << 31) || c.in_end < c.in_start;
+    const bool heavy = heavy_append<E>(P, prod > kLightMax || (long_span && !empty), narrow, prod > kBigProduct, T.unit, i, prod, U.skip ? 0 : first_cands);
     P.span_cls[U.in_off + i] = heavy ? 1 : 0;
 }
 
@@ -773,8 +801,12 @@ __global__ void __launch_bounds__(kTile) TW_LIGHT_ATTR k_enumerate_light(Dev P, 
         constexpr int NC = Wt > 0 ? E * Wt * 2 : 1;   // cells per thread
         static_assert(NC <= 64, "a thread's cells are counted in one 64-bit mask");
         __shared__ double tab[NC * kTile];
+        __shared__ int32_t sotab[NC * kTile];
         c.tab = tab + threadIdx.x;
+        c.so = sotab + threadIdx.x;
         c.tab_stride = blockDim.x;
+#pragma unroll
+        for (int e = 0; e < E; e++) { c.cxo[e] = 0; c.nst[e] = 0; }
         if (!dense) {
             if (!empty) {
 #pragma unroll
@@ -785,8 +817,12 @@ __global__ void __launch_bounds__(kTile) TW_LIGHT_ATTR k_enumerate_light(Dev P, 
                         if (c.in_start > st || en > c.in_end) continue;
                         c.tab[(e * Wt + r) * 2 * c.tab_stride] = U.npred[e] == 0 ? score_term(c.S, slot_root(E, e), c.in_start, st) : 0.0;
                         c.tab[((e * Wt + r) * 2 + 1) * c.tab_stride] = score_term(c.S, slot_close(E, e), en, c.in_end);
+                        c.so[(e * Wt + r) * 2 * c.tab_stride] = (int32_t)(st - c.in_start);
+                        c.so[((e * Wt + r) * 2 + 1) * c.tab_stride] = (int32_t)(en - c.in_start);
+                        c.cxo[e] |= (uint64_t)(cx - c.lo[e]) << (8 * r);
                         r++;
                     }
+                    c.nst[e] = r;
                 }
             }
         } else if constexpr (Wt > 0) {
@@ -810,8 +846,12 @@ __global__ void __launch_bounds__(kTile) TW_LIGHT_ATTR k_enumerate_light(Dev P, 
                         else c.tab[cell * c.tab_stride] = 0.0;
                         c.tab[(cell + 1) * c.tab_stride] = (double)(c.in_end - en);
                         used |= 1ull << (cell + 1);
+                        c.so[cell * c.tab_stride] = (int32_t)(st - c.in_start);
+                        c.so[(cell + 1) * c.tab_stride] = (int32_t)(en - c.in_start);
+                        c.cxo[e] |= (uint64_t)(cx - c.lo[e]) << (8 * r);
                         r++;
                     }
+                    c.nst[e] = r;
                 }
             }
             wave_sync();
