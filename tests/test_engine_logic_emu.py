@@ -280,3 +280,24 @@ def test_split_service_with_windows_at_the_size_cap(emu_lib, seed, shape, conc):
     stitched = np.concatenate([ra["parent"], np.where(rb["parent"] >= 0, rb["parent"] + 200, -1)], axis=1)
     assert np.array_equal(stitched, whole["parent"])
     assert np.array_equal(np.concatenate([ra["leaves"], rb["leaves"]]), whole["leaves"])
+
+
+@pytest.mark.parametrize("case", [(71, 57, "chain3", 2.0, 1), (72, 129, "par4", 1.5, 1), (73, 100, "single", 4.0, 1000)])
+def test_requests_longer_than_32_bit_offsets(emu_lib, case):
+    """k_enumerate_light stages a request's candidates as 32-bit offsets from its start; a request of 2^31 time units or
+    more must not reach it (k_classify hands it to the wavefront kernel).  Every timestamp of a stress unit times 5e6 --
+    requests of a few hundred microseconds become longer than 2^31 -- and a unit in which only the last request is that
+    long: bit-identical to the oracle either way."""
+    from traceweaver_amd import synth
+    from traceweaver_amd.engine import UnitArrays
+
+    if case[2] not in synth.SHAPES:
+        pytest.skip("shape %s not defined" % case[2])
+    (u,), _ = parity.stress_units([case])
+    k = 5000000
+    scaled = UnitArrays(u.in_start * k, u.in_end * k, u.out_off, u.out_start * k, u.out_end * k, u.dag, u.key_rank)
+    assert ((scaled.in_end - scaled.in_start) >= 2 ** 31).any()
+    in_end = u.in_end.copy()
+    in_end[-1] += 3 * 10 ** 9
+    tail = UnitArrays(u.in_start, in_end, u.out_off, u.out_start, u.out_end, u.dag, u.key_rank)
+    parity.check_units(emu_lib, [scaled, tail, u])

@@ -71,6 +71,23 @@ def test_stress_units():
     assert sum(r["repaired_windows"] for r in r1) > 0
 
 
+def test_requests_longer_than_32_bit_offsets():
+    """The per-thread enumeration kernel stages candidates as 32-bit offsets from the request's start: requests of 2^31 time
+    units or more go to the wavefront kernel (production thresholds here; tests/test_engine_logic_emu.py has the emulated twin)."""
+    from traceweaver_amd.engine import UnitArrays
+
+    units = []
+    for case in [(71, 600, "chain3", 2.0, 1), (72, 1200, "par4", 1.5, 1), (73, 900, "single", 4.0, 1000)]:
+        (u,), _ = parity.stress_units([case])
+        k = 5000000
+        units.append(UnitArrays(u.in_start * k, u.in_end * k, u.out_off, u.out_start * k, u.out_end * k, u.dag, u.key_rank))
+        in_end = u.in_end.copy()
+        in_end[-1] += 3 * 10 ** 9
+        units.append(UnitArrays(u.in_start, in_end, u.out_off, u.out_start, u.out_end, u.dag, u.key_rank))
+        units.append(u)
+    parity.check_units(None, units)
+
+
 def test_heavier_stress_units():
     cases = [(21, 3000, "chain3", 6, 1), (22, 3000, "par2", 8, 1000), (23, 2000, "diamond", 4, 1),
              (24, 5000, "single", 12, 1), (25, 1500, "par4", 2.5, 1), (26, 4000, "chain2", 10, 1000)]
