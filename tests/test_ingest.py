@@ -360,3 +360,85 @@ def test_scanner_escapes_numbers_and_duplicates(emu_lib, tmp_path):
     counts = c.add_files([str(bad)], first_span=None, max_traces=0)
     assert counts["files_rejected"] == 1 and "bad escape" in c.first_error()
     c.close()
+
+
+def _same_corpus(a, b):
+    ua, sa, na = a.units()
+    ub, sb, nb = b.units()
+    assert sa == sb and na == nb and len(ua) == len(ub)
+    assert {k: v for k, v in a.counts().items() if k != "strings"} == {k: v for k, v in b.counts().items() if k != "strings"}   # (a live corpus interns names as they are asked for)
+    for x, y in zip(ua, ub):
+        assert (x.service, x.in_ep, x.out_eps, x.process_id) == (y.service, y.in_ep, y.out_eps, y.process_id)
+        for k in ("in_start", "in_end", "out_off", "out_start", "out_end", "dag", "key_rank"):
+            assert np.array_equal(getattr(x.arrays, k), getattr(y.arrays, k)), k
+        assert np.array_equal(x.true_parent, y.true_parent) and np.array_equal(x.in_trace, y.in_trace) and np.array_equal(x.in_rows, y.in_rows)
+        assert all(np.array_equal(p, q) for p, q in zip(x.out_rows, y.out_rows))
+    ta, tb = a.span_table(), b.span_table()
+    assert all(np.array_equal(ta[k], tb[k]) for k in ta)
+    assert np.array_equal(a.trace_names(), b.trace_names())
+    for col in ("span_id", "service", "op_name"):
+        for h in np.unique(ta[col])[:200]:
+            assert a.string(h) == b.string(h)
+    for h in a.trace_names():
+        assert a.string(h) == b.string(h)
+    assert a.string(-5) is None and b.string(-5) is None
+
+
+@pytest.mark.parametrize("kind", ["hotel", "alibaba"])
+def test_span_table_cache_of_a_directory(emu_lib, tmp_path, kind):
+    """ingest.open_directory: the second load of a directory starts from the cache file the first one left
+    in it and offers exactly the same corpus; --clear_cache, other arguments, a changed directory or a broken file mean a
+    fresh load."""
+    from traceweaver_amd import ingest
+
+    d = str(tmp_path)
+    if kind == "alibaba":
+        synth.write_alibaba_corpus(d, 5, 300, concurrency=1.5)
+        kw = dict(first_span=None, max_traces=0, fix="rpc_twins")
+    else:
+        synth.write_jaeger_corpus(d, 5, 300, app=synth.HOTEL_APP)
+        kw = dict(first_span=synth.HOTEL_APP["root_op"], max_traces=0, fix=None)
+    fresh, counts = ingest.open_directory(d, lib_path=emu_lib, **kw)
+    assert not fresh.from_cache and os.path.exists(os.path.join(d, ingest.CACHE_FILE)) and counts["traces"] > 0
+    again, counts2 = ingest.open_directory(d, lib_path=emu_lib, **kw)
+    assert again.from_cache and counts2 == counts
+    _same_corpus(fresh, again)
+    if kind == "alibaba":
+        loops = [u.service for u in fresh.units()[0] if u.service.endswith("-loop")]
+        for sv in loops + ["no-such-service"]:
+            assert fresh.loop_origin(sv) == again.loop_origin(sv)
+    # a miss: other arguments / cache not wanted / cleared / a trace removed / a damaged file
+    assert not ingest.open_directory(d, lib_path=emu_lib, **dict(kw, max_traces=7))[0].from_cache
+    assert not ingest.open_directory(d, lib_path=emu_lib, cache=False, **dict(kw, max_traces=7))[0].from_cache
+    assert ingest.open_directory(d, lib_path=emu_lib, **dict(kw, max_traces=7))[0].from_cache
+    assert not ingest.open_directory(d, lib_path=emu_lib, clear_cache=True, **kw)[0].from_cache
+    assert ingest.open_directory(d, lib_path=emu_lib, **kw)[0].from_cache
+    victim = sorted(f for f in os.listdir(d) if f.endswith("json"))[0]
+    os.remove(os.path.join(d, victim))
+    smaller, counts3 = ingest.open_directory(d, lib_path=emu_lib, **kw)
+    assert not smaller.from_cache and counts3["files"] == counts["files"] - 1
+    with open(os.path.join(d, ingest.CACHE_FILE), "r+b") as f:
+        f.truncate(100)
+    assert not ingest.open_directory(d, lib_path=emu_lib, **kw)[0].from_cache
+    assert ingest.open_directory(d, lib_path=emu_lib, **kw)[0].from_cache
+
+
+def test_command_line_from_the_span_table_cache(emu_lib, tmp_path):
+    """`--span_cache 1`: the second run of the command line starts from the directory's cache and writes the same result files."""
+    import pickle
+
+    from traceweaver_amd import executor, ingest
+
+    data = tmp_path / "data"
+    data.mkdir()
+    synth.write_jaeger_corpus(str(data), 5, 400, app=synth.HOTEL_APP, concurrency=2.0)
+    runs = []
+    for k in range(2):
+        out = str(tmp_path / ("out%d" % k)) + "/"
+        executor.main(["--absolute_path", str(data), "--compressed", "0", "--cache_rate", "0", "--fix", "2", "--test_name", "t",
+                       "--load_level", "100", "--results_directory", out, "--predictor_indices", "3,4,7,10", "--span_cache", "1",
+                       "--engine_library", emu_lib])
+        runs.append({f: pickle.load(open(out + f, "rb")) for f in sorted(os.listdir(out)) if f.endswith(".pickle")})
+    assert os.path.exists(str(data / ingest.CACHE_FILE))
+    assert runs[0].keys() == runs[1].keys() and len(runs[0]) >= 5
+    assert pickle.dumps(runs[0]) == pickle.dumps(runs[1])

@@ -71,6 +71,10 @@ def parse_args(argv=None):
     ap.add_argument("--max_traces", type=int, default=1001, help="the reference's literal limit (executor.py:873); 0 = all")
     ap.add_argument("--replicas_file", type=q, default=None,
                     help="pickle {service: [replica ids]} for --compress_factor > 1 (default: data/misc/service_to_replica_new.pickle under --project_root, executor.py:912)")
+    ap.add_argument("--span_cache", type=int, default=0, choices=[0, 1],
+                    help="1: keep the parsed span table of the trace directory in it (tw_span_table.bin) and start from it next time; "
+                         "--clear_cache 1 rebuilds it, as it does the reference's file-order cache.  Off by default: it writes into "
+                         "the data directory")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--fit", default="device", choices=["device", "device-batch", "sklearn"],
                     help="mixture refit between the passes: the reference's procedure (traceweaver_v3.py:764-786) in every case.  'device' "
@@ -142,18 +146,21 @@ def scale_load(units, args, trace_id, corpus):
 def run(args):
     from . import baselines
     from .engine import Engine, EngineError
-    from .ingest import Corpus, REFERENCE_FIX
+    from .ingest import REFERENCE_FIX, open_directory
 
     if args.fix not in REFERENCE_FIX:
         raise SystemExit("--fix %d is not one of the reference's values 0..5" % args.fix)
     first_span, surgery = REFERENCE_FIX[args.fix]
     directory = args.absolute_path.rstrip("\\") if args.absolute_path else os.path.join(args.project_root, args.relative_path)
     t0 = time.time()
-    corpus = Corpus(lib_path=args.engine_library)
-    counts = corpus.add_directory(directory, first_span=first_span, max_traces=args.max_traces, fix=surgery)
+    # the span table of the directory is kept next to the reference's own time_order_filenames.pickle, under the same rule:
+    # trusted until --clear_cache 1 (executor.py:320-339; ingest.open_directory has the guard it adds)
+    corpus, counts = open_directory(directory, lib_path=args.engine_library, first_span=first_span, max_traces=args.max_traces, fix=surgery,
+                                    cache=bool(args.span_cache), clear_cache=bool(args.clear_cache))
     units, skipped, n_traces = corpus.units()
-    print("Loaded %d traces, %d spans in %.2f s (%d files rejected, %d traces filtered); %d services to solve, left out: %s"
-          % (counts["traces"], counts["spans"], time.time() - t0, counts["files_rejected"], counts["traces_filtered"], len(units), skipped))
+    print("Loaded %d traces, %d spans in %.2f s%s (%d files rejected, %d traces filtered); %d services to solve, left out: %s"
+          % (counts["traces"], counts["spans"], time.time() - t0, " from the directory's span table cache" if corpus.from_cache else "",
+             counts["files_rejected"], counts["traces_filtered"], len(units), skipped))
     if not units:
         raise SystemExit("no service of this corpus can be solved (see the counts above)")
     # `several_callers` is a skip the reference performs itself (executor.py:1126-1128).  A service in which some request

@@ -4,6 +4,7 @@ Mirrors what the reference's executor does between reading a trace directory and
 (executor.py:287-339,755-849,1080-1135) for corpora that need no span rewriting; see include/traceweaver_amd.h.
 """
 import ctypes
+import json
 import os
 
 import numpy as np
@@ -136,6 +137,7 @@ class Corpus(object):
                 return np.zeros(0, dtype=dtype)
             return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(count,)).copy()
 
+        self._last_unit_set = None
         in_off = view(us.unit_in_off, n + 1, np.int64)
         E = view(us.unit_E, n, np.int32)
         n_ep = int(E.sum())
@@ -163,4 +165,182 @@ class Corpus(object):
             d0 += e * e
             t0 += e * (b - a)
         skipped = dict(zip(("several_callers", "skip_mode", "too_small", "cyclic_order"), (int(x) for x in us.skipped)))
+        self._last_unit_set = {"in_off": in_off, "E": E, "ep_off": ep_off, "dag": dag, "key_rank": key_rank, "in_start": in_start, "in_end": in_end,
+                               "out_start": out_start, "out_end": out_end, "truth": truth, "in_trace": in_trace, "in_row": in_row, "out_row": out_row,
+                               "order": order, "_units": out, "_skipped": skipped, "_n_traces": int(us.n_traces)}
         return out, skipped, int(us.n_traces)
+
+    def _unit_set_arrays(self):
+        """The flat arrays units() was built from (what the directory cache stores)."""
+        self.units()
+        return dict(self._last_unit_set)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The span table of a directory, kept next to its traces (SURVEY.md 8 f1: "a one-time binary cache next to
+# time_order_filenames.pickle").  The reference keeps the time-ordered file list of a directory in a pickle inside it and
+# trusts it until --clear_cache 1 (executor.py:320-339); this cache holds what the native loader made of the files -- span
+# table, units, the strings results are keyed by -- under the same rule, plus a cheap guard: loader version and sources,
+# the arguments of the load and the directory's modification time (entries added, removed or renamed; a file rewritten in
+# place is not seen -- that is what --clear_cache is for).  A hit replaces reading and parsing every JSON file.
+CACHE_FILE = "tw_span_table.bin"
+CACHE_VERSION = 1
+_UNIT_ARRAYS = ("in_off", "E", "ep_off", "dag", "key_rank", "in_start", "in_end", "out_start", "out_end", "truth", "in_trace", "in_row", "out_row", "order")
+_TABLE_COLUMNS = ("trace", "span_id", "service", "op_name", "parent", "start", "duration", "kind")
+
+
+def _cache_key(directory, first_span, max_traces, fix, callers):
+    from . import build
+
+    return json.dumps({"version": CACHE_VERSION, "loader": build.source_digest(), "dir_mtime_ns": os.stat(directory).st_mtime_ns,
+                       "first_span": first_span, "max_traces": int(max_traces), "fix": fix,
+                       "callers": sorted((NODEJS_CALLERS if callers is None else callers).items()) if fix == "client_twins" else None}, sort_keys=True)
+
+
+_CACHE_MAGIC = b"TWSPANS1"
+
+
+def _write_arrays(path, header, arrays):
+    """One file: magic, length of the JSON header, the header (with every array's dtype, shape and offset), then the arrays
+    on 64-byte boundaries -- read back as views of one memory map, nothing is copied or checksummed."""
+    directory, at = {}, 0
+    for name, a in arrays.items():
+        a = np.ascontiguousarray(a)
+        arrays[name] = a
+        directory[name] = (a.dtype.str, list(a.shape), at)
+        at += (a.nbytes + 63) // 64 * 64
+    head = json.dumps(dict(header, arrays=directory)).encode()
+    pad = (-(len(_CACHE_MAGIC) + 8 + len(head))) % 64
+    with open(path, "wb") as f:
+        f.write(_CACHE_MAGIC + np.uint64(len(head) + pad).tobytes() + head + b" " * pad)
+        for name, a in arrays.items():
+            f.write(a.tobytes())
+            f.write(b"\0" * ((-a.nbytes) % 64))
+
+
+def _read_arrays(path):
+    import mmap
+
+    with open(path, "rb") as f:
+        m = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+    if m[:8] != _CACHE_MAGIC:
+        raise ValueError("not a span table cache")
+    n = int(np.frombuffer(m, dtype=np.uint64, count=1, offset=8)[0])
+    header = json.loads(m[16:16 + n].decode())
+    base = 16 + n
+    arrays = {}
+    for name, (dtype, shape, off) in header.pop("arrays").items():
+        count = int(np.prod(shape)) if shape else 1
+        arrays[name] = np.frombuffer(m, dtype=np.dtype(dtype), count=count, offset=base + off).reshape(shape)
+    return header, arrays
+
+
+class CachedCorpus(object):
+    """What Corpus offers after add_directory(), read back from the directory's cache file (read-only views of it)."""
+
+    def __init__(self, meta, z):
+        self._counts, self._skipped, self._n_traces = meta["counts"], meta["skipped"], meta["n_traces"]
+        self._unit_names, self._loop_origin = meta["unit_names"], meta["loop_origin"]
+        self._units = {k: z["u_" + k] for k in _UNIT_ARRAYS}
+        self._table = {k: z["t_" + k] for k in _TABLE_COLUMNS}
+        self._trace_names = z["trace_names"]
+        self._handles, self._str_off, self._str_blob = z["str_handle"], z["str_off"], z["str_blob"]
+        self.from_cache = True
+
+    def close(self):
+        pass
+
+    def counts(self):
+        return dict(self._counts)
+
+    def first_error(self):
+        return ""
+
+    def string(self, idx):
+        k = int(np.searchsorted(self._handles, idx))
+        if k >= len(self._handles) or self._handles[k] != idx:
+            return None
+        return self._str_blob[int(self._str_off[k]):int(self._str_off[k + 1])].tobytes().decode()
+
+    def loop_origin(self, service):
+        return self._loop_origin.get(service)
+
+    def trace_names(self):
+        return self._trace_names
+
+    def span_table(self):
+        return dict(self._table)
+
+    def units(self):
+        a = self._units
+        in_off, E, ep_off = a["in_off"], a["E"], a["ep_off"]
+        out, ep0, d0, t0 = [], 0, 0, 0
+        for u in range(len(E)):
+            e, lo, hi = int(E[u]), int(in_off[u]), int(in_off[u + 1])
+            o0, o1 = int(ep_off[ep0]), int(ep_off[ep0 + e])
+            arrays = UnitArrays(a["in_start"][lo:hi], a["in_end"][lo:hi], ep_off[ep0:ep0 + e + 1] - o0, a["out_start"][o0:o1], a["out_end"][o0:o1],
+                                a["dag"][d0:d0 + e * e].reshape(e, e), a["key_rank"][ep0:ep0 + e])
+            rows = [a["out_row"][int(ep_off[ep0 + k]):int(ep_off[ep0 + k + 1])] for k in range(e)]
+            service, in_ep, out_eps = self._unit_names[u]
+            out.append(IngestedUnit(arrays, a["truth"][t0:t0 + e * (hi - lo)].reshape(e, hi - lo), a["in_trace"][lo:hi], service, in_ep, list(out_eps),
+                                    a["in_row"][lo:hi], rows, int(a["order"][u])))
+            ep0 += e
+            d0 += e * e
+            t0 += e * (hi - lo)
+        return out, dict(self._skipped), int(self._n_traces)
+
+
+def _save_cache(corpus, directory, key_args, counts):
+    """Writes the cache of a freshly loaded directory.  The file is created first and the key taken afterwards: creating it is
+    what changes the directory's modification time, rewriting it does not."""
+    path = os.path.join(directory, CACHE_FILE)
+    open(path, "ab").close()
+    key = _cache_key(directory, *key_args)
+    raw = corpus._unit_set_arrays()
+    table = corpus.span_table()
+    names = corpus.trace_names()
+    units, skipped, n_traces = raw.pop("_units"), raw.pop("_skipped"), raw.pop("_n_traces")
+    handles = np.unique(np.concatenate([table["span_id"], table["service"], table["op_name"], names]).astype(np.int64))
+    strings = [corpus.string(h) for h in handles]
+    keep = np.array([x is not None for x in strings], dtype=bool)
+    handles, strings = handles[keep], [x.encode() for x in strings if x is not None]
+    off = np.zeros(len(strings) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in strings], out=off[1:])
+    services = sorted({u.service for u in units} | {corpus.string(h) for h in np.unique(table["service"]) if corpus.string(h) is not None})
+    loops = {sv: corpus.loop_origin(sv) for sv in services}
+    header = {"key": key, "counts": counts, "skipped": skipped, "n_traces": n_traces,
+              "unit_names": [(u.service, u.in_ep, list(u.out_eps)) for u in units], "loop_origin": {k: v for k, v in loops.items() if v is not None}}
+    arrays = {"trace_names": names, "str_handle": handles, "str_off": off, "str_blob": np.frombuffer(b"".join(strings), dtype=np.uint8)}
+    arrays.update({"u_" + k: raw[k] for k in _UNIT_ARRAYS})
+    arrays.update({"t_" + k: table[k] for k in _TABLE_COLUMNS})
+    _write_arrays(path, header, arrays)
+
+
+def open_directory(directory, lib_path=None, first_span=None, max_traces=1001, fix=None, callers=None, threads=0, cache=True, clear_cache=False):
+    """The traces of a directory as a corpus: from its cache file when there is a valid one (and `cache` / not `clear_cache`),
+    otherwise through the native loader -- which then leaves the cache behind (silently not, in a read-only directory).
+    Returns (Corpus or CachedCorpus, counts)."""
+    path = os.path.join(directory, CACHE_FILE)
+    key_args = (first_span, max_traces, fix, callers)
+    if clear_cache and os.path.exists(path):
+        try:
+            os.remove(path)
+        except OSError:
+            cache = False
+    if cache and os.path.exists(path):
+        try:
+            meta, z = _read_arrays(path)
+            if meta.get("key") == _cache_key(directory, *key_args):
+                c = CachedCorpus(meta, z)
+                return c, c.counts()
+        except Exception:   # unreadable / incomplete / written by another version: a miss
+            pass
+    corpus = Corpus(lib_path=lib_path)
+    counts = corpus.add_directory(directory, first_span=first_span, max_traces=max_traces, fix=fix, callers=callers, threads=threads)
+    corpus.from_cache = False
+    if cache:
+        try:
+            _save_cache(corpus, directory, key_args, counts)
+        except OSError:
+            pass
+    return corpus, counts
