@@ -268,8 +268,10 @@ void launch_enumerate_all(tw_engine* e, int pass, int mode) {
     bool used = false;
     // (the frontier cursors were reset with the counter block of the pass / the repair round)
     (void)hipEventRecord(e->cls_ev[0], e->stream);
-    launch_enumerate<1>(e, pass, mode, used); launch_enumerate<2>(e, pass, mode, used); launch_enumerate<3>(e, pass, mode, used); launch_enumerate<4>(e, pass, mode, used);
-    launch_enumerate<5>(e, pass, mode, used); launch_enumerate<6>(e, pass, mode, used); launch_enumerate<7>(e, pass, mode, used); launch_enumerate<8>(e, pass, mode, used);
+    // the classes with the most endpoints first: their enumerations are the longest and end the group (each class runs on a
+    // stream of its own; what is launched first is dispatched first)
+    launch_enumerate<8>(e, pass, mode, used); launch_enumerate<7>(e, pass, mode, used); launch_enumerate<6>(e, pass, mode, used); launch_enumerate<5>(e, pass, mode, used);
+    launch_enumerate<4>(e, pass, mode, used); launch_enumerate<3>(e, pass, mode, used); launch_enumerate<2>(e, pass, mode, used); launch_enumerate<1>(e, pass, mode, used);
 }
 
 // The listed windows: those of up to kBruteMax spans (nearly all of them) by k_select_tiny, whose workgroups hold 1 KB of LDS
