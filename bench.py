@@ -53,6 +53,9 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# hardware queues for the engine's class streams (traceweaver_amd/csrc/tw_engine.hip, tw_create): set before torch or the engine
+# initialise HIP; the ranks of `--gpus N` inherit it
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALG_BYTES_PER_SPAN_PER_PASS = 20  # 16 B read (start, end) + 4 B parent index written

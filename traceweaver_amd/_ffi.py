@@ -73,6 +73,9 @@ EXPORTS = ["tw_create", "tw_destroy", "tw_last_error", "tw_load_batch", "tw_run_
 
 def load(path=None):
     path = path or DEFAULT_LIB
+    # hardware queues for the engine's class streams (tw_create has the measurements); read by the HIP runtime when it
+    # initialises, which in a process that also holds torch is at its first device call -- normally after this import
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
     if not os.path.exists(path):
         raise ImportError(
             "traceweaver_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "

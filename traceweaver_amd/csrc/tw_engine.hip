@@ -627,6 +627,13 @@ int tw_create(int device_id, tw_engine** out) {
     e->device = device_id;
     e->tile = std::min(std::max(env_int("TW_TILE", kTile), 1), kTile);
     e->coop = std::min(std::max(env_int("TW_COOP_THREADS", kCoop), 1), kCoop);
+    // The engine runs its endpoint-count classes and window classes on streams of their own (up to 8 + 3 beside its own).  The
+    // runtime multiplexes a process' streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default: classes that share a queue run one
+    // after the other (Alibaba-shape slice, eight classes: 9.5 / 11.2 ms per pass with 4 or 8 queues, 6.3 / 7.0 ms with 12 or 16;
+    // three classes: the same either way).  The variable is read when the runtime initialises: this takes effect if the engine is
+    // the first user of HIP in the process (command line, C callers) -- a host that initialises HIP earlier exports it itself
+    // (traceweaver_amd/_ffi.py and bench.py do, before anything touches the device).
+    setenv("GPU_MAX_HW_QUEUES", "12", 0);
     hipError_t s = hipSetDevice(device_id);
     if (s == hipSuccess) s = hipStreamCreate(&e->stream);
     for (int i = 0; i < EV_COUNT && s == hipSuccess; i++) s = hipEventCreate(&e->ev[i]);
