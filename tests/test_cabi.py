@@ -64,3 +64,17 @@ def test_ctypes_structures_match_the_header(tmp_path):
         cls = getattr(_ffi, fields[c_name][0])
         assert ctypes.sizeof(cls) == int(size), c_name
         assert [getattr(cls, f).offset for f in fields[c_name][1]] == [int(o) for o in offs], c_name
+
+
+def test_loading_the_library_asks_for_hardware_queues(monkeypatch):
+    """The engine's class streams need hardware queues of their own (csrc/tw_engine.hip, tw_create): loading the library exports
+    GPU_MAX_HW_QUEUES unless the user chose a value."""
+    from traceweaver_amd import _ffi, build
+
+    path = build.build()
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    _ffi.load(path)
+    assert os.environ.get("GPU_MAX_HW_QUEUES") == "12"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")
+    _ffi.load(path)
+    assert os.environ.get("GPU_MAX_HW_QUEUES") == "6"
