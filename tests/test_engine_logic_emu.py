@@ -189,6 +189,30 @@ def test_lane_threaded_emulation(emu_lib):
     assert out.returncode == 0 and "lanes ok" in out.stdout, out.stderr[-2000:]
 
 
+def test_lane_threaded_tile_kernel_with_production_tables():
+    """k_enumerate_tile by 256 host threads per tile of 128 requests with the table sizes of the HIP build (slices of 192
+    outgoing spans, enumerations of up to 256 tuples by the workgroup): block-wide reductions and prefix sums, the slice
+    staging, items / tuples spread over the lanes, the rank counting, several segments per tile (par4 at concurrency 3:
+    more than 1536 tuples per tile), ordered and unordered call graphs, millisecond-granular ties -- against the oracle."""
+    import subprocess
+    import sys
+
+    from tests.hostemu.build_emu import build
+
+    code = (
+        "import sys, os\n"
+        "sys.path[:0] = [%r, %r, %r]\n"
+        "import parity\n"
+        "units, _ = parity.stress_units([(41, 300, 'par4', 3, 1), (42, 300, 'chain3', 3, 1), (43, 260, 'par2', 2, 1000), (44, 200, 'diamond', 2.5, 1), (45, 140, 'mix7', 1.5, 1)])\n"
+        "r1, r2, _ = parity.check_units(%r, units, allow_budget=True)\n"
+        "print('lanes ok')\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+         os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"), build(production=True))
+    env = dict(os.environ, TW_EMU_LANES="1", TW_TILE="128", TW_COOP_THREADS="256")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0 and "lanes ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_split_enumerations(emu_lib, monkeypatch):
     """Very long enumerations are cut into parts by the first endpoint's candidate and merged (k_merge_parts).  The
     host-emulation build splits from ~100 grid points on: units without call-order constraints (every grid point a

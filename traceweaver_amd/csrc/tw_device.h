@@ -238,6 +238,36 @@ __device__ inline double tw_exp(double x) {
     return with_hi(y, hi_word(y) + ((k + 1000) << 20)) * twom1000;
 }
 
+// exp(x) for x <= 0 (or NaN): the arithmetic of tw_exp with its case distinctions written as selects, so that a wavefront whose
+// lanes fall into different ranges runs one instruction stream (in the mixture terms of pass 2 every lane evaluates exp of another
+// argument; the branches of tw_exp then cost the sum of their paths).  Bit-identical to tw_exp on that domain: the reduction
+// k = (int)(invln2 * x - 0.5), hi = x - k * ln2HI, lo = k * ln2LO is what the k = -1 shortcut of e_exp.c computes too (-1 * ln2HI
+// and -1 * ln2LO are exact, and invln2 * x - 0.5 truncates to -1 on all of its range), and with k = 0 it leaves x unchanged.
+__device__ __forceinline__ double tw_exp_nonpos(double x) {
+    const double u_threshold = -7.45133219101941108420e+02,
+                 ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                 P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08,
+                 twom1000 = 9.33263618503218878990e-302;
+    const bool special = !(x >= u_threshold);   // below the underflow threshold, -inf or NaN
+    const double xs = special ? 0.0 : x;
+    const int32_t hx = hi_word(xs) & 0x7fffffff;
+    const int32_t k = hx > 0x3fd62e42 ? (int32_t)(invln2 * xs - 0.5) : 0;
+    const double t = (double)k;
+    const double hi = xs - t * ln2HI, lo = t * ln2LO;
+    const double xr = hi - lo;
+    const double t2 = xr * xr;
+    const double c = xr - t2 * (P1 + t2 * (P2 + t2 * (P3 + t2 * (P4 + t2 * P5))));
+    const double q = (xr * c) / (k == 0 ? c - 2.0 : 2.0 - c);
+    const double r0 = 1.0 - (q - xr);
+    const double y = 1.0 - ((lo - q) - hi);
+    const double ys = with_hi(y, hi_word(y) + ((k >= -1021 ? k : k + 1000) << 20));
+    double r = k == 0 ? r0 : (k >= -1021 ? ys : ys * twom1000);
+    r = hx < 0x3e300000 ? 1.0 + xs : r;
+    return special ? (x != x ? x + x : 0.0) : r;
+}
+
 __device__ inline double tw_log1p(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  two54 = 1.80143985094819840000e+16, Lp1 = 6.666666666666735130e-01,

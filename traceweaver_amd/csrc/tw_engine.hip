@@ -76,6 +76,7 @@ struct tw_engine {
     std::string err;
     int state = ST_EMPTY;
     int tile = kTile;   // incoming spans (threads) per workgroup of the per-span kernels
+    int tile_threads = 2; // threads per incoming span of k_enumerate_tile (its items and tuples are spread over all of them)
     int coop = kCoop;   // threads of the per-unit cooperative kernels
     std::vector<UnitDev> units;
     std::vector<TileDev> tiles;
@@ -255,8 +256,7 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
         // cut-offs and work lists, the per-thread kernel, the wavefront kernels (which also take the few spans the per-thread kernel
         // hands over).  Running the last two side by side was measured (second stream of higher priority, i.e. another hardware
         // queue): the kernels do overlap, the class does not finish earlier -- together they saturate the LDS and issue slots
-        hipLaunchKernelGGL((k_classify<E>), dim3(nt), dim3(e->tile), 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
-        hipLaunchKernelGGL((k_enumerate_light<E>), dim3(nt), dim3(e->tile), 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
+        hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt), dim3(e->tile >= 64 ? e->tile * e->tile_threads : e->tile), 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
     }
     wavefront_kernels(st);
     (void)hipEventRecord(e->cls_ev[E], st);
@@ -626,6 +626,7 @@ int tw_create(int device_id, tw_engine** out) {
     tw_engine* e = new tw_engine();
     e->device = device_id;
     e->tile = std::min(std::max(env_int("TW_TILE", kTile), 1), kTile);
+    e->tile_threads = std::min(std::max(env_int("TW_TILE_THREADS", 2), 1), 4);
     e->coop = std::min(std::max(env_int("TW_COOP_THREADS", kCoop), 1), kCoop);
     // The engine runs its endpoint-count classes and window classes on streams of their own (up to 8 + 3 beside its own).  The
     // runtime multiplexes a process' streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default: classes that share a queue run one

@@ -308,7 +308,7 @@ __device__ __noinline__ double term_mix(int n, const double* c, double x) {
     double m = 0.0, s = 0.0;  // scipy.special.logsumexp: max split out, log1p of the rest
     for (int k = 0; k < n; k++) {   // (left to the compiler's unroller: rolled, the five values cost 4 more VGPRs and one wave of occupancy in three kernels)
         const double ak = k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : (k == 3 ? a3 : a4)));
-        if (ak == amax) m += 1.0; else s += tw_exp(ak - amax);   // adding the 0.0 of a maximal component changes nothing: s >= +0.0
+        if (ak == amax) m += 1.0; else s += tw_exp_nonpos(ak - amax);   // adding the 0.0 of a maximal component changes nothing: s >= +0.0
     }
     if (s != 0.0) s = s / m;
     return (tw_log1p(s) + (m == 1.0 ? 0.0 : tw_log(m))) + amax;  // log(1.0) is exactly 0.0
@@ -2906,3 +2906,5 @@ __global__ void k_gaps(Dev P) {
 }
 
 }  // namespace tw
+
+#include "tw_tile.h"
