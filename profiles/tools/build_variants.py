@@ -14,16 +14,13 @@ sys.path.insert(0, REPO)
 from traceweaver_amd import build as B  # noqa: E402
 
 WPE = lambda n: "__attribute__((amdgpu_waves_per_eu(%d)))" % n  # noqa: E731
-SMALL_TAB = "((E)==1?0:(E)==2?4:(E)==3?3:(E)==4?2:2)"
-MID_TAB = "((E)==1?0:(E)==2?6:(E)==3?4:(E)==4?3:2)"
 
 VARIANTS = {
     "base": [],
     "memo64": ["-DTW_MEMO_SLOTS=64"],
     "memo32": ["-DTW_MEMO_SLOTS=32"],
-    "light3": ["-DTW_LIGHT_ATTR=" + WPE(3), "-DTW_LIGHT_TABW(E)=" + MID_TAB],
-    "light4": ["-DTW_LIGHT_ATTR=" + WPE(4), "-DTW_LIGHT_TABW(E)=" + SMALL_TAB],
-    "light4reg": ["-DTW_LIGHT_ATTR=" + WPE(4)],
+    "tile_big": ["-DTW_TILE_ITEMS=1024", "-DTW_TILE_GRID=1536"],
+    "tile128": ["-DTW_TILE_MAX=128"],
     "heavy3": ["-DTW_HEAVY_ATTR=" + WPE(3)],
     "heavy4": ["-DTW_HEAVY_ATTR=" + WPE(4)],
 }

@@ -67,3 +67,13 @@ def assert_pass_equal(res, ora, end_flag, tag=""):
     assert res["not_best_count"] == ora["not_best_count"], tag + " not_best_count"
     assert res["cnt_unassigned"] == ora["cnt_unassigned"], tag + " cnt_unassigned"
     assert res["n_windows"] == ora["n_windows"], tag + " window count"
+
+
+def skip_tie_requests(name):
+    """Requests of a frozen skip-mode run (refskip_<...>__frontend) that lie in a window where the exact selection is proven a
+    near-tie of the frozen run's (tests/golden/skip_tie_windows.json, written by tests/golden/make_skip_tie_windows.py): only
+    there may the engine's assignment differ from the frozen run's."""
+    import json
+
+    with open(os.path.join(REPO, "tests", "golden", "skip_tie_windows.json")) as f:
+        return set(json.load(f)[name])

@@ -122,3 +122,47 @@ def assert_assignment_properties(u, par):
         for p in range(e):
             if u.dag[p, e]:
                 assert (u.out_end[u.out_off[p] + par[p][assigned]] <= s).all()
+
+
+def seeded_chain(lib_path, dataset, goldens, device=0):
+    """The whole seeded chain of one frozen reference run (tests/golden/ref_<dataset>__*.npz) through the predictor's
+    array route: numpy's global RNG seeded like the run, the services in the run's order (tests/golden/service_order.json),
+    per service pass 1 -> the reference's refit on the device, fed exactly the doubles numpy hands scikit-learn at that point
+    of the run (incl. the fits the reference discards and its reseeding at the service named "frontend") -> pass 2.
+    Yields (golden path, golden, pass-1 leaves, pass-2 result)."""
+    import json
+    import os
+
+    from traceweaver_amd import skipmode
+    from traceweaver_amd.predictor import TraceWeaverGPU
+
+    from conftest import unit_from_golden
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "service_order.json")) as fh:
+        order = json.load(fh)[dataset]
+    paths = {os.path.basename(p)[len("ref_%s__" % dataset):-4]: p for p in goldens if os.path.basename(p).startswith("ref_%s__" % dataset)}
+    assert sorted(paths) == sorted(order), (sorted(paths), order)
+    pred = TraceWeaverGPU({}, {}, device=device, fit="device", lib_path=lib_path)
+    out = []
+    seeded = False
+    for svc in order:
+        d = np.load(paths[svc])
+        if not seeded:
+            np.random.seed(int(d["seed"]))
+            seeded = True
+        _, unit = unit_from_golden(d)
+        if svc == "frontend":   # executor.py:1150-1152: create_cache_hits reseeds at every cache rate, also 0
+            skipmode.cache_hit_draws(unit.n_in, 0.0)
+        r1, r2 = pred.solve_arrays(unit, np.asarray(d["true_parent"]), svc)
+        out.append((paths[svc], d, r1, r2))
+    pred._engine.close()
+    return out
+
+
+def millisecond_granular(d):
+    """True for the frozen runs on millisecond-granular corpora (the nodejs applications).  There mixture components collapse
+    onto repeated sample values: the variance of such a component is reg_covar plus the rounding noise of its moments,
+    scikit-learn's own result depends on the summation order of its BLAS, and a fit may select another component count on
+    another machine.  The GPU tier then bounds how many requests of the second pass may differ."""
+    return bool((d["in_start"] % 1000 == 0).all() and (d["out_start"] % 1000 == 0).all() and (d["in_dur"] % 1000 == 0).all())

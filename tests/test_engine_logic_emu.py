@@ -308,8 +308,8 @@ def test_split_service_with_windows_at_the_size_cap(emu_lib, seed, shape, conc):
 
 @pytest.mark.parametrize("case", [(71, 57, "chain3", 2.0, 1), (72, 129, "par4", 1.5, 1), (73, 100, "single", 4.0, 1000)])
 def test_requests_longer_than_32_bit_offsets(emu_lib, case):
-    """k_enumerate_light stages a request's candidates as 32-bit offsets from its start; a request of 2^31 time units or
-    more must not reach it (k_classify hands it to the wavefront kernel).  Every timestamp of a stress unit times 5e6 --
+    """k_enumerate_tile stages a tile's candidates as 32-bit offsets from the tile's first start; a request of 2^31 time units or
+    more (or that far from the tile's first request) must not be enumerated by it (it goes to the wavefront kernel).  Every timestamp of a stress unit times 5e6 --
     requests of a few hundred microseconds become longer than 2^31 -- and a unit in which only the last request is that
     long: bit-identical to the oracle either way."""
     from traceweaver_amd import synth

@@ -2,7 +2,9 @@
 accuracy -> the reference's result files.  CPU tier through the host-emulation build; the figures are compared
 with the frozen reference run of the same corpus: the default refit (`--fit device --seed 10`) is the reference's
 procedure on the reference's RNG stream, so the run reproduces the frozen run (np.random.seed(10)) -- per service to
-the few requests whose window optimum is not unique, end to end to 0.25 pp."""
+the few requests whose window optimum is not unique, end to end to 0.1 pp (north_star's bar); only the millisecond-granular
+corpora (the nodejs applications: mixture components collapsed onto repeated sample values, whose fits depend on the summation
+order of scikit-learn's BLAS -- DESIGN.md 7) keep a band of 0.25 pp."""
 import os
 import pickle
 
@@ -12,6 +14,11 @@ import pytest
 from conftest import GOLDEN
 
 REF = "/root/reference"
+
+
+def e2e_band(name):
+    """Allowed distance of an end-to-end accuracy (percent) from the frozen reference run of corpus `name`."""
+    return (0.25 if name.startswith("node") else 0.1) + 1e-9
 
 
 def run_cli(tmp_path, emu_lib, rel, fix, name):
@@ -40,7 +47,7 @@ def test_hotel_run_matches_the_frozen_reference_run(emu_lib, tmp_path):
         ref_acc = float(np.all(g["final_parent"] == g["true_parent"], axis=0).mean())
         assert n == len(g["in_start"]) and abs(acc - ref_acc) <= 4.0 / n and abs(not_best - int(g["not_best_count"])) <= 4
     ref_e2e = float(gold["frontend"]["e2e_accuracy"])
-    assert abs(got["accuracy"][method] - ref_e2e) <= 0.25 and got["accuracy"][method + "TopK"] >= got["accuracy"][method]
+    assert abs(got["accuracy"][method] - ref_e2e) <= e2e_band("hotel_load100") and got["accuracy"][method + "TopK"] >= got["accuracy"][method]
     assert [p for p, _, _ in got["bin_acc"][method]] == [10.0 * (b + 1) for b in range(10)]
     true_traces, pred_traces = got["e2e"][method]
     assert len(true_traces) == len(pred_traces) == 1000
@@ -62,7 +69,7 @@ def test_corpora_that_need_span_surgery(emu_lib, tmp_path, name, rel, fix, n_ser
         ref_acc = float(np.all(g["final_parent"] == g["true_parent"], axis=0).mean())
         assert n == len(g["in_start"]) and abs(acc - ref_acc) <= 4.0 / n, (svc, acc, ref_acc)
     ref_e2e = float(next(iter(gold.values()))["e2e_accuracy"])
-    assert abs(got["accuracy"]["MaxScoreBatchSubsetWithSkips"] - ref_e2e) <= 0.25
+    assert abs(got["accuracy"]["MaxScoreBatchSubsetWithSkips"] - ref_e2e) <= e2e_band(name)
 
 
 def _all_corpora():
@@ -77,7 +84,7 @@ def test_end_to_end_accuracy_tracks_the_reference_on_every_corpus(emu_lib, tmp_p
     g = np.load([p for p in GOLDEN if "ref_%s__" % name in p][0])
     method = "MaxScoreBatchSubsetWithSkips"
     assert int(g["seed"]) == 10   # run_cli's default --seed
-    assert abs(got["accuracy"][method] - float(g["e2e_accuracy"])) <= 0.25
+    assert abs(got["accuracy"][method] - float(g["e2e_accuracy"])) <= e2e_band(name)
     assert abs(got["accuracy"][method + "TopK"] - float(g["e2e_topk_accuracy"])) <= 0.1
 
 
@@ -89,7 +96,7 @@ def test_fit_sklearn_reproduces_the_seeded_reference_run(emu_lib, tmp_path, name
     """--fit sklearn --seed 10 (the cross-check of the default): scikit-learn itself on the host where the device refit
     runs otherwise, the RNG stream replayed service by service -- the command line reproduces the frozen reference run
     (np.random.seed(10)) of the corpus: per-service accuracy to within the few requests whose window optimum is not unique,
-    end-to-end accuracy to +-0.25 pp (SURVEY.md hazard H9)."""
+    end-to-end accuracy to +-0.1 pp (+-0.25 pp on the millisecond-granular corpora; SURVEY.md hazard H9)."""
     from traceweaver_amd import executor
 
     out = str(tmp_path) + "/"
@@ -108,8 +115,8 @@ def test_fit_sklearn_reproduces_the_seeded_reference_run(emu_lib, tmp_path, name
         assert abs(a - ref) <= 4.0 / n, svc
     g0 = next(iter(gold.values()))
     method = "MaxScoreBatchSubsetWithSkips"
-    assert abs(acc[method] - float(g0["e2e_accuracy"])) <= 0.25
-    assert abs(acc[method + "TopK"] - float(g0["e2e_topk_accuracy"])) <= 0.25
+    assert abs(acc[method] - float(g0["e2e_accuracy"])) <= e2e_band(name)
+    assert abs(acc[method + "TopK"] - float(g0["e2e_topk_accuracy"])) <= e2e_band(name)
 
 
 def _band():
@@ -142,8 +149,8 @@ def test_seeded_runs_sit_in_the_references_multi_seed_band(emu_lib, tmp_path, na
     method = "MaxScoreBatchSubsetWithSkips"
     for fit in ("device", "sklearn") if seed_pos in (1, 3) else ("device",):
         acc = run(fit, band["seeds"][seed_pos])
-        assert abs(acc[method] - band["e2e"][seed_pos]) <= 0.25, fit
-        assert abs(acc[method + "TopK"] - band["e2e_topk"][seed_pos]) <= 0.25, fit
+        assert abs(acc[method] - band["e2e"][seed_pos]) <= e2e_band(name), fit
+        assert abs(acc[method + "TopK"] - band["e2e_topk"][seed_pos]) <= e2e_band(name), fit
     if seed_pos == 3:
         spread = max(band["e2e"]) - min(band["e2e"])
         dev = run("device-batch", 0)
@@ -182,7 +189,9 @@ def test_cache_hit_runs_of_exp2(emu_lib, tmp_path, rate):
     g = gold["frontend"]
     ref_acc = float(np.all(g["final_parent"] == g["true_parent"], axis=0).mean())
     assert abs(conf["frontend"][0] - ref_acc) <= 0.005 and conf["frontend"][2] == 1000
-    assert abs(conf["frontend"][1] - int(g["not_best_count"])) <= 20
+    from conftest import skip_tie_requests
+
+    assert abs(conf["frontend"][1] - int(g["not_best_count"])) <= len(skip_tie_requests("refskip_hotel_load150_c%s__frontend" % rate.replace(".", "p")))
     method = "MaxScoreBatchSubsetWithSkips"
     assert abs(acc[method] - float(g["e2e_accuracy"])) < 1.5 and acc[method + "TopK"] >= acc[method]
     assert acc["FCFS"] < acc[method] and acc["WAP5"] < acc[method]

@@ -55,6 +55,43 @@ def test_reference_corpora(path):
     assert np.allclose(r2[0]["topk_score"].T[m], ref[m], rtol=1e-12, atol=0)
 
 
+def _datasets():
+    import json
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "service_order.json")) as fh:
+        return sorted(json.load(fh))
+
+
+def check_seeded_chain(lib_path, dataset, strict=False):
+    """-> (services, requests that differ from the frozen run outside the tied windows)."""
+    n_svc = outside = 0
+    for path, d, r1, r2 in parity.seeded_chain(lib_path, dataset, GOLDEN):
+        diff = set(np.flatnonzero((r2["parent"] != d["final_parent"]).any(axis=0)).tolist())
+        n = r2["parent"].shape[1]
+        assert np.array_equal(r1["leaves"] + r2["leaves"], d["per_span_candidates"]), path
+        assert r2["budget_windows"] == 0
+        _, t2 = tie_spans(path)
+        if parity.millisecond_granular(d) and not strict:
+            # collapsed mixture components: the refit's reductions run in another order on the GPU than in scikit-learn's BLAS
+            assert len(diff - t2) <= max(2, n // 200), (path, sorted(diff - t2))
+        else:
+            assert diff <= t2, "%s: the seeded chain differs from the frozen reference run outside the tied windows: %s" % (path, sorted(diff - t2))
+            assert r2["cnt_unassigned"] == int(d["cnt_unassigned"]), path
+        n_svc += 1
+        outside += len(diff - t2)
+    return n_svc, outside
+
+
+@pytest.mark.parametrize("dataset", _datasets())
+def test_seeded_chain_on_every_corpus(dataset):
+    """All 90 services of the 23 frozen reference runs, the WHOLE chain on the GPU: pass 1 -> tw_fit_mixtures_tape with the
+    doubles np.random.seed(seed) yields in the reference's service order -> pass 2 -> final_parent of the frozen run, request
+    by request outside the windows whose optimum is proven not unique (nothing teacher-forced: the mixtures are the ones the
+    device fits).  On the millisecond-granular corpora (collapsed mixture components: parity.millisecond_granular) at most
+    0.5 % of a service's requests may differ; everywhere else none."""
+    check_seeded_chain(None, dataset)
+
+
 def test_all_corpora_in_one_batch():
     """Units of different E in one launch (shared kernels, per-unit descriptors)."""
     ds = [np.load(p) for p in GOLDEN]

@@ -5,6 +5,8 @@ end-to-end case re-creates the hotel `frontend` call of the frozen reference run
 same partition-key order, numpy RNG seeded like the reference run) and must return the same
 assignments, top-5 lists and counters as the reference did -- including the scikit-learn refit between
 the passes, which the predictor replays in the reference's call order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -120,8 +122,13 @@ def test_skip_mode_behind_the_protocol(emu_lib):
     code = lambda v: -2 if v == ("Skip", "Skip") else (-1 if v == ("NA", "NA") else int(v[1].rsplit("_", 1)[1]))
     parent = np.array([[code(all_asg[ep][s.GetId()]) for s in in_spans] for ep in out_eps])
     assert n_in == 1000 and (parent == -2).sum() > 50
-    assert (parent != d["final_parent"]).any(axis=0).sum() <= 20          # up to the reference solver's tolerance (tests/test_skip_oracle.py)
-    assert unassigned == int(d["cnt_unassigned"]) and abs(not_best - int(d["not_best_count"])) <= 20
+    # identical to the frozen run outside the windows where the solver's choice is proven a near-tie of the exact optimum
+    from conftest import skip_tie_requests
+
+    ties = skip_tie_requests(os.path.basename(path)[:-4])
+    differing = set(np.flatnonzero((parent != d["final_parent"]).any(axis=0)).tolist())
+    assert differing <= ties, sorted(differing - ties)
+    assert unassigned == int(d["cnt_unassigned"]) and abs(not_best - int(d["not_best_count"])) <= len(ties)
     assert [per_span[s.GetId()] for s in in_spans] == d["per_span_candidates"].tolist()
     for k, ep in enumerate(out_eps):
         for i, s in enumerate(in_spans):
@@ -142,6 +149,17 @@ def test_unseeded_run(emu_lib):
     in_spans = list(in_parts.values())[0]
     ok = sum(all(ret[0][ep][s.GetId()] == truth[ep][s.GetId()] for ep in out_eps) for s in in_spans)
     assert ok / len(in_spans) > 0.97    # the frozen reference run scored 0.991 on this service
+
+
+@pytest.mark.parametrize("dataset", ["hotel_load100", "media_load150", "nodeio_1", "node_load50"])
+def test_seeded_chain_of_whole_corpora(emu_lib, dataset):
+    """CPU twin of tests/test_gpu_parity.py::test_seeded_chain_on_every_corpus: every service of a frozen reference run in the
+    run's order on one RNG stream, nothing teacher-forced -- final_parent of the frozen run outside the proven tie windows
+    (on the emulator also for the millisecond-granular corpora)."""
+    from test_gpu_parity import check_seeded_chain
+
+    n_svc, outside = check_seeded_chain(emu_lib, dataset, strict=True)
+    assert n_svc >= 2 and outside == 0
 
 
 @pytest.mark.gpu

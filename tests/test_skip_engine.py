@@ -68,7 +68,10 @@ def check(lib_path, path):
     # against the reference run itself: the lists (skip spans decoded), and the assignment up to the solver's tolerance
     idx, w = skipmode.decode(np.transpose(r["topk_idx"], (2, 0, 1)))
     assert np.array_equal(idx, d["p0_topk2_idx"]) and np.array_equal(w, d["p0_topk2_win"])
-    assert (r["parent"] != d["final_parent"]).any(axis=0).sum() <= 0.02 * unit.n_in
+    from conftest import skip_tie_requests
+
+    differing = set(np.flatnonzero((r["parent"] != d["final_parent"]).any(axis=0)).tolist())
+    assert differing <= skip_tie_requests(os.path.basename(path)[:-4])   # only inside the proven near-tie windows
     assert (r["parent"] == -2).sum() > 0
     assert ev["correct"] == int(np.all(r["parent"] == truth, axis=0).sum())
     assert abs(ev["accuracy"] - float(np.all(d["final_parent"] == truth, axis=0).mean())) <= 0.005

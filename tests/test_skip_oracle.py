@@ -68,6 +68,16 @@ def test_skip_mode_oracle_reproduces_the_reference(oracle, path):
         assert ca == cb and abs(wa - wb) < 1e-6 and wa >= wb - 1e-9
     differing = int((o["chosen"] != d["p0_chosen"]).sum())
     assert differing <= 0.02 * svc.n_in
+    # the committed list of near-tie windows (tests/golden/skip_tie_windows.json) is current
+    import json
+    import sys
+
+    sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+    from make_skip_tie_windows import near_tie_requests
+
+    with open(os.path.join(REPO, "tests", "golden", "skip_tie_windows.json")) as f:
+        assert json.load(f)[os.path.basename(path)[:-4]] == near_tie_requests(oracle, d)
+    assert set(np.flatnonzero((o["parent"] != d["final_parent"]).any(axis=0)).tolist()) <= set(near_tie_requests(oracle, d))
     assert o["cnt_unassigned"] == int(d["cnt_unassigned"])
     assert (o["parent"] != d["final_parent"]).any(axis=0).sum() <= differing
     assert abs(o["not_best_count"] - int(d["not_best_count"])) <= differing

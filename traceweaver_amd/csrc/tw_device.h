@@ -124,13 +124,12 @@ struct Dev {
     int32_t *tiny_unit, *tiny_win;
     int32_t* heavy_in_count;  // [2][kMaxEp+1] incoming spans deferred to k_enumerate_heavy per endpoint count E: narrow, wide windows
     int32_t* heavy_in_next;   // [3][kMaxEp+1] next unclaimed entry of each list: narrow, wide, long enumerations (when launched on their own)
-    uint8_t* span_cls;        // per incoming span: 0 enumerated by its thread of k_enumerate_light, 1 by a wavefront (k_classify)
     int32_t heavy_in_off[kMaxEp + 2];  // class offsets into heavy_in_unit / heavy_in_idx
     int32_t *heavy_in_unit, *heavy_in_idx;
     int32_t* heavy_big_count;   // [kMaxEp+1] narrow spans with a long enumeration: served first
     int32_t *heavy_big_unit, *heavy_big_idx;   // class offsets heavy_big_off (room for the extra entries of split spans)
     int32_t heavy_big_off[kMaxEp + 2];
-    // A very long enumeration is cut into parts by the position of the first endpoint's candidate (k_enumerate_light lists one
+    // A very long enumeration is cut into parts by the position of the first endpoint's candidate (k_enumerate_tile lists one
     // entry per part); the parts leave their top-5 in a scratch slot each and k_merge_parts combines them.
     int32_t* heavy_big_part;   // [big list] number of parts | part << 8 | wide windows << 24   (1 = the whole enumeration)
     int32_t* heavy_big_slot;   // [big list] scratch slot of the part's result

@@ -840,7 +840,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.owner, n_out_total);
     ALLOC(P.gaps, gaps);
     ALLOC(e->tile_ids, (int64_t)tile_ids_h.size());
-    ALLOC(P.span_cls, n_in_total); ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
+    ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
     {   // long enumerations: a list entry per span plus the extra entries of the split ones (an eighth of the class + 64), two
         // scratch slots per extra entry
         int64_t big_total = 0, slots = 0;

@@ -3,7 +3,7 @@
 // Kernel map (reference function -> kernel), paths under
 // /root/reference/src/trace_reconstructor/ports/python/algorithms/:
 //   k_block_params      ComputeEpPairDistParams3            traceweaver_v3.py:580-646
-//   k_enumerate_light / k_enumerate_heavy
+//   k_enumerate_tile (tw_tile.h) / k_enumerate_heavy
 //                       FindCutoffs + DfsTraverseX/3 + ScoreAssignmentAsPerInvocationGraph + heap top-5
 //                                                           traceweaver_v3.py:182-351, traceweaver_v1.py:259-361
 //   k_scan_* / k_perfect_cut / k_window_flags / k_window_index
@@ -338,17 +338,13 @@ struct Cand {
 // Speculative enumeration on all spans: this *is* top_k_2 (traceweaver_v3.py:1185) and equals top_k
 // (traceweaver_v3.py:1182) for every span none of whose candidates was consumed by an earlier window.
 //
-// Two tiers.  k_enumerate_light: one thread per incoming span computes the cutoffs and, when the
-// candidate product prod_e (hi_e - lo_e + 1) is small, enumerates it on the spot (mean 1.5-3 tuples on
-// the reference corpora).  Spans with a larger product go to a work list and are enumerated by
+// Two tiers.  k_enumerate_tile (tw_tile.h): one workgroup per tile of incoming spans computes the cut-offs, stages the
+// tile's candidate windows in LDS and enumerates the spans with up to kTileMax tuples, items and tuples spread over its
+// lanes.  Spans with a longer enumeration (or windows that do not fit its tables) go to a work list and are enumerated by
 // k_enumerate_heavy, one wavefront per span: the wavefront walks the leading endpoints together and
 // spreads the tuples of the trailing endpoints over its lanes -- feasibility and the log-likelihood (the
 // costly part) run in parallel, the heap is then fed in enumeration order (wave-uniform pushes) so that
 // ties resolve exactly as in the sequential reference.
-#ifndef TW_LIGHT_MAX
-#define TW_LIGHT_MAX 64
-#endif
-constexpr int kLightMax = TW_LIGHT_MAX;  // largest candidate product the per-thread kernel enumerates itself
 constexpr int kHeavyThreads = 64;
 
 // Optional phase timers (build with -DTW_PROFILE; read back through tw_debug_profile): cycles spent by
@@ -446,298 +442,6 @@ __device__ __forceinline__ bool heavy_append_rt(const Dev& P, int E, bool pred, 
     return true;
 }
 
-// Per-thread enumeration state with compile-time indexing only (the depth-first walk is unrolled by
-// template recursion over the endpoints), so that it lives in registers: no scratch traffic.
-template <int E>
-struct LightCtx {
-    const UnitDev* U;
-    Scorer S;
-    int64_t in_start, in_end;
-    const int64_t* os[E];
-    const int64_t* oe[E];
-    int32_t lo[E], hi[E], x[E];
-    int64_t xs[E], xe[E];
-    double ts[kTopK];          // kept tuples, best first
-    int32_t tidx[kTopK][E];
-    int nk;
-    int64_t leaves;
-    uint64_t bits[E][kCandWords];
-    bool ambiguous;            // an equivalence (equal score, equal start at the first differing span) could matter
-    double troot[E], tclose[E];  // root / closing term of the span currently chosen at each level
-    double* tab;               // this thread's column of the workgroup's LDS term table (stride = workgroup size)
-    int tab_stride;
-    // the tabulated candidates themselves are staged next to their terms: (start, end) as offsets from in_start in LDS, the
-    // position in the window a byte each in a register -- the tree below re-reads a level's candidates for every prefix,
-    // and from global memory that was the kernel's time (1 032 VMEM reads per wavefront at E = 4, 54 % of cycles waiting)
-    int32_t* so;               // this thread's column of the offset table, same stride
-    uint64_t cxo[E];           // cx - lo of the staged candidates of every endpoint
-    int nst[E];                // how many are staged (<= light_tab_width<E>())
-};
-
-// Terms that depend on one outgoing span only -- root(in.start -> s.start) and closing(s.end -> in.end),
-// traceweaver_v1.py:349-357 -- are tabulated once per candidate span (the first light_tab_width<E>() candidates of
-// every endpoint, in LDS) instead of being evaluated at every tuple that contains the span; wider endpoints fall
-// back to evaluating at the tree level where the span is chosen.  The tuple score adds the same doubles in the
-// same order, so it is bit-identical.
-#ifndef TW_LIGHT_TABW
-#define TW_LIGHT_TABW(E) ((E) == 1 ? 5 : (E) == 2 ? 5 : (E) == 3 ? 4 : (E) == 4 ? 3 : 2)   // 24 B of LDS per (endpoint, candidate) and thread
-#endif
-template <int E>
-__host__ __device__ constexpr int light_tab_width() { return TW_LIGHT_TABW(E); }
-
-// order of the current tuple c.x against kept tuple k when the scores are equal: +1 greater, -1 smaller, 0 equivalent
-template <int E>
-__device__ __forceinline__ int light_tie(const LightCtx<E>& c, int k) {
-    int res = 0;
-    bool done = false;
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        int32_t ki = 0;
-#pragma unroll
-        for (int q = 0; q < kTopK; q++) if (q == k) ki = c.tidx[q][e];
-        if (!done && c.x[e] != ki) {
-            const int64_t a = c.xs[e], b2 = c.os[e][ki];
-            res = a > b2 ? 1 : (a < b2 ? -1 : 0);
-            done = true;
-        }
-    }
-    return res;
-}
-
-template <int E>
-__device__ void light_leaf(LightCtx<E>& c, bool want_bits) {
-    c.leaves++;
-    if (want_bits) {
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int r = c.x[e] - c.lo[e];
-#pragma unroll
-            for (int w = 0; w < kCandWords; w++) if ((r >> 6) == w) c.bits[e][w] |= 1ull << (r & 63);
-        }
-    }
-    // ScoreAssignmentAsPerInvocationGraph, no-skip branch (traceweaver_v1.py:305-361)
-    const UnitDev& U = *c.U;
-    int last = 0;
-    int64_t last_end = c.xe[0];
-#pragma unroll
-    for (int e = 1; e < E; e++) if (c.xe[e] > last_end) { last_end = c.xe[e]; last = e; }
-    double sj = 0.0;
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        const int np = U.npred[e];
-        for (int j = 0; j < np; j++) {
-            if (!U.pred_prim[e][j]) continue;
-            const int p = U.pred_list[e][j];
-            int64_t pend = 0;
-#pragma unroll
-            for (int q = 0; q < E; q++) if (q == p) pend = c.xe[q];
-            sj += score_term(c.S, slot_prim(E, p, e), pend, c.xs[e]);
-        }
-        if (np == 0) sj += c.troot[e];
-        if (e == last) sj += c.tclose[e];
-    }
-    // insert into the kept list (strict part of Python's order; equivalences that could matter are flagged)
-    if (c.nk == kTopK && sj < c.ts[kTopK - 1]) return;
-    int tie[kTopK];
-#pragma unroll
-    for (int k = 0; k < kTopK; k++) {
-        tie[k] = 0;
-        if (k < c.nk && sj == c.ts[k]) { tie[k] = light_tie<E>(c, k); if (tie[k] == 0) c.ambiguous = true; }
-    }
-    if (c.nk == kTopK) {
-        if (!(sj > c.ts[kTopK - 1] || (sj == c.ts[kTopK - 1] && tie[kTopK - 1] > 0))) return;
-        if (c.ts[kTopK - 2] == c.ts[kTopK - 1]) {  // the entry that drops out must be the unique minimum
-            bool same = true, decided = false;
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                const int32_t ia = c.tidx[kTopK - 2][e], ib = c.tidx[kTopK - 1][e];
-                if (!decided && ia != ib) { same = c.os[e][ia] == c.os[e][ib]; decided = true; }
-            }
-            if (same) c.ambiguous = true;
-        }
-    }
-    int pos = c.nk < kTopK ? c.nk : kTopK - 1;
-    if constexpr (E <= 6) {
-        // written as selects, not as conditional stores: the optimiser turns "if (k == pos) list[k] = ..." into a store at
-        // a dynamic index, which moves the list from registers into scratch memory (seen in the ISA for E >= 2; as selects
-        // the kernels for E <= 6 are free of scratch memory at unchanged occupancy)
-#pragma unroll
-        for (int k = kTopK - 1; k >= 1; k--) {
-            const bool shift = k == pos && (sj > c.ts[k - 1] || (sj == c.ts[k - 1] && tie[k - 1] > 0));
-            c.ts[k] = shift ? c.ts[k - 1] : c.ts[k];
-#pragma unroll
-            for (int e = 0; e < E; e++) c.tidx[k][e] = shift ? c.tidx[k - 1][e] : c.tidx[k][e];
-            pos = shift ? k - 1 : pos;
-        }
-#pragma unroll
-        for (int k = 0; k < kTopK; k++) {
-            const bool here = k == pos;
-            c.ts[k] = here ? sj : c.ts[k];
-#pragma unroll
-            for (int e = 0; e < E; e++) c.tidx[k][e] = here ? c.x[e] : c.tidx[k][e];
-        }
-    } else {  // 7 and 8 endpoints: 40 list registers more would cost the second wavefront per SIMD
-#pragma unroll
-        for (int k = kTopK - 1; k >= 1; k--) {
-            if (k == pos && (sj > c.ts[k - 1] || (sj == c.ts[k - 1] && tie[k - 1] > 0))) {
-                c.ts[k] = c.ts[k - 1];
-#pragma unroll
-                for (int e = 0; e < E; e++) c.tidx[k][e] = c.tidx[k - 1][e];
-                pos = k - 1;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kTopK; k++)
-            if (k == pos) {
-                c.ts[k] = sj;
-#pragma unroll
-                for (int e = 0; e < E; e++) c.tidx[k][e] = c.x[e];
-            }
-    }
-    if (c.nk < kTopK) c.nk++;
-}
-
-template <int E, int D>
-__device__ void light_dfs(LightCtx<E>& c, bool want_bits);
-// candidate cx = [st, en] (contained in the incoming span; r = its rank among the contained spans of endpoint D)
-template <int E, int D>
-__device__ __forceinline__ void light_visit(LightCtx<E>& c, bool want_bits, int cx, int64_t st, int64_t en, int r) {
-    const UnitDev& U = *c.U;
-    bool ok = true;
-#pragma unroll
-    for (int p = 0; p < D; p++)
-        if (((U.pred_mask[D] >> p) & 1) && c.xe[p] > st) ok = false;
-    if (!ok) return;
-    c.x[D] = cx; c.xs[D] = st; c.xe[D] = en;
-    constexpr int Wt = light_tab_width<E>();
-    if (r < Wt) {
-        c.troot[D] = c.tab[(D * Wt + r) * 2 * c.tab_stride];
-        c.tclose[D] = c.tab[((D * Wt + r) * 2 + 1) * c.tab_stride];
-    } else {
-        c.troot[D] = U.npred[D] == 0 ? score_term(c.S, slot_root(E, D), c.in_start, st) : 0.0;
-        c.tclose[D] = score_term(c.S, slot_close(E, D), en, c.in_end);
-    }
-    light_dfs<E, D + 1>(c, want_bits);
-}
-template <int E, int D>
-__device__ void light_dfs(LightCtx<E>& c, bool want_bits) {
-    if constexpr (D == E) {
-        light_leaf<E>(c, want_bits);
-    } else {
-        constexpr int Wt = light_tab_width<E>();
-        const int ns = c.nst[D];
-        int cx = c.lo[D] - 1;
-        for (int r = 0;; r++) {   // (one call site below: the tree is instantiated once per level, not once per route to it)
-            int64_t st, en;
-            if (r < ns) {   // a staged candidate: from LDS
-                cx = c.lo[D] + (int)((c.cxo[D] >> (8 * r)) & 255ull);
-                st = c.in_start + c.so[(D * Wt + r) * 2 * c.tab_stride];
-                en = c.in_start + c.so[((D * Wt + r) * 2 + 1) * c.tab_stride];
-            } else {        // the window may hold more contained spans than the table: the rest as they lie in global memory
-                if (ns < Wt) break;
-                bool found = false;
-                for (cx = cx + 1; cx <= c.hi[D]; cx++) {
-                    st = c.os[D][cx]; en = c.oe[D][cx];
-                    if (!(c.in_start > st || en > c.in_end)) { found = true; break; }
-                }
-                if (!found) break;
-            }
-            light_visit<E, D>(c, want_bits, cx, st, en, r);
-        }
-    }
-}
-
-// Cut-offs and work lists, one thread per incoming span, ahead of the enumeration kernels: FindCutoffs
-// (traceweaver_v3.py:182-217) in pass 1 (kept in c_lo / c_hi: they depend on timestamps only), then the size of the span's
-// enumeration decides who enumerates it -- this thread's slot in k_enumerate_light (span_cls 0) or a wavefront of
-// k_enumerate_heavy (span_cls 1: listed here).  This kernel holds no LDS, so its 2E dependent searches per span run at full
-// occupancy (inside the per-thread kernel, whose term tables allow two wavefronts per SIMD, they were 40 % of its pass-1 time).
-template <int E>
-__global__ void __launch_bounds__(kTile) k_classify(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
-    if (*P.err != 0) return;  // e.g. NaN parameters (hazard H3): nothing downstream is meaningful
-    const int tile = tile_ids[xcd_tile(blockIdx.x, n_tiles_e)];
-    const TileDev T = P.tiles[tile];
-    const UnitDev& U = P.units[T.unit];
-    const int i = T.first + threadIdx.x;
-    if (i >= U.n_in) return;
-    LightCtx<E> c;
-    c.U = &U;
-    c.in_start = P.in_start[U.in_off + i];
-    c.in_end = P.in_end[U.in_off + i];
-#pragma unroll
-    for (int e = 0; e < E; e++) { c.os[e] = P.out_start + U.ep_off[e]; c.oe[e] = P.out_end + U.ep_off[e]; }
-    // the cut-offs depend on timestamps only: pass 1 computes and keeps them, the wavefront kernel and pass 2
-    // read them back instead of repeating 2E dependent searches per span
-    if (pass == 1) {
-        // FindCutoffs (traceweaver_v3.py:182-217), reverse topological order
-#pragma unroll
-        for (int e = E - 1; e >= 0; e--) {
-            const int n = (int)(U.ep_off[e + 1] - U.ep_off[e]);
-            int64_t tmax = c.in_end;
-#pragma unroll
-            for (int f = e + 1; f < E; f++) {
-                if (!((U.succ_mask[e] >> f) & 1)) continue;
-                const int nf = (int)(U.ep_off[f + 1] - U.ep_off[f]);
-                const int anchor = c.hi[f] >= 0 ? c.hi[f] : nf - 1;  // Python's [-1] wrap (hazard H10)
-                const int64_t st = c.os[f][anchor];
-                if (st < tmax) tmax = st;
-            }
-            if (U.skip) {   // lists as handed over, possibly out of order: exactly Python's bisect_left / bisect_right
-                c.lo[e] = lower_bound_i64(c.os[e], n, c.in_start);
-                c.hi[e] = upper_bound_i64(c.os[e], n, tmax) - 1;
-            } else {
-                c.lo[e] = bound_near<false>(c.os[e], n, c.in_start, i);
-                c.hi[e] = bound_near<true>(c.os[e], n, tmax, c.lo[e]) - 1;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < E; e++) { P.c_lo[ie_index(U, e, i)] = c.lo[e]; P.c_hi[ie_index(U, e, i)] = c.hi[e]; }
-    } else {
-#pragma unroll
-        for (int e = 0; e < E; e++) { c.lo[e] = P.c_lo[ie_index(U, e, i)]; c.hi[e] = P.c_hi[ie_index(U, e, i)]; }
-    }
-    bool wide = false, empty = false, narrow = true;
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        const int w = c.hi[e] - c.lo[e] + 1;
-        wide |= (w > 64 * kCandWords);
-        narrow &= (w <= kNarrow);
-        empty |= (w <= 0);
-    }
-    if (wide) { raise_err(P, TW_ERR_WINDOW_WIDTH); return; }
-    int64_t prod = empty ? 0 : 1;
-#pragma unroll
-    for (int e = 0; e < E; e++) if (prod > 0 && prod <= kLightMax) prod *= (c.hi[e] - c.lo[e] + 1);
-    int first_cands = 0;
-    if (prod > kLightMax) {
-        // the windows also hold spans that start inside the incoming span but end after it; what the enumeration
-        // costs is the product of the *contained* candidates (a third of the raw product on the bench workload)
-        prod = 1;
-        bool twins = false;   // two candidates of one endpoint that start together: Python's order of tuples may not decide
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            int v = 0;
-            int64_t prev = INT64_MIN;
-            for (int cx = c.lo[e]; cx <= c.hi[e]; cx++) {
-                const int64_t st = c.os[e][cx];
-                if (st >= c.in_start && c.oe[e][cx] <= c.in_end) { v++; twins |= st == prev; prev = st; }
-            }
-            if (prod <= (1ll << 40)) prod *= v;
-            if (e == 0) first_cands = v;
-        }
-        // parts are only worth it when they settle the top five among themselves (k_merge_parts): with twins the span would
-        // most likely be enumerated again as a whole (millisecond-granular traces: nearly always)
-        if (twins && !P.split_twins) first_cands = 0;
-    }
-    // (the per-thread kernel stages its candidates as 32-bit offsets from in_start: a span longer than that is not for it)
-    const bool long_span = c.in_end - c.in_start >= (1ll << 31) || c.in_end < c.in_start;
-    const bool heavy = heavy_append<E>(P, prod > kLightMax || (long_span && !empty), narrow, prod > kBigProduct, T.unit, i, prod, U.skip ? 0 : first_cands);
-    P.span_cls[U.in_off + i] = heavy ? 1 : 0;
-}
-
-#ifndef TW_LIGHT_ATTR
-#define TW_LIGHT_ATTR
-#endif
 // position of the n-th set bit of m (n < popcount(m)): six halvings
 __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
     int pos = 0;
@@ -756,171 +460,6 @@ __device__ __forceinline__ double score_term_mix_x(const Scorer& S, int slot, do
     const double* c = S.mix_c + (int64_t)slot * kMaxComp * 4;
     if (n <= 0) return term_gauss(c[0], c[1], c[2], x);
     return term_mix(n, c, x);
-}
-
-template <int E>
-__global__ void __launch_bounds__(kTile) TW_LIGHT_ATTR k_enumerate_light(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
-    if (*P.err != 0) return;  // e.g. NaN parameters (hazard H3): nothing downstream is meaningful
-    const int tile = tile_ids[xcd_tile(blockIdx.x, n_tiles_e)];
-    const TileDev T = P.tiles[tile];
-    const UnitDev& U = P.units[T.unit];
-    const int i = T.first + threadIdx.x;
-    constexpr int Wt = light_tab_width<E>();
-    // pass 2 with a term table: the lanes without a span of their own stay for the table (its mixture terms are evaluated by
-    // all lanes of the wavefront, see below); otherwise they leave here
-    const bool dense = Wt > 0 && pass == 2;
-    bool mine = i < U.n_in;
-    if (mine && P.span_cls[U.in_off + i] != 0) mine = false;   // enumerated by a wavefront (k_classify listed it)
-    if (!mine && !dense) return;
-    LightCtx<E> c;
-    c.U = &U;
-    c.in_start = mine ? P.in_start[U.in_off + i] : 0;
-    c.in_end = mine ? P.in_end[U.in_off + i] : 0;
-    c.S.pass = pass;
-    c.S.gp = P.gparam + (U.gp_off + (int64_t)((mine ? i : 0) / P.batch_size) * U.nslot) * 4;
-    c.S.mix_n = P.mix_n + U.slot_off;
-    c.S.mix_c = P.mix_c + (int64_t)U.slot_off * kMaxComp * 4;
-#pragma unroll
-    for (int e = 0; e < E; e++) { c.os[e] = P.out_start + U.ep_off[e]; c.oe[e] = P.out_end + U.ep_off[e]; }
-    bool empty = !mine, narrow = true;
-#pragma unroll
-    for (int e = 0; e < E; e++) {   // cut-offs: k_classify
-        c.lo[e] = mine ? P.c_lo[ie_index(U, e, i)] : 0; c.hi[e] = mine ? P.c_hi[ie_index(U, e, i)] : -1;
-        const int w = c.hi[e] - c.lo[e] + 1;
-        narrow &= (w <= kNarrow);
-        empty |= (w <= 0);
-    }
-    c.nk = 0; c.leaves = 0; c.ambiguous = false;
-#pragma unroll
-    for (int k = 0; k < kTopK; k++) c.ts[k] = -dinf();
-#pragma unroll
-    for (int e = 0; e < E; e++)
-#pragma unroll
-        for (int w = 0; w < kCandWords; w++) c.bits[e][w] = 0;
-    {   // term table of this thread: [endpoint][candidate][root, closing], one LDS column per thread
-        constexpr int NC = Wt > 0 ? E * Wt * 2 : 1;   // cells per thread
-        static_assert(NC <= 64, "a thread's cells are counted in one 64-bit mask");
-        __shared__ double tab[NC * kTile];
-        __shared__ int32_t sotab[NC * kTile];
-        c.tab = tab + threadIdx.x;
-        c.so = sotab + threadIdx.x;
-        c.tab_stride = blockDim.x;
-#pragma unroll
-        for (int e = 0; e < E; e++) { c.cxo[e] = 0; c.nst[e] = 0; }
-        if (!dense) {
-            if (!empty) {
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    int r = 0;  // rows = the first Wt *contained* candidates (the others never occur in a tuple)
-                    for (int cx = c.lo[e]; cx <= c.hi[e] && r < Wt; cx++) {
-                        const int64_t st = c.os[e][cx], en = c.oe[e][cx];
-                        if (c.in_start > st || en > c.in_end) continue;
-                        c.tab[(e * Wt + r) * 2 * c.tab_stride] = U.npred[e] == 0 ? score_term(c.S, slot_root(E, e), c.in_start, st) : 0.0;
-                        c.tab[((e * Wt + r) * 2 + 1) * c.tab_stride] = score_term(c.S, slot_close(E, e), en, c.in_end);
-                        c.so[(e * Wt + r) * 2 * c.tab_stride] = (int32_t)(st - c.in_start);
-                        c.so[((e * Wt + r) * 2 + 1) * c.tab_stride] = (int32_t)(en - c.in_start);
-                        c.cxo[e] |= (uint64_t)(cx - c.lo[e]) << (8 * r);
-                        r++;
-                    }
-                    c.nst[e] = r;
-                }
-            }
-        } else if constexpr (Wt > 0) {
-            // Pass 2: a mixture term is ~1.5 k instructions and a thread has 2-20 of them -- built thread by thread, a wavefront
-            // runs as long as its thread with the most candidates (lanes active: 0.16-0.27).  Instead every thread only writes the
-            // *gaps* into its cells; one ballot per cell says which lanes use it; then the wavefront evaluates the used cells of an
-            // endpoint 64 at a time, item g = the n-th user of cell k (prefix sums over the ballots), whoever owns it.  Same function
-            // on the same binary64 gap: the table holds the same numbers.
-            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-            const int nl = (int)blockDim.x - 64 * wv < 64 ? (int)blockDim.x - 64 * wv : 64;   // lanes of this wavefront (64 unless the emulation runs narrower workgroups)
-            unsigned long long used = 0;
-            if (!empty) {
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    int r = 0;
-                    for (int cx = c.lo[e]; cx <= c.hi[e] && r < Wt; cx++) {
-                        const int64_t st = c.os[e][cx], en = c.oe[e][cx];
-                        if (c.in_start > st || en > c.in_end) continue;
-                        const int cell = (e * Wt + r) * 2;
-                        if (U.npred[e] == 0) { c.tab[cell * c.tab_stride] = (double)(st - c.in_start); used |= 1ull << cell; }
-                        else c.tab[cell * c.tab_stride] = 0.0;
-                        c.tab[(cell + 1) * c.tab_stride] = (double)(c.in_end - en);
-                        used |= 1ull << (cell + 1);
-                        c.so[cell * c.tab_stride] = (int32_t)(st - c.in_start);
-                        c.so[(cell + 1) * c.tab_stride] = (int32_t)(en - c.in_start);
-                        c.cxo[e] |= (uint64_t)(cx - c.lo[e]) << (8 * r);
-                        r++;
-                    }
-                    c.nst[e] = r;
-                }
-            }
-            wave_sync();
-            // endpoint by endpoint: the ballots and their prefix sums are wave-uniform and indexed by compile-time constants only --
-            // they live in scalar registers, the table's LDS footprint stays what it was
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                constexpr int C = 2 * Wt;   // cells of one endpoint
-                unsigned long long users[C];
-                int first[C + 1];
-                first[0] = 0;
-#pragma unroll
-                for (int k = 0; k < C; k++) {
-                    users[k] = __ballot((int)((used >> (e * C + k)) & 1ull));
-                    first[k + 1] = first[k] + __popcll(users[k]);
-                }
-                for (int g = lane; g < first[C]; g += nl) {
-                    int k = 0, base = 0;
-                    unsigned long long mk = users[0];
-#pragma unroll
-                    for (int j = 1; j < C; j++)
-                        if (g >= first[j]) { k = j; mk = users[j]; base = first[j]; }
-                    const int owner = nth_set_bit(mk, g - base);
-                    double* cellp = tab + (size_t)(e * C + k) * blockDim.x + (size_t)(wv * 64 + owner);
-                    *cellp = score_term_mix_x(c.S, (k & 1) ? slot_close(E, e) : slot_root(E, e), *cellp);
-                }
-            }
-            wave_sync();
-            if (!mine) return;
-        }
-    }
-    if (!empty) light_dfs<E, 0>(c, pass == 1);
-    // the kept tuples themselves must be pairwise ordered
-#pragma unroll
-    for (int a2 = 0; a2 < kTopK; a2++)
-#pragma unroll
-        for (int b2 = a2 + 1; b2 < kTopK; b2++)
-            if (b2 < c.nk && c.ts[a2] == c.ts[b2]) {
-                bool same = true, decided = false;
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    const int32_t ia = c.tidx[a2][e], ib = c.tidx[b2][e];
-                    if (!decided && ia != ib) { same = c.os[e][ia] == c.os[e][ib]; decided = true; }
-                }
-                if (same) c.ambiguous = true;
-            }
-    // rare (millisecond-granular data): CPython's heapq / list.sort must be replayed push by push.  That needs
-    // dynamically indexed per-thread state; keeping it out of this kernel keeps this kernel free of scratch memory
-    // (measured: 8x faster) -- the span goes to the wavefront kernel, which replays from LDS.
-    if (heavy_append<E>(P, c.ambiguous, narrow, false, T.unit, i)) return;
-    const int64_t g = U.in_off + i;
-    P.tk_n[g] = c.nk;
-    P.leaves[g] = c.leaves;
-    P.rep[g] = 0;
-#pragma unroll
-    for (int k = 0; k < kTopK; k++) {
-        // a span's list has min(5, feasible tuples) entries in every pass; the unused entries keep the -1 / NaN
-        // pattern of tw_load_batch and are never written (most lists are short: this halves the store traffic)
-        if (k < c.nk) {
-            P.tk_score[tks_index(U, k, i)] = c.ts[k];
-#pragma unroll
-            for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, i)] = c.tidx[k][e];
-        }
-    }
-    if (pass == 1) {
-#pragma unroll
-        for (int e = 0; e < E; e++)
-            for (int w = 0; w < kCandWords; w++) P.c_bits[ie_index(U, e, i) * kCandWords + w] = c.bits[e][w];
-    }
 }
 
 // CPython heap / sort replay on an LDS-resident heap (k_enumerate_heavy, degenerate-tie spans only).  Entries hold
@@ -1102,7 +641,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         S.gp = P.gparam + (U.gp_off + (int64_t)(i / P.batch_size) * U.nslot) * 4;
         S.mix_n = P.mix_n + U.slot_off;
         S.mix_c = P.mix_c + (int64_t)U.slot_off * kMaxComp * 4;
-        // cut-offs (FindCutoffs, traceweaver_v3.py:182-217) were computed by k_enumerate_light in pass 1
+        // cut-offs (FindCutoffs, traceweaver_v3.py:182-217) were computed by k_enumerate_tile in pass 1
         int32_t lo[E], cn[E];   // first span of the cut-off window; number of staged candidates
         // the unit's call-order DAG in registers: predecessor masks, predecessor counts, and per endpoint the
         // predecessor list in in_edges() order packed 4 bits each (index | primary << 3)
