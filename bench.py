@@ -26,15 +26,19 @@ Workloads (--workload):
 
   alibaba-full  config 5: the 15 Alibaba-shape call graphs (--total-spans engine spans in all) at the six load levels of
            exps/exp5 (compress factors 1 ... 15000; a service's load factor is max(1, ceil(factor / #replicas)),
-           executor.py:1089-1097, replica table generated with the corpus): the services are sharded over the ranks and
-           uploaded ONCE; every step scales the resident table to each level in turn (tw_scale_load), solves it and
-           gathers the parents (RCCL on the engine's buffers).  Strong scaling; value = spans x levels per second.
+           executor.py:1089-1097, replica table generated with the corpus): every (level, service) pair is a unit; the units
+           are sharded over the ranks and uploaded ONCE, all levels resident together; every step scales each copy to its
+           level on the device (one tw_scale_load call), solves the whole matrix in one step and gathers the parents (RCCL on
+           the engine's buffers).  Strong scaling; value = spans x levels per second.
 
   media-split  within-service sharding: ONE media-shape graph whose six services hold --n-in x --replicas requests each;
            every service is cut at idle moments into one part per rank (sharding.split_points / split_unit), the parts'
            gap samples are all-gathered between the passes and every rank refits on the union
            (sharding.refit_split_services), parents are gathered at the end.  Strong scaling; bit-identical to the
            unsplit run (--verify 1 checks it on rank 0).
+
+`python bench.py --gpus N` with N > 1 and no --workload prints the media line (weak scaling) and, under `scale_regimes`, the two
+sharded modes north_star names -- `alibaba` and `alibaba-full`, each with --verify 1 (`sharded_equals_single_gpu`).
 
 N > 1: `python bench.py --gpus N` starts N ranks itself (re-exec under torch.distributed.run on 127.0.0.1); when the
 driver has already started the ranks (RANK / WORLD_SIZE in the environment) --gpus must equal WORLD_SIZE.  One process
@@ -66,7 +70,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="media", choices=["media", "nodejs", "alibaba", "alibaba-full", "media-split"])
+    ap.add_argument("--workload", default=None, choices=["media", "nodejs", "alibaba", "alibaba-full", "media-split"],
+                    help="default: media -- and with --gpus N > 1 also the two sharded modes (alibaba, alibaba-full, each with --verify 1) under `scale_regimes`")
+    ap.add_argument("--scale-regimes", type=int, default=1, help="--gpus N > 1 without --workload: also run the sharded modes (0 = only the media line)")
     ap.add_argument("--levels", default="1,200,1000,4000,10000,15000",
                     help="alibaba-full: the --compress_factor values every call graph is solved at (exps/exp5/run_experiment.sh:60-156)")
     ap.add_argument("--n-in", type=int, default=100000, help="requests per service unit (media / nodejs)")
@@ -96,7 +102,11 @@ def parse_args():
                          "rocprofv3 passes do not spend a minute each importing torch on a fresh box")
     ap.add_argument("--lib", default=None, help="TESTING ONLY: path of an alternative build of libtwgpu (the host-emulation "
                                                 "library of tests/hostemu); no GPU is touched then")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.default_line = args.workload is None   # the driver's line: media, plus the sharded modes when N > 1 (main)
+    if args.default_line:
+        args.workload = "media"
+    return args
 
 
 def free_port():
@@ -183,6 +193,19 @@ REGIMES = [   # (key, workload, overrides): BASELINE.json configs 3 and 4 on one
     ("media_concurrency4", "media", {"n_in": 20000, "replicas": 4, "concurrency": 4.0}),
     ("media_concurrency8", "media", {"n_in": 5000, "replicas": 4, "concurrency": 8.0}),
 ]
+# the record of the reference itself (oracle/refrun/time_reference.py, build container) that belongs to each regime's shape
+REGIME_REFERENCE = {"config3_nodejs": "nodeio", "config4_alibaba_1gpu": "alibaba", "media_concurrency4": "media", "media_concurrency8": "media"}
+
+
+def reference_record(shape):
+    """The reference's own throughput on a corpus of this shape: profiles/cpu_reference.json (one core; see cpu_baseline)."""
+    ref = os.path.join(REPO, "profiles", "cpu_reference.json")
+    if not os.path.exists(ref):
+        return None
+    r = json.load(open(ref)).get("shapes", {}).get(shape)
+    if r is None:
+        return None
+    return {k: r[k] for k in ("value", "unit", "cores", "kind", "what", "spans", "find_assignments_s", "end_to_end_accuracy_pct", "measured_in") if k in r}
 
 
 def run_regimes(args, eng, steps=3):
@@ -218,7 +241,12 @@ def run_regimes(args, eng, steps=3):
                     "repair_rounds_per_pass": float(np.mean(rounds)),
                     "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                  "frac": achieved / HBM_PEAK_GBPS, "kernel_ms": groups[dominant], "group_ms_per_launch": groups,
-                                 "algorithmic_bytes_per_launch": float(ALG_BYTES_PER_SPAN_PER_PASS * spans), "traffic": None}}
+                                 "algorithmic_bytes_per_launch": float(ALG_BYTES_PER_SPAN_PER_PASS * spans), "traffic": None},
+                    "cpu_baseline": {"reference": reference_record(REGIME_REFERENCE[key])}}
+        if key.startswith("media_concurrency"):
+            out[key]["cpu_baseline"]["note"] = ("the reference was timed on the media shape at concurrency 1.6 (at 10 x load it did not finish a "
+                                                "4000-span service in 600 s, SURVEY.md 0); beyond 14 requests in flight results are pinned "
+                                                "engine-vs-oracle only (DESIGN.md 8)")
     return out
 
 
@@ -435,55 +463,58 @@ def profile_traffic(dominant, spans_rank):
     return g["fetch_bytes_x2"] + g["write_bytes"], os.path.basename(tpaths[-1])
 
 
-def main():
-    args = parse_args()
-    if args.cpu_worker:   # a process of cpu_all_cores
-        spans, dt, _ = _cpu_sample(args, 1000)
-        print(json.dumps({"spans": spans, "seconds": dt}))
-        return
-    if args.gpus < 1:
-        sys.exit("--gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(launch_ranks(args))
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: start one rank per GPU (or let `python bench.py --gpus N` start them)" % (args.gpus, world))
-    no_torch = world == 1 and args.sync == "engine"
-    if no_torch:
-        torch = None
+class Ctx(object):
+    """What every workload of one bench process shares: the rank's place in the job, its device, the collectives."""
+
+
+def setup(args):
+    c = Ctx()
+    c.rank = int(os.environ.get("RANK", "0"))
+    c.world = int(os.environ.get("WORLD_SIZE", "1"))
+    c.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if c.world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: start one rank per GPU (or let `python bench.py --gpus N` start them)" % (args.gpus, c.world))
+    c.no_torch = c.world == 1 and args.sync == "engine"
+    if c.no_torch:
+        c.torch = None
         # (no torch to ask for a GPU: the host-emulation build of the tests is known by its file name)
-        emulated = args.lib is not None and os.path.basename(args.lib).endswith("_emu.so")
-        device = 0
+        c.emulated = args.lib is not None and os.path.basename(args.lib).endswith("_emu.so")
+        c.device = 0
     else:
         import torch
 
-        emulated = args.lib is not None and not torch.cuda.is_available()
-    if emulated:
-        device = 0
+        c.torch = torch
+        c.emulated = args.lib is not None and not torch.cuda.is_available()
+    if c.emulated:
+        c.device = 0
         os.environ.setdefault("TW_TILE", "1")
         os.environ.setdefault("TW_COOP_THREADS", "1")
-    elif no_torch:
-        pass
-    else:
-        ndev = torch.cuda.device_count()
+    elif not c.no_torch:
+        ndev = c.torch.cuda.device_count()
         if ndev < 1:
             sys.exit("bench.py: no GPU visible (the HIP engine has no CPU fallback)")
-        if args.backend == "nccl" and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > ndev:
-            sys.exit("bench.py: %d ranks on this node but only %d GPU(s) visible" % (int(os.environ.get("LOCAL_WORLD_SIZE", world)), ndev))
-        device = local_rank % ndev
-        torch.cuda.set_device(device)
-    dist = None
-    if world > 1:
+        if args.backend == "nccl" and int(os.environ.get("LOCAL_WORLD_SIZE", c.world)) > ndev:
+            sys.exit("bench.py: %d ranks on this node but only %d GPU(s) visible" % (int(os.environ.get("LOCAL_WORLD_SIZE", c.world)), ndev))
+        c.device = c.local_rank % ndev
+        c.torch.cuda.set_device(c.device)
+    c.dist = None
+    if c.world > 1:
         import torch.distributed as dist
 
+        c.dist = dist
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group(backend="nccl", device_id=c.torch.device("cuda", c.device))
         else:
             dist.init_process_group(backend="gloo")
-    red_dev = "cuda" if (args.backend == "nccl" and not emulated) else "cpu"
+    c.red_dev = "cuda" if (args.backend == "nccl" and not c.emulated) else "cpu"
+    return c
 
+
+def run_workload(args, c, primary=True):
+    """One workload on the ranks of this job: load, warm up, the timed step loop between barriers, the bench line (a dict
+    on rank 0, None elsewhere).  `primary`: the workload the driver's line is quoted on (only it carries the single-GPU
+    extras: regimes, CPU baseline, ingest / end-to-end legs)."""
+    rank, world, device, dist, torch, emulated, no_torch, red_dev = c.rank, c.world, c.device, c.dist, c.torch, c.emulated, c.no_torch, c.red_dev
     from traceweaver_amd import sharding
     from traceweaver_amd.engine import Engine
 
@@ -491,6 +522,21 @@ def main():
     split = args.workload == "media-split"
     full = args.workload == "alibaba-full"
     all_units, all_truth, wl_name = make_units(args, 1000 + (0 if strong else rank))
+    levels, unit_factor = [None], None
+    if full:
+        # exp5's load levels (exps/exp5/run_experiment.sh:60-156): every call graph at every --compress_factor; a service's load
+        # factor follows from the replica table (executor.py:1089-1097).  Every (level, service) pair is a unit of its own: the
+        # services are uploaded once per level and ALL levels are resident together -- one tw_scale_load call per step scales
+        # each copy to its level on the device, then one step solves the whole matrix (six small solves one after the other
+        # left the GPU mostly idle, and cost five more round trips through tw_scale_load)
+        from traceweaver_amd import synth, transforms
+
+        levels = [float(x) for x in args.levels.split(",")]
+        replicas_all = synth.alibaba_replicas(10, len(all_units))
+        n_base = len(all_units)
+        unit_factor = [transforms.load_factor(f, r) for f in levels for r in replicas_all]   # unit id = level index * n_base + service
+        all_units = [u for _ in levels for u in all_units]
+        all_truth = [t for _ in levels for t in all_truth]
     whole_units, whole_truth = all_units, all_truth
     part_service, part_order, part_base = [], [], []
     if split:   # every service in `world` parts (fewer if it has too few idle block boundaries)
@@ -530,24 +576,10 @@ def main():
             dist.barrier()
         sync()
 
-    levels, level_factors = [None], {}
-    if full:   # exp5's load levels: per-service load factor from the replica table (executor.py:1089-1097)
-        from traceweaver_amd import synth, transforms
-
-        levels = [float(x) for x in args.levels.split(",")]
-        replicas_all = synth.alibaba_replicas(10, len(all_units))
-        level_factors = {f: [transforms.load_factor(f, r) for r in replicas_all] for f in levels}
-
     def step():
-        """One step = every load level in turn (one for the workloads without levels): list of (t1, t2, res, gathered)."""
-        out = []
-        for f in levels:
-            if f is not None:   # the resident table, as uploaded, scaled to this level (helpers/transforms.py:10-40 on the device)
-                eng.scale_load([level_factors[f][k] for k in mine])
-            out.append(step_level())
-        return out
-
-    def step_level():
+        """One step: (t1, t2, res, gathered)."""
+        if full:   # the resident table, as uploaded, every copy scaled to its level (helpers/transforms.py:10-40 on the device)
+            eng.scale_load([unit_factor[k] for k in mine])
         if split:   # pass 1 -> gap rows of all parts on every rank -> the same refit everywhere -> pass 2
             eng.run_pass1()
             t1 = eng.timing()
@@ -572,6 +604,8 @@ def main():
     if strong and world > 1 and args.warmup > 0:
         # re-balance on measured work: enumerated tuples per unit from a first pass (candidate products span orders of
         # magnitude, the static estimate does not see them); every rank computes the same partition
+        if full:
+            eng.scale_load([unit_factor[k] for k in mine])
         eng.run_pass1()
         leaves = np.zeros(len(all_units), dtype=np.float64)
         for k, r in zip(mine, eng.results(1, fields=("leaves",))):
@@ -594,14 +628,13 @@ def main():
     t0 = time.perf_counter()
     enum_ms, sel_ms, fit_ms, pass_ms, rep_ms, rounds = [], [], [], [], [], []
     for _ in range(args.steps):
-        per_level = step()
-        for t1, t2, res, gathered in per_level:
-            enum_ms += [t1["enumerate"], t2["enumerate"]]
-            sel_ms += [t1["select"], t2["select"]]
-            rep_ms += [t1["repair"], t2["repair"]]
-            rounds += [t1["rounds"], t2["rounds"]]
-            fit_ms += [t2["fit"]]
-            pass_ms += [t1["pass"], t2["pass"]]
+        t1, t2, res, gathered = step()
+        enum_ms += [t1["enumerate"], t2["enumerate"]]
+        sel_ms += [t1["select"], t2["select"]]
+        rep_ms += [t1["repair"], t2["repair"]]
+        rounds += [t1["rounds"], t2["rounds"]]
+        fit_ms += [t2["fit"]]
+        pass_ms += [t1["pass"], t2["pass"]]
     barrier()
     dt = time.perf_counter() - t0
     stats2 = eng.results(2, fields=("unit_stats",))
@@ -616,14 +649,16 @@ def main():
         s[rank] = spans_rank
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         per_rank_spans = [int(x) for x in s.cpu().tolist()]
-        c = torch.from_numpy(np.concatenate([counters, acc_sum])).to(red_dev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        c = c.cpu().numpy()
-        counters, acc_sum = c[:4], c[4:]
-    spans_total = float(sum(per_rank_spans)) * len(levels)   # every level is a reconstruction of all spans
+        cc = torch.from_numpy(np.concatenate([counters, acc_sum])).to(red_dev)
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        cc = cc.cpu().numpy()
+        counters, acc_sum = cc[:4], cc[4:]
+    spans_total = float(sum(per_rank_spans))   # (alibaba-full: every level is a reconstruction of all spans -- its units hold them)
     acc_levels = []
     if full:
-        lv = np.array([[sum(r["correct"] for r in lr[2]), sum(r["n_in"] for r in lr[2])] for lr in per_level], dtype=np.float64)
+        lv = np.zeros((len(levels), 2), dtype=np.float64)
+        for k, r in zip(mine, res):
+            lv[k // n_base] += (r["correct"], r["n_in"])
         if world > 1:
             tl = torch.from_numpy(lv).to(red_dev)
             dist.all_reduce(tl, op=dist.ReduceOp.SUM)
@@ -645,13 +680,8 @@ def main():
         if args.verify and rank == 0 and (world > 1 or split):
             eng.load(whole_units)
             eng.set_truth(whole_truth)
-            for li, f in enumerate(levels[:-1]):   # (the last level's result is compared below)
-                eng.scale_load(level_factors[f])
-                one_step(eng, args.fit)
-                assert all(np.array_equal(g, a["parent"]) for g, a in zip(per_level[li][3], eng.results(2, fields=("parent",)))), \
-                    "sharded result differs from the single-GPU result at load level %g" % f
             if full:
-                eng.scale_load(level_factors[levels[-1]])
+                eng.scale_load(unit_factor)
             one_step(eng, args.fit)
             alone = eng.results(2, fields=("parent",))
             if split:   # stitch the parts of every service
@@ -663,6 +693,7 @@ def main():
             else:
                 verified = all(np.array_equal(g, a["parent"]) for g, a in zip(gathered, alone))
             assert verified, "sharded result differs from the single-GPU result"
+    out = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = spans_total * args.steps / dt
@@ -673,7 +704,7 @@ def main():
         dominant = max(groups, key=lambda k: groups[k] * (1 if k == "k_fit" else 2))
         alg_bytes = float(ALG_BYTES_PER_SPAN_PER_PASS) * spans_rank  # per launch of a per-pass kernel group
         achieved = alg_bytes / (groups[dominant] * 1e-3) / 1e9
-        traffic, traffic_src = (None, None) if emulated else profile_traffic(dominant, spans_rank)
+        traffic, traffic_src = (None, None) if (emulated or not primary) else profile_traffic(dominant, spans_rank)
         out = {
             "metric": "spans/sec reconstructed + assignment accuracy vs ground truth",
             "value": value, "unit": "spans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -694,11 +725,11 @@ def main():
         }
         if verified is not None:
             out["sharded_equals_single_gpu"] = bool(verified)
-        if not emulated and world == 1:
+        if primary and not emulated and world == 1:
             out["roofline"]["peak_measured"] = eng.hbm_copy_gbps()
-        if args.regimes and world == 1 and not emulated and args.workload == "media" and args.concurrency is None:
+        if primary and args.regimes and world == 1 and not emulated and args.workload == "media" and args.concurrency is None:
             out["regimes"] = run_regimes(args, eng)
-        if args.cpu_sample > 0 and world == 1:
+        if primary and args.cpu_sample > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, 1000)
             import tempfile
 
@@ -713,10 +744,54 @@ def main():
                         out["end_to_end_cached" + tag] = end_to_end(device, lib=args.lib, kind=kind, n_traces=n_traces, corpus=corpus, cache_dir=d)
             if args.end_to_end:
                 out["load_levels"] = load_levels(device, lib=args.lib)
+    eng.close()
+    if fit_eng is not None:
+        fit_eng.close()
+    return out
+
+
+SCALE_REGIMES = [   # (key, workload): what `--gpus N > 1` without --workload measures next to the weak-scaling media line
+    ("config4_alibaba_slice_sharded", "alibaba"),          # BASELINE config 4: one 1 M-span slice sharded per service, all-gather of parents
+    ("config5_alibaba_full_sharded", "alibaba-full"),      # BASELINE config 5: 15 call graphs x 6 load levels resident, one step
+]
+
+
+def main():
+    args = parse_args()
+    if args.cpu_worker:   # a process of cpu_all_cores
+        spans, dt, _ = _cpu_sample(args, 1000)
+        print(json.dumps({"spans": spans, "seconds": dt}))
+        return
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    c = setup(args)
+    out = run_workload(args, c, primary=True)
+    if args.default_line and c.world > 1 and args.scale_regimes:
+        # the driver's multi-GPU line: next to the weak-scaling media workload (no data-path collective) the two sharded modes
+        # north_star names -- strong scaling, every step ends with the all-gather of the parent arrays (RCCL on the engine's
+        # device buffers with backend nccl), each verified on rank 0 against the single-GPU result
+        import copy
+
+        regs = {}
+        for key, workload in SCALE_REGIMES:
+            a = copy.copy(args)
+            a.workload, a.verify, a.concurrency, a.replicas = workload, 1, None, None
+            a.steps, a.warmup = min(args.steps, 5), min(max(args.warmup, 1), 2)
+            r = run_workload(a, c, primary=False)
+            if c.rank == 0:
+                regs[key] = {k: r[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "config", "accuracy", "budget_windows",
+                                               "sharded_equals_single_gpu", "roofline") if k in r}
+                if "accuracy_by_level" in r:
+                    regs[key]["accuracy_by_level"] = r["accuracy_by_level"]
+        if c.rank == 0:
+            out["scale_regimes"] = regs
+    if c.rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if c.world > 1:
+        c.dist.barrier()
+        c.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

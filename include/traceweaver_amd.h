@@ -72,7 +72,10 @@ const char *tw_last_error(const tw_engine *e);
 
 /* A batch of independent units in structure-of-arrays form.
  * Replaces: the in_span_partitions / out_span_partitions / invocation_graph arguments of
- * FindAssignments (traceweaver_v3.py:1087) for each unit. */
+ * FindAssignments (traceweaver_v3.py:1087) for each unit.
+ * Initialise the whole struct to zero (`tw_batch b = {0};` / memset) before filling it in: optional members are NULL = absent,
+ * and members added by later versions of this header are appended at the end with zero meaning "as before" -- a caller that
+ * leaves them uninitialised hands tw_load_batch a garbage pointer. */
 typedef struct {
     int32_t n_units;
     const int64_t *unit_in_off; /* [n_units+1] offsets into in_start/in_end                        */

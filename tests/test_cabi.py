@@ -66,13 +66,18 @@ def test_ctypes_structures_match_the_header(tmp_path):
         assert [getattr(cls, f).offset for f in fields[c_name][1]] == [int(o) for o in offs], c_name
 
 
-def test_loading_the_library_asks_for_hardware_queues(monkeypatch):
-    """The engine's class streams need hardware queues of their own (csrc/tw_engine.hip, tw_create): loading the library exports
-    GPU_MAX_HW_QUEUES unless the user chose a value."""
+def test_loading_the_library_leaves_the_process_environment_alone(monkeypatch):
+    """The engine's class streams want hardware queues of their own (csrc/tw_engine.hip, tw_create), but GPU_MAX_HW_QUEUES holds
+    for every HIP user of the process: loading the library exports it only when the host opts in (TW_SET_HW_QUEUES=1), and never
+    over a value the user chose.  (bench.py and the executor's command line export it themselves.)"""
     from traceweaver_amd import _ffi, build
 
     path = build.build()
     monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.delenv("TW_SET_HW_QUEUES", raising=False)
+    _ffi.load(path)
+    assert "GPU_MAX_HW_QUEUES" not in os.environ
+    monkeypatch.setenv("TW_SET_HW_QUEUES", "1")
     _ffi.load(path)
     assert os.environ.get("GPU_MAX_HW_QUEUES") == "12"
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")

@@ -165,7 +165,7 @@ def test_bench_gpus_2_starts_two_ranks(emu_lib):
     """`python bench.py --gpus 2` launches its own ranks (torch.distributed.run on 127.0.0.1) -- here over gloo against
     the host-emulation build of the engine -- and reports the whole job."""
     one = _run_bench(emu_lib, "--gpus", "1", "--n-in", "1500", "--replicas", "1")
-    two = _run_bench(emu_lib, "--gpus", "2", "--backend", "gloo", "--n-in", "1500", "--replicas", "1")
+    two = _run_bench(emu_lib, "--gpus", "2", "--backend", "gloo", "--n-in", "1500", "--replicas", "1", "--scale-regimes", "0")
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
     assert two["config"]["spans_total"] == 2 * one["config"]["spans_total"] == 2 * two["config"]["spans_per_gpu"]
     assert two["budget_windows"] == 0 and 0.9 < two["accuracy"] <= 1.0
@@ -262,14 +262,29 @@ def test_one_service_split_over_two_ranks_equals_the_unsplit_run(emu_lib):
 
 def test_bench_alibaba_full_matrix_over_two_ranks_equals_one(emu_lib):
     """BASELINE.json config 5 in small: the 15 call graphs at several of exp5's load levels -- services sharded over two ranks,
-    uploaded once, scaled on the resident table per level (tw_scale_load with the per-service factor of the replica table),
-    parents gathered per level; rank 0 re-solves every level alone and the results must be identical."""
+    every (level, service) pair a unit, uploaded once, all levels resident and scaled on the device by one tw_scale_load call per
+    step (the per-service factor of the replica table), solved in one step, parents gathered; rank 0 re-solves the whole matrix
+    alone and the results must be identical."""
     r = _run_bench(emu_lib, "--gpus", "2", "--backend", "gloo", "--workload", "alibaba-full", "--total-spans", "24000",
                    "--levels", "1,4000,15000", "--verify", "1")
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["sharded_equals_single_gpu"] is True
-    assert r["config"]["spans_total"] == 3 * sum(r["config"]["spans_per_gpu"])
+    assert r["config"]["spans_total"] == sum(r["config"]["spans_per_gpu"]) and r["config"]["spans_total"] % 3 == 0   # every (level, service) is a unit
     assert list(r["accuracy_by_level"]) == ["1", "4000", "15000"] and all(0.8 < a <= 1.0 for a in r["accuracy_by_level"].values())
     assert r["budget_windows"] == 0
+
+
+def test_bench_default_line_with_two_ranks_carries_the_sharded_modes(emu_lib):
+    """`bench.py --gpus 2` without --workload (what the driver runs for its scaling record): the weak-scaling media line and,
+    under `scale_regimes`, BASELINE configs 4 and 5 -- sharded per service, parents all-gathered every step, each verified
+    against the single-GPU result on rank 0."""
+    r = _run_bench(emu_lib, "--gpus", "2", "--backend", "gloo", "--n-in", "600", "--replicas", "1", "--total-spans", "20000", "--levels", "1,4000")
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and "media" in r["config"]["workload"]
+    regs = r["scale_regimes"]
+    assert set(regs) == {"config4_alibaba_slice_sharded", "config5_alibaba_full_sharded"}
+    for v in regs.values():
+        assert v["scaling"] == "strong" and v["sharded_equals_single_gpu"] is True and v["n_gpus"] == 2 and v["budget_windows"] == 0
+        assert v["value"] > 0 and 0.8 < v["accuracy"] <= 1.0 and "frac" in v["roofline"]
+    assert list(regs["config5_alibaba_full_sharded"]["accuracy_by_level"]) == ["1", "4000"]
 
 
 def test_generated_corpus_comes_with_its_replica_table(tmp_path):

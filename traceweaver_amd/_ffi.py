@@ -73,9 +73,12 @@ EXPORTS = ["tw_create", "tw_destroy", "tw_last_error", "tw_load_batch", "tw_run_
 
 def load(path=None):
     path = path or DEFAULT_LIB
-    # hardware queues for the engine's class streams (tw_create has the measurements); read by the HIP runtime when it
-    # initialises, which in a process that also holds torch is at its first device call -- normally after this import
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+    # Hardware queues for the engine's class streams (tw_create has the measurements).  GPU_MAX_HW_QUEUES is read by the HIP
+    # runtime when it initialises and holds for every HIP user of the process (torch, RCCL): loading this library does not
+    # change it unless the host opts in with TW_SET_HW_QUEUES=1 (the applications of this repository -- bench.py, the
+    # executor's command line -- export it themselves before anything touches the device).
+    if os.environ.get("TW_SET_HW_QUEUES", "0") not in ("", "0"):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
     if not os.path.exists(path):
         raise ImportError(
             "traceweaver_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -78,12 +78,12 @@ __global__ void k_wap5_delays(Dev P, BaseDev B) {
     const TileDev Tl = P.tiles[blockIdx.x];
     const UnitDev& U = P.units[Tl.unit];
     const int x = Tl.first + threadIdx.x;
-    if (x >= U.n_in) return;
+    const bool live = x < U.n_in;   // (the lanes beyond the unit stay for the wavefront reduction below)
     const double large = (double)B.unit_maxdur[Tl.unit];
     for (int e = 0; e < U.E; e++) {
         long long d = 0;
         bool have = false;
-        if (x < (int)(U.ep_off[e + 1] - U.ep_off[e])) {
+        if (live && x < (int)(U.ep_off[e + 1] - U.ep_off[e])) {
             const int64_t sent = P.out_start[U.ep_off[e] + x];
             const int ub = in_upper(P, U, sent);
             if (ub > 0) {

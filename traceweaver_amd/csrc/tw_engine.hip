@@ -110,6 +110,7 @@ struct tw_engine {
     int64_t fit_tape_cap = 0;
     bool fit_prepared = false;              // the gap rows of the resident pass-1 result are sorted and run-length compressed
     std::vector<int32_t> fit_max_n;         // per slot min(5, #unique), 0 = nothing to fit (host copy, tw_fit_rows)
+    bool fit_max_n_valid = false;           // ... of the rows that are prepared now (cleared with fit_prepared)
     Mt19937 fit_rng;                        // stream of tw_fit_mixtures (tw_set_fit_seed; restarted by every tw_load_batch)
     uint32_t fit_seed = 0;
     int32_t* slot_unit = nullptr;
@@ -631,10 +632,11 @@ int tw_create(int device_id, tw_engine** out) {
     // The engine runs its endpoint-count classes and window classes on streams of their own (up to 8 + 3 beside its own).  The
     // runtime multiplexes a process' streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default: classes that share a queue run one
     // after the other (Alibaba-shape slice, eight classes: 9.5 / 11.2 ms per pass with 4 or 8 queues, 6.3 / 7.0 ms with 12 or 16;
-    // three classes: the same either way).  The variable is read when the runtime initialises: this takes effect if the engine is
-    // the first user of HIP in the process (command line, C callers) -- a host that initialises HIP earlier exports it itself
-    // (traceweaver_amd/_ffi.py and bench.py do, before anything touches the device).
-    setenv("GPU_MAX_HW_QUEUES", "12", 0);
+    // three classes: the same either way).  The variable is read when the runtime initialises and belongs to the whole process
+    // (torch, RCCL, other HIP libraries in it): the library does not touch it.  The applications of this repository export it
+    // before anything initialises HIP (bench.py, python -m traceweaver_amd.executor); other hosts do the same, or set
+    // TW_SET_HW_QUEUES=1 to let this call export it when it is still unset (effective if the engine is the process' first user of HIP).
+    if (env_int("TW_SET_HW_QUEUES", 0) != 0) setenv("GPU_MAX_HW_QUEUES", "12", 0);
     hipError_t s = hipSetDevice(device_id);
     if (s == hipSuccess) s = hipStreamCreate(&e->stream);
     for (int i = 0; i < EV_COUNT && s == hipSuccess; i++) s = hipEventCreate(&e->ev[i]);
@@ -676,7 +678,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     if (b->batch_size <= 0 || b->batch_size_mis <= 0) return fail(e, TW_ERR_ARG, "batch sizes must be positive");
     free_all(e);
     e->fit_rng = Mt19937(e->fit_seed);   // a batch's refit does not depend on what the engine solved before
-    e->fit_prepared = false;
+    e->fit_prepared = false; e->fit_max_n_valid = false;
     e->units.assign((size_t)b->n_units, UnitDev{});
     e->tiles.clear();
     e->gs_off_h.assign((size_t)b->n_units, 0);
@@ -978,7 +980,7 @@ int tw_run_pass1(tw_engine* e) {
     if (e->state < ST_LOADED) return fail(e, TW_ERR_STATE, "tw_run_pass1 before tw_load_batch");
     HIPCHK(hipSetDevice(e->device));
     const int rc = run_pass(e, 1);
-    e->fit_prepared = false;
+    e->fit_prepared = false; e->fit_max_n_valid = false;
     if (rc == TW_OK) e->state = ST_PASS1;
     return rc;
 }
@@ -1000,7 +1002,7 @@ int tw_set_gaps(tw_engine* e, const double* gaps) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->P.gaps, gaps, sizeof(double) * e->n_gaps, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->fit_prepared = false;
+    e->fit_prepared = false; e->fit_max_n_valid = false;
     e->state = ST_PASS1;
     return TW_OK;
 }
@@ -1021,7 +1023,7 @@ int tw_set_gaps_device(tw_engine* e, const double* dev_gaps) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->P.gaps, dev_gaps, sizeof(double) * e->n_gaps, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->fit_prepared = false;
+    e->fit_prepared = false; e->fit_max_n_valid = false;
     e->state = ST_PASS1;
     return TW_OK;
 }
@@ -1083,6 +1085,7 @@ int fit_prepare(tw_engine* e) {
     hipLaunchKernelGGL(k_fit_compress, dim3((unsigned)e->n_slots), dim3(e->coop), 0, e->stream, F);
     HIPCHK(hipGetLastError());
     e->fit_prepared = true;
+    e->fit_max_n_valid = false;   // (the host copy of the rows' distinct-value counts belongs to the rows prepared before)
     return TW_OK;
 }
 
@@ -1149,6 +1152,7 @@ int tw_fit_rows(tw_engine* e, int32_t* max_n) {
     HIPCHK(hipStreamSynchronize(e->stream));
     e->fit_max_n.assign((size_t)e->n_slots, 0);
     for (int64_t q = 0; q < e->n_slots; q++) max_n[q] = e->fit_max_n[(size_t)q] = std::min<int32_t>(uniq[(size_t)q], kMaxComp);
+    e->fit_max_n_valid = true;
     return TW_OK;
 }
 
@@ -1157,7 +1161,7 @@ int tw_fit_mixtures_tape(tw_engine* e, const double* tape, int64_t tape_len, con
     int rc = fit_check_state(e, "tw_fit_mixtures_tape");
     if (rc != TW_OK) return rc;
     HIPCHK(hipSetDevice(e->device));
-    if (!e->fit_prepared || e->fit_max_n.size() != (size_t)e->n_slots) {
+    if (!e->fit_prepared || !e->fit_max_n_valid || e->fit_max_n.size() != (size_t)e->n_slots) {
         std::vector<int32_t> tmp((size_t)e->n_slots);
         rc = tw_fit_rows(e, tmp.data());
         if (rc != TW_OK) return rc;

@@ -11,6 +11,12 @@
 // mean log-likelihood moves by less than 1e-3 (<= 100 iterations), reg_covar 1e-6; a covariance <= 0 is scikit-learn's
 // ValueError, which the reference skips (V3:777-779).
 //
+// Restated from scikit-learn 1.7.2 (the version the tests pin it against; the reference's requirements.txt names 1.5.1): the
+// diagonal covariance is avg_X2 - means^2 + reg_covar (two terms, as that version computes it -- where a component sits on a
+// single large sample value the sign of a covariance next to reg_covar = 1e-6 is rounding noise in either form, and such a
+// fit "raises" or not depending on the summation order, in scikit-learn itself too), and the first k-means++ centre is drawn
+// with `choice(n, p)` (one uniform: scikit-learn >= 1.3), which gives the draw schedule below.
+//
 // Randomness: the only random draws are the k-means++ seeds -- one uniform for the first centre (`choice(n, p)`), then
 // 2 + int(ln n) per further centre -- 1, 3, 7, 10, 13 doubles for n = 1..5, independent of the data.  They come from a
 // *tape* of uniforms: either handed over by the host (the doubles numpy's global MT19937 would have produced at that point

@@ -361,6 +361,9 @@ def run(args):
 
 
 def main(argv=None):
+    # this is an application: it asks for the hardware queues the engine's class streams want before HIP initialises
+    # (csrc/tw_engine.hip, tw_create) -- unless the user chose a value
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
     args = parse_args(argv)
     problems = unsupported(args)
     if problems:

@@ -192,7 +192,7 @@ _TABLE_COLUMNS = ("trace", "span_id", "service", "op_name", "parent", "start", "
 def _cache_key(directory, first_span, max_traces, fix, callers):
     from . import build
 
-    return json.dumps({"version": CACHE_VERSION, "loader": build.source_digest(), "dir_mtime_ns": os.stat(directory).st_mtime_ns,
+    return json.dumps({"version": CACHE_VERSION, "loader": build.source_digest(),
                        "first_span": first_span, "max_traces": int(max_traces), "fix": fix,
                        "callers": sorted((NODEJS_CALLERS if callers is None else callers).items()) if fix == "client_twins" else None}, sort_keys=True)
 
@@ -211,11 +211,21 @@ def _write_arrays(path, header, arrays):
         at += (a.nbytes + 63) // 64 * 64
     head = json.dumps(dict(header, arrays=directory)).encode()
     pad = (-(len(_CACHE_MAGIC) + 8 + len(head))) % 64
-    with open(path, "wb") as f:
-        f.write(_CACHE_MAGIC + np.uint64(len(head) + pad).tobytes() + head + b" " * pad)
-        for name, a in arrays.items():
-            f.write(a.tobytes())
-            f.write(b"\0" * ((-a.nbytes) % 64))
+    # never rewritten in place: readers hand out views of a memory map of the file (several executors of one exps script
+    # share a data directory) -- the new file replaces the old name, a running reader keeps the old inode
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    try:
+        with open(tmp, "wb") as f:
+            f.write(_CACHE_MAGIC + np.uint64(len(head) + pad).tobytes() + head + b" " * pad)
+            for name, a in arrays.items():
+                f.write(a.tobytes())
+                f.write(b"\0" * ((-a.nbytes) % 64))
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    m = os.stat(os.path.dirname(path) or ".").st_mtime_ns   # the directory's modification time after the rename: the file carries
+    os.utime(path, ns=(m, m))                               # it as its own (see _cache_fresh)
 
 
 def _read_arrays(path):
@@ -290,11 +300,16 @@ class CachedCorpus(object):
         return out, dict(self._skipped), int(self._n_traces)
 
 
+def _cache_fresh(directory, path):
+    """The cache file carries the directory's modification time as it was right after the file was put in place: entries
+    added to, removed from or renamed in the directory since then have moved it on.  Like the reference's cache of a
+    directory (its time-ordered file list, executor.py:320-339) this does not see a trace file edited in place."""
+    return os.stat(directory).st_mtime_ns == os.stat(path).st_mtime_ns
+
+
 def _save_cache(corpus, directory, key_args, counts):
-    """Writes the cache of a freshly loaded directory.  The file is created first and the key taken afterwards: creating it is
-    what changes the directory's modification time, rewriting it does not."""
+    """Writes the cache of a freshly loaded directory (to a temporary name, then renamed over the cache file)."""
     path = os.path.join(directory, CACHE_FILE)
-    open(path, "ab").close()
     key = _cache_key(directory, *key_args)
     raw = corpus._unit_set_arrays()
     table = corpus.span_table()
@@ -329,7 +344,7 @@ def open_directory(directory, lib_path=None, first_span=None, max_traces=1001, f
             cache = False
     if cache and os.path.exists(path):
         try:
-            meta, z = _read_arrays(path)
+            meta, z = _read_arrays(path) if _cache_fresh(directory, path) else ({}, None)
             if meta.get("key") == _cache_key(directory, *key_args):
                 c = CachedCorpus(meta, z)
                 return c, c.counts()
@@ -341,6 +356,6 @@ def open_directory(directory, lib_path=None, first_span=None, max_traces=1001, f
     if cache:
         try:
             _save_cache(corpus, directory, key_args, counts)
-        except OSError:
+        except Exception:   # read-only directory, disk full, ...: a problem with the cache never fails the run
             pass
     return corpus, counts

@@ -90,6 +90,12 @@ class TraceWeaverGPU(object):
         reproduces a seeded reference run, and leaves the RNG where the reference leaves it for the next service."""
         self.all_spans = all_spans
         self.all_processes = all_processes
+        if fit == "sklearn":   # the cross-check consumes numpy's RNG as the installed scikit-learn does: the draw schedule the
+            import sklearn     # device refit replays (1, 3, 7, 10, 13 uniforms for 1..5 components) is that of scikit-learn >= 1.3
+
+            if tuple(int(x) for x in sklearn.__version__.split(".")[:2]) < (1, 3):
+                warnings.warn("scikit-learn %s draws its k-means++ seeds on another schedule than the device refit replays "
+                              "(>= 1.3): fit='sklearn' and fit='device' will not reproduce each other" % sklearn.__version__)
         self.fit = fit
         self.replay_true_fit = replay_true_fit
         self._engine = Engine(device, lib_path=lib_path)
