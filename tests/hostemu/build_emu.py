@@ -23,7 +23,8 @@ def build(force=False, production=False):
         "-DTW_BIG_PRODUCT=40", "-DTW_SPLIT_MIN=96", "-DTW_SPLIT_GRAIN=24", "-DTW_GRID_TARGET=16",   # enumerations are split from ~100 grid points on, prefixes walked
         "-DTW_FRONTIER_CAP=512", "-DTW_FRONTIER_BIG_CAP=8192", "-DTW_FRONTIER_BIG_SLOTS=3",   # small lists: own buffers, pool slots and the walk all occur in the tests
         "-DTW_MATCH_NODES_1=48", "-DTW_MATCH_NODES=256",
-        "-DTW_TILE_SMALL", "-DTW_TILE_MAX=24"]   # the tile kernel: short slices (windows beyond them go to the wavefront kernel), several segments per tile   # the selection search consults the matching relaxation early
+        "-DTW_TILE_SMALL", "-DTW_TILE_MAX=24",
+        "-DTW_PRUNE_MIN=48", "-DTW_PRUNE_GRID=8"]   # the wavefront kernel's walk is pruned from 48 grid points on   # the tile kernel: short slices (windows beyond them go to the wavefront kernel), several segments per tile   # the selection search consults the matching relaxation early
     subprocess.check_call(
         ["g++", "-x", "c++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
          # the emulated LDS arrays are static locals of kernel templates: as GNU-unique symbols the two builds of this library

@@ -88,6 +88,7 @@ struct Dev {
     int32_t* unit_ndirty;
     int32_t* tk_n;      // candidates found on all spans (top_k_2)
     int64_t* leaves;
+    int64_t* leaves0;   // tuples of the first solve (on all spans) as counted in pass 1: the same in pass 2, whose pruned walks do not recount them
     int32_t* chosen;
     uint8_t* rep;       // 1 <=> candidate list was recomputed with consumed spans masked out
     int32_t* tkr_n;

@@ -832,7 +832,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.pm_val, n_in_total); ALLOC(P.pm_idx, n_in_total); ALLOC(P.pc, n_in_total + 1); ALLOC(P.seg, n_in_total);
     ALLOC(P.win_end, n_in_total); ALLOC(P.wid, n_in_total); ALLOC(P.w_last, n_in_total);
     ALLOC(P.unit_nwin, P.n_units); ALLOC(P.w_dirty, n_in_total); ALLOC(P.w_conf, n_in_total);
-    ALLOC(P.tk_n, n_in_total); ALLOC(P.leaves, n_in_total); ALLOC(P.chosen, n_in_total); ALLOC(P.rep, n_in_total);
+    ALLOC(P.tk_n, n_in_total); ALLOC(P.leaves, n_in_total); ALLOC(P.leaves0, n_in_total); ALLOC(P.chosen, n_in_total); ALLOC(P.rep, n_in_total);
     ALLOC(P.tkr_n, n_in_total);
     ALLOC(P.tk_idx, ie * kTopK); ALLOC(P.tkr_idx, ie * kTopK);
     ALLOC(P.tk_score, n_in_total * kTopK); ALLOC(P.tkr_score, n_in_total * kTopK);

@@ -565,6 +565,13 @@ constexpr int kGridTarget = TW_GRID_TARGET;     // grid points per prefix the sp
 // leaves most lanes idle (0.1 % of the grid is feasible).  Such a span first lists its feasible tuples, level by level
 // (see the kernel), in the reference's depth-first order, and then scores them a wavefront at a time.
 constexpr long long kFrontierGrid = 1 << 15;   // from this many grid points (staged candidates) on, and E >= 3
+// Long enumerations are walked with an upper bound (see "bounds of the pruned walk" in the kernel): from this many grid points on
+#ifndef TW_PRUNE_MIN
+#define TW_PRUNE_MIN 1024
+#define TW_PRUNE_GRID 128
+#endif
+constexpr long long kPruneMin = TW_PRUNE_MIN;
+constexpr int kPruneGrid = TW_PRUNE_GRID;    // grid points per prefix the split of the endpoints aims at when the walk is pruned (finer prefixes: more to cut)
 #ifndef TW_FRONTIER_CAP
 #define TW_FRONTIER_CAP (1 << 15)
 #define TW_FRONTIER_BIG_CAP (1 << 21)
@@ -594,6 +601,8 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
     __shared__ int32_t keep_idx[kTopK][E];      // staged positions of the kept entries otherwise
     __shared__ int32_t px[E];                   // the prefix the wavefront is walking (staged positions, same for every lane)
     __shared__ int64_t pxs[E], pxe[E];
+    __shared__ double pxp[E];                   // ... and the sum of the score terms its levels 0..d determine (pruned walk)
+    __shared__ double sbound[E + 1];            // upper bound of the terms the levels d.. can add (pruned walk)
     const int t = threadIdx.x, nt = blockDim.x;
     const int n_big = part == 2 ? 0 : P.heavy_big_count[E];   // (both instantiations walk the list of long enumerations; each takes its own)
     const int count = n_big + (part == 1 ? 0 : P.heavy_in_count[kList]);
@@ -751,6 +760,82 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                 }
             }
         }
+        // ---- bounds of the pruned walk.  A tuple's score is a sum of tabulated terms: per endpoint the root term or the terms of
+        // its primary in-edges (fixed once the endpoint and its predecessors are chosen), plus ONE closing term (of whichever
+        // span ends last).  For a prefix x_0..x_d the real number  P_d + sbound[d+1] + max closing term,  P_d = the terms the
+        // prefix determines, sbound[d+1] = per remaining endpoint the largest value its terms can take, bounds the exact
+        // score of every tuple below the prefix.  The scores themselves are binary64 sums in the reference's order; they differ
+        // from the exact sums by at most (2E + 1) ulp-sized errors of the partial sums -- `margin` (1e-12 of the sum of the
+        // largest |term| per position) covers both that and the rounding of the bound, with three orders of magnitude to spare.
+        // A prefix is cut when bound + margin < threshold STRICTLY, threshold = a score that five distinct tuples are known to
+        // reach: the fifth kept score, or thr0 -- the fifth largest score of up to 64 distinct tuples built greedily from the
+        // best two candidates per endpoint before the walk starts.  Every tuple that reaches the final fifth score is still
+        // visited (thresholds only rise towards it), so the kept five and the check for undecided ties see what the full walk
+        // sees.  In the replay of CPython's heap (second attempt) the threshold is the heap's current minimum: a tuple strictly
+        // below it is a no-op there (see the batch loop), so skipping it changes nothing either.
+        // What the cut tuples would have added to the tuple count and the candidate bitmap must be known without visiting them:
+        // without call-order constraints every grid point is a tuple (closed form); in pass 2 the first solve has the same
+        // tuples as in pass 1 (leaves0).  Otherwise the walk is not pruned.
+        bool prune = false;
+        double mclose = -dinf(), margin = 0.0, thr0 = -dinf();
+        long long tail[E];   // tuples below a prefix that ends at level d when every grid point is one: the product of the later counts
+        uint32_t any_order = 0;
+        {
+            long long grid = 1;
+#pragma unroll
+            for (int e = E - 1; e >= 0; e--) { tail[e] = grid; grid = grid < (1ll << 40) ? grid * cn[e] : grid; any_order |= dag_pm[e]; }
+            const bool countable = any_order == 0 || (pass == 2 && mode == 0);
+            if (E >= 2 && grid >= kPruneMin && countable && !U.skip) {
+                auto wave_max = [&](double v) -> double {
+                    for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(v, off); v = o > v ? o : v; }
+                    return v;
+                };
+                bool tables = true;
+                double aabs = 0.0, aclose = 0.0, ube[E];
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    double m = -dinf(), a = 0.0, mc = -dinf(), ac = 0.0;
+                    for (int c = t; c < cn[e]; c += nt) {
+                        const double vr = troot[e][c], vc = tclose[e][c];
+                        m = vr > m ? vr : m; a = fabs(vr) > a ? fabs(vr) : a;
+                        mc = vc > mc ? vc : mc; ac = fabs(vc) > ac ? fabs(vc) : ac;
+                    }
+                    m = wave_max(m); a = wave_max(a); mc = wave_max(mc); ac = wave_max(ac);
+                    mclose = mc > mclose ? mc : mclose;
+                    aclose = ac > aclose ? ac : aclose;   // (one closing term per tuple: its largest magnitude counts once)
+                    ube[e] = dag_np[e] == 0 ? m : 0.0;
+                    double ae = dag_np[e] == 0 ? a : 0.0;
+#pragma unroll
+                    for (int j = 0; j < E; j++) {
+                        if (j >= (int)dag_np[e]) continue;
+                        const uint32_t pj = (dag_pl[e] >> (4 * j)) & 15u;
+                        if (!(pj & 8u)) continue;
+                        const int p = (int)(pj & 7u);
+                        const int off = (int)tp_off[e][j];
+                        if (off < 0) { tables = false; continue; }
+                        int cp = 0;
+#pragma unroll
+                        for (int q = 0; q < E; q++) if (q == p) cp = cn[q];
+                        double mp = -dinf(), ap = 0.0;
+                        for (int q = t; q < cp * cn[e]; q += nt) {
+                            const int a2 = q / cn[e], b2 = q % cn[e];
+                            if (le[p][a2] <= ls[e][b2]) { const double v = tpair[off + q]; mp = v > mp ? v : mp; ap = fabs(v) > ap ? fabs(v) : ap; }
+                        }
+                        ube[e] += wave_max(mp);
+                        ae += wave_max(ap);
+                    }
+                    aabs += ae;
+                }
+                aabs += aclose;
+                double sb = 0.0;
+                if (t == 0) sbound[E] = 0.0;
+#pragma unroll
+                for (int e = E - 1; e >= 0; e--) { sb += ube[e]; if (t == 0) sbound[e] = sb; }
+                margin = aabs * 1.0e-12 + 1.0e-300;
+                prune = tables && aabs < dinf() && aabs == aabs;
+            }
+        }
+        wave_sync();
         // Python orders (score, [spans]) tuples by score, then by start_mus of the first differing span; two
         // tuples whose first differing spans start at the same time are "equivalent" (neither is less), and
         // only then does the outcome of heapq / list.sort depend on the order of the pushes.  First attempt:
@@ -767,10 +852,11 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         int n_front = 0;
         const unsigned long long* front = nullptr;
         if constexpr (E >= 3) {
-            long long grid = 1;
-            uint32_t any_order = 0;   // without call-order constraints every grid point is a tuple: nothing to gain from listing them
+            long long grid = 1;   // (without call-order constraints every grid point is a tuple: nothing to gain from listing them;
+                                  // a pruned walk -- pass 2: the tuple count is known -- visits far fewer tuples than the list holds)
 #pragma unroll
-            for (int e = 0; e < E; e++) { grid = grid < (1ll << 40) ? grid * cn[e] : grid; any_order |= dag_pm[e]; }
+            for (int e = 0; e < E; e++) grid = grid < (1ll << 40) ? grid * cn[e] : grid;
+            if (prune) grid = 0;
             if (grid >= kFrontierGrid && any_order != 0 && !U.skip && front_slot < 0 && front_slot != -2) {
                 // the first such span of this wavefront claims one of the kFrontierSlots buffer pairs (kernels of several
                 // classes run side by side: the block index does not identify a wavefront across them)
@@ -836,6 +922,80 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         LdsHeap<E, W> hp;
         hp.heap = sheap; hp.nheap = 0; hp.ls = ls;
         wave_sync();
+        if (prune) {
+            // thr0: up to 64 distinct tuples, lane t taking at endpoint e (in call order) the best -- or, where bit e of t is set,
+            // the second best -- admissible candidate by the terms the endpoint adds given the lane's earlier choices; their scores in
+            // the reference's order of additions; the fifth largest.  (Two lanes differ at the first endpoint where their bits
+            // differ, so the tuples are distinct; a lane that finds no candidate drops out.)
+            constexpr int NB = E < 6 ? E : 6;
+            bool valid = t < (1 << NB);
+            int32_t x[E];
+            int64_t xs[E], xe[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                double best = -dinf(), second = -dinf();
+                int bi = -1, si = -1;
+                for (int c = 0; c < cn[e]; c++) {
+                    const int64_t st = ls[e][c];
+                    bool ok = valid;
+                    double v = dag_np[e] == 0 ? troot[e][c] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < E; j++) {
+                        if (j >= (int)dag_np[e]) continue;
+                        const uint32_t pj = (dag_pl[e] >> (4 * j)) & 15u;
+                        const int p = (int)(pj & 7u);
+                        int64_t pend = 0;
+                        int xp = 0;
+#pragma unroll
+                        for (int q = 0; q < E; q++) if (q == p) { pend = xe[q]; xp = x[q]; }
+                        if (pend > st) ok = false;
+                        else if (pj & 8u) v += tpair[(int)tp_off[e][j] + xp * cn[e] + c];
+                    }
+                    if (ok) {
+                        if (v > best) { second = best; si = bi; best = v; bi = c; }
+                        else if (v > second) { second = v; si = c; }
+                    }
+                }
+                const int pick = (e < NB && ((t >> e) & 1)) ? si : bi;
+                if (pick < 0) valid = false;
+                x[e] = pick < 0 ? 0 : pick;
+                xs[e] = ls[e][x[e]]; xe[e] = le[e][x[e]];
+            }
+            double score = 0.0;
+            if (valid) {   // ScoreAssignmentAsPerInvocationGraph (traceweaver_v1.py:305-361) from the term tables, as in the walk below
+                int last = 0;
+                int64_t last_end = xe[0];
+#pragma unroll
+                for (int e = 1; e < E; e++) if (xe[e] > last_end) { last_end = xe[e]; last = e; }
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int np = (int)dag_np[e];
+#pragma unroll
+                    for (int j = 0; j < E; j++) {
+                        if (j >= np) continue;
+                        const uint32_t pj = (dag_pl[e] >> (4 * j)) & 15u;
+                        if (!(pj & 8u)) continue;
+                        const int p = (int)(pj & 7u);
+                        int xp = 0;
+#pragma unroll
+                        for (int q = 0; q < E; q++) if (q == p) xp = x[q];
+                        score += tpair[(int)tp_off[e][j] + xp * cn[e] + x[e]];
+                    }
+                    if (np == 0) score += troot[e][x[e]];
+                    if (e == last) score += tclose[e][x[e]];
+                }
+            }
+            double rest = valid ? score : -dinf();
+            const int nvalid = __popcll(__ballot(valid));
+            for (int r = 0; r < kTopK; r++) {
+                double m = rest;
+                for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(m, off); m = o > m ? o : m; }
+                thr0 = m;
+                const unsigned long long at = __ballot(valid && rest == m);
+                if (at != 0ull && t == __ffsll((long long)at) - 1) rest = -dinf();
+            }
+            if (nvalid < kTopK) thr0 = -dinf();
+        }
         TW_PHASE(2);
         // candidate spans that occur in a feasible tuple (pass 1): every lane collects its own in registers and adds them
         // to the bitmap in LDS once per span -- one same-address LDS atomic per lane, endpoint and BATCH was a fifth of the walk
@@ -858,13 +1018,14 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         // the lanes.  L is the deepest split that gives a prefix about kGridTarget grid points (< kGridTarget * 128).
         int L = E - 1;
         int G = cn[E - 1];
+        const int gtarget = prune ? kPruneGrid : kGridTarget;
 #pragma unroll
         for (int e = E - 2; e >= 0; e--)
-            if (L == e + 1 && G * cn[e] <= kGridTarget * 2 && G < kGridTarget) { L = e; G *= cn[e]; }
+            if (L == e + 1 && G * cn[e] <= gtarget * 2 && G < gtarget) { L = e; G *= cn[e]; }
         if (G < kHeavyThreads) {   // at least a wavefront of grid points whenever the product allows it
 #pragma unroll
             for (int e = E - 2; e >= 0; e--)
-                if (L == e + 1 && G < kHeavyThreads) { L = e; G *= cn[e]; }
+                if (L == e + 1 && G < kHeavyThreads && (!prune || e >= 1)) { L = e; G *= cn[e]; }   // (a pruned walk keeps at least one level to cut at)
         }
         if (use_front) { L = E; G = 1; }   // the tuples are listed: no walk, no grid
         // a part walks its share of the first level; if that level is inside the grid (short enumerations only: never with the
@@ -911,6 +1072,12 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
             }
             return 0;
         };
+        auto cd_full = [&](int dd) -> int {
+            int v = 0;
+#pragma unroll
+            for (int e = 0; e < E; e++) if (e == dd) v = cn[e];
+            return v;
+        };
         int d = 0;
         if (L > 0 && t == 0) px[0] = w0_begin - 1;
         wave_sync();
@@ -926,16 +1093,41 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                 int c = px[d] + 1;
                 bool found = false;
                 int64_t fst = 0, fen = 0;
+                double fpp = 0.0;
+                // the threshold a tuple must reach to matter (see "bounds of the pruned walk")
+                double thr = -dinf();
+                if (prune) {
+                    if (exact_replay) { if (__shfl(hp.nheap, 0) == kTopK) thr = sheap[0].score; }
+                    else { thr = nk == kTopK ? ts[kTopK - 1] : -dinf(); thr = thr0 > thr ? thr0 : thr; }
+                }
+                uint32_t npd = 0, pld = 0;
+                long long taild = 0;
+#pragma unroll
+                for (int e = 0; e < E; e++) if (e == d) { npd = dag_np[e]; pld = dag_pl[e]; taild = tail[e]; }
                 for (; c < cd; c++) {
                     const int64_t st = ls[d][c];
                     bool ok = true;
                     for (int p = 0; p < d; p++)
                         if (((pmd >> p) & 1) && pxe[p] > st) { ok = false; break; }
-                    if (ok) { fst = st; fen = le[d][c]; found = true; break; }
+                    if (!ok) continue;
+                    if (prune) {
+                        double pp = d > 0 ? pxp[d - 1] : 0.0;
+                        if (npd == 0) pp += troot[d][c];
+                        for (int j = 0; j < (int)npd; j++) {
+                            const uint32_t pj = (pld >> (4 * j)) & 15u;
+                            if (pj & 8u) pp += tpair[(int)tp_off[d][j] + px[pj & 7u] * cd_full(d) + c];
+                        }
+                        if (pp + sbound[d + 1] + mclose + margin < thr) {   // nothing below this prefix reaches the threshold
+                            if (any_order == 0) leaves += taild;            // ... every grid point below it is a tuple
+                            continue;
+                        }
+                        fpp = pp;
+                    }
+                    fst = st; fen = le[d][c]; found = true; break;
                 }
                 wave_sync();   // every lane has read px[d] before it changes
                 if (!found) { d--; continue; }
-                if (t == 0) { px[d] = c; pxs[d] = fst; pxe[d] = fen; }
+                if (t == 0) { px[d] = c; pxs[d] = fst; pxe[d] = fen; pxp[d] = fpp; }
                 if (d < L - 1) {
                     d++;
                     if (t == 0) px[d] = -1;
@@ -1139,7 +1331,15 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
             for (int e = 0; e < E; e++)
 #pragma unroll
                 for (int w = 0; w < kBitWords; w++) if (mybits[e][w] != 0ull) atomicOr(&sbits[e][w], mybits[e][w]);
+            if (prune) {   // (no call-order constraints: every staged candidate occurs in a tuple, visited or cut)
+#pragma unroll
+                for (int e = 0; e < E; e++)
+                    for (int c = t; c < cn[e]; c += nt) { const int r = lr[e][c]; atomicOr(&sbits[e][r >> 6], 1ull << (r & 63)); }
+            }
         }
+        // the tuples of the first solve are the same in both passes: where the pruned walk of pass 2 did not count them (call-order
+        // constraints: the cut prefixes' tuples are not a product), the count of pass 1 stands
+        if (prune && any_order != 0) leaves = nparts > 1 ? 0 : P.leaves0[U.in_off + i];
         wave_sync();
         TW_PHASE(3);
         if (t == 0) {
@@ -1179,7 +1379,10 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
             int32_t* out_n = mode == 1 ? P.tkr_n : P.tk_n;
             int32_t* out_idx = mode == 1 ? P.tkr_idx : P.tk_idx;
             double* out_score = mode == 1 ? P.tkr_score : P.tk_score;
-            if (t == 0) { out_n[g] = nout; (mode == 1 ? P.leaves_r : P.leaves)[g] = leaves; P.rep[g] = (uint8_t)mode; }
+            if (t == 0) {
+                out_n[g] = nout; (mode == 1 ? P.leaves_r : P.leaves)[g] = leaves; P.rep[g] = (uint8_t)mode;
+                if (mode == 0 && pass == 1) P.leaves0[g] = leaves;
+            }
             for (int q = t; q < kTopK * (E + 1); q += nt) {
                 const int k = q / (E + 1), f = q % (E + 1);
                 if (mode == 0 && k >= nout) continue;  // unused entries keep the -1 / NaN pattern they were given at load time
@@ -1283,6 +1486,8 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
             }
         } else {
             const int64_t g = U.in_off + i;
+            if (pass == 1) { if (t == 0) P.leaves0[g] = leaves; }
+            else leaves = P.leaves0[g];   // (a pruned part of pass 2 does not count what it cuts: same tuples as in pass 1)
             if (t == 0) { P.tk_n[g] = total < kTopK ? total : kTopK; P.leaves[g] = leaves; P.rep[g] = 0; }
             for (int a = t; a < C; a += nt) {   // entries a span does not have keep the -1 / NaN pattern of tw_load_batch
                 const int k = rk[a];

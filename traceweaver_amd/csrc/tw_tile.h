@@ -468,6 +468,7 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
             const int leaves = s_leaves[t];
             P.tk_n[g] = leaves < kTopK ? leaves : kTopK;
             P.leaves[g] = leaves;
+            if (pass == 1) P.leaves0[g] = leaves;
             P.rep[g] = 0;
             if (pass == 1) {
 #pragma unroll
