@@ -690,7 +690,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         const int64_t n = b->unit_in_off[u + 1] - b->unit_in_off[u];
         if (E < 1 || E > TW_MAX_EP) return fail(e, TW_ERR_UNSUPPORTED, "unit has E outside [1, TW_MAX_EP]");
         if (n < 2) return fail(e, TW_ERR_ARG, "a unit needs at least 2 incoming spans (the reference raises on max([]) for 1, traceweaver_v3.py:1119)");
-        if (n > 0x7fffffff / 16) return fail(e, TW_ERR_ARG, "unit too large");
+        if (n > (1 << 26)) return fail(e, TW_ERR_ARG, "unit too large (more than 2^26 incoming spans: the selection work lists address a window's first span in 26 bits)");
         U.in_off = b->unit_in_off[u];
         U.tscale = b->unit_time_scale != nullptr ? b->unit_time_scale[u] : 1.0;
         U.float_time = b->unit_time_scale != nullptr ? 1 : 0;

@@ -2227,9 +2227,24 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
     TW_SEL_T0();
     for (int q = t; q < m * kTopK; q += nt) {
         const int b = q / kTopK, k = q % kTopK;
-        const int n = cand_n(P, U, first + b);
-        L.w[b][k] = k < n ? sel_weight(cand_score(P, U, first + b, k)) : 0;
-        for (int e = 0; e < E; e++) L.idx[b][k][e] = k < n ? cand_idx(P, U, first + b, k, e) : -1 - q;
+        // all loads of the candidate at once, from the list on all spans (nearly every span's current list): one memory round
+        // trip; a span whose list was recomputed without the spans earlier windows took (rep) reads that one afterwards
+        const int64_t g = U.in_off + first + b;
+        const uint8_t rep = P.rep[g];
+        int n = P.tk_n[g];
+        double sc = P.tk_score[tks_index(U, k, first + b)];
+        int32_t ix[kMaxEp];
+#pragma unroll
+        for (int e = 0; e < kMaxEp; e++) ix[e] = e < E ? P.tk_idx[tk_index(U, k, e, first + b)] : 0;
+        if (rep) {
+            n = P.tkr_n[g];
+            sc = P.tkr_score[tks_index(U, k, first + b)];
+#pragma unroll
+            for (int e = 0; e < kMaxEp; e++) ix[e] = e < E ? P.tkr_idx[tk_index(U, k, e, first + b)] : 0;
+        }
+        L.w[b][k] = k < n ? sel_weight(sc) : 0;
+#pragma unroll
+        for (int e = 0; e < kMaxEp; e++) if (e < E) L.idx[b][k][e] = k < n ? ix[e] : -1 - q;
         if (k == 0) { L.ncand[b] = (uint8_t)n; L.comp[b] = (uint8_t)b; L.pick[b] = -1; }
     }
     if (t == 0) { L.budget_hit = 0; L.nodes_total = 0ull; }
@@ -2381,9 +2396,10 @@ __device__ __forceinline__ int32_t* sel_counter(const Dev& P, int list, int s) {
 // (called by the per-span kernels, one workgroup per tile: blockIdx.x is the tile)
 __device__ __forceinline__ void list_window(const Dev& P, const UnitDev& U, int unit, int w, bool listed) {
     int cls = -1;   // 0 short (<= kBruteMax), 1 long (kBigWindow ..), 2 middle, 3 very long (kHugeWindow ..)
+    int first = 0, m = 0;
     if (listed) {
-        const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
-        const int m = P.w_last[U.in_off + w] - first + 1;
+        first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
+        m = P.w_last[U.in_off + w] - first + 1;
         cls = m <= kBruteMax ? 0 : (m < kBigWindow ? 2 : (m < kHugeWindow ? 1 : 3));
     }
     const int s = (int)((long long)blockIdx.x * kSelSeg / gridDim.x);
@@ -2395,8 +2411,10 @@ __device__ __forceinline__ void list_window(const Dev& P, const UnitDev& U, int 
     // (a segment has room for every window of its tiles)
     int32_t *au = (cls == 0 || cls == 3) ? P.tiny_unit : P.heavy_unit, *aw = (cls == 0 || cls == 3) ? P.tiny_win : P.heavy_win;
     const int pos = cls == 0 ? base + s0 : (cls == 1 ? base + s1 : (cls == 2 ? end - 1 - s2 : end - 1 - s3));
+    // (the window as its first span and its size, 26 + 6 bits: the consumer's chain of dependent loads -- item, unit, window
+    // bounds, candidates -- is what a short window costs)
     au[pos] = unit;
-    aw[pos] = w;
+    aw[pos] = (int32_t)(((uint32_t)first << 6) | (uint32_t)(m - 1));
 }
 
 // Consumers: the segment counts of one list as prefix sums in LDS (first[kSelSeg] = the list's size), and the position of item i
@@ -2491,10 +2509,10 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
         }
         const int pos = sel_position(P, G, item, LIST != 1);
         const int32_t *au = LIST == 3 ? P.tiny_unit : P.heavy_unit, *aw = LIST == 3 ? P.tiny_win : P.heavy_win;
-        const int unit = __builtin_amdgcn_readfirstlane(au[pos]), w = __builtin_amdgcn_readfirstlane(aw[pos]);  // wave-uniform: scalar loads below
+        const int unit = __builtin_amdgcn_readfirstlane(au[pos]);  // wave-uniform: scalar loads below
+        const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane(aw[pos]);
         const UnitDev& U = P.units[unit];
-        const int last = P.w_last[U.in_off + w];
-        const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
+        const int first = (int)(fm >> 6), last = first + (int)(fm & 63u);
 #ifdef TW_PROFILE_SEL
         const long long _w0 = wall_clock64();
 #endif
@@ -2534,10 +2552,10 @@ __global__ void __launch_bounds__(64) k_select_tiny(Dev P) {  // persistent work
         if (chunk_pos >= count) { TW_SEL_FLUSH(); break; }
         const int item = chunk_pos++;
         const int pos = sel_position(P, G, item, false);
-        const int unit = __builtin_amdgcn_readfirstlane(P.tiny_unit[pos]), w = __builtin_amdgcn_readfirstlane(P.tiny_win[pos]);
+        const int unit = __builtin_amdgcn_readfirstlane(P.tiny_unit[pos]);
+        const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane(P.tiny_win[pos]);
         const UnitDev& U = P.units[unit];
-        const int last = P.w_last[U.in_off + w];
-        const int first = w == 0 ? 0 : P.w_last[U.in_off + w - 1] + 1;
+        const int first = (int)(fm >> 6), last = first + (int)(fm & 63u);
         select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS);
     }
 }
