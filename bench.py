@@ -444,6 +444,50 @@ def end_to_end(device, lib=None, n_traces=20000, threads=0, kind="hotel", repeat
                         else "JSON files -> native ingest", kind, repeats))}
 
 
+def shipped_corpora(device, lib=None, repeats=5):
+    """What a user of exps/exp1 has: every service of the 23 corpora the reference ships (1000 traces each), here the inputs the
+    reference's executor handed its predictor in the frozen runs (tests/golden/ref_*.npz -- the data directory itself is not on
+    the GPU box) -- all 90 services in ONE batch: pass 1 -> refit -> pass 2 -> parents on the host, best of `repeats`; beside it
+    the reference's own FindAssignments wall time for the same services (recorded when the goldens were frozen: one core of the
+    build container, HiGHS in place of Gurobi).  Small inputs: a solve is a chain of dependent launches, not throughput."""
+    import glob
+
+    from traceweaver_amd.engine import Engine, UnitArrays
+
+    files = sorted(glob.glob(os.path.join(REPO, "tests", "golden", "ref_*__*.npz")))
+    if not files:
+        return None
+    units, truth, ref_wall = [], [], 0.0
+    for f in files:
+        d = np.load(f)
+        order = [str(x) for x in d["partition_key_order"]]
+        key_rank = np.array([order.index(str(e)) for e in d["out_eps"]], dtype=np.int32)
+        units.append(UnitArrays(d["in_start"], d["in_start"] + d["in_dur"], d["out_off"], d["out_start"], d["out_start"] + d["out_dur"], d["dag"], key_rank))
+        truth.append(np.asarray(d["true_parent"], dtype=np.int32))
+        ref_wall += float(d["ref_wall_s"])
+    spans = int(sum(u.n_spans for u in units))
+    eng = Engine(device, lib_path=lib)
+    runs = []
+    for _ in range(repeats + 1):
+        t0 = time.perf_counter()
+        eng.load(units)
+        t1 = time.perf_counter()
+        eng.run_pass1()
+        eng.fit_mixtures()
+        eng.run_pass2()
+        parents = eng.results(2, fields=("parent",))
+        runs.append((time.perf_counter() - t1, t1 - t0))
+    eng.close()
+    solve, load = min(runs[1:])
+    acc = float(np.mean([np.all(p["parent"] == tp, axis=0).mean() for p, tp in zip(parents, truth)]))
+    return {"services": len(units), "corpora": len({os.path.basename(f).split("__")[0] for f in files}), "spans": spans,
+            "solve_s": solve, "load_s": load, "value": spans / solve, "unit": "spans/s", "accuracy_mean_per_service": acc,
+            "reference": {"find_assignments_s": ref_wall, "value": spans / ref_wall, "unit": "spans/s", "cores": 1,
+                          "what": "sum of the reference's FindAssignments wall times for the same 90 services (tests/golden/*.npz ref_wall_s: "
+                                  "build container, one core, HiGHS in place of Gurobi)"},
+            "what": "all %d services of the shipped corpora in one batch: upload excluded, pass 1 + refit + pass 2 + parents to the host, best of %d" % (len(units), repeats)}
+
+
 def profile_traffic(dominant, spans_rank):
     """HBM bytes per launch of the dominant kernel group from the newest committed rocprofv3 PMC passes
     (profiles/collect.sh) -- only if that profile was taken from exactly these kernel sources and this workload."""
@@ -744,6 +788,7 @@ def run_workload(args, c, primary=True):
                         out["end_to_end_cached" + tag] = end_to_end(device, lib=args.lib, kind=kind, n_traces=n_traces, corpus=corpus, cache_dir=d)
             if args.end_to_end:
                 out["load_levels"] = load_levels(device, lib=args.lib)
+                out["shipped_corpora"] = shipped_corpora(device, lib=args.lib)
     eng.close()
     if fit_eng is not None:
         fit_eng.close()

@@ -161,6 +161,7 @@ inline long long __double_as_longlong(double x) { long long r; memcpy(&r, &x, 8)
 inline double __longlong_as_double(long long x) { double r; memcpy(&r, &x, 8); return r; }
 inline int __builtin_amdgcn_readfirstlane(int v);
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
 inline void __builtin_amdgcn_wave_barrier() { if (emu_wave) emu_wave->bar.arrive_and_wait(); }
 
 // every lane deposits a value, all live lanes meet, every lane reads what it needs, all meet again

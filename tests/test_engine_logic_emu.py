@@ -203,7 +203,7 @@ def test_lane_threaded_tile_kernel_with_production_tables():
         "import sys, os\n"
         "sys.path[:0] = [%r, %r, %r]\n"
         "import parity\n"
-        "units, _ = parity.stress_units([(41, 300, 'par4', 3, 1), (42, 300, 'chain3', 3, 1), (43, 260, 'par2', 2, 1000), (44, 200, 'diamond', 2.5, 1), (45, 140, 'mix7', 1.5, 1)])\n"
+        "units, _ = parity.stress_units([(41, 260, 'par4', 3, 1), (42, 200, 'chain3', 3, 1), (43, 200, 'par2', 2, 1000), (45, 130, 'mix7', 1.5, 1)])\n"
         "r1, r2, _ = parity.check_units(%r, units, allow_budget=True)\n"
         "print('lanes ok')\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),

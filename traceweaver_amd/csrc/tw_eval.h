@@ -97,10 +97,27 @@ __global__ void __launch_bounds__(kTile) k_evaluate(Dev P, const int32_t* truth,
     }
 }
 
-// Streaming copy, 16 B per lane (tw_measure_hbm_copy): the HBM rate a plain kernel reaches on this device, the
-// measured ceiling quoted next to the 8 TB/s specification in the roofline figures.
+// Streaming copy, 16 B per lane and load (tw_measure_hbm_copy): the HBM rate a plain kernel reaches on this device, the
+// measured ceiling quoted next to the 8 TB/s specification in the roofline figures.  U loads of a thread are in flight
+// before its first store (one load per trip left the memory pipes idle between trips: 4.7 TB/s where the guide's float4
+// copy reaches 6.3); NT: stores that bypass the caches (the data is not read again).
+template <int U, bool NT>
 __global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (NT) {
+                __builtin_nontemporal_store(v[u].x, &dst[i + u * stride].x); __builtin_nontemporal_store(v[u].y, &dst[i + u * stride].y);
+                __builtin_nontemporal_store(v[u].z, &dst[i + u * stride].z); __builtin_nontemporal_store(v[u].w, &dst[i + u * stride].w);
+            } else dst[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
 }
 
 __global__ void k_count_flags(const uint8_t* a, const uint8_t* b, int64_t n, unsigned long long* out) {  // out[0] += #a[i]==0, out[1] += #b[i]==0
