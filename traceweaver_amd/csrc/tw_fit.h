@@ -37,7 +37,10 @@
 
 namespace tw {
 
-constexpr int kFitThreads = 512;
+#ifndef TW_FIT_THREADS
+#define TW_FIT_THREADS 512
+#endif
+constexpr int kFitThreads = TW_FIT_THREADS;
 constexpr int kFitWaves = kFitThreads / 64;
 constexpr int kFitStats = 3 * kMaxComp + 2;
 constexpr int kFitMaxIter = 100;          // GaussianMixture(max_iter=100)

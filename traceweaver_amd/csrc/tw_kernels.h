@@ -2221,8 +2221,10 @@ __device__ long long g_sel_acc[8];
 #define TW_SEL_ARG
 #define TW_SEL_PASS
 #endif
+// flush_nodes = false: the caller adds L.nodes_total to the unit's statistics itself (the window kernels: once per run of windows of
+// one unit -- one same-address atomic per window kept every window's next loads waiting behind it)
 template <class LDS>
-__device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int first, int m, LDS& L TW_SEL_ARG) {
+__device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int first, int m, LDS& L TW_SEL_ARG, bool flush_nodes = true) {
     const int t = threadIdx.x, nt = blockDim.x, E = U.E;
     TW_SEL_T0();
     for (int q = t; q < m * kTopK; q += nt) {
@@ -2380,7 +2382,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
     TW_SEL_TICK(6);
     for (int b = t; b < m; b += nt) P.chosen[U.in_off + first + b] = L.pick[b];
     if (t == 0 && L.budget_hit) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 4], 1ull);
-    if (t == 0 && L.nodes_total) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 5], L.nodes_total);
+    if (flush_nodes && t == 0 && L.nodes_total) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 5], L.nodes_total);
     group_sync();
     TW_SEL_TICK(7);
 }
@@ -2485,6 +2487,8 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
     group_sync();
     int chunk_pos = 0, chunk_end = 0;
     bool first_chunk = true;
+    int nodes_unit = 0;
+    unsigned long long nodes_sum = 0ull;
     TW_SEL_DECL();
     while (true) {
         if (chunk_pos == chunk_end) {  // dynamic distribution (search effort varies by orders of magnitude), kWorkChunk windows per atomic;
@@ -2498,7 +2502,11 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
             }
             const int limit = chunk_pos < (int)gridDim.x * kWorkChunk ? (int)gridDim.x * kWorkChunk : count;   // static chunks are remapped below
             chunk_end = chunk_pos + kWorkChunk < limit ? chunk_pos + kWorkChunk : limit;
-            if (chunk_pos >= count && chunk_pos >= (int)gridDim.x * kWorkChunk) { TW_SEL_FLUSH(); break; }
+            if (chunk_pos >= count && chunk_pos >= (int)gridDim.x * kWorkChunk) {
+                if (threadIdx.x == 0 && nodes_sum) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)nodes_unit * 8 + 5], nodes_sum);
+                TW_SEL_FLUSH();
+                break;
+            }
         }
         int item = chunk_pos++;
         {   // the static chunks are strided over the workgroups: the long windows at the front of the list go to different
@@ -2516,7 +2524,12 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
 #ifdef TW_PROFILE_SEL
         const long long _w0 = wall_clock64();
 #endif
-        select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS);
+        select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS, false);
+        if (unit != nodes_unit) {   // (uniform) search nodes per unit, added up over the windows this workgroup serves
+            if (threadIdx.x == 0 && nodes_sum) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)nodes_unit * 8 + 5], nodes_sum);
+            nodes_unit = unit; nodes_sum = 0ull;
+        }
+        nodes_sum += L.nodes_total;
 #ifdef TW_PROFILE_SEL
         if (threadIdx.x == 0) {
             const unsigned long long dur = (unsigned long long)(wall_clock64() - _w0);
@@ -2556,7 +2569,7 @@ __global__ void __launch_bounds__(64) k_select_tiny(Dev P) {  // persistent work
         const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane(P.tiny_win[pos]);
         const UnitDev& U = P.units[unit];
         const int first = (int)(fm >> 6), last = first + (int)(fm & 63u);
-        select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS);
+        select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS, false);   // (complete enumeration only: no search nodes to report)
     }
 }
 
