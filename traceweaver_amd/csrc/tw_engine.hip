@@ -1456,15 +1456,14 @@ int tw_measure_hbm_copy(tw_engine* e, int64_t bytes, int32_t iters, double* gbps
     if (s == hipSuccess) s = hipMalloc(&b, n16 * 16);
     if (s == hipSuccess) s = hipMemsetAsync(a, 1, n16 * 16, e->stream);
     *gbps = 0.0;
-    // the best of a few shapes of the same plain copy (loads in flight per thread, cached / streaming stores, workgroups per CU)
-    for (int variant = 0; variant < 6 && s == hipSuccess; variant++) {
-        const unsigned grid = 256 * (variant % 2 == 0 ? 8 : 16);
+    // One 16-byte load and store per thread, one workgroup per 4 KB (consecutive workgroups walk consecutive DRAM pages): 6.2 TB/s
+    // on MI355X, the guide's float4-copy figure.  The grid-stride form of the same copy (2048 persistent workgroups, four loads in
+    // flight) reaches 4.4-4.7 TB/s -- what round 3 quoted as the ceiling; it is timed too, the better one is reported.
+    for (int variant = 0; variant < 2 && s == hipSuccess; variant++) {
+        const unsigned grid = variant == 0 ? (unsigned)((n16 + 255) / 256) : 2048u;
         auto launch = [&]() {
-            switch (variant / 2) {
-                case 0: hipLaunchKernelGGL((k_copy16<4, false>), dim3(grid), dim3(256), 0, e->stream, (const uint4*)a, (uint4*)b, (int64_t)n16); break;
-                case 1: hipLaunchKernelGGL((k_copy16<8, false>), dim3(grid), dim3(256), 0, e->stream, (const uint4*)a, (uint4*)b, (int64_t)n16); break;
-                default: hipLaunchKernelGGL((k_copy16<4, true>), dim3(grid), dim3(256), 0, e->stream, (const uint4*)a, (uint4*)b, (int64_t)n16); break;
-            }
+            if (variant == 0) hipLaunchKernelGGL((k_copy16<1, false>), dim3(grid), dim3(256), 0, e->stream, (const uint4*)a, (uint4*)b, (int64_t)n16);
+            else hipLaunchKernelGGL((k_copy16<4, false>), dim3(grid), dim3(256), 0, e->stream, (const uint4*)a, (uint4*)b, (int64_t)n16);
         };
         launch();  // warm-up
         s = hipEventRecord(e->ev[EV_BEGIN], e->stream);
@@ -1473,7 +1472,11 @@ int tw_measure_hbm_copy(tw_engine* e, int64_t bytes, int32_t iters, double* gbps
         if (s == hipSuccess) s = hipStreamSynchronize(e->stream);
         float ms = 0.f;
         if (s == hipSuccess) s = hipEventElapsedTime(&ms, e->ev[EV_BEGIN], e->ev[EV_END]);
-        if (s == hipSuccess) { const double r = 2.0 * (double)(n16 * 16) * iters / ((double)ms * 1e-3) / 1e9; if (r > *gbps) *gbps = r; }
+        if (s == hipSuccess) {
+            const double r = 2.0 * (double)(n16 * 16) * iters / ((double)ms * 1e-3) / 1e9;
+            if (env_int("TW_COPY_TRACE", 0)) fprintf(stderr, "tw_measure_hbm_copy: variant %d, %u workgroups: %.0f GB/s\n", variant, grid, r);
+            if (r > *gbps) *gbps = r;
+        }
     }
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);

@@ -99,8 +99,8 @@ __global__ void __launch_bounds__(kTile) k_evaluate(Dev P, const int32_t* truth,
 
 // Streaming copy, 16 B per lane and load (tw_measure_hbm_copy): the HBM rate a plain kernel reaches on this device, the
 // measured ceiling quoted next to the 8 TB/s specification in the roofline figures.  U loads of a thread are in flight
-// before its first store (one load per trip left the memory pipes idle between trips: 4.7 TB/s where the guide's float4
-// copy reaches 6.3); NT: stores that bypass the caches (the data is not read again).
+// before its first store; with U = 1 and one workgroup per 4 KB (no grid-stride loop) consecutive workgroups walk
+// consecutive DRAM pages: 6.2 TB/s, where the grid-stride form reaches 4.4-4.7.  NT: stores that bypass the caches.
 template <int U, bool NT>
 __global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

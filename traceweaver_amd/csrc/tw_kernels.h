@@ -775,8 +775,11 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         // below it is a no-op there (see the batch loop), so skipping it changes nothing either.
         // What the cut tuples would have added to the tuple count and the candidate bitmap must be known without visiting them:
         // without call-order constraints every grid point is a tuple (closed form); in pass 2 the first solve has the same
-        // tuples as in pass 1 (leaves0).  Otherwise the walk is not pruned.
-        bool prune = false;
+        // tuples as in pass 1 (leaves0); the long enumerations of deep call graphs (those that list their tuples, below) list only
+        // the prefixes of E - 1 endpoints and count the last level: tuple count and candidate bitmap without a single score.
+        // Otherwise the walk is not pruned.
+        bool prune = false, tables_ok = false, counted = false;
+        long long leaves_counted = 0;
         double mclose = -dinf(), margin = 0.0, thr0 = -dinf();
         long long tail[E];   // tuples below a prefix that ends at level d when every grid point is one: the product of the later counts
         uint32_t any_order = 0;
@@ -784,8 +787,8 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
             long long grid = 1;
 #pragma unroll
             for (int e = E - 1; e >= 0; e--) { tail[e] = grid; grid = grid < (1ll << 40) ? grid * cn[e] : grid; any_order |= dag_pm[e]; }
-            const bool countable = any_order == 0 || (pass == 2 && mode == 0);
-            if (E >= 2 && grid >= kPruneMin && countable && !U.skip) {
+            const bool countable = any_order == 0 || (pass == 2 && mode == 0);   // (otherwise, for the long enumerations of deep call graphs: counted by listing prefixes, below)
+            if (E >= 2 && grid >= kPruneMin && (countable || (E >= 3 && grid >= kFrontierGrid)) && !U.skip) {
                 auto wave_max = [&](double v) -> double {
                     for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(v, off); v = o > v ? o : v; }
                     return v;
@@ -832,7 +835,8 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
 #pragma unroll
                 for (int e = E - 1; e >= 0; e--) { sb += ube[e]; if (t == 0) sbound[e] = sb; }
                 margin = aabs * 1.0e-12 + 1.0e-300;
-                prune = tables && aabs < dinf() && aabs == aabs;
+                tables_ok = tables && aabs < dinf() && aabs == aabs;
+                prune = tables_ok && countable;
             }
         }
         wave_sync();
@@ -857,6 +861,10 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
 #pragma unroll
             for (int e = 0; e < E; e++) grid = grid < (1ll << 40) ? grid * cn[e] : grid;
             if (prune) grid = 0;
+            // count_only: the prefixes of E - 1 endpoints are listed, their tuples counted and their candidates marked -- the pruned
+            // walk then finds the five best without scoring the rest
+            const bool count_only = tables_ok && !prune;
+            int minlo = 0x7fffffff;
             if (grid >= kFrontierGrid && any_order != 0 && !U.skip && front_slot < 0 && front_slot != -2) {
                 // the first such span of this wavefront claims one of the kFrontierSlots buffer pairs (kernels of several
                 // classes run side by side: the block index does not identify a wavefront across them)
@@ -873,12 +881,14 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                     for (int c = c0_begin + t; c < c0_end; c += nt) fa[c - c0_begin] = (unsigned long long)c;
                     int nprev = c0_end - c0_begin;
                     use_front = true;
+                    leaves_counted = 0;
                     __threadfence_block();
                     wave_sync();
 #pragma unroll
                     for (int d = 1; d < E; d++) {
                         if (!use_front) continue;
                         const int cd = cn[d];
+                        const bool last_count = count_only && d == E - 1;
                         int nnext = 0;
                         for (int base = 0; base < nprev; base += nt) {
                             const int f = base + t;
@@ -894,6 +904,19 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                             int incl = cnt;
                             for (int off = 1; off < 64; off <<= 1) { const int v = __shfl(incl, lane >= off ? lane - off : lane); if (lane >= off) incl += v; }
                             const int total = __shfl(incl, nt - 1 < 63 ? nt - 1 : 63);
+                            if (last_count) {   // the tuples below every prefix: counted, their spans marked (not written, not scored)
+                                leaves_counted += total;
+                                if (cnt > 0 && pass == 1 && mode == 0) {
+#pragma unroll
+                                    for (int q = 0; q < E - 1; q++) {
+                                        const int r = lr[q][(ent >> (8 * q)) & 255ull];
+                                        const unsigned long long bit = 1ull << (r & 63);
+                                        if (!(sbits[q][r >> 6] & bit)) atomicOr(&sbits[q][r >> 6], bit);
+                                    }
+                                    minlo = lo2 < minlo ? lo2 : minlo;
+                                }
+                                continue;
+                            }
                             const int start = nnext + incl - cnt;
                             if (nnext + total <= cap)
                                 for (int c = lo2; c < lo2 + cnt; c++) fb[start + (c - lo2)] = ent | ((unsigned long long)c << (8 * d));
@@ -908,6 +931,13 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                     }
                     front = fa;
                     n_front = nprev;
+                    if (count_only && use_front) {   // counted: on to the pruned walk
+                        for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(minlo, off); minlo = o < minlo ? o : minlo; }
+                        if (pass == 1 && mode == 0)   // (the admissible candidates of the last endpoint are tails of its list: their union is one)
+                            for (int c = t; c < cn[E - 1]; c += nt) if (c >= minlo) { const int r = lr[E - 1][c]; atomicOr(&sbits[E - 1][r >> 6], 1ull << (r & 63)); }
+                        counted = true; prune = true; use_front = false;
+                        break;
+                    }
                     if (use_front || tries == 1) break;
                     // the lists outgrew the wavefront's own buffers: once more in a slot of the pool, if one is left
                     int slot = 0;
@@ -1331,7 +1361,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
             for (int e = 0; e < E; e++)
 #pragma unroll
                 for (int w = 0; w < kBitWords; w++) if (mybits[e][w] != 0ull) atomicOr(&sbits[e][w], mybits[e][w]);
-            if (prune) {   // (no call-order constraints: every staged candidate occurs in a tuple, visited or cut)
+            if (prune && any_order == 0) {   // (no call-order constraints: every staged candidate occurs in a tuple, visited or cut)
 #pragma unroll
                 for (int e = 0; e < E; e++)
                     for (int c = t; c < cn[e]; c += nt) { const int r = lr[e][c]; atomicOr(&sbits[e][r >> 6], 1ull << (r & 63)); }
@@ -1339,7 +1369,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         }
         // the tuples of the first solve are the same in both passes: where the pruned walk of pass 2 did not count them (call-order
         // constraints: the cut prefixes' tuples are not a product), the count of pass 1 stands
-        if (prune && any_order != 0) leaves = nparts > 1 ? 0 : P.leaves0[U.in_off + i];
+        if (prune && any_order != 0) leaves = counted ? leaves_counted : (nparts > 1 ? 0 : P.leaves0[U.in_off + i]);
         wave_sync();
         TW_PHASE(3);
         if (t == 0) {
