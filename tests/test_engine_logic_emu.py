@@ -178,7 +178,7 @@ def test_lane_threaded_emulation(emu_lib):
         "import sys, os\n"
         "sys.path[:0] = [%r, %r, %r]\n"
         "import parity\n"
-        "units, _ = parity.stress_units([(6, 150, 'single', 10, 1), (4, 150, 'par2', 6, 1), (11, 130, 'single', 1.2, 1), (18, 10, 'mix7', 3, 1000)])\n"
+        "units, _ = parity.stress_units([(6, 200, 'single', 10, 1), (4, 200, 'par2', 6, 1), (11, 130, 'single', 1.2, 1), (18, 10, 'mix7', 3, 1000)])\n"
         "r1, r2, _ = parity.check_units(%r, units)\n"
         "assert sum(r['repaired_windows'] for r in r1) > 0\n"
         "print('lanes ok')\n"
