@@ -123,6 +123,7 @@ struct Dev {
     int32_t* heavy_next;    // [4] next unclaimed item of every list
     int32_t *heavy_unit, *heavy_win;
     int32_t *tiny_unit, *tiny_win;
+    int32_t *hard_unit, *hard_win;   // windows k_select_heavy gave up on, for k_select_dp (count and cursor: heavy_next[4], [5])
     int32_t* heavy_in_count;  // [2][kMaxEp+1] incoming spans deferred to k_enumerate_heavy per endpoint count E: narrow, wide windows
     int32_t* heavy_in_next;   // [3][kMaxEp+1] next unclaimed entry of each list: narrow, wide, long enumerations (when launched on their own)
     int32_t heavy_in_off[kMaxEp + 2];  // class offsets into heavy_in_unit / heavy_in_idx

@@ -298,6 +298,8 @@ void launch_select_listed(tw_engine* e) {
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[1], 0);
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[2], 0);
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[3], 0);
+    // the windows the searches gave up on (kDpNodes), level by level over 256 lanes each; nothing listed: the workgroups leave at once
+    hipLaunchKernelGGL(k_select_dp, dim3(256), dim3(std::min(e->coop, kDpThreads)), 0, e->stream, P);
 }
 
 // OR of (key ^ first key) and of the keys themselves over a set of index ranges (see k_key_bits)
@@ -883,6 +885,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     }
     ALLOC(P.heavy_unit, sel_cap); ALLOC(P.heavy_win, sel_cap);
     ALLOC(P.tiny_unit, sel_cap); ALLOC(P.tiny_win, sel_cap);
+    ALLOC(P.hard_unit, sel_cap / (kBruteMax + 1) + 1); ALLOC(P.hard_win, sel_cap / (kBruteMax + 1) + 1);   // (a searched window holds more than kBruteMax spans)
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
     ALLOC(e->gaps_sorted, gaps); ALLOC(e->fit_models, slots * kMaxComp * kModelStride);

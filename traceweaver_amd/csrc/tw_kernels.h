@@ -1976,8 +1976,10 @@ __device__ __forceinline__ long long uni(long long x) {
 // programme over the sets of taken outgoing spans rather than over the assignments that produce them: the largest
 // component of the heavy-load test workloads takes ~2e3 nodes instead of 4e6 (nodejs shape) / 8e8 (tie-saturated set).
 // Needs L.cm, L.mem, L.ncand, L.w, L.ub, L.cmask3; writes L.pick of the members.
+// node_cap > 0: a search that has not finished after that many nodes is given up (returns true, L.pick of the members is not
+// written): the window goes to k_select_dp, which solves such components level by level over all lanes (select_dp).
 template <class LDS>
-__device__ void select_search(LDS& L, int E) {
+__device__ bool select_search_body(LDS& L, int E, int node_cap) {
     constexpr int W = LDS::kW;   // words of the blocked mask: kept in up to three registers, the unused ones are constant zero
     static_assert(W >= 1 && W <= 3 && kBlkWords == 3, "the blocked mask is kept in three registers");
     static_assert(kMaxWin < 64 && kTopK <= 8, "one lane per depth, one bit per candidate");
@@ -2041,7 +2043,7 @@ __device__ void select_search(LDS& L, int E) {
     sel_w best_w = 0, acc = 0;      // only strict improvements replace the incumbent
     ull b0 = 0, b1 = 0, b2 = 0;
     int d = 0, nodes = 0;
-    bool entered = true, over = false;
+    bool entered = true, over = false, capped = false;
     // One endpoint: a search that is still running after kMatchNodes1 nodes asks for the optimum of the whole component (one
     // matching) and from then on only looks for the first selection in depth-first order that reaches it: the incumbent is
     // floored at optimum - 1, every node is tested with the exact bound of its sub-problem, so the walk descends without
@@ -2051,6 +2053,7 @@ __device__ void select_search(LDS& L, int E) {
         int k = 0;
         if (entered) {
             if (++nodes > kNodeBudget) { over = true; break; }
+            if (node_cap > 0 && nodes > node_cap) { capped = true; break; }
             if (E == 1 && exact == 0 && nodes > kMatchNodes1) {
                 sel_w opt = 0;
                 if (t == 0) opt = select_match_bound(L, 0, 0, 0ull, 0ull, 0ull);   // (the matching runs in one lane, on LDS)
@@ -2144,12 +2147,234 @@ __device__ void select_search(LDS& L, int E) {
 #endif
         L.nodes_total += (unsigned long long)nodes;
     }
+    if (capped) return true;
     best.store(cm, [&](int q, int kq) {
         const int bq = L.mem[q];
         if (!(best_w > 0)) kq = -1;
         L.pick[bq] = (int8_t)((kq < 0 || kq == (int)L.ncand[bq]) ? -1 : kq);
     });
+    return false;
+}
+template <class LDS>
+__device__ bool select_search(LDS& L, int E, int node_cap = 0) {
+    const bool capped = select_search_body(L, E, node_cap);
     group_sync();
+    return capped;
+}
+
+// ---- level-synchronous search of a component (select_dp) --------------------------------------------------------------
+// What can still be gained below a node of the canonical search depends only on its depth and on which candidates of the
+// remaining spans are blocked (the transposition table of select_search says the same).  So the tree is a layered graph:
+// level d holds the distinct *states* (blocked candidates of the spans d..) that some assignment of the spans 0..d-1 reaches,
+// each with the best such assignment -- largest weight, among equal weights the one that the depth-first order visits first,
+// i.e. the lexicographically smallest choice vector (candidates by list position, "none" last).  The first selection of
+// maximum weight in depth-first order is then the survivor of the single state of level cm.  One level is expanded by all
+// lanes at once: every (state, choice) pair is an item; children meet in a hash table in LDS (claim by a 64-bit tag, keys
+// verified, atomicMax on the weight, atomicMin on the choice vector among the maxima: order-independent, so the result does
+// not depend on the interleaving); a child that cannot reach the greedy leaf's weight is dropped (weight + grouped bound of
+// the suffix < that weight: strictly below a feasible selection, so never part of a maximum).  Exact integers throughout.
+// With that bound most levels hold one or two states (measured: the 31-span components of the nodejs shape that take the
+// depth-first search 5-9 x 10^3 nodes hold 1 405 states over all levels).  A level that outgrows the table (or a tag collision
+// between different keys) returns false: k_select_heavy (tables of kDpCapSmall states, one wavefront) then lists the window for
+// k_select_dp (kDpCap states, kDpThreads lanes), and that one falls back to select_search.
+#ifndef TW_DP_CAP
+#define TW_DP_CAP 768
+#endif
+#ifndef TW_DP_SLOTS
+#define TW_DP_SLOTS 1024
+#endif
+#ifndef TW_DP_CAP_SMALL
+#define TW_DP_CAP_SMALL 32
+#endif
+#ifndef TW_DP_SLOTS_SMALL
+#define TW_DP_SLOTS_SMALL 64
+#endif
+constexpr int kDpCap = TW_DP_CAP, kDpSlots = TW_DP_SLOTS;                    // k_select_dp: states per level, hash table slots
+constexpr int kDpCapSmall = TW_DP_CAP_SMALL, kDpSlotsSmall = TW_DP_SLOTS_SMALL;   // k_select_heavy
+constexpr int kDpThreads = 256;
+constexpr int kDpDigit = 3, kDpNone = 7, kDpWord0 = 21;   // choice vector: 3 bits a level, levels 0..20 in the first word (earlier = more significant)
+static_assert(kTopK < kDpNone && kMaxWin <= 2 * kDpWord0, "choice vector in two words");
+template <int W, int CAP, int SLOTS>
+struct SelectDpT {
+    typedef unsigned long long ull;
+    static constexpr int kW = W, kCap = CAP, kSlots = SLOTS;
+    static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS > CAP, "open addressing needs a free slot");
+    ull ck[W][CAP], cacc[CAP], cp[2][CAP];                    // the states of the current level
+    ull th[SLOTS], tk[W][SLOTS], tacc[SLOTS], tp[2][SLOTS];   // the next level as a hash table
+    ull lb;
+    int n_cur, n_next, n_claim, fail, fail2;   // fail: set in pass 1 (a level outgrew the table), fail2: in pass 2 (two keys with one tag)
+};
+struct SelectDpNone { static constexpr int kW = 0; };   // select_window_coop without the level-by-level solver (k_select_tiny, skip mode)
+typedef SelectDpT<kBlkWords, kDpCap, kDpSlots> SelectDp;
+
+template <class LDS, class DP>
+__device__ bool select_dp(LDS& L, DP& D, int E) {
+    typedef unsigned long long ull;
+    constexpr int W = LDS::kW;
+    static_assert(W == DP::kW && W >= 1 && W <= 3, "tables of the layout's mask width");
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int cm = L.cm;
+    if (t == 0) {   // the greedy leaf: the first leaf of the depth-first order
+        ull b[W], acc = 0ull;
+        for (int w = 0; w < W; w++) b[w] = 0ull;
+        for (int d = 0; d < cm; d++) {
+            const int bm = L.mem[d], bit = d * kTopK;
+            for (int k = 0; k < (int)L.ncand[bm]; k++) {
+                if (!(L.w[bm][k] > 0) || ((b[(bit + k) >> 6] >> ((bit + k) & 63)) & 1ull)) continue;
+                acc += (ull)L.w[bm][k];
+                for (int w = 0; w < W; w++) b[w] |= L.cmask3[d][k][w];
+                break;
+            }
+        }
+        D.lb = acc; D.n_cur = 1; D.fail = 0; D.fail2 = 0;
+        for (int w = 0; w < W; w++) D.ck[w][0] = 0ull;
+        D.cacc[0] = 0ull; D.cp[0][0] = 0ull; D.cp[1][0] = 0ull;
+    }
+    group_sync();
+    const ull lb = D.lb;
+    unsigned long long states = 0ull;
+#ifdef TW_DP_TRACE
+    int trace_max = 0;
+#endif
+    struct Child { ull k[3], acc, p[2], tag; unsigned slot; bool ok; };
+    for (int d = 0; d < cm; d++) {
+        for (int q = t; q < DP::kSlots; q += nt) { D.th[q] = 0ull; D.tacc[q] = 0ull; D.tp[0][q] = ~0ull; D.tp[1][q] = ~0ull; }
+        if (t == 0) { D.n_next = 0; D.n_claim = 0; }
+        group_sync();
+        const int S = D.n_cur, bm = L.mem[d], nc = (int)L.ncand[bm];
+        const int bit = d * kTopK, nbit = bit + kTopK, nwd = nbit >> 6;
+        const ull keep = ~0ull << (nbit & 63), ubn = (ull)L.ub[d + 1];
+        const int items = S * (kTopK + 1);
+        states += (unsigned long long)S;
+#ifdef TW_DP_TRACE
+        if (t == 0 && S > trace_max) trace_max = S;
+#endif
+        // child c of state s: candidate c (c < kTopK; must be eligible and not blocked) or "none" (c == kTopK)
+        auto child = [&](int item, Child& C) {
+            const int s = item / (kTopK + 1), c = item % (kTopK + 1);
+            ull k0 = D.ck[0][s], k1 = 0ull, k2 = 0ull;
+            if constexpr (W > 1) k1 = D.ck[1][s];
+            if constexpr (W > 2) k2 = D.ck[2][s];
+            C.acc = D.cacc[s];
+            C.ok = true;
+            if (c < kTopK) {
+                const int pos = bit + c;
+                const ull word = (pos >> 6) == 0 ? k0 : ((pos >> 6) == 1 ? k1 : k2);
+                C.ok = c < nc && L.w[bm][c] > 0 && !((word >> (pos & 63)) & 1ull);
+                if (!C.ok) return;
+                C.acc += (ull)L.w[bm][c];
+                k0 |= L.cmask3[d][c][0];
+                if constexpr (W > 1) k1 |= L.cmask3[d][c][1];
+                if constexpr (W > 2) k2 |= L.cmask3[d][c][2];
+            }
+            if (C.acc + ubn < lb) { C.ok = false; return; }
+            C.k[0] = nwd == 0 ? (k0 & keep) : 0ull;
+            C.k[1] = nwd == 1 ? (k1 & keep) : (nwd < 1 ? k1 : 0ull);
+            C.k[2] = nwd == 2 ? (k2 & keep) : (nwd < 2 ? k2 : 0ull);
+            const ull digit = c < kTopK ? (ull)c : (ull)kDpNone;
+            C.p[0] = D.cp[0][s]; C.p[1] = D.cp[1][s];
+            if (d < kDpWord0) C.p[0] |= digit << ((kDpWord0 - 1 - d) * kDpDigit);
+            else C.p[1] |= digit << ((2 * kDpWord0 - 1 - d) * kDpDigit);
+            ull h = (C.k[0] * 0x9E3779B97F4A7C15ull) ^ (C.k[1] * 0xC2B2AE3D27D4EB4Full) ^ (C.k[2] * 0x165667B19E3779F9ull);
+            h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+            C.slot = (unsigned)h & (DP::kSlots - 1);
+            C.tag = h | 1ull;
+        };
+        auto key_is = [&](int q, const Child& C) -> bool {
+            bool eq = D.tk[0][q] == C.k[0];
+            if constexpr (W > 1) eq = eq && D.tk[1][q] == C.k[1];
+            if constexpr (W > 2) eq = eq && D.tk[2][q] == C.k[2];
+            return eq;
+        };
+        // the child's slot: the first slot of its probe sequence that carries its tag (slots are never released within a level)
+        auto find = [&](const Child& C) -> int {
+            unsigned q = C.slot;
+            for (int pr = 0; pr < DP::kSlots; pr++, q = (q + 1) & (DP::kSlots - 1)) {
+                const ull v = D.th[q];
+                if (v == C.tag) return (int)q;
+                if (v == 0ull) return -1;
+            }
+            return -1;
+        };
+        // pass 1: every child claims or finds the slot of its key
+        for (int item = t; item < items; item += nt) {
+            Child C;
+            child(item, C);
+            if (!C.ok) continue;
+            unsigned q = C.slot;
+            bool placed = false;
+            for (int pr = 0; pr < DP::kSlots && !placed; pr++, q = (q + 1) & (DP::kSlots - 1)) {
+                const ull old = atomicCAS(&D.th[q], 0ull, C.tag);
+                if (old == 0ull) {
+                    if (atomicAdd(&D.n_claim, 1) >= DP::kCap) D.fail = 1;
+                    D.tk[0][q] = C.k[0];
+                    if constexpr (W > 1) D.tk[1][q] = C.k[1];
+                    if constexpr (W > 2) D.tk[2][q] = C.k[2];
+                    placed = true;
+                } else if (old == C.tag) placed = true;
+                if (*(volatile int*)&D.fail) break;
+            }
+            if (!placed) D.fail = 1;
+        }
+        group_sync();
+        if (D.fail) break;   // (uniform: read after the barrier)
+        // pass 2: keys verified (two keys with one tag: give up), largest weight per state
+        for (int item = t; item < items; item += nt) {
+            Child C;
+            child(item, C);
+            if (!C.ok) continue;
+            const int q = find(C);
+            if (q < 0 || !key_is(q, C)) { D.fail2 = 1; continue; }   // (a flag of its own: a lane already in this pass must not change what a slower one reads after the barrier above)
+            atomicMax(&D.tacc[q], C.acc);
+        }
+        group_sync();
+        if (D.fail2) break;
+        // passes 3 / 4: among the heaviest assignments of a state the one the depth-first order visits first
+        for (int item = t; item < items; item += nt) {
+            Child C;
+            child(item, C);
+            if (!C.ok) continue;
+            const int q = find(C);
+            if (q >= 0 && D.tacc[q] == C.acc) atomicMin(&D.tp[0][q], C.p[0]);
+        }
+        group_sync();
+        if (d >= kDpWord0) {
+            for (int item = t; item < items; item += nt) {
+                Child C;
+                child(item, C);
+                if (!C.ok) continue;
+                const int q = find(C);
+                if (q >= 0 && D.tacc[q] == C.acc && D.tp[0][q] == C.p[0]) atomicMin(&D.tp[1][q], C.p[1]);
+            }
+            group_sync();
+        }
+        // the table becomes the list of the next level
+        for (int q = t; q < DP::kSlots; q += nt) {
+            if (D.th[q] == 0ull) continue;
+            const int pos = atomicAdd(&D.n_next, 1);
+            D.ck[0][pos] = D.tk[0][q];
+            if constexpr (W > 1) D.ck[1][pos] = D.tk[1][q];
+            if constexpr (W > 2) D.ck[2][pos] = D.tk[2][q];
+            D.cacc[pos] = D.tacc[q]; D.cp[0][pos] = D.tp[0][q]; D.cp[1][pos] = d >= kDpWord0 ? D.tp[1][q] : 0ull;
+        }
+        group_sync();
+        if (t == 0) D.n_cur = D.n_next;
+        group_sync();
+    }
+    if (t == 0) L.nodes_total += states;
+    const bool failed = D.fail != 0 || D.fail2 != 0 || D.n_cur != 1;
+#ifdef TW_DP_TRACE
+    if (t == 0) printf("select_dp<%d>: component of %d spans, %llu states, widest level %d, %s\n", DP::kCap, cm, states, trace_max, failed ? "given back" : "solved");
+#endif
+    if (!failed) {
+        const ull acc = D.cacc[0], p0 = D.cp[0][0], p1 = D.cp[1][0];
+        for (int q = t; q < cm; q += nt) {
+            const int digit = (int)((q < kDpWord0 ? p0 >> ((kDpWord0 - 1 - q) * kDpDigit) : p1 >> ((2 * kDpWord0 - 1 - q) * kDpDigit)) & 7ull);
+            L.pick[L.mem[q]] = (int8_t)((acc > 0ull && digit != kDpNone) ? digit : -1);
+        }
+    }
+    group_sync();
+    return !failed;
 }
 
 // Complete enumeration of a component of cm <= kBruteMax spans by all lanes: combination index = the choices
@@ -2253,8 +2478,12 @@ __device__ long long g_sel_acc[8];
 #endif
 // flush_nodes = false: the caller adds L.nodes_total to the unit's statistics itself (the window kernels: once per run of windows of
 // one unit -- one same-address atomic per window kept every window's next loads waiting behind it)
-template <class LDS>
-__device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int first, int m, LDS& L TW_SEL_ARG, bool flush_nodes = true) {
+// dp != nullptr: every searched component is first tried level by level (select_dp) on the tables *dp.  If a level outgrows them:
+// dfs_fallback = false (k_select_heavy) ends the window unsolved -- returns true, nothing is written to P.chosen, the caller lists it
+// for k_select_dp; dfs_fallback = true (k_select_dp) hands the component to the depth-first search (first wavefront).
+template <class LDS, class DP = SelectDpNone>
+__device__ bool select_window_coop(const Dev& P, const UnitDev& U, int unit, int first, int m, LDS& L TW_SEL_ARG, bool flush_nodes = true,
+                                   DP* dp = nullptr, bool dfs_fallback = true) {
     const int t = threadIdx.x, nt = blockDim.x, E = U.E;
     TW_SEL_T0();
     for (int q = t; q < m * kTopK; q += nt) {
@@ -2337,6 +2566,7 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
     }
     group_sync();
     TW_SEL_TICK(2);
+    bool hard = false;
     for (int root = 0; root < m; root++) {
         if (L.comp[root] != root) continue;  // uniform: comp is in LDS and stable here
         TW_SEL_TICK(6);
@@ -2366,61 +2596,80 @@ __device__ void select_window_coop(const Dev& P, const UnitDev& U, int unit, int
                     }
             }
         }
-        {   // Upper bound of a suffix d..cm-1 of the component: cut it into groups of 1-3 consecutive spans, solve
-            // every group exactly on its own (conflicts inside the group only) and take the cheapest cutting.  It
-            // sees spans that compete for the same outgoing spans (one of them must stay unassigned: -10000), which
-            // the sum of best weights does not.  All pairs and triples are evaluated at once, one (group, combination)
-            // per lane; weights are positive integers.
-            const int cm = L.cm, npair = cm > 1 ? cm - 1 : 0, ntrip = cm > 2 ? cm - 2 : 0;
-            constexpr int C = kTopK + 1;  // choices per span: a candidate or "none"
-            const int total = npair * C * C + ntrip * C * C * C;
-            for (int q = t; q < total; q += nt) {
-                int d, g, ch[3];
-                if (q < npair * C * C) { d = q / (C * C); const int c = q % (C * C); ch[0] = c / C; ch[1] = c % C; ch[2] = kTopK; g = 2; }
-                else { const int r = q - npair * C * C; d = r / (C * C * C); const int c = r % (C * C * C); ch[0] = c / (C * C); ch[1] = (c / C) % C; ch[2] = c % C; g = 3; }
-                bool ok = true;
-                sel_w sum = 0;
-                for (int x = 0; x < g && ok; x++) {
-                    if (ch[x] == kTopK) continue;  // "none"
-                    const int b = L.mem[d + x];
-                    if (ch[x] >= L.ncand[b] || !(L.w[b][ch[x]] > 0)) { ok = false; break; }
-                    for (int y = 0; y < x && ok; y++)
-                        if (ch[y] != kTopK && lds_share(L, E, L.mem[d + y], ch[y], b, ch[x])) ok = false;
-                    sum += L.w[b][ch[x]];
+        // Upper bound of a suffix d..cm-1 of the component.  The level-by-level solver runs on the sum of the spans' best weights
+        // (it keeps states by their blocked sets; the tighter bound below saves it 5-10 % of its states and costs more than that);
+        // the depth-first search gets the grouped bound: the suffix cut into groups of 1-3 consecutive spans, every group solved
+        // exactly on its own (conflicts inside the group only), the cheapest cutting.  It sees spans that compete for the same
+        // outgoing spans (one of them must stay unassigned: -10000), which the sum of best weights does not.  All pairs and
+        // triples are evaluated at once, one (group, combination) per lane; weights are positive integers.
+        auto suffix_bound = [&](bool grouped) {
+            if (t == 0) {
+                const int cm = L.cm;
+                L.ub[cm] = 0;
+                for (int d = cm - 1; d >= 0; d--) {
+                    sel_w mx = 0;
+                    for (int k = 0; k < L.ncand[L.mem[d]]; k++) if (L.w[L.mem[d]][k] > mx) mx = L.w[L.mem[d]][k];
+                    sel_w u = mx + L.ub[d + 1];
+                    if (grouped && d + 2 <= cm) { const sel_w c2 = (sel_w)L.g2[d] + L.ub[d + 2]; if (c2 < u) u = c2; }
+                    if (grouped && d + 3 <= cm) { const sel_w c3 = (sel_w)L.g3[d] + L.ub[d + 3]; if (c3 < u) u = c3; }
+                    L.ub[d] = u;
                 }
-                if (ok && sum > 0) atomicMax(g == 2 ? &L.g2[d] : &L.g3[d], (unsigned long long)sum);
+            }
+            group_sync();
+        };
+        bool solved = false;
+        if constexpr (DP::kW != 0) {
+            if (dp != nullptr) {
+                group_sync();
+                suffix_bound(false);
+                solved = select_dp(L, *dp, E);
             }
         }
-        group_sync();
-        if (t == 0) {
-            const int cm = L.cm;
-            L.ub[cm] = 0;
-            for (int d = cm - 1; d >= 0; d--) {
-                sel_w mx = 0;
-                for (int k = 0; k < L.ncand[L.mem[d]]; k++) if (L.w[L.mem[d]][k] > mx) mx = L.w[L.mem[d]][k];
-                sel_w u = mx + L.ub[d + 1];
-                if (d + 2 <= cm) { const sel_w c2 = (sel_w)L.g2[d] + L.ub[d + 2]; if (c2 < u) u = c2; }
-                if (d + 3 <= cm) { const sel_w c3 = (sel_w)L.g3[d] + L.ub[d + 3]; if (c3 < u) u = c3; }
-                L.ub[d] = u;
+        if (!solved) {
+            if (dp != nullptr && !dfs_fallback) { hard = true; break; }   // (uniform)
+            {
+                const int cm = L.cm, npair = cm > 1 ? cm - 1 : 0, ntrip = cm > 2 ? cm - 2 : 0;
+                constexpr int C = kTopK + 1;  // choices per span: a candidate or "none"
+                const int total = npair * C * C + ntrip * C * C * C;
+                for (int q = t; q < total; q += nt) {
+                    int d, g, ch[3];
+                    if (q < npair * C * C) { d = q / (C * C); const int c = q % (C * C); ch[0] = c / C; ch[1] = c % C; ch[2] = kTopK; g = 2; }
+                    else { const int r = q - npair * C * C; d = r / (C * C * C); const int c = r % (C * C * C); ch[0] = c / (C * C); ch[1] = (c / C) % C; ch[2] = c % C; g = 3; }
+                    bool ok = true;
+                    sel_w sum = 0;
+                    for (int x = 0; x < g && ok; x++) {
+                        if (ch[x] == kTopK) continue;  // "none"
+                        const int b = L.mem[d + x];
+                        if (ch[x] >= L.ncand[b] || !(L.w[b][ch[x]] > 0)) { ok = false; break; }
+                        for (int y = 0; y < x && ok; y++)
+                            if (ch[y] != kTopK && lds_share(L, E, L.mem[d + y], ch[y], b, ch[x])) ok = false;
+                        sum += L.w[b][ch[x]];
+                    }
+                    if (ok && sum > 0) atomicMax(g == 2 ? &L.g2[d] : &L.g3[d], (unsigned long long)sum);
+                }
             }
+            group_sync();
+            suffix_bound(true);
+            if (t < 64) select_search_body(L, E, 0);
+            group_sync();
         }
-        group_sync();
-        select_search(L, E);
         TW_SEL_TICK(5);
         }
     }
     TW_SEL_TICK(6);
-    for (int b = t; b < m; b += nt) P.chosen[U.in_off + first + b] = L.pick[b];
+    if (!hard) for (int b = t; b < m; b += nt) P.chosen[U.in_off + first + b] = L.pick[b];
     if (t == 0 && L.budget_hit) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 4], 1ull);
     if (flush_nodes && t == 0 && L.nodes_total) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 5], L.nodes_total);
     group_sync();
     TW_SEL_TICK(7);
+    return hard;
 }
 
 // Puts window w of the unit on a work list (`listed` lanes only; every lane of the wavefront calls): windows of up to
 // kBruteMax spans -- nearly all -- on the list of k_select_tiny, the others on the list of k_select_heavy.  There, long windows
 // can take a thousand times longer than short ones: they are listed from the front and served first, the short ones from the
 // back of the same array, so that no long search starts when the kernel is about to drain.
+constexpr int kHardCount = 4, kHardNext = 5;   // P.heavy_next[kHardCount]: windows listed for k_select_dp, [kHardNext]: its work cursor
 constexpr int kSelSeg = 32;      // segments of the selection work lists (one counter each)
 constexpr int kCtrStride = 32;   // ints between two counters: a cache line each
 __device__ __forceinline__ int sel_first_tile(int s, int n_tiles) { return (int)(((long long)s * n_tiles + kSelSeg - 1) / kSelSeg); }  // segment s = tiles [this, next)
@@ -2507,6 +2756,7 @@ template <class LDS, int LIST>
 __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent workgroups, one deferred window at a time
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     __shared__ LDS L;
+    __shared__ SelectDpT<LDS::kW, kDpCapSmall, kDpSlotsSmall> D;
     __shared__ int next_item;
     __shared__ SelSegs G;
     sel_segments(P, LIST, G);
@@ -2554,7 +2804,12 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
 #ifdef TW_PROFILE_SEL
         const long long _w0 = wall_clock64();
 #endif
-        select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS, false);
+        if (select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS, false, &D, false)) {   // (uniform) a level outgrew the tables: listed for k_select_dp
+            if (threadIdx.x == 0) {
+                const int at = atomicAdd(&P.heavy_next[kHardCount], 1);
+                P.hard_unit[at] = unit; P.hard_win[at] = (int32_t)fm;
+            }
+        }
         if (unit != nodes_unit) {   // (uniform) search nodes per unit, added up over the windows this workgroup serves
             if (threadIdx.x == 0 && nodes_sum) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)nodes_unit * 8 + 5], nodes_sum);
             nodes_unit = unit; nodes_sum = 0ull;
@@ -2601,6 +2856,34 @@ __global__ void __launch_bounds__(64) k_select_tiny(Dev P) {  // persistent work
         const int first = (int)(fm >> 6), last = first + (int)(fm & 63u);
         select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS, false);   // (complete enumeration only: no search nodes to report)
     }
+}
+
+// The windows k_select_heavy gave up on (a level of a component outgrew its small tables): one workgroup of kDpThreads lanes per
+// window, the same solver on tables of kDpCap states; a component that outgrows those too is searched depth first.  Launched after
+// the three instantiations of k_select_heavy have finished; with nothing listed the workgroups leave at once.
+__global__ void __launch_bounds__(kDpThreads) k_select_dp(Dev P) {
+    if (*P.err != 0) return;
+    __shared__ SelectLds L;
+    __shared__ SelectDp D;
+    __shared__ int next_item;
+    const int count = P.heavy_next[kHardCount];
+    if ((int)blockIdx.x >= count) return;
+    for (int q = threadIdx.x; q < SelectLds::kSlots; q += blockDim.x) L.memo[q].state = 0u;
+    if (threadIdx.x == 0) L.memo_gen = 0u;
+    group_sync();
+    TW_SEL_DECL();
+    int item = (int)blockIdx.x;
+    while (item < count) {
+        const int unit = __builtin_amdgcn_readfirstlane(P.hard_unit[item]);
+        const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane(P.hard_win[item]);
+        const UnitDev& U = P.units[unit];
+        select_window_coop(P, U, unit, (int)(fm >> 6), (int)(fm & 63u) + 1, L TW_SEL_PASS, true, &D, true);
+        if (threadIdx.x == 0) next_item = (int)gridDim.x + atomicAdd(&P.heavy_next[kHardNext], 1);
+        group_sync();
+        item = next_item;
+        group_sync();
+    }
+    TW_SEL_FLUSH();
 }
 
 // ---------------------------------------------------------------------------------------------
