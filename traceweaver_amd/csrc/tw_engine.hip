@@ -286,13 +286,13 @@ void launch_select_listed(tw_engine* e) {
     const dim3 grid((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096));
     (void)hipEventRecord(e->cls_ev[0], e->stream);
     (void)hipStreamWaitEvent(e->cls_stream[1], e->cls_ev[0], 0);
-    hipLaunchKernelGGL((k_select_heavy<SelectLds, 3>), grid, wave, 0, e->cls_stream[1], P);      // the longest searches first
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsLvl, 3>), grid, wave, 0, e->cls_stream[1], P);      // the longest searches first
     (void)hipEventRecord(e->cls_ev[1], e->cls_stream[1]);
     (void)hipStreamWaitEvent(e->cls_stream[2], e->cls_ev[0], 0);
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsBig, 1>), grid, wave, 0, e->cls_stream[2], P);
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsBigLvl, 1>), grid, wave, 0, e->cls_stream[2], P);
     (void)hipEventRecord(e->cls_ev[2], e->cls_stream[2]);
     (void)hipStreamWaitEvent(e->cls_stream[3], e->cls_ev[0], 0);
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsMid, 2>), grid, wave, 0, e->cls_stream[3], P);
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsMidLvl, 2>), grid, wave, 0, e->cls_stream[3], P);
     (void)hipEventRecord(e->cls_ev[3], e->cls_stream[3]);
     hipLaunchKernelGGL(k_select_tiny, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 8192)), wave, 0, e->stream, P);
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[1], 0);

@@ -1785,11 +1785,13 @@ constexpr int kMemoSlots = TW_MEMO_SLOTS;      // transposition table entries (L
 // ---- cooperative path: one workgroup per window --------------------------------------------------
 // MW = spans a window may hold; SEARCH = false leaves out what only select_search needs (windows of <= kBruteMax spans
 // have no larger component: k_select_tiny, 1 KB instead of 22 KB of LDS per wavefront)
-template <int MW, bool SEARCH>
+// DFS = false leaves out what only the depth-first search needs (transposition table, matching relaxation): the layouts of
+// k_select_heavy, whose components are solved level by level (select_dp) or handed to k_select_dp -- more workgroups per CU
+template <int MW, bool SEARCH, bool DFS = true>
 struct SelectLdsT {
     static constexpr bool kSearch = SEARCH;
     // transposition table entries by layout (TW_MEMO_MID / TW_MEMO_BIG: the windows of 5-7 and 8-15 spans)
-    static constexpr int kS = SEARCH ? MW : 1, kSlots = !SEARCH ? 1 : (MW <= 8 ? TW_MEMO_MID : (MW <= 16 ? TW_MEMO_BIG : kMemoSlots));
+    static constexpr int kS = SEARCH ? MW : 1, kSlots = !(SEARCH && DFS) ? 1 : (MW <= 8 ? TW_MEMO_MID : (MW <= 16 ? TW_MEMO_BIG : kMemoSlots));
     static constexpr int kW = SEARCH ? (MW * kTopK + 63) / 64 : 1;   // words of a mask over all candidates of a component
     int32_t idx[MW][kTopK][kMaxEp];
     sel_w w[MW][kTopK];  // sel_weight(score); <= 0 means not eligible
@@ -1819,14 +1821,16 @@ struct SelectLdsT {
 #endif
     // matching relaxation (select_match_prunes): columns = outgoing spans of one endpoint addressed by index - base, then
     // one "unassigned" column per row
-    static constexpr int kCols = SEARCH ? MW * 4 : 1;   // (candidates of a component lie close together: its spans overlap in time)
+    static constexpr int kCols = (SEARCH && DFS) ? MW * 4 : 1;   // (candidates of a component lie close together: its spans overlap in time)
     sel_w hu[kS + 1], hv[kCols + 1], hminv[kCols + 1];
     uint8_t hp[kCols + 1], hway[kCols + 1], hused[kCols + 1], htouch[kCols + 1];
 };
 typedef SelectLdsT<kMaxWin, true> SelectLds;
 typedef SelectLdsT<kBruteMax, false> SelectLdsTiny;
-typedef SelectLdsT<kHugeWindow, true> SelectLdsBig;   // windows of kBigWindow <= m < kHugeWindow spans: two-word masks, 12 KB
-typedef SelectLdsT<kBigWindow, true> SelectLdsMid;   // windows of kBruteMax < m < kBigWindow spans: one-word masks, 7 KB
+// k_select_heavy: the three window classes without the depth-first search's tables
+typedef SelectLdsT<kMaxWin, true, false> SelectLdsLvl;        // kHugeWindow .. kMaxWin spans: three-word masks
+typedef SelectLdsT<kHugeWindow, true, false> SelectLdsBigLvl; // windows of kBigWindow <= m < kHugeWindow spans: two-word masks
+typedef SelectLdsT<kBigWindow, true, false> SelectLdsMidLvl;  // windows of kBruteMax < m < kBigWindow spans: one-word masks
 
 template <class LDS>
 __device__ inline bool lds_share(const LDS& L, int E, int b1, int k1, int b2, int k2) {
@@ -1979,7 +1983,7 @@ __device__ __forceinline__ long long uni(long long x) {
 // node_cap > 0: a search that has not finished after that many nodes is given up (returns true, L.pick of the members is not
 // written): the window goes to k_select_dp, which solves such components level by level over all lanes (select_dp).
 template <class LDS>
-__device__ bool select_search_body(LDS& L, int E, int node_cap) {
+__device__ bool select_search_body(LDS& L, int E, int node_cap, int match_after = kMatchNodes1) {
     constexpr int W = LDS::kW;   // words of the blocked mask: kept in up to three registers, the unused ones are constant zero
     static_assert(W >= 1 && W <= 3 && kBlkWords == 3, "the blocked mask is kept in three registers");
     static_assert(kMaxWin < 64 && kTopK <= 8, "one lane per depth, one bit per candidate");
@@ -2054,7 +2058,7 @@ __device__ bool select_search_body(LDS& L, int E, int node_cap) {
         if (entered) {
             if (++nodes > kNodeBudget) { over = true; break; }
             if (node_cap > 0 && nodes > node_cap) { capped = true; break; }
-            if (E == 1 && exact == 0 && nodes > kMatchNodes1) {
+            if (E == 1 && exact == 0 && nodes > match_after) {
                 sel_w opt = 0;
                 if (t == 0) opt = select_match_bound(L, 0, 0, 0ull, 0ull, 0ull);   // (the matching runs in one lane, on LDS)
                 opt = uni(opt);
@@ -2192,12 +2196,14 @@ __device__ bool select_search(LDS& L, int E, int node_cap = 0) {
 constexpr int kDpCap = TW_DP_CAP, kDpSlots = TW_DP_SLOTS;                    // k_select_dp: states per level, hash table slots
 constexpr int kDpCapSmall = TW_DP_CAP_SMALL, kDpSlotsSmall = TW_DP_SLOTS_SMALL;   // k_select_heavy
 constexpr int kDpThreads = 256;
+constexpr unsigned long long kDpSlack0 = 16ull << 32;   // the first guess of select_dp's threshold: the sum of the best weights less 16.0 in score units
 constexpr int kDpDigit = 3, kDpNone = 7, kDpWord0 = 21;   // choice vector: 3 bits a level, levels 0..20 in the first word (earlier = more significant)
 static_assert(kTopK < kDpNone && kMaxWin <= 2 * kDpWord0, "choice vector in two words");
 template <int W, int CAP, int SLOTS>
 struct SelectDpT {
     typedef unsigned long long ull;
     static constexpr int kW = W, kCap = CAP, kSlots = SLOTS;
+    static constexpr int kGuesses = CAP > TW_DP_CAP_SMALL ? 5 : 0;   // guessed thresholds after the greedy leaf's (the small tables of k_select_heavy: none, the window goes to k_select_dp)
     static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS > CAP, "open addressing needs a free slot");
     ull ck[W][CAP], cacc[CAP], cp[2][CAP];                    // the states of the current level
     ull th[SLOTS], tk[W][SLOTS], tacc[SLOTS], tp[2][SLOTS];   // the next level as a hash table
@@ -2226,15 +2232,38 @@ __device__ bool select_dp(LDS& L, DP& D, int E) {
                 break;
             }
         }
-        D.lb = acc; D.n_cur = 1; D.fail = 0; D.fail2 = 0;
+        D.lb = acc;
+    }
+    group_sync();
+    // The threshold below which children are dropped: first the greedy leaf's weight (nearly always enough: one attempt).  Where
+    // the levels outgrow the table with it -- the leaf can be two or three assignments short of the optimum, and then the levels
+    // hold every state that has lost that much (measured on the nodejs shape: levels of 700 states with it, of 19 with the optimum
+    // itself) -- the threshold is *guessed* instead: (sum of the spans' best weights) - slack, slack = 16, 256, 4096 in units of
+    // the score (what second-best candidates cost), then 1/2, 3/2, ... average weights (what unassigned spans cost).  A guess
+    // above the optimum kills every state at some level: raise the slack; a guess whose levels outgrow the table: halve the
+    // distance to the largest slack that died; a guess that reaches level cm has kept, at every level, all states that can
+    // reach its threshold <= optimum, i.e. every prefix of every maximum: its survivor is the answer.  Nothing between a dead
+    // and an outgrown slack one score unit apart: given back.
+    const ull lb_greedy = D.lb, ub_all = (ull)L.ub[0], unit = ub_all / (ull)(cm > 0 ? cm : 1) + 1ull;
+    const ull slack_greedy = ub_all > lb_greedy ? ub_all - lb_greedy : 0ull;
+    ull slack = slack_greedy, slack_dead = 0ull, slack_over = slack_greedy;   // died at <= slack_dead, outgrew the table at >= slack_over
+    unsigned long long states = 0ull;
+    bool dead = false, gave_up = false, exact_asked = false;
+#ifdef TW_DP_TRACE
+    int trace_max = 0, attempts = 0;
+#endif
+    for (int attempt = 0;; attempt++) {
+    const ull lb = ub_all - slack;
+    group_sync();   // (every lane has read the last attempt's D.n_cur)
+    if (t == 0) {
+        D.n_cur = 1; D.fail = 0; D.fail2 = 0;
         for (int w = 0; w < W; w++) D.ck[w][0] = 0ull;
         D.cacc[0] = 0ull; D.cp[0][0] = 0ull; D.cp[1][0] = 0ull;
     }
     group_sync();
-    const ull lb = D.lb;
-    unsigned long long states = 0ull;
+    dead = false;
 #ifdef TW_DP_TRACE
-    int trace_max = 0;
+    attempts++;
 #endif
     struct Child { ull k[3], acc, p[2], tag; unsigned slot; bool ok; };
     for (int d = 0; d < cm; d++) {
@@ -2360,11 +2389,35 @@ __device__ bool select_dp(LDS& L, DP& D, int E) {
         group_sync();
         if (t == 0) D.n_cur = D.n_next;
         group_sync();
+        if (D.n_cur == 0) { dead = true; break; }   // (uniform) the guess was above the optimum
+    }
+    if (!dead && D.fail == 0) break;            // reached level cm, or two keys with one tag (fail2)
+    if (dead) slack_dead = slack; else slack_over = slack;
+    if (E == 1 && DP::kGuesses > 0) {
+        // one endpoint: the matching relaxation of the whole component is its optimum (select_match_bound; one lane, about as
+        // long as fifty nodes of the depth-first search) -- the threshold that keeps nothing but prefixes of maxima
+        if (exact_asked) { gave_up = true; break; }   // (the levels outgrow the table even so)
+        exact_asked = true;
+        if (t == 0) D.lb = (ull)select_match_bound(L, 0, 0, 0ull, 0ull, 0ull);
+        group_sync();
+        const ull opt = D.lb;
+        if (opt != (ull)kNoBound && opt <= ub_all && opt >= lb_greedy) { slack = ub_all - opt; continue; }
+    }
+    if (attempt >= DP::kGuesses) { gave_up = true; break; }   // (tie-saturated components outgrow the table at every slack that is not dead)
+    {   // the next guess: the schedule's first slack above the largest dead one, or half way to the smallest outgrown one
+        ull next = kDpSlack0;
+        for (int j = 0; next <= slack_dead; j++) next = j < 2 ? next << 4 : (j == 2 ? unit / 2ull : next + unit);
+        if (next >= slack_over) {
+            if (slack_over - slack_dead <= (1ull << 32)) { gave_up = true; break; }
+            next = slack_dead + (slack_over - slack_dead) / 2ull;
+        }
+        slack = next;
+    }
     }
     if (t == 0) L.nodes_total += states;
-    const bool failed = D.fail != 0 || D.fail2 != 0 || D.n_cur != 1;
+    const bool failed = gave_up || dead || D.fail != 0 || D.fail2 != 0 || D.n_cur != 1;
 #ifdef TW_DP_TRACE
-    if (t == 0) printf("select_dp<%d>: component of %d spans, %llu states, widest level %d, %s\n", DP::kCap, cm, states, trace_max, failed ? "given back" : "solved");
+    if (t == 0) printf("select_dp<%d>: component of %d spans, %llu states, widest level %d, attempts %d, %s\n", DP::kCap, cm, states, trace_max, attempts, failed ? "given back" : "solved");
 #endif
     if (!failed) {
         const ull acc = D.cacc[0], p0 = D.cp[0][0], p1 = D.cp[1][0];
@@ -2622,6 +2675,7 @@ __device__ bool select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             if (dp != nullptr) {
                 group_sync();
                 suffix_bound(false);
+                TW_SEL_TICK(3);
                 solved = select_dp(L, *dp, E);
             }
         }
@@ -2650,7 +2704,7 @@ __device__ bool select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             }
             group_sync();
             suffix_bound(true);
-            if (t < 64) select_search_body(L, E, 0);
+            if (t < 64) select_search_body(L, E, 0, dp != nullptr ? 0 : kMatchNodes1);   // (behind the level-by-level solver: a hard one, ask for the optimum at once)
             group_sync();
         }
         TW_SEL_TICK(5);
