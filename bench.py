@@ -192,9 +192,14 @@ REGIMES = [   # (key, workload, overrides): BASELINE.json configs 3 and 4 on one
     ("config4_alibaba_1gpu", "alibaba", {}),
     ("media_concurrency4", "media", {"n_in": 20000, "replicas": 4, "concurrency": 4.0}),
     ("media_concurrency8", "media", {"n_in": 5000, "replicas": 4, "concurrency": 8.0}),
+    # the same two BASELINE shapes with enough resident work to fill the GPU (the lines above are latency at the configs' own sizes):
+    # saturated throughput of the ms-granular / deep-call-graph paths
+    ("config3_nodejs_saturated", "nodejs", {"n_in": 100000, "replicas": 16}),
+    ("config4_alibaba_saturated", "alibaba", {"total_spans": 16000000}),
 ]
 # the record of the reference itself (oracle/refrun/time_reference.py, build container) that belongs to each regime's shape
-REGIME_REFERENCE = {"config3_nodejs": "nodeio", "config4_alibaba_1gpu": "alibaba", "media_concurrency4": "media", "media_concurrency8": "media"}
+REGIME_REFERENCE = {"config3_nodejs": "nodeio", "config4_alibaba_1gpu": "alibaba", "media_concurrency4": "media", "media_concurrency8": "media",
+                    "config3_nodejs_saturated": "nodeio", "config4_alibaba_saturated": "alibaba"}
 
 
 def reference_record(shape):
@@ -218,7 +223,7 @@ def run_regimes(args, eng, steps=3):
         a = copy.copy(args)
         a.workload = workload
         a.concurrency = over.get("concurrency")
-        units, truth, name = make_units(a, 1000, n_in=over.get("n_in"), replicas=over.get("replicas"))
+        units, truth, name = make_units(a, 1000, n_in=over.get("n_in"), replicas=over.get("replicas"), total_spans=over.get("total_spans"))
         spans = int(sum(u.n_spans for u in units))
         eng.load(units)
         eng.set_truth(truth)
@@ -238,6 +243,8 @@ def run_regimes(args, eng, steps=3):
         out[key] = {"workload": name, "spans": spans, "value": spans / dt, "unit": "spans/s", "ms_per_step": dt * 1e3, "steps": steps,
                     "accuracy": float(sum(r["accuracy"] * u.n_in for r, u in zip(res, units)) / n_req),
                     "budget_windows": int(sum(r["budget_windows"] for r in stats)), "repaired_windows": int(sum(r["repaired_windows"] for r in stats)),
+                    "windows": int(sum(r["n_windows"] for r in stats)), "dp_windows": int(sum(r["dp_windows"] for r in stats)),
+                    "dfs_components": int(sum(r["dfs_components"] for r in stats)),
                     "repair_rounds_per_pass": float(np.mean(rounds)),
                     "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                  "frac": achieved / HBM_PEAK_GBPS, "kernel_ms": groups[dominant], "group_ms_per_launch": groups,

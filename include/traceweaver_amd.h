@@ -218,7 +218,9 @@ int tw_run_pass2(tw_engine *e);
  *   window_end  uint8  [n_in] 1 where a window closes (traceweaver_v3.py:1192)
  *   unit_stats  int64  [n_units][8]: not_best_count, cnt_unassigned, n_windows, windows re-solved
  *                      because an earlier window consumed one of their candidates, windows whose
- *                      exact selection search hit its node budget (incumbent returned), 3 reserved */
+ *                      exact selection search hit its node budget (incumbent returned), search nodes /
+ *                      states of the selection, windows solved by k_select_dp (a level outgrew the small
+ *                      tables of k_select_heavy), components it handed on to the depth-first search */
 typedef struct {
     int32_t *parent;
     int32_t *topk_idx;

@@ -24,7 +24,7 @@ def build(force=False, production=False):
         "-DTW_FRONTIER_CAP=512", "-DTW_FRONTIER_BIG_CAP=8192", "-DTW_FRONTIER_BIG_SLOTS=3",   # small lists: own buffers, pool slots and the walk all occur in the tests
         "-DTW_MATCH_NODES_1=48", "-DTW_MATCH_NODES=256",
         "-DTW_TILE_SMALL", "-DTW_TILE_MAX=24",
-        "-DTW_DP_CAP=96", "-DTW_DP_SLOTS=128", "-DTW_DP_CAP_SMALL=6", "-DTW_DP_SLOTS_SMALL=8",   # small tables of the level-by-level solver: both overflow routes (k_select_dp, then the depth-first search) occur
+        "-DTW_DP_CAP=24", "-DTW_DP_SLOTS=32", "-DTW_DP_CAP_SMALL=6", "-DTW_DP_SLOTS_SMALL=8",   # small tables of the level-by-level solver: both overflow routes (k_select_dp, then the depth-first search) occur
         "-DTW_PRUNE_MIN=48", "-DTW_PRUNE_GRID=8"]   # the wavefront kernel's walk is pruned from 48 grid points on   # the tile kernel: short slices (windows beyond them go to the wavefront kernel), several segments per tile   # the selection search consults the matching relaxation early
     subprocess.check_call(
         ["g++", "-x", "c++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",

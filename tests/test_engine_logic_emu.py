@@ -35,6 +35,19 @@ def test_emulated_engine_matches_oracle_on_stress_units(emu_lib):
     assert sum(r["repaired_windows"] for r in r1) > 0, "the stress set must exercise the consumption repair walk"
 
 
+def test_selection_takes_every_route_of_the_level_solver(emu_lib):
+    """The selection of a component of more than four spans is solved level by level (select_dp): on the small tables of
+    k_select_heavy, on the large ones of k_select_dp when a level outgrows those, by the depth-first search when a level
+    outgrows those too (the test build's tables hold 6 / 24 states).  The heavy-load units below take all three routes;
+    check_units holds every one of them to the oracle's canonical selection."""
+    cases = [(2, 400, "chain3", 4, 1), (3, 300, "chain3", 8, 1), (6, 400, "single", 10, 1), (8, 300, "chain2", 12, 1000), (13, 513, "par2", 2, 1000)]
+    units, _ = parity.stress_units(cases)
+    r1, r2, _ = parity.check_units(emu_lib, units)
+    assert sum(r["dp_windows"] for r in r1 + r2) > 0, "no window outgrew the small tables"
+    assert sum(r["dfs_components"] for r in r1 + r2) > 0, "no component outgrew the large tables"
+    assert sum(r["budget_windows"] for r in r1 + r2) == 0
+
+
 def test_error_statuses(emu_lib):
     from traceweaver_amd import synth
     from traceweaver_amd.engine import Engine, EngineError, UnitArrays

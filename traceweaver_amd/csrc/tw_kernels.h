@@ -2681,6 +2681,7 @@ __device__ bool select_window_coop(const Dev& P, const UnitDev& U, int unit, int
         }
         if (!solved) {
             if (dp != nullptr && !dfs_fallback) { hard = true; break; }   // (uniform)
+            if (dp != nullptr && t == 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 7], 1ull);
             {
                 const int cm = L.cm, npair = cm > 1 ? cm - 1 : 0, ntrip = cm > 2 ? cm - 2 : 0;
                 constexpr int C = kTopK + 1;  // choices per span: a candidate or "none"
@@ -2862,6 +2863,7 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
             if (threadIdx.x == 0) {
                 const int at = atomicAdd(&P.heavy_next[kHardCount], 1);
                 P.hard_unit[at] = unit; P.hard_win[at] = (int32_t)fm;
+                atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 6], 1ull);
             }
         }
         if (unit != nodes_unit) {   // (uniform) search nodes per unit, added up over the windows this workgroup serves

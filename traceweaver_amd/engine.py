@@ -294,7 +294,8 @@ class Engine(object):
             if buf["unit_stats"] is not None:
                 st = buf["unit_stats"][k]
                 o.update({"not_best_count": int(st[0]), "cnt_unassigned": int(st[1]), "n_windows": int(st[2]),
-                          "repaired_windows": int(st[3]), "budget_windows": int(st[4]), "search_nodes": int(st[5])})
+                          "repaired_windows": int(st[3]), "budget_windows": int(st[4]), "search_nodes": int(st[5]),
+                          "dp_windows": int(st[6]), "dfs_components": int(st[7])})
             out.append(o)
         return out
 
