@@ -107,9 +107,10 @@ __device__ inline void block_reduce(double (&vals)[cnt], double* sh) {
 
 // One workgroup per scored row: distinct values and their first positions (a head is a sample that differs
 // from its left neighbour; NaN = dropped samples, sorted last, are not counted).
-__global__ void __launch_bounds__(kCoop) k_fit_compress(FitDev F) {
-    constexpr int R = 4;  // chunks of blockDim samples per round: their loads are in flight together
-    __shared__ int32_t wave_heads[R][kCoop / 64];
+constexpr int kCompressThreads = 1024;   // a row of 10^5 samples in a dozen rounds (256 threads, 4 chunks a round: a hundred rounds of two barriers each, 0.54 ms)
+__global__ void __launch_bounds__(kCompressThreads) k_fit_compress(FitDev F) {
+    constexpr int R = 8;  // chunks of blockDim samples per round: their loads are in flight together
+    __shared__ int32_t wave_heads[R][kCompressThreads / 64];
     __shared__ int32_t carry_sh, n_sh;
     const int64_t q = blockIdx.x;
     const int t = threadIdx.x, nt = blockDim.x;
