@@ -299,7 +299,7 @@ void launch_select_listed(tw_engine* e) {
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[2], 0);
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[3], 0);
     // the windows the searches gave up on (kDpNodes), level by level over 256 lanes each; nothing listed: the workgroups leave at once
-    hipLaunchKernelGGL(k_select_dp, dim3(256), dim3(std::min(e->coop, kDpThreads)), 0, e->stream, P);
+    hipLaunchKernelGGL(k_select_dp, dim3(kDpCap <= 384 ? 512 : 256), dim3(std::min(e->coop, kDpThreads)), 0, e->stream, P);   // (one / two workgroups per CU by their LDS)
 }
 
 // OR of (key ^ first key) and of the keys themselves over a set of index ranges (see k_key_bits)

@@ -2181,11 +2181,14 @@ __device__ bool select_search(LDS& L, int E, int node_cap = 0) {
 // depth-first search 5-9 x 10^3 nodes hold 1 405 states over all levels).  A level that outgrows the table (or a tag collision
 // between different keys) returns false: k_select_heavy (tables of kDpCapSmall states, one wavefront) then lists the window for
 // k_select_dp (kDpCap states, kDpThreads lanes), and that one falls back to select_search.
+// (k_select_dp: 384 states a level = 47 KB of tables + the window's 22 KB: two workgroups per CU.  768 / 1024 -- one per CU -- was
+// measured: the nodejs shape's selection 2.56 instead of 2.35 ms per launch, 20.1 instead of 19.2 ms with 14 M spans resident; the
+// few levels between 384 and 768 states go through the guessed thresholds instead.)
 #ifndef TW_DP_CAP
-#define TW_DP_CAP 768
+#define TW_DP_CAP 384
 #endif
 #ifndef TW_DP_SLOTS
-#define TW_DP_SLOTS 1024
+#define TW_DP_SLOTS 512
 #endif
 #ifndef TW_DP_CAP_SMALL
 #define TW_DP_CAP_SMALL 32
