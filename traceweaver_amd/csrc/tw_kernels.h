@@ -1920,11 +1920,100 @@ __device__ sel_w select_match_bound(LDS& L, int e, int d, unsigned long long b0,
         return L.hv[0];   // = -(minimum cost) = maximum weight of the relaxed sub-problem
     }
 }
+__device__ __forceinline__ int uni(int x);               // (the value of the first active lane; defined with the lane arrays below)
+__device__ __forceinline__ long long uni(long long x);
+// The same bound by the whole wavefront (every lane of the first wavefront calls, with wave-uniform arguments): lane j holds
+// column j -- its potential, slack, tree flag, predecessor and matched row -- and lane i the potential of row i, in registers;
+// one step of the shortest-augmenting-path search is a handful of broadcast row edges, one minimum over the lanes and one
+// update of every lane's own column, instead of the serial walk over the touched columns in LDS (a matching of 18 rows:
+// ~100 us in one lane, a tenth of that here).  The optimum of an assignment problem is unique, so both return the same bound
+// whatever augmenting paths they take.  Needs rows + columns <= 63; otherwise (and in the one-thread emulation of the tests)
+// the serial form runs in the first lane.
+template <class LDS>
+__device__ sel_w select_match_bound_wave(LDS& L, int e, int d, unsigned long long b0, unsigned long long b1, unsigned long long b2) {
+    const int lane = (int)threadIdx.x & 63;
+    const sel_w INF = kNoBound;
+    const int cm = L.cm, nrow = cm - d;
+    auto eligible = [&L, b0, b1, b2](int dd, int k) -> bool {
+        const int b = L.mem[dd];
+        if (k >= L.ncand[b] || !(L.w[b][k] > 0)) return false;
+        const int bit = dd * kTopK + k;
+        unsigned long long w = b2;
+        if (bit < 128) w = b1;
+        if (bit < 64) w = b0;
+        return !((w >> (bit & 63)) & 1ull);
+    };
+    // the range of the endpoint's candidate indices: a row per lane, then the minimum / maximum over the lanes
+    int32_t base = 0x7fffffff, top = -0x7fffffff - 1;
+    if (lane < nrow)
+        for (int k = 0; k < kTopK; k++)
+            if (eligible(d + lane, k)) { const int32_t x = L.idx[L.mem[d + lane]][k][e]; base = x < base ? x : base; top = x > top ? x : top; }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int32_t ob = __shfl_xor(base, off), ot = __shfl_xor(top, off);
+        base = ob < base ? ob : base; top = ot > top ? ot : top;
+    }
+    if (top < base) { top = 0; base = 1; }
+    const long long span = (long long)top - base + 1;
+    if (span + nrow > 63 || (int)blockDim.x < 64) {   // (uniform) too many columns for a lane each, or no lanes at all
+        sel_w r = 0;
+        if (threadIdx.x == 0) r = select_match_bound(L, e, d, b0, b1, b2);
+        return uni((long long)r);
+    }
+    const int ncol = (int)span, m = ncol + nrow;   // columns 1..ncol: outgoing spans; ncol + i: row i stays unassigned; column 0: the search's root
+#ifdef TW_DP_TRACE
+    if (threadIdx.x == 0) printf("match_wave: %d rows, %d columns\n", nrow, m);
+#endif
+    sel_w v = 0, u = 0, minv = INF;
+    int p = 0, way = 0;
+    bool used = false, in_tree = false;
+    for (int i = 1; i <= nrow; i++) {
+        if (lane == 0) p = i;
+        minv = INF; used = false; in_tree = false;
+        int j0 = 0;
+        while (true) {
+            if (lane == j0) used = true;
+            const int i0 = uni(__shfl(p, j0));
+            if (lane == i0) in_tree = true;
+            const sel_w ui = (sel_w)uni((long long)__shfl(u, i0));
+            const int dd = d + i0 - 1, b = L.mem[dd];
+            for (int k = 0; k <= kTopK; k++) {   // the row's edges: its eligible candidates, then "unassigned"
+                int j;
+                sel_w a;
+                if (k < kTopK) {
+                    if (!eligible(dd, k)) continue;   // (uniform)
+                    j = L.idx[b][k][e] - base + 1;
+                    a = -L.w[b][k];
+                } else { j = ncol + i0; a = 0; }
+                if (lane == j && !used) {
+                    const sel_w cur = a - ui - v;
+                    if (cur < minv) { minv = cur; way = j0; }
+                }
+            }
+            // the unused column of least slack (every row has its "unassigned" column, so one always exists)
+            sel_w best = (!used && lane >= 1 && lane <= m) ? minv : INF;
+            for (int off = 32; off >= 1; off >>= 1) { const sel_w o = __shfl_xor(best, off); best = o < best ? o : best; }
+            const sel_w delta = best;
+            const unsigned long long at = __ballot(!used && lane >= 1 && lane <= m && minv == delta);
+            const int j1 = __ffsll((long long)at) - 1;
+            if (used) v -= delta; else if (minv != INF) minv -= delta;
+            if (in_tree) u += delta;
+            j0 = j1;
+            if (uni(__shfl(p, j0)) == 0) break;
+        }
+        while (j0 != 0) {   // the augmenting path back to the root
+            const int j1 = uni(__shfl(way, j0));
+            const int pj = uni(__shfl(p, j1));
+            if (lane == j0) p = pj;
+            j0 = j1;
+        }
+    }
+    return (sel_w)uni((long long)__shfl(v, 0));   // = -(minimum cost) = maximum weight of the relaxed sub-problem
+}
 // true when for some endpoint weight above + bound <= incumbent: nothing below the node can improve on it
 template <class LDS>
 __device__ bool select_match_prunes(LDS& L, int E, int d, sel_w acc, sel_w best_w, unsigned long long b0, unsigned long long b1, unsigned long long b2) {
-    for (int e = 0; e < E; e++) {
-        const sel_w bound = select_match_bound(L, e, d, b0, b1, b2);
+    for (int e = 0; e < E; e++) {   // (called by every lane of the first wavefront: uniform arguments, uniform result)
+        const sel_w bound = select_match_bound_wave(L, e, d, b0, b1, b2);
         if (bound != kNoBound && acc + bound <= best_w) return true;
     }
     return false;
@@ -2060,8 +2149,7 @@ __device__ bool select_search_body(LDS& L, int E, int node_cap, int match_after 
             if (node_cap > 0 && nodes > node_cap) { capped = true; break; }
             if (E == 1 && exact == 0 && nodes > match_after) {
                 sel_w opt = 0;
-                if (t == 0) opt = select_match_bound(L, 0, 0, 0ull, 0ull, 0ull);   // (the matching runs in one lane, on LDS)
-                opt = uni(opt);
+                opt = select_match_bound_wave(L, 0, 0, 0ull, 0ull, 0ull);
                 exact = opt == kNoBound ? -1 : 1;
                 if (exact == 1) {
                     if (best_w >= opt) break;   // the incumbent is the first selection of that weight in depth-first order
@@ -2094,8 +2182,8 @@ __device__ bool select_search_body(LDS& L, int E, int node_cap, int match_after 
                 const long long _m0 = wall_clock64();
 #endif
                 int hit = 0;
-                if (t == 0) hit = select_match_prunes(L, E, d, acc, best_w, b0, b1, b2);
-                cut = uni(hit) != 0;
+                hit = select_match_prunes(L, E, d, acc, best_w, b0, b1, b2) ? 1 : 0;
+                cut = hit != 0;
 #ifdef TW_PROFILE_SEL
                 if (t == 0) { L.pt[1] += wall_clock64() - _m0; L.pt[2] += 1; }
 #endif
@@ -2401,7 +2489,7 @@ __device__ bool select_dp(LDS& L, DP& D, int E) {
         // long as fifty nodes of the depth-first search) -- the threshold that keeps nothing but prefixes of maxima
         if (exact_asked) { gave_up = true; break; }   // (the levels outgrow the table even so)
         exact_asked = true;
-        if (t == 0) D.lb = (ull)select_match_bound(L, 0, 0, 0ull, 0ull, 0ull);
+        if (t < 64) { const sel_w mo = select_match_bound_wave(L, 0, 0, 0ull, 0ull, 0ull); if (t == 0) D.lb = (ull)mo; }
         group_sync();
         const ull opt = D.lb;
         if (opt != (ull)kNoBound && opt <= ub_all && opt >= lb_greedy) { slack = ub_all - opt; continue; }
