@@ -1789,7 +1789,7 @@ constexpr int kMemoSlots = TW_MEMO_SLOTS;      // transposition table entries (L
 // k_select_heavy, whose components are solved level by level (select_dp) or handed to k_select_dp -- more workgroups per CU
 template <int MW, bool SEARCH, bool DFS = true>
 struct SelectLdsT {
-    static constexpr bool kSearch = SEARCH;
+    static constexpr bool kSearch = SEARCH, kDfs = DFS;
     // transposition table entries by layout (TW_MEMO_MID / TW_MEMO_BIG: the windows of 5-7 and 8-15 spans)
     static constexpr int kS = SEARCH ? MW : 1, kSlots = !(SEARCH && DFS) ? 1 : (MW <= 8 ? TW_MEMO_MID : (MW <= 16 ? TW_MEMO_BIG : kMemoSlots));
     static constexpr int kW = SEARCH ? (MW * kTopK + 63) / 64 : 1;   // words of a mask over all candidates of a component
@@ -2771,7 +2771,8 @@ __device__ bool select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             }
         }
         if (!solved) {
-            if (dp != nullptr && !dfs_fallback) { hard = true; break; }   // (uniform)
+            if (!LDS::kDfs || (dp != nullptr && !dfs_fallback)) { hard = true; break; }   // (uniform)
+            if constexpr (LDS::kDfs) {   // (the layouts of k_select_heavy carry neither the search's tables nor its code)
             if (dp != nullptr && t == 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 7], 1ull);
             {
                 const int cm = L.cm, npair = cm > 1 ? cm - 1 : 0, ntrip = cm > 2 ? cm - 2 : 0;
@@ -2798,6 +2799,7 @@ __device__ bool select_window_coop(const Dev& P, const UnitDev& U, int unit, int
             suffix_bound(true);
             if (t < 64) select_search_body(L, E, 0, dp != nullptr ? 0 : kMatchNodes1);   // (behind the level-by-level solver: a hard one, ask for the optimum at once)
             group_sync();
+            }
         }
         TW_SEL_TICK(5);
         }
