@@ -166,6 +166,9 @@ def test_nodejs_fileio_shape_at_scale():
     r1, r2, _ = parity.check_units(None, units)
     assert sum(r["budget_windows"] for r in r1 + r2) == 0           # every selection is a proven optimum
     assert sum(r["repaired_windows"] for r in r1 + r2) > 0
+    # the level-by-level solver with its production tables: some windows outgrow the 32 states a level of k_select_heavy and are
+    # solved by k_select_dp (all of them held to the oracle's canonical selection above)
+    assert sum(r["dp_windows"] for r in r1 + r2) > 0
     for u, r in zip(units, r2):
         parity.assert_assignment_properties(u, r["parent"])
 
