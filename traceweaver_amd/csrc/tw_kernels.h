@@ -1801,6 +1801,11 @@ struct SelectLdsT {
     uint8_t ncand[MW], comp[MW], mem[MW];
     int8_t pick[MW];
     uint32_t adj[MW];  // span conflict relation as bit rows
+    // conflict relation through an occupancy table: per endpoint one word per outgoing-span index in [occ_lo, occ_hi], bit b set <=>
+    // span b has an eligible candidate that uses that outgoing span (windows whose index ranges add up to <= kOcc words)
+    static constexpr int kOcc = SEARCH ? 256 : 1;
+    uint32_t occ[kOcc];
+    int32_t occ_lo[kMaxEp], occ_hi[kMaxEp], occ_off[kMaxEp + 1];
     uint32_t cmask[kBruteMax][kTopK], celig[kBruteMax];  // select_brute: conflicts among / eligibility of the component's candidates
     unsigned long long g2[kS], g3[kS];  // pair / triple optima of the grouped bound (weights are > 0)
     // select_search: conflicts of candidate k of member x with the candidates of the other members as a bit
@@ -2663,7 +2668,50 @@ __device__ bool select_window_coop(const Dev& P, const UnitDev& U, int unit, int
     // candidate of c; one lane per pair
     // (a lane's chain of dependent LDS reads is what this phase costs: with few pairs the candidates of a pair are spread over
     // the lanes as well -- a window of four spans has 6 pairs for 64 lanes and up to 25 x E comparisons per pair)
-    if (m * (m - 1) / 2 * kTopK * kTopK <= 4 * nt) {   // one (pair, candidate, candidate) per lane
+    bool by_table = false;
+    if constexpr (LDS::kSearch) {
+        if (m > 2 * kBruteMax) {   // (long windows: one lane per pair walks 25 x E comparisons -- 20-50 us for 17 spans, measured)
+            for (int e = t; e < E; e += nt) { L.occ_lo[e] = 0x7fffffff; L.occ_hi[e] = -0x7fffffff - 1; }
+            group_sync();
+            for (int q = t; q < m * kTopK; q += nt) {
+                const int b = q / kTopK, k = q % kTopK;
+                if (k >= L.ncand[b] || !(L.w[b][k] > 0)) continue;
+                for (int e = 0; e < E; e++) { atomicMin(&L.occ_lo[e], L.idx[b][k][e]); atomicMax(&L.occ_hi[e], L.idx[b][k][e]); }
+            }
+            group_sync();
+            if (t == 0) {
+                long long at = 0;
+                for (int e = 0; e < E; e++) {
+                    L.occ_off[e] = (int32_t)at;
+                    if (L.occ_hi[e] >= L.occ_lo[e]) at += (long long)L.occ_hi[e] - L.occ_lo[e] + 1;
+                    if (at > LDS::kOcc) at = LDS::kOcc + 1;
+                }
+                L.occ_off[E] = (int32_t)at;
+            }
+            group_sync();
+            by_table = L.occ_off[E] <= LDS::kOcc;   // (uniform)
+            if (by_table) {
+                for (int q = t; q < L.occ_off[E]; q += nt) L.occ[q] = 0u;
+                group_sync();
+                for (int q = t; q < m * kTopK; q += nt) {
+                    const int b = q / kTopK, k = q % kTopK;
+                    if (k >= L.ncand[b] || !(L.w[b][k] > 0)) continue;
+                    for (int e = 0; e < E; e++) atomicOr(&L.occ[L.occ_off[e] + (L.idx[b][k][e] - L.occ_lo[e])], 1u << b);
+                }
+                group_sync();
+                for (int q = t; q < m * kTopK; q += nt) {
+                    const int b = q / kTopK, k = q % kTopK;
+                    if (k >= L.ncand[b] || !(L.w[b][k] > 0)) continue;
+                    uint32_t others = 0u;
+                    for (int e = 0; e < E; e++) others |= L.occ[L.occ_off[e] + (L.idx[b][k][e] - L.occ_lo[e])];
+                    others &= ~(1u << b);
+                    if (others) atomicOr(&L.adj[b], others);
+                }
+            }
+        }
+    }
+    if (by_table) {
+    } else if (m * (m - 1) / 2 * kTopK * kTopK <= 4 * nt) {   // one (pair, candidate, candidate) per lane
         for (int q = t; q < m * m * kTopK * kTopK; q += nt) {
             const int kb = q % kTopK, ka = (q / kTopK) % kTopK, c = (q / (kTopK * kTopK)) % m, b = q / (kTopK * kTopK * m);
             if (c >= b || ka >= L.ncand[b] || kb >= L.ncand[c] || !(L.w[b][ka] > 0) || !(L.w[c][kb] > 0)) continue;
