@@ -158,6 +158,7 @@ def _run_bench(emu_lib, *flags):
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.split("\n") if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints the one JSON line
+    assert out.stdout.rstrip("\n").split("\n")[-1] == lines[0] and len(lines[0]) < 2048, len(lines[0])   # ... last, and short enough for the driver's tail
     return json.loads(lines[0])
 
 
