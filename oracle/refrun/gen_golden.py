@@ -62,6 +62,7 @@ DATASETS = [
     ("hotel_load25", "data/hotel_reservation/hotel_load25/", 2), ("hotel_load75", "data/hotel_reservation/hotel_load75/", 2),
     ("hotel_load125", "data/hotel_reservation/hotel_load125/", 2),
     ("media_load25", "data/media_microservices/media_load25/", 1), ("media_load125", "data/media_microservices/media_load125/", 1),
+    ("media_load75", "data/media_microservices/media_load75/", 1),   # 1500 files: make_scratch_root keeps the first 1000 by name (reference hazard H3)
     ("node_load25", "data/nodejs_microservices/node_load25/", 0), ("node_load50", "data/nodejs_microservices/node_load50/", 0),
     ("node_load75", "data/nodejs_microservices/node_load75/", 0), ("node_load125", "data/nodejs_microservices/node_load125/", 0),
     ("nodeio_0", "data/nodejs_microservices_with_arbitrary_file_io/node_0/", 0),

@@ -20,7 +20,7 @@ REF_DATA = "/root/reference/data"
 
 
 def main():
-    from test_ingest import REFERENCE_CORPORA
+    from test_ingest import REFERENCE_CORPORA, reference_files
     from traceweaver_amd.ingest import REFERENCE_FIX, Corpus
 
     lib = sys.argv[1] if len(sys.argv) > 1 else None
@@ -32,7 +32,7 @@ def main():
     for name, rel, fix in REFERENCE_CORPORA:
         first_span, surgery = REFERENCE_FIX[fix]
         c = Corpus(lib_path=lib)
-        c.add_directory(os.path.join(REF_DATA, rel), first_span=first_span, max_traces=1001, fix=surgery)
+        c.add_files(reference_files(os.path.join(REF_DATA, rel)), first_span=first_span, max_traces=1001, fix=surgery)
         units, _, _ = c.units()
         out[name] = [u.service for u in units]
         c.close()

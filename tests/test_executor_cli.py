@@ -74,7 +74,9 @@ def test_corpora_that_need_span_surgery(emu_lib, tmp_path, name, rel, fix, n_ser
 
 def _all_corpora():
     from test_ingest import REFERENCE_CORPORA
-    return REFERENCE_CORPORA
+    # (media_load75 is frozen on its first 1000 files by name; the command line reads a directory, where the reference keeps the
+    # first 1001 of the 1500 traces in time order and then fails on a NaN parameter block, hazard H3: array-level tests only)
+    return [c for c in REFERENCE_CORPORA if c[0] != "media_load75"]
 
 
 @pytest.mark.skipif(not os.path.isdir(REF + "/data"), reason="the reference's data directory is not present")
