@@ -230,9 +230,9 @@ def test_split_enumerations(emu_lib, monkeypatch):
     """Very long enumerations are cut into parts by the first endpoint's candidate and merged (k_merge_parts).  The
     host-emulation build splits from ~100 grid points on: units without call-order constraints (every grid point a
     tuple, the prefix walk) and chains (the tuple list).  A span with two candidates of one endpoint that start together
-    is not split (Python's order of tuples may not decide between them); with TW_SPLIT_TWINS=1 it is, so that the
-    merge's way back -- order of equal scores not decided: the span is listed again and enumerated whole -- is reached
-    (millisecond timestamps).  Every unit equals the oracle bit for bit either way (check_units)."""
+    is split in log mode (heavy_append in tw_kernels.h); TW_SPLIT_TWINS=0 does not split it, TW_SPLIT_TWINS=1 splits it like the
+    others, so that the merge's way back -- order of equal scores not decided: the span is listed again and enumerated whole -- is
+    reached (millisecond timestamps).  Every unit equals the oracle bit for bit in all three settings (check_units)."""
     from traceweaver_amd.engine import Engine
 
     cases = [(21, 120, "par4", 4, 1), (22, 120, "chain3", 6, 1), (23, 100, "diamond", 5, 1), (24, 120, "par4", 3, 1000), (25, 80, "chain5", 3, 1),
@@ -249,11 +249,20 @@ def test_split_enumerations(emu_lib, monkeypatch):
         eng.close()
         return seen
 
+    # default (TW_SPLIT_TWINS=2): spans with twin candidates are split in log mode -- every part replays CPython's heap on its share
+    # and logs what entered it, k_merge_parts replays the logs; a log that outgrows its dozen entries (test build) sends the span
+    # back to be enumerated whole
+    parity.check_units(emu_lib, units, allow_budget=True)
+    logged = lists()
+    assert all(w["split_spans"] > 0 for w in logged), logged
+    monkeypatch.setenv("TW_SPLIT_TWINS", "0")   # twins not split: nothing comes back
     parity.check_units(emu_lib, units, allow_budget=True)
     seen = lists()
     assert all(w["split_spans"] > 0 for w in seen), seen
     assert all(w["split_redone"] == 0 for w in seen), seen         # no twins, no undecided order
-    monkeypatch.setenv("TW_SPLIT_TWINS", "1")
+    assert logged[3]["split_spans"] > seen[3]["split_spans"]        # (the millisecond-granular unit: twins)
+    assert logged[3]["split_redone"] < logged[3]["split_spans"] - seen[3]["split_spans"], logged   # ... and most of their logs were complete
+    monkeypatch.setenv("TW_SPLIT_TWINS", "1")   # twins split like the others: the order of equal scores is not decided, the span comes back
     parity.check_units(emu_lib, units, allow_budget=True)
     forced = lists()
     assert forced[3]["split_spans"] > seen[3]["split_spans"] and forced[3]["split_redone"] > 0, forced
@@ -338,3 +347,14 @@ def test_requests_longer_than_32_bit_offsets(emu_lib, case):
     in_end[-1] += 3 * 10 ** 9
     tail = UnitArrays(u.in_start, in_end, u.out_off, u.out_start, u.out_end, u.dag, u.key_rank)
     parity.check_units(emu_lib, [scaled, tail, u])
+
+
+def test_sliced_enumeration_equals_the_unsliced(emu_lib, monkeypatch):
+    """A class with many tiles is enumerated in slices of its tiles, each slice with its own ranges of the class' work lists and
+    its own counters (tw_engine.hip launch_enumerate): forced here on small units (every class in three slices), held to the
+    oracle like any other run -- incl. the split enumerations, whose parts and merge records live in the slice's ranges."""
+    monkeypatch.setenv("TW_ENUM_SLICES", "3")
+    monkeypatch.setenv("TW_ENUM_SLICE_MIN_TILES", "1")
+    units, _ = parity.stress_units(parity.STRESS)
+    r1, r2, _ = parity.check_units(emu_lib, units)
+    assert sum(r["repaired_windows"] for r in r1) > 0

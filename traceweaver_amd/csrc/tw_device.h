@@ -102,8 +102,9 @@ struct Dev {
     uint64_t* gone;     // kCandWords words: candidate spans taken by earlier windows when the span's current list was computed
     int64_t* leaves_r;  // per incoming span: tuples of the enumeration on the remaining spans (rep = 1)
     unsigned long long* frontier_big;  // pool of kFrontierBigSlots longer lists for the spans that outgrow their wavefront's buffers
-    int32_t* frontier_big_next;
-    int32_t* frontier_next;
+    int32_t* frontier_big_busy;   // [frontier_big_slots] 1 <=> the list is in use (pool_acquire / pool_release)
+    int32_t frontier_big_slots;
+    int32_t* frontier_busy;       // [kFrontierSlots] ... of the wavefronts' own buffer pairs
     unsigned long long* frontier;  // scratch of k_enumerate_heavy: per wavefront two lists of kFrontierCap feasible prefixes
     int32_t* round_changed;  // spans whose set of taken candidate spans changed in the current repair round
     int32_t* parent;
@@ -136,7 +137,10 @@ struct Dev {
     int32_t* heavy_big_part;   // [big list] number of parts | part << 8 | wide windows << 24   (1 = the whole enumeration)
     int32_t* heavy_big_slot;   // [big list] scratch slot of the part's result
     int32_t part_off[kMaxEp + 2];   // class offsets into the part scratch and the split-span records (2 slots per extra entry)
-    int32_t split_twins;       // debug (TW_SPLIT_TWINS=1): also split spans with twin candidates, so that tests reach the merge's way back
+    int32_t split_twins;       // spans with twin candidates (two candidates of one endpoint that start together: Python's order of tuples may not
+                               // decide): 2 (default) split, every part replays CPython's heap on its share and logs what entered it, k_merge_parts
+                               // replays the logs; 1 split like the others, the span enumerated again as a whole when the order is not decided
+                               // (tests: the merge's way back); 0 not split (TW_SPLIT_TWINS)
     int32_t* part_used;        // [kMaxEp+1] extra list entries handed out per class
     int32_t* split_count;      // [kMaxEp+1] split spans per class
     int32_t *split_unit, *split_idx, *split_slot, *split_parts;   // [part_off region] one record per split span
@@ -145,6 +149,11 @@ struct Dev {
     double* part_score;        // [slot][kTopK]
     int32_t* part_idx;         // [slot][kTopK][kMaxEp] span indices in the endpoint lists
     unsigned long long* part_bits;   // [slot][kMaxEp][kCandWords] candidate spans seen in a feasible tuple
+    // log mode (split spans with twin candidates): the tuples a part pushed on its own heap while their score was not below the
+    // heap's root -- a superset of the part's tuples that enter the heap of the whole enumeration -- in enumeration order
+    int32_t* part_logn;        // [slot] entries logged (more than kPartLogCap: the log is incomplete)
+    double* part_log_sc;       // [slot][kPartLogCap] score
+    unsigned long long* part_log_ix;   // [slot][kPartLogCap] positions in the cut-off windows, 8 bits per endpoint
     int32_t* err;           // first error raised by a kernel (tw_status)
     unsigned long long* prof;  // [16] phase timers of -DTW_PROFILE builds
 };

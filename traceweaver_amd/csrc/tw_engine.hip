@@ -27,6 +27,8 @@ using namespace tw;
 namespace {
 
 constexpr int kMaxRepairRounds = 1 << 20;
+constexpr int kMaxSlices = 8;        // slices of a class' tiles (launch_enumerate)
+constexpr int kSliceCtrInts = 160;   // heavy_in_count, heavy_in_next, heavy_big_count, part_used, split_count: 32 ints each
 enum { ST_EMPTY = 0, ST_LOADED = 1, ST_PASS1 = 2, ST_MIX = 3, ST_PASS2 = 4 };
 enum { EV_BEGIN = 0, EV_PARAMS, EV_ENUM0, EV_ENUM1, EV_WIN, EV_SEL, EV_REPAIR, EV_END, EV_COUNT };
 
@@ -73,6 +75,16 @@ struct tw_engine {
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[kMaxEp + 1] = {};   // one stream per endpoint count: the enumeration kernels of different classes overlap
     hipEvent_t cls_ev[kMaxEp + 2] = {};        // [0] fork, [E] class E done
+    // A class with many tiles is enumerated in slices of its tiles (launch_enumerate): the wavefront kernels of slice s -- the
+    // class' long tail -- run on the class' second stream beside the tile kernel of slice s + 1 instead of alone after it
+    hipStream_t cls_stream2[kMaxEp + 1] = {};
+    hipEvent_t cls_ev2[kMaxEp + 1] = {};
+    hipEvent_t slice_ev[kMaxEp + 1][kMaxSlices] = {};
+    int enum_slices = 1, slice_min_tiles = 2048;   // TW_ENUM_SLICES, TW_ENUM_SLICE_MIN_TILES
+    int cls_slices[kMaxEp + 1] = {};
+    int32_t slice_tile0[kMaxEp + 1][kMaxSlices + 1] = {};   // first tile of the slice within the class
+    int32_t slice_in0[kMaxEp + 1][kMaxSlices + 1] = {}, slice_big0[kMaxEp + 1][kMaxSlices + 1] = {}, slice_part0[kMaxEp + 1][kMaxSlices + 1] = {};
+    int32_t* slice_ctr = nullptr;              // [kMaxSlices - 1][kSliceCtrInts] work-list counters of the slices beyond the first
     std::string err;
     int state = ST_EMPTY;
     int tile = kTile;   // incoming spans (threads) per workgroup of the per-span kernels
@@ -226,22 +238,36 @@ int run_scan(tw_engine* e, typename Tr::T* agg) {
 // (work per span spans four orders of magnitude): each class runs on a stream of its own, forked from and joined to the
 // engine's stream by events, so that the tails overlap.  The wide instantiation of a class owns the big-list pool slots
 // together with the narrow one (one counter): no conflict, they only ever add.
+// The view of slice s of class E: its own ranges of the class' work lists and (s > 0) its own counters.
+template <int E>
+Dev slice_dev(const tw_engine* e, int s) {
+    Dev D = e->P;
+    if (e->cls_slices[E] <= 1) return D;
+    D.heavy_in_off[E] = e->slice_in0[E][s]; D.heavy_in_off[E + 1] = e->slice_in0[E][s + 1];
+    D.heavy_big_off[E] = e->slice_big0[E][s]; D.heavy_big_off[E + 1] = e->slice_big0[E][s + 1];
+    D.part_off[E] = e->slice_part0[E][s]; D.part_off[E + 1] = e->slice_part0[E][s + 1];
+    if (s > 0) {
+        int32_t* c = e->slice_ctr + (int64_t)(s - 1) * kSliceCtrInts;
+        D.heavy_in_count = c; D.heavy_in_next = c + 32; D.heavy_big_count = c + 64; D.part_used = c + 96; D.split_count = c + 128;
+    }
+    return D;
+}
+
 template <int E>
 void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
-    const Dev& P = e->P;
     const int nt = e->tile_cls_off[E + 1] - e->tile_cls_off[E];
     if (nt == 0) return;
     hipStream_t st = e->cls_stream[E];
     (void)hipStreamWaitEvent(st, e->cls_ev[0], 0);
-    const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
-    const int grid = std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096);  // persistent wavefronts pulling spans from the class' work list
     const dim3 hb(std::min(e->coop, kHeavyThreads));
     const int pool = E > 4 ? 2048 : (E > 1 ? kPairPoolPerEp * E : 1);       // doubles of pair-term tables per wavefront
     const size_t pool_bytes = sizeof(double) * (size_t)pool;
-    // the wavefront kernels of the class: the two lists of narrow spans in one launch, the long enumerations (and the parts of the
-    // split ones) first; the parts of the split spans combined, the few whose order of equal scores is not decided listed again
-    // (list emptied first) and enumerated whole; the wide windows
-    auto wavefront_kernels = [&](hipStream_t q) {
+    // the wavefront kernels of the class (or of one slice of it): the two lists of narrow spans in one launch, the long enumerations
+    // (and the parts of the split ones) first; the parts of the split spans combined, the few whose order of equal scores is not
+    // decided listed again (list emptied first) and enumerated whole; the wide windows
+    auto wavefront_kernels = [&](hipStream_t q, const Dev& P) {
+        const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
+        const int grid = std::max(std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096), 1);  // persistent wavefronts pulling spans from the work list
         hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, pool_bytes, q, P, pass, mode, 0, pool);
         hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), hb, pool_bytes, q, P, pass, mode, 0, pool);
         if (mode == 0 && E > 1) {
@@ -253,13 +279,31 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
             hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(64), hb, pool_bytes, q, P, pass, mode, 1, pool);
         }
     };
-    if (mode == 0) {
-        // cut-offs and work lists, the per-thread kernel, the wavefront kernels (which also take the few spans the per-thread kernel
-        // hands over).  Running the last two side by side was measured (second stream of higher priority, i.e. another hardware
-        // queue): the kernels do overlap, the class does not finish earlier -- together they saturate the LDS and issue slots
-        hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt), dim3(e->tile >= 64 ? e->tile * e->tile_threads : e->tile), 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
+    const dim3 tile_block(e->tile >= 64 ? e->tile * e->tile_threads : e->tile);
+    const int S = mode == 0 ? e->cls_slices[E] : 1;
+    if (S <= 1) {
+        // mode 0: cut-offs and work lists, the tile kernel, the wavefront kernels (which take the spans the tile kernel hands over);
+        // mode 1: the spans k_detect_gone listed
+        if (mode == 0) hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt), tile_block, 0, st, e->P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
+        wavefront_kernels(st, e->P);
+    } else {
+        // slices of the class' tiles: tile kernel s, then its wavefront kernels on the second stream while tile kernel s + 1 runs --
+        // the last slice's on the class stream.  (A class' wavefront kernels used to run alone on the GPU for a quarter of the
+        // launch set: the E = 4 class of the media shape, 1.1 of 4.5 ms at a third of the VALU.)
+        hipStream_t st2 = e->cls_stream2[E];
+        for (int sl = 0; sl < S; sl++) {
+            const Dev Ps = slice_dev<E>(e, sl);
+            const int t0 = e->slice_tile0[E][sl], cnt = e->slice_tile0[E][sl + 1] - t0;
+            if (cnt > 0) hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(cnt), tile_block, 0, st, Ps, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E] + t0), cnt);
+            if (sl + 1 < S) {
+                (void)hipEventRecord(e->slice_ev[E][sl], st);
+                (void)hipStreamWaitEvent(st2, e->slice_ev[E][sl], 0);
+                wavefront_kernels(st2, Ps);
+            } else wavefront_kernels(st, Ps);
+        }
+        (void)hipEventRecord(e->cls_ev2[E], st2);
+        (void)hipStreamWaitEvent(e->stream, e->cls_ev2[E], 0);
     }
-    wavefront_kernels(st);
     (void)hipEventRecord(e->cls_ev[E], st);
     used = true;
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[E], 0);
@@ -648,6 +692,13 @@ int tw_create(int device_id, tw_engine** out) {
     // partly serialise.  Only the long classes prioritised: no change.  Plain streams.)
     for (int i = 1; i <= kMaxEp && s == hipSuccess; i++) s = hipStreamCreate(&e->cls_stream[i]);
     for (int i = 0; i <= kMaxEp + 1 && s == hipSuccess; i++) s = hipEventCreateWithFlags(&e->cls_ev[i], hipEventDisableTiming);
+    e->enum_slices = std::min(std::max(env_int("TW_ENUM_SLICES", 1), 1), kMaxSlices);   // (measured: slower -- 4.5 ms per launch set unsliced, 4.7 / 4.9 / 6.2 ms in 2 / 4 / 8 slices; profiles/HISTORY.md)
+    e->slice_min_tiles = std::max(env_int("TW_ENUM_SLICE_MIN_TILES", 2048), 1);
+    for (int i = 1; i <= kMaxEp && s == hipSuccess && e->enum_slices > 1; i++) {
+        s = hipStreamCreate(&e->cls_stream2[i]);
+        if (s == hipSuccess) s = hipEventCreateWithFlags(&e->cls_ev2[i], hipEventDisableTiming);
+        for (int k = 0; k < kMaxSlices && s == hipSuccess; k++) s = hipEventCreateWithFlags(&e->slice_ev[i][k], hipEventDisableTiming);
+    }
     if (s != hipSuccess) {
         fprintf(stderr, "tw_create: %s\n", hipGetErrorString(s));
         delete e;
@@ -666,8 +717,13 @@ void tw_destroy(tw_engine* e) {
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     for (int i = 0; i <= kMaxEp + 1; i++)
         if (e->cls_ev[i]) (void)hipEventDestroy(e->cls_ev[i]);
-    for (int i = 1; i <= kMaxEp; i++)
+    for (int i = 1; i <= kMaxEp; i++) {
         if (e->cls_stream[i]) (void)hipStreamDestroy(e->cls_stream[i]);
+        if (e->cls_stream2[i]) (void)hipStreamDestroy(e->cls_stream2[i]);
+        if (e->cls_ev2[i]) (void)hipEventDestroy(e->cls_ev2[i]);
+        for (int k = 0; k < kMaxSlices; k++)
+            if (e->slice_ev[i][k]) (void)hipEventDestroy(e->slice_ev[i][k]);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -823,7 +879,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     P.n_out_total = n_out_total;
     P.batch_size = b->batch_size;
     P.batch_mis = b->batch_size_mis;
-    P.split_twins = env_int("TW_SPLIT_TWINS", 0);
+    P.split_twins = env_int("TW_SPLIT_TWINS", 2);
     int rc;
 #define ALLOC(ptr, count) do { rc = dev_alloc(e, &(ptr), (count)); if (rc != TW_OK) return rc; } while (0)
     e->arena_req.clear();
@@ -844,7 +900,10 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.tk_score, n_in_total * kTopK); ALLOC(P.tkr_score, n_in_total * kTopK);
     ALLOC(P.c_lo, ie); ALLOC(P.c_hi, ie); ALLOC(P.c_bits, ie * kCandWords); ALLOC(P.parent, ie);
     ALLOC(P.gone, ie * kCandWords); ALLOC(P.leaves_r, n_in_total);
-    ALLOC(P.frontier, (int64_t)kFrontierSlots * 2 * kFrontierCap); ALLOC(P.frontier_big, (int64_t)kFrontierBigSlots * 2 * kFrontierBigCap);
+    ALLOC(P.frontier, (int64_t)kFrontierSlots * 2 * kFrontierCap); 
+    // long tuple lists: a pool that grows with the batch (one list per 16 k incoming spans, 48 ... 512 of 32 MB each; recycled)
+    P.frontier_big_slots = (int32_t)std::min<int64_t>(std::max<int64_t>(n_in_total / 16384, kFrontierBigSlots), std::max(kFrontierBigSlots, 512));
+    ALLOC(P.frontier_big, (int64_t)P.frontier_big_slots * 2 * kFrontierBigCap);
     ALLOC(P.owner, n_out_total);
     ALLOC(P.gaps, gaps);
     ALLOC(e->tile_ids, (int64_t)tile_ids_h.size());
@@ -864,25 +923,50 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         ALLOC(P.split_unit, slots); ALLOC(P.split_idx, slots); ALLOC(P.split_slot, slots); ALLOC(P.split_parts, slots);
         ALLOC(P.part_n, slots); ALLOC(P.part_leaves, slots); ALLOC(P.part_score, slots * kTopK); ALLOC(P.part_idx, slots * kTopK * kMaxEp);
         ALLOC(P.part_bits, slots * kMaxEp * kCandWords);
+        ALLOC(P.part_logn, slots); ALLOC(P.part_log_sc, slots * kPartLogCap); ALLOC(P.part_log_ix, slots * kPartLogCap);
     }
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
+    for (int cls = 1; cls <= kMaxEp; cls++) {   // slices of the class' tiles with their shares of the class' work lists (launch_enumerate)
+        const int nt = e->tile_cls_off[cls + 1] - e->tile_cls_off[cls];
+        const int S = (e->enum_slices > 1 && nt >= e->slice_min_tiles && nt >= e->enum_slices && b->skip == nullptr) ? e->enum_slices : 1;
+        e->cls_slices[cls] = S;
+        if (S <= 1) continue;
+        const int64_t n_cls = heavy_off_h[cls + 1] - heavy_off_h[cls], extra = n_cls / 8 + 64;
+        int64_t spans = 0;
+        for (int sl = 0; sl <= S; sl++) {
+            const int t0 = (int)((int64_t)nt * sl / S);
+            if (sl > 0)
+                for (int tix = e->slice_tile0[cls][sl - 1]; tix < t0; tix++) {
+                    const TileDev& T = e->tiles[(size_t)tile_ids_h[(size_t)(e->tile_cls_off[cls] + tix)]];
+                    spans += std::min<int64_t>(e->tile, e->units[(size_t)T.unit].n_in - T.first);
+                }
+            const int64_t ex = extra * spans / std::max<int64_t>(n_cls, 1);   // the slice's share of the extra entries of split spans
+            e->slice_tile0[cls][sl] = t0;
+            e->slice_in0[cls][sl] = (int32_t)(heavy_off_h[cls] + spans);
+            e->slice_big0[cls][sl] = (int32_t)(P.heavy_big_off[cls] + spans + ex);
+            e->slice_part0[cls][sl] = (int32_t)(P.part_off[cls] + 2 * ex);
+        }
+    }
     ALLOC(P.prof, 16); ALLOC(e->key_acc, 2);
     const int64_t sel_cap = (int64_t)P.n_tiles * e->tile + 1;   // every segment of the selection lists has room for all windows of its tiles
     {   // the counter block (every array on a 128-byte line of its own: their atomics come from different kernels)
         int64_t at = 0;
         auto take = [&](int64_t ints) { const int64_t o = at; at += (ints + 31) / 32 * 32; return o; };
         const int64_t o_hc = take(4 * kSelSeg * kCtrStride), o_hn = take(4), o_ic = take(2 * (kMaxEp + 1)), o_in = take(3 * (kMaxEp + 1)), o_bc = take(kMaxEp + 1),
-                      o_rc = take(1), o_fn = take(1), o_fb = take(1);
+                      o_rc = take(1);
         e->ctr_round_ints = at;
         const int64_t o_pu = take(kMaxEp + 1), o_sc = take(kMaxEp + 1), o_err = take(1), o_nd = take(P.n_units), o_us = take((int64_t)P.n_units * 16);
+        const int64_t o_fn = take(kFrontierSlots), o_fb = take(P.frontier_big_slots);   // flags of the tuple-list pools (given back by the kernels themselves)
+        const int64_t o_sl = take((int64_t)(kMaxSlices - 1) * kSliceCtrInts);   // work-list counters of the slices beyond the first (launch_enumerate)
         e->ctr_pass_ints = at;
         auto place = [=](void* q) {
             Dev& D = e->P;
             int32_t* c = e->ctr = (int32_t*)q;
             D.heavy_count = c + o_hc; D.heavy_next = c + o_hn; D.heavy_in_count = c + o_ic; D.heavy_in_next = c + o_in; D.heavy_big_count = c + o_bc;
-            D.round_changed = c + o_rc; D.frontier_next = c + o_fn; D.frontier_big_next = c + o_fb;
+            D.round_changed = c + o_rc; D.frontier_busy = c + o_fn; D.frontier_big_busy = c + o_fb;
             D.part_used = c + o_pu; D.split_count = c + o_sc; D.err = c + o_err; D.unit_ndirty = c + o_nd;
             D.unit_stats = (int64_t*)(c + o_us);
+            e->slice_ctr = c + o_sl;
         };
         if (e->arena_open) e->arena_req.emplace_back(place, ((size_t)at * sizeof(int32_t) + 255) / 256 * 256);   // (placed by arena_commit, like the rest)
         else { ALLOC(e->ctr, at); place(e->ctr); }
@@ -1063,9 +1147,30 @@ FitDev fit_dev(tw_engine* e) {
     return F;
 }
 
-// Sorts every scored gap row and turns it into (value, multiplicity) runs; idempotent per pass-1 result.
+// Turns every scored gap row into (value, multiplicity) runs; idempotent per pass-1 result.  Default route: k_fit_runs (a hash
+// table per row in LDS, the row read once); rows it cannot take -- and TW_FIT_SORT=1 -- go the sort route below: composite-key
+// radix sort of all rows + k_fit_compress.  Both leave the same arrays (uval, ustart, row_n, row_uniq).
 int fit_prepare(tw_engine* e) {
     if (e->fit_prepared) return TW_OK;
+    if (env_int("TW_FIT_SORT", 0) == 0) {
+        int32_t* flag = (int32_t*)e->key_acc;
+        HIPCHK(hipMemsetAsync(flag, 0, sizeof(int32_t), e->stream));
+#ifdef TW_HOST_EMULATION
+        const int runs_threads = e->coop;
+#else
+        const int runs_threads = e->coop >= 64 ? kRunsThreads : e->coop;
+#endif
+        hipLaunchKernelGGL(k_fit_runs, dim3((unsigned)e->n_slots), dim3(runs_threads), 0, e->stream, fit_dev(e), flag);
+        HIPCHK(hipGetLastError());
+        int32_t refused = 0;
+        HIPCHK(hipMemcpyAsync(&refused, flag, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (!refused) {
+            e->fit_prepared = true;
+            e->fit_max_n_valid = false;
+            return TW_OK;
+        }
+    }
     size_t bytes = 0;
     const unsigned size = (unsigned)e->n_gaps, nseg = (unsigned)e->n_gap_rows;
     // gap samples are non-negative integers (and NaN = 0x7ff8...0) stored as doubles: their low mantissa bits

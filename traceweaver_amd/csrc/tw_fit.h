@@ -167,6 +167,108 @@ __global__ void __launch_bounds__(kCompressThreads) k_fit_compress(FitDev F) {
     if (t == 0) { F.row_n[q] = n_sh; F.row_uniq[q] = carry_sh; }
 }
 
+// The same run-length form WITHOUT sorting the row (the default route of fit_prepare; the sort + k_fit_compress above is its
+// fallback).  A row of 10^5 gap samples holds 10^2..10^4 distinct values and every value is a non-negative integer multiple of
+// the unit's time scale: one workgroup per scored row counts the samples per value in an open-addressing hash table in LDS
+// (one 64-bit word per value: integer value << 32 | multiplicity, claimed by a compare-and-swap, counted by an add -- both
+// order-independent), sorts the table's words (bitonic network, empty words last) and writes the runs: distinct values
+// ascending, exclusive prefix sums of the multiplicities = index of each value's first occurrence in the sorted row.  The row
+// is read once (the sort route: one pack, four to five radix passes, one unpack and k_fit_compress's read -- 10 GB per step on
+// the bench workload).  A row the table cannot take (a sample that is negative, not an integer multiple of the scale or beyond
+// 32 bits; more than kHashMax distinct values) raises `*fallback`: the host then runs the sort route for the batch.
+#ifndef TW_FIT_HASH_SLOTS
+#define TW_FIT_HASH_SLOTS 16384
+#endif
+constexpr int kHashSlots = TW_FIT_HASH_SLOTS;           // words of the table (128 KB of LDS: one workgroup per CU)
+constexpr int kHashMax = kHashSlots / 4 * 3;            // distinct values of a row on this route
+constexpr unsigned long long kHashEmpty = ~0ull;
+constexpr int kRunsThreads = 1024;
+static_assert((kHashSlots & (kHashSlots - 1)) == 0 && kHashSlots >= 64, "the table size is a power of two");
+
+__global__ void __launch_bounds__(kRunsThreads) k_fit_runs(FitDev F, int32_t* fallback) {
+    constexpr int R = 8;  // samples per thread and round: their loads are in flight together
+    __shared__ unsigned long long tab[kHashSlots];
+    __shared__ int32_t s_part[kRunsThreads / 64];
+    __shared__ int32_t s_uniq, s_n, s_bad;
+    const int64_t q = blockIdx.x;
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int lane = t & 63, wave = t >> 6;
+    if (!F.slot_scored[q]) {
+        if (t == 0) { F.row_n[q] = 0; F.row_uniq[q] = 0; }
+        return;
+    }
+    const UnitDev& U = F.units[F.slot_unit[q]];
+    const int n_all = U.n_in;
+    const int64_t row = F.gs_off[F.slot_unit[q]] + (q - U.slot_off) * (int64_t)n_all;
+    const double* x = F.gaps + row;
+    const double scale = U.tscale, inv = 1.0 / U.tscale;   // a power of two: both exact
+    for (int r = t; r < kHashSlots; r += nt) tab[r] = kHashEmpty;
+    if (t == 0) { s_uniq = 0; s_n = 0; s_bad = 0; }
+    __syncthreads();
+    int mine = 0;
+    for (int base = 0; base < n_all; base += R * nt) {
+        double xi[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) { const int i = base + j * nt + t; xi[j] = i < n_all ? x[i] : dnan(); }
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            if (!(xi[j] == xi[j])) continue;   // NaN = dropped sample
+            mine++;
+            const double v = xi[j] * inv;
+            const uint32_t key = (uint32_t)v;
+            if (__double_as_longlong(xi[j]) < 0 || !(v < 4294967295.0) || (double)key != v) { s_bad = 1; continue; }
+            uint32_t slot = (key * 2654435761u) >> (32 - __builtin_ctz((unsigned)kHashSlots));   // multiplicative hashing: the product's top bits
+            const unsigned long long word = (unsigned long long)key << 32;
+            bool placed = false;
+            for (int probe = 0; probe < kHashSlots && !placed; probe++) {
+                const unsigned long long old = atomicCAS(&tab[slot], kHashEmpty, word);
+                if (old == kHashEmpty) { if (atomicAdd(&s_uniq, 1) >= kHashMax) s_bad = 1; placed = true; }
+                else if ((uint32_t)(old >> 32) == key) placed = true;
+                else slot = (slot + 1) & (uint32_t)(kHashSlots - 1);
+            }
+            if (placed) atomicAdd(&tab[slot], 1ull); else s_bad = 1;
+        }
+        if (s_bad) break;   // (every thread leaves within a round of the first refusal; the table never fills: kHashMax + threads < slots, or the probe bound ends it)
+    }
+    atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (s_bad) {
+        if (t == 0) atomicExch(fallback, 1);
+        return;
+    }
+    // bitonic sort of the table's words, ascending (a value's word orders by the value; empty words are the largest)
+    for (int k = 2; k <= kHashSlots; k <<= 1) {
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            for (int p = t; p < kHashSlots / 2; p += nt) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));   // the p-th index whose bit j is clear
+                const unsigned long long a = tab[i], b = tab[i | j];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { tab[i] = b; tab[i | j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // runs: every thread a stretch of consecutive words; exclusive prefix sums of the multiplicities (wavefront scan by shuffles,
+    // the wavefronts' totals through LDS)
+    const int uniq = s_uniq, per = (uniq + nt - 1) / nt;
+    const int r_lo = t * per < uniq ? t * per : uniq, r_hi = r_lo + per < uniq ? r_lo + per : uniq;
+    int sum = 0;
+    for (int r = r_lo; r < r_hi; r++) sum += (int)(uint32_t)tab[r];
+    int inc = sum;
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+    if (lane == 63 || t == nt - 1) s_part[wave] = inc;
+    __syncthreads();
+    int before = inc - sum;
+    for (int w = 0; w < wave; w++) before += s_part[w];
+    for (int r = r_lo; r < r_hi; r++) {
+        const unsigned long long w = tab[r];
+        F.uval[row + r] = (double)(uint32_t)(w >> 32) * scale;
+        F.ustart[row + r] = before;
+        before += (int)(uint32_t)w;
+    }
+    if (t == 0) { F.row_n[q] = s_n; F.row_uniq[q] = uniq; }
+}
+
 // sklearn.metrics.pairwise._euclidean_distances(c, X, squared=True) for one feature: ((-2 (c x)) + c c) + x x, clipped at 0
 __device__ __forceinline__ double fit_dist(double c, double x) {
     double d = -2.0 * (c * x);

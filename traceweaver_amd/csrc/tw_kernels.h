@@ -391,10 +391,23 @@ constexpr int kBigProduct = TW_BIG_PRODUCT;
 // takes the tuples whose first span is among the p-th share of that endpoint's staged candidates.  (The host-emulation
 // build of the tests sets tiny thresholds so that the route is exercised.)
 constexpr int kSplitMin = TW_SPLIT_MIN, kSplitGrain = TW_SPLIT_GRAIN, kMaxParts = 16;
+// A span with twin candidates (Python's order of tuples may not decide between two of its tuples) is split in LOG MODE: CPython's
+// size-5 heap (traceweaver_v3.py:304-307) is an exact function of the sequence of pushes, and a push whose score is strictly below
+// the score of the root of a full heap leaves the array as it was.  The root's score is the fifth largest score pushed so far, and
+// the fifth largest of a part's own tuples so far is never above that of all tuples so far: so the tuples of a part whose score is
+// not below the running root score of the part's OWN heap are a superset of the part's tuples that change the real heap.  Every
+// part replays the heap on its share and logs those tuples in order (kPartLogCap of them); k_merge_parts replays the concatenation
+// of the logs, part after part -- the reference's heap, push by push, without one wavefront walking the whole enumeration.
+#ifndef TW_PART_LOG_CAP
+#define TW_PART_LOG_CAP 128
+#endif
+constexpr int kPartLogCap = TW_PART_LOG_CAP;
+constexpr int kPartLogFlag = 1 << 25;   // in heavy_big_part / split_parts
 template <int E>
-__device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narrow, bool big, int unit, int i, long long prod = 0, int first_cands = 0) {
+__device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narrow, bool big, int unit, int i, long long prod = 0, int first_cands = 0,
+                                             bool twins = false) {
     const bool isbig = pred && big;   // narrow or wide windows: the list entry says which instantiation takes it
-    const int wide_flag = narrow ? 0 : 1 << 24;
+    const int wide_flag = (narrow ? 0 : 1 << 24) | ((twins && P.split_twins == 2) ? kPartLogFlag : 0);
     int nparts = 1, slot_base = 0;
     if (E >= 2 && isbig && prod >= kSplitMin && first_cands >= 2) {
         long long want = prod / kSplitGrain;
@@ -415,7 +428,7 @@ __device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narro
         const int base = P.heavy_big_off[E] + atomicAdd(&P.heavy_big_count[E], nparts);
         for (int p = 0; p < nparts; p++) {
             P.heavy_big_unit[base + p] = unit; P.heavy_big_idx[base + p] = i;
-            P.heavy_big_part[base + p] = nparts | (p << 8) | wide_flag; P.heavy_big_slot[base + p] = slot_base + p;
+            P.heavy_big_part[base + p] = nparts | (p << 8) | wide_flag; P.heavy_big_slot[base + p] = slot_base + p;   // (wide_flag: wide windows, log mode)
         }
         const int k = P.part_off[E] + atomicAdd(&P.split_count[E], 1);
         P.split_unit[k] = unit; P.split_idx[k] = i; P.split_slot[k] = slot_base; P.split_parts[k] = nparts | wide_flag;
@@ -423,7 +436,7 @@ __device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narro
     }
     if (isbig) {
         const int q = P.heavy_big_off[E] + sb;
-        P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | wide_flag; P.heavy_big_slot[q] = 0;
+        P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | (wide_flag & (1 << 24)); P.heavy_big_slot[q] = 0;
         return true;
     }
     const int pos = narrow ? P.heavy_in_off[E] + sn : P.heavy_in_off[E + 1] - 1 - sw;
@@ -581,6 +594,23 @@ constexpr int kFrontierCap = TW_FRONTIER_CAP;          // prefixes per level and
 constexpr int kFrontierBigCap = TW_FRONTIER_BIG_CAP;       // ... of kFrontierBigSlots lists this long (32 MB a slot); beyond, or none left: the walk
 constexpr int kFrontierSlots = 4096;            // buffer pairs of kFrontierCap entries, claimed by the wavefronts that need one
 constexpr int kFrontierBigSlots = TW_FRONTIER_BIG_SLOTS;   // (the host-emulation build of the tests uses tiny sizes so that all three routes are exercised)
+// The tuple-list buffers are pools with a flag per buffer: claimed by a compare-and-swap (a few probes from a start that differs
+// from wavefront to wavefront), given back when the wavefront (its own pair) or the span (a long list) is done -- so what a batch
+// needs is bounded by the wavefronts resident at a time, not by how many spans of the batch ask (a bump counter that was only reset
+// between the passes ran dry on large batches, and those spans fell back to the plain walk: 16 M resident spans of the deep
+// call graphs were slower per span than 1 M).  One lane calls.
+__device__ __forceinline__ int pool_acquire(int32_t* busy, int n, unsigned start) {
+    for (int k = 0; k < 64 && k < n; k++) {
+        const int s = (int)((start + (unsigned)k) % (unsigned)n);
+        if (atomicCAS(&busy[s], 0, 1) == 0) return s;
+    }
+    return -1;
+}
+__device__ __forceinline__ void pool_release(int32_t* busy, int slot) {
+    __threadfence();
+    atomicExch(&busy[slot], 0);
+}
+
 template <int E, int W>
 __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy(Dev P, int pass, int mode, int part, int pool) {
     // part: 0 = the class' lists, the long enumerations first (one launch serves both); 1 = only the long ones (the split spans
@@ -641,6 +671,8 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         const int part_info = from_big ? __builtin_amdgcn_readfirstlane(P.heavy_big_part[pos]) : 1;
         if (from_big && (((part_info >> 24) & 1) != 0) != kWide) continue;   // the other instantiation's
         const int nparts = part_info & 255, part_no = (part_info >> 8) & 0xffff;
+        const bool part_log = nparts > 1 && (part_info & kPartLogFlag) != 0;   // log mode: this part replays CPython's heap and logs what entered it
+        int nlog = 0;                                                         // (lane 0's count)
         const int part_slot = from_big ? __builtin_amdgcn_readfirstlane(P.heavy_big_slot[pos]) : 0;
         const UnitDev& U = P.units[unit];
         TW_ITEM_BEGIN();
@@ -708,7 +740,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         wave_sync();
         TW_PHASE(0);
         int64_t leaves = 0;
-        int nout = 0;
+        int nout = 0, big_slot = -1;   // (big_slot: a long tuple list of the pool, given back when the span is done)
         int c0_begin = 0, c0_end = cn[0];   // the staged candidates of the first endpoint this wavefront enumerates
         if (nparts > 1) { c0_begin = (int)((long long)part_no * cn[0] / nparts); c0_end = (int)((long long)(part_no + 1) * cn[0] / nparts); none |= c0_begin == c0_end; }
         bool part_ambiguous = false;
@@ -868,9 +900,9 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
             if (grid >= kFrontierGrid && any_order != 0 && !U.skip && front_slot < 0 && front_slot != -2) {
                 // the first such span of this wavefront claims one of the kFrontierSlots buffer pairs (kernels of several
                 // classes run side by side: the block index does not identify a wavefront across them)
-                if (t == 0) front_slot = atomicAdd(P.frontier_next, 1);
+                if (t == 0) front_slot = pool_acquire(P.frontier_busy, kFrontierSlots, ((unsigned)blockIdx.x * 40503u + (unsigned)(E * 2 + (kWide ? 1 : 0)) * 7919u + (unsigned)part * 104729u));
                 front_slot = __shfl(front_slot, 0);
-                if (front_slot >= kFrontierSlots) front_slot = -2;   // none left: this wavefront walks
+                if (front_slot < 0) front_slot = -2;   // none free: this wavefront walks
             }
             if (grid >= kFrontierGrid && any_order != 0 && !U.skip && front_slot >= 0) {
                 unsigned long long* fa = P.frontier + (size_t)front_slot * 2 * kFrontierCap;
@@ -941,9 +973,10 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                     if (use_front || tries == 1) break;
                     // the lists outgrew the wavefront's own buffers: once more in a slot of the pool, if one is left
                     int slot = 0;
-                    if (t == 0) slot = atomicAdd(P.frontier_big_next, 1);
+                    if (t == 0) slot = pool_acquire(P.frontier_big_busy, P.frontier_big_slots, (unsigned)blockIdx.x * 40503u + (unsigned)i * 7919u + (unsigned)E);
                     slot = __shfl(slot, 0);
-                    if (slot >= kFrontierBigSlots) break;
+                    if (slot < 0) break;
+                    big_slot = slot;
                     fa = P.frontier_big + (size_t)slot * 2 * kFrontierBigCap;
                     cap = kFrontierBigCap;
                 }
@@ -1038,7 +1071,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         double ts[kTopK];
         int tslot[kTopK], nk = 0;
         bool exact_replay = false, ambiguous = false;
-        for (int attempt = 0; attempt < 2; attempt++) {
+        for (int attempt = part_log ? 1 : 0; attempt < 2; attempt++) {
         exact_replay = attempt == 1;
         hp.nheap = 0; nk = 0; leaves = 0;
 #pragma unroll
@@ -1254,6 +1287,16 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
 #pragma unroll
                             for (int e = 0; e < E; e++) cand.idx[e] = (int32_t)((pj >> (8 * e)) & 255ull);
                             hp.push(cand);
+                            if (part_log) {   // (its score was not below the root's when it came: it may enter the heap of the whole enumeration)
+                                if (nlog < kPartLogCap) {
+                                    unsigned long long wpos = 0ull;   // positions in the cut-off windows: the same in every part
+#pragma unroll
+                                    for (int e = 0; e < E; e++) wpos |= (unsigned long long)lr[e][cand.idx[e]] << (8 * e);
+                                    P.part_log_sc[(int64_t)part_slot * kPartLogCap + nlog] = sj;
+                                    P.part_log_ix[(int64_t)part_slot * kPartLogCap + nlog] = wpos;
+                                }
+                                nlog++;
+                            }
                         }
                     }
                 } else {
@@ -1390,7 +1433,11 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         nout = exact_replay ? __shfl(hp.nheap, 0) : nk;
         }  // !none
         if (nparts > 1) {   // a part: its top-5 (span indices), tuple count and candidate bitmap go to the scratch slot
-            if (t == 0) { P.part_n[part_slot] = nout | (part_ambiguous ? 256 : 0); P.part_leaves[part_slot] = leaves; }
+            if (t == 0) {
+                P.part_n[part_slot] = nout | (part_ambiguous ? 256 : 0) | (nlog > kPartLogCap ? 512 : 0);   // (flags: the span is enumerated again as a whole)
+                P.part_leaves[part_slot] = leaves;
+                if (part_log) P.part_logn[part_slot] = nlog;
+            }
             for (int q = t; q < kTopK * (E + 1); q += nt) {
                 const int k = q / (E + 1), f = q % (E + 1);
                 if (k >= nout) continue;
@@ -1432,9 +1479,11 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
             }
         }
         wave_sync();
+        if (big_slot >= 0 && t == 0) pool_release(P.frontier_big_busy, big_slot);
         TW_PHASE(4);
         TW_ITEM_END(leaves);
     }
+    if (front_slot >= 0 && t == 0) pool_release(P.frontier_busy, front_slot);
 }
 
 // Combines the parts of the split spans of the endpoint-count class E (see kSplitMin): the five largest tuples of the union
@@ -1446,6 +1495,85 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
 // emptied it) and enumerated once more by one wavefront, which replays CPython's heap.
 // One wavefront per split span: the kept tuples (<= kMaxParts * 5) sit in LDS, every lane ranks one or two of them against
 // all others, and the tuples ranked 0..4 are written by the lanes that hold them.
+// A split span in log mode (twin candidates, see heavy_append): the concatenation of the parts' logs, part after part, is replayed
+// through CPython's heapq (push; beyond five entries pop the smallest) and sorted like the reference's final list.sort -- LdsHeap's
+// operations on (score, window positions) entries with the endpoint count at run time.  Lane 0 works; the logs and the start
+// times of the spans' cut-off windows sit in LDS.
+struct MergeHeap {
+    double* hs;                      // [kTopK + 1] scores
+    unsigned long long* hx;          // [kTopK + 1] positions in the cut-off windows, 8 bits per endpoint
+    int n, E;
+    const int64_t (*st)[64 * kCandWords];   // start times of the windows' spans [endpoint][position]
+    __device__ bool lt(double sa, unsigned long long xa, double sb, unsigned long long xb) const {
+        if (sa != sb) return sa < sb;
+        for (int e = 0; e < E; e++) {
+            const int a = (int)((xa >> (8 * e)) & 255ull), b = (int)((xb >> (8 * e)) & 255ull);
+            if (a != b) return st[e][a] < st[e][b];
+        }
+        return false;
+    }
+    __device__ void siftdown(int startpos, int pos) {
+        const double is = hs[pos]; const unsigned long long ix = hx[pos];
+        while (pos > startpos) {
+            const int parent = (pos - 1) >> 1;
+            if (lt(is, ix, hs[parent], hx[parent])) { hs[pos] = hs[parent]; hx[pos] = hx[parent]; pos = parent; continue; }
+            break;
+        }
+        hs[pos] = is; hx[pos] = ix;
+    }
+    __device__ void siftup(int pos) {
+        const int startpos = pos;
+        const double is = hs[pos]; const unsigned long long ix = hx[pos];
+        int child = 2 * pos + 1;
+        while (child < n) {
+            const int right = child + 1;
+            if (right < n && !lt(hs[child], hx[child], hs[right], hx[right])) child = right;
+            hs[pos] = hs[child]; hx[pos] = hx[child];
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        hs[pos] = is; hx[pos] = ix;
+        siftdown(startpos, pos);
+    }
+    __device__ void push(double s, unsigned long long x) {
+        hs[n] = s; hx[n] = x; n++;
+        siftdown(0, n - 1);
+        if (n > kTopK) {
+            n--;
+            const double ls = hs[n]; const unsigned long long lx = hx[n];
+            if (n > 0) { hs[0] = ls; hx[0] = lx; siftup(0); }
+        }
+    }
+    __device__ void reverse(int m) {
+        for (int i = 0, j = m - 1; i < j; i++, j--) {
+            const double a = hs[i]; hs[i] = hs[j]; hs[j] = a;
+            const unsigned long long b = hx[i]; hx[i] = hx[j]; hx[j] = b;
+        }
+    }
+    __device__ void sort_desc() {   // list.sort(reverse=True) of <= 5 entries: reverse, count_run + binary insertion, reverse
+        if (n < 2) return;
+        reverse(n);
+        int run = 2;
+        if (lt(hs[1], hx[1], hs[0], hx[0])) {
+            for (int i = 2; i < n; i++, run++) if (!lt(hs[i], hx[i], hs[i - 1], hx[i - 1])) break;
+            reverse(run);
+        } else {
+            for (int i = 2; i < n; i++, run++) if (lt(hs[i], hx[i], hs[i - 1], hx[i - 1])) break;
+        }
+        for (int start = run; start < n; start++) {
+            int l = 0, r = start;
+            const double ps = hs[start]; const unsigned long long px = hx[start];
+            do {
+                const int p = l + ((r - l) >> 1);
+                if (lt(ps, px, hs[p], hx[p])) r = p; else l = p + 1;
+            } while (l < r);
+            for (int p = start; p > l; p--) { hs[p] = hs[p - 1]; hx[p] = hx[p - 1]; }
+            hs[l] = ps; hx[l] = px;
+        }
+        reverse(n);
+    }
+};
+
 __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
     if (*P.err != 0) return;
     constexpr int kCandMax = kMaxParts * kTopK;
@@ -1454,6 +1582,12 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
     __shared__ int64_t ss[kCandMax][kMaxEp];    // start of the tuple's span at every endpoint
     __shared__ uint8_t ok[kCandMax], rk[kCandMax];
     __shared__ int redo_flag;
+    __shared__ int64_t w_st[kMaxEp][64 * kCandWords];           // log mode: start times of the cut-off windows' spans
+    __shared__ double lg_sc[kMaxParts * kPartLogCap];          // ... the parts' logs behind one another
+    __shared__ unsigned long long lg_ix[kMaxParts * kPartLogCap];
+    __shared__ double h_sc[kTopK + 1];
+    __shared__ unsigned long long h_ix[kTopK + 1];
+    __shared__ int h_n;
     const int t = threadIdx.x, nt = blockDim.x;
     const int n = P.split_count[E];
     for (int s = (int)blockIdx.x; s < n; s += (int)gridDim.x) {
@@ -1462,6 +1596,73 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
         const int nparts = P.split_parts[rec] & 255, wide_bit = P.split_parts[rec] & (1 << 24);
         const UnitDev& U = P.units[unit];
         const int C = nparts * kTopK;
+        if (P.split_parts[rec] & kPartLogFlag) {
+            // ---- log mode: replay the parts' logs
+            bool redo = false;
+            int total_log = 0;
+            long long leaves = 0;
+            for (int p = 0; p < nparts; p++) {   // (<= kMaxParts: every lane the same few loads)
+                if (P.part_n[slot0 + p] >> 8) redo = true;   // a log that is not complete
+                total_log += P.part_logn[slot0 + p];
+                leaves += P.part_leaves[slot0 + p];
+            }
+            if (redo) {
+                if (t == 0) {
+                    const int q = P.heavy_big_off[E] + atomicAdd(&P.heavy_big_count[E], 1);
+                    P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | wide_bit; P.heavy_big_slot[q] = 0;
+                    atomicAdd(&P.split_count[0], 1);
+                }
+                wave_sync();
+                continue;
+            }
+            for (int e = 0; e < E; e++) {
+                const int lo = P.c_lo[ie_index(U, e, i)], w = P.c_hi[ie_index(U, e, i)] - lo + 1;
+                for (int r = t; r < w && r < 64 * kCandWords; r += nt) w_st[e][r] = P.out_start[U.ep_off[e] + lo + r];
+            }
+            {
+                int at = 0;
+                for (int p = 0; p < nparts; p++) {
+                    const int m = P.part_logn[slot0 + p];
+                    for (int k = t; k < m; k += nt) {
+                        lg_sc[at + k] = P.part_log_sc[(int64_t)(slot0 + p) * kPartLogCap + k];
+                        lg_ix[at + k] = P.part_log_ix[(int64_t)(slot0 + p) * kPartLogCap + k];
+                    }
+                    at += m;
+                }
+            }
+            wave_sync();
+            if (t == 0) {
+                MergeHeap H;
+                H.hs = h_sc; H.hx = h_ix; H.n = 0; H.E = E; H.st = w_st;
+                for (int k = 0; k < total_log; k++) {
+                    const double sk = lg_sc[k];
+                    if (H.n == kTopK && sk < H.hs[0]) continue;   // strictly below the root of a full heap: the push leaves the array as it is
+                    H.push(sk, lg_ix[k]);
+                }
+                H.sort_desc();
+                h_n = H.n;
+            }
+            wave_sync();
+            const int nout = h_n;
+            const int64_t g = U.in_off + i;
+            if (pass == 1) { if (t == 0) P.leaves0[g] = leaves; }
+            else leaves = P.leaves0[g];
+            if (t == 0) { P.tk_n[g] = nout; P.leaves[g] = leaves; P.rep[g] = 0; }
+            for (int q = t; q < nout * (E + 1); q += nt) {   // entries a span does not have keep the -1 / NaN pattern of tw_load_batch
+                const int k = q / (E + 1), f = q % (E + 1);
+                if (f == E) P.tk_score[tks_index(U, k, i)] = h_sc[k];
+                else P.tk_idx[tk_index(U, k, f, i)] = P.c_lo[ie_index(U, f, i)] + (int)((h_ix[k] >> (8 * f)) & 255ull);
+            }
+            if (pass == 1)
+                for (int q = t; q < E * kCandWords; q += nt) {
+                    const int e = q / kCandWords, w = q % kCandWords;
+                    unsigned long long bits = 0ull;
+                    for (int p = 0; p < nparts; p++) bits |= P.part_bits[((int64_t)(slot0 + p) * kMaxEp + e) * kCandWords + w];
+                    P.c_bits[ie_index(U, e, i) * kCandWords + w] = bits;
+                }
+            wave_sync();
+            continue;
+        }
         if (t == 0) redo_flag = 0;
         for (int c = t; c < C; c += nt) {
             const int slot = slot0 + c / kTopK, k = c % kTopK;

@@ -226,6 +226,7 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
     {   // the others: listed for the wavefront kernel with what it needs to plan (k_enumerate_heavy)
         long long hprod = 0;
         int first_cands = 0;
+        bool twins_any = false;
         if (live && !mine && !wide) {
             // the windows also hold spans that start inside the incoming span but end after it; what the enumeration
             // costs is the product of the *contained* candidates (a third of the raw product on the bench workload)
@@ -251,11 +252,12 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
                 if (hprod <= (1ll << 40)) hprod *= v;
                 if (e == 0) first_cands = v;
             }
-            // parts are only worth it when they settle the top five among themselves (k_merge_parts): with twins the span would
-            // most likely be enumerated again as a whole (millisecond-granular traces: nearly always)
-            if (twins && !P.split_twins) first_cands = 0;
+            // with twins the parts cannot settle the top five among themselves (millisecond-granular traces: nearly always): they
+            // replay CPython's heap on their shares and log what entered it (log mode, see heavy_append)
+            if (twins && P.split_twins == 0) first_cands = 0;
+            twins_any = twins;
         }
-        heavy_append<E>(P, live && !mine && !wide, narrow, hprod > kBigProduct, T.unit, i, hprod, U.skip ? 0 : first_cands);
+        heavy_append<E>(P, live && !mine && !wide, narrow, hprod > kBigProduct, T.unit, i, hprod, U.skip ? 0 : first_cands, twins_any);
     }
     const bool some = mine && !empty && prod > 0;   // has tuples to enumerate here
     int nitem = 0;
