@@ -23,6 +23,12 @@ VARIANTS = {
     "tile128": ["-DTW_TILE_MAX=128"],
     "heavy3": ["-DTW_HEAVY_ATTR=" + WPE(3)],
     "heavy4": ["-DTW_HEAVY_ATTR=" + WPE(4)],
+    "hw_all2": ["-DTW_HEAVY_WAVES(E)=2"],                 # round 5: every endpoint-count class of k_enumerate_heavy at two wavefronts per SIMD
+    "prof8": ["-DTW_PROFILE", "-DTW_PROFILE_E=8"],
+    "prof7": ["-DTW_PROFILE", "-DTW_PROFILE_E=7"],
+    "log256": ["-DTW_PART_LOG_CAP=256"],
+    "log512": ["-DTW_PART_LOG_CAP=512"],
+    "hw_e6": ["-DTW_HEAVY_WAVES(E)=((E)<=6?2:1)"],
 }
 
 

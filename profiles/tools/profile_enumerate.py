@@ -5,7 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from traceweaver_amd import synth
 from traceweaver_amd.engine import Engine
 conc = float(os.environ.get("TW_CONC", "1.6")); n_in = int(os.environ.get("TW_NIN", "100000"))
-units, truth = synth.make_workload(1000, n_in, services=synth.MEDIA_SERVICES, replicas=int(os.environ.get("TW_REPLICAS", "4")), concurrency=conc)
+if os.environ.get("WL") == "alibaba":   # the Alibaba-shape slice; build the library with -DTW_PROFILE_E=<class> (default 4)
+    import bench
+    sys.argv = ["bench.py", "--workload", "alibaba"]
+    units, truth, _ = bench.make_units(bench.parse_args(), 1000)
+else:
+    units, truth = synth.make_workload(1000, n_in, services=synth.MEDIA_SERVICES, replicas=int(os.environ.get("TW_REPLICAS", "4")), concurrency=conc)
 eng = Engine(0, lib_path=os.environ.get("TW_PROFILE_LIB", "scratch/prof.so")); eng.load(units)
 lib = eng._lib
 lib.tw_debug_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -23,3 +28,7 @@ for pass_no in (1, 2):
     tot = float(a[:5].sum())
     print("   phases: " + ", ".join("%s %.0f%%" % (n, 100.0 * a[k] / tot) for k, n in enumerate(os.environ.get("TW_PHASE_NAMES", "stage,tables,tuple list,walk+top5,results").split(","))))
     print("   longest item: tuple list %.1f us, walk+top5 %.1f us" % (int(cur[7]) / 100.0, int(cur[10]) / 100.0))
+    info = int(cur[5])
+    print("   longest item: flags prune=%d replay=%d list=%d counted=%d log=%d list_scored=%d list_all=%d tables=%d, part %d of %d, staged candidates %s"
+          % (info & 1, info >> 1 & 1, info >> 2 & 1, info >> 3 & 1, info >> 4 & 1, info >> 5 & 1, info >> 6 & 1, info >> 7 & 1, info >> 16 & 255, info >> 8 & 255,
+             [info >> (24 + 5 * e) & 31 for e in range(8)]))

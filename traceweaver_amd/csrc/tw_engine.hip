@@ -239,6 +239,15 @@ int run_scan(tw_engine* e, typename Tr::T* agg) {
 // engine's stream by events, so that the tails overlap.  The wide instantiation of a class owns the big-list pool slots
 // together with the narrow one (one counter): no conflict, they only ever add.
 // The view of slice s of class E: its own ranges of the class' work lists and (s > 0) its own counters.
+// Extra work-list entries of a class for the parts of its split enumerations.  Up to four endpoints few spans are split (an eighth of
+// the class + 64 was never short); in the deep call graphs most wavefront-enumerated spans are, and a budget that runs out leaves
+// whichever spans come last unsplit -- single wavefronts then hold the class' kernel for milliseconds (round 5: 3 of its 4 ms).
+int64_t part_extra(int cls, int64_t n_cls) {
+    if (n_cls <= 0) return 0;
+    static const int deep = env_int("TW_PART_BUDGET_DEEP", 2);
+    return (cls >= 5 && deep > 0 ? n_cls * deep : n_cls / 8) + 64;
+}
+
 template <int E>
 Dev slice_dev(const tw_engine* e, int s) {
     Dev D = e->P;
@@ -433,6 +442,10 @@ int run_pass(tw_engine* e, int pass) {
     const dim3 tiles(P.n_tiles), tb(e->tile);
     HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
     HIPCHK(hipMemsetAsync(e->ctr, 0, sizeof(int32_t) * (size_t)e->ctr_pass_ints, e->stream));   // error flag, statistics, every work-list counter
+#ifdef TW_PROFILE
+    HIPCHK(hipMemsetAsync(P.prof + 5, 0, sizeof(unsigned long long) * 3, e->stream));    // the longest item / wavefront of THIS pass (the sums run on)
+    HIPCHK(hipMemsetAsync(P.prof + 10, 0, sizeof(unsigned long long) * 3, e->stream));
+#endif
     if (pass == 1 && !e->skip_mode) {
         int rc = sort_ends(e);
         if (rc != TW_OK) return rc;
@@ -913,7 +926,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         int64_t big_total = 0, slots = 0;
         for (int cls = 0; cls <= kMaxEp; cls++) {
             const int64_t n_cls = heavy_off_h[cls + 1] - heavy_off_h[cls];
-            const int64_t extra = n_cls > 0 ? n_cls / 8 + 64 : 0;
+            const int64_t extra = part_extra(cls, n_cls);
             P.heavy_big_off[cls] = (int32_t)big_total; P.part_off[cls] = (int32_t)slots;
             big_total += n_cls + extra; slots += 2 * extra;
         }
@@ -931,7 +944,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         const int S = (e->enum_slices > 1 && nt >= e->slice_min_tiles && nt >= e->enum_slices && b->skip == nullptr) ? e->enum_slices : 1;
         e->cls_slices[cls] = S;
         if (S <= 1) continue;
-        const int64_t n_cls = heavy_off_h[cls + 1] - heavy_off_h[cls], extra = n_cls / 8 + 64;
+        const int64_t n_cls = heavy_off_h[cls + 1] - heavy_off_h[cls], extra = part_extra(cls, n_cls);
         int64_t spans = 0;
         for (int sl = 0; sl <= S; sl++) {
             const int t0 = (int)((int64_t)nt * sl / S);

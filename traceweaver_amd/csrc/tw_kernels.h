@@ -350,16 +350,20 @@ constexpr int kHeavyThreads = 64;
 // Optional phase timers (build with -DTW_PROFILE; read back through tw_debug_profile): cycles spent by
 // lane 0 of every heavy-enumeration wavefront per phase.  Compiled out by default.
 #ifdef TW_PROFILE
+#ifndef TW_PROFILE_E
+#define TW_PROFILE_E 4   // the endpoint-count class whose narrow instantiation is timed
+#endif
 // prof[12] longest item (ticks << 24 | tuples, capped), [13] sum of item ticks, [14] items, [8] sum of wavefront lifetimes,
 // [9] wavefronts that drew work, [6] longest wavefront lifetime, [15] items >= 100 us -- of the narrow E = 4 instantiation
-#define TW_PROF_DECL() const long long _tw_born = wall_clock64(); long long _tw_t = _tw_born, _tw_p = _tw_born, _tw_ph[5] = {0, 0, 0, 0, 0}, _tw_it[5] = {0, 0, 0, 0, 0}; const bool _tw_on = (E == 4 && !kWide && mode == 0)
+#define TW_PROF_DECL() unsigned long long _tw_info = 0ull; const long long _tw_born = wall_clock64(); long long _tw_t = _tw_born, _tw_p = _tw_born, _tw_ph[5] = {0, 0, 0, 0, 0}, _tw_it[5] = {0, 0, 0, 0, 0}; const bool _tw_on = (E == TW_PROFILE_E && !kWide && mode == 0)
 #define TW_ITEM_BEGIN() do { _tw_t = wall_clock64(); _tw_p = _tw_t; for (int _k = 0; _k < 5; _k++) _tw_it[_k] = 0; } while (0)
 // phases of an item: [0] stage candidates, [1] term and pair tables, [2] tuple list, [3] walk + top-5, [4] results
 #define TW_PHASE(k) do { const long long _n = wall_clock64(); _tw_ph[k] += _n - _tw_p; _tw_it[k] += _n - _tw_p; _tw_p = _n; } while (0)
 #define TW_ITEM_END(tuples) do { if (_tw_on && threadIdx.x == 0) { const unsigned long long _d = (unsigned long long)(wall_clock64() - _tw_t); \
     const unsigned long long _l = (unsigned long long)(tuples) > 0xffffffull ? 0xffffffull : (unsigned long long)(tuples); \
-    if (atomicMax((unsigned long long*)&P.prof[12], (_d << 24) | _l) < ((_d << 24) | _l)) { P.prof[11] = ((unsigned long long)_tw_it[0] << 48) | ((unsigned long long)_tw_it[1] << 32) | ((unsigned long long)_tw_it[2] << 16) | (unsigned long long)_tw_it[3]; P.prof[10] = (unsigned long long)_tw_it[3]; P.prof[7] = (unsigned long long)_tw_it[2]; } atomicAdd((unsigned long long*)&P.prof[13], _d); atomicAdd((unsigned long long*)&P.prof[14], 1ull); \
+    if (atomicMax((unsigned long long*)&P.prof[12], (_d << 24) | _l) < ((_d << 24) | _l)) { P.prof[11] = ((unsigned long long)_tw_it[0] << 48) | ((unsigned long long)_tw_it[1] << 32) | ((unsigned long long)_tw_it[2] << 16) | (unsigned long long)_tw_it[3]; P.prof[10] = (unsigned long long)_tw_it[3]; P.prof[7] = (unsigned long long)_tw_it[2]; P.prof[5] = _tw_info; } atomicAdd((unsigned long long*)&P.prof[13], _d); atomicAdd((unsigned long long*)&P.prof[14], 1ull); \
     if (_d >= 10000ull) atomicAdd((unsigned long long*)&P.prof[15], 1ull); } } while (0)
+#define TW_ITEM_INFO(v) do { _tw_info = (v); } while (0)
 #define TW_PROF_FLUSH() do { if (_tw_on && threadIdx.x == 0) { const unsigned long long _d = (unsigned long long)(wall_clock64() - _tw_born); \
     atomicAdd((unsigned long long*)&P.prof[8], _d); atomicAdd((unsigned long long*)&P.prof[9], 1ull); atomicMax((unsigned long long*)&P.prof[6], _d); \
     for (int _k = 0; _k < 5; _k++) atomicAdd((unsigned long long*)&P.prof[_k], (unsigned long long)_tw_ph[_k]); } } while (0)
@@ -368,6 +372,7 @@ constexpr int kHeavyThreads = 64;
 #define TW_ITEM_BEGIN() do {} while (0)
 #define TW_PHASE(k) do {} while (0)
 #define TW_ITEM_END(tuples) do {} while (0)
+#define TW_ITEM_INFO(v) do {} while (0)
 #define TW_PROF_FLUSH() do {} while (0)
 #endif
 
@@ -399,10 +404,16 @@ constexpr int kSplitMin = TW_SPLIT_MIN, kSplitGrain = TW_SPLIT_GRAIN, kMaxParts 
 // part replays the heap on its share and logs those tuples in order (kPartLogCap of them); k_merge_parts replays the concatenation
 // of the logs, part after part -- the reference's heap, push by push, without one wavefront walking the whole enumeration.
 #ifndef TW_PART_LOG_CAP
-#define TW_PART_LOG_CAP 128
+#define TW_PART_LOG_CAP 256
 #endif
 constexpr int kPartLogCap = TW_PART_LOG_CAP;
 constexpr int kPartLogFlag = 1 << 25;   // in heavy_big_part / split_parts
+// A span with twin candidates that is enumerated whole goes straight to the replay of CPython's heap (the second attempt of
+// k_enumerate_heavy): on millisecond-granular traces the first attempt -- the five largest under the strict part of Python's order --
+// nearly always ends undecided, and the span was walked twice.  The replay is the reference's procedure itself, so starting with it
+// never changes a result.  In heavy_big_part (long enumerations) / in heavy_in_idx (the others; span indices stay below 2^26).
+constexpr int kReplayFlag = 1 << 26;
+constexpr int kIdxReplayFlag = 1 << 30;
 template <int E>
 __device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narrow, bool big, int unit, int i, long long prod = 0, int first_cands = 0,
                                              bool twins = false) {
@@ -436,12 +447,12 @@ __device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narro
     }
     if (isbig) {
         const int q = P.heavy_big_off[E] + sb;
-        P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | (wide_flag & (1 << 24)); P.heavy_big_slot[q] = 0;
+        P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | (wide_flag & (1 << 24)) | (twins ? kReplayFlag : 0); P.heavy_big_slot[q] = 0;
         return true;
     }
     const int pos = narrow ? P.heavy_in_off[E] + sn : P.heavy_in_off[E + 1] - 1 - sw;
     P.heavy_in_unit[pos] = unit;
-    P.heavy_in_idx[pos] = i;
+    P.heavy_in_idx[pos] = i | (twins ? kIdxReplayFlag : 0);
     return true;
 }
 
@@ -568,8 +579,18 @@ struct LdsHeap {
 // its 232 registers allow (E = 4) -- and the enumeration group does get 7 % faster (2.57 -> 2.39 ms per launch at 6.4 M spans,
 // 8.70 -> 8.08 ms at 25.6 M), but the 256 B per lane it then spills are written back to HBM: 2.4 GB per launch at 25.6 M spans,
 // five times everything else the group writes.  The registers have to go by restructuring (cold paths out of line), not by a cap.
+// Round 5: the log-mode bookkeeping took the E = 4 instantiation from 256 to 257 registers -- one wavefront per SIMD instead of two,
+// 1.09 -> 2.09 ms for the media shape's class (profiles/HISTORY.md).  Up to four endpoints the kernel is therefore held to two
+// wavefronts per SIMD (256 registers: what it used before; the few bytes it spills stay in the scratch's L2 lines).
+#ifndef TW_HEAVY_WAVES
+#define TW_HEAVY_WAVES(E) ((E) <= 4 ? 2 : 1)
+#endif
 #ifndef TW_HEAVY_ATTR
+#ifdef TW_HOST_EMULATION
 #define TW_HEAVY_ATTR
+#else
+#define TW_HEAVY_ATTR __attribute__((amdgpu_waves_per_eu(TW_HEAVY_WAVES(E))))
+#endif
 #endif
 constexpr int kPairPoolPerEp = 160;   // doubles of pair-term tables per endpoint (E <= 4); 2048 doubles (16 KB) for the deep call graphs
 constexpr int kGridTarget = TW_GRID_TARGET;     // grid points per prefix the split of the endpoints aims at (a prefix step costs about as much as five grid batches)
@@ -590,6 +611,14 @@ constexpr int kPruneGrid = TW_PRUNE_GRID;    // grid points per prefix the split
 #define TW_FRONTIER_BIG_CAP (1 << 21)
 #define TW_FRONTIER_BIG_SLOTS 48
 #endif
+// A listed enumeration with no more tuples than this is scored from its list (every tuple, a wavefront at a time); one with more only
+// counts its last level and finds the five best by the pruned walk.  (Round 5: the walk's threshold is a score that five tuples reach --
+// an enumeration of fewer than five tuples, or one whose bound is loose, walked every feasible prefix one after the other: single
+// spans of the deep call graphs held their class' kernel for 3 ms with a list of a few thousand tuples at hand.)
+#ifndef TW_LIST_SCORE_MAX
+#define TW_LIST_SCORE_MAX 16384
+#endif
+constexpr long long kListScoreMax = TW_LIST_SCORE_MAX;
 constexpr int kFrontierCap = TW_FRONTIER_CAP;          // prefixes per level and wavefront (two buffers of 8 B entries); beyond: a slot of the pool
 constexpr int kFrontierBigCap = TW_FRONTIER_BIG_CAP;       // ... of kFrontierBigSlots lists this long (32 MB a slot); beyond, or none left: the walk
 constexpr int kFrontierSlots = 4096;            // buffer pairs of kFrontierCap entries, claimed by the wavefronts that need one
@@ -666,12 +695,14 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         const bool from_big = item < n_big;
         const int pos = from_big ? P.heavy_big_off[E] + item : (kWide ? P.heavy_in_off[E + 1] - 1 - (item - n_big) : P.heavy_in_off[E] + (item - n_big));
         const int unit = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_unit : P.heavy_in_unit)[pos]);
-        const int i = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_idx : P.heavy_in_idx)[pos]);
+        const int i_raw = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_idx : P.heavy_in_idx)[pos]);
+        const int i = i_raw & ~kIdxReplayFlag;
         // a part of a split enumeration?  (number of parts, which one, where its result goes)
         const int part_info = from_big ? __builtin_amdgcn_readfirstlane(P.heavy_big_part[pos]) : 1;
         if (from_big && (((part_info >> 24) & 1) != 0) != kWide) continue;   // the other instantiation's
         const int nparts = part_info & 255, part_no = (part_info >> 8) & 0xffff;
         const bool part_log = nparts > 1 && (part_info & kPartLogFlag) != 0;   // log mode: this part replays CPython's heap and logs what entered it
+        const bool replay_first = nparts == 1 && (from_big ? (part_info & kReplayFlag) != 0 : (i_raw & kIdxReplayFlag) != 0);   // twin candidates: see kReplayFlag
         int nlog = 0;                                                         // (lane 0's count)
         const int part_slot = from_big ? __builtin_amdgcn_readfirstlane(P.heavy_big_slot[pos]) : 0;
         const UnitDev& U = P.units[unit];
@@ -810,7 +841,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         // tuples as in pass 1 (leaves0); the long enumerations of deep call graphs (those that list their tuples, below) list only
         // the prefixes of E - 1 endpoints and count the last level: tuple count and candidate bitmap without a single score.
         // Otherwise the walk is not pruned.
-        bool prune = false, tables_ok = false, counted = false;
+        bool prune = false, tables_ok = false, counted = false, list_all = false;
         long long leaves_counted = 0;
         double mclose = -dinf(), margin = 0.0, thr0 = -dinf();
         long long tail[E];   // tuples below a prefix that ends at level d when every grid point is one: the product of the later counts
@@ -819,7 +850,10 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
             long long grid = 1;
 #pragma unroll
             for (int e = E - 1; e >= 0; e--) { tail[e] = grid; grid = grid < (1ll << 40) ? grid * cn[e] : grid; any_order |= dag_pm[e]; }
-            const bool countable = any_order == 0 || (pass == 2 && mode == 0);   // (otherwise, for the long enumerations of deep call graphs: counted by listing prefixes, below)
+            // pass 2 knows the tuple count of pass 1: a long enumeration of few tuples is listed and scored whole (list_all), not walked
+            if (E >= 3 && pass == 2 && mode == 0 && any_order != 0 && grid >= kFrontierGrid && !U.skip)
+                list_all = P.leaves0[U.in_off + i] <= kListScoreMax;
+            const bool countable = any_order == 0 || (pass == 2 && mode == 0 && !list_all);   // (otherwise, for the long enumerations of deep call graphs: counted by listing prefixes, below)
             if (E >= 2 && grid >= kPruneMin && (countable || (E >= 3 && grid >= kFrontierGrid)) && !U.skip) {
                 auto wave_max = [&](double v) -> double {
                     for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(v, off); v = o > v ? o : v; }
@@ -884,7 +918,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         // candidates are in start order, so that is a tail of the list, found by bisection: one lane per prefix, the
         // children written behind one another (wavefront prefix sum of the counts), depth-first order kept
         TW_PHASE(1);
-        bool use_front = false;
+        bool use_front = false, list_scored = false;
         int n_front = 0;
         const unsigned long long* front = nullptr;
         if constexpr (E >= 3) {
@@ -895,7 +929,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
             if (prune) grid = 0;
             // count_only: the prefixes of E - 1 endpoints are listed, their tuples counted and their candidates marked -- the pruned
             // walk then finds the five best without scoring the rest
-            const bool count_only = tables_ok && !prune;
+            const bool count_only = tables_ok && !prune && !list_all;
             int minlo = 0x7fffffff;
             if (grid >= kFrontierGrid && any_order != 0 && !U.skip && front_slot < 0 && front_slot != -2) {
                 // the first such span of this wavefront claims one of the kFrontierSlots buffer pairs (kernels of several
@@ -920,12 +954,23 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                     for (int d = 1; d < E; d++) {
                         if (!use_front) continue;
                         const int cd = cn[d];
-                        const bool last_count = count_only && d == E - 1;
+                        const bool count_level = count_only && d == E - 1;
                         int nnext = 0;
+                        // the last level of a counted enumeration: counted first (rep 0) and -- only where the count is small -- written
+                        // after all (rep 1: the enumeration is scored from its list, see kListScoreMax); every other level is written
+                        for (int rep = count_level ? 0 : 1; rep < 2; rep++) {
+                        const bool last_count = rep == 0;
+                        if (rep == 1 && count_level) {
+                            if (leaves_counted > kListScoreMax || leaves_counted > cap) break;
+                            list_scored = true;
+                        }
+                        nnext = 0;
+                        unsigned long long ent_ahead = t < nprev ? fa[t] : 0ull;   // (the list lives in global memory: one batch ahead of its use)
                         for (int base = 0; base < nprev; base += nt) {
                             const int f = base + t;
                             const bool valid = f < nprev;
-                            const unsigned long long ent = valid ? fa[f] : 0ull;
+                            const unsigned long long ent = ent_ahead;
+                            ent_ahead = f + nt < nprev ? fa[f + nt] : 0ull;
                             int64_t tmin = INT64_MIN;   // the latest end among the predecessors' spans
 #pragma unroll
                             for (int q = 0; q < E - 1; q++)
@@ -955,6 +1000,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                             nnext += total;
                             if (nnext > cap) break;   // uniform
                         }
+                        }
                         if (nnext > cap) use_front = false;
                         unsigned long long* sw = fa; fa = fb; fb = sw;
                         nprev = nnext;
@@ -963,7 +1009,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                     }
                     front = fa;
                     n_front = nprev;
-                    if (count_only && use_front) {   // counted: on to the pruned walk
+                    if (count_only && use_front && !list_scored) {   // counted: on to the pruned walk
                         for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(minlo, off); minlo = o < minlo ? o : minlo; }
                         if (pass == 1 && mode == 0)   // (the admissible candidates of the last endpoint are tails of its list: their union is one)
                             for (int c = t; c < cn[E - 1]; c += nt) if (c >= minlo) { const int r = lr[E - 1][c]; atomicOr(&sbits[E - 1][r >> 6], 1ull << (r & 63)); }
@@ -982,6 +1028,12 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                 }
             }
         }
+#ifdef TW_ENUM_TRACE
+        if (t == 0 && E >= 3 && (use_front || counted))
+            printf("enumerate_heavy<%d>: pass %d mode %d span %d part %d/%d: %s, %lld tuples\n", E, pass, mode, i, part_no, nparts,
+                   list_scored ? "counted, then scored from its list" : list_all ? "listed (count of pass 1) and scored" : counted ? "counted, pruned walk" : "listed and scored",
+                   counted ? leaves_counted : (long long)n_front);
+#endif
         LdsHeap<E, W> hp;
         hp.heap = sheap; hp.nheap = 0; hp.ls = ls;
         wave_sync();
@@ -1071,7 +1123,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         double ts[kTopK];
         int tslot[kTopK], nk = 0;
         bool exact_replay = false, ambiguous = false;
-        for (int attempt = part_log ? 1 : 0; attempt < 2; attempt++) {
+        for (int attempt = (part_log || replay_first) ? 1 : 0; attempt < 2; attempt++) {
         exact_replay = attempt == 1;
         hp.nheap = 0; nk = 0; leaves = 0;
 #pragma unroll
@@ -1414,6 +1466,15 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         // constraints: the cut prefixes' tuples are not a product), the count of pass 1 stands
         if (prune && any_order != 0) leaves = counted ? leaves_counted : (nparts > 1 ? 0 : P.leaves0[U.in_off + i]);
         wave_sync();
+#ifdef TW_PROFILE
+        {   // what the longest item was: flags | parts << 8 | part << 16 | staged candidates per endpoint, 6 bits each, from bit 24
+            unsigned long long info = (prune ? 1ull : 0ull) | (exact_replay ? 2ull : 0ull) | (use_front ? 4ull : 0ull) | (counted ? 8ull : 0ull) | (part_log ? 16ull : 0ull) |
+                                      (list_scored ? 32ull : 0ull) | (list_all ? 64ull : 0ull) | (tables_ok ? 128ull : 0ull) | ((unsigned long long)nparts << 8) | ((unsigned long long)(part_no & 255) << 16);
+#pragma unroll
+            for (int e = 0; e < E; e++) info |= (unsigned long long)(cn[e] > 31 ? 31 : cn[e]) << (24 + 5 * e);
+            TW_ITEM_INFO(info);
+        }
+#endif
         TW_PHASE(3);
         if (t == 0) {
             if (exact_replay) hp.sort_desc();
@@ -1609,7 +1670,7 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
             if (redo) {
                 if (t == 0) {
                     const int q = P.heavy_big_off[E] + atomicAdd(&P.heavy_big_count[E], 1);
-                    P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | wide_bit; P.heavy_big_slot[q] = 0;
+                    P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | wide_bit | kReplayFlag; P.heavy_big_slot[q] = 0;
                     atomicAdd(&P.split_count[0], 1);
                 }
                 wave_sync();
@@ -1712,7 +1773,7 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
         if (redo) {
             if (t == 0) {
                 const int q = P.heavy_big_off[E] + atomicAdd(&P.heavy_big_count[E], 1);
-                P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | wide_bit; P.heavy_big_slot[q] = 0;
+                P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | wide_bit | kReplayFlag; P.heavy_big_slot[q] = 0;
                 atomicAdd(&P.split_count[0], 1);   // (classes start at E = 2: entry 0 counts the spans listed again, for tw_debug_worklists)
             }
         } else {
