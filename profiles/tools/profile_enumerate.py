@@ -15,6 +15,7 @@ eng = Engine(0, lib_path=os.environ.get("TW_PROFILE_LIB", "scratch/prof.so")); e
 lib = eng._lib
 lib.tw_debug_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 prev = np.zeros(16, dtype=np.uint64)
+hprev = np.zeros(16, dtype=np.uint64)
 for pass_no in (1, 2):
     if pass_no == 1: eng.run_pass1()
     else: eng.fit_mixtures(); eng.run_pass2()
@@ -32,3 +33,7 @@ for pass_no in (1, 2):
     print("   longest item: flags prune=%d replay=%d list=%d counted=%d log=%d list_scored=%d list_all=%d tables=%d, part %d of %d, staged candidates %s"
           % (info & 1, info >> 1 & 1, info >> 2 & 1, info >> 3 & 1, info >> 4 & 1, info >> 5 & 1, info >> 6 & 1, info >> 7 & 1, info >> 16 & 255, info >> 8 & 255,
              [info >> (24 + 5 * e) & 31 for e in range(8)]))
+    if hasattr(lib, "tw_debug_profile_hist"):
+        h = np.zeros(16, dtype=np.uint64); lib.tw_debug_profile_hist(eng._h, ctypes.c_void_p(h.ctypes.data))
+        d = h - hprev; hprev = h.copy()
+        print("   items by duration: " + ", ".join("%s %d" % (("<%.0f us" % (5.12 * 2 ** (b + 1))) if b < 15 else "more", int(d[b])) for b in range(16) if d[b]))

@@ -25,6 +25,7 @@ def build(force=False, production=False):
         "-DTW_MATCH_NODES_1=48", "-DTW_MATCH_NODES=256",
         "-DTW_TILE_SMALL", "-DTW_TILE_MAX=24",
         "-DTW_DP_CAP=24", "-DTW_DP_SLOTS=32", "-DTW_DP_CAP_SMALL=6", "-DTW_DP_SLOTS_SMALL=8",   # small tables of the level-by-level solver: both overflow routes (k_select_dp, then the depth-first search) occur
+        "-DTW_DEFER_TUPLES=40", "-DTW_SPLIT_TUPLES=12", "-DTW_DEFER_PREFIXES=24", "-DTW_DEFER_PREFIX_GRAIN=6",   # spans of the deferring classes (five endpoints and more) with more than 40 tuples are cut into list parts of a dozen
         "-DTW_LIST_SCORE_MAX=64",   # listed enumerations of up to 64 tuples are scored from the list, longer ones counted and walked: both occur
         "-DTW_PART_LOG_CAP=12",   # log-mode parts: a dozen entries, so that some logs overflow and the span is enumerated again as a whole
         "-DTW_FIT_HASH_SLOTS=512",   # refit: rows of more than 384 distinct gap values take the sort route, the others the hash table

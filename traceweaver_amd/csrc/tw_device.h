@@ -121,7 +121,7 @@ struct Dev {
     // the positions [first tile of s, first tile of s + 1) * tile_spans of tiny_* (short windows from the front of the segment, very
     // long ones from its back) and of heavy_* (long ones from the front, middle ones from the back).
     int32_t* heavy_count;
-    int32_t* heavy_next;    // [4] next unclaimed item of every list
+    int32_t* heavy_next;    // [kHardNext + 1 = 6] next unclaimed item of every selection list; [4], [5]: see hard_unit
     int32_t *heavy_unit, *heavy_win;
     int32_t *tiny_unit, *tiny_win;
     int32_t *hard_unit, *hard_win;   // windows k_select_heavy gave up on, for k_select_dp (count and cursor: heavy_next[4], [5])
@@ -142,6 +142,14 @@ struct Dev {
                                // replays the logs; 1 split like the others, the span enumerated again as a whole when the order is not decided
                                // (tests: the merge's way back); 0 not split (TW_SPLIT_TWINS)
     int32_t* part_used;        // [kMaxEp+1] extra list entries handed out per class
+    // deferred spans (deep call graphs; kListSplitFlag in tw_kernels.h): their listed prefixes, cut into list parts
+    int32_t defer_min_e;       // classes from this many endpoints on defer their long spans (TW_DEFER_MIN_E, default 5; 9 = none)
+    int32_t defer_cap;         // entries of defer_list
+    unsigned long long* defer_list;   // arena of prefix lists (bump-allocated per pass)
+    int32_t* defer_used;       // [1] entries handed out
+    int32_t* defer_count;      // [kMaxEp+1] list parts appended behind the class' listed entries
+    int32_t *part_lo, *part_hi;   // [slot] a list part's stretch of defer_list
+    int32_t* part_lvl;            // [slot] ... whose entries are prefixes of the endpoints 0 .. part_lvl
     int32_t* split_count;      // [kMaxEp+1] split spans per class
     int32_t *split_unit, *split_idx, *split_slot, *split_parts;   // [part_off region] one record per split span
     int32_t* part_n;           // [slot] entries | ambiguous << 8

@@ -252,6 +252,7 @@ template <int E>
 Dev slice_dev(const tw_engine* e, int s) {
     Dev D = e->P;
     if (e->cls_slices[E] <= 1) return D;
+    D.defer_min_e = kMaxEp + 1;   // (a sliced class cuts its long spans by the first endpoint's candidate: the deferred parts' counters are per class)
     D.heavy_in_off[E] = e->slice_in0[E][s]; D.heavy_in_off[E + 1] = e->slice_in0[E][s + 1];
     D.heavy_big_off[E] = e->slice_big0[E][s]; D.heavy_big_off[E + 1] = e->slice_big0[E][s + 1];
     D.part_off[E] = e->slice_part0[E][s]; D.part_off[E + 1] = e->slice_part0[E][s + 1];
@@ -279,6 +280,12 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
         const int grid = std::max(std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096), 1);  // persistent wavefronts pulling spans from the work list
         hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, pool_bytes, q, P, pass, mode, 0, pool);
         hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), hb, pool_bytes, q, P, pass, mode, 0, pool);
+        if (mode == 0 && E >= 3 && E >= P.defer_min_e) {   // the list parts of the spans the launches above deferred (kListSplitFlag)
+            (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), q);
+            hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, pool_bytes, q, P, pass, mode, 3, pool);
+            (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), q);
+            hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), hb, pool_bytes, q, P, pass, mode, 3, pool);
+        }
         if (mode == 0 && E > 1) {
             (void)hipMemsetAsync(P.heavy_big_count + E, 0, sizeof(int32_t), q);
             hipLaunchKernelGGL(k_merge_parts, dim3(1024), dim3(std::min(e->coop, 64)), 0, q, P, pass, E);
@@ -893,6 +900,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     P.batch_size = b->batch_size;
     P.batch_mis = b->batch_size_mis;
     P.split_twins = env_int("TW_SPLIT_TWINS", 2);
+    P.defer_min_e = env_int("TW_DEFER_MIN_E", 5);
     int rc;
 #define ALLOC(ptr, count) do { rc = dev_alloc(e, &(ptr), (count)); if (rc != TW_OK) return rc; } while (0)
     e->arena_req.clear();
@@ -937,6 +945,12 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         ALLOC(P.part_n, slots); ALLOC(P.part_leaves, slots); ALLOC(P.part_score, slots * kTopK); ALLOC(P.part_idx, slots * kTopK * kMaxEp);
         ALLOC(P.part_bits, slots * kMaxEp * kCandWords);
         ALLOC(P.part_logn, slots); ALLOC(P.part_log_sc, slots * kPartLogCap); ALLOC(P.part_log_ix, slots * kPartLogCap);
+        ALLOC(P.part_lo, slots); ALLOC(P.part_hi, slots); ALLOC(P.part_lvl, slots);
+        // the arena of the deferred spans' prefix lists: a few thousand entries per span that defers, recycled every pass
+        int64_t deep = 0;
+        for (int cls = std::max(P.defer_min_e, 3); cls <= kMaxEp; cls++) deep += heavy_off_h[cls + 1] - heavy_off_h[cls];
+        P.defer_cap = (int32_t)(deep > 0 ? std::min<int64_t>(std::max<int64_t>(deep * kDeferListPerSpan, kDeferListMin), 1ll << 28) : 1);
+        ALLOC(P.defer_list, P.defer_cap);
     }
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
     for (int cls = 1; cls <= kMaxEp; cls++) {   // slices of the class' tiles with their shares of the class' work lists (launch_enumerate)
@@ -960,15 +974,15 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
             e->slice_part0[cls][sl] = (int32_t)(P.part_off[cls] + 2 * ex);
         }
     }
-    ALLOC(P.prof, 16); ALLOC(e->key_acc, 2);
+    ALLOC(P.prof, 32); ALLOC(e->key_acc, 2);
     const int64_t sel_cap = (int64_t)P.n_tiles * e->tile + 1;   // every segment of the selection lists has room for all windows of its tiles
     {   // the counter block (every array on a 128-byte line of its own: their atomics come from different kernels)
         int64_t at = 0;
         auto take = [&](int64_t ints) { const int64_t o = at; at += (ints + 31) / 32 * 32; return o; };
-        const int64_t o_hc = take(4 * kSelSeg * kCtrStride), o_hn = take(4), o_ic = take(2 * (kMaxEp + 1)), o_in = take(3 * (kMaxEp + 1)), o_bc = take(kMaxEp + 1),
+        const int64_t o_hc = take(4 * kSelSeg * kCtrStride), o_hn = take(kHardNext + 1), o_ic = take(2 * (kMaxEp + 1)), o_in = take(3 * (kMaxEp + 1)), o_bc = take(kMaxEp + 1),
                       o_rc = take(1);
         e->ctr_round_ints = at;
-        const int64_t o_pu = take(kMaxEp + 1), o_sc = take(kMaxEp + 1), o_err = take(1), o_nd = take(P.n_units), o_us = take((int64_t)P.n_units * 16);
+        const int64_t o_pu = take(kMaxEp + 1), o_sc = take(kMaxEp + 1), o_dc = take(kMaxEp + 1), o_du = take(1), o_err = take(1), o_nd = take(P.n_units), o_us = take((int64_t)P.n_units * 16);
         const int64_t o_fn = take(kFrontierSlots), o_fb = take(P.frontier_big_slots);   // flags of the tuple-list pools (given back by the kernels themselves)
         const int64_t o_sl = take((int64_t)(kMaxSlices - 1) * kSliceCtrInts);   // work-list counters of the slices beyond the first (launch_enumerate)
         e->ctr_pass_ints = at;
@@ -977,6 +991,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
             int32_t* c = e->ctr = (int32_t*)q;
             D.heavy_count = c + o_hc; D.heavy_next = c + o_hn; D.heavy_in_count = c + o_ic; D.heavy_in_next = c + o_in; D.heavy_big_count = c + o_bc;
             D.round_changed = c + o_rc; D.frontier_busy = c + o_fn; D.frontier_big_busy = c + o_fb;
+            D.defer_count = c + o_dc; D.defer_used = c + o_du;
             D.part_used = c + o_pu; D.split_count = c + o_sc; D.err = c + o_err; D.unit_ndirty = c + o_nd;
             D.unit_stats = (int64_t*)(c + o_us);
             e->slice_ctr = c + o_sl;
@@ -1044,7 +1059,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         HIPCHK(hipMemcpyAsync(e->skip_dist, dist_h.data(), sizeof(double) * dist_h.size(), hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));   // the staging vectors go out of scope
     }
-    HIPCHK(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 16, e->stream));
+    HIPCHK(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 32, e->stream));
     HIPCHK(hipMemsetAsync(P.prof + 10, 0xff, sizeof(unsigned long long), e->stream));
     P.units = d_units; P.tiles = d_tiles;
     P.in_start = d_is; P.in_end = d_ie; P.out_start = d_os; P.out_end = d_oe;
@@ -1412,6 +1427,13 @@ int tw_get_timing(tw_engine* e, double* ms, int32_t n) {
 }
 
 /* Debug aid, not part of the public header: phase timers of -DTW_PROFILE builds (zeros otherwise). */
+int tw_debug_profile_hist(tw_engine* e, unsigned long long* out16) {   // item durations of the profiled kernel, by powers of two (TW_ITEM_END)
+    if (e == nullptr || out16 == nullptr) return TW_ERR_ARG;
+    HIPCHK(hipMemcpyAsync(out16, e->P.prof + 16, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TW_OK;
+}
+
 int tw_debug_profile(tw_engine* e, unsigned long long* out16) {
     if (e == nullptr || out16 == nullptr || e->state < ST_LOADED) return TW_ERR_ARG;
     HIPCHK(hipMemcpyAsync(out16, e->P.prof, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, e->stream));

@@ -362,7 +362,8 @@ constexpr int kHeavyThreads = 64;
 #define TW_ITEM_END(tuples) do { if (_tw_on && threadIdx.x == 0) { const unsigned long long _d = (unsigned long long)(wall_clock64() - _tw_t); \
     const unsigned long long _l = (unsigned long long)(tuples) > 0xffffffull ? 0xffffffull : (unsigned long long)(tuples); \
     if (atomicMax((unsigned long long*)&P.prof[12], (_d << 24) | _l) < ((_d << 24) | _l)) { P.prof[11] = ((unsigned long long)_tw_it[0] << 48) | ((unsigned long long)_tw_it[1] << 32) | ((unsigned long long)_tw_it[2] << 16) | (unsigned long long)_tw_it[3]; P.prof[10] = (unsigned long long)_tw_it[3]; P.prof[7] = (unsigned long long)_tw_it[2]; P.prof[5] = _tw_info; } atomicAdd((unsigned long long*)&P.prof[13], _d); atomicAdd((unsigned long long*)&P.prof[14], 1ull); \
-    if (_d >= 10000ull) atomicAdd((unsigned long long*)&P.prof[15], 1ull); } } while (0)
+    if (_d >= 10000ull) atomicAdd((unsigned long long*)&P.prof[15], 1ull); \
+    { int _b = 63 - __clzll((long long)(_d | 1ull)) - 9; _b = _b < 0 ? 0 : (_b > 15 ? 15 : _b); atomicAdd((unsigned long long*)&P.prof[16 + _b], 1ull); } } } while (0)   /* [16 + b]: items of 5.12 us x 2^b .. 2^(b+1) */
 #define TW_ITEM_INFO(v) do { _tw_info = (v); } while (0)
 #define TW_PROF_FLUSH() do { if (_tw_on && threadIdx.x == 0) { const unsigned long long _d = (unsigned long long)(wall_clock64() - _tw_born); \
     atomicAdd((unsigned long long*)&P.prof[8], _d); atomicAdd((unsigned long long*)&P.prof[9], 1ull); atomicMax((unsigned long long*)&P.prof[6], _d); \
@@ -414,6 +415,30 @@ constexpr int kPartLogFlag = 1 << 25;   // in heavy_big_part / split_parts
 // never changes a result.  In heavy_big_part (long enumerations) / in heavy_in_idx (the others; span indices stay below 2^26).
 constexpr int kReplayFlag = 1 << 26;
 constexpr int kIdxReplayFlag = 1 << 30;
+// Deep call graphs (P.defer_min_e endpoints and more, call-order constraints): a span's cost is its tuple count, which neither the grid
+// of its candidates (a thousand times larger) nor ranges of the first endpoint's candidates (most feasible tuples sit under one or two
+// of them) predict.  The wavefront that draws such a span lists its prefixes of E - 1 endpoints and counts the last level anyway
+// (count_only); from kDeferTuples tuples on it does not go on alone: it copies the list to an arena (P.defer_list), cuts it into
+// stretches of about kSplitTuples tuples -- contiguous stretches of the enumeration, balanced by construction -- and appends one LIST
+// PART per stretch behind the class' listed entries.  A second launch of the kernel (part = 3) serves them: a list part stages the
+// span's candidates like any other item, expands its stretch's last level into its own buffer and scores the tuples from there;
+// k_merge_parts combines the parts as it does those cut by the first endpoint's candidate (top five or logs, in part order).
+constexpr int kListSplitFlag = 1 << 27;   // in heavy_big_part / split_parts
+#ifndef TW_DEFER_TUPLES
+#define TW_DEFER_TUPLES 4096
+#define TW_SPLIT_TUPLES 2048
+#endif
+constexpr long long kDeferTuples = TW_DEFER_TUPLES;
+constexpr int kSplitTuples = TW_SPLIT_TUPLES;
+// The listing itself is one wavefront's work, a batch of 64 prefixes at a time (2.5 us a batch on a SIMD of its own: 1.6 ms for the
+// 20 000 prefixes of a 51 000-tuple span): a span whose list reaches kDeferPrefixes entries at a level before the last is cut THERE,
+// into stretches of equal numbers of prefixes -- its list parts list the remaining levels themselves (P.part_lvl = the level handed over).
+#ifndef TW_DEFER_PREFIXES
+#define TW_DEFER_PREFIXES 1024
+#define TW_DEFER_PREFIX_GRAIN 64
+#endif
+constexpr int kDeferPrefixes = TW_DEFER_PREFIXES, kDeferPrefixGrain = TW_DEFER_PREFIX_GRAIN;
+constexpr long long kDeferListPerSpan = 64, kDeferListMin = 1ll << 22;   // entries of the arena per incoming span of the deferring classes / at least
 template <int E>
 __device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narrow, bool big, int unit, int i, long long prod = 0, int first_cands = 0,
                                              bool twins = false) {
@@ -598,7 +623,14 @@ constexpr int kGridTarget = TW_GRID_TARGET;     // grid points per prefix the sp
 // points for 10^4-10^5 feasible tuples): walking the prefixes one after the other and testing a dense grid below each
 // leaves most lanes idle (0.1 % of the grid is feasible).  Such a span first lists its feasible tuples, level by level
 // (see the kernel), in the reference's depth-first order, and then scores them a wavefront at a time.
-constexpr long long kFrontierGrid = 1 << 15;   // from this many grid points (staged candidates) on, and E >= 3
+#ifndef TW_FRONTIER_GRID_DEEP
+#define TW_FRONTIER_GRID_DEEP 1024
+#endif
+// from this many grid points (staged candidates) on, and E >= 3.  The deep classes list much earlier: a batch of 64 grid points costs an
+// eight-endpoint wavefront 3 us (it runs alone on its SIMD), and a grid of 32 400 points with 598 tuples held the class' kernel for
+// 1.7 ms of walking (round 5) where the list of its tuples takes ten batches to score.
+__host__ __device__ constexpr long long frontier_grid(int E) { return E >= 5 ? TW_FRONTIER_GRID_DEEP : 1 << 15; }
+#define kFrontierGrid frontier_grid(E)
 // Long enumerations are walked with an upper bound (see "bounds of the pruned walk" in the kernel): from this many grid points on
 #ifndef TW_PRUNE_MIN
 #define TW_PRUNE_MIN 1024
@@ -662,10 +694,13 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
     __shared__ int64_t pxs[E], pxe[E];
     __shared__ double pxp[E];                   // ... and the sum of the score terms its levels 0..d determine (pruned walk)
     __shared__ double sbound[E + 1];            // upper bound of the terms the levels d.. can add (pruned walk)
+    __shared__ int32_t defer_lo[kMaxParts + 1]; // first listed prefix of every list part (deferred spans)
     const int t = threadIdx.x, nt = blockDim.x;
-    const int n_big = part == 2 ? 0 : P.heavy_big_count[E];   // (both instantiations walk the list of long enumerations; each takes its own)
-    const int count = n_big + (part == 1 ? 0 : P.heavy_in_count[kList]);
-    int32_t* next_counter = &P.heavy_in_next[part == 1 ? 2 * (kMaxEp + 1) + E : kNext];
+    // part 3: the list parts of the deferred spans (see kListSplitFlag), appended behind the class' listed entries by the launch before
+    const int defer_base = part == 3 ? P.heavy_big_count[E] : 0;
+    const int n_big = part == 2 ? 0 : (part == 3 ? P.defer_count[E] : P.heavy_big_count[E]);   // (both instantiations walk the list of long enumerations; each takes its own)
+    const int count = n_big + ((part == 1 || part == 3) ? 0 : P.heavy_in_count[kList]);
+    int32_t* next_counter = &P.heavy_in_next[(part == 1 || part == 3) ? 2 * (kMaxEp + 1) + E : kNext];
     const int nstatic = (int)gridDim.x * kWorkChunk;
     if ((int)blockIdx.x >= count) return;   // nothing for this wavefront (its strided static items start at its block index)
     int chunk_pos = 0, chunk_end = 0;
@@ -693,7 +728,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         // wave-uniform by construction; telling the compiler so turns every access to the unit descriptor below
         // into a scalar load (SGPRs, constant cache) instead of 64 lanes loading the same address
         const bool from_big = item < n_big;
-        const int pos = from_big ? P.heavy_big_off[E] + item : (kWide ? P.heavy_in_off[E + 1] - 1 - (item - n_big) : P.heavy_in_off[E] + (item - n_big));
+        const int pos = from_big ? P.heavy_big_off[E] + defer_base + item : (kWide ? P.heavy_in_off[E + 1] - 1 - (item - n_big) : P.heavy_in_off[E] + (item - n_big));
         const int unit = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_unit : P.heavy_in_unit)[pos]);
         const int i_raw = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_idx : P.heavy_in_idx)[pos]);
         const int i = i_raw & ~kIdxReplayFlag;
@@ -704,6 +739,8 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         const bool part_log = nparts > 1 && (part_info & kPartLogFlag) != 0;   // log mode: this part replays CPython's heap and logs what entered it
         const bool replay_first = nparts == 1 && (from_big ? (part_info & kReplayFlag) != 0 : (i_raw & kIdxReplayFlag) != 0);   // twin candidates: see kReplayFlag
         int nlog = 0;                                                         // (lane 0's count)
+        const bool list_part = nparts > 1 && (part_info & kListSplitFlag) != 0;   // its tuples: a stretch of the span's listed prefixes (P.part_lo / part_hi)
+        bool part_failed = false, deferred = false;
         const int part_slot = from_big ? __builtin_amdgcn_readfirstlane(P.heavy_big_slot[pos]) : 0;
         const UnitDev& U = P.units[unit];
         TW_ITEM_BEGIN();
@@ -773,7 +810,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         int64_t leaves = 0;
         int nout = 0, big_slot = -1;   // (big_slot: a long tuple list of the pool, given back when the span is done)
         int c0_begin = 0, c0_end = cn[0];   // the staged candidates of the first endpoint this wavefront enumerates
-        if (nparts > 1) { c0_begin = (int)((long long)part_no * cn[0] / nparts); c0_end = (int)((long long)(part_no + 1) * cn[0] / nparts); none |= c0_begin == c0_end; }
+        if (nparts > 1 && !list_part) { c0_begin = (int)((long long)part_no * cn[0] / nparts); c0_end = (int)((long long)(part_no + 1) * cn[0] / nparts); none |= c0_begin == c0_end; }
         bool part_ambiguous = false;
         if (!none) {
         {   // one (candidate span, root | closing) term per lane, all endpoints at once
@@ -841,7 +878,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         // tuples as in pass 1 (leaves0); the long enumerations of deep call graphs (those that list their tuples, below) list only
         // the prefixes of E - 1 endpoints and count the last level: tuple count and candidate bitmap without a single score.
         // Otherwise the walk is not pruned.
-        bool prune = false, tables_ok = false, counted = false, list_all = false;
+        bool prune = false, tables_ok = false, counted = false, list_all = false, can_defer = false;
         long long leaves_counted = 0;
         double mclose = -dinf(), margin = 0.0, thr0 = -dinf();
         long long tail[E];   // tuples below a prefix that ends at level d when every grid point is one: the product of the later counts
@@ -851,10 +888,16 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
 #pragma unroll
             for (int e = E - 1; e >= 0; e--) { tail[e] = grid; grid = grid < (1ll << 40) ? grid * cn[e] : grid; any_order |= dag_pm[e]; }
             // pass 2 knows the tuple count of pass 1: a long enumeration of few tuples is listed and scored whole (list_all), not walked
-            if (E >= 3 && pass == 2 && mode == 0 && any_order != 0 && grid >= kFrontierGrid && !U.skip)
-                list_all = P.leaves0[U.in_off + i] <= kListScoreMax;
-            const bool countable = any_order == 0 || (pass == 2 && mode == 0 && !list_all);   // (otherwise, for the long enumerations of deep call graphs: counted by listing prefixes, below)
-            if (E >= 2 && grid >= kPruneMin && (countable || (E >= 3 && grid >= kFrontierGrid)) && !U.skip) {
+            // (a class that defers its long spans lists and counts them in pass 2 as well: the count decides who scores them)
+            can_defer = E >= 3 && E >= P.defer_min_e && part == 0 && mode == 0 && nparts == 1 && !U.skip && any_order != 0 && (!replay_first || P.split_twins == 2);
+            bool count_again = false;
+            if (E >= 3 && pass == 2 && mode == 0 && any_order != 0 && grid >= kFrontierGrid && !U.skip) {
+                const long long n0 = P.leaves0[U.in_off + i];
+                list_all = n0 <= (can_defer ? kDeferTuples : kListScoreMax);
+                count_again = can_defer && !list_all;
+            }
+            const bool countable = any_order == 0 || (pass == 2 && mode == 0 && !list_all && !count_again);   // (otherwise, for the long enumerations of deep call graphs: counted by listing prefixes, below)
+            if (E >= 2 && grid >= kPruneMin && (countable || (E >= 3 && grid >= kFrontierGrid)) && !U.skip && !list_part) {
                 auto wave_max = [&](double v) -> double {
                     for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(v, off); v = o > v ? o : v; }
                     return v;
@@ -929,30 +972,53 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
             if (prune) grid = 0;
             // count_only: the prefixes of E - 1 endpoints are listed, their tuples counted and their candidates marked -- the pruned
             // walk then finds the five best without scoring the rest
-            const bool count_only = tables_ok && !prune && !list_all;
+            const bool count_only = tables_ok && !prune && !list_all && !list_part;
             int minlo = 0x7fffffff;
-            if (grid >= kFrontierGrid && any_order != 0 && !U.skip && front_slot < 0 && front_slot != -2) {
+            const bool listed = (grid >= kFrontierGrid && any_order != 0 && !U.skip) || list_part;
+            int defer_np = 0, defer_slot = 0, defer_at = 0, defer_level = 0;
+            bool defer_by_tuples = false;
+            // the class' budget of extra list entries and the arena: room for np parts and n list entries?  (lane 0 asks, all lanes hear)
+            auto defer_reserve = [&](int np, int n) -> bool {
+                int got = -1, at = 0;
+                if (t == 0 && np >= 2) {
+                    const int old = atomicAdd(&P.part_used[E], np);   // (the span's own entry stays on the list: every part is an extra one)
+                    if (old + np <= (P.part_off[E + 1] - P.part_off[E]) / 2) {
+                        at = atomicAdd(P.defer_used, n);
+                        if ((long long)at + n <= (long long)P.defer_cap) got = P.part_off[E] + 2 * old;
+                    }
+                }
+                defer_slot = __shfl(got, 0); defer_at = __shfl(at, 0); defer_np = np;
+                return defer_slot >= 0;
+            };
+            if (listed && front_slot < 0 && front_slot != -2) {
                 // the first such span of this wavefront claims one of the kFrontierSlots buffer pairs (kernels of several
                 // classes run side by side: the block index does not identify a wavefront across them)
                 if (t == 0) front_slot = pool_acquire(P.frontier_busy, kFrontierSlots, ((unsigned)blockIdx.x * 40503u + (unsigned)(E * 2 + (kWide ? 1 : 0)) * 7919u + (unsigned)part * 104729u));
                 front_slot = __shfl(front_slot, 0);
                 if (front_slot < 0) front_slot = -2;   // none free: this wavefront walks
             }
-            if (grid >= kFrontierGrid && any_order != 0 && !U.skip && front_slot >= 0) {
+            if (listed && front_slot >= 0) {
                 unsigned long long* fa = P.frontier + (size_t)front_slot * 2 * kFrontierCap;
                 int cap = kFrontierCap;
                 const int lane = t & 63;
                 for (int tries = 0; tries < 2; tries++) {
                     unsigned long long* fb = fa + cap;
-                    for (int c = c0_begin + t; c < c0_end; c += nt) fa[c - c0_begin] = (unsigned long long)c;
                     int nprev = c0_end - c0_begin;
+                    int part_lvl = 0;
+                    if (list_part) {   // the stretch of the span's listed prefixes of level part_lvl: the levels below are left to list (into the own buffers)
+                        const int p_lo = P.part_lo[part_slot], p_hi = P.part_hi[part_slot];
+                        part_lvl = P.part_lvl[part_slot];
+                        fb = fa; fa = P.defer_list + p_lo; nprev = p_hi - p_lo;
+                    } else
+                        for (int c = c0_begin + t; c < c0_end; c += nt) fa[c - c0_begin] = (unsigned long long)c;
                     use_front = true;
                     leaves_counted = 0;
                     __threadfence_block();
                     wave_sync();
 #pragma unroll
                     for (int d = 1; d < E; d++) {
-                        if (!use_front) continue;
+                        if (!use_front || deferred) continue;
+                        if (list_part && d <= part_lvl) continue;
                         const int cd = cn[d];
                         const bool count_level = count_only && d == E - 1;
                         int nnext = 0;
@@ -961,6 +1027,10 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                         for (int rep = count_level ? 0 : 1; rep < 2; rep++) {
                         const bool last_count = rep == 0;
                         if (rep == 1 && count_level) {
+                            if (can_defer && leaves_counted > kDeferTuples) {   // many tuples: cut into list parts, if the class' budget and the arena allow
+                                const long long want = (leaves_counted + kSplitTuples - 1) / kSplitTuples;
+                                if (defer_reserve((int)(want > kMaxParts ? kMaxParts : want), nprev)) { deferred = true; defer_by_tuples = true; defer_level = E - 2; break; }
+                            }
                             if (leaves_counted > kListScoreMax || leaves_counted > cap) break;
                             list_scored = true;
                         }
@@ -1002,13 +1072,81 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                         }
                         }
                         if (nnext > cap) use_front = false;
-                        unsigned long long* sw = fa; fa = fb; fb = sw;
-                        nprev = nnext;
+                        if (!(count_level && !list_scored)) {   // (a level that was only counted leaves the list of its prefixes where it is)
+                            unsigned long long* sw = fa; fa = fb; fb = sw;
+                            if (list_part && d == part_lvl + 1) fb = fa + cap;   // (a list part's first level came from the arena: on between its own two buffers)
+                            nprev = nnext;
+                            // a long list before the last level: the span is cut here, its parts list the rest (see kDeferPrefixes)
+                            if (can_defer && use_front && d < E - 1 && nprev >= kDeferPrefixes) {
+                                const int want = nprev / kDeferPrefixGrain;
+                                if (defer_reserve(want > kMaxParts ? kMaxParts : want, nprev)) { deferred = true; defer_level = d; }
+                            }
+                        }
                         __threadfence_block();
                         wave_sync();
                     }
                     front = fa;
                     n_front = nprev;
+                    if (deferred) {
+                        // The list parts.  Prefix f begins at tuple s_f (running sum of the children counts): it belongs to part
+                        // floor(s_f np / total); the first prefix of every part is where that number changes (parts that no prefix
+                        // begins in stay empty).  The list is copied to the arena on the way.
+                        const int cd = cn[E - 1];
+                        for (int q = t; q <= kMaxParts; q += nt) defer_lo[q] = defer_by_tuples ? nprev : (int)((long long)q * nprev / defer_np);
+                        wave_sync();
+                        long long running = 0;
+                        int carry_pid = -1;
+                        if (!defer_by_tuples)   // stretches of equal numbers of prefixes: only the copy
+                            for (int f = t; f < nprev; f += nt) P.defer_list[(int64_t)defer_at + f] = fa[f];
+                        for (int base = 0; defer_by_tuples && base < nprev; base += nt) {
+                            const int f = base + t;
+                            const bool valid = f < nprev;
+                            const unsigned long long ent = valid ? fa[f] : 0ull;
+                            int64_t tmin = INT64_MIN;
+#pragma unroll
+                            for (int q = 0; q < E - 1; q++)
+                                if ((dag_pm[E - 1] >> q) & 1) { const int64_t en = le[q][(ent >> (8 * q)) & 255ull]; tmin = en > tmin ? en : tmin; }
+                            int lo2 = 0, hi2 = cd;
+                            while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (ls[E - 1][mid] < tmin) lo2 = mid + 1; else hi2 = mid; }
+                            const int cnt = valid ? cd - lo2 : 0;
+                            int incl = cnt;
+                            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl(incl, lane >= off ? lane - off : lane); if (lane >= off) incl += v; }
+                            const long long s0 = running + incl - cnt;
+                            int pid = (int)(s0 * defer_np / leaves_counted);
+                            pid = pid > defer_np - 1 ? defer_np - 1 : pid;
+                            const int last_valid = nprev - base - 1 < 63 ? nprev - base - 1 : 63;
+                            if (!valid) pid = __shfl(pid, last_valid);
+                            int prev_pid = __shfl(pid, lane > 0 ? lane - 1 : 0);
+                            if (lane == 0) prev_pid = carry_pid;
+                            if (valid) {
+                                for (int q = prev_pid + 1; q <= pid; q++) defer_lo[q] = f;
+                                P.defer_list[(int64_t)defer_at + f] = ent;
+                            }
+                            carry_pid = __shfl(pid, 63);
+                            running += __shfl(incl, 63);
+                        }
+                        __threadfence();
+                        wave_sync();
+                        const int log_flag = (replay_first && P.split_twins == 2) ? kPartLogFlag : 0;
+                        const int flags = (kWide ? 1 << 24 : 0) | log_flag | kListSplitFlag;
+                        int ebase = 0;
+                        if (t == 0) {
+                            ebase = P.heavy_big_off[E] + P.heavy_big_count[E] + atomicAdd(&P.defer_count[E], defer_np);
+                            const int k = P.part_off[E] + atomicAdd(&P.split_count[E], 1);
+                            P.split_unit[k] = unit; P.split_idx[k] = i; P.split_slot[k] = defer_slot; P.split_parts[k] = defer_np | flags;
+                        }
+                        ebase = __shfl(ebase, 0);
+                        for (int q = t; q < defer_np; q += nt) {
+                            P.part_lo[defer_slot + q] = defer_at + defer_lo[q];
+                            P.part_hi[defer_slot + q] = defer_at + (q + 1 < defer_np ? defer_lo[q + 1] : nprev);
+                            P.part_lvl[defer_slot + q] = defer_level;
+                            P.heavy_big_unit[ebase + q] = unit; P.heavy_big_idx[ebase + q] = i;
+                            P.heavy_big_part[ebase + q] = defer_np | (q << 8) | flags; P.heavy_big_slot[ebase + q] = defer_slot + q;
+                        }
+                        wave_sync();
+                        use_front = false;
+                        break;
+                    }
                     if (count_only && use_front && !list_scored) {   // counted: on to the pruned walk
                         for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(minlo, off); minlo = o < minlo ? o : minlo; }
                         if (pass == 1 && mode == 0)   // (the admissible candidates of the last endpoint are tails of its list: their union is one)
@@ -1027,12 +1165,13 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                     cap = kFrontierBigCap;
                 }
             }
+            if (list_part && !use_front) part_failed = true;   // (no buffer for its tuples: the span is enumerated again as a whole)
         }
 #ifdef TW_ENUM_TRACE
-        if (t == 0 && E >= 3 && (use_front || counted))
+        if (t == 0 && E >= 3 && (use_front || counted || deferred || part_failed))
             printf("enumerate_heavy<%d>: pass %d mode %d span %d part %d/%d: %s, %lld tuples\n", E, pass, mode, i, part_no, nparts,
-                   list_scored ? "counted, then scored from its list" : list_all ? "listed (count of pass 1) and scored" : counted ? "counted, pruned walk" : "listed and scored",
-                   counted ? leaves_counted : (long long)n_front);
+                   deferred ? "counted, deferred to list parts" : part_failed ? "list part without a buffer" : list_part ? "list part, scored" : list_scored ? "counted, then scored from its list" : list_all ? "listed (count of pass 1) and scored" : counted ? "counted, pruned walk" : "listed and scored",
+                   (counted || deferred) ? leaves_counted : (long long)n_front);
 #endif
         LdsHeap<E, W> hp;
         hp.heap = sheap; hp.nheap = 0; hp.ls = ls;
@@ -1123,7 +1262,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         double ts[kTopK];
         int tslot[kTopK], nk = 0;
         bool exact_replay = false, ambiguous = false;
-        for (int attempt = (part_log || replay_first) ? 1 : 0; attempt < 2; attempt++) {
+        for (int attempt = (deferred || part_failed) ? 2 : (part_log || replay_first) ? 1 : 0; attempt < 2; attempt++) {
         exact_replay = attempt == 1;
         hp.nheap = 0; nk = 0; leaves = 0;
 #pragma unroll
@@ -1495,7 +1634,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         }  // !none
         if (nparts > 1) {   // a part: its top-5 (span indices), tuple count and candidate bitmap go to the scratch slot
             if (t == 0) {
-                P.part_n[part_slot] = nout | (part_ambiguous ? 256 : 0) | (nlog > kPartLogCap ? 512 : 0);   // (flags: the span is enumerated again as a whole)
+                P.part_n[part_slot] = nout | ((part_ambiguous || part_failed) ? 256 : 0) | (nlog > kPartLogCap ? 512 : 0);   // (flags: the span is enumerated again as a whole)
                 P.part_leaves[part_slot] = leaves;
                 if (part_log) P.part_logn[part_slot] = nlog;
             }
@@ -1511,7 +1650,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                 }
             }
             for (int q = t; q < E * kCandWords; q += nt) P.part_bits[((int64_t)part_slot * kMaxEp + q / kCandWords) * kCandWords + q % kCandWords] = sbits[q / kCandWords][q % kCandWords];
-        } else
+        } else if (!deferred)
         {   // results leave through all lanes: one (entry, field) per lane; staged positions back to span indices
             const int64_t g = U.in_off + i;
             int32_t* out_n = mode == 1 ? P.tkr_n : P.tk_n;

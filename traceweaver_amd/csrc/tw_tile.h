@@ -256,6 +256,13 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
             // replay CPython's heap on their shares and log what entered it (log mode, see heavy_append)
             if (twins && P.split_twins == 0) first_cands = 0;
             twins_any = twins;
+            // a class that defers its long spans cuts them by their listed prefixes once their tuples are counted (kListSplitFlag)
+            if (E >= 3 && E >= P.defer_min_e) {
+                uint32_t any_order = 0;
+#pragma unroll
+                for (int e = 0; e < E; e++) any_order |= U.pred_mask[e];
+                if (any_order != 0) first_cands = 0;
+            }
         }
         heavy_append<E>(P, live && !mine && !wide, narrow, hprod > kBigProduct, T.unit, i, hprod, U.skip ? 0 : first_cands, twins_any);
     }
