@@ -24,6 +24,10 @@ VARIANTS = {
     "heavy3": ["-DTW_HEAVY_ATTR=" + WPE(3)],
     "heavy4": ["-DTW_HEAVY_ATTR=" + WPE(4)],
     "hw_all2": ["-DTW_HEAVY_WAVES(E)=2"],                 # round 5: every endpoint-count class of k_enumerate_heavy at two wavefronts per SIMD
+    "tile384": ["-DTW_TILE_MAX=384"],
+    "tile512": ["-DTW_TILE_MAX=512"],
+    "tile768g": ["-DTW_TILE_MAX=768", "-DTW_TILE_ITEMS=1024", "-DTW_TILE_GRID=1536"],
+    "prof4": ["-DTW_PROFILE", "-DTW_PROFILE_E=4"],
     "prof8": ["-DTW_PROFILE", "-DTW_PROFILE_E=8"],
     "prof7": ["-DTW_PROFILE", "-DTW_PROFILE_E=7"],
     "log256": ["-DTW_PART_LOG_CAP=256"],

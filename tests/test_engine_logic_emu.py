@@ -75,6 +75,15 @@ def test_error_statuses(emu_lib):
     with pytest.raises(EngineError) as ei:       # pass 2 needs mixtures
         eng.run_pass2()
     assert ei.value.code == -4
+    g = eng.gaps()
+    eng.fit_mixtures()
+    mix = eng.mixtures()
+    eng.load([u])                                # an engine that only serves the refit (gaps handed over, mixtures fitted) never ran
+    eng.set_gaps(g)                              # pass 1 on this batch: the second pass has nothing to read cut-offs and windows from
+    eng.set_mixtures([m[0] for m in mix], [m[1] for m in mix])
+    with pytest.raises(EngineError) as ei:
+        eng.run_pass2()
+    assert ei.value.code == -4 and "first pass" in str(ei.value)
     eng.close()
 
 

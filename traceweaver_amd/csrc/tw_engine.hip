@@ -121,6 +121,7 @@ struct tw_engine {
     int64_t* fit_tape_off = nullptr;
     int64_t fit_tape_cap = 0;
     bool fit_prepared = false;              // the gap rows of the resident pass-1 result are sorted and run-length compressed
+    bool pass1_done = false;                // tw_run_pass1 has run on the resident batch (tw_run_pass2 reads its cut-offs, windows, tuple counts)
     std::vector<int32_t> fit_max_n;         // per slot min(5, #unique), 0 = nothing to fit (host copy, tw_fit_rows)
     bool fit_max_n_valid = false;           // ... of the rows that are prepared now (cleared with fit_prepared)
     Mt19937 fit_rng;                        // stream of tw_fit_mixtures (tw_set_fit_seed; restarted by every tw_load_batch)
@@ -681,7 +682,7 @@ extern "C" int tw_scale_load(tw_engine* e, const int32_t* unit_factor, const int
     }
     HIPCHK(hipMemcpyAsync(const_cast<UnitDev*>(P.units), e->units.data(), sizeof(UnitDev) * e->units.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->state = ST_LOADED;
+    e->state = ST_LOADED; e->pass1_done = false;
     return TW_OK;
 }
 
@@ -1090,7 +1091,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipMemsetAsync(e->mix_n_dev, 0, sizeof(int32_t) * std::max<int64_t>(slots, 1), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->scaled_upload = b->unit_time_scale != nullptr;
-    e->state = ST_LOADED;
+    e->state = ST_LOADED; e->pass1_done = false;
     return TW_OK;
 }
 
@@ -1100,7 +1101,7 @@ int tw_run_pass1(tw_engine* e) {
     HIPCHK(hipSetDevice(e->device));
     const int rc = run_pass(e, 1);
     e->fit_prepared = false; e->fit_max_n_valid = false;
-    if (rc == TW_OK) e->state = ST_PASS1;
+    if (rc == TW_OK) { e->state = ST_PASS1; e->pass1_done = true; }
     return rc;
 }
 
@@ -1377,6 +1378,9 @@ int tw_get_mixtures(tw_engine* e, int32_t* mix_n, double* mix_p) {
 int tw_run_pass2(tw_engine* e) {
     if (e == nullptr) return TW_ERR_ARG;
     if (e->state != ST_MIX && e->state != ST_PASS2) return fail(e, TW_ERR_STATE, "tw_run_pass2 needs tw_run_pass1 and tw_set_mixtures first");
+    // (tw_set_gaps* + tw_set_mixtures reach ST_MIX on a batch that never ran pass 1 -- an engine that only serves the refit; the second
+    // pass reads what the first left behind: cut-offs, window flags, tuple counts)
+    if (!e->pass1_done) return fail(e, TW_ERR_STATE, "tw_run_pass2 on a batch whose first pass has not run (tw_run_pass1 first)");
     HIPCHK(hipSetDevice(e->device));
     const int rc = run_pass(e, 2);
     if (rc == TW_OK) e->state = ST_PASS2;

@@ -181,8 +181,8 @@ class Corpus(object):
 # time_order_filenames.pickle").  The reference keeps the time-ordered file list of a directory in a pickle inside it and
 # trusts it until --clear_cache 1 (executor.py:320-339); this cache holds what the native loader made of the files -- span
 # table, units, the strings results are keyed by -- under the same rule, plus a cheap guard: loader version and sources,
-# the arguments of the load and the directory's modification time (entries added, removed or renamed; a file rewritten in
-# place is not seen -- that is what --clear_cache is for).  A hit replaces reading and parsing every JSON file.
+# the arguments of the load and a digest of the names of the directory's trace files, taken before the load (files added, removed
+# or renamed; a file rewritten in place is not seen -- that is what --clear_cache is for).  A hit replaces reading and parsing every JSON file.
 CACHE_FILE = "tw_span_table.bin"
 CACHE_VERSION = 1
 _UNIT_ARRAYS = ("in_off", "E", "ep_off", "dag", "key_rank", "in_start", "in_end", "out_start", "out_end", "truth", "in_trace", "in_row", "out_row", "order")
@@ -224,8 +224,6 @@ def _write_arrays(path, header, arrays):
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)
-    m = os.stat(os.path.dirname(path) or ".").st_mtime_ns   # the directory's modification time after the rename: the file carries
-    os.utime(path, ns=(m, m))                               # it as its own (see _cache_fresh)
 
 
 def _read_arrays(path):
@@ -300,17 +298,25 @@ class CachedCorpus(object):
         return out, dict(self._skipped), int(self._n_traces)
 
 
-def _cache_fresh(directory, path):
-    """The cache file carries the directory's modification time as it was right after the file was put in place: entries
-    added to, removed from or renamed in the directory since then have moved it on.  Like the reference's cache of a
-    directory (its time-ordered file list, executor.py:320-339) this does not see a trace file edited in place."""
-    return os.stat(directory).st_mtime_ns == os.stat(path).st_mtime_ns
+def _listing_digest(directory):
+    """Digest of the directory's trace files by name (what the loader would read), taken BEFORE a load or a cache hit: the cache
+    is valid for exactly this set of files.  Entries that are not traces (another process' temporary file, a result file, the
+    cache itself) do not count; like the reference's cache of a directory (its time-ordered file list, executor.py:320-339) this
+    does not see a trace file edited in place -- that is what --clear_cache is for."""
+    import hashlib
+
+    h = hashlib.sha256()
+    with os.scandir(directory) as it:
+        for name in sorted(e.name for e in it if e.name.endswith(".json")):
+            h.update(name.encode("utf-8", "surrogateescape") + b"\0")
+    return h.hexdigest()[:32]
 
 
-def _save_cache(corpus, directory, key_args, counts):
-    """Writes the cache of a freshly loaded directory (to a temporary name, then renamed over the cache file)."""
+def _save_cache(corpus, directory, key_args, counts, listing):
+    """Writes the cache of a freshly loaded directory (to a temporary name, then renamed over the cache file); `listing` = the
+    digest of the directory's trace files as they were before the load."""
     path = os.path.join(directory, CACHE_FILE)
-    key = _cache_key(directory, *key_args)
+    key = _cache_key(directory, *key_args) + listing
     raw = corpus._unit_set_arrays()
     table = corpus.span_table()
     names = corpus.trace_names()
@@ -342,20 +348,21 @@ def open_directory(directory, lib_path=None, first_span=None, max_traces=1001, f
             os.remove(path)
         except OSError:
             cache = False
+    listing = _listing_digest(directory) if cache else ""
     if cache and os.path.exists(path):
         try:
-            meta, z = _read_arrays(path) if _cache_fresh(directory, path) else ({}, None)
-            if meta.get("key") == _cache_key(directory, *key_args):
+            meta, z = _read_arrays(path)
+            if meta.get("key") == _cache_key(directory, *key_args) + listing:
                 c = CachedCorpus(meta, z)
                 return c, c.counts()
-        except Exception:   # unreadable / incomplete / written by another version: a miss
+        except (OSError, ValueError, KeyError):   # unreadable / incomplete / written by another version: a miss
             pass
     corpus = Corpus(lib_path=lib_path)
     counts = corpus.add_directory(directory, first_span=first_span, max_traces=max_traces, fix=fix, callers=callers, threads=threads)
     corpus.from_cache = False
     if cache:
         try:
-            _save_cache(corpus, directory, key_args, counts)
-        except Exception:   # read-only directory, disk full, ...: a problem with the cache never fails the run
+            _save_cache(corpus, directory, key_args, counts, listing)
+        except OSError:   # read-only directory, disk full, ...: a problem with the cache FILE never fails the run (anything else is a bug and shows)
             pass
     return corpus, counts

@@ -93,7 +93,10 @@ class TraceWeaverGPU(object):
         if fit == "sklearn":   # the cross-check consumes numpy's RNG as the installed scikit-learn does: the draw schedule the
             import sklearn     # device refit replays (1, 3, 7, 10, 13 uniforms for 1..5 components) is that of scikit-learn >= 1.3
 
-            if tuple(int(x) for x in sklearn.__version__.split(".")[:2]) < (1, 3):
+            import re
+
+            ver = re.match(r"^(\d+)\.(\d+)", sklearn.__version__)   # ("1.6rc1", "1.8.dev0": only the leading numbers count; unparsable: no warning)
+            if ver is not None and (int(ver.group(1)), int(ver.group(2))) < (1, 3):
                 warnings.warn("scikit-learn %s draws its k-means++ seeds on another schedule than the device refit replays "
                               "(>= 1.3): fit='sklearn' and fit='device' will not reproduce each other" % sklearn.__version__)
         self.fit = fit
