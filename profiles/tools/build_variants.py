@@ -27,6 +27,7 @@ VARIANTS = {
     "tile384": ["-DTW_TILE_MAX=384"],
     "tile512": ["-DTW_TILE_MAX=512"],
     "tile768g": ["-DTW_TILE_MAX=768", "-DTW_TILE_ITEMS=1024", "-DTW_TILE_GRID=1536"],
+    "dptrace": ["-DTW_DP_TRACE"],
     "prof4": ["-DTW_PROFILE", "-DTW_PROFILE_E=4"],
     "prof8": ["-DTW_PROFILE", "-DTW_PROFILE_E=8"],
     "prof7": ["-DTW_PROFILE", "-DTW_PROFILE_E=7"],

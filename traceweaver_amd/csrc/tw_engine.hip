@@ -121,6 +121,7 @@ struct tw_engine {
     int64_t* fit_tape_off = nullptr;
     int64_t fit_tape_cap = 0;
     bool fit_prepared = false;              // the gap rows of the resident pass-1 result are sorted and run-length compressed
+    int tile_sub_max = 8;
     bool pass1_done = false;                // tw_run_pass1 has run on the resident batch (tw_run_pass2 reads its cut-offs, windows, tuple counts)
     std::vector<int32_t> fit_max_n;         // per slot min(5, #unique), 0 = nothing to fit (host copy, tw_fit_rows)
     bool fit_max_n_valid = false;           // ... of the rows that are prepared now (cleared with fit_prepared)
@@ -301,7 +302,12 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
     if (S <= 1) {
         // mode 0: cut-offs and work lists, the tile kernel, the wavefront kernels (which take the spans the tile kernel hands over);
         // mode 1: the spans k_detect_gone listed
-        if (mode == 0) hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt), tile_block, 0, st, e->P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt);
+        if (mode == 0) {
+            // a class of few tiles: several workgroups per tile (k_enumerate_tile), until the class fills the CUs twice over
+            int sub = 1;
+            while (sub < e->tile_sub_max && nt * sub < 512 && (e->tile / (sub * 2)) * (sub * 2) == e->tile && e->tile / (sub * 2) >= 8) sub *= 2;
+            hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt * sub), tile_block, 0, st, e->P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt, sub);
+        }
         wavefront_kernels(st, e->P);
     } else {
         // slices of the class' tiles: tile kernel s, then its wavefront kernels on the second stream while tile kernel s + 1 runs --
@@ -311,7 +317,7 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
         for (int sl = 0; sl < S; sl++) {
             const Dev Ps = slice_dev<E>(e, sl);
             const int t0 = e->slice_tile0[E][sl], cnt = e->slice_tile0[E][sl + 1] - t0;
-            if (cnt > 0) hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(cnt), tile_block, 0, st, Ps, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E] + t0), cnt);
+            if (cnt > 0) hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(cnt), tile_block, 0, st, Ps, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E] + t0), cnt, 1);
             if (sl + 1 < S) {
                 (void)hipEventRecord(e->slice_ev[E][sl], st);
                 (void)hipStreamWaitEvent(st2, e->slice_ev[E][sl], 0);
@@ -713,6 +719,7 @@ int tw_create(int device_id, tw_engine** out) {
     // partly serialise.  Only the long classes prioritised: no change.  Plain streams.)
     for (int i = 1; i <= kMaxEp && s == hipSuccess; i++) s = hipStreamCreate(&e->cls_stream[i]);
     for (int i = 0; i <= kMaxEp + 1 && s == hipSuccess; i++) s = hipEventCreateWithFlags(&e->cls_ev[i], hipEventDisableTiming);
+    e->tile_sub_max = std::max(env_int("TW_TILE_SUB", 8), 1);   // workgroups per tile for classes of few tiles (1 = never)
     e->enum_slices = std::min(std::max(env_int("TW_ENUM_SLICES", 1), 1), kMaxSlices);   // (measured: slower -- 4.5 ms per launch set unsliced, 4.7 / 4.9 / 6.2 ms in 2 / 4 / 8 slices; profiles/HISTORY.md)
     e->slice_min_tiles = std::max(env_int("TW_ENUM_SLICE_MIN_TILES", 2048), 1);
     for (int i = 1; i <= kMaxEp && s == hipSuccess && e->enum_slices > 1; i++) {

@@ -202,7 +202,12 @@ __global__ void __launch_bounds__(kRunsThreads) k_fit_runs(FitDev F, int32_t* fa
     const int64_t row = F.gs_off[F.slot_unit[q]] + (q - U.slot_off) * (int64_t)n_all;
     const double* x = F.gaps + row;
     const double scale = U.tscale, inv = 1.0 / U.tscale;   // a power of two: both exact
-    for (int r = t; r < kHashSlots; r += nt) tab[r] = kHashEmpty;
+    // a short row takes a short table (a power of two of at least twice its samples): what is cleared and sorted is the table, not
+    // the row -- 16 384 words cost a row of 600 samples 0.14 ms
+    int slots = kHashSlots < 256 ? kHashSlots : 256;
+    while (slots < kHashSlots && slots < 2 * n_all) slots <<= 1;
+    const int slot_shift = 32 - __builtin_ctz((unsigned)slots), hash_max = slots / 4 * 3;
+    for (int r = t; r < slots; r += nt) tab[r] = kHashEmpty;
     if (t == 0) { s_uniq = 0; s_n = 0; s_bad = 0; }
     __syncthreads();
     int mine = 0;
@@ -217,14 +222,14 @@ __global__ void __launch_bounds__(kRunsThreads) k_fit_runs(FitDev F, int32_t* fa
             const double v = xi[j] * inv;
             const uint32_t key = (uint32_t)v;
             if (__double_as_longlong(xi[j]) < 0 || !(v < 4294967295.0) || (double)key != v) { s_bad = 1; continue; }
-            uint32_t slot = (key * 2654435761u) >> (32 - __builtin_ctz((unsigned)kHashSlots));   // multiplicative hashing: the product's top bits
+            uint32_t slot = (key * 2654435761u) >> slot_shift;   // multiplicative hashing: the product's top bits
             const unsigned long long word = (unsigned long long)key << 32;
             bool placed = false;
-            for (int probe = 0; probe < kHashSlots && !placed; probe++) {
+            for (int probe = 0; probe < slots && !placed; probe++) {
                 const unsigned long long old = atomicCAS(&tab[slot], kHashEmpty, word);
-                if (old == kHashEmpty) { if (atomicAdd(&s_uniq, 1) >= kHashMax) s_bad = 1; placed = true; }
+                if (old == kHashEmpty) { if (atomicAdd(&s_uniq, 1) >= hash_max) s_bad = 1; placed = true; }
                 else if ((uint32_t)(old >> 32) == key) placed = true;
-                else slot = (slot + 1) & (uint32_t)(kHashSlots - 1);
+                else slot = (slot + 1) & (uint32_t)(slots - 1);
             }
             if (placed) atomicAdd(&tab[slot], 1ull); else s_bad = 1;
         }
@@ -237,9 +242,9 @@ __global__ void __launch_bounds__(kRunsThreads) k_fit_runs(FitDev F, int32_t* fa
         return;
     }
     // bitonic sort of the table's words, ascending (a value's word orders by the value; empty words are the largest)
-    for (int k = 2; k <= kHashSlots; k <<= 1) {
+    for (int k = 2; k <= slots; k <<= 1) {
         for (int j = k >> 1; j >= 1; j >>= 1) {
-            for (int p = t; p < kHashSlots / 2; p += nt) {
+            for (int p = t; p < slots / 2; p += nt) {
                 const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));   // the p-th index whose bit j is clear
                 const unsigned long long a = tab[i], b = tab[i | j];
                 const bool up = (i & k) == 0;

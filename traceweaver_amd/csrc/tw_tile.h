@@ -89,15 +89,20 @@ __device__ __forceinline__ double score_term_gap(const Scorer& S, int slot, long
 #endif
 
 template <int E>
-__global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e) {
+__global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e, int sub_tiles) {
     if (*P.err != 0) return;  // e.g. NaN parameters (hazard H3): nothing downstream is meaningful
     typedef TileCfg<E> C;
     constexpr int SL = C::kSlice;
-    const int tile = tile_ids[xcd_tile(blockIdx.x, n_tiles_e)];
+    // sub_tiles > 1: a class of few tiles (the deep call graphs of a small batch: 57 tiles on 256 CUs, each a millisecond of
+    // segments one after the other) is launched with sub_tiles workgroups per tile, each serving a stretch of the tile's spans
+    const int vb = xcd_tile(blockIdx.x, n_tiles_e * sub_tiles);
+    const int tile = tile_ids[vb / sub_tiles];
     const TileDev T = P.tiles[tile];
     const UnitDev& U = P.units[T.unit];
     const int t = threadIdx.x, nt = blockDim.x;
-    const int ns = min(P.tile_spans, U.n_in - T.first);   // spans of this tile; thread t < ns owns span t (the block has >= tile_spans threads)
+    const int sub_spans = P.tile_spans / sub_tiles, first = T.first + (vb % sub_tiles) * sub_spans;
+    const int ns = min(sub_spans, min(P.tile_spans, U.n_in - T.first) - (vb % sub_tiles) * sub_spans);   // spans of this workgroup; thread t < ns owns span t
+    if (ns <= 0) return;
     __shared__ int32_t s_is[kTile], s_ie[kTile];          // start / end of the incoming spans as offsets from `base`
     __shared__ int32_t sl_st[E][SL], sl_en[E][SL];        // the staged slice of every endpoint list, same offsets (clamped)
     __shared__ int32_t s_A[E], s_B[E];                    // the slice = positions [A, B) of the endpoint's list
@@ -114,8 +119,8 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
     __shared__ uint8_t g_span[C::kGrid], g_rank[C::kGrid];   // the tuple's span (tile-local) / its rank; an infeasible grid point has score NaN
     __shared__ int32_t s_segend;
     const bool live = t < ns;
-    const int i = T.first + (live ? t : 0);
-    const int64_t base = P.in_start[U.in_off + T.first];
+    const int i = first + (live ? t : 0);
+    const int64_t base = P.in_start[U.in_off + first];
     const int64_t in_start = P.in_start[U.in_off + i], in_end = P.in_end[U.in_off + i];
     const int64_t* os[E];
     const int64_t* oe[E];
@@ -348,7 +353,7 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
             bool is_root = false;
 #pragma unroll
             for (int e = 0; e < E; e++) if (e == es) { st = sl_st[e][idx]; en = sl_en[e][idx]; is_root = dag_np[e] == 0; }
-            S.gp = P.gparam + (U.gp_off + (int64_t)((T.first + s) / P.batch_size) * U.nslot) * 4;
+            S.gp = P.gparam + (U.gp_off + (int64_t)((first + s) / P.batch_size) * U.nslot) * 4;
             t_root[k] = is_root ? score_term_gap(S, slot_root(E, es), (long long)st - s_is[s]) : 0.0;
             t_close[k] = score_term_gap(S, slot_close(E, es), (long long)s_ie[s] - en);
             it_idx[k] = (uint16_t)idx;
@@ -382,7 +387,7 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
                 int32_t last_end = en[0];
 #pragma unroll
                 for (int e = 1; e < E; e++) if (en[e] > last_end) { last_end = en[e]; last = e; }
-                S.gp = P.gparam + (U.gp_off + (int64_t)((T.first + s) / P.batch_size) * U.nslot) * 4;
+                S.gp = P.gparam + (U.gp_off + (int64_t)((first + s) / P.batch_size) * U.nslot) * 4;
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     const int np = (int)dag_np[e];
@@ -465,7 +470,7 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
             if (s_amb[s]) continue;
             int32_t kx[E], ix[E];
             decode(s, g0 + g - s_grid0[s], it0, kx, ix);
-            const int k = g_rank[g], si = T.first + s;
+            const int k = g_rank[g], si = first + s;
             P.tk_score[tks_index(U, k, si)] = g_sc[g];
 #pragma unroll
             for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, si)] = s_A[e] + ix[e];
