@@ -181,8 +181,8 @@ class Corpus(object):
 # time_order_filenames.pickle").  The reference keeps the time-ordered file list of a directory in a pickle inside it and
 # trusts it until --clear_cache 1 (executor.py:320-339); this cache holds what the native loader made of the files -- span
 # table, units, the strings results are keyed by -- under the same rule, plus a cheap guard: loader version and sources,
-# the arguments of the load and a digest of the names of the directory's trace files, taken before the load (files added, removed
-# or renamed; a file rewritten in place is not seen -- that is what --clear_cache is for).  A hit replaces reading and parsing every JSON file.
+# the arguments of the load and the directory's modification time (entries added, removed or renamed; a file rewritten in
+# place is not seen -- that is what --clear_cache is for).  A hit replaces reading and parsing every JSON file.
 CACHE_FILE = "tw_span_table.bin"
 CACHE_VERSION = 1
 _UNIT_ARRAYS = ("in_off", "E", "ep_off", "dag", "key_rank", "in_start", "in_end", "out_start", "out_end", "truth", "in_trace", "in_row", "out_row", "order")
@@ -298,25 +298,27 @@ class CachedCorpus(object):
         return out, dict(self._skipped), int(self._n_traces)
 
 
-def _listing_digest(directory):
-    """Digest of the directory's trace files by name (what the loader would read), taken BEFORE a load or a cache hit: the cache
-    is valid for exactly this set of files.  Entries that are not traces (another process' temporary file, a result file, the
-    cache itself) do not count; like the reference's cache of a directory (its time-ordered file list, executor.py:320-339) this
-    does not see a trace file edited in place -- that is what --clear_cache is for."""
-    import hashlib
-
-    h = hashlib.sha256()
+def _trace_count(directory):
+    """Number of trace files in the directory (what the loader would read)."""
     with os.scandir(directory) as it:
-        for name in sorted(e.name for e in it if e.name.endswith(".json")):
-            h.update(name.encode("utf-8", "surrogateescape") + b"\0")
-    return h.hexdigest()[:32]
+        return sum(1 for e in it if e.name.endswith(".json"))
 
 
-def _save_cache(corpus, directory, key_args, counts, listing):
-    """Writes the cache of a freshly loaded directory (to a temporary name, then renamed over the cache file); `listing` = the
-    digest of the directory's trace files as they were before the load."""
+def _cache_fresh(directory, path):
+    """The cache file carries the directory's modification time as it was right after the file was put in place (stamped by
+    _write_arrays' caller only if no trace file came or went while the directory was being loaded): entries added to, removed from
+    or renamed in the directory since then have moved it on.  One stat each -- a hit must not cost a listing of 20 000 files.  Like
+    the reference's cache of a directory (its time-ordered file list, executor.py:320-339) this does not see a trace file edited in
+    place, and a file system with coarse time stamps can miss a change within one tick: that is what --clear_cache is for."""
+    return os.stat(directory).st_mtime_ns == os.stat(path).st_mtime_ns
+
+
+def _save_cache(corpus, directory, key_args, counts, n_before):
+    """Writes the cache of a freshly loaded directory (to a temporary name, then renamed over the cache file) and stamps it with the
+    directory's modification time after the rename -- unless the number of trace files differs from `n_before`, the count taken
+    before the load: then a file arrived (or left) while the directory was being read, and the cache stays unstamped = stale."""
     path = os.path.join(directory, CACHE_FILE)
-    key = _cache_key(directory, *key_args) + listing
+    key = _cache_key(directory, *key_args)
     raw = corpus._unit_set_arrays()
     table = corpus.span_table()
     names = corpus.trace_names()
@@ -335,6 +337,10 @@ def _save_cache(corpus, directory, key_args, counts, listing):
     arrays.update({"u_" + k: raw[k] for k in _UNIT_ARRAYS})
     arrays.update({"t_" + k: table[k] for k in _TABLE_COLUMNS})
     _write_arrays(path, header, arrays)
+    m = os.stat(directory).st_mtime_ns   # the directory's modification time after the rename: the file carries it as its own (_cache_fresh)
+    if _trace_count(directory) != n_before:
+        m = 0
+    os.utime(path, ns=(m, m))
 
 
 def open_directory(directory, lib_path=None, first_span=None, max_traces=1001, fix=None, callers=None, threads=0, cache=True, clear_cache=False):
@@ -348,21 +354,21 @@ def open_directory(directory, lib_path=None, first_span=None, max_traces=1001, f
             os.remove(path)
         except OSError:
             cache = False
-    listing = _listing_digest(directory) if cache else ""
     if cache and os.path.exists(path):
         try:
-            meta, z = _read_arrays(path)
-            if meta.get("key") == _cache_key(directory, *key_args) + listing:
+            meta, z = _read_arrays(path) if _cache_fresh(directory, path) else ({}, None)
+            if meta.get("key") == _cache_key(directory, *key_args):
                 c = CachedCorpus(meta, z)
                 return c, c.counts()
         except (OSError, ValueError, KeyError):   # unreadable / incomplete / written by another version: a miss
             pass
+    n_before = _trace_count(directory) if cache else 0
     corpus = Corpus(lib_path=lib_path)
     counts = corpus.add_directory(directory, first_span=first_span, max_traces=max_traces, fix=fix, callers=callers, threads=threads)
     corpus.from_cache = False
     if cache:
         try:
-            _save_cache(corpus, directory, key_args, counts, listing)
+            _save_cache(corpus, directory, key_args, counts, n_before)
         except OSError:   # read-only directory, disk full, ...: a problem with the cache FILE never fails the run (anything else is a bug and shows)
             pass
     return corpus, counts
