@@ -27,6 +27,8 @@ VARIANTS = {
     "tile384": ["-DTW_TILE_MAX=384"],
     "tile512": ["-DTW_TILE_MAX=512"],
     "tile768g": ["-DTW_TILE_MAX=768", "-DTW_TILE_ITEMS=1024", "-DTW_TILE_GRID=1536"],
+    "parts16": ["-DTW_MAX_PARTS=16"],
+    "parts48s1k": ["-DTW_DEFER_TUPLES=2048", "-DTW_SPLIT_TUPLES=1024"],
     "dptrace": ["-DTW_DP_TRACE"],
     "prof4": ["-DTW_PROFILE", "-DTW_PROFILE_E=4"],
     "prof8": ["-DTW_PROFILE", "-DTW_PROFILE_E=8"],

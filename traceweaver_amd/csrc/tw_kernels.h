@@ -396,7 +396,12 @@ constexpr int kBigProduct = TW_BIG_PRODUCT;
 // span is listed kSplitGrain points a part (at most kMaxParts, at most one part per candidate of the first endpoint): part p
 // takes the tuples whose first span is among the p-th share of that endpoint's staged candidates.  (The host-emulation
 // build of the tests sets tiny thresholds so that the route is exercised.)
-constexpr int kSplitMin = TW_SPLIT_MIN, kSplitGrain = TW_SPLIT_GRAIN, kMaxParts = 16;
+#ifndef TW_MAX_PARTS
+#define TW_MAX_PARTS 48
+#endif
+// kMaxParts: parts of a span cut by its listed prefixes (deferred spans, see kListSplitFlag); kMaxCandParts: by the first endpoint's candidate
+constexpr int kSplitMin = TW_SPLIT_MIN, kSplitGrain = TW_SPLIT_GRAIN, kMaxParts = TW_MAX_PARTS, kMaxCandParts = 16;
+static_assert(kMaxParts >= kMaxCandParts && kMaxParts <= 255, "part numbers are eight bits");
 // A span with twin candidates (Python's order of tuples may not decide between two of its tuples) is split in LOG MODE: CPython's
 // size-5 heap (traceweaver_v3.py:304-307) is an exact function of the sequence of pushes, and a push whose score is strictly below
 // the score of the root of a full heap leaves the array as it was.  The root's score is the fifth largest score pushed so far, and
@@ -447,7 +452,7 @@ __device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narro
     int nparts = 1, slot_base = 0;
     if (E >= 2 && isbig && prod >= kSplitMin && first_cands >= 2) {
         long long want = prod / kSplitGrain;
-        want = want > kMaxParts ? kMaxParts : want;
+        want = want > kMaxCandParts ? kMaxCandParts : want;
         nparts = (int)(want > first_cands ? first_cands : want);
         if (nparts >= 2) {   // the class' budget of extra list entries (two scratch slots go with each)
             const int old = atomicAdd(&P.part_used[E], nparts - 1);
@@ -1780,11 +1785,12 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
     __shared__ double sc[kCandMax];
     __shared__ int32_t sp[kCandMax][kMaxEp];
     __shared__ int64_t ss[kCandMax][kMaxEp];    // start of the tuple's span at every endpoint
-    __shared__ uint8_t ok[kCandMax], rk[kCandMax];
+    __shared__ uint8_t ok[kCandMax];
+    __shared__ uint16_t rk[kCandMax];
     __shared__ int redo_flag;
     __shared__ int64_t w_st[kMaxEp][64 * kCandWords];           // log mode: start times of the cut-off windows' spans
-    __shared__ double lg_sc[kMaxParts * kPartLogCap];          // ... the parts' logs behind one another
-    __shared__ unsigned long long lg_ix[kMaxParts * kPartLogCap];
+    __shared__ double lg_sc[kPartLogCap];                      // ... one part's log at a time
+    __shared__ unsigned long long lg_ix[kPartLogCap];
     __shared__ double h_sc[kTopK + 1];
     __shared__ unsigned long long h_ix[kTopK + 1];
     __shared__ int h_n;
@@ -1799,11 +1805,9 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
         if (P.split_parts[rec] & kPartLogFlag) {
             // ---- log mode: replay the parts' logs
             bool redo = false;
-            int total_log = 0;
             long long leaves = 0;
             for (int p = 0; p < nparts; p++) {   // (<= kMaxParts: every lane the same few loads)
                 if (P.part_n[slot0 + p] >> 8) redo = true;   // a log that is not complete
-                total_log += P.part_logn[slot0 + p];
                 leaves += P.part_leaves[slot0 + p];
             }
             if (redo) {
@@ -1819,29 +1823,24 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
                 const int lo = P.c_lo[ie_index(U, e, i)], w = P.c_hi[ie_index(U, e, i)] - lo + 1;
                 for (int r = t; r < w && r < 64 * kCandWords; r += nt) w_st[e][r] = P.out_start[U.ep_off[e] + lo + r];
             }
-            {
-                int at = 0;
-                for (int p = 0; p < nparts; p++) {
-                    const int m = P.part_logn[slot0 + p];
-                    for (int k = t; k < m; k += nt) {
-                        lg_sc[at + k] = P.part_log_sc[(int64_t)(slot0 + p) * kPartLogCap + k];
-                        lg_ix[at + k] = P.part_log_ix[(int64_t)(slot0 + p) * kPartLogCap + k];
+            MergeHeap H;   // (lane 0's; the logs pass through LDS part after part, in part order = enumeration order)
+            H.hs = h_sc; H.hx = h_ix; H.n = 0; H.E = E; H.st = w_st;
+            for (int p = 0; p < nparts; p++) {
+                const int m = P.part_logn[slot0 + p];
+                for (int k = t; k < m; k += nt) {
+                    lg_sc[k] = P.part_log_sc[(int64_t)(slot0 + p) * kPartLogCap + k];
+                    lg_ix[k] = P.part_log_ix[(int64_t)(slot0 + p) * kPartLogCap + k];
+                }
+                wave_sync();
+                if (t == 0)
+                    for (int k = 0; k < m; k++) {
+                        const double sk = lg_sc[k];
+                        if (H.n == kTopK && sk < H.hs[0]) continue;   // strictly below the root of a full heap: the push leaves the array as it is
+                        H.push(sk, lg_ix[k]);
                     }
-                    at += m;
-                }
+                wave_sync();
             }
-            wave_sync();
-            if (t == 0) {
-                MergeHeap H;
-                H.hs = h_sc; H.hx = h_ix; H.n = 0; H.E = E; H.st = w_st;
-                for (int k = 0; k < total_log; k++) {
-                    const double sk = lg_sc[k];
-                    if (H.n == kTopK && sk < H.hs[0]) continue;   // strictly below the root of a full heap: the push leaves the array as it is
-                    H.push(sk, lg_ix[k]);
-                }
-                H.sort_desc();
-                h_n = H.n;
-            }
+            if (t == 0) { H.sort_desc(); h_n = H.n; }
             wave_sync();
             const int nout = h_n;
             const int64_t g = U.in_off + i;
@@ -1882,7 +1881,7 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
         // or straddling it is reported)
         bool undecided = false;
         for (int a = t; a < C; a += nt) {
-            if (!ok[a]) { rk[a] = (uint8_t)kCandMax; continue; }
+            if (!ok[a]) { rk[a] = (uint16_t)kCandMax; continue; }
             int r = 0;
             bool tie_here = false;
             for (int b = 0; b < C; b++) {
@@ -1895,7 +1894,7 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
                 if (o > 0) r++;
                 if (o == 0) tie_here = true;
             }
-            rk[a] = (uint8_t)r;
+            rk[a] = (uint16_t)r;
             if (tie_here && r <= kTopK) undecided = true;
         }
         int total = 0;
