@@ -200,13 +200,13 @@ def test_lane_threaded_emulation(emu_lib):
         "import sys, os\n"
         "sys.path[:0] = [%r, %r, %r]\n"
         "import parity\n"
-        "units, _ = parity.stress_units([(6, 200, 'single', 10, 1), (4, 200, 'par2', 6, 1), (11, 130, 'single', 1.2, 1), (18, 10, 'mix7', 3, 1000)])\n"
+        "units, _ = parity.stress_units([(6, 90, 'single', 10, 1), (4, 90, 'par2', 6, 1), (11, 130, 'single', 1.2, 1), (18, 10, 'mix7', 3, 1000)])\n"
         "r1, r2, _ = parity.check_units(%r, units)\n"
         "assert sum(r['repaired_windows'] for r in r1) > 0\n"
         "print('lanes ok')\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
          os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"), emu_lib)
-    env = dict(os.environ, TW_EMU_LANES="1", TW_TILE="128", TW_COOP_THREADS="256")
+    env = dict(os.environ, TW_EMU_LANES="1", TW_TILE="128", TW_COOP_THREADS="256", TW_TILE_SUB="2")   # (two workgroups per tile: the sub-tile launch with a quarter of the host threads of the default eight)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "lanes ok" in out.stdout, out.stderr[-2000:]
 
@@ -225,12 +225,12 @@ def test_lane_threaded_tile_kernel_with_production_tables():
         "import sys, os\n"
         "sys.path[:0] = [%r, %r, %r]\n"
         "import parity\n"
-        "units, _ = parity.stress_units([(41, 200, 'par4', 3, 1), (42, 160, 'chain3', 3, 1), (43, 160, 'par2', 2, 1000), (45, 100, 'mix7', 1.5, 1)])\n"
+        "units, _ = parity.stress_units([(41, 140, 'par4', 3, 1), (42, 130, 'chain3', 3, 1), (43, 130, 'par2', 2, 1000), (45, 24, 'mix7', 1.5, 1)])\n"
         "r1, r2, _ = parity.check_units(%r, units, allow_budget=True)\n"
         "print('lanes ok')\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
          os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"), build(production=True))
-    env = dict(os.environ, TW_EMU_LANES="1", TW_TILE="128", TW_COOP_THREADS="256")
+    env = dict(os.environ, TW_EMU_LANES="1", TW_TILE="128", TW_COOP_THREADS="256", TW_TILE_SUB="2")   # (two workgroups per tile: the sub-tile launch with a quarter of the host threads of the default eight)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1800)
     assert out.returncode == 0 and "lanes ok" in out.stdout, out.stderr[-2000:]
 
