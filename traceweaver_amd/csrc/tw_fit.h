@@ -83,8 +83,8 @@ struct FitDev {
 // deterministic block reduction of `cnt` doubles per thread: lanes of a wavefront by shuffles (fixed
 // butterfly order), wavefronts by thread 0 in wavefront order.  Result broadcast to every thread.
 template <int cnt>
-__device__ inline void block_reduce(double (&vals)[cnt], double* sh) {
-    const int t = threadIdx.x, nt = blockDim.x;
+__device__ inline void block_reduce(double (&vals)[cnt], double* sh, int nt) {   // nt: threads of the workgroup that take part
+    const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6, nwave = (nt + 63) >> 6;
 #pragma unroll
     for (int c = 0; c < cnt; c++) {
@@ -357,11 +357,11 @@ __global__ void __launch_bounds__(kFitThreads) TW_FIT_SEED_ATTR k_fit_seed(FitDe
     // ---- mean and variance of the samples (exact sum: integers below 2^53)
     double mv[1] = {0.0};
     for (int r = t; r < uniq; r += nt) mv[0] += RUN_X(r) * RUN_C(r);
-    block_reduce<1>(mv, sh);
+    block_reduce<1>(mv, sh, nt);
     const double mean = mv[0] / dn;
     mv[0] = 0.0;
     for (int r = t; r < uniq; r += nt) { const double d = RUN_X(r) - mean; mv[0] += (d * d) * RUN_C(r); }
-    block_reduce<1>(mv, sh);
+    block_reduce<1>(mv, sh, nt);
     const double km_tol = mv[0] / dn * kKmTol;
 
     // ---- k-means++ seeding (sklearn.cluster._kmeans._kmeans_plusplus) on the centred samples in request order.
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(kFitThreads) TW_FIT_SEED_ATTR k_fit_seed(FitDe
 #pragma unroll
             for (int j = 0; j < kFitMaxTrials; j++) if (j < trials) { const double d = fit_dist(cv[j], xc); a[j] += cw * (d < v ? d : v); }
         }
-        block_reduce<kFitMaxTrials>(a, sh);
+        block_reduce<kFitMaxTrials>(a, sh, nt);
         double bp = a[0], bc = cv[0];   // np.argmin: the first minimum
         if (trials > 1 && a[1] < bp) { bp = a[1]; bc = cv[1]; }
         if (trials > 2 && a[2] < bp) { bp = a[2]; bc = cv[2]; }
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(kFitThreads) TW_FIT_SEED_ATTR k_fit_seed(FitDe
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) if (j == lab) { v[j] += cw; v[kMaxComp + j] += xc * cw; }
         }
-        block_reduce<2 * kMaxComp + 1>(v, sh);
+        block_reduce<2 * kMaxComp + 1>(v, sh, nt);
         bool any_empty = false;
 #pragma unroll
         for (int j = 0; j < kMaxComp; j++) if (j < k && v[j] == 0.0) any_empty = true;
@@ -624,12 +624,13 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
     const FitRow R = fit_row<kFull>(F, false);
     const int k = R.k, n = R.n, uniq = R.uniq;
     const int64_t q = R.q;
-    const int t = threadIdx.x, nt = blockDim.x;
+    const int t = threadIdx.x;
     double* model = kFull ? nullptr : F.models + (q * kMaxComp + (k - 1)) * kModelStride;
     if (!R.live) {
         if (!kFull && t == 0 && k >= 1 && k <= kMaxComp) model[0] = dinf();
         return;
     }
+    const int nt = blockDim.x;
     const double* xv = F.uval + R.row;      // distinct values, ascending
     const int32_t* xa = F.ustart + R.row;   // first index of each value in the sorted row
     const double dn = (double)n;
@@ -656,7 +657,7 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) if (j == lab) { v[j] += cw; v[kMaxComp + j] += cw * x; v[2 * kMaxComp + j] += cw * (x * x); }
         }
-        block_reduce<3 * kMaxComp>(v, sh);
+        block_reduce<3 * kMaxComp>(v, sh, nt);
 #pragma unroll
         for (int j = 0; j < kMaxComp; j++) {
             const double nk = v[j] + kEps10;
@@ -675,7 +676,7 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
 #pragma unroll
                 for (int j = 0; j < kMaxComp; j++) if (j == lab) { const double d = x - pm[j]; c2[j] += cw * (d * d); }
             }
-            block_reduce<kMaxComp>(c2, sh);
+            block_reduce<kMaxComp>(c2, sh, nt);
 #pragma unroll
             for (int j = 0; j < kMaxComp; j++) pv[j] = c2[j] / (v[j] + kEps10) + kFitRegCovar;
         }
@@ -691,20 +692,39 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
     bool last = false;
     for (int iter = 0; iter <= kFitMaxIter && !failed; iter++) {
         if (iter == kFitMaxIter) last = true;
-        double a0[kMaxComp], a1[kMaxComp], a2[kMaxComp], cst[kMaxComp], v[kFitStats];
+        double a0[kMaxComp], a1[kMaxComp], a2[kMaxComp], cst[kMaxComp], lwt[kMaxComp], v[kFitStats];
+        // The sweep's constants of component j (a reciprocal square root and two logarithms, ~300 dependent f64 instructions a
+        // component) used to be computed by every thread for every component: a fifth of a sweep over a long row and most of a sweep
+        // over a short one.  Lane j of every wavefront computes component j's and hands them to the other lanes by shuffle -- the
+        // same operations on the same operands, once.
+        if (nt >= 64) {
+            const int lane = t & 63;
+            double wj = pw[0], mj = pm[0], vj = pv[0];
 #pragma unroll
-        for (int j = 0; j < kMaxComp; j++) {
-            a0[j] = 0.0; a1[j] = 0.0; a2[j] = 0.0; cst[j] = 0.0;
-            if (j < k) {
-                const double pc = 1.0 / sqrt(pv[j]);   // _compute_precision_cholesky
-                if (kFull) { a0[j] = pm[j] * pc; a1[j] = pc; }
-                else { const double prec = pc * pc; a0[j] = (pm[j] * pm[j]) * prec; a1[j] = pm[j] * prec; a2[j] = prec; }
-                cst[j] = log(pc);
+            for (int j = 1; j < kMaxComp; j++) if (lane == j) { wj = pw[j]; mj = pm[j]; vj = pv[j]; }
+            double b0 = 0.0, b1 = 0.0, b2 = 0.0, bc = 0.0, bl = 0.0;
+            if (lane < k) {
+                const double pc = 1.0 / sqrt(vj);   // _compute_precision_cholesky
+                if (kFull) { b0 = mj * pc; b1 = pc; }
+                else { const double prec = pc * pc; b0 = (mj * mj) * prec; b1 = mj * prec; b2 = prec; }
+                bc = log(pc);
+                bl = log(wj);
+            }
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) { a0[j] = __shfl(b0, j); a1[j] = __shfl(b1, j); a2[j] = __shfl(b2, j); cst[j] = __shfl(bc, j); lwt[j] = __shfl(bl, j); }
+        } else {   // (workgroups of less than a wavefront: the host emulation of the tests)
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) {
+                a0[j] = 0.0; a1[j] = 0.0; a2[j] = 0.0; cst[j] = 0.0;
+                if (j < k) {
+                    const double pc = 1.0 / sqrt(pv[j]);   // _compute_precision_cholesky
+                    if (kFull) { a0[j] = pm[j] * pc; a1[j] = pc; }
+                    else { const double prec = pc * pc; a0[j] = (pm[j] * pm[j]) * prec; a1[j] = pm[j] * prec; a2[j] = prec; }
+                    cst[j] = log(pc);
+                }
+                lwt[j] = j < k ? log(pw[j]) : 0.0;
             }
         }
-        double lwt[kMaxComp];
-#pragma unroll
-        for (int j = 0; j < kMaxComp; j++) lwt[j] = j < k ? log(pw[j]) : 0.0;
 #pragma unroll
         for (int c = 0; c < kFitStats; c++) v[c] = 0.0;
         for (int r = t; r < uniq; r += nt) {
@@ -740,24 +760,51 @@ __global__ void __launch_bounds__(kFitThreads) k_fit_em(FitDev F) {
                 }
             }
         }
-        block_reduce<kFitStats>(v, sh);
+        block_reduce<kFitStats>(v, sh, nt);
         const double lb = v[3 * kMaxComp] / dn;
         if (last) { lower = lb; break; }
         double nks = 0.0;
+        if (nt >= 64) {   // the M step's three divisions a component: lane j of every wavefront for component j (see the sweep's constants)
+            const int lane = t & 63;
+            double s0 = v[0], s1 = v[kMaxComp], s2 = v[2 * kMaxComp], mj = pm[0];
 #pragma unroll
-        for (int j = 0; j < kMaxComp; j++) {
-            if (j < k) {
-                const double nk = v[j] + kEps10;
-                const double m1 = v[kMaxComp + j] / nk;
-                pw[j] = nk;
-                nks += nk;
-                pv[j] = (v[2 * kMaxComp + j] / nk - m1 * m1) + kFitRegCovar;
-                pm[j] = kFull ? pm[j] + m1 : m1;
-                if (!(pv[j] > 0.0)) failed = true;
+            for (int j = 1; j < kMaxComp; j++) if (lane == j) { s0 = v[j]; s1 = v[kMaxComp + j]; s2 = v[2 * kMaxComp + j]; mj = pm[j]; }
+            const double nk = s0 + kEps10;
+            const double m1 = s1 / nk;
+            const double nv = (s2 / nk - m1 * m1) + kFitRegCovar;
+            const double nm = kFull ? mj + m1 : m1;
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) {
+                if (j < k) {
+                    pw[j] = __shfl(nk, j);
+                    nks += pw[j];
+                    pv[j] = __shfl(nv, j);
+                    pm[j] = __shfl(nm, j);
+                    if (!(pv[j] > 0.0)) failed = true;
+                }
             }
-        }
+            double wq = pw[0];
 #pragma unroll
-        for (int j = 0; j < kMaxComp; j++) if (j < k) pw[j] /= nks;
+            for (int j = 1; j < kMaxComp; j++) if (lane == j) wq = pw[j];
+            wq /= nks;
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) if (j < k) pw[j] = __shfl(wq, j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) {
+                if (j < k) {
+                    const double nk = v[j] + kEps10;
+                    const double m1 = v[kMaxComp + j] / nk;
+                    pw[j] = nk;
+                    nks += nk;
+                    pv[j] = (v[2 * kMaxComp + j] / nk - m1 * m1) + kFitRegCovar;
+                    pm[j] = kFull ? pm[j] + m1 : m1;
+                    if (!(pv[j] > 0.0)) failed = true;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kMaxComp; j++) if (j < k) pw[j] /= nks;
+        }
         const double change = lb - lower;
         lower = lb;
         if (fabs(change) < kFitTol) last = true;   // converged: one more sweep scores the parameters just set
