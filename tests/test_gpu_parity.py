@@ -199,18 +199,22 @@ def test_nodejs_fileio_shape_with_the_refitted_mixtures():
 
 def test_alibaba_shape_1m_span_slice():
     """BASELINE config 4 size: a 1 M-span slice of Alibaba-shape call graphs (15 graphs, 39 services, E up to 8,
-    millisecond timestamps, zero network gap) in one batch.  Every third unit is compared with the oracle in
-    full; all units must satisfy the size-independent properties, and the device-side accuracy must agree with
-    the host's."""
+    millisecond timestamps, zero network gap) in one batch.  EVERY unit is compared with the oracle in full (windows,
+    tuple counts, top-5 lists and scores of both passes, selections, parents) -- with the production thresholds the long
+    spans of the deep services are cut by their listed prefixes into list parts (up to 51 000 tuples a span; twin candidates:
+    the parts' logs replayed by k_merge_parts), the short ones scored from their lists; all units must satisfy the
+    size-independent properties, and the device-side accuracy must agree with the host's."""
     from traceweaver_amd.engine import Engine
 
     units, truth, _ = synth.make_alibaba_workload(3, 1_000_000)
     assert 990_000 <= sum(u.n_spans for u in units) <= 1_010_000
-    parity.check_units(None, units[::3])
+    r1, _, _ = parity.check_units(None, units)
+    assert max(int(r["leaves"].max()) for r in r1) > 10_000         # (a span with tens of thousands of tuples is among them)
     eng = Engine(0)
     eng.load(units)
     eng.set_truth(truth)
     eng.run_pass1()
+    assert eng.worklists()["split_spans"] >= 20                      # spans cut into parts (deferred by their tuple count / prefix list)
     eng.fit_mixtures()
     eng.run_pass2()
     res = eng.results(2, fields=("parent", "unit_stats"))
