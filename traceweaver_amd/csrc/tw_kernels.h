@@ -987,9 +987,11 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                 int got = -1, at = 0;
                 if (t == 0 && np >= 2) {
                     const int old = atomicAdd(&P.part_used[E], np);   // (the span's own entry stays on the list: every part is an extra one)
-                    if (old + np <= (P.part_off[E + 1] - P.part_off[E]) / 2) {
+                    // (a full arena is not asked again: the counter stays below 2^31 however many spans of a very large batch would like
+                    // to defer -- what can be added beyond the cap is bounded by the lists resident at a time)
+                    if (old + np <= (P.part_off[E + 1] - P.part_off[E]) / 2 && atomicAdd(P.defer_used, 0) < P.defer_cap) {
                         at = atomicAdd(P.defer_used, n);
-                        if ((long long)at + n <= (long long)P.defer_cap) got = P.part_off[E] + 2 * old;
+                        if (at >= 0 && (long long)at + n <= (long long)P.defer_cap) got = P.part_off[E] + 2 * old;
                     }
                 }
                 defer_slot = __shfl(got, 0); defer_at = __shfl(at, 0); defer_np = np;
