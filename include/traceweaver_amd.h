@@ -240,7 +240,9 @@ int tw_get_gauss_params(tw_engine *e, double *gauss);
 /* Timing of the last pass, measured with HIP events on the engine's stream:
  * ms[0] whole pass, ms[1] candidate-enumeration kernel, ms[2] selection kernel,
  * ms[3] window construction, ms[4] claim/detect/repair kernels, ms[5] parameter kernels (sort + block
- * sums), ms[6] last tw_fit_mixtures call, ms[7] (a count, not a time) rounds of the span-consumption fixed point. */
+ * sums), ms[6] last tw_fit_mixtures call, ms[7] (a count, not a time) rounds of the span-consumption fixed point,
+ * ms[8] / ms[9] host wall clock the last pass spent submitting its first enumeration / in the whole call (a pass of a small
+ * batch is bound by that, not by the kernels). */
 int tw_get_timing(tw_engine *e, double *ms, int32_t n);
 
 /* ---- neighbours of the hot path on the same device arrays -------------------------------

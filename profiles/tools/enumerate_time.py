@@ -24,12 +24,15 @@ else:
 for lib in libs:
     eng = Engine(0, lib_path=None if lib == "default" else lib)
     eng.load(units)
-    e1, e2 = [], []
+    e1, e2, h1, h2, p1, p2 = [], [], [], [], [], []
     for _ in range(3):
         eng.run_pass1()
-        e1.append(eng.timing()["enumerate"])
+        t = eng.timing()
+        e1.append(t["enumerate"]); h1.append(t["host_enum_submit"]); p1.append((t["pass"], t["host_pass"]))
         eng.fit_mixtures()
         eng.run_pass2()
-        e2.append(eng.timing()["enumerate"])
-    print(wl, lib, "enumerate ms pass1 %.2f pass2 %.2f" % (min(e1), min(e2)))
+        t = eng.timing()
+        e2.append(t["enumerate"]); h2.append(t["host_enum_submit"]); p2.append((t["pass"], t["host_pass"]))
+    print(wl, lib, "enumerate ms pass1 %.2f pass2 %.2f; host submit of the enumeration %.2f / %.2f ms; pass (events, host wall) %s / %s" % (
+        min(e1), min(e2), min(h1), min(h2), "%.2f, %.2f" % min(p1), "%.2f, %.2f" % min(p2)))
     eng.close()

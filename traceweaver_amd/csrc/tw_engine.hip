@@ -2,6 +2,7 @@
 // kernels in tw_kernels.h.  One engine = one HIP device + one stream; inputs stay resident in HBM
 // between the two passes (spans are read from host memory exactly once, in tw_load_batch).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -156,6 +157,7 @@ struct tw_engine {
     bool scaled_upload = false;             // the batch was uploaded with unit_time_scale (already load-scaled by the caller)
     hipEvent_t ev[EV_COUNT] = {};
     double ms[6] = {0, 0, 0, 0, 0, 0};
+    double host_ms[2] = {0, 0};             // host wall clock of the last pass: submitting the first enumeration / the whole tw_run_pass call
 };
 
 namespace {
@@ -454,6 +456,7 @@ int sort_ends(tw_engine* e) {
 int run_pass(tw_engine* e, int pass) {
     const Dev& P = e->P;
     const dim3 tiles(P.n_tiles), tb(e->tile);
+    const auto host_t0 = std::chrono::steady_clock::now();
     HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
     HIPCHK(hipMemsetAsync(e->ctr, 0, sizeof(int32_t) * (size_t)e->ctr_pass_ints, e->stream));   // error flag, statistics, every work-list counter
 #ifdef TW_PROFILE
@@ -474,7 +477,9 @@ int run_pass(tw_engine* e, int pass) {
     }
     HIPCHK(hipEventRecord(e->ev[EV_PARAMS], e->stream));
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
+    const auto host_t1 = std::chrono::steady_clock::now();
     launch_enumerate_all(e, pass, 0);
+    e->host_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t1).count();
     HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
     if (pass == 1) {
         int rc = run_scan<ScanMaxEnd>(e, e->agg_pair);
@@ -541,6 +546,7 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventElapsedTime(&f, e->ev[EV_ENUM1], e->ev[EV_WIN])); e->ms[3] = f;
     HIPCHK(hipEventElapsedTime(&f, e->ev[EV_SEL], e->ev[EV_REPAIR])); e->ms[4] = f;
     HIPCHK(hipEventElapsedTime(&f, e->ev[EV_BEGIN], e->ev[EV_PARAMS])); e->ms[5] = f;
+    e->host_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (kerr != 0) return fail(e, kerr, kernel_error_text(kerr));
     return TW_OK;
 }
@@ -1434,6 +1440,8 @@ int tw_get_timing(tw_engine* e, double* ms, int32_t n) {
     for (int i = 0; i < n && i < 6; i++) ms[i] = e->ms[i];
     if (n > 6) ms[6] = e->fit_ms;
     if (n > 7) ms[7] = (double)e->rounds;
+    if (n > 8) ms[8] = e->host_ms[0];
+    if (n > 9) ms[9] = e->host_ms[1];
     return TW_OK;
 }
 

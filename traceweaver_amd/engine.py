@@ -469,7 +469,8 @@ class Engine(object):
         return float(g.value)
 
     def timing(self):
-        """ms of the last pass: total, enumerate kernel, select kernel, windows, claim+detect+repair, params."""
-        ms = np.zeros(8, dtype=np.float64)
-        self._check(self._lib.tw_get_timing(self._h, _vp(ms), 8))
-        return dict(zip(("pass", "enumerate", "select", "windows", "repair", "params", "fit", "rounds"), ms.tolist()))
+        """ms of the last pass: total, enumerate kernel, select kernel, windows, claim+detect+repair, params (HIP events); the last
+        refit; repair rounds; host wall clock of submitting the first enumeration and of the whole pass call."""
+        ms = np.zeros(10, dtype=np.float64)
+        self._check(self._lib.tw_get_timing(self._h, _vp(ms), 10))
+        return dict(zip(("pass", "enumerate", "select", "windows", "repair", "params", "fit", "rounds", "host_enum_submit", "host_pass"), ms.tolist()))

@@ -88,7 +88,7 @@ class Corpus(object):
         return self.counts()
 
     def add_directory(self, directory, **kw):
-        files = sorted(os.path.join(directory, f) for f in os.listdir(directory) if f.endswith("json"))
+        files = sorted(os.path.join(directory, f) for f in os.listdir(directory) if _is_trace_file(f))
         return self.add_files(files, **kw)
 
     def counts(self):
@@ -227,19 +227,32 @@ def _write_arrays(path, header, arrays):
 
 
 def _read_arrays(path):
+    """Header and arrays of a cache file.  Anything that is not a complete file of this version raises ValueError (or OSError):
+    the caller counts that as a miss."""
     import mmap
 
     with open(path, "rb") as f:
         m = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
-    if m[:8] != _CACHE_MAGIC:
+    if len(m) < 16 or m[:8] != _CACHE_MAGIC:
         raise ValueError("not a span table cache")
     n = int(np.frombuffer(m, dtype=np.uint64, count=1, offset=8)[0])
-    header = json.loads(m[16:16 + n].decode())
+    if 16 + n > len(m):
+        raise ValueError("span table cache: truncated header")
+    header = json.loads(m[16:16 + n].decode())   # (json.JSONDecodeError and UnicodeDecodeError are ValueErrors)
+    if not isinstance(header, dict) or not isinstance(header.get("arrays"), dict):
+        raise ValueError("span table cache: header of another version")
     base = 16 + n
     arrays = {}
-    for name, (dtype, shape, off) in header.pop("arrays").items():
+    for name, entry in header.pop("arrays").items():
+        try:
+            dtype, shape, off = entry
+            dtype, shape, off = np.dtype(dtype), tuple(int(x) for x in shape), int(off)
+        except (TypeError, ValueError) as exc:
+            raise ValueError("span table cache: malformed array entry %r" % (name,)) from exc
         count = int(np.prod(shape)) if shape else 1
-        arrays[name] = np.frombuffer(m, dtype=np.dtype(dtype), count=count, offset=base + off).reshape(shape)
+        if off < 0 or base + off + count * dtype.itemsize > len(m):
+            raise ValueError("span table cache: array %r reaches beyond the file" % (name,))
+        arrays[name] = np.frombuffer(m, dtype=dtype, count=count, offset=base + off).reshape(shape)
     return header, arrays
 
 
@@ -298,10 +311,16 @@ class CachedCorpus(object):
         return out, dict(self._skipped), int(self._n_traces)
 
 
-def _trace_count(directory):
-    """Number of trace files in the directory (what the loader would read)."""
+def _is_trace_file(name):
+    """What the loader reads from a directory (the reference's filter, executor.py:331): one predicate for the loader and the cache."""
+    return name.endswith("json")
+
+
+def _dir_state(directory):
+    """(modification time, number of trace files) of the directory: what must not move while it is being loaded."""
     with os.scandir(directory) as it:
-        return sum(1 for e in it if e.name.endswith(".json"))
+        n = sum(1 for e in it if _is_trace_file(e.name))
+    return os.stat(directory).st_mtime_ns, n
 
 
 def _cache_fresh(directory, path):
@@ -313,10 +332,12 @@ def _cache_fresh(directory, path):
     return os.stat(directory).st_mtime_ns == os.stat(path).st_mtime_ns
 
 
-def _save_cache(corpus, directory, key_args, counts, n_before):
+def _save_cache(corpus, directory, key_args, counts, state_before):
     """Writes the cache of a freshly loaded directory (to a temporary name, then renamed over the cache file) and stamps it with the
-    directory's modification time after the rename -- unless the number of trace files differs from `n_before`, the count taken
-    before the load: then a file arrived (or left) while the directory was being read, and the cache stays unstamped = stale."""
+    directory's modification time after the rename -- unless the directory's (modification time, number of trace files) just before
+    the cache file is written differs from `state_before`, taken before the load: then an entry arrived, left or was renamed while
+    the directory was being read (a rename keeps the count and moves the time), and the cache stays unstamped = stale."""
+    unchanged = _dir_state(directory) == state_before
     path = os.path.join(directory, CACHE_FILE)
     key = _cache_key(directory, *key_args)
     raw = corpus._unit_set_arrays()
@@ -338,7 +359,7 @@ def _save_cache(corpus, directory, key_args, counts, n_before):
     arrays.update({"t_" + k: table[k] for k in _TABLE_COLUMNS})
     _write_arrays(path, header, arrays)
     m = os.stat(directory).st_mtime_ns   # the directory's modification time after the rename: the file carries it as its own (_cache_fresh)
-    if _trace_count(directory) != n_before:
+    if not unchanged or _dir_state(directory)[1] != state_before[1]:
         m = 0
     os.utime(path, ns=(m, m))
 
@@ -360,15 +381,15 @@ def open_directory(directory, lib_path=None, first_span=None, max_traces=1001, f
             if meta.get("key") == _cache_key(directory, *key_args):
                 c = CachedCorpus(meta, z)
                 return c, c.counts()
-        except (OSError, ValueError, KeyError):   # unreadable / incomplete / written by another version: a miss
-            pass
-    n_before = _trace_count(directory) if cache else 0
+        except (OSError, ValueError, KeyError):   # unreadable / incomplete / written by another version (_read_arrays raises ValueError for
+            pass                                  # every malformed header; CachedCorpus KeyError for a missing array): a miss
+    state_before = _dir_state(directory) if cache else (0, 0)
     corpus = Corpus(lib_path=lib_path)
     counts = corpus.add_directory(directory, first_span=first_span, max_traces=max_traces, fix=fix, callers=callers, threads=threads)
     corpus.from_cache = False
     if cache:
         try:
-            _save_cache(corpus, directory, key_args, counts, n_before)
+            _save_cache(corpus, directory, key_args, counts, state_before)
         except OSError:   # read-only directory, disk full, ...: a problem with the cache FILE never fails the run (anything else is a bug and shows)
             pass
     return corpus, counts
