@@ -29,7 +29,7 @@ def build(force=False, production=False):
         "-DTW_LIST_SCORE_MAX=64",   # listed enumerations of up to 64 tuples are scored from the list, longer ones counted and walked: both occur
         "-DTW_PART_LOG_CAP=12",   # log-mode parts: a dozen entries, so that some logs overflow and the span is enumerated again as a whole
         "-DTW_FIT_HASH_SLOTS=512",   # refit: rows of more than 384 distinct gap values take the sort route, the others the hash table
-        "-DTW_PRUNE_MIN=48", "-DTW_PRUNE_GRID=8"]   # the wavefront kernel's walk is pruned from 48 grid points on   # the tile kernel: short slices (windows beyond them go to the wavefront kernel), several segments per tile   # the selection search consults the matching relaxation early
+        "-DTW_PRUNE_MIN=48", "-DTW_PRUNE_GRID=8", "-DTW_LEAN_GRID=40"]   # the wavefront kernel's walk is pruned from 48 grid points on   # the tile kernel: short slices (windows beyond them go to the wavefront kernel), several segments per tile   # the selection search consults the matching relaxation early
     subprocess.check_call(
         ["g++", "-x", "c++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
          # the emulated LDS arrays are static locals of kernel templates: as GNU-unique symbols the two builds of this library

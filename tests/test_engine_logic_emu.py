@@ -358,14 +358,3 @@ def test_requests_longer_than_32_bit_offsets(emu_lib, case):
     in_end[-1] += 3 * 10 ** 9
     tail = UnitArrays(u.in_start, in_end, u.out_off, u.out_start, u.out_end, u.dag, u.key_rank)
     parity.check_units(emu_lib, [scaled, tail, u])
-
-
-def test_sliced_enumeration_equals_the_unsliced(emu_lib, monkeypatch):
-    """A class with many tiles is enumerated in slices of its tiles, each slice with its own ranges of the class' work lists and
-    its own counters (tw_engine.hip launch_enumerate): forced here on small units (every class in three slices), held to the
-    oracle like any other run -- incl. the split enumerations, whose parts and merge records live in the slice's ranges."""
-    monkeypatch.setenv("TW_ENUM_SLICES", "3")
-    monkeypatch.setenv("TW_ENUM_SLICE_MIN_TILES", "1")
-    units, _ = parity.stress_units(parity.STRESS)
-    r1, r2, _ = parity.check_units(emu_lib, units)
-    assert sum(r["repaired_windows"] for r in r1) > 0

@@ -126,7 +126,7 @@ struct Dev {
     int32_t *tiny_unit, *tiny_win;
     int32_t *hard_unit, *hard_win;   // windows k_select_heavy gave up on, for k_select_dp (count and cursor: heavy_next[4], [5])
     int32_t* heavy_in_count;  // [2][kMaxEp+1] incoming spans deferred to k_enumerate_heavy per endpoint count E: narrow, wide windows
-    int32_t* heavy_in_next;   // [3][kMaxEp+1] next unclaimed entry of each list: narrow, wide, long enumerations (when launched on their own)
+    int32_t* heavy_in_next;   // [4][2][kMaxEp+1] work-list cursors of the wavefront kernels: per kind of launch (the class' lists, list parts, spans listed again, fallback), instantiation (narrow, wide) and class (enum_cursor)
     int32_t heavy_in_off[kMaxEp + 2];  // class offsets into heavy_in_unit / heavy_in_idx
     int32_t *heavy_in_unit, *heavy_in_idx;
     int32_t* heavy_big_count;   // [kMaxEp+1] narrow spans with a long enumeration: served first
@@ -150,6 +150,13 @@ struct Dev {
     int32_t* defer_count;      // [kMaxEp+1] list parts appended behind the class' listed entries
     int32_t *part_lo, *part_hi;   // [slot] a list part's stretch of defer_list
     int32_t* part_lvl;            // [slot] ... whose entries are prefixes of the endpoints 0 .. part_lvl
+    int32_t* redo_count;       // [kMaxEp+1] spans k_merge_parts lists again (their parts left the order of equal scores undecided): entries [0, redo_count) of the class' list of long enumerations
+    int32_t* defer_refused;    // [kMaxEp+1] spans that asked for list parts / parts and were refused (budget of extra entries or arena exhausted): enumerated by one wavefront
+    // what k_enumerate_lean leaves to k_enumerate_heavy (part = 4): entries in the format of the list of long enumerations, class offsets heavy_big_off
+    int32_t lean_min_e;        // classes from this many endpoints on are enumerated by k_enumerate_lean (TW_LEAN_MIN_E, default 5; 9 = none)
+    int32_t* fb_count;         // [kMaxEp+1] entries of the current launch chain (reset with the work lists of a repair round)
+    int32_t* fb_total;         // [kMaxEp+1] ... of the whole pass (tw_debug_worklists)
+    int32_t *fb_unit, *fb_idx, *fb_part, *fb_slot;
     int32_t* split_count;      // [kMaxEp+1] split spans per class
     int32_t *split_unit, *split_idx, *split_slot, *split_parts;   // [part_off region] one record per split span
     int32_t* part_n;           // [slot] entries | ambiguous << 8

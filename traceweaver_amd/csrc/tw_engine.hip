@@ -28,8 +28,6 @@ using namespace tw;
 namespace {
 
 constexpr int kMaxRepairRounds = 1 << 20;
-constexpr int kMaxSlices = 8;        // slices of a class' tiles (launch_enumerate)
-constexpr int kSliceCtrInts = 160;   // heavy_in_count, heavy_in_next, heavy_big_count, part_used, split_count: 32 ints each
 enum { ST_EMPTY = 0, ST_LOADED = 1, ST_PASS1 = 2, ST_MIX = 3, ST_PASS2 = 4 };
 enum { EV_BEGIN = 0, EV_PARAMS, EV_ENUM0, EV_ENUM1, EV_WIN, EV_SEL, EV_REPAIR, EV_END, EV_COUNT };
 
@@ -76,16 +74,6 @@ struct tw_engine {
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[kMaxEp + 1] = {};   // one stream per endpoint count: the enumeration kernels of different classes overlap
     hipEvent_t cls_ev[kMaxEp + 2] = {};        // [0] fork, [E] class E done
-    // A class with many tiles is enumerated in slices of its tiles (launch_enumerate): the wavefront kernels of slice s -- the
-    // class' long tail -- run on the class' second stream beside the tile kernel of slice s + 1 instead of alone after it
-    hipStream_t cls_stream2[kMaxEp + 1] = {};
-    hipEvent_t cls_ev2[kMaxEp + 1] = {};
-    hipEvent_t slice_ev[kMaxEp + 1][kMaxSlices] = {};
-    int enum_slices = 1, slice_min_tiles = 2048;   // TW_ENUM_SLICES, TW_ENUM_SLICE_MIN_TILES
-    int cls_slices[kMaxEp + 1] = {};
-    int32_t slice_tile0[kMaxEp + 1][kMaxSlices + 1] = {};   // first tile of the slice within the class
-    int32_t slice_in0[kMaxEp + 1][kMaxSlices + 1] = {}, slice_big0[kMaxEp + 1][kMaxSlices + 1] = {}, slice_part0[kMaxEp + 1][kMaxSlices + 1] = {};
-    int32_t* slice_ctr = nullptr;              // [kMaxSlices - 1][kSliceCtrInts] work-list counters of the slices beyond the first
     std::string err;
     int state = ST_EMPTY;
     int tile = kTile;   // incoming spans (threads) per workgroup of the per-span kernels
@@ -242,7 +230,6 @@ int run_scan(tw_engine* e, typename Tr::T* agg) {
 // (work per span spans four orders of magnitude): each class runs on a stream of its own, forked from and joined to the
 // engine's stream by events, so that the tails overlap.  The wide instantiation of a class owns the big-list pool slots
 // together with the narrow one (one counter): no conflict, they only ever add.
-// The view of slice s of class E: its own ranges of the class' work lists and (s > 0) its own counters.
 // Extra work-list entries of a class for the parts of its split enumerations.  Up to four endpoints few spans are split (an eighth of
 // the class + 64 was never short); in the deep call graphs most wavefront-enumerated spans are, and a budget that runs out leaves
 // whichever spans come last unsplit -- single wavefronts then hold the class' kernel for milliseconds (round 5: 3 of its 4 ms).
@@ -250,21 +237,6 @@ int64_t part_extra(int cls, int64_t n_cls) {
     if (n_cls <= 0) return 0;
     static const int deep = env_int("TW_PART_BUDGET_DEEP", 2);
     return (cls >= 5 && deep > 0 ? n_cls * deep : n_cls / 8) + 64;
-}
-
-template <int E>
-Dev slice_dev(const tw_engine* e, int s) {
-    Dev D = e->P;
-    if (e->cls_slices[E] <= 1) return D;
-    D.defer_min_e = kMaxEp + 1;   // (a sliced class cuts its long spans by the first endpoint's candidate: the deferred parts' counters are per class)
-    D.heavy_in_off[E] = e->slice_in0[E][s]; D.heavy_in_off[E + 1] = e->slice_in0[E][s + 1];
-    D.heavy_big_off[E] = e->slice_big0[E][s]; D.heavy_big_off[E + 1] = e->slice_big0[E][s + 1];
-    D.part_off[E] = e->slice_part0[E][s]; D.part_off[E + 1] = e->slice_part0[E][s + 1];
-    if (s > 0) {
-        int32_t* c = e->slice_ctr + (int64_t)(s - 1) * kSliceCtrInts;
-        D.heavy_in_count = c; D.heavy_in_next = c + 32; D.heavy_big_count = c + 64; D.part_used = c + 96; D.split_count = c + 128;
-    }
-    return D;
 }
 
 template <int E>
@@ -279,56 +251,42 @@ void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
     // the wavefront kernels of the class (or of one slice of it): the two lists of narrow spans in one launch, the long enumerations
     // (and the parts of the split ones) first; the parts of the split spans combined, the few whose order of equal scores is not
     // decided listed again (list emptied first) and enumerated whole; the wide windows
+    // (every launch of the chain has a work-list cursor of its own, enum_cursor: nothing is reset in between)
     auto wavefront_kernels = [&](hipStream_t q, const Dev& P) {
         const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
         const int grid = std::max(std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096), 1);  // persistent wavefronts pulling spans from the work list
-        hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, pool_bytes, q, P, pass, mode, 0, pool);
-        hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), hb, pool_bytes, q, P, pass, mode, 0, pool);
-        if (mode == 0 && E >= 3 && E >= P.defer_min_e) {   // the list parts of the spans the launches above deferred (kListSplitFlag)
-            (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), q);
-            hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, pool_bytes, q, P, pass, mode, 3, pool);
-            (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), q);
-            hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(std::min(grid, 1024)), hb, pool_bytes, q, P, pass, mode, 3, pool);
+        const int grid_w = std::min(grid, 1024);
+        const bool lean = E >= P.lean_min_e && !e->skip_mode;   // the deep call graphs: k_enumerate_lean, what it hands on to k_enumerate_heavy afterwards (part 4)
+        auto narrow = [&](int part, int g) {
+            if (lean) hipLaunchKernelGGL((k_enumerate_lean<kNarrow>), dim3(g), hb, pool_bytes, q, P, pass, mode, part, pool, E);
+            else hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(g), hb, pool_bytes, q, P, pass, mode, part, pool);
+        };
+        auto wide = [&](int part, int g) {
+            if (lean) hipLaunchKernelGGL((k_enumerate_lean<64 * kCandWords>), dim3(g), hb, pool_bytes, q, P, pass, mode, part, pool, E);
+            else hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(g), hb, pool_bytes, q, P, pass, mode, part, pool);
+        };
+        narrow(0, grid); wide(0, grid_w);
+        if (mode == 0 && E >= 3 && E >= P.defer_min_e) { narrow(3, grid); wide(3, grid_w); }   // the list parts of the spans the launches above deferred (kListSplitFlag)
+        if (lean) {   // what k_enumerate_lean handed on (whole spans and list parts alike), before the parts are combined
+            hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(256), hb, pool_bytes, q, P, pass, mode, 4, pool);
+            hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(64), hb, pool_bytes, q, P, pass, mode, 4, pool);
         }
-        if (mode == 0 && E > 1) {
-            (void)hipMemsetAsync(P.heavy_big_count + E, 0, sizeof(int32_t), q);
+        if (mode == 0 && E > 1) {   // the parts combined; the few spans listed again are enumerated whole (by k_enumerate_heavy in every class)
             hipLaunchKernelGGL(k_merge_parts, dim3(1024), dim3(std::min(e->coop, 64)), 0, q, P, pass, E);
-            (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), q);
             hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(256), hb, pool_bytes, q, P, pass, mode, 1, pool);
-            (void)hipMemsetAsync(P.heavy_in_next + 2 * (kMaxEp + 1) + E, 0, sizeof(int32_t), q);
             hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(64), hb, pool_bytes, q, P, pass, mode, 1, pool);
         }
     };
     const dim3 tile_block(e->tile >= 64 ? e->tile * e->tile_threads : e->tile);
-    const int S = mode == 0 ? e->cls_slices[E] : 1;
-    if (S <= 1) {
-        // mode 0: cut-offs and work lists, the tile kernel, the wavefront kernels (which take the spans the tile kernel hands over);
-        // mode 1: the spans k_detect_gone listed
-        if (mode == 0) {
-            // a class of few tiles: several workgroups per tile (k_enumerate_tile), until the class fills the CUs twice over
-            int sub = 1;
-            while (sub < e->tile_sub_max && nt * sub < 512 && (e->tile / (sub * 2)) * (sub * 2) == e->tile && e->tile / (sub * 2) >= 8) sub *= 2;
-            hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt * sub), tile_block, 0, st, e->P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt, sub);
-        }
-        wavefront_kernels(st, e->P);
-    } else {
-        // slices of the class' tiles: tile kernel s, then its wavefront kernels on the second stream while tile kernel s + 1 runs --
-        // the last slice's on the class stream.  (A class' wavefront kernels used to run alone on the GPU for a quarter of the
-        // launch set: the E = 4 class of the media shape, 1.1 of 4.5 ms at a third of the VALU.)
-        hipStream_t st2 = e->cls_stream2[E];
-        for (int sl = 0; sl < S; sl++) {
-            const Dev Ps = slice_dev<E>(e, sl);
-            const int t0 = e->slice_tile0[E][sl], cnt = e->slice_tile0[E][sl + 1] - t0;
-            if (cnt > 0) hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(cnt), tile_block, 0, st, Ps, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E] + t0), cnt, 1);
-            if (sl + 1 < S) {
-                (void)hipEventRecord(e->slice_ev[E][sl], st);
-                (void)hipStreamWaitEvent(st2, e->slice_ev[E][sl], 0);
-                wavefront_kernels(st2, Ps);
-            } else wavefront_kernels(st, Ps);
-        }
-        (void)hipEventRecord(e->cls_ev2[E], st2);
-        (void)hipStreamWaitEvent(e->stream, e->cls_ev2[E], 0);
+    // mode 0: cut-offs and work lists, the tile kernel, the wavefront kernels (which take the spans the tile kernel hands over);
+    // mode 1: the spans k_detect_gone listed
+    if (mode == 0) {
+        // a class of few tiles: several workgroups per tile (k_enumerate_tile), until the class fills the CUs twice over
+        int sub = 1;
+        while (sub < e->tile_sub_max && nt * sub < 512 && (e->tile / (sub * 2)) * (sub * 2) == e->tile && e->tile / (sub * 2) >= 8) sub *= 2;
+        hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt * sub), tile_block, 0, st, e->P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt, sub);
     }
+    wavefront_kernels(st, e->P);
     (void)hipEventRecord(e->cls_ev[E], st);
     used = true;
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[E], 0);
@@ -726,13 +684,6 @@ int tw_create(int device_id, tw_engine** out) {
     for (int i = 1; i <= kMaxEp && s == hipSuccess; i++) s = hipStreamCreate(&e->cls_stream[i]);
     for (int i = 0; i <= kMaxEp + 1 && s == hipSuccess; i++) s = hipEventCreateWithFlags(&e->cls_ev[i], hipEventDisableTiming);
     e->tile_sub_max = std::max(env_int("TW_TILE_SUB", 8), 1);   // workgroups per tile for classes of few tiles (1 = never)
-    e->enum_slices = std::min(std::max(env_int("TW_ENUM_SLICES", 1), 1), kMaxSlices);   // (measured: slower -- 4.5 ms per launch set unsliced, 4.7 / 4.9 / 6.2 ms in 2 / 4 / 8 slices; profiles/HISTORY.md)
-    e->slice_min_tiles = std::max(env_int("TW_ENUM_SLICE_MIN_TILES", 2048), 1);
-    for (int i = 1; i <= kMaxEp && s == hipSuccess && e->enum_slices > 1; i++) {
-        s = hipStreamCreate(&e->cls_stream2[i]);
-        if (s == hipSuccess) s = hipEventCreateWithFlags(&e->cls_ev2[i], hipEventDisableTiming);
-        for (int k = 0; k < kMaxSlices && s == hipSuccess; k++) s = hipEventCreateWithFlags(&e->slice_ev[i][k], hipEventDisableTiming);
-    }
     if (s != hipSuccess) {
         fprintf(stderr, "tw_create: %s\n", hipGetErrorString(s));
         delete e;
@@ -751,13 +702,8 @@ void tw_destroy(tw_engine* e) {
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     for (int i = 0; i <= kMaxEp + 1; i++)
         if (e->cls_ev[i]) (void)hipEventDestroy(e->cls_ev[i]);
-    for (int i = 1; i <= kMaxEp; i++) {
+    for (int i = 1; i <= kMaxEp; i++)
         if (e->cls_stream[i]) (void)hipStreamDestroy(e->cls_stream[i]);
-        if (e->cls_stream2[i]) (void)hipStreamDestroy(e->cls_stream2[i]);
-        if (e->cls_ev2[i]) (void)hipEventDestroy(e->cls_ev2[i]);
-        for (int k = 0; k < kMaxSlices; k++)
-            if (e->slice_ev[i][k]) (void)hipEventDestroy(e->slice_ev[i][k]);
-    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -915,6 +861,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     P.batch_mis = b->batch_size_mis;
     P.split_twins = env_int("TW_SPLIT_TWINS", 2);
     P.defer_min_e = env_int("TW_DEFER_MIN_E", 5);
+    P.lean_min_e = env_int("TW_LEAN_MIN_E", 5);
     int rc;
 #define ALLOC(ptr, count) do { rc = dev_alloc(e, &(ptr), (count)); if (rc != TW_OK) return rc; } while (0)
     e->arena_req.clear();
@@ -955,6 +902,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         P.heavy_big_off[kMaxEp + 1] = (int32_t)big_total; P.part_off[kMaxEp + 1] = (int32_t)slots;
         ALLOC(P.heavy_big_unit, big_total); ALLOC(P.heavy_big_idx, big_total);
         ALLOC(P.heavy_big_part, big_total); ALLOC(P.heavy_big_slot, big_total);
+        ALLOC(P.fb_unit, big_total); ALLOC(P.fb_idx, big_total); ALLOC(P.fb_part, big_total); ALLOC(P.fb_slot, big_total);
         ALLOC(P.split_unit, slots); ALLOC(P.split_idx, slots); ALLOC(P.split_slot, slots); ALLOC(P.split_parts, slots);
         ALLOC(P.part_n, slots); ALLOC(P.part_leaves, slots); ALLOC(P.part_score, slots * kTopK); ALLOC(P.part_idx, slots * kTopK * kMaxEp);
         ALLOC(P.part_bits, slots * kMaxEp * kCandWords);
@@ -967,38 +915,17 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         ALLOC(P.defer_list, P.defer_cap);
     }
     for (int cls = 0; cls <= kMaxEp + 1; cls++) P.heavy_in_off[cls] = heavy_off_h[cls];
-    for (int cls = 1; cls <= kMaxEp; cls++) {   // slices of the class' tiles with their shares of the class' work lists (launch_enumerate)
-        const int nt = e->tile_cls_off[cls + 1] - e->tile_cls_off[cls];
-        const int S = (e->enum_slices > 1 && nt >= e->slice_min_tiles && nt >= e->enum_slices && b->skip == nullptr) ? e->enum_slices : 1;
-        e->cls_slices[cls] = S;
-        if (S <= 1) continue;
-        const int64_t n_cls = heavy_off_h[cls + 1] - heavy_off_h[cls], extra = part_extra(cls, n_cls);
-        int64_t spans = 0;
-        for (int sl = 0; sl <= S; sl++) {
-            const int t0 = (int)((int64_t)nt * sl / S);
-            if (sl > 0)
-                for (int tix = e->slice_tile0[cls][sl - 1]; tix < t0; tix++) {
-                    const TileDev& T = e->tiles[(size_t)tile_ids_h[(size_t)(e->tile_cls_off[cls] + tix)]];
-                    spans += std::min<int64_t>(e->tile, e->units[(size_t)T.unit].n_in - T.first);
-                }
-            const int64_t ex = extra * spans / std::max<int64_t>(n_cls, 1);   // the slice's share of the extra entries of split spans
-            e->slice_tile0[cls][sl] = t0;
-            e->slice_in0[cls][sl] = (int32_t)(heavy_off_h[cls] + spans);
-            e->slice_big0[cls][sl] = (int32_t)(P.heavy_big_off[cls] + spans + ex);
-            e->slice_part0[cls][sl] = (int32_t)(P.part_off[cls] + 2 * ex);
-        }
-    }
     ALLOC(P.prof, 32); ALLOC(e->key_acc, 2);
     const int64_t sel_cap = (int64_t)P.n_tiles * e->tile + 1;   // every segment of the selection lists has room for all windows of its tiles
     {   // the counter block (every array on a 128-byte line of its own: their atomics come from different kernels)
         int64_t at = 0;
         auto take = [&](int64_t ints) { const int64_t o = at; at += (ints + 31) / 32 * 32; return o; };
-        const int64_t o_hc = take(4 * kSelSeg * kCtrStride), o_hn = take(kHardNext + 1), o_ic = take(2 * (kMaxEp + 1)), o_in = take(3 * (kMaxEp + 1)), o_bc = take(kMaxEp + 1),
-                      o_rc = take(1);
+        const int64_t o_hc = take(4 * kSelSeg * kCtrStride), o_hn = take(kHardNext + 1), o_ic = take(2 * (kMaxEp + 1)), o_in = take(8 * (kMaxEp + 1)), o_bc = take(kMaxEp + 1),
+                      o_rc = take(1), o_rd = take(kMaxEp + 1), o_fc = take(kMaxEp + 1);
         e->ctr_round_ints = at;
         const int64_t o_pu = take(kMaxEp + 1), o_sc = take(kMaxEp + 1), o_dc = take(kMaxEp + 1), o_du = take(1), o_err = take(1), o_nd = take(P.n_units), o_us = take((int64_t)P.n_units * 16);
+        const int64_t o_dr = take(kMaxEp + 1), o_ft = take(kMaxEp + 1);
         const int64_t o_fn = take(kFrontierSlots), o_fb = take(P.frontier_big_slots);   // flags of the tuple-list pools (given back by the kernels themselves)
-        const int64_t o_sl = take((int64_t)(kMaxSlices - 1) * kSliceCtrInts);   // work-list counters of the slices beyond the first (launch_enumerate)
         e->ctr_pass_ints = at;
         auto place = [=](void* q) {
             Dev& D = e->P;
@@ -1007,8 +934,8 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
             D.round_changed = c + o_rc; D.frontier_busy = c + o_fn; D.frontier_big_busy = c + o_fb;
             D.defer_count = c + o_dc; D.defer_used = c + o_du;
             D.part_used = c + o_pu; D.split_count = c + o_sc; D.err = c + o_err; D.unit_ndirty = c + o_nd;
+            D.redo_count = c + o_rd; D.fb_count = c + o_fc; D.defer_refused = c + o_dr; D.fb_total = c + o_ft;
             D.unit_stats = (int64_t*)(c + o_us);
-            e->slice_ctr = c + o_sl;
         };
         if (e->arena_open) e->arena_req.emplace_back(place, ((size_t)at * sizeof(int32_t) + 255) / 256 * 256);   // (placed by arena_commit, like the rest)
         else { ALLOC(e->ctr, at); place(e->ctr); }
@@ -1804,6 +1731,12 @@ int tw_debug_worklists(tw_engine* e, int32_t* out) {
     HIPCHK(hipMemcpy(split, e->P.split_count, sizeof(split), hipMemcpyDeviceToHost));
     out[2 + kMaxEp] = 0; out[3 + kMaxEp] = split[0];
     for (int k = 2; k <= kMaxEp; k++) out[2 + kMaxEp] += split[k];
+    // [12] items k_enumerate_lean handed to k_enumerate_heavy, [13] spans refused list parts / parts (budget or arena), [14] list parts
+    int32_t more[3][kMaxEp + 1];
+    HIPCHK(hipMemcpy(more[0], e->P.fb_total, sizeof(more[0]), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(more[1], e->P.defer_refused, sizeof(more[1]), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(more[2], e->P.defer_count, sizeof(more[2]), hipMemcpyDeviceToHost));
+    for (int q = 0; q < 3; q++) { out[4 + kMaxEp + q] = 0; for (int k = 0; k <= kMaxEp; k++) out[4 + kMaxEp + q] += more[q][k]; }
     return TW_OK;
 }
 

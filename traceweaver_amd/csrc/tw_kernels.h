@@ -456,7 +456,7 @@ __device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narro
         nparts = (int)(want > first_cands ? first_cands : want);
         if (nparts >= 2) {   // the class' budget of extra list entries (two scratch slots go with each)
             const int old = atomicAdd(&P.part_used[E], nparts - 1);
-            if (old + nparts - 1 > (P.part_off[E + 1] - P.part_off[E]) / 2) nparts = 1;
+            if (old + nparts - 1 > (P.part_off[E + 1] - P.part_off[E]) / 2) { atomicAdd(&P.part_used[E], -(nparts - 1)); atomicAdd(&P.defer_refused[E], 1); nparts = 1; }   // (refused: the share goes back, the refusal is counted)
             else slot_base = P.part_off[E] + 2 * old;
         } else nparts = 1;
     }
@@ -677,6 +677,13 @@ __device__ __forceinline__ void pool_release(int32_t* busy, int slot) {
     atomicExch(&busy[slot], 0);
 }
 
+// the work-list cursors of the wavefront kernels: one per (kind of launch, instantiation, class), all reset with the counter block of
+// the pass / the repair round -- no memset between the launches of a class' chain
+__device__ __forceinline__ int32_t* enum_cursor(const Dev& P, int part, bool wide, int E) {
+    const int kind = part == 0 || part == 2 ? 0 : (part == 3 ? 1 : (part == 1 ? 2 : 3));
+    return P.heavy_in_next + ((kind * 2 + (wide ? 1 : 0)) * (kMaxEp + 1) + E);
+}
+
 template <int E, int W>
 __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy(Dev P, int pass, int mode, int part, int pool) {
     // part: 0 = the class' lists, the long enumerations first (one launch serves both); 1 = only the long ones (the split spans
@@ -685,7 +692,6 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
     static_assert(W == kNarrow || W == 64 * kCandWords, "one instantiation per half of the work list");
     constexpr bool kWide = W != kNarrow;
     constexpr int kList = kWide ? kMaxEp + 1 + E : E;
-    constexpr int kNext = kWide ? kMaxEp + 1 + E : E;   // (part 1 has a counter of its own, see below)
     const int kPool = pool;
     __shared__ unsigned long long sbits[kMaxEp][kCandWords];
     __shared__ int64_t ls[E][W], le[E][W];      // staged candidates: start / end
@@ -702,10 +708,13 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
     __shared__ int32_t defer_lo[kMaxParts + 1]; // first listed prefix of every list part (deferred spans)
     const int t = threadIdx.x, nt = blockDim.x;
     // part 3: the list parts of the deferred spans (see kListSplitFlag), appended behind the class' listed entries by the launch before
+    // part 4: what k_enumerate_lean left to this kernel (P.fb_*: entries in the format of the list of long enumerations)
     const int defer_base = part == 3 ? P.heavy_big_count[E] : 0;
-    const int n_big = part == 2 ? 0 : (part == 3 ? P.defer_count[E] : P.heavy_big_count[E]);   // (both instantiations walk the list of long enumerations; each takes its own)
-    const int count = n_big + ((part == 1 || part == 3) ? 0 : P.heavy_in_count[kList]);
-    int32_t* next_counter = &P.heavy_in_next[(part == 1 || part == 3) ? 2 * (kMaxEp + 1) + E : kNext];
+    const int n_big = part == 2 ? 0 : (part == 3 ? P.defer_count[E] : (part == 1 ? P.redo_count[E] : (part == 4 ? P.fb_count[E] : P.heavy_big_count[E])));   // (both instantiations walk the list of long enumerations; each takes its own)
+    const int count = n_big + ((part == 0 || part == 2) ? P.heavy_in_count[kList] : 0);
+    int32_t* next_counter = enum_cursor(P, part, kWide, E);   // (a cursor per kind of launch: nothing to reset between the launches of a class)
+    const int32_t *big_unit = part == 4 ? P.fb_unit : P.heavy_big_unit, *big_idx = part == 4 ? P.fb_idx : P.heavy_big_idx;
+    const int32_t *big_part = part == 4 ? P.fb_part : P.heavy_big_part, *big_slot_of = part == 4 ? P.fb_slot : P.heavy_big_slot;
     const int nstatic = (int)gridDim.x * kWorkChunk;
     if ((int)blockIdx.x >= count) return;   // nothing for this wavefront (its strided static items start at its block index)
     int chunk_pos = 0, chunk_end = 0;
@@ -734,11 +743,11 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         // into a scalar load (SGPRs, constant cache) instead of 64 lanes loading the same address
         const bool from_big = item < n_big;
         const int pos = from_big ? P.heavy_big_off[E] + defer_base + item : (kWide ? P.heavy_in_off[E + 1] - 1 - (item - n_big) : P.heavy_in_off[E] + (item - n_big));
-        const int unit = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_unit : P.heavy_in_unit)[pos]);
-        const int i_raw = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_idx : P.heavy_in_idx)[pos]);
+        const int unit = __builtin_amdgcn_readfirstlane((from_big ? big_unit : P.heavy_in_unit)[pos]);
+        const int i_raw = __builtin_amdgcn_readfirstlane((from_big ? big_idx : P.heavy_in_idx)[pos]);
         const int i = i_raw & ~kIdxReplayFlag;
         // a part of a split enumeration?  (number of parts, which one, where its result goes)
-        const int part_info = from_big ? __builtin_amdgcn_readfirstlane(P.heavy_big_part[pos]) : 1;
+        const int part_info = from_big ? __builtin_amdgcn_readfirstlane(big_part[pos]) : 1;
         if (from_big && (((part_info >> 24) & 1) != 0) != kWide) continue;   // the other instantiation's
         const int nparts = part_info & 255, part_no = (part_info >> 8) & 0xffff;
         const bool part_log = nparts > 1 && (part_info & kPartLogFlag) != 0;   // log mode: this part replays CPython's heap and logs what entered it
@@ -746,7 +755,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         int nlog = 0;                                                         // (lane 0's count)
         const bool list_part = nparts > 1 && (part_info & kListSplitFlag) != 0;   // its tuples: a stretch of the span's listed prefixes (P.part_lo / part_hi)
         bool part_failed = false, deferred = false;
-        const int part_slot = from_big ? __builtin_amdgcn_readfirstlane(P.heavy_big_slot[pos]) : 0;
+        const int part_slot = from_big ? __builtin_amdgcn_readfirstlane(big_slot_of[pos]) : 0;
         const UnitDev& U = P.units[unit];
         TW_ITEM_BEGIN();
         const int64_t in_start = P.in_start[U.in_off + i], in_end = P.in_end[U.in_off + i];
@@ -993,6 +1002,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
                         at = atomicAdd(P.defer_used, n);
                         if (at >= 0 && (long long)at + n <= (long long)P.defer_cap) got = P.part_off[E] + 2 * old;
                     }
+                    if (got < 0) { atomicAdd(&P.part_used[E], -np); atomicAdd(&P.defer_refused[E], 1); }   // a refusal gives its share of the budget back (a smaller request may still fit) and is counted
                 }
                 defer_slot = __shfl(got, 0); defer_at = __shfl(at, 0); defer_np = np;
                 return defer_slot >= 0;
@@ -1814,7 +1824,7 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
             }
             if (redo) {
                 if (t == 0) {
-                    const int q = P.heavy_big_off[E] + atomicAdd(&P.heavy_big_count[E], 1);
+                    const int q = P.heavy_big_off[E] + atomicAdd(&P.redo_count[E], 1);
                     P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | wide_bit | kReplayFlag; P.heavy_big_slot[q] = 0;
                     atomicAdd(&P.split_count[0], 1);
                 }
@@ -1912,7 +1922,7 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
         const bool redo = redo_flag != 0;
         if (redo) {
             if (t == 0) {
-                const int q = P.heavy_big_off[E] + atomicAdd(&P.heavy_big_count[E], 1);
+                const int q = P.heavy_big_off[E] + atomicAdd(&P.redo_count[E], 1);
                 P.heavy_big_unit[q] = unit; P.heavy_big_idx[q] = i; P.heavy_big_part[q] = 1 | wide_bit | kReplayFlag; P.heavy_big_slot[q] = 0;
                 atomicAdd(&P.split_count[0], 1);   // (classes start at E = 2: entry 0 counts the spans listed again, for tw_debug_worklists)
             }
@@ -3595,3 +3605,4 @@ __global__ void k_gaps(Dev P) {
 }  // namespace tw
 
 #include "tw_tile.h"
+#include "tw_lean.h"

@@ -345,11 +345,13 @@ class Engine(object):
     def worklists(self):
         """Sizes of the device work lists of the last pass (debug aid, tw_debug_worklists): windows sent to the exact
         search, spans sent to the wavefront enumeration per endpoint count, spans whose enumeration was split into parts
-        and, of those, the ones enumerated once more as a whole (order of equal scores not decided by the parts)."""
+        and, of those, the ones enumerated once more as a whole (order of equal scores not decided by the parts); items the lean wavefront
+        kernel handed to k_enumerate_heavy, spans that were refused parts (budget of extra list entries / arena exhausted), list parts."""
         out = np.zeros(16, dtype=np.int32)
         self._lib.tw_debug_worklists.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self._check(self._lib.tw_debug_worklists(self._h, _vp(out)))
-        return {"select_windows": int(out[0]), "enumerate_spans": [int(x) for x in out[1:10]], "split_spans": int(out[10]), "split_redone": int(out[11])}
+        return {"select_windows": int(out[0]), "enumerate_spans": [int(x) for x in out[1:10]], "split_spans": int(out[10]), "split_redone": int(out[11]),
+                "handed_to_heavy": int(out[12]), "parts_refused": int(out[13]), "list_parts": int(out[14])}
 
     def set_truth(self, true_parent, in_trace=None, n_traces=0):
         """Ground truth of the loaded batch: per unit [E, n_in] index of the true outgoing span; optionally per
