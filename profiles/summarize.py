@@ -45,7 +45,8 @@ def group_of(name):
 
 def counter_per_group(path, counter):
     per, calls = collections.defaultdict(float), collections.defaultdict(int)
-    first_kernel_calls = collections.defaultdict(int)
+    if not os.path.exists(path):   # (a quick look without the FETCH / WRITE passes: the traffic columns stay zero)
+        return per, calls
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue

@@ -13,7 +13,7 @@ def build(force=False, production=False):
     """production=True: the thresholds of the HIP build (long enumerations from 768 tuples, split from 4096 grid points, tuple lists
     of 2^15 entries) instead of the tiny ones that make the small test units take every route."""
     out = OUT.replace("libtwgpu_emu.so", "libtwgpu_emu_prod.so") if production else OUT
-    deps = [os.path.join(SRC, f) for f in ("tw_engine.hip", "tw_kernels.h", "tw_tile.h", "tw_device.h", "tw_fit.h", "tw_eval.h", "tw_skip.h", "tw_load.h", "tw_baselines.h", "tw_ingest.cpp")]
+    deps = [os.path.join(SRC, f) for f in ("tw_engine.hip", "tw_kernels.h", "tw_tile.h", "tw_lean.h", "tw_device.h", "tw_fit.h", "tw_eval.h", "tw_skip.h", "tw_load.h", "tw_baselines.h", "tw_ingest.cpp")]
     deps += [os.path.join(REPO, "include", "traceweaver_amd.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
              os.path.join(HERE, "rocprim", "rocprim.hpp")]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libtwgpu.so")
-SOURCES = ["tw_engine.hip", "tw_kernels.h", "tw_tile.h", "tw_device.h", "tw_fit.h", "tw_eval.h", "tw_skip.h", "tw_load.h", "tw_baselines.h", "tw_ingest.cpp"]
+SOURCES = ["tw_engine.hip", "tw_kernels.h", "tw_tile.h", "tw_lean.h", "tw_device.h", "tw_fit.h", "tw_eval.h", "tw_skip.h", "tw_load.h", "tw_baselines.h", "tw_ingest.cpp"]
 
 # -ffp-contract=off: scores are chains of plain IEEE double operations in the reference's order;
 # an FMA would change the last bit and with it the resolution of exact ties (DESIGN.md "Scores").

@@ -154,6 +154,11 @@ struct Dev {
     int32_t* defer_refused;    // [kMaxEp+1] spans that asked for list parts / parts and were refused (budget of extra entries or arena exhausted): enumerated by one wavefront
     // what k_enumerate_lean leaves to k_enumerate_heavy (part = 4): entries in the format of the list of long enumerations, class offsets heavy_big_off
     int32_t lean_min_e;        // classes from this many endpoints on are enumerated by k_enumerate_lean (TW_LEAN_MIN_E, default 5; 9 = none)
+    int32_t lean_grid;         // ... which walks enumerations of up to this many grid points as a grid and lists the others (TW_LEAN_GRID)
+    // pair-term tables that do not fit the wavefront's (small) LDS pool: slots of kPairSpill doubles in global memory, claimed by the
+    // wavefronts that need one (pool_acquire), kept until the wavefront ends
+    double* pair_pool;
+    int32_t* pair_busy;
     int32_t* fb_count;         // [kMaxEp+1] entries of the current launch chain (reset with the work lists of a repair round)
     int32_t* fb_total;         // [kMaxEp+1] ... of the whole pass (tw_debug_worklists)
     int32_t *fb_unit, *fb_idx, *fb_part, *fb_slot;

@@ -111,6 +111,7 @@ struct tw_engine {
     int64_t fit_tape_cap = 0;
     bool fit_prepared = false;              // the gap rows of the resident pass-1 result are sorted and run-length compressed
     int tile_sub_max = 8;
+    int lean_pool = 512;                    // doubles of LDS for the pair tables of k_enumerate_lean (TW_LEAN_POOL)
     bool pass1_done = false;                // tw_run_pass1 has run on the resident batch (tw_run_pass2 reads its cut-offs, windows, tuple counts)
     std::vector<int32_t> fit_max_n;         // per slot min(5, #unique), 0 = nothing to fit (host copy, tw_fit_rows)
     bool fit_max_n_valid = false;           // ... of the rows that are prepared now (cleared with fit_prepared)
@@ -239,67 +240,93 @@ int64_t part_extra(int cls, int64_t n_cls) {
     return (cls >= 5 && deep > 0 ? n_cls * deep : n_cls / 8) + 64;
 }
 
+// `listed` (mode 1 only): the class' entries of heavy_in_count as the host read them with the round's change count -- a class, or an
+// instantiation, with nothing listed is not launched at all
 template <int E>
-void launch_enumerate(tw_engine* e, int pass, int mode, bool& used) {
+void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
     const int nt = e->tile_cls_off[E + 1] - e->tile_cls_off[E];
     if (nt == 0) return;
+    const int n_narrow = listed != nullptr ? listed[E] : -1, n_wide = listed != nullptr ? listed[kMaxEp + 1 + E] : -1;   // (-1: not known)
+    if (n_narrow == 0 && n_wide == 0) return;
     hipStream_t st = e->cls_stream[E];
     (void)hipStreamWaitEvent(st, e->cls_ev[0], 0);
+    const Dev& P = e->P;
     const dim3 hb(std::min(e->coop, kHeavyThreads));
-    const int pool = E > 4 ? 2048 : (E > 1 ? kPairPoolPerEp * E : 1);       // doubles of pair-term tables per wavefront
+    const int pool = E > 4 ? 2048 : (E > 1 ? kPairPoolPerEp * E : 1);       // doubles of pair-term tables per wavefront of k_enumerate_heavy
     const size_t pool_bytes = sizeof(double) * (size_t)pool;
-    // the wavefront kernels of the class (or of one slice of it): the two lists of narrow spans in one launch, the long enumerations
-    // (and the parts of the split ones) first; the parts of the split spans combined, the few whose order of equal scores is not
-    // decided listed again (list emptied first) and enumerated whole; the wide windows
-    // (every launch of the chain has a work-list cursor of its own, enum_cursor: nothing is reset in between)
-    auto wavefront_kernels = [&](hipStream_t q, const Dev& P) {
-        const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
-        const int grid = std::max(std::min((cap + kWorkChunk - 1) / kWorkChunk, 4096), 1);  // persistent wavefronts pulling spans from the work list
-        const int grid_w = std::min(grid, 1024);
-        const bool lean = E >= P.lean_min_e && !e->skip_mode;   // the deep call graphs: k_enumerate_lean, what it hands on to k_enumerate_heavy afterwards (part 4)
-        auto narrow = [&](int part, int g) {
-            if (lean) hipLaunchKernelGGL((k_enumerate_lean<kNarrow>), dim3(g), hb, pool_bytes, q, P, pass, mode, part, pool, E);
-            else hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(g), hb, pool_bytes, q, P, pass, mode, part, pool);
-        };
-        auto wide = [&](int part, int g) {
-            if (lean) hipLaunchKernelGGL((k_enumerate_lean<64 * kCandWords>), dim3(g), hb, pool_bytes, q, P, pass, mode, part, pool, E);
-            else hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(g), hb, pool_bytes, q, P, pass, mode, part, pool);
-        };
-        narrow(0, grid); wide(0, grid_w);
-        if (mode == 0 && E >= 3 && E >= P.defer_min_e) { narrow(3, grid); wide(3, grid_w); }   // the list parts of the spans the launches above deferred (kListSplitFlag)
-        if (lean) {   // what k_enumerate_lean handed on (whole spans and list parts alike), before the parts are combined
-            hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(256), hb, pool_bytes, q, P, pass, mode, 4, pool);
-            hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(64), hb, pool_bytes, q, P, pass, mode, 4, pool);
-        }
-        if (mode == 0 && E > 1) {   // the parts combined; the few spans listed again are enumerated whole (by k_enumerate_heavy in every class)
-            hipLaunchKernelGGL(k_merge_parts, dim3(1024), dim3(std::min(e->coop, 64)), 0, q, P, pass, E);
-            hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(256), hb, pool_bytes, q, P, pass, mode, 1, pool);
-            hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(64), hb, pool_bytes, q, P, pass, mode, 1, pool);
-        }
+    // (k_enumerate_lean: root / closing term tables + an LDS pool of pair tables for the common case, larger pair tables in global memory)
+    const size_t lean_bytes = sizeof(double) * (size_t)(2 * kMaxEp * kNarrow + e->lean_pool), lean_bytes_w = sizeof(double) * (size_t)(2 * kMaxEp * 64 * kCandWords + e->lean_pool);
+    const bool lean = E >= P.lean_min_e && !e->skip_mode;   // the deep call graphs: k_enumerate_lean; what it hands on to k_enumerate_heavy is launched by launch_enumerate_all
+    const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
+    auto grid_for = [&](int known, int most) { return std::max(std::min(((known >= 0 ? known : cap) + kWorkChunk - 1) / kWorkChunk, most), 1); };   // persistent wavefronts pulling spans from the work list
+    auto narrow = [&](int part, int g) {
+        if (lean) hipLaunchKernelGGL((k_enumerate_lean<kNarrow>), dim3(g), hb, lean_bytes, st, P, pass, mode, part, e->lean_pool, E);
+        else hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(g), hb, pool_bytes, st, P, pass, mode, part, pool);
     };
-    const dim3 tile_block(e->tile >= 64 ? e->tile * e->tile_threads : e->tile);
-    // mode 0: cut-offs and work lists, the tile kernel, the wavefront kernels (which take the spans the tile kernel hands over);
-    // mode 1: the spans k_detect_gone listed
+    auto wide = [&](int part, int g) {
+        if (lean) hipLaunchKernelGGL((k_enumerate_lean<64 * kCandWords>), dim3(g), hb, lean_bytes_w, st, P, pass, mode, part, e->lean_pool, E);
+        else hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(g), hb, pool_bytes, st, P, pass, mode, part, pool);
+    };
     if (mode == 0) {
-        // a class of few tiles: several workgroups per tile (k_enumerate_tile), until the class fills the CUs twice over
+        // cut-offs and work lists, the short enumerations: the tile kernel.  A class of few tiles: several workgroups per tile, until
+        // the class fills the CUs twice over
+        const dim3 tile_block(e->tile >= 64 ? e->tile * e->tile_threads : e->tile);
         int sub = 1;
         while (sub < e->tile_sub_max && nt * sub < 512 && (e->tile / (sub * 2)) * (sub * 2) == e->tile && e->tile / (sub * 2) >= 8) sub *= 2;
-        hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt * sub), tile_block, 0, st, e->P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt, sub);
+        hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt * sub), tile_block, 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt, sub);
     }
-    wavefront_kernels(st, e->P);
+    // the wavefront kernels of the class: the spans the tile kernel handed over (mode 1: the spans k_detect_gone listed), the long
+    // enumerations first; the list parts of the spans those launches deferred (kListSplitFlag); the parts combined, the few spans whose
+    // order of equal scores the parts left undecided enumerated whole.  Every launch of the chain has a work-list cursor of its own
+    // (enum_cursor): nothing is reset in between.
+    if (n_narrow != 0) narrow(0, grid_for(n_narrow, 4096));
+    if (n_wide != 0) wide(0, grid_for(n_wide, 1024));
+    if (mode == 0 && E >= 3 && E >= P.defer_min_e) { narrow(3, grid_for(-1, 4096)); wide(3, grid_for(-1, 1024)); }
+    if (mode == 0 && E > 1) {
+        hipLaunchKernelGGL(k_merge_parts, dim3(256), dim3(std::min(e->coop, 64)), 0, st, P, pass, E);   // (38 KB of LDS a workgroup: a thousand of them ask for all there is)
+        narrow(1, 256); wide(1, 64);
+    }
     (void)hipEventRecord(e->cls_ev[E], st);
-    used = true;
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[E], 0);
 }
 
-void launch_enumerate_all(tw_engine* e, int pass, int mode) {
-    bool used = false;
-    // (the frontier cursors were reset with the counter block of the pass / the repair round)
+// What k_enumerate_lean handed on (whole spans only: P.fb_*), class by class, by k_enumerate_heavy (part 4).  Rare at scale, and a launch
+// of that kernel -- 256 + 256 registers for eight endpoints: it needs a SIMD to itself -- waits for one even when its list is empty: the
+// host reads the counts (one small copy, the enumeration has to be complete anyway) and launches only what has entries.
+template <int E>
+void launch_fallback(tw_engine* e, int pass, int mode, const int32_t* fb) {
+    if (fb[E] <= 0) return;
+    hipStream_t st = e->cls_stream[E];
+    (void)hipStreamWaitEvent(st, e->cls_ev[0], 0);
+    const dim3 hb(std::min(e->coop, kHeavyThreads));
+    const int pool = E > 4 ? 2048 : (E > 1 ? kPairPoolPerEp * E : 1);
+    const int grid = std::max(std::min((fb[E] + kWorkChunk - 1) / kWorkChunk, 1024), 1);
+    hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, sizeof(double) * (size_t)pool, st, e->P, pass, mode, 4, pool);
+    hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(grid), hb, sizeof(double) * (size_t)pool, st, e->P, pass, mode, 4, pool);
+    (void)hipEventRecord(e->cls_ev[E], st);
+    (void)hipStreamWaitEvent(e->stream, e->cls_ev[E], 0);
+}
+
+int launch_enumerate_all(tw_engine* e, int pass, int mode, const int32_t* listed = nullptr) {
+    // (the work-list cursors were reset with the counter block of the pass / the repair round)
     (void)hipEventRecord(e->cls_ev[0], e->stream);
     // the classes with the most endpoints first: their enumerations are the longest and end the group (each class runs on a
     // stream of its own; what is launched first is dispatched first)
-    launch_enumerate<8>(e, pass, mode, used); launch_enumerate<7>(e, pass, mode, used); launch_enumerate<6>(e, pass, mode, used); launch_enumerate<5>(e, pass, mode, used);
-    launch_enumerate<4>(e, pass, mode, used); launch_enumerate<3>(e, pass, mode, used); launch_enumerate<2>(e, pass, mode, used); launch_enumerate<1>(e, pass, mode, used);
+    launch_enumerate<8>(e, pass, mode, listed); launch_enumerate<7>(e, pass, mode, listed); launch_enumerate<6>(e, pass, mode, listed); launch_enumerate<5>(e, pass, mode, listed);
+    launch_enumerate<4>(e, pass, mode, listed); launch_enumerate<3>(e, pass, mode, listed); launch_enumerate<2>(e, pass, mode, listed); launch_enumerate<1>(e, pass, mode, listed);
+    bool any_lean = false;
+    for (int E = std::max(e->P.lean_min_e, 1); E <= kMaxEp; E++) any_lean |= e->tile_cls_off[E + 1] > e->tile_cls_off[E];
+    if (!any_lean || e->skip_mode) return TW_OK;
+    int32_t fb[kMaxEp + 1] = {};
+    HIPCHK(hipMemcpyAsync(fb, e->P.fb_count, sizeof(fb), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    bool any = false;
+    for (int E = 1; E <= kMaxEp; E++) any |= fb[E] > 0;
+    if (!any) return TW_OK;
+    (void)hipEventRecord(e->cls_ev[0], e->stream);
+    launch_fallback<8>(e, pass, mode, fb); launch_fallback<7>(e, pass, mode, fb); launch_fallback<6>(e, pass, mode, fb); launch_fallback<5>(e, pass, mode, fb);
+    launch_fallback<4>(e, pass, mode, fb); launch_fallback<3>(e, pass, mode, fb); launch_fallback<2>(e, pass, mode, fb); launch_fallback<1>(e, pass, mode, fb);
+    return TW_OK;
 }
 
 // The listed windows: those of up to kBruteMax spans (nearly all of them) by k_select_tiny, whose workgroups hold 1 KB of LDS
@@ -436,7 +463,7 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventRecord(e->ev[EV_PARAMS], e->stream));
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
     const auto host_t1 = std::chrono::steady_clock::now();
-    launch_enumerate_all(e, pass, 0);
+    { int rc = launch_enumerate_all(e, pass, 0); if (rc != TW_OK) return rc; }
     e->host_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t1).count();
     HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
     if (pass == 1) {
@@ -480,13 +507,14 @@ int run_pass(tw_engine* e, int pass) {
         hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P);
         HIPCHK(hipMemsetAsync(e->ctr, 0, sizeof(int32_t) * (size_t)e->ctr_round_ints, e->stream));   // work lists, round_changed, frontier cursors
         hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, e->stream, P, round);
-        int32_t changed = 0;
+        int32_t changed = 0, listed[2 * (kMaxEp + 1)] = {};
         HIPCHK(hipMemcpyAsync(&changed, P.round_changed, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(listed, P.heavy_in_count, sizeof(listed), hipMemcpyDeviceToHost, e->stream));   // (what k_detect_gone listed, per class and instantiation)
         HIPCHK(hipStreamSynchronize(e->stream));
         if (changed == 0) break;
         if (round >= kMaxRepairRounds) return fail(e, TW_ERR_DEVICE, "span consumption did not settle (more repair rounds than windows)");
         e->rounds = round + 1;
-        launch_enumerate_all(e, pass, 1);
+        { int rc = launch_enumerate_all(e, pass, 1, listed); if (rc != TW_OK) return rc; }
         launch_select_listed(e);
     }
     HIPCHK(hipEventRecord(e->ev[EV_REPAIR], e->stream));
@@ -684,6 +712,7 @@ int tw_create(int device_id, tw_engine** out) {
     for (int i = 1; i <= kMaxEp && s == hipSuccess; i++) s = hipStreamCreate(&e->cls_stream[i]);
     for (int i = 0; i <= kMaxEp + 1 && s == hipSuccess; i++) s = hipEventCreateWithFlags(&e->cls_ev[i], hipEventDisableTiming);
     e->tile_sub_max = std::max(env_int("TW_TILE_SUB", 8), 1);   // workgroups per tile for classes of few tiles (1 = never)
+    e->lean_pool = std::min(std::max(env_int("TW_LEAN_POOL", 512), 1), 4096);
     if (s != hipSuccess) {
         fprintf(stderr, "tw_create: %s\n", hipGetErrorString(s));
         delete e;
@@ -862,6 +891,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     P.split_twins = env_int("TW_SPLIT_TWINS", 2);
     P.defer_min_e = env_int("TW_DEFER_MIN_E", 5);
     P.lean_min_e = env_int("TW_LEAN_MIN_E", 5);
+    P.lean_grid = std::max(env_int("TW_LEAN_GRID", TW_LEAN_GRID), 1);
     int rc;
 #define ALLOC(ptr, count) do { rc = dev_alloc(e, &(ptr), (count)); if (rc != TW_OK) return rc; } while (0)
     e->arena_req.clear();
@@ -886,6 +916,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     // long tuple lists: a pool that grows with the batch (one list per 16 k incoming spans, 48 ... 512 of 32 MB each; recycled)
     P.frontier_big_slots = (int32_t)std::min<int64_t>(std::max<int64_t>(n_in_total / 16384, kFrontierBigSlots), std::max(kFrontierBigSlots, 512));
     ALLOC(P.frontier_big, (int64_t)P.frontier_big_slots * 2 * kFrontierBigCap);
+    ALLOC(P.pair_pool, (int64_t)kPairSlots * kPairSpill);
     ALLOC(P.owner, n_out_total);
     ALLOC(P.gaps, gaps);
     ALLOC(e->tile_ids, (int64_t)tile_ids_h.size());
@@ -925,7 +956,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         e->ctr_round_ints = at;
         const int64_t o_pu = take(kMaxEp + 1), o_sc = take(kMaxEp + 1), o_dc = take(kMaxEp + 1), o_du = take(1), o_err = take(1), o_nd = take(P.n_units), o_us = take((int64_t)P.n_units * 16);
         const int64_t o_dr = take(kMaxEp + 1), o_ft = take(kMaxEp + 1);
-        const int64_t o_fn = take(kFrontierSlots), o_fb = take(P.frontier_big_slots);   // flags of the tuple-list pools (given back by the kernels themselves)
+        const int64_t o_fn = take(kFrontierSlots), o_fb = take(P.frontier_big_slots), o_pb = take(kPairSlots);   // flags of the tuple-list pools (given back by the kernels themselves)
         e->ctr_pass_ints = at;
         auto place = [=](void* q) {
             Dev& D = e->P;
@@ -934,7 +965,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
             D.round_changed = c + o_rc; D.frontier_busy = c + o_fn; D.frontier_big_busy = c + o_fb;
             D.defer_count = c + o_dc; D.defer_used = c + o_du;
             D.part_used = c + o_pu; D.split_count = c + o_sc; D.err = c + o_err; D.unit_ndirty = c + o_nd;
-            D.redo_count = c + o_rd; D.fb_count = c + o_fc; D.defer_refused = c + o_dr; D.fb_total = c + o_ft;
+            D.redo_count = c + o_rd; D.fb_count = c + o_fc; D.defer_refused = c + o_dr; D.fb_total = c + o_ft; D.pair_busy = c + o_pb;
             D.unit_stats = (int64_t*)(c + o_us);
         };
         if (e->arena_open) e->arena_req.emplace_back(place, ((size_t)at * sizeof(int32_t) + 255) / 256 * 256);   // (placed by arena_commit, like the rest)

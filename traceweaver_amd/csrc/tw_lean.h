@@ -33,7 +33,6 @@ template <int W>
 struct LeanLds {
     unsigned long long sbits[kMaxEp][kCandWords];
     int64_t ls[kMaxEp][W], le[kMaxEp][W];          // staged candidates: start / end
-    double troot[kMaxEp][W], tclose[kMaxEp][W];
     uint8_t lr[kMaxEp][W];                         // position of the staged candidate in the cut-off window
     int32_t cn[kMaxEp], lo[kMaxEp], wd[kMaxEp];    // staged candidates, first span of the cut-off window, its width
     uint32_t pm[kMaxEp], magic[kMaxEp];            // predecessor masks; reciprocals of the counts (grid decoding)
@@ -45,12 +44,27 @@ struct LeanLds {
     int32_t defer_lo[kMaxParts + 1];               // first listed prefix of every list part (deferred spans)
 };
 
-// one addition of a tuple's score: kind (0 pair term of the primary in-edge p -> e, 1 root term of e, 2 closing term of e -- added by
-// the lanes whose last-ending span is at e), e, p, the count of e's staged candidates, offset of the pair table in the pool
+// one addition of a tuple's score: the term tabs[off + position at p * factor + position at e] -- kind 0 always (pair term of the primary
+// in-edge p -> e: factor = the count of e's staged candidates; root term of e: factor 0), kind 1 by the lanes whose last-ending span is
+// at e (closing term), kind 2 nothing (padding), kind 3 a pair term from the wavefront's slot of P.pair_pool (off within the slot)
+// The LDS pool of pair tables is what limits the wavefronts per CU (an eight-endpoint item with four candidates per endpoint needs
+// ~200 doubles, one with fourteen 2 000): the launch asks for a pool that holds the common case (TW_LEAN_POOL, 512 doubles: 11
+// wavefronts per CU instead of 6 with 2 048), tables beyond it go to a slot of kPairSpill doubles in global memory (L2-resident).
+constexpr int kPairSlots = 4096, kPairSpill = 2048;
 __device__ __forceinline__ uint32_t lean_op(int kind, int e, int p, int cn_e, int off) {
     return (uint32_t)kind | ((uint32_t)e << 2) | ((uint32_t)p << 5) | ((uint32_t)cn_e << 8) | ((uint32_t)off << 16);
 }
 __device__ __forceinline__ int lean_pos(unsigned long long pk, int e) { return (int)((pk >> (8 * e)) & 255ull); }
+// the value lane j holds (j wave-uniform), in scalar registers: v_readlane instead of a shuffle through the LDS crossbar
+#ifdef TW_HOST_EMULATION
+__device__ __forceinline__ unsigned long long lane_value(unsigned long long v, int j) { return __shfl(v, j); }
+#else
+__device__ __forceinline__ unsigned long long lane_value(unsigned long long v, int j) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, j), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), j);
+    return ((unsigned long long)hi << 32) | lo;
+}
+#endif
+__device__ __forceinline__ double lane_value(double v, int j) { return __longlong_as_double((long long)lane_value((unsigned long long)__double_as_longlong(v), j)); }
 
 // CPython's heapq / list.sort on (score, tuple) entries in LDS (lane 0): LdsHeap of k_enumerate_heavy with packed tuples and a
 // run-time endpoint count.  Python's order on equal scores: start_mus of the first differing span.
@@ -130,10 +144,13 @@ struct LeanHeap {
     }
 };
 
+// Enumerations of up to P.lean_grid grid points (TW_LEAN_GRID) are walked as a grid, no list: a batch of 64 grid points costs about what
+// a batch of 64 listed tuples costs plus the call-order tests, and with call-order constraints a few per cent of the grid are tuples --
+// listing visits only the feasible prefixes (measured on the Alibaba-shape slice: items of 100-200 tuples in grids of 4 096 points
+// took 300 us as grids).
 #ifndef TW_LEAN_GRID
-#define TW_LEAN_GRID 4096
+#define TW_LEAN_GRID 256
 #endif
-constexpr long long kLeanGrid = TW_LEAN_GRID;   // enumerations of up to this many grid points are walked as a grid (no list)
 #ifdef TW_HOST_EMULATION
 #define TW_LEAN_ATTR
 #else
@@ -148,7 +165,12 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
     constexpr bool kWide = W != kNarrow;
     const int kList = kWide ? kMaxEp + 1 + E : E;
     __shared__ LeanLds<W> L;
-    HIP_DYNAMIC_SHARED(double, tpair)
+    // every term table in ONE array of dynamic LDS, so that a word of the scoring program addresses its term by an index (a pointer
+    // that may point at one of several LDS arrays or at global memory is a generic pointer: flat loads, a wait on both counters per term):
+    // [0, kMaxEp W) root terms by (endpoint, staged position), [kMaxEp W, 2 kMaxEp W) closing terms, from kTabPairs on `pool` doubles of
+    // pair tables
+    HIP_DYNAMIC_SHARED(double, tabs)
+    constexpr int kTabClose = kMaxEp * W, kTabPairs = 2 * kMaxEp * W;
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63;
     const int defer_base = part == 3 ? P.heavy_big_count[E] : 0;
     const int n_big = part == 3 ? P.defer_count[E] : (part == 1 ? P.redo_count[E] : P.heavy_big_count[E]);
@@ -158,6 +180,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
     if ((int)blockIdx.x >= count) return;
     int chunk_pos = 0, chunk_end = 0;
     int front_slot = -1;   // this wavefront's pair of tuple-list buffers: -1 not claimed yet, -2 none left
+    int pair_slot = -1;    // ... slot of P.pair_pool (pair tables beyond the LDS pool)
     bool first_chunk = true;
     TW_PROF_DECL();
     while (true) {
@@ -197,7 +220,11 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
                 P.fb_slot[q] = part_slot;
             }
         };
-        if (U.skip || (nparts > 1 && !list_part)) { fallback(); continue; }   // skip mode; parts cut by the first endpoint's candidate
+        if (nparts > 1 && !list_part) {   // a part cut by the first endpoint's candidate (the tile kernel does not cut that way in this kernel's classes):
+            if (t == 0) { P.part_n[part_slot] = 256; P.part_leaves[part_slot] = 0; if (part_log) P.part_logn[part_slot] = 0; }   // reported as failed, the span is listed again
+            continue;
+        }
+        if (U.skip) { fallback(); continue; }   // (skip-mode batches are not launched here at all)
         TW_ITEM_BEGIN();
         const int64_t in_start = P.in_start[U.in_off + i], in_end = P.in_end[U.in_off + i];
         Scorer S;
@@ -275,55 +302,73 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
                 int es = 0, r = q >> 1;
                 for (int e = 0; e < E; e++) { if (r < L.cn[e]) { es = e; break; } r -= L.cn[e]; }
                 const int64_t st = L.ls[es][r], e2 = L.le[es][r];
-                if (q & 1) L.tclose[es][r] = score_term(S, slot_close(E, es), e2, in_end);
-                else L.troot[es][r] = ((roots >> es) & 1u) ? score_term(S, slot_root(E, es), in_start, st) : 0.0;
+                if (q & 1) tabs[kTabClose + es * W + r] = score_term(S, slot_close(E, es), e2, in_end);
+                else tabs[es * W + r] = ((roots >> es) & 1u) ? score_term(S, slot_root(E, es), in_start, st) : 0.0;
             }
             // ---- pair tables of the primary in-edges and the scoring program, in scoring order
-            int used = 0, n_ops = 0;
+            int used = 0, gused = 0, n_ops = 0;
             bool tables = true;
+            double* gpair = pair_slot >= 0 ? P.pair_pool + (size_t)pair_slot * kPairSpill : nullptr;
             for (int e = 0; e < E; e++) {
                 const int np = U.npred[e], ce = L.cn[e];
                 for (int j = 0; j < np; j++) {
                     if (!U.pred_prim[e][j]) continue;
                     const int p = U.pred_list[e][j];
                     const int need = L.cn[p] * ce;
-                    if (used + need > pool || used + need > 0xffff) { tables = false; continue; }
+                    const bool in_lds = used + need <= pool && used + need <= 0xffff;
+                    if (!in_lds) {   // beyond the LDS pool: the wavefront's slot of the global pool (claimed at the first such table)
+                        if (pair_slot == -1) {
+                            if (t == 0) pair_slot = pool_acquire(P.pair_busy, kPairSlots, (unsigned)blockIdx.x * 48271u + (unsigned)(E * 2 + (kWide ? 1 : 0)) * 7919u + (unsigned)part * 104729u + 11u);
+                            pair_slot = __shfl(pair_slot, 0);
+                            if (pair_slot < 0) pair_slot = -2;
+                            gpair = pair_slot >= 0 ? P.pair_pool + (size_t)pair_slot * kPairSpill : nullptr;
+                        }
+                        if (gpair == nullptr || gused + need > kPairSpill) { tables = false; continue; }
+                    }
                     for (int q = t; q < need; q += nt) {
                         const int a = q / ce, b2 = q % ce;
                         const int64_t pend = L.le[p][a], st = L.ls[e][b2];
-                        if (pend <= st) tpair[used + q] = score_term(S, slot_prim(E, p, e), pend, st);   // other pairs never occur in a tuple
+                        if (pend <= st) {   // other pairs never occur in a tuple
+                            const double v = score_term(S, slot_prim(E, p, e), pend, st);
+                            if (in_lds) tabs[kTabPairs + used + q] = v; else gpair[gused + q] = v;
+                        }
                     }
-                    if (t == 0) L.ops[n_ops] = lean_op(0, e, p, ce, used);
+                    if (t == 0) L.ops[n_ops] = in_lds ? lean_op(0, e, p, ce, kTabPairs + used) : lean_op(3, e, p, ce, gused);
                     n_ops++;
-                    used += need;
+                    if (in_lds) used += need; else gused += need;
                 }
-                if (np == 0) { if (t == 0) L.ops[n_ops] = lean_op(1, e, 0, ce, 0); n_ops++; }
-                if (t == 0) L.ops[n_ops] = lean_op(2, e, 0, ce, 0);
+                if (np == 0) { if (t == 0) L.ops[n_ops] = lean_op(0, e, e, 0, e * W); n_ops++; }   // (the root term: a table of one row)
+                if (t == 0) L.ops[n_ops] = lean_op(1, e, e, 0, kTabClose + e * W);
                 n_ops++;
             }
+            for (int k = n_ops; k < ((n_ops + 3) & ~3); k++) if (t == 0) L.ops[k] = lean_op(2, 0, 0, 0, 0);   // (the program is run four words at a time)
+            n_ops = (n_ops + 3) & ~3;
             if (t == 0) L.n_ops = n_ops;
+            if (gused > 0) __threadfence_block();   // (tables in global memory: written by all lanes, read by all lanes)
             wave_sync();
             TW_PHASE(1);
             // ---- which route
             const bool can_defer = E >= 3 && E >= P.defer_min_e && part == 0 && mode == 0 && nparts == 1 && any_order != 0 && (!replay_first || P.split_twins == 2);
-            const bool as_grid = !list_part && grid <= kLeanGrid;
+            const bool as_grid = !list_part && (grid <= P.lean_grid || (any_order == 0 && grid <= 4096));   // (without call-order constraints every grid point is a tuple)
             bool list_all = false;    // pass 2 knows the tuple count of pass 1: few tuples are listed whole and scored
             if (!list_part && !as_grid && pass == 2 && mode == 0) list_all = P.leaves0[U.in_off + i] <= (can_defer ? kDeferTuples : kListScoreMax);
             // not for this kernel: a pair table beyond the pool; a long enumeration without call-order constraints (every grid point a tuple:
             // the pruned walk counts in closed form) or one of pass 2 known to hold more tuples than a list is scored from (pruned walk)
             if (!tables || (!list_part && !as_grid && any_order == 0) ||
-                (!list_part && !as_grid && pass == 2 && mode == 0 && !can_defer && !list_all)) { fallback(); fell_back = true; }
+                (!list_part && !as_grid && pass == 2 && mode == 0 && !can_defer && !list_all)) {
+                if (list_part) part_failed = true; else { fallback(); fell_back = true; }   // (a part never goes there: it reports failure and its span is listed again, whole)
+            }
             bool use_front = false;
             int n_front = 0;
             const unsigned long long* front = nullptr;
-            if (!fell_back && !as_grid) {
+            if (!fell_back && !part_failed && !as_grid) {
                 // ---- the feasible tuples as a list, level by level, depth-first order kept (k_enumerate_heavy, "tuple list")
                 if (front_slot == -1) {
                     if (t == 0) front_slot = pool_acquire(P.frontier_busy, kFrontierSlots, ((unsigned)blockIdx.x * 40503u + (unsigned)(E * 2 + (kWide ? 1 : 0)) * 7919u + (unsigned)part * 104729u + 3u));
                     front_slot = __shfl(front_slot, 0);
                     if (front_slot < 0) front_slot = -2;
                 }
-                if (front_slot < 0) { fallback(); fell_back = true; }   // (k_enumerate_heavy asks again, then walks / reports the part as failed)
+                if (front_slot < 0) { if (list_part) part_failed = true; else { fallback(); fell_back = true; } }   // (no buffer pair left: a part reports failure -- its span is listed again --, a span goes to k_enumerate_heavy)
                 else {
                     unsigned long long* fa = P.frontier + (size_t)front_slot * 2 * kFrontierCap;
                     const int cap = kFrontierCap;
@@ -494,7 +539,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
                         // too many tuples to score from a list of this wavefront (or a level outgrew its buffers): the pruned walk of
                         // k_enumerate_heavy; a list part without room is enumerated again with its span
                         use_front = false;
-                        fallback(); fell_back = true;
+                        if (list_part) part_failed = true; else { fallback(); fell_back = true; }
                     }
                     (void)minlo;
                 }
@@ -508,10 +553,104 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
             // ---- the tuples: a grid point or a listed tuple per lane; feasibility (grid), score by the program, top five
             const int Gtot = use_front ? n_front : ((deferred || part_failed) ? 0 : (int)grid);
             const int n_ops2 = L.n_ops;
+            const double* gpair2 = P.pair_pool + (size_t)(pair_slot >= 0 ? pair_slot : 0) * kPairSpill;
+            // What the batch loop needs per endpoint and is the same for every lane, in (scalar) registers -- a rolled loop that reads it
+            // from LDS pays a round trip per endpoint and batch (measured: 6.7 us a batch, one wavefront in three waiting on LDS at any
+            // time); the loops over endpoints below are unrolled to kMaxEp with a uniform guard.  The program: word k in lane k of one
+            // register (LaneArr), fetched by v_readlane.
+            static_assert(kMaxEp == 8, "the endpoint loops of the batch body are unrolled to eight");
+            int cnS[kMaxEp];
+            uint32_t pmS[kMaxEp], magicS[kMaxEp];
+#pragma unroll
+            for (int e = 0; e < kMaxEp; e++) {
+                cnS[e] = e < E ? __builtin_amdgcn_readfirstlane(L.cn[e]) : 1;
+                pmS[e] = e < E ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(L.pm[e] & ((1u << e) - 1u))) : 0u;
+                magicS[e] = e < E ? (uint32_t)__builtin_amdgcn_readfirstlane((int)L.magic[e]) : 0u;
+            }
+            LaneArr<uint32_t> prog;
+            prog.load(n_ops2, [&](int q) { return L.ops[q]; });
+            // candidate spans that occur in a feasible tuple (pass 1): every lane collects its own by staged position in registers
+            // (narrow windows: 32 positions an endpoint), OR-ed over the wavefront once per item
+            uint32_t seen[kMaxEp];
+#pragma unroll
+            for (int e = 0; e < kMaxEp; e++) seen[e] = 0u;
+            const bool mark = pass == 1 && mode == 0;
+            // the value one word of the program adds
+            auto fetch = [&](uint32_t op, unsigned long long pk) -> double {
+                const int at = (int)(op >> 16) + lean_pos(pk, (int)((op >> 5) & 7u)) * (int)((op >> 8) & 255u) + lean_pos(pk, (int)((op >> 2) & 7u));
+                if ((op & 3u) == 3u) return gpair2[at];   // (uniform)
+                return tabs[at];
+            };
+            // CPython's heap of the replay (traceweaver_v3.py:304-307: heappush, beyond five entries heappop) in registers, the same
+            // values in every lane, every lane computing alike: the six slots are named, the sift paths of a heap this small are
+            // written out (push at slot n: parents (n - 1) >> 1; pop of a six-entry heap: the last entry sifts up from the root
+            // through the smaller children, then down again -- heapq._siftup / _siftdown).  (A heap in LDS worked by lane 0 cost
+            // ~2.5 us a push, some fifty dependent LDS operations; on millisecond-granular traces -- twin candidates everywhere --
+            // that was half of an item.)
+            double hS[kTopK + 1];
+            unsigned long long hX[kTopK + 1];
+            int hN = 0;
+#pragma unroll
+            for (int k = 0; k <= kTopK; k++) { hS[k] = 0.0; hX[k] = 0ull; }
+            static_assert(kTopK == 5, "the sift paths of heap_push are written for a heap of five (+ 1)");
+            auto heap_lt = [&](double sa, unsigned long long xa, double sb, unsigned long long xb) -> bool {   // Python's (score, [spans]) <
+                if (sa != sb) return sa < sb;
+                if (xa == xb) return false;
+                for (int e = 0; e < E; e++) {
+                    const int a = lean_pos(xa, e), b = lean_pos(xb, e);
+                    if (a != b) return L.ls[e][a] < L.ls[e][b];
+                }
+                return false;
+            };
+            auto heap_push = [&](double s, unsigned long long x) {
+                if (hN < kTopK) {   // heappush only: the new entry at slot hN sifts towards the root
+                    if (hN == 0) { hS[0] = s; hX[0] = x; }
+                    else if (hN <= 2) {
+                        const bool up = heap_lt(s, x, hS[0], hX[0]);
+                        const double ds = up ? hS[0] : s; const unsigned long long dx = up ? hX[0] : x;
+                        if (hN == 1) { hS[1] = ds; hX[1] = dx; } else { hS[2] = ds; hX[2] = dx; }
+                        if (up) { hS[0] = s; hX[0] = x; }
+                    } else {   // slot 3 or 4: parent 1, then 0
+                        const bool up1 = heap_lt(s, x, hS[1], hX[1]);
+                        const double ds = up1 ? hS[1] : s; const unsigned long long dx = up1 ? hX[1] : x;
+                        if (hN == 3) { hS[3] = ds; hX[3] = dx; } else { hS[4] = ds; hX[4] = dx; }
+                        if (up1) {
+                            const bool up0 = heap_lt(s, x, hS[0], hX[0]);
+                            if (up0) { hS[1] = hS[0]; hX[1] = hX[0]; hS[0] = s; hX[0] = x; } else { hS[1] = s; hX[1] = x; }
+                        }
+                    }
+                    hN++;
+                    return;
+                }
+                // heappush at slot 5 (parents 2, 0) ...
+                double ls5 = s; unsigned long long lx5 = x;   // slot 5 after the push = what heappop takes off the end
+                if (heap_lt(s, x, hS[2], hX[2])) {
+                    ls5 = hS[2]; lx5 = hX[2];
+                    if (heap_lt(s, x, hS[0], hX[0])) { hS[2] = hS[0]; hX[2] = hX[0]; hS[0] = s; hX[0] = x; } else { hS[2] = s; hX[2] = x; }
+                }
+                // ... heappop: the root leaves, the last entry sifts up from the root (five entries: slots 0 .. 4) through the smaller children
+                int pos;
+                if (!heap_lt(hS[1], hX[1], hS[2], hX[2])) { hS[0] = hS[2]; hX[0] = hX[2]; pos = 2; }
+                else {
+                    hS[0] = hS[1]; hX[0] = hX[1];
+                    if (!heap_lt(hS[3], hX[3], hS[4], hX[4])) { hS[1] = hS[4]; hX[1] = hX[4]; pos = 4; } else { hS[1] = hS[3]; hX[1] = hX[3]; pos = 3; }
+                }
+                // ... and down again from the leaf it reached (_siftdown(heap, 0, pos))
+                if (pos == 2) {
+                    if (heap_lt(ls5, lx5, hS[0], hX[0])) { hS[2] = hS[0]; hX[2] = hX[0]; hS[0] = ls5; hX[0] = lx5; } else { hS[2] = ls5; hX[2] = lx5; }
+                } else {
+                    const bool up1 = heap_lt(ls5, lx5, hS[1], hX[1]);
+                    const double ds = up1 ? hS[1] : ls5; const unsigned long long dx = up1 ? hX[1] : lx5;
+                    if (pos == 3) { hS[3] = ds; hX[3] = dx; } else { hS[4] = ds; hX[4] = dx; }
+                    if (up1) {
+                        if (heap_lt(ls5, lx5, hS[0], hX[0])) { hS[1] = hS[0]; hX[1] = hX[0]; hS[0] = ls5; hX[0] = lx5; } else { hS[1] = ls5; hX[1] = lx5; }
+                    }
+                }
+            };
             for (int attempt = (deferred || part_failed) ? 2 : (part_log || replay_first) ? 1 : 0; attempt < 2; attempt++) {
                 exact_replay = attempt == 1;
                 bool ambiguous = false;
-                hp.n = 0; nk = 0; leaves = 0;
+                hN = 0; nk = 0; leaves = 0;
 #pragma unroll
                 for (int k = 0; k < kTopK; k++) { ts[k] = -dinf(); tslot[k] = k; }
                 unsigned long long ent_next = use_front && t < Gtot ? front[t] : 0ull;   // listed tuples: one batch ahead of their use
@@ -519,46 +658,63 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
                     const int g = base + t;
                     bool ok = g < Gtot;
                     unsigned long long pk = 0ull;
+                    int64_t en8[kMaxEp];
                     if (use_front) {
                         pk = ent_next;
                         ent_next = g + nt < Gtot ? front[g + nt] : 0ull;
+#pragma unroll
+                        for (int e = 0; e < kMaxEp; e++) en8[e] = e < E ? L.le[e][lean_pos(pk, e)] : INT64_MIN;
                     } else {
                         uint32_t rest = ok ? (uint32_t)g : 0u;   // grid point -> staged positions, last endpoint fastest
-                        for (int e = E - 1; e >= 0; e--) {
-                            const uint32_t c = (uint32_t)L.cn[e];
-                            const uint32_t q = c == 1 ? rest : __umulhi(rest, L.magic[e]);
+#pragma unroll
+                        for (int e = kMaxEp - 1; e >= 0; e--) {
+                            if (e >= E) continue;
+                            const uint32_t c = (uint32_t)cnS[e];
+                            const uint32_t q = c == 1 ? rest : __umulhi(rest, magicS[e]);
                             pk |= (unsigned long long)(rest - q * c) << (8 * e);
                             rest = q;
                         }
-                        for (int e = 1; e < E && ok; e++) {   // call order: no predecessor's span ends after this one starts (traceweaver_v3.py:343-347)
-                            const uint32_t pme = L.pm[e] & ((1u << e) - 1u);
-                            if (pme == 0u) continue;
-                            const int64_t st = L.ls[e][lean_pos(pk, e)];
-                            for (uint32_t r2 = pme; r2 != 0u; r2 &= r2 - 1u) {
-                                const int p = __ffs((int)r2) - 1;
-                                if (L.le[p][lean_pos(pk, p)] > st) ok = false;
-                            }
+                        int64_t st8[kMaxEp];
+#pragma unroll
+                        for (int e = 0; e < kMaxEp; e++) {
+                            const int x = lean_pos(pk, e);
+                            st8[e] = e < E ? L.ls[e][x] : 0; en8[e] = e < E ? L.le[e][x] : INT64_MIN;
                         }
+                        // call order: no predecessor's span ends after this one starts (traceweaver_v3.py:343-347)
+#pragma unroll
+                        for (int e = 1; e < kMaxEp; e++)
+#pragma unroll
+                            for (int p = 0; p < e; p++)
+                                if ((pmS[e] >> p) & 1u) ok = ok && !(en8[p] > st8[e]);
                     }
                     // ScoreAssignmentAsPerInvocationGraph (traceweaver_v1.py:305-361) from the term tables, the additions in its order.
                     // (Every lane runs the program -- a lane without a tuple on positions that exist, its sum is not used -- so that the
-                    // words of the program are fetched once for the wavefront, uniformly.)
+                    // words of the program are uniform; the value of word k + 1 is on its way while word k is added.)
                     double score = 0.0;
                     {
                         int last = 0;
-                        int64_t last_end = L.le[0][lean_pos(pk, 0)];
-                        for (int e = 1; e < E; e++) { const int64_t en = L.le[e][lean_pos(pk, e)]; if (en > last_end) { last_end = en; last = e; } }
-                        for (int k = 0; k < n_ops2; k++) {
-                            const uint32_t op = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.ops[k]);
-                            const int kind = (int)(op & 3u), e = (int)((op >> 2) & 7u);
-                            const int xe = lean_pos(pk, e);
-                            if (kind == 0) score += tpair[(int)(op >> 16) + lean_pos(pk, (int)((op >> 5) & 7u)) * (int)((op >> 8) & 255u) + xe];
-                            else if (kind == 1) score += L.troot[e][xe];
-                            else if (e == last) score += L.tclose[e][xe];
+                        int64_t last_end = en8[0];
+#pragma unroll
+                        for (int e = 1; e < kMaxEp; e++) if (e < E && en8[e] > last_end) { last_end = en8[e]; last = e; }
+                        for (int k = 0; k < n_ops2; k += 4) {   // four words at a time: their terms are read together, then added in order
+                            uint32_t op[4];
+                            double v[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) { op[q] = prog.get(k + q); v[q] = fetch(op[q], pk); }
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const uint32_t kind = op[q] & 3u;
+                                const bool add = kind == 0u || kind == 3u || (kind == 1u && (int)((op[q] >> 2) & 7u) == last);
+                                const double s2 = score + v[q];
+                                score = add ? s2 : score;
+                            }
                         }
                     }
-                    if (ok) {
-                        if (pass == 1 && mode == 0) {
+                    if (ok && mark) {
+                        if constexpr (!kWide) {
+#pragma unroll
+                            for (int e = 0; e < kMaxEp; e++) if (e < E) seen[e] |= 1u << lean_pos(pk, e);
+                        } else {
                             for (int e = 0; e < E; e++) {
                                 const int r = L.lr[e][lean_pos(pk, e)];
                                 const unsigned long long bit = 1ull << (r & 63);
@@ -570,25 +726,19 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
                     leaves += __popcll(feasible);
                     if (exact_replay) {
                         // (a tuple strictly below the root of a full heap of five is a no-op: see k_enumerate_heavy)
-                        const int nh = __shfl(hp.n, 0);
-                        const double hmin = nh == kTopK ? L.hs[0] : -dinf();
-                        unsigned long long todo = __ballot(ok && !(score < hmin));
-                        while (todo) {   // in enumeration order, CPython's heappush / heappop replayed by lane 0
+                        unsigned long long todo = __ballot(ok && !(hN == kTopK && score < hS[0]));
+                        while (todo) {   // in enumeration order, CPython's heappush / heappop replayed by every lane alike (see heap_push)
                             const int j = __ffsll((long long)todo) - 1;
                             todo &= todo - 1;
-                            const double sj = __shfl(score, j);
-                            const unsigned long long pj = __shfl(pk, j);
-                            if (t == 0) {
-                                hp.push(sj, pj);
-                                if (part_log) {   // (its score was not below the root's when it came: it may enter the heap of the whole enumeration)
-                                    if (nlog < kPartLogCap) {
-                                        unsigned long long wpos = 0ull;   // positions in the cut-off windows: the same in every part
-                                        for (int e = 0; e < E; e++) wpos |= (unsigned long long)L.lr[e][lean_pos(pj, e)] << (8 * e);
-                                        P.part_log_sc[(int64_t)part_slot * kPartLogCap + nlog] = sj;
-                                        P.part_log_ix[(int64_t)part_slot * kPartLogCap + nlog] = wpos;
-                                    }
-                                    nlog++;
+                            const double sj = lane_value(score, j);
+                            const unsigned long long pj = lane_value(pk, j);
+                            heap_push(sj, pj);
+                            if (part_log) {   // (its score was not below the root's when it came: it may enter the heap of the whole enumeration)
+                                if (t == 0 && nlog < kPartLogCap) {   // (staged positions for now: turned into window positions when the item is done)
+                                    P.part_log_sc[(int64_t)part_slot * kPartLogCap + nlog] = sj;
+                                    P.part_log_ix[(int64_t)part_slot * kPartLogCap + nlog] = pj;
                                 }
+                                nlog++;
                             }
                         }
                     } else {
@@ -693,11 +843,41 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
                     wave_sync();
                 }
             }
+            if (part_log && nlog > 0) {   // the log's tuples as positions in the cut-off windows (the same in every part), an entry per lane
+                __threadfence_block();
+                wave_sync();
+                const int m = nlog < kPartLogCap ? nlog : kPartLogCap;
+                for (int k = t; k < m; k += nt) {
+                    const unsigned long long pj = P.part_log_ix[(int64_t)part_slot * kPartLogCap + k];
+                    unsigned long long wpos = 0ull;
+                    for (int e = 0; e < E; e++) wpos |= (unsigned long long)L.lr[e][lean_pos(pj, e)] << (8 * e);
+                    P.part_log_ix[(int64_t)part_slot * kPartLogCap + k] = wpos;
+                }
+            }
+            if constexpr (!kWide) {
+                if (mark) {   // staged positions seen by any lane -> positions in the cut-off windows
+#pragma unroll
+                    for (int e = 0; e < kMaxEp; e++) {
+                        if (e >= E) continue;
+                        uint32_t m = seen[e];
+                        for (int off = 32; off >= 1; off >>= 1) m |= __shfl_xor(m, off);
+                        for (int c = t; c < cnS[e]; c += nt)
+                            if ((m >> c) & 1u) { const int r = L.lr[e][c]; atomicOr(&L.sbits[e][r >> 6], 1ull << (r & 63)); }
+                    }
+                }
+            }
             wave_sync();
             TW_PHASE(3);
-            if (t == 0 && exact_replay) hp.sort_desc();
+            if (exact_replay) {   // the heap as CPython's list, sorted like the reference's final list.sort(reverse=True) (lane 0, in LDS)
+                if (t == 0) {
+#pragma unroll
+                    for (int k = 0; k < kTopK; k++) { L.hs[k] = hS[k]; L.hx[k] = hX[k]; }
+                    hp.n = hN;
+                    hp.sort_desc();
+                }
+            }
             wave_sync();
-            nout = exact_replay ? __shfl(hp.n, 0) : nk;
+            nout = exact_replay ? hN : nk;
             if (!exact_replay) {   // the kept five into the heap arrays (the result stores below read those)
                 if (t == 0) {
 #pragma unroll
@@ -750,6 +930,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
         TW_ITEM_END(leaves);
     }
     if (front_slot >= 0 && t == 0) pool_release(P.frontier_busy, front_slot);
+    if (pair_slot >= 0 && t == 0) pool_release(P.pair_busy, pair_slot);
 }
 
 }  // namespace tw

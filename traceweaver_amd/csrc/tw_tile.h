@@ -261,6 +261,7 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
             // replay CPython's heap on their shares and log what entered it (log mode, see heavy_append)
             if (twins && P.split_twins == 0) first_cands = 0;
             twins_any = twins;
+            if (E >= P.lean_min_e) first_cands = 0;   // (k_enumerate_lean's classes are never cut by the first endpoint's candidate)
             // a class that defers its long spans cuts them by their listed prefixes once their tuples are counted (kListSplitFlag)
             if (E >= 3 && E >= P.defer_min_e) {
                 uint32_t any_order = 0;
