@@ -36,6 +36,11 @@ VARIANTS = {
     "log256": ["-DTW_PART_LOG_CAP=256"],
     "log512": ["-DTW_PART_LOG_CAP=512"],
     "hw_e6": ["-DTW_HEAVY_WAVES(E)=((E)<=6?2:1)"],
+    "proftile6": ["-DTW_PROFILE_TILE", "-DTW_PROFILE_TILE_E=6"],
+    "proftile8": ["-DTW_PROFILE_TILE", "-DTW_PROFILE_TILE_E=8"],
+    "lean3": ["-DTW_LEAN_ATTR=__attribute__((amdgpu_waves_per_eu(3,3)))"],   # round 6: k_enumerate_lean held to 168 / 128 registers
+    "lean4": ["-DTW_LEAN_ATTR=__attribute__((amdgpu_waves_per_eu(4,4)))"],
+    "lean2": ["-DTW_LEAN_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"],
 }
 
 

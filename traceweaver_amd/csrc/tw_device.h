@@ -150,10 +150,13 @@ struct Dev {
     int32_t* defer_count;      // [kMaxEp+1] list parts appended behind the class' listed entries
     int32_t *part_lo, *part_hi;   // [slot] a list part's stretch of defer_list
     int32_t* part_lvl;            // [slot] ... whose entries are prefixes of the endpoints 0 .. part_lvl
+    int32_t* any_wide;         // [kMaxEp+1] 1 <=> the class listed a span with wide windows in the first enumeration of this pass (the same spans in pass 2: the host
+                               // launches the wide instantiations of pass 2 only for such classes)
     int32_t* redo_count;       // [kMaxEp+1] spans k_merge_parts lists again (their parts left the order of equal scores undecided): entries [0, redo_count) of the class' list of long enumerations
     int32_t* defer_refused;    // [kMaxEp+1] spans that asked for list parts / parts and were refused (budget of extra entries or arena exhausted): enumerated by one wavefront
     // what k_enumerate_lean leaves to k_enumerate_heavy (part = 4): entries in the format of the list of long enumerations, class offsets heavy_big_off
     int32_t lean_min_e;        // classes from this many endpoints on are enumerated by k_enumerate_lean (TW_LEAN_MIN_E, default 5; 9 = none)
+    int32_t tile_max_deep;     // ... and take over from the tile kernel from this many tuples on (TW_TILE_MAX_DEEP <= kTileMax)
     int32_t lean_grid;         // ... which walks enumerations of up to this many grid points as a grid and lists the others (TW_LEAN_GRID)
     // pair-term tables that do not fit the wavefront's (small) LDS pool: slots of kPairSpill doubles in global memory, claimed by the
     // wavefronts that need one (pool_acquire), kept until the wavefront ends

@@ -111,6 +111,7 @@ struct tw_engine {
     int64_t fit_tape_cap = 0;
     bool fit_prepared = false;              // the gap rows of the resident pass-1 result are sorted and run-length compressed
     int tile_sub_max = 8;
+    int8_t wide_pass1[kMaxEp + 1] = {};     // per class: -1 not known, 0 / 1 = the first enumeration of pass 1 listed no / some span with wide windows
     int lean_pool = 512;                    // doubles of LDS for the pair tables of k_enumerate_lean (TW_LEAN_POOL)
     bool pass1_done = false;                // tw_run_pass1 has run on the resident batch (tw_run_pass2 reads its cut-offs, windows, tuple counts)
     std::vector<int32_t> fit_max_n;         // per slot min(5, #unique), 0 = nothing to fit (host copy, tw_fit_rows)
@@ -241,12 +242,17 @@ int64_t part_extra(int cls, int64_t n_cls) {
 }
 
 // `listed` (mode 1 only): the class' entries of heavy_in_count as the host read them with the round's change count -- a class, or an
-// instantiation, with nothing listed is not launched at all
+// instantiation, with nothing listed is not launched at all.
+// The whole chain of a class on the class' stream: tile kernel, wavefront kernels (k_enumerate_heavy<E>; from lean_min_e endpoints on
+// k_enumerate_lean), k_merge_parts.  (k_enumerate_lean and k_merge_parts can serve several classes in one launch; measured on the
+// Alibaba-shape slice, one launch per phase for the four deep classes: 2.5 ms per pass instead of 1.9 -- the phases of different classes
+// no longer overlap, and every phase ends with its longest item.)
 template <int E>
 void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
     const int nt = e->tile_cls_off[E + 1] - e->tile_cls_off[E];
     if (nt == 0) return;
-    const int n_narrow = listed != nullptr ? listed[E] : -1, n_wide = listed != nullptr ? listed[kMaxEp + 1 + E] : -1;   // (-1: not known)
+    // (-1: not known.  The first enumeration of pass 2 lists the spans pass 1 listed: a class without wide windows then has none now)
+    const int n_narrow = listed != nullptr ? listed[E] : -1, n_wide = listed != nullptr ? listed[kMaxEp + 1 + E] : ((pass == 2 && mode == 0 && e->wide_pass1[E] == 0) ? 0 : -1);
     if (n_narrow == 0 && n_wide == 0) return;
     hipStream_t st = e->cls_stream[E];
     (void)hipStreamWaitEvent(st, e->cls_ev[0], 0);
@@ -260,11 +266,11 @@ void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
     const int cap = P.heavy_in_off[E + 1] - P.heavy_in_off[E];
     auto grid_for = [&](int known, int most) { return std::max(std::min(((known >= 0 ? known : cap) + kWorkChunk - 1) / kWorkChunk, most), 1); };   // persistent wavefronts pulling spans from the work list
     auto narrow = [&](int part, int g) {
-        if (lean) hipLaunchKernelGGL((k_enumerate_lean<kNarrow>), dim3(g), hb, lean_bytes, st, P, pass, mode, part, e->lean_pool, E);
+        if (lean) hipLaunchKernelGGL((k_enumerate_lean<kNarrow>), dim3(g), hb, lean_bytes, st, P, pass, mode, part, e->lean_pool, E, E);
         else hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(g), hb, pool_bytes, st, P, pass, mode, part, pool);
     };
     auto wide = [&](int part, int g) {
-        if (lean) hipLaunchKernelGGL((k_enumerate_lean<64 * kCandWords>), dim3(g), hb, lean_bytes_w, st, P, pass, mode, part, e->lean_pool, E);
+        if (lean) hipLaunchKernelGGL((k_enumerate_lean<64 * kCandWords>), dim3(g), hb, lean_bytes_w, st, P, pass, mode, part, e->lean_pool, E, E);
         else hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(g), hb, pool_bytes, st, P, pass, mode, part, pool);
     };
     if (mode == 0) {
@@ -273,7 +279,10 @@ void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
         const dim3 tile_block(e->tile >= 64 ? e->tile * e->tile_threads : e->tile);
         int sub = 1;
         while (sub < e->tile_sub_max && nt * sub < 512 && (e->tile / (sub * 2)) * (sub * 2) == e->tile && e->tile / (sub * 2) >= 8) sub *= 2;
-        hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt * sub), tile_block, 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt, sub);
+        if (e->tile == kTile && e->tile / sub == kSubTileSpans)   // (the instantiation with tables for a sub-tile's 16 spans: a third of the LDS)
+            hipLaunchKernelGGL((k_enumerate_tile<E, kSubTileSpans>), dim3(nt * sub), tile_block, 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt, sub);
+        else
+            hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt * sub), tile_block, 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt, sub);
     }
     // the wavefront kernels of the class: the spans the tile kernel handed over (mode 1: the spans k_detect_gone listed), the long
     // enumerations first; the list parts of the spans those launches deferred (kListSplitFlag); the parts combined, the few spans whose
@@ -281,10 +290,10 @@ void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
     // (enum_cursor): nothing is reset in between.
     if (n_narrow != 0) narrow(0, grid_for(n_narrow, 4096));
     if (n_wide != 0) wide(0, grid_for(n_wide, 1024));
-    if (mode == 0 && E >= 3 && E >= P.defer_min_e) { narrow(3, grid_for(-1, 4096)); wide(3, grid_for(-1, 1024)); }
+    if (mode == 0 && E >= 3 && E >= P.defer_min_e) { narrow(3, grid_for(-1, 4096)); if (n_wide != 0) wide(3, grid_for(-1, 1024)); }
     if (mode == 0 && E > 1) {
-        hipLaunchKernelGGL(k_merge_parts, dim3(256), dim3(std::min(e->coop, 64)), 0, st, P, pass, E);   // (38 KB of LDS a workgroup: a thousand of them ask for all there is)
-        narrow(1, 256); wide(1, 64);
+        hipLaunchKernelGGL(k_merge_parts, dim3(256), dim3(std::min(e->coop, 64)), 0, st, P, pass, E, E);   // (34 KB of LDS a workgroup: a thousand of them ask for all there is)
+        narrow(1, 256); if (n_wide != 0) wide(1, 64);
     }
     (void)hipEventRecord(e->cls_ev[E], st);
     (void)hipStreamWaitEvent(e->stream, e->cls_ev[E], 0);
@@ -317,9 +326,11 @@ int launch_enumerate_all(tw_engine* e, int pass, int mode, const int32_t* listed
     bool any_lean = false;
     for (int E = std::max(e->P.lean_min_e, 1); E <= kMaxEp; E++) any_lean |= e->tile_cls_off[E + 1] > e->tile_cls_off[E];
     if (!any_lean || e->skip_mode) return TW_OK;
-    int32_t fb[kMaxEp + 1] = {};
+    int32_t fb[kMaxEp + 1] = {}, aw[kMaxEp + 1] = {};
     HIPCHK(hipMemcpyAsync(fb, e->P.fb_count, sizeof(fb), hipMemcpyDeviceToHost, e->stream));
+    if (pass == 1 && mode == 0) HIPCHK(hipMemcpyAsync(aw, e->P.any_wide, sizeof(aw), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (pass == 1 && mode == 0) for (int E = 1; E <= kMaxEp; E++) e->wide_pass1[E] = aw[E] != 0 ? 1 : 0;
     bool any = false;
     for (int E = 1; E <= kMaxEp; E++) any |= fb[E] > 0;
     if (!any) return TW_OK;
@@ -681,6 +692,7 @@ extern "C" int tw_scale_load(tw_engine* e, const int32_t* unit_factor, const int
     HIPCHK(hipMemcpyAsync(const_cast<UnitDev*>(P.units), e->units.data(), sizeof(UnitDev) * e->units.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->state = ST_LOADED; e->pass1_done = false;
+    for (int E = 0; E <= kMaxEp; E++) e->wide_pass1[E] = -1;
     return TW_OK;
 }
 
@@ -892,6 +904,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     P.defer_min_e = env_int("TW_DEFER_MIN_E", 5);
     P.lean_min_e = env_int("TW_LEAN_MIN_E", 5);
     P.lean_grid = std::max(env_int("TW_LEAN_GRID", TW_LEAN_GRID), 1);
+    P.tile_max_deep = std::min(std::max(env_int("TW_TILE_MAX_DEEP", kTileMax), 0), kTileMax);
     int rc;
 #define ALLOC(ptr, count) do { rc = dev_alloc(e, &(ptr), (count)); if (rc != TW_OK) return rc; } while (0)
     e->arena_req.clear();
@@ -955,7 +968,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
                       o_rc = take(1), o_rd = take(kMaxEp + 1), o_fc = take(kMaxEp + 1);
         e->ctr_round_ints = at;
         const int64_t o_pu = take(kMaxEp + 1), o_sc = take(kMaxEp + 1), o_dc = take(kMaxEp + 1), o_du = take(1), o_err = take(1), o_nd = take(P.n_units), o_us = take((int64_t)P.n_units * 16);
-        const int64_t o_dr = take(kMaxEp + 1), o_ft = take(kMaxEp + 1);
+        const int64_t o_dr = take(kMaxEp + 1), o_ft = take(kMaxEp + 1), o_aw = take(kMaxEp + 1);
         const int64_t o_fn = take(kFrontierSlots), o_fb = take(P.frontier_big_slots), o_pb = take(kPairSlots);   // flags of the tuple-list pools (given back by the kernels themselves)
         e->ctr_pass_ints = at;
         auto place = [=](void* q) {
@@ -965,7 +978,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
             D.round_changed = c + o_rc; D.frontier_busy = c + o_fn; D.frontier_big_busy = c + o_fb;
             D.defer_count = c + o_dc; D.defer_used = c + o_du;
             D.part_used = c + o_pu; D.split_count = c + o_sc; D.err = c + o_err; D.unit_ndirty = c + o_nd;
-            D.redo_count = c + o_rd; D.fb_count = c + o_fc; D.defer_refused = c + o_dr; D.fb_total = c + o_ft; D.pair_busy = c + o_pb;
+            D.redo_count = c + o_rd; D.fb_count = c + o_fc; D.defer_refused = c + o_dr; D.fb_total = c + o_ft; D.pair_busy = c + o_pb; D.any_wide = c + o_aw;
             D.unit_stats = (int64_t*)(c + o_us);
         };
         if (e->arena_open) e->arena_req.emplace_back(place, ((size_t)at * sizeof(int32_t) + 255) / 256 * 256);   // (placed by arena_commit, like the rest)
@@ -1063,6 +1076,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipStreamSynchronize(e->stream));
     e->scaled_upload = b->unit_time_scale != nullptr;
     e->state = ST_LOADED; e->pass1_done = false;
+    for (int E = 0; E <= kMaxEp; E++) e->wide_pass1[E] = -1;
     return TW_OK;
 }
 

@@ -461,6 +461,7 @@ __device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narro
         } else nparts = 1;
     }
     const bool split = nparts > 1;
+    if (pred && !narrow) P.any_wide[E] = 1;   // (every writer stores the same value)
     const int sb = wave_append(&P.heavy_big_count[E], isbig && !split);
     const int sn = wave_append(&P.heavy_in_count[E], pred && narrow && !big);
     const int sw = wave_append(&P.heavy_in_count[kMaxEp + 1 + E], pred && !narrow && !big);
@@ -1716,6 +1717,90 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
 // through CPython's heapq (push; beyond five entries pop the smallest) and sorted like the reference's final list.sort -- LdsHeap's
 // operations on (score, window positions) entries with the endpoint count at run time.  Lane 0 works; the logs and the start
 // times of the spans' cut-off windows sit in LDS.
+// CPython's heap of the replay (traceweaver_v3.py:304-307: heappush, beyond five entries heappop) in registers, the same values in
+// every lane, every lane computing alike: the six slots are named, the sift paths of a heap this small are written out (push at slot
+// n: parents (n - 1) >> 1; pop of a six-entry heap: the last entry sifts up from the root through the smaller children, then down
+// again -- heapq._siftup / _siftdown).  Entries are (score, tuple as 8-bit positions per endpoint); Python's order on equal scores is
+// start_mus of the first differing span: start_of(endpoint, position).  (A heap in LDS worked by lane 0 cost ~2.5 us a push, some
+// fifty dependent LDS operations; on millisecond-granular traces -- twin candidates everywhere -- that was half of an item.)
+struct RegHeap {
+    double s[kTopK + 1];
+    unsigned long long x[kTopK + 1];
+    int n, E;
+    __device__ __forceinline__ void clear(int endpoints) {
+        E = endpoints; n = 0;
+#pragma unroll
+        for (int k = 0; k <= kTopK; k++) { s[k] = 0.0; x[k] = 0ull; }
+    }
+    template <class F>
+    __device__ __forceinline__ bool lt(double sa, unsigned long long xa, double sb, unsigned long long xb, const F& start_of) const {   // Python's (score, [spans]) <
+        if (sa != sb) return sa < sb;
+        if (xa == xb) return false;
+        for (int e = 0; e < E; e++) {
+            const int a = (int)((xa >> (8 * e)) & 255ull), b = (int)((xb >> (8 * e)) & 255ull);
+            if (a != b) return start_of(e, a) < start_of(e, b);
+        }
+        return false;
+    }
+    __device__ __forceinline__ bool below_root(double sc) const { return n == kTopK && sc < s[0]; }   // a push that leaves a full heap as it is (k_enumerate_heavy)
+    template <class F>
+    __device__ __forceinline__ void push(double sc, unsigned long long xc, const F& start_of) {
+        static_assert(kTopK == 5, "the sift paths are written for a heap of five (+ 1)");
+        if (n < kTopK) {   // heappush only: the new entry at slot n sifts towards the root
+            if (n == 0) { s[0] = sc; x[0] = xc; }
+            else if (n <= 2) {
+                const bool up = lt(sc, xc, s[0], x[0], start_of);
+                const double ds = up ? s[0] : sc; const unsigned long long dx = up ? x[0] : xc;
+                if (n == 1) { s[1] = ds; x[1] = dx; } else { s[2] = ds; x[2] = dx; }
+                if (up) { s[0] = sc; x[0] = xc; }
+            } else {   // slot 3 or 4: parent 1, then 0
+                const bool up1 = lt(sc, xc, s[1], x[1], start_of);
+                const double ds = up1 ? s[1] : sc; const unsigned long long dx = up1 ? x[1] : xc;
+                if (n == 3) { s[3] = ds; x[3] = dx; } else { s[4] = ds; x[4] = dx; }
+                if (up1) {
+                    if (lt(sc, xc, s[0], x[0], start_of)) { s[1] = s[0]; x[1] = x[0]; s[0] = sc; x[0] = xc; } else { s[1] = sc; x[1] = xc; }
+                }
+            }
+            n++;
+            return;
+        }
+        // heappush at slot 5 (parents 2, 0) ...
+        double ls5 = sc; unsigned long long lx5 = xc;   // slot 5 after the push = what heappop takes off the end
+        if (lt(sc, xc, s[2], x[2], start_of)) {
+            ls5 = s[2]; lx5 = x[2];
+            if (lt(sc, xc, s[0], x[0], start_of)) { s[2] = s[0]; x[2] = x[0]; s[0] = sc; x[0] = xc; } else { s[2] = sc; x[2] = xc; }
+        }
+        // ... heappop: the root leaves, the last entry sifts up from the root (five entries: slots 0 .. 4) through the smaller children
+        int pos;
+        if (!lt(s[1], x[1], s[2], x[2], start_of)) { s[0] = s[2]; x[0] = x[2]; pos = 2; }
+        else {
+            s[0] = s[1]; x[0] = x[1];
+            if (!lt(s[3], x[3], s[4], x[4], start_of)) { s[1] = s[4]; x[1] = x[4]; pos = 4; } else { s[1] = s[3]; x[1] = x[3]; pos = 3; }
+        }
+        // ... and down again from the leaf it reached (_siftdown(heap, 0, pos))
+        if (pos == 2) {
+            if (lt(ls5, lx5, s[0], x[0], start_of)) { s[2] = s[0]; x[2] = x[0]; s[0] = ls5; x[0] = lx5; } else { s[2] = ls5; x[2] = lx5; }
+        } else {
+            const bool up1 = lt(ls5, lx5, s[1], x[1], start_of);
+            const double ds = up1 ? s[1] : ls5; const unsigned long long dx = up1 ? x[1] : lx5;
+            if (pos == 3) { s[3] = ds; x[3] = dx; } else { s[4] = ds; x[4] = dx; }
+            if (up1) {
+                if (lt(ls5, lx5, s[0], x[0], start_of)) { s[1] = s[0]; x[1] = x[0]; s[0] = ls5; x[0] = lx5; } else { s[1] = ls5; x[1] = lx5; }
+            }
+        }
+    }
+};
+// the value lane j holds (j wave-uniform), in scalar registers: v_readlane instead of a shuffle through the LDS crossbar
+#ifdef TW_HOST_EMULATION
+__device__ __forceinline__ unsigned long long lane_value(unsigned long long v, int j) { return __shfl(v, j); }
+#else
+__device__ __forceinline__ unsigned long long lane_value(unsigned long long v, int j) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, j), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), j);
+    return ((unsigned long long)hi << 32) | lo;
+}
+#endif
+__device__ __forceinline__ double lane_value(double v, int j) { return __longlong_as_double((long long)lane_value((unsigned long long)__double_as_longlong(v), j)); }
+
 struct MergeHeap {
     double* hs;                      // [kTopK + 1] scores
     unsigned long long* hx;          // [kTopK + 1] positions in the cut-off windows, 8 bits per endpoint
@@ -1791,7 +1876,7 @@ struct MergeHeap {
     }
 };
 
-__global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
+__global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E_lo, int E_hi) {   // the split spans of the classes E_lo .. E_hi in one launch
     if (*P.err != 0) return;
     constexpr int kCandMax = kMaxParts * kTopK;
     __shared__ double sc[kCandMax];
@@ -1801,14 +1886,15 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
     __shared__ uint16_t rk[kCandMax];
     __shared__ int redo_flag;
     __shared__ int64_t w_st[kMaxEp][64 * kCandWords];           // log mode: start times of the cut-off windows' spans
-    __shared__ double lg_sc[kPartLogCap];                      // ... one part's log at a time
-    __shared__ unsigned long long lg_ix[kPartLogCap];
     __shared__ double h_sc[kTopK + 1];
     __shared__ unsigned long long h_ix[kTopK + 1];
     __shared__ int h_n;
     const int t = threadIdx.x, nt = blockDim.x;
-    const int n = P.split_count[E];
-    for (int s = (int)blockIdx.x; s < n; s += (int)gridDim.x) {
+    int n_all = 0;
+    for (int Ec = E_lo; Ec <= E_hi; Ec++) n_all += P.split_count[Ec];
+    for (int s_all = (int)blockIdx.x; s_all < n_all; s_all += (int)gridDim.x) {
+        int E = E_lo, s = s_all;   // the class of the record and its number within the class
+        while (s >= P.split_count[E]) { s -= P.split_count[E]; E++; }
         const int rec = P.part_off[E] + s;
         const int unit = P.split_unit[rec], i = P.split_idx[rec], slot0 = P.split_slot[rec];
         const int nparts = P.split_parts[rec] & 255, wide_bit = P.split_parts[rec] & (1 << 24);
@@ -1835,24 +1921,36 @@ __global__ void __launch_bounds__(64) k_merge_parts(Dev P, int pass, int E) {
                 const int lo = P.c_lo[ie_index(U, e, i)], w = P.c_hi[ie_index(U, e, i)] - lo + 1;
                 for (int r = t; r < w && r < 64 * kCandWords; r += nt) w_st[e][r] = P.out_start[U.ep_off[e] + lo + r];
             }
-            MergeHeap H;   // (lane 0's; the logs pass through LDS part after part, in part order = enumeration order)
-            H.hs = h_sc; H.hx = h_ix; H.n = 0; H.E = E; H.st = w_st;
+            // the logs in part order = enumeration order, 64 entries at a time: an entry per lane, those that can change the heap pushed
+            // one after the other (every lane keeps the heap, RegHeap); the final list.sort by lane 0 on the LDS copy
+            RegHeap RH;
+            RH.clear(E);
+            auto start_of = [&](int e, int pos2) -> int64_t { return w_st[e][pos2]; };
+            wave_sync();
             for (int p = 0; p < nparts; p++) {
                 const int m = P.part_logn[slot0 + p];
-                for (int k = t; k < m; k += nt) {
-                    lg_sc[k] = P.part_log_sc[(int64_t)(slot0 + p) * kPartLogCap + k];
-                    lg_ix[k] = P.part_log_ix[(int64_t)(slot0 + p) * kPartLogCap + k];
-                }
-                wave_sync();
-                if (t == 0)
-                    for (int k = 0; k < m; k++) {
-                        const double sk = lg_sc[k];
-                        if (H.n == kTopK && sk < H.hs[0]) continue;   // strictly below the root of a full heap: the push leaves the array as it is
-                        H.push(sk, lg_ix[k]);
+                for (int base = 0; base < m; base += nt) {
+                    const int k = base + t;
+                    const bool valid = k < m;
+                    const double sk = valid ? P.part_log_sc[(int64_t)(slot0 + p) * kPartLogCap + k] : 0.0;
+                    const unsigned long long xk = valid ? P.part_log_ix[(int64_t)(slot0 + p) * kPartLogCap + k] : 0ull;
+                    unsigned long long todo = __ballot(valid && !RH.below_root(sk));   // strictly below the root of a full heap: the push leaves the array as it is
+                    while (todo) {
+                        const int j = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const double sj = lane_value(sk, j);
+                        if (RH.below_root(sj)) continue;   // (the root has risen since the ballot)
+                        RH.push(sj, lane_value(xk, j), start_of);
                     }
-                wave_sync();
+                }
             }
-            if (t == 0) { H.sort_desc(); h_n = H.n; }
+            MergeHeap H;
+            H.hs = h_sc; H.hx = h_ix; H.n = RH.n; H.E = E; H.st = w_st;
+            if (t == 0) {
+#pragma unroll
+                for (int k = 0; k < kTopK; k++) { h_sc[k] = RH.s[k]; h_ix[k] = RH.x[k]; }
+                H.sort_desc(); h_n = H.n;
+            }
             wave_sync();
             const int nout = h_n;
             const int64_t g = U.in_off + i;

@@ -37,6 +37,8 @@ struct LeanLds {
     int32_t cn[kMaxEp], lo[kMaxEp], wd[kMaxEp];    // staged candidates, first span of the cut-off window, its width
     uint32_t pm[kMaxEp], magic[kMaxEp];            // predecessor masks; reciprocals of the counts (grid decoding)
     uint32_t ops[kMaxEp * kMaxEp + 2 * kMaxEp];    // the scoring program (see lean_op)
+    int32_t edge_first[kMaxEp * kMaxEp + 1];       // first pair of every primary in-edge in the item's index space of terms
+    uint8_t edge_op[kMaxEp * kMaxEp];              // ... and its word of the program
     int32_t n_ops;
     double hs[kTopK + 1];                          // CPython heap replay: scores / tuples (staged positions, 8 bits each)
     unsigned long long hx[kTopK + 1];
@@ -55,17 +57,6 @@ __device__ __forceinline__ uint32_t lean_op(int kind, int e, int p, int cn_e, in
     return (uint32_t)kind | ((uint32_t)e << 2) | ((uint32_t)p << 5) | ((uint32_t)cn_e << 8) | ((uint32_t)off << 16);
 }
 __device__ __forceinline__ int lean_pos(unsigned long long pk, int e) { return (int)((pk >> (8 * e)) & 255ull); }
-// the value lane j holds (j wave-uniform), in scalar registers: v_readlane instead of a shuffle through the LDS crossbar
-#ifdef TW_HOST_EMULATION
-__device__ __forceinline__ unsigned long long lane_value(unsigned long long v, int j) { return __shfl(v, j); }
-#else
-__device__ __forceinline__ unsigned long long lane_value(unsigned long long v, int j) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, j), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), j);
-    return ((unsigned long long)hi << 32) | lo;
-}
-#endif
-__device__ __forceinline__ double lane_value(double v, int j) { return __longlong_as_double((long long)lane_value((unsigned long long)__double_as_longlong(v), j)); }
-
 // CPython's heapq / list.sort on (score, tuple) entries in LDS (lane 0): LdsHeap of k_enumerate_heavy with packed tuples and a
 // run-time endpoint count.  Python's order on equal scores: start_mus of the first differing span.
 template <int W>
@@ -151,20 +142,26 @@ struct LeanHeap {
 #ifndef TW_LEAN_GRID
 #define TW_LEAN_GRID 256
 #endif
+#ifndef TW_LEAN_ATTR
 #ifdef TW_HOST_EMULATION
 #define TW_LEAN_ATTR
 #else
 #define TW_LEAN_ATTR __attribute__((amdgpu_waves_per_eu(2, 4)))
 #endif
+#endif
 
 template <int W>
-__global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(Dev P, int pass, int mode, int part, int pool, int E) {
-    // part: 0 the class' lists (long enumerations first), 1 the spans k_merge_parts lists again, 3 the list parts of the deferred spans
+__global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(Dev P, int pass, int mode, int part, int pool, int E_lo, int E_hi) {
+    // part: 0 the classes' lists (long enumerations first), 1 the spans k_merge_parts lists again, 3 the list parts of the deferred spans.
+    // ONE launch serves the classes E_lo .. E_hi (the endpoint count is a run-time value here): the GPU runs about four kernels at a time
+    // whatever their sizes (measured: with a chain of kernels per class, the fifth class' first kernel started when another class'
+    // kernel ended), so the classes' work is put into few large launches instead of many small ones.  The launch's work list = the lists
+    // of long enumerations of its classes, most endpoints first, then their other lists.
     if (*P.err != 0) return;
     static_assert(W == kNarrow || W == 64 * kCandWords, "one instantiation per half of the work list");
     constexpr bool kWide = W != kNarrow;
-    const int kList = kWide ? kMaxEp + 1 + E : E;
     __shared__ LeanLds<W> L;
+    __shared__ int32_t seg_first[2 * kMaxEp + 1];   // first item of every segment of the launch's work list (segment = one list of one class)
     // every term table in ONE array of dynamic LDS, so that a word of the scoring program addresses its term by an index (a pointer
     // that may point at one of several LDS arrays or at global memory is a generic pointer: flat loads, a wait on both counters per term):
     // [0, kMaxEp W) root terms by (endpoint, staged position), [kMaxEp W, 2 kMaxEp W) closing terms, from kTabPairs on `pool` doubles of
@@ -172,16 +169,25 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
     HIP_DYNAMIC_SHARED(double, tabs)
     constexpr int kTabClose = kMaxEp * W, kTabPairs = 2 * kMaxEp * W;
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63;
-    const int defer_base = part == 3 ? P.heavy_big_count[E] : 0;
-    const int n_big = part == 3 ? P.defer_count[E] : (part == 1 ? P.redo_count[E] : P.heavy_big_count[E]);
-    const int count = n_big + (part == 0 ? P.heavy_in_count[kList] : 0);
-    int32_t* next_counter = enum_cursor(P, part, kWide, E);
+    const int ncls = E_hi - E_lo + 1;
+    if (t == 0) {
+        int acc = 0;
+        for (int k = 0; k < ncls; k++) { const int Ec = E_hi - k; seg_first[k] = acc; acc += part == 3 ? P.defer_count[Ec] : (part == 1 ? P.redo_count[Ec] : P.heavy_big_count[Ec]); }
+        for (int k = 0; k < ncls; k++) { const int Ec = E_hi - k; seg_first[ncls + k] = acc; acc += part == 0 ? P.heavy_in_count[kWide ? kMaxEp + 1 + Ec : Ec] : 0; }
+        seg_first[2 * ncls] = acc;
+    }
+    wave_sync();
+    const int count = seg_first[2 * ncls];
+    int32_t* next_counter = enum_cursor(P, part, kWide, E_lo);
     const int nstatic = (int)gridDim.x * kWorkChunk;
     if ((int)blockIdx.x >= count) return;
     int chunk_pos = 0, chunk_end = 0;
     int front_slot = -1;   // this wavefront's pair of tuple-list buffers: -1 not claimed yet, -2 none left
     int pair_slot = -1;    // ... slot of P.pair_pool (pair tables beyond the LDS pool)
     bool first_chunk = true;
+#ifdef TW_PROFILE
+    const int E = E_hi;   // (the timers of a -DTW_PROFILE build are switched on by the launch's largest class; shadowed by the item's own class below)
+#endif
     TW_PROF_DECL();
     while (true) {
         if (chunk_pos == chunk_end) {
@@ -197,8 +203,12 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
         int item = chunk_pos++;
         if (item < nstatic) item = (item % kWorkChunk) * (int)gridDim.x + item / kWorkChunk;   // the long spans at the front: one to a wavefront
         if (item >= count) continue;
-        const bool from_big = item < n_big;
-        const int pos = from_big ? P.heavy_big_off[E] + defer_base + item : (kWide ? P.heavy_in_off[E + 1] - 1 - (item - n_big) : P.heavy_in_off[E] + (item - n_big));
+        int sg = 0;   // the segment of the item: which list of which class
+        while (sg + 1 < 2 * ncls && seg_first[sg + 1] <= item) sg++;
+        const bool from_big = sg < ncls;
+        const int E = __builtin_amdgcn_readfirstlane(E_hi - (from_big ? sg : sg - ncls));
+        const int at = item - seg_first[sg];
+        const int pos = from_big ? P.heavy_big_off[E] + (part == 3 ? P.heavy_big_count[E] : 0) + at : (kWide ? P.heavy_in_off[E + 1] - 1 - at : P.heavy_in_off[E] + at);
         const int unit = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_unit : P.heavy_in_unit)[pos]);
         const int i_raw = __builtin_amdgcn_readfirstlane((from_big ? P.heavy_big_idx : P.heavy_in_idx)[pos]);
         const int i = i_raw & ~kIdxReplayFlag;
@@ -298,15 +308,9 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
             uint32_t any_order = 0, roots = 0;
             long long grid = 1;
             for (int e = 0; e < E; e++) { wsum += L.cn[e]; any_order |= L.pm[e]; roots |= U.npred[e] == 0 ? 1u << e : 0u; grid = grid < (1ll << 40) ? grid * L.cn[e] : grid; }
-            for (int q = t; q < 2 * wsum; q += nt) {
-                int es = 0, r = q >> 1;
-                for (int e = 0; e < E; e++) { if (r < L.cn[e]) { es = e; break; } r -= L.cn[e]; }
-                const int64_t st = L.ls[es][r], e2 = L.le[es][r];
-                if (q & 1) tabs[kTabClose + es * W + r] = score_term(S, slot_close(E, es), e2, in_end);
-                else tabs[es * W + r] = ((roots >> es) & 1u) ? score_term(S, slot_root(E, es), in_start, st) : 0.0;
-            }
-            // ---- pair tables of the primary in-edges and the scoring program, in scoring order
-            int used = 0, gused = 0, n_ops = 0;
+            // ---- the plan: per primary in-edge, in scoring order, where its pair table goes (the LDS pool while it lasts, then the
+            // wavefront's slot of the global pool), and the scoring program
+            int used = 0, gused = 0, n_ops = 0, n_edge = 0, pairs = 0;
             bool tables = true;
             double* gpair = pair_slot >= 0 ? P.pair_pool + (size_t)pair_slot * kPairSpill : nullptr;
             for (int e = 0; e < E; e++) {
@@ -315,7 +319,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
                     if (!U.pred_prim[e][j]) continue;
                     const int p = U.pred_list[e][j];
                     const int need = L.cn[p] * ce;
-                    const bool in_lds = used + need <= pool && used + need <= 0xffff;
+                    const bool in_lds = used + need <= pool && kTabPairs + used + need <= 0xffff;
                     if (!in_lds) {   // beyond the LDS pool: the wavefront's slot of the global pool (claimed at the first such table)
                         if (pair_slot == -1) {
                             if (t == 0) pair_slot = pool_acquire(P.pair_busy, kPairSlots, (unsigned)blockIdx.x * 48271u + (unsigned)(E * 2 + (kWide ? 1 : 0)) * 7919u + (unsigned)part * 104729u + 11u);
@@ -325,21 +329,43 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
                         }
                         if (gpair == nullptr || gused + need > kPairSpill) { tables = false; continue; }
                     }
-                    for (int q = t; q < need; q += nt) {
-                        const int a = q / ce, b2 = q % ce;
-                        const int64_t pend = L.le[p][a], st = L.ls[e][b2];
-                        if (pend <= st) {   // other pairs never occur in a tuple
-                            const double v = score_term(S, slot_prim(E, p, e), pend, st);
-                            if (in_lds) tabs[kTabPairs + used + q] = v; else gpair[gused + q] = v;
-                        }
+                    if (t == 0) {
+                        L.ops[n_ops] = in_lds ? lean_op(0, e, p, ce, kTabPairs + used) : lean_op(3, e, p, ce, gused);
+                        L.edge_first[n_edge] = pairs; L.edge_op[n_edge] = (uint8_t)n_ops;
                     }
-                    if (t == 0) L.ops[n_ops] = in_lds ? lean_op(0, e, p, ce, kTabPairs + used) : lean_op(3, e, p, ce, gused);
-                    n_ops++;
+                    n_ops++; n_edge++;
+                    pairs += need;
                     if (in_lds) used += need; else gused += need;
                 }
                 if (np == 0) { if (t == 0) L.ops[n_ops] = lean_op(0, e, e, 0, e * W); n_ops++; }   // (the root term: a table of one row)
                 if (t == 0) L.ops[n_ops] = lean_op(1, e, e, 0, kTabClose + e * W);
                 n_ops++;
+            }
+            if (t == 0) L.edge_first[n_edge] = pairs;
+            wave_sync();
+            // ---- every term of the item, one per lane: root / closing terms per staged candidate, pair terms per pair of staged
+            // candidates of a primary in-edge -- ONE index space, so that an item of a few dozen terms is one batch of the (in pass 2:
+            // ~1.5 k instructions) term evaluation, not one batch per table
+            for (int q = t; q < 2 * wsum + pairs; q += nt) {
+                if (q < 2 * wsum) {
+                    int es = 0, r = q >> 1;
+                    for (int e = 0; e < E; e++) { if (r < L.cn[e]) { es = e; break; } r -= L.cn[e]; }
+                    const int64_t st = L.ls[es][r], e2 = L.le[es][r];
+                    if (q & 1) tabs[kTabClose + es * W + r] = score_term(S, slot_close(E, es), e2, in_end);
+                    else tabs[es * W + r] = ((roots >> es) & 1u) ? score_term(S, slot_root(E, es), in_start, st) : 0.0;
+                    continue;
+                }
+                const int x = q - 2 * wsum;
+                int lo2 = 0, hi2 = n_edge - 1;   // the edge with edge_first[k] <= x < edge_first[k + 1]
+                while (lo2 < hi2) { const int mid = (lo2 + hi2 + 1) >> 1; if (L.edge_first[mid] <= x) lo2 = mid; else hi2 = mid - 1; }
+                const uint32_t op = L.ops[L.edge_op[lo2]];   // its word of the program: endpoints, row length, where the table lies
+                const int e = (int)((op >> 2) & 7u), p = (int)((op >> 5) & 7u), ce = (int)((op >> 8) & 255u), at = (int)(op >> 16);
+                const int y = x - L.edge_first[lo2], a2 = y / ce, b2 = y % ce;
+                const int64_t pend = L.le[p][a2], st = L.ls[e][b2];
+                if (pend <= st) {   // other pairs never occur in a tuple
+                    const double v = score_term(S, slot_prim(E, p, e), pend, st);
+                    if ((op & 3u) == 0u) tabs[at + y] = v; else gpair[at + y] = v;
+                }
             }
             for (int k = n_ops; k < ((n_ops + 3) & ~3); k++) if (t == 0) L.ops[k] = lean_op(2, 0, 0, 0, 0);   // (the program is run four words at a time)
             n_ops = (n_ops + 3) & ~3;
@@ -581,76 +607,13 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
                 if ((op & 3u) == 3u) return gpair2[at];   // (uniform)
                 return tabs[at];
             };
-            // CPython's heap of the replay (traceweaver_v3.py:304-307: heappush, beyond five entries heappop) in registers, the same
-            // values in every lane, every lane computing alike: the six slots are named, the sift paths of a heap this small are
-            // written out (push at slot n: parents (n - 1) >> 1; pop of a six-entry heap: the last entry sifts up from the root
-            // through the smaller children, then down again -- heapq._siftup / _siftdown).  (A heap in LDS worked by lane 0 cost
-            // ~2.5 us a push, some fifty dependent LDS operations; on millisecond-granular traces -- twin candidates everywhere --
-            // that was half of an item.)
-            double hS[kTopK + 1];
-            unsigned long long hX[kTopK + 1];
-            int hN = 0;
-#pragma unroll
-            for (int k = 0; k <= kTopK; k++) { hS[k] = 0.0; hX[k] = 0ull; }
-            static_assert(kTopK == 5, "the sift paths of heap_push are written for a heap of five (+ 1)");
-            auto heap_lt = [&](double sa, unsigned long long xa, double sb, unsigned long long xb) -> bool {   // Python's (score, [spans]) <
-                if (sa != sb) return sa < sb;
-                if (xa == xb) return false;
-                for (int e = 0; e < E; e++) {
-                    const int a = lean_pos(xa, e), b = lean_pos(xb, e);
-                    if (a != b) return L.ls[e][a] < L.ls[e][b];
-                }
-                return false;
-            };
-            auto heap_push = [&](double s, unsigned long long x) {
-                if (hN < kTopK) {   // heappush only: the new entry at slot hN sifts towards the root
-                    if (hN == 0) { hS[0] = s; hX[0] = x; }
-                    else if (hN <= 2) {
-                        const bool up = heap_lt(s, x, hS[0], hX[0]);
-                        const double ds = up ? hS[0] : s; const unsigned long long dx = up ? hX[0] : x;
-                        if (hN == 1) { hS[1] = ds; hX[1] = dx; } else { hS[2] = ds; hX[2] = dx; }
-                        if (up) { hS[0] = s; hX[0] = x; }
-                    } else {   // slot 3 or 4: parent 1, then 0
-                        const bool up1 = heap_lt(s, x, hS[1], hX[1]);
-                        const double ds = up1 ? hS[1] : s; const unsigned long long dx = up1 ? hX[1] : x;
-                        if (hN == 3) { hS[3] = ds; hX[3] = dx; } else { hS[4] = ds; hX[4] = dx; }
-                        if (up1) {
-                            const bool up0 = heap_lt(s, x, hS[0], hX[0]);
-                            if (up0) { hS[1] = hS[0]; hX[1] = hX[0]; hS[0] = s; hX[0] = x; } else { hS[1] = s; hX[1] = x; }
-                        }
-                    }
-                    hN++;
-                    return;
-                }
-                // heappush at slot 5 (parents 2, 0) ...
-                double ls5 = s; unsigned long long lx5 = x;   // slot 5 after the push = what heappop takes off the end
-                if (heap_lt(s, x, hS[2], hX[2])) {
-                    ls5 = hS[2]; lx5 = hX[2];
-                    if (heap_lt(s, x, hS[0], hX[0])) { hS[2] = hS[0]; hX[2] = hX[0]; hS[0] = s; hX[0] = x; } else { hS[2] = s; hX[2] = x; }
-                }
-                // ... heappop: the root leaves, the last entry sifts up from the root (five entries: slots 0 .. 4) through the smaller children
-                int pos;
-                if (!heap_lt(hS[1], hX[1], hS[2], hX[2])) { hS[0] = hS[2]; hX[0] = hX[2]; pos = 2; }
-                else {
-                    hS[0] = hS[1]; hX[0] = hX[1];
-                    if (!heap_lt(hS[3], hX[3], hS[4], hX[4])) { hS[1] = hS[4]; hX[1] = hX[4]; pos = 4; } else { hS[1] = hS[3]; hX[1] = hX[3]; pos = 3; }
-                }
-                // ... and down again from the leaf it reached (_siftdown(heap, 0, pos))
-                if (pos == 2) {
-                    if (heap_lt(ls5, lx5, hS[0], hX[0])) { hS[2] = hS[0]; hX[2] = hX[0]; hS[0] = ls5; hX[0] = lx5; } else { hS[2] = ls5; hX[2] = lx5; }
-                } else {
-                    const bool up1 = heap_lt(ls5, lx5, hS[1], hX[1]);
-                    const double ds = up1 ? hS[1] : ls5; const unsigned long long dx = up1 ? hX[1] : lx5;
-                    if (pos == 3) { hS[3] = ds; hX[3] = dx; } else { hS[4] = ds; hX[4] = dx; }
-                    if (up1) {
-                        if (heap_lt(ls5, lx5, hS[0], hX[0])) { hS[1] = hS[0]; hX[1] = hX[0]; hS[0] = ls5; hX[0] = lx5; } else { hS[1] = ls5; hX[1] = lx5; }
-                    }
-                }
-            };
+            RegHeap RH;   // CPython's heap of the replay, in registers (tw_kernels.h)
+            RH.clear(E);
+            auto start_of = [&](int e, int pos2) -> int64_t { return L.ls[e][pos2]; };
             for (int attempt = (deferred || part_failed) ? 2 : (part_log || replay_first) ? 1 : 0; attempt < 2; attempt++) {
                 exact_replay = attempt == 1;
                 bool ambiguous = false;
-                hN = 0; nk = 0; leaves = 0;
+                RH.n = 0; nk = 0; leaves = 0;
 #pragma unroll
                 for (int k = 0; k < kTopK; k++) { ts[k] = -dinf(); tslot[k] = k; }
                 unsigned long long ent_next = use_front && t < Gtot ? front[t] : 0ull;   // listed tuples: one batch ahead of their use
@@ -726,13 +689,13 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
                     leaves += __popcll(feasible);
                     if (exact_replay) {
                         // (a tuple strictly below the root of a full heap of five is a no-op: see k_enumerate_heavy)
-                        unsigned long long todo = __ballot(ok && !(hN == kTopK && score < hS[0]));
-                        while (todo) {   // in enumeration order, CPython's heappush / heappop replayed by every lane alike (see heap_push)
+                        unsigned long long todo = __ballot(ok && !RH.below_root(score));
+                        while (todo) {   // in enumeration order, CPython's heappush / heappop replayed by every lane alike (RegHeap)
                             const int j = __ffsll((long long)todo) - 1;
                             todo &= todo - 1;
                             const double sj = lane_value(score, j);
                             const unsigned long long pj = lane_value(pk, j);
-                            heap_push(sj, pj);
+                            RH.push(sj, pj, start_of);
                             if (part_log) {   // (its score was not below the root's when it came: it may enter the heap of the whole enumeration)
                                 if (t == 0 && nlog < kPartLogCap) {   // (staged positions for now: turned into window positions when the item is done)
                                     P.part_log_sc[(int64_t)part_slot * kPartLogCap + nlog] = sj;
@@ -871,13 +834,13 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
             if (exact_replay) {   // the heap as CPython's list, sorted like the reference's final list.sort(reverse=True) (lane 0, in LDS)
                 if (t == 0) {
 #pragma unroll
-                    for (int k = 0; k < kTopK; k++) { L.hs[k] = hS[k]; L.hx[k] = hX[k]; }
-                    hp.n = hN;
+                    for (int k = 0; k < kTopK; k++) { L.hs[k] = RH.s[k]; L.hx[k] = RH.x[k]; }
+                    hp.n = RH.n;
                     hp.sort_desc();
                 }
             }
             wave_sync();
-            nout = exact_replay ? hN : nk;
+            nout = exact_replay ? RH.n : nk;
             if (!exact_replay) {   // the kept five into the heap arrays (the result stores below read those)
                 if (t == 0) {
 #pragma unroll

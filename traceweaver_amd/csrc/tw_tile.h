@@ -39,14 +39,20 @@ constexpr int kTileMax = TW_TILE_MAX;   // largest enumeration (product of the c
 #define TW_TILE_ITEMS 768
 #define TW_TILE_GRID 1024
 #endif
-template <int E>
+// SPANS = incoming spans a workgroup serves: kTile, or kTile / 8 for the sub-tile launches of a class of few tiles (the deep call
+// graphs of a small batch) -- with tables sized for those 16 spans: 15 KB of LDS instead of 48 KB.  (The sub-tile workgroups of one
+// such class used to ask for all the LDS of the GPU, 912 x 43 KB; workgroups that need a third of a CU's LDS at once are not placed
+// while smaller ones -- the wavefront kernels of the other classes -- keep taking what becomes free: the classes' tile kernels ran one
+// after the other.)
+constexpr int kSubTileSpans = kTile / 8;
+template <int E, int SPANS = kTile>
 struct TileCfg {
 #ifdef TW_TILE_SMALL   // host-emulation build of the tests: tiny tables, so that segments and slice overflows occur
     static constexpr int kSlice = 24, kItems = kMaxEp * 32, kGrid = kTileMax > 64 ? kTileMax : 64;
 #else
-    static constexpr int kSlice = E <= 4 ? 192 : 160;   // outgoing spans staged per endpoint
-    static constexpr int kItems = TW_TILE_ITEMS;        // (span, endpoint, candidate) items per segment of the tile
-    static constexpr int kGrid = TW_TILE_GRID;          // tuple slots per segment (a span's slots are padded to a multiple of four)
+    static constexpr int kSlice = SPANS < kTile ? 64 : (E <= 4 ? 192 : 160);   // outgoing spans staged per endpoint
+    static constexpr int kItems = SPANS < kTile ? kMaxEp * 32 : TW_TILE_ITEMS;   // (span, endpoint, candidate) items per segment of the tile
+    static constexpr int kGrid = SPANS < kTile ? (kTileMax > 512 ? kTileMax : 512) : TW_TILE_GRID;   // tuple slots per segment (a span's slots are padded to a multiple of four)
 #endif
     static_assert(kItems >= kMaxEp * 32 && kGrid >= ((kTileMax + 3) & ~3) && kGrid % 4 == 0, "a single span must fit a segment");
 };
@@ -73,13 +79,16 @@ __device__ __forceinline__ double score_term_gap(const Scorer& S, int slot, long
 }
 
 // Optional phase timers (build with -DTW_PROFILE_TILE; read back through tw_debug_profile): 10 ns ticks of thread 0 of every
-// workgroup of the E = 4 class per phase -- [0] cut-offs, [1] slices, [2] masks / lists / prefix sums, [3] terms, [4] tuples,
+// workgroup of the class TW_PROFILE_TILE_E (4) per phase -- [0] cut-offs, [1] slices, [2] masks / lists / prefix sums, [3] terms, [4] tuples,
 // [5] ranks, [6] results, [7] workgroup lifetime, [8] workgroups, [9] segments, [10] items, [11] tuples.  Compiled out by default.
 #ifdef TW_PROFILE_TILE
+#ifndef TW_PROFILE_TILE_E
+#define TW_PROFILE_TILE_E 4   // the endpoint-count class that is timed
+#endif
 #define TW_TILE_T0() long long _tp = wall_clock64(); const long long _tb = _tp; long long _ta[7] = {0, 0, 0, 0, 0, 0, 0}
 #define TW_TILE_TICK(k) do { const long long _n = wall_clock64(); _ta[k] += _n - _tp; _tp = _n; } while (0)
-#define TW_TILE_COUNT(k, v) do { if (E == 4 && threadIdx.x == 0) atomicAdd((unsigned long long*)&P.prof[k], (unsigned long long)(v)); } while (0)
-#define TW_TILE_FLUSH() do { if (E == 4 && threadIdx.x == 0) { for (int _k = 0; _k < 7; _k++) atomicAdd((unsigned long long*)&P.prof[_k], (unsigned long long)_ta[_k]); \
+#define TW_TILE_COUNT(k, v) do { if (E == TW_PROFILE_TILE_E && threadIdx.x == 0) atomicAdd((unsigned long long*)&P.prof[k], (unsigned long long)(v)); } while (0)
+#define TW_TILE_FLUSH() do { if (E == TW_PROFILE_TILE_E && threadIdx.x == 0) { for (int _k = 0; _k < 7; _k++) atomicAdd((unsigned long long*)&P.prof[_k], (unsigned long long)_ta[_k]); \
     atomicAdd((unsigned long long*)&P.prof[7], (unsigned long long)(wall_clock64() - _tb)); atomicAdd((unsigned long long*)&P.prof[8], 1ull); } } while (0)
 #else
 #define TW_TILE_T0() do {} while (0)
@@ -88,10 +97,10 @@ __device__ __forceinline__ double score_term_gap(const Scorer& S, int slot, long
 #define TW_TILE_FLUSH() do {} while (0)
 #endif
 
-template <int E>
+template <int E, int SPANS = kTile>
 __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e, int sub_tiles) {
     if (*P.err != 0) return;  // e.g. NaN parameters (hazard H3): nothing downstream is meaningful
-    typedef TileCfg<E> C;
+    typedef TileCfg<E, SPANS> C;
     constexpr int SL = C::kSlice;
     // sub_tiles > 1: a class of few tiles (the deep call graphs of a small batch: 57 tiles on 256 CUs, each a millisecond of
     // segments one after the other) is launched with sub_tiles workgroups per tile, each serving a stretch of the tile's spans
@@ -103,15 +112,15 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
     const int sub_spans = P.tile_spans / sub_tiles, first = T.first + (vb % sub_tiles) * sub_spans;
     const int ns = min(sub_spans, min(P.tile_spans, U.n_in - T.first) - (vb % sub_tiles) * sub_spans);   // spans of this workgroup; thread t < ns owns span t
     if (ns <= 0) return;
-    __shared__ int32_t s_is[kTile], s_ie[kTile];          // start / end of the incoming spans as offsets from `base`
+    __shared__ int32_t s_is[SPANS], s_ie[SPANS];          // start / end of the incoming spans as offsets from `base`
     __shared__ int32_t sl_st[E][SL], sl_en[E][SL];        // the staged slice of every endpoint list, same offsets (clamped)
     __shared__ int32_t s_A[E], s_B[E];                    // the slice = positions [A, B) of the endpoint's list
-    __shared__ uint16_t s_lo[E][kTile];                   // first position of the span's window, relative to A
-    __shared__ uint32_t s_cm[E][kTile];                   // bit r: position lo + r holds a contained candidate
-    __shared__ uint32_t s_bits[E][kTile];                 // ... that occurs in a feasible tuple
-    __shared__ int32_t s_item0[kTile + 1], s_grid0[kTile + 1], s_leaves[kTile];
-    __shared__ uint8_t s_amb[kTile];
-    __shared__ unsigned long long s_cn[kTile];            // contained candidates per endpoint, 8 bits each
+    __shared__ uint16_t s_lo[E][SPANS];                   // first position of the span's window, relative to A
+    __shared__ uint32_t s_cm[E][SPANS];                   // bit r: position lo + r holds a contained candidate
+    __shared__ uint32_t s_bits[E][SPANS];                 // ... that occurs in a feasible tuple
+    __shared__ int32_t s_item0[SPANS + 1], s_grid0[SPANS + 1], s_leaves[SPANS];
+    __shared__ uint8_t s_amb[SPANS];
+    __shared__ unsigned long long s_cn[SPANS];            // contained candidates per endpoint, 8 bits each
     __shared__ int32_t s_wtot[4 * kTile / 64][2];
     __shared__ double t_root[C::kItems], t_close[C::kItems];
     __shared__ uint16_t it_idx[C::kItems];                // slice position of the item's candidate
@@ -198,6 +207,11 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
     int32_t cnt[E];
 #pragma unroll
     for (int e = 0; e < E; e++) { const int c = s_B[e] - s_A[e]; cnt[e] = c < 0 ? 0 : (c > SL ? SL : c); }
+    // (a class whose every span goes to the wavefront kernel -- TW_TILE_MAX_DEEP = 0 -- only classifies here: no slice)
+    if (E >= P.lean_min_e && P.tile_max_deep == 0) {
+#pragma unroll
+        for (int e = 0; e < E; e++) cnt[e] = 0;
+    }
     auto clamp32 = [](long long v) -> int32_t { return (int32_t)(v > 0x7fffffffll ? 0x7fffffffll : (v < -0x7fffffffll ? -0x7fffffffll : v)); };
     for (int x0 = 0; x0 < SL; x0 += nt) {   // (one round with the production sizes: the loads of all endpoints are in flight together)
         const int x = x0 + t;
@@ -227,7 +241,10 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
             prod = prod <= kTileMax ? prod * __popcll((unsigned long long)cm[e]) : prod;
         }
     }
-    const bool mine = live && !wide && (empty || (fits && prod <= kTileMax));   // this kernel enumerates the span
+    // (the deep call graphs: every tuple costs this kernel a term per primary call-order edge -- in pass 2 a mixture term of ~1.5 k
+    // instructions --, the wavefront kernel tabulates those per pair of candidates: its classes hand over from P.tile_max_deep tuples on)
+    const long long tile_max = E >= P.lean_min_e ? (long long)P.tile_max_deep : (long long)kTileMax;
+    const bool mine = live && !wide && (empty || (fits && prod <= tile_max));   // this kernel enumerates the span
     {   // the others: listed for the wavefront kernel with what it needs to plan (k_enumerate_heavy)
         long long hprod = 0;
         int first_cands = 0;
