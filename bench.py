@@ -705,6 +705,17 @@ def run_workload(args, c, primary=True):
         dist.all_reduce(cc, op=dist.ReduceOp.SUM)
         cc = cc.cpu().numpy()
         counters, acc_sum = cc[:4], cc[4:]
+    # who ran: the process group's own view (world size, backend) and the device every rank drove -- into the detail file, so that
+    # the first run on several physical GPUs can be read against what it was meant to be
+    ranks_info = {"world_size": world, "backend": "none", "device_of_rank": [int(device)], "emulated": bool(emulated),
+                  "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+    if world > 1:
+        dv = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        dv[rank] = float(device)
+        dist.all_reduce(dv, op=dist.ReduceOp.SUM)
+        ranks_info.update({"world_size": int(dist.get_world_size()), "backend": str(dist.get_backend()), "device_of_rank": [int(x) for x in dv.cpu().tolist()]})
+    if not emulated and not no_torch:
+        ranks_info["device_name"] = torch.cuda.get_device_name(device)
     spans_total = float(sum(per_rank_spans))   # (alibaba-full: every level is a reconstruction of all spans -- its units hold them)
     acc_levels = []
     if full:
@@ -770,6 +781,7 @@ def run_workload(args, c, primary=True):
             **({"accuracy_by_level": dict(zip(args.levels.split(","), acc_levels))} if full else {}),
             "budget_windows": int(counters[0]), "repaired_windows": int(counters[1]), "windows": int(counters[2]), "unassigned": int(counters[3]),
             "repair_rounds_per_pass": float(np.mean(rounds)),
+            "ranks": ranks_info,
             "gpu_pass_ms": {"pass1": float(np.mean(pass_ms[0::2])), "pass2": float(np.mean(pass_ms[1::2]))},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -897,7 +909,7 @@ def main():
             r = run_workload(a, c, primary=False)
             if c.rank == 0:
                 regs[key] = {k: r[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "config", "accuracy", "budget_windows",
-                                               "sharded_equals_single_gpu", "roofline") if k in r}
+                                               "sharded_equals_single_gpu", "roofline", "ranks", "gpu_pass_ms") if k in r}
                 if "accuracy_by_level" in r:
                     regs[key]["accuracy_by_level"] = r["accuracy_by_level"]
         if c.rank == 0:

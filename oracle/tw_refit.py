@@ -125,14 +125,30 @@ def kmeans_labels(x, k, tape):
     return lloyd(xc, kmeans_plusplus(xc, k, tape), tol)
 
 
+# How the M step's column sums are taken: "pairwise" (numpy's reduction, the default: what the restatement is pinned to scikit-learn
+# with), "sequential" (left to right) or "exact" (math.fsum: correctly rounded).  All three are evaluations of the same procedure in
+# binary64; where they select different component counts for a row, the row's fit depends on the summation order -- in scikit-learn
+# too, whose sums are BLAS reductions (tests/golden/make_refit_tie_rows.py lists those rows).
+SUM_MODE = "pairwise"
+
+
+def _colsum(a):
+    if SUM_MODE == "pairwise":
+        return a.sum(axis=0)
+    if SUM_MODE == "sequential":
+        return np.cumsum(a, axis=0)[-1]
+    import math
+    return np.array([math.fsum(a[:, j]) for j in range(a.shape[1])])
+
+
 def _params(x, resp, full):
-    nk = resp.sum(axis=0) + EPS10
-    means = (resp * x[:, None]).sum(axis=0) / nk
+    nk = _colsum(resp) + EPS10
+    means = _colsum(resp * x[:, None]) / nk
     if full:
         d = x[:, None] - means[None, :]
-        cov = (resp * d * d).sum(axis=0) / nk + REG_COVAR
+        cov = _colsum(resp * d * d) / nk + REG_COVAR
     else:
-        cov = (resp * (x * x)[:, None]).sum(axis=0) / nk - means ** 2 + REG_COVAR
+        cov = _colsum(resp * (x * x)[:, None]) / nk - means ** 2 + REG_COVAR
     return nk, means, cov
 
 

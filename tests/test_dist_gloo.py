@@ -278,8 +278,30 @@ def test_bench_default_line_with_two_ranks_carries_the_sharded_modes(emu_lib):
     """`bench.py --gpus 2` without --workload (what the driver runs for its scaling record): the weak-scaling media line and,
     under `scale_regimes`, BASELINE configs 4 and 5 -- sharded per service, parents all-gathered every step, each verified
     against the single-GPU result on rank 0."""
-    r = _run_bench(emu_lib, "--gpus", "2", "--backend", "gloo", "--n-in", "600", "--replicas", "1", "--total-spans", "20000", "--levels", "1,4000")
+    import json
+    import tempfile
+
+    detail = os.path.join(tempfile.mkdtemp(), "detail.json")
+    r = _run_bench(emu_lib, "--gpus", "2", "--backend", "gloo", "--n-in", "600", "--replicas", "1", "--total-spans", "20000", "--levels", "1,4000",
+                   "--detail-file", detail)
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and "media" in r["config"]["workload"]
+    # the full record of the same run: who ran (the process group's world size and backend, every rank's device) ...
+    full = json.load(open(detail))
+    assert full["ranks"]["world_size"] == 2 and full["ranks"]["backend"] == "gloo" and full["ranks"]["device_of_rank"] == [0, 0]
+    assert all(v["ranks"]["world_size"] == 2 for v in full["scale_regimes"].values())
+    # ... and the compact line the driver would get from the same record at eight ranks (per-rank span lists of eight entries in the
+    # media line and in both sharded modes): still under 2 KB, still carrying the verification of the sharded modes
+    sys.path.insert(0, REPO)
+    import bench
+
+    full["n_gpus"] = 8
+    for rec in [full] + list(full["scale_regimes"].values()):
+        per = rec["config"]["spans_per_gpu"]
+        rec["config"]["spans_per_gpu"] = (per if isinstance(per, list) else [per, per]) * 4
+        rec["n_gpus"] = 8
+    line8 = json.dumps(bench.compact_line(full, "gpurun_out/bench_detail_n8.json"), separators=(",", ":"))
+    assert len(line8) < 2048, len(line8)
+    assert all(v["sharded_equals_single_gpu"] is True for v in json.loads(line8)["scale_regimes"].values())
     regs = r["scale_regimes"]
     assert set(regs) == {"config4_alibaba_slice_sharded", "config5_alibaba_full_sharded"}
     for v in regs.values():

@@ -2,9 +2,8 @@
 accuracy -> the reference's result files.  CPU tier through the host-emulation build; the figures are compared
 with the frozen reference run of the same corpus: the default refit (`--fit device --seed 10`) is the reference's
 procedure on the reference's RNG stream, so the run reproduces the frozen run (np.random.seed(10)) -- per service to
-the few requests whose window optimum is not unique, end to end to 0.1 pp (north_star's bar); only the millisecond-granular
-corpora (the nodejs applications: mixture components collapsed onto repeated sample values, whose fits depend on the summation
-order of scikit-learn's BLAS -- DESIGN.md 7) keep a band of 0.25 pp."""
+the few requests whose window optimum is proven not unique, end to end exactly but for the traces of those requests
+(e2e_band: a listed rule, the millisecond-granular nodejs corpora included)."""
 import os
 import pickle
 
@@ -16,9 +15,21 @@ from conftest import GOLDEN
 REF = "/root/reference"
 
 
-def e2e_band(name):
-    """Allowed distance of an end-to-end accuracy (percent) from the frozen reference run of corpus `name`."""
-    return (0.25 if name.startswith("node") else 0.1) + 1e-9
+def e2e_band(name, traces=1000):
+    """Allowed distance of an end-to-end accuracy (percent) from the frozen reference run of corpus `name` -- a listed rule, no
+    band: a trace may differ from the frozen run only through a request that lies in a window whose optimum is PROVEN not unique
+    (tests/golden/tie_windows.json: north_star's "where the ILP admits ties"), so the distance is at most those requests' share of the
+    traces (0 for most corpora, 0.2 - 0.3 pp on the millisecond-granular nodejs corpora whose windows hold such ties); a run with a
+    mixture row whose scikit-learn fit is shown to depend on the summation order (tests/golden/refit_tie_rows.json: three runs)
+    gets north_star's 0.1 pp on top."""
+    import json
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "tie_windows.json")) as f:
+        ties = sum(len(v["pass2"]) for k, v in json.load(f).items() if k.startswith("ref_%s__" % name))
+    with open(os.path.join(here, "refit_tie_rows.json")) as f:
+        rows = any(json.load(f).get(name, {}).values())
+    return 100.0 * ties / traces + (0.1 if rows else 0.0) + 1e-9
 
 
 def run_cli(tmp_path, emu_lib, rel, fix, name):
@@ -70,6 +81,20 @@ def test_corpora_that_need_span_surgery(emu_lib, tmp_path, name, rel, fix, n_ser
         assert n == len(g["in_start"]) and abs(acc - ref_acc) <= 4.0 / n, (svc, acc, ref_acc)
     ref_e2e = float(next(iter(gold.values()))["e2e_accuracy"])
     assert abs(got["accuracy"]["MaxScoreBatchSubsetWithSkips"] - ref_e2e) <= e2e_band(name)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/data"), reason="the reference's data directory is not present")
+def test_media_load75_directory_ends_where_the_reference_ends(emu_lib, tmp_path):
+    """The one shipped corpus the reference cannot finish from its directory: it keeps the first 1001 of media_load75's 1500 traces in
+    time order (executor.py:873), and a service of 1001 requests leaves a last parameter block of ONE sample -- std = NaN, the
+    reference aborts in its solver (SURVEY.md hazard H3).  The command line loads the same 1001 traces and stops with the status that
+    names exactly that: TW_ERR_NAN_PARAMS, no result files, nothing approximated."""
+    from traceweaver_amd.engine import EngineError
+
+    with pytest.raises(EngineError) as err:
+        run_cli(tmp_path, emu_lib, "data/media_microservices/media_load75/", 1, "media_load75")
+    assert err.value.code == -7 and "TW_ERR_NAN_PARAMS" in str(err.value)
+    assert not [f for f in os.listdir(str(tmp_path)) if f.endswith(".pickle")]
 
 
 def _all_corpora():

@@ -154,12 +154,12 @@ def test_unseeded_run(emu_lib):
 @pytest.mark.parametrize("dataset", ["hotel_load100", "media_load150", "nodeio_1", "node_load50"])
 def test_seeded_chain_of_whole_corpora(emu_lib, dataset):
     """CPU twin of tests/test_gpu_parity.py::test_seeded_chain_on_every_corpus: every service of a frozen reference run in the
-    run's order on one RNG stream, nothing teacher-forced -- final_parent of the frozen run outside the proven tie windows
-    (on the emulator also for the millisecond-granular corpora)."""
+    run's order on one RNG stream, nothing teacher-forced -- the frozen run's mixture table row by row (but for the rows listed as
+    summation-order dependent) and its final_parent outside the proven tie windows, on every corpus."""
     from test_gpu_parity import check_seeded_chain
 
-    n_svc, outside = check_seeded_chain(emu_lib, dataset, strict=True)
-    assert n_svc >= 2 and outside == 0
+    n_svc, listed_rows = check_seeded_chain(emu_lib, dataset)
+    assert n_svc >= 2 and listed_rows <= 1
 
 
 @pytest.mark.gpu

@@ -326,11 +326,9 @@ int launch_enumerate_all(tw_engine* e, int pass, int mode, const int32_t* listed
     bool any_lean = false;
     for (int E = std::max(e->P.lean_min_e, 1); E <= kMaxEp; E++) any_lean |= e->tile_cls_off[E + 1] > e->tile_cls_off[E];
     if (!any_lean || e->skip_mode) return TW_OK;
-    int32_t fb[kMaxEp + 1] = {}, aw[kMaxEp + 1] = {};
+    int32_t fb[kMaxEp + 1] = {};
     HIPCHK(hipMemcpyAsync(fb, e->P.fb_count, sizeof(fb), hipMemcpyDeviceToHost, e->stream));
-    if (pass == 1 && mode == 0) HIPCHK(hipMemcpyAsync(aw, e->P.any_wide, sizeof(aw), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (pass == 1 && mode == 0) for (int E = 1; E <= kMaxEp; E++) e->wide_pass1[E] = aw[E] != 0 ? 1 : 0;
     bool any = false;
     for (int E = 1; E <= kMaxEp; E++) any |= fb[E] > 0;
     if (!any) return TW_OK;
@@ -533,9 +531,11 @@ int run_pass(tw_engine* e, int pass) {
     if (pass == 1) hipLaunchKernelGGL(k_gaps, tiles, tb, 0, e->stream, P);
     HIPCHK(hipEventRecord(e->ev[EV_END], e->stream));
     HIPCHK(hipGetLastError());
-    int32_t kerr = 0;
+    int32_t kerr = 0, aw[kMaxEp + 1] = {};
     HIPCHK(hipMemcpyAsync(&kerr, P.err, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (pass == 1) HIPCHK(hipMemcpyAsync(aw, P.any_wide, sizeof(aw), hipMemcpyDeviceToHost, e->stream));   // (which classes listed spans with wide windows: pass 2 lists the same spans)
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (pass == 1) for (int E = 1; E <= kMaxEp; E++) e->wide_pass1[E] = aw[E] != 0 ? 1 : 0;
     float f = 0.f;
     HIPCHK(hipEventElapsedTime(&f, e->ev[EV_BEGIN], e->ev[EV_END])); e->ms[0] = f;
     HIPCHK(hipEventElapsedTime(&f, e->ev[EV_ENUM0], e->ev[EV_ENUM1])); e->ms[1] = f;
@@ -1419,7 +1419,7 @@ int tw_get_timing(tw_engine* e, double* ms, int32_t n) {
 
 /* Debug aid, not part of the public header: phase timers of -DTW_PROFILE builds (zeros otherwise). */
 int tw_debug_profile_hist(tw_engine* e, unsigned long long* out16) {   // item durations of the profiled kernel, by powers of two (TW_ITEM_END)
-    if (e == nullptr || out16 == nullptr) return TW_ERR_ARG;
+    if (e == nullptr || out16 == nullptr || e->state < ST_LOADED) return TW_ERR_ARG;
     HIPCHK(hipMemcpyAsync(out16, e->P.prof + 16, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return TW_OK;
