@@ -37,6 +37,7 @@ def emu_lib():
     """Engine source compiled for the host against tests/hostemu (logic checks without a GPU)."""
     os.environ["TW_TILE"] = "1"
     os.environ["TW_COOP_THREADS"] = "1"
+    os.environ.setdefault("TW_STAGE_MIN_TILES", "0")   # the small units of the CPU tier take the per-class window / selection stages too
     from tests.hostemu.build_emu import build
 
     return build()

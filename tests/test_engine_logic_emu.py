@@ -35,6 +35,15 @@ def test_emulated_engine_matches_oracle_on_stress_units(emu_lib):
     assert sum(r["repaired_windows"] for r in r1) > 0, "the stress set must exercise the consumption repair walk"
 
 
+def test_classes_joined_after_the_enumeration(emu_lib, monkeypatch):
+    """TW_CLASS_PIPELINE=0: windows and first selection over all tiles on the engine's stream (the route of small batches and of
+    skip mode) instead of per endpoint-count class on the class' stream: the same results."""
+    monkeypatch.setenv("TW_CLASS_PIPELINE", "0")
+    units, _ = parity.stress_units(parity.STRESS)
+    r1, r2, _ = parity.check_units(emu_lib, units)
+    assert sum(r["repaired_windows"] for r in r1) > 0
+
+
 def test_selection_takes_every_route_of_the_level_solver(emu_lib):
     """The selection of a component of more than four spans is solved level by level (select_dp): on the small tables of
     k_select_heavy, on the large ones of k_select_dp when a level outgrows those, by the depth-first search when a level

@@ -111,6 +111,18 @@ def test_stress_units():
     assert sum(r["repaired_windows"] for r in r1) > 0
 
 
+@pytest.mark.parametrize("env", [{"TW_STAGE_MIN_TILES": "0"}, {"TW_CLASS_PIPELINE": "0"}, {"TW_STAGE_MIN_TILES": "0", "TW_TILE_GATE": "1"}])
+def test_stress_units_staged_and_joined(env, monkeypatch):
+    """The window / selection stage per endpoint-count class on the class' stream (forced for these small units), all classes joined
+    after the enumeration, and the tile kernels gated one after the other: the same results, bit for bit against the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    units, _ = parity.stress_units(parity.STRESS)
+    extra, _ = synth.make_workload(5, 3000, services=synth.MEDIA_SERVICES, concurrency=3.0)
+    r1, r2, _ = parity.check_units(None, list(units) + list(extra))
+    assert sum(r["repaired_windows"] for r in r1) > 0
+
+
 def test_requests_longer_than_32_bit_offsets():
     """The per-thread enumeration kernel stages candidates as 32-bit offsets from the request's start: requests of 2^31 time
     units or more go to the wavefront kernel (production thresholds here; tests/test_engine_logic_emu.py has the emulated twin)."""

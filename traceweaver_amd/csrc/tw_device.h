@@ -57,6 +57,16 @@ struct PairVI {
     int32_t i;
 };
 
+// The tiles a per-span kernel of the window / selection stage is launched over: every tile of the batch (ids == nullptr: workgroup b
+// serves tile b; the repair rounds, skip mode) or the tiles of one endpoint-count class (workgroup b serves tile ids[b]) -- units of
+// different classes are independent, so a class' windows and selection run on the class' stream as soon as ITS enumeration is
+// complete, beside the longer enumerations of the other classes.  `base` = tiles before the set in the class order (the set's share
+// of the selection work lists starts at base * tile_spans), `slot` = its block of list counters and cursors (0 = all tiles, E = class E).
+struct TileSet {
+    const int32_t* ids;
+    int32_t base, n, slot;
+};
+
 // All device pointers, passed to kernels by value.
 struct Dev {
     const UnitDev* units;
@@ -100,6 +110,7 @@ struct Dev {
     int32_t* c_hi;      // last candidate index
     uint64_t* c_bits;   // kCandWords words: spans that occur in >= 1 feasible tuple
     uint64_t* gone;     // kCandWords words: candidate spans taken by earlier windows when the span's current list was computed
+    uint8_t* gone_valid;   // per incoming span: its words of `gone` have been written in this pass (else they read as zero)
     int64_t* leaves_r;  // per incoming span: tuples of the enumeration on the remaining spans (rep = 1)
     unsigned long long* frontier_big;  // pool of kFrontierBigSlots longer lists for the spans that outgrow their wavefront's buffers
     int32_t* frontier_big_busy;   // [frontier_big_slots] 1 <=> the list is in use (pool_acquire / pool_release)
@@ -117,11 +128,11 @@ struct Dev {
     // Windows whose best candidates clash, listed by k_select_fast / k_detect_gone: four lists (0 windows of <= kBruteMax spans for
     // k_select_tiny; 1 long, 2 middle and 3 very long ones for the three instantiations of k_select_heavy), each cut into kSelSeg
     // segments by tile range with a counter of its own on a cache line of its own (same-address atomics serialise: one counter per
-    // list kept k_select_fast at 1.4 ms for 150 k wavefronts).  heavy_count[(list * kSelSeg + segment) * kCtrStride]; segment s owns
-    // the positions [first tile of s, first tile of s + 1) * tile_spans of tiny_* (short windows from the front of the segment, very
+    // list kept k_select_fast at 1.4 ms for 150 k wavefronts).  heavy_count[((slot * 4 + list) * kSelSeg + segment) * kCtrStride] (slot: TileSet);
+    // segment s owns the positions (set base + [first tile of s, first tile of s + 1)) * tile_spans of tiny_* (short windows from the front of the segment, very
     // long ones from its back) and of heavy_* (long ones from the front, middle ones from the back).
     int32_t* heavy_count;
-    int32_t* heavy_next;    // [kHardNext + 1 = 6] next unclaimed item of every selection list; [4], [5]: see hard_unit
+    int32_t* heavy_next;    // [tile set slot][8] next unclaimed item of every selection list of the set; [0][4], [0][5]: see hard_unit
     int32_t *heavy_unit, *heavy_win;
     int32_t *tiny_unit, *tiny_win;
     int32_t *hard_unit, *hard_win;   // windows k_select_heavy gave up on, for k_select_dp (count and cursor: heavy_next[4], [5])

@@ -73,7 +73,18 @@ struct tw_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[kMaxEp + 1] = {};   // one stream per endpoint count: the enumeration kernels of different classes overlap
-    hipEvent_t cls_ev[kMaxEp + 2] = {};        // [0] fork, [E] class E done
+    hipEvent_t cls_ev[kMaxEp + 2] = {};        // [0] fork, [E] class E's enumeration done
+    // the window / selection stage of a class follows its enumeration on the class' stream (run_pass): the three instantiations of
+    // k_select_heavy on streams of their own beside it, forked from and joined to the class' stream
+    hipStream_t sel_stream[3] = {};
+    hipEvent_t prep_ev = nullptr;              // the per-pass fills the selection stage needs (main stream, beside the enumerations)
+    hipEvent_t post_fork[kMaxEp + 1] = {}, post_join[kMaxEp + 1][3] = {}, post_done[kMaxEp + 1] = {};
+    hipEvent_t tile_ev[kMaxEp + 1] = {};       // class E's tile kernel done (launch_enumerate: gating of the classes launched after it)
+    hipEvent_t gate_ev = nullptr;              // ... the last one recorded in the current launch_enumerate_all
+    int tile_gate = 0;                         // TW_TILE_GATE (measured on the media shape: the tile kernels one after the other take 1.9 + 1.5 + 1.9 ms, beside one another 3.7 -- off)
+    int stage_min_tiles = 1024;                // TW_STAGE_MIN_TILES: batches of fewer tiles per class on average join the classes after the enumeration (a stage is 17 small
+                                               // launches per class: the 1 M-span Alibaba-shape slice, eight classes of 300 tiles, takes 7.8 ms per step staged and 6.4 joined)
+    int pipeline = 1;                          // TW_CLASS_PIPELINE=0: every class joins the engine's stream after its enumeration (measurements, tests)
     std::string err;
     int state = ST_EMPTY;
     int tile = kTile;   // incoming spans (threads) per workgroup of the per-span kernels
@@ -216,12 +227,13 @@ const char* kernel_error_text(int code) {
     }
 }
 
+// (S: all tiles or the tiles of one endpoint-count class, TileSet in tw_device.h)
 template <class Tr>
-int run_scan(tw_engine* e, typename Tr::T* agg) {
+int run_scan(tw_engine* e, const TileSet& S, hipStream_t st, typename Tr::T* agg) {
     const Dev& P = e->P;
-    hipLaunchKernelGGL((k_scan_local<Tr>), dim3(P.n_tiles), dim3(e->tile), 0, e->stream, P, agg);
-    hipLaunchKernelGGL((k_scan_spine<Tr>), dim3(P.n_units), dim3(e->coop), 0, e->stream, P, agg);
-    hipLaunchKernelGGL((k_scan_fix<Tr>), dim3(P.n_tiles), dim3(e->tile), 0, e->stream, P, agg);
+    hipLaunchKernelGGL((k_scan_local<Tr>), dim3(S.n), dim3(e->tile), 0, st, P, S, agg);
+    hipLaunchKernelGGL((k_scan_spine<Tr>), dim3(P.n_units), dim3(e->coop), 0, st, P, S, agg);
+    hipLaunchKernelGGL((k_scan_fix<Tr>), dim3(S.n), dim3(e->tile), 0, st, P, S, agg);
     HIPCHK(hipGetLastError());
     return TW_OK;
 }
@@ -256,6 +268,10 @@ void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
     if (n_narrow == 0 && n_wide == 0) return;
     hipStream_t st = e->cls_stream[E];
     (void)hipStreamWaitEvent(st, e->cls_ev[0], 0);
+    // The tile kernel of a class that fills the GPU runs before those of the classes with fewer endpoints instead of beside them: its
+    // chain (wavefront kernels, merge, selection: few wavefronts, long tails) is the longest of the pass and overlaps with the tile
+    // kernels that follow, instead of starting when everything else has ended (TW_TILE_GATE: tiles from which a class gates, 0 = never)
+    if (mode == 0 && e->gate_ev != nullptr) (void)hipStreamWaitEvent(st, e->gate_ev, 0);
     const Dev& P = e->P;
     const dim3 hb(std::min(e->coop, kHeavyThreads));
     const int pool = E > 4 ? 2048 : (E > 1 ? kPairPoolPerEp * E : 1);       // doubles of pair-term tables per wavefront of k_enumerate_heavy
@@ -283,6 +299,7 @@ void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
             hipLaunchKernelGGL((k_enumerate_tile<E, kSubTileSpans>), dim3(nt * sub), tile_block, 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt, sub);
         else
             hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt * sub), tile_block, 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt, sub);
+        if (e->tile_gate > 0 && nt >= e->tile_gate) { (void)hipEventRecord(e->tile_ev[E], st); e->gate_ev = e->tile_ev[E]; }
     }
     // the wavefront kernels of the class: the spans the tile kernel handed over (mode 1: the spans k_detect_gone listed), the long
     // enumerations first; the list parts of the spans those launches deferred (kListSplitFlag); the parts combined, the few spans whose
@@ -295,8 +312,7 @@ void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
         hipLaunchKernelGGL(k_merge_parts, dim3(256), dim3(std::min(e->coop, 64)), 0, st, P, pass, E, E);   // (34 KB of LDS a workgroup: a thousand of them ask for all there is)
         narrow(1, 256); if (n_wide != 0) wide(1, 64);
     }
-    (void)hipEventRecord(e->cls_ev[E], st);
-    (void)hipStreamWaitEvent(e->stream, e->cls_ev[E], 0);
+    (void)hipEventRecord(e->cls_ev[E], st);   // (who waits for it: launch_enumerate_all)
 }
 
 // What k_enumerate_lean handed on (whole spans only: P.fb_*), class by class, by k_enumerate_heavy (part 4).  Rare at scale, and a launch
@@ -313,56 +329,124 @@ void launch_fallback(tw_engine* e, int pass, int mode, const int32_t* fb) {
     hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid), hb, sizeof(double) * (size_t)pool, st, e->P, pass, mode, 4, pool);
     hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(grid), hb, sizeof(double) * (size_t)pool, st, e->P, pass, mode, 4, pool);
     (void)hipEventRecord(e->cls_ev[E], st);
-    (void)hipStreamWaitEvent(e->stream, e->cls_ev[E], 0);
 }
 
-int launch_enumerate_all(tw_engine* e, int pass, int mode, const int32_t* listed = nullptr) {
+TileSet all_tiles_host(const tw_engine* e) { return TileSet{nullptr, 0, e->P.n_tiles, 0}; }
+TileSet class_tiles(const tw_engine* e, int E) { return TileSet{e->tile_ids + e->tile_cls_off[E], e->tile_cls_off[E], e->tile_cls_off[E + 1] - e->tile_cls_off[E], E}; }
+
+// CreateWindows2 + PerfectCut (traceweaver_v3.py:1020-1078) over the tiles of S on stream st: needs the candidate sets of S's spans.
+int launch_windows(tw_engine* e, const TileSet& S, hipStream_t st) {
+    const Dev& P = e->P;
+    const dim3 tiles(S.n), tb(e->tile);
+    int rc = run_scan<ScanMaxEnd>(e, S, st, e->agg_pair);
+    if (rc != TW_OK) return rc;
+    hipLaunchKernelGGL(k_perfect_cut, tiles, tb, 0, st, P, S);
+    rc = run_scan<ScanSegStart>(e, S, st, e->agg_i32);
+    if (rc != TW_OK) return rc;
+    hipLaunchKernelGGL(k_window_flags, tiles, tb, 0, st, P, S);
+    rc = run_scan<ScanWinId>(e, S, st, e->agg_i32);
+    if (rc != TW_OK) return rc;
+    hipLaunchKernelGGL(k_window_index, tiles, tb, 0, st, P, S);
+    return TW_OK;
+}
+
+// The listed windows of the tile set S: those of up to kBruteMax spans (nearly all of them) by k_select_tiny, whose workgroups hold 1 KB
+// of LDS and fill the SIMDs, on stream st; the middle ones (up to kBigWindow - 1 spans: one-word masks, 7 KB) and the long ones (22 KB:
+// seven wavefronts per CU, ends with its longest search) by the instantiations of k_select_heavy -- each on a stream of its own,
+// forked from and joined to st by events, so that the many short windows run beside the long searches' tail instead of before it.
+// What the searches give up on goes to one list for k_select_dp (the caller launches it when every set has joined).
+void launch_select_listed(tw_engine* e, const TileSet& S, hipStream_t st, int64_t n_spans) {
+    const Dev& P = e->P;
+    const dim3 wave(std::min(e->coop, 64));
+    const dim3 grid((unsigned)std::min<int64_t>(n_spans / 2 + 1, 4096));
+    (void)hipEventRecord(e->post_fork[S.slot], st);
+    for (int j = 0; j < 3; j++) (void)hipStreamWaitEvent(e->sel_stream[j], e->post_fork[S.slot], 0);
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsLvl, 3>), grid, wave, 0, e->sel_stream[0], P, S);      // the longest searches first
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsBigLvl, 1>), grid, wave, 0, e->sel_stream[1], P, S);
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsMidLvl, 2>), grid, wave, 0, e->sel_stream[2], P, S);
+    for (int j = 0; j < 3; j++) (void)hipEventRecord(e->post_join[S.slot][j], e->sel_stream[j]);
+    hipLaunchKernelGGL(k_select_tiny, dim3((unsigned)std::min<int64_t>(n_spans / 2 + 1, 8192)), wave, 0, st, P, S);
+    for (int j = 0; j < 3; j++) (void)hipStreamWaitEvent(st, e->post_join[S.slot][j], 0);
+}
+
+// the windows the searches gave up on (kDpNodes), level by level over 256 lanes each; nothing listed: the workgroups leave at once
+void launch_select_hard(tw_engine* e, const TileSet& S, hipStream_t st) {
+    hipLaunchKernelGGL(k_select_dp, dim3(kDpCap <= 384 ? 512 : 256), dim3(std::min(e->coop, kDpThreads)), 0, st, e->P, S);   // (one / two workgroups per CU by their LDS)
+}
+
+// What follows a class' first enumeration, on the class' stream: its windows (pass 1), the first selection of its windows, the first
+// round of the span consumption (claim, detect) and -- in anticipation of that round finding nothing to repair, the usual case --
+// the parents and gap samples of its units (run_pass runs both again over all tiles when a repair round changed something).  Units
+// of different classes are independent (traceweaver_v3.py:1182-1193 runs per service): nothing here waits for another class.
+int launch_class_stage(tw_engine* e, int pass, int E) {
+    const TileSet S = class_tiles(e, E);
+    if (S.n == 0) return TW_OK;
+    hipStream_t st = e->cls_stream[E];
+    if (pass == 1) { int rc = launch_windows(e, S, st); if (rc != TW_OK) return rc; }
+    (void)hipStreamWaitEvent(st, e->prep_ev, 0);
+    hipLaunchKernelGGL(k_select_fast, dim3(S.n), dim3(e->tile), 0, st, e->P, S);
+    launch_select_listed(e, S, st, (int64_t)e->P.heavy_in_off[E + 1] - e->P.heavy_in_off[E]);
+    launch_select_hard(e, S, st);
+    const dim3 tiles(S.n), tb(e->tile);
+    hipLaunchKernelGGL(k_claim, tiles, tb, 0, st, e->P, S);
+    hipLaunchKernelGGL(k_reset_class, dim3(1), dim3(64), 0, st, e->P, E);
+    hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, st, e->P, S, 0);
+    hipLaunchKernelGGL(k_finalize, tiles, tb, 0, st, e->P, S);
+    if (pass == 1) hipLaunchKernelGGL(k_gaps, tiles, tb, 0, st, e->P, S);
+    (void)hipEventRecord(e->post_done[E], st);
+    return TW_OK;
+}
+
+// mode 0 with `staged`: every class goes on to its windows and first selection on its own stream (launch_class_stage); the engine's
+// stream waits for the enumerations (EV_ENUM1: the group's timer), then for the stages.
+template <class Prep>
+int launch_enumerate_all(tw_engine* e, int pass, int mode, const int32_t* listed, bool staged, Prep prep) {
     // (the work-list cursors were reset with the counter block of the pass / the repair round)
     (void)hipEventRecord(e->cls_ev[0], e->stream);
+    e->gate_ev = nullptr;
     // the classes with the most endpoints first: their enumerations are the longest and end the group (each class runs on a
     // stream of its own; what is launched first is dispatched first)
     launch_enumerate<8>(e, pass, mode, listed); launch_enumerate<7>(e, pass, mode, listed); launch_enumerate<6>(e, pass, mode, listed); launch_enumerate<5>(e, pass, mode, listed);
     launch_enumerate<4>(e, pass, mode, listed); launch_enumerate<3>(e, pass, mode, listed); launch_enumerate<2>(e, pass, mode, listed); launch_enumerate<1>(e, pass, mode, listed);
+    { int rc = prep(); if (rc != TW_OK) return rc; }   // (fills on the engine's stream, beside the enumerations)
+    auto has = [&](int E) { return e->tile_cls_off[E + 1] > e->tile_cls_off[E]; };
+    auto is_lean = [&](int E) { return E >= e->P.lean_min_e && !e->skip_mode; };
     bool any_lean = false;
-    for (int E = std::max(e->P.lean_min_e, 1); E <= kMaxEp; E++) any_lean |= e->tile_cls_off[E + 1] > e->tile_cls_off[E];
-    if (!any_lean || e->skip_mode) return TW_OK;
-    int32_t fb[kMaxEp + 1] = {};
-    HIPCHK(hipMemcpyAsync(fb, e->P.fb_count, sizeof(fb), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    bool any = false;
-    for (int E = 1; E <= kMaxEp; E++) any |= fb[E] > 0;
-    if (!any) return TW_OK;
-    (void)hipEventRecord(e->cls_ev[0], e->stream);
-    launch_fallback<8>(e, pass, mode, fb); launch_fallback<7>(e, pass, mode, fb); launch_fallback<6>(e, pass, mode, fb); launch_fallback<5>(e, pass, mode, fb);
-    launch_fallback<4>(e, pass, mode, fb); launch_fallback<3>(e, pass, mode, fb); launch_fallback<2>(e, pass, mode, fb); launch_fallback<1>(e, pass, mode, fb);
+    for (int E = 1; E <= kMaxEp; E++) any_lean |= has(E) && is_lean(E);
+    // the classes that are complete with their chain go on at once -- those expected to end first first (the selection streams serve
+    // the classes in this order): the fewest endpoints, or, when the tile kernels ran one after the other, the most
+    const bool deep_first = e->gate_ev != nullptr;
+    if (staged)
+        for (int k = 1; k <= kMaxEp; k++) {
+            const int E = deep_first ? kMaxEp + 1 - k : k;
+            if (has(E) && !is_lean(E)) { int rc = launch_class_stage(e, pass, E); if (rc != TW_OK) return rc; }
+        }
+    if (any_lean) {
+        // what k_enumerate_lean handed on: the host reads the counts when the lean classes' chains have ended
+        int32_t fb[kMaxEp + 1] = {};
+        int first_lean = 0;
+        for (int E = kMaxEp; E >= 1; E--)
+            if (has(E) && is_lean(E)) {
+                if (listed == nullptr || listed[E] != 0 || listed[kMaxEp + 1 + E] != 0) HIPCHK(hipEventSynchronize(e->cls_ev[E]));
+                first_lean = E;
+            }
+        HIPCHK(hipMemcpyAsync(fb, e->P.fb_count, sizeof(fb), hipMemcpyDeviceToHost, e->cls_stream[first_lean]));
+        HIPCHK(hipStreamSynchronize(e->cls_stream[first_lean]));
+        launch_fallback<8>(e, pass, mode, fb); launch_fallback<7>(e, pass, mode, fb); launch_fallback<6>(e, pass, mode, fb); launch_fallback<5>(e, pass, mode, fb);
+        launch_fallback<4>(e, pass, mode, fb); launch_fallback<3>(e, pass, mode, fb); launch_fallback<2>(e, pass, mode, fb); launch_fallback<1>(e, pass, mode, fb);
+        if (staged)
+            for (int E = 1; E <= kMaxEp; E++)
+                if (has(E) && is_lean(E)) { int rc = launch_class_stage(e, pass, E); if (rc != TW_OK) return rc; }
+    }
+    for (int E = 1; E <= kMaxEp; E++)
+        if (has(E)) (void)hipStreamWaitEvent(e->stream, e->cls_ev[E], 0);
+    HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
+    if (staged) {
+        HIPCHK(hipEventRecord(e->ev[EV_WIN], e->stream));   // (the windows are inside the class stages: what the timers show after this point is the part of the stages that outlasts the enumerations)
+        for (int E = 1; E <= kMaxEp; E++)
+            if (has(E)) (void)hipStreamWaitEvent(e->stream, e->post_done[E], 0);
+    }
     return TW_OK;
-}
-
-// The listed windows: those of up to kBruteMax spans (nearly all of them) by k_select_tiny, whose workgroups hold 1 KB of LDS
-// and fill the SIMDs; the middle ones (up to kBigWindow - 1 spans: one-word masks, 7 KB) and the long ones (22 KB: seven
-// wavefronts per CU, ends with its longest search) by the two instantiations of k_select_heavy -- each on an idle class
-// stream of its own, forked from and joined to the engine's stream by events, so that the many short windows run
-// beside the long searches' tail instead of before it.
-void launch_select_listed(tw_engine* e) {
-    const Dev& P = e->P;
-    const dim3 wave(std::min(e->coop, 64));
-    const dim3 grid((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 4096));
-    (void)hipEventRecord(e->cls_ev[0], e->stream);
-    (void)hipStreamWaitEvent(e->cls_stream[1], e->cls_ev[0], 0);
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsLvl, 3>), grid, wave, 0, e->cls_stream[1], P);      // the longest searches first
-    (void)hipEventRecord(e->cls_ev[1], e->cls_stream[1]);
-    (void)hipStreamWaitEvent(e->cls_stream[2], e->cls_ev[0], 0);
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsBigLvl, 1>), grid, wave, 0, e->cls_stream[2], P);
-    (void)hipEventRecord(e->cls_ev[2], e->cls_stream[2]);
-    (void)hipStreamWaitEvent(e->cls_stream[3], e->cls_ev[0], 0);
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsMidLvl, 2>), grid, wave, 0, e->cls_stream[3], P);
-    (void)hipEventRecord(e->cls_ev[3], e->cls_stream[3]);
-    hipLaunchKernelGGL(k_select_tiny, dim3((unsigned)std::min<int64_t>(P.n_in_total / 2 + 1, 8192)), wave, 0, e->stream, P);
-    (void)hipStreamWaitEvent(e->stream, e->cls_ev[1], 0);
-    (void)hipStreamWaitEvent(e->stream, e->cls_ev[2], 0);
-    (void)hipStreamWaitEvent(e->stream, e->cls_ev[3], 0);
-    // the windows the searches gave up on (kDpNodes), level by level over 256 lanes each; nothing listed: the workgroups leave at once
-    hipLaunchKernelGGL(k_select_dp, dim3(kDpCap <= 384 ? 512 : 256), dim3(std::min(e->coop, kDpThreads)), 0, e->stream, P);   // (one / two workgroups per CU by their LDS)
 }
 
 // OR of (key ^ first key) and of the keys themselves over a set of index ranges (see k_key_bits)
@@ -472,21 +556,30 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventRecord(e->ev[EV_PARAMS], e->stream));
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
     const auto host_t1 = std::chrono::steady_clock::now();
-    { int rc = launch_enumerate_all(e, pass, 0); if (rc != TW_OK) return rc; }
-    e->host_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t1).count();
-    HIPCHK(hipEventRecord(e->ev[EV_ENUM1], e->stream));
-    if (pass == 1) {
-        int rc = run_scan<ScanMaxEnd>(e, e->agg_pair);
+    // Every class on its own stream: enumeration, then (staged) its windows and the first selection of its windows, while the longer
+    // enumerations of other classes are still running.  TW_CLASS_PIPELINE=0 / skip mode: the classes join after the enumeration.
+    int n_cls = 0;
+    for (int E = 1; E <= kMaxEp; E++) n_cls += e->tile_cls_off[E + 1] > e->tile_cls_off[E] ? 1 : 0;
+    const bool staged = !e->skip_mode && e->pipeline != 0 && P.n_tiles >= (int64_t)e->stage_min_tiles * std::max(n_cls, 1);
+    {
+        // what the selection stage and the repair rounds start from: filled on the engine's stream beside the enumerations
+        int rc = launch_enumerate_all(e, pass, 0, nullptr, staged, [&]() -> int {
+            if (e->skip_mode) return TW_OK;
+            HIPCHK(hipMemsetAsync(P.w_conf, 0, sizeof(int32_t) * (size_t)P.n_in_total, e->stream));
+            HIPCHK(hipMemsetAsync(P.gone_valid, 0, (size_t)P.n_in_total, e->stream));   // (P.gone itself is not filled: k_detect_gone)
+            HIPCHK(hipMemsetAsync(P.w_dirty, 0, (size_t)P.n_in_total, e->stream));
+            HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
+            HIPCHK(hipEventRecord(e->prep_ev, e->stream));
+            return TW_OK;
+        });
         if (rc != TW_OK) return rc;
-        hipLaunchKernelGGL(k_perfect_cut, tiles, tb, 0, e->stream, P);
-        rc = run_scan<ScanSegStart>(e, e->agg_i32);
-        if (rc != TW_OK) return rc;
-        hipLaunchKernelGGL(k_window_flags, tiles, tb, 0, e->stream, P);
-        rc = run_scan<ScanWinId>(e, e->agg_i32);
-        if (rc != TW_OK) return rc;
-        hipLaunchKernelGGL(k_window_index, tiles, tb, 0, e->stream, P);
     }
-    HIPCHK(hipEventRecord(e->ev[EV_WIN], e->stream));
+    e->host_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t1).count();
+    if (pass == 1 && !staged) {
+        int rc = launch_windows(e, all_tiles_host(e), e->stream);
+        if (rc != TW_OK) return rc;
+    }
+    if (!staged) HIPCHK(hipEventRecord(e->ev[EV_WIN], e->stream));
     if (e->skip_mode) {   // the reference's loop in its own order, one wavefront per unit (tw_skip.h)
         HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
         HIPCHK(hipMemsetAsync(e->skip_fetch, 0, sizeof(long long) * (size_t)std::max<int64_t>(e->skip_fetch_n, 1), e->stream));
@@ -494,7 +587,7 @@ int run_pass(tw_engine* e, int pass) {
         hipLaunchKernelGGL(k_skip_walk, dim3(P.n_units), dim3(std::min(e->coop, 64)), 0, e->stream, P, (const SkipUnitDev*)e->skip_units);
         HIPCHK(hipEventRecord(e->ev[EV_SEL], e->stream));
         HIPCHK(hipEventRecord(e->ev[EV_REPAIR], e->stream));
-        hipLaunchKernelGGL(k_finalize, tiles, tb, 0, e->stream, P);
+        hipLaunchKernelGGL(k_finalize, tiles, tb, 0, e->stream, P, all_tiles_host(e));
         HIPCHK(hipEventRecord(e->ev[EV_END], e->stream));
         HIPCHK(hipGetLastError());
         int32_t kerr0 = 0;
@@ -503,19 +596,21 @@ int run_pass(tw_engine* e, int pass) {
         if (kerr0 != 0) return fail(e, kerr0, kernel_error_text(kerr0));
         return TW_OK;
     }
-    HIPCHK(hipMemsetAsync(P.w_conf, 0, sizeof(int32_t) * (size_t)P.n_in_total, e->stream));
-    hipLaunchKernelGGL(k_select_fast, tiles, tb, 0, e->stream, P);
-    launch_select_listed(e);
+    if (!staged) {
+        hipLaunchKernelGGL(k_select_fast, tiles, tb, 0, e->stream, P, all_tiles_host(e));
+        launch_select_listed(e, all_tiles_host(e), e->stream, P.n_in_total);
+        launch_select_hard(e, all_tiles_host(e), e->stream);
+    }
     HIPCHK(hipEventRecord(e->ev[EV_SEL], e->stream));
     // span consumption: rounds of claim / detect / re-enumerate / re-select until no span's set of taken candidates changes
-    HIPCHK(hipMemsetAsync(P.gone, 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(e->n_ie * kCandWords, 1), e->stream));
-    HIPCHK(hipMemsetAsync(P.w_dirty, 0, (size_t)P.n_in_total, e->stream));
     e->rounds = 0;
     for (int round = 0;; round++) {
-        HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
-        hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P);
-        HIPCHK(hipMemsetAsync(e->ctr, 0, sizeof(int32_t) * (size_t)e->ctr_round_ints, e->stream));   // work lists, round_changed, frontier cursors
-        hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, e->stream, P, round);
+        if (!(staged && round == 0)) {   // (staged: the first round ran class by class, launch_class_stage)
+            if (round > 0) HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
+            hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P, all_tiles_host(e));
+            HIPCHK(hipMemsetAsync(e->ctr, 0, sizeof(int32_t) * (size_t)e->ctr_round_ints, e->stream));   // work lists, round_changed, frontier cursors
+            hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, e->stream, P, all_tiles_host(e), round);
+        }
         int32_t changed = 0, listed[2 * (kMaxEp + 1)] = {};
         HIPCHK(hipMemcpyAsync(&changed, P.round_changed, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipMemcpyAsync(listed, P.heavy_in_count, sizeof(listed), hipMemcpyDeviceToHost, e->stream));   // (what k_detect_gone listed, per class and instantiation)
@@ -523,12 +618,16 @@ int run_pass(tw_engine* e, int pass) {
         if (changed == 0) break;
         if (round >= kMaxRepairRounds) return fail(e, TW_ERR_DEVICE, "span consumption did not settle (more repair rounds than windows)");
         e->rounds = round + 1;
-        { int rc = launch_enumerate_all(e, pass, 1, listed); if (rc != TW_OK) return rc; }
-        launch_select_listed(e);
+        { int rc = launch_enumerate_all(e, pass, 1, listed, false, []() { return (int)TW_OK; }); if (rc != TW_OK) return rc; }
+        launch_select_listed(e, all_tiles_host(e), e->stream, P.n_in_total);
+        launch_select_hard(e, all_tiles_host(e), e->stream);
     }
     HIPCHK(hipEventRecord(e->ev[EV_REPAIR], e->stream));
-    hipLaunchKernelGGL(k_finalize, tiles, tb, 0, e->stream, P);
-    if (pass == 1) hipLaunchKernelGGL(k_gaps, tiles, tb, 0, e->stream, P);
+    if (!(staged && e->rounds == 0)) {   // (staged and nothing repaired: the classes' stages have written parents and gap samples)
+        if (staged) hipLaunchKernelGGL(k_reset_stats, dim3((unsigned)((P.n_units + 255) / 256)), dim3(256), 0, e->stream, P);
+        hipLaunchKernelGGL(k_finalize, tiles, tb, 0, e->stream, P, all_tiles_host(e));
+        if (pass == 1) hipLaunchKernelGGL(k_gaps, tiles, tb, 0, e->stream, P, all_tiles_host(e));
+    }
     HIPCHK(hipEventRecord(e->ev[EV_END], e->stream));
     HIPCHK(hipGetLastError());
     int32_t kerr = 0, aw[kMaxEp + 1] = {};
@@ -721,8 +820,27 @@ int tw_create(int device_id, tw_engine** out) {
     // endpoints highest -- takes the media shape's enumeration from 4.6 to 4.4 ms per launch set and the nodejs shape's from 0.9
     // to 1.2 ms: streams created with a priority, any, are mapped to the hardware queues differently and that shape's two classes
     // partly serialise.  Only the long classes prioritised: no change.  Plain streams.)
-    for (int i = 1; i <= kMaxEp && s == hipSuccess; i++) s = hipStreamCreate(&e->cls_stream[i]);
+    // Round 6, with the classes' window / selection stages on their streams: what a deep class' tile kernel gains by going first is no
+    // longer lost to a join -- its wavefront kernels and its stage then run beside the other classes' tile kernels.  TW_PRIO_MIN_E:
+    // classes from this many endpoints on get the high priority (0 = plain streams everywhere).
+    const int prio_min_e = env_int("TW_PRIO_MIN_E", 0);
+    int prio_least = 0, prio_greatest = 0;
+    if (s == hipSuccess) s = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    for (int i = 1; i <= kMaxEp && s == hipSuccess; i++)
+        s = (prio_min_e > 0 && i >= prio_min_e && prio_greatest != prio_least) ? hipStreamCreateWithPriority(&e->cls_stream[i], hipStreamDefault, prio_greatest)
+                                                                                : hipStreamCreate(&e->cls_stream[i]);
     for (int i = 0; i <= kMaxEp + 1 && s == hipSuccess; i++) s = hipEventCreateWithFlags(&e->cls_ev[i], hipEventDisableTiming);
+    for (int i = 0; i < 3 && s == hipSuccess; i++) s = hipStreamCreate(&e->sel_stream[i]);
+    if (s == hipSuccess) s = hipEventCreateWithFlags(&e->prep_ev, hipEventDisableTiming);
+    for (int i = 0; i <= kMaxEp && s == hipSuccess; i++) {
+        s = hipEventCreateWithFlags(&e->post_fork[i], hipEventDisableTiming);
+        if (s == hipSuccess) s = hipEventCreateWithFlags(&e->tile_ev[i], hipEventDisableTiming);
+        if (s == hipSuccess) s = hipEventCreateWithFlags(&e->post_done[i], hipEventDisableTiming);
+        for (int j = 0; j < 3 && s == hipSuccess; j++) s = hipEventCreateWithFlags(&e->post_join[i][j], hipEventDisableTiming);
+    }
+    e->pipeline = env_int("TW_CLASS_PIPELINE", 1);
+    e->tile_gate = env_int("TW_TILE_GATE", 0);
+    e->stage_min_tiles = env_int("TW_STAGE_MIN_TILES", 1024);
     e->tile_sub_max = std::max(env_int("TW_TILE_SUB", 8), 1);   // workgroups per tile for classes of few tiles (1 = never)
     e->lean_pool = std::min(std::max(env_int("TW_LEAN_POOL", 512), 1), 4096);
     if (s != hipSuccess) {
@@ -745,6 +863,16 @@ void tw_destroy(tw_engine* e) {
         if (e->cls_ev[i]) (void)hipEventDestroy(e->cls_ev[i]);
     for (int i = 1; i <= kMaxEp; i++)
         if (e->cls_stream[i]) (void)hipStreamDestroy(e->cls_stream[i]);
+    for (int i = 0; i < 3; i++)
+        if (e->sel_stream[i]) (void)hipStreamDestroy(e->sel_stream[i]);
+    if (e->prep_ev) (void)hipEventDestroy(e->prep_ev);
+    for (int i = 0; i <= kMaxEp; i++) {
+        if (e->post_fork[i]) (void)hipEventDestroy(e->post_fork[i]);
+        if (e->tile_ev[i]) (void)hipEventDestroy(e->tile_ev[i]);
+        if (e->post_done[i]) (void)hipEventDestroy(e->post_done[i]);
+        for (int j = 0; j < 3; j++)
+            if (e->post_join[i][j]) (void)hipEventDestroy(e->post_join[i][j]);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -924,7 +1052,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.tk_idx, ie * kTopK); ALLOC(P.tkr_idx, ie * kTopK);
     ALLOC(P.tk_score, n_in_total * kTopK); ALLOC(P.tkr_score, n_in_total * kTopK);
     ALLOC(P.c_lo, ie); ALLOC(P.c_hi, ie); ALLOC(P.c_bits, ie * kCandWords); ALLOC(P.parent, ie);
-    ALLOC(P.gone, ie * kCandWords); ALLOC(P.leaves_r, n_in_total);
+    ALLOC(P.gone, ie * kCandWords); ALLOC(P.gone_valid, n_in_total); ALLOC(P.leaves_r, n_in_total);
     ALLOC(P.frontier, (int64_t)kFrontierSlots * 2 * kFrontierCap); 
     // long tuple lists: a pool that grows with the batch (one list per 16 k incoming spans, 48 ... 512 of 32 MB each; recycled)
     P.frontier_big_slots = (int32_t)std::min<int64_t>(std::max<int64_t>(n_in_total / 16384, kFrontierBigSlots), std::max(kFrontierBigSlots, 512));
@@ -964,7 +1092,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     {   // the counter block (every array on a 128-byte line of its own: their atomics come from different kernels)
         int64_t at = 0;
         auto take = [&](int64_t ints) { const int64_t o = at; at += (ints + 31) / 32 * 32; return o; };
-        const int64_t o_hc = take(4 * kSelSeg * kCtrStride), o_hn = take(kHardNext + 1), o_ic = take(2 * (kMaxEp + 1)), o_in = take(8 * (kMaxEp + 1)), o_bc = take(kMaxEp + 1),
+        const int64_t o_hc = take(kSelSlots * 4 * kSelSeg * kCtrStride), o_hn = take(kSelSlots * 8), o_ic = take(2 * (kMaxEp + 1)), o_in = take(8 * (kMaxEp + 1)), o_bc = take(kMaxEp + 1),
                       o_rc = take(1), o_rd = take(kMaxEp + 1), o_fc = take(kMaxEp + 1);
         e->ctr_round_ints = at;
         const int64_t o_pu = take(kMaxEp + 1), o_sc = take(kMaxEp + 1), o_dc = take(kMaxEp + 1), o_du = take(1), o_err = take(1), o_nd = take(P.n_units), o_us = take((int64_t)P.n_units * 16);
@@ -986,7 +1114,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     }
     ALLOC(P.heavy_unit, sel_cap); ALLOC(P.heavy_win, sel_cap);
     ALLOC(P.tiny_unit, sel_cap); ALLOC(P.tiny_win, sel_cap);
-    ALLOC(P.hard_unit, sel_cap / (kBruteMax + 1) + 1); ALLOC(P.hard_win, sel_cap / (kBruteMax + 1) + 1);   // (a searched window holds more than kBruteMax spans)
+    ALLOC(P.hard_unit, sel_cap / (kBruteMax + 1) + 1 + kSelSlots); ALLOC(P.hard_win, sel_cap / (kBruteMax + 1) + 1 + kSelSlots);   // (a searched window holds more than kBruteMax spans)
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
     ALLOC(e->gaps_sorted, gaps); ALLOC(e->fit_models, slots * kMaxComp * kModelStride);
@@ -1158,6 +1286,8 @@ FitDev fit_dev(tw_engine* e) {
     F.gs_off = e->P.gs_off; F.slot_unit = e->slot_unit; F.slot_scored = e->slot_scored; F.models = e->fit_models; F.mix_n = e->mix_n_dev; F.mix_p = e->mix_p_dev;
     F.uval = e->fit_uval; F.ustart = e->fit_ustart; F.row_n = e->fit_row_n; F.row_uniq = e->fit_row_uniq;
     F.tape = e->fit_tape; F.tape_off = e->fit_tape_off; F.tape100 = e->fit_tape100; F.err = e->P.err; F.centres = e->fit_centres;
+    static const int by_row = env_int("TW_FIT_BY_ROW", 0);
+    F.by_row = by_row;
     return F;
 }
 

@@ -2090,24 +2090,29 @@ struct ScanWinId {  // inclusive count of window ends; the window id is count - 
     __device__ static T reload(const Dev& P, const UnitDev& U, int i) { return P.wid[U.in_off + i]; }
 };
 
+__device__ __forceinline__ int set_tile(const TileSet& S) { return S.ids != nullptr ? S.ids[blockIdx.x] : (int)blockIdx.x; }   // the tile of this workgroup
+__device__ __forceinline__ TileSet all_tiles(const Dev& P) { return TileSet{nullptr, 0, P.n_tiles, 0}; }
+
 template <class Tr>
-__global__ void k_scan_local(Dev P, typename Tr::T* agg) {
+__global__ void k_scan_local(Dev P, TileSet S, typename Tr::T* agg) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     __shared__ typename Tr::T sh[kTile];
-    const TileDev Tl = P.tiles[blockIdx.x];
+    const int tile = set_tile(S);
+    const TileDev Tl = P.tiles[tile];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     typename Tr::T v = i < U.n_in ? Tr::load(P, U, i) : Tr::identity();
     v = block_scan_incl(v, sh, Tr::comb);
     if (i < U.n_in) Tr::store(P, U, i, v);
-    if (threadIdx.x == blockDim.x - 1) agg[blockIdx.x] = v;
+    if (threadIdx.x == blockDim.x - 1) agg[tile] = v;
 }
 template <class Tr>
-__global__ void k_scan_spine(Dev P, typename Tr::T* agg) {  // one workgroup per unit: exclusive scan of its tiles
+__global__ void k_scan_spine(Dev P, TileSet S, typename Tr::T* agg) {  // one workgroup per unit: exclusive scan of its tiles
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     __shared__ typename Tr::T sh[kCoop];
     __shared__ typename Tr::T carry_sh;
     const UnitDev& U = P.units[blockIdx.x];
+    if (S.slot != 0 && U.E != S.slot) return;   // (a class' launch: the units of the other classes are not its business)
     const int t = threadIdx.x, n = blockDim.x;
     if (t == 0) carry_sh = Tr::identity();
     __syncthreads();
@@ -2124,20 +2129,21 @@ __global__ void k_scan_spine(Dev P, typename Tr::T* agg) {  // one workgroup per
     }
 }
 template <class Tr>
-__global__ void k_scan_fix(Dev P, const typename Tr::T* agg) {
+__global__ void k_scan_fix(Dev P, TileSet S, const typename Tr::T* agg) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    const TileDev Tl = P.tiles[blockIdx.x];
+    const int tile = set_tile(S);
+    const TileDev Tl = P.tiles[tile];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in || Tl.first == 0) return;
-    Tr::store(P, U, i, Tr::comb(agg[blockIdx.x], Tr::reload(P, U, i)));
+    Tr::store(P, U, i, Tr::comb(agg[tile], Tr::reload(P, U, i)));
 }
 
 // PerfectCut(i) (traceweaver_v3.py:1024-1039): candidates of the latest-ending earlier span and of
 // span i are disjoint, and that earlier span ends no later than span i.
-__global__ void k_perfect_cut(Dev P) {
+__global__ void k_perfect_cut(Dev P, TileSet S) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    const TileDev Tl = P.tiles[blockIdx.x];
+    const TileDev Tl = P.tiles[set_tile(S)];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
@@ -2168,9 +2174,9 @@ __global__ void k_perfect_cut(Dev P) {
 
 // Window ends (traceweaver_v3.py:1056-1076): the last span, the span before every PerfectCut, and a
 // size cut every batch_size_mis spans counted from the segment start.
-__global__ void k_window_flags(Dev P) {
+__global__ void k_window_flags(Dev P, TileSet S) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    const TileDev Tl = P.tiles[blockIdx.x];
+    const TileDev Tl = P.tiles[set_tile(S)];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
@@ -2185,9 +2191,9 @@ __global__ void k_window_flags(Dev P) {
     }
     P.win_end[g] = end ? 1 : 0;
 }
-__global__ void k_window_index(Dev P) {  // after the ScanWinId scan: wid currently holds the inclusive count
+__global__ void k_window_index(Dev P, TileSet S) {  // after the ScanWinId scan: wid currently holds the inclusive count
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    const TileDev Tl = P.tiles[blockIdx.x];
+    const TileDev Tl = P.tiles[set_tile(S)];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
@@ -3379,9 +3385,12 @@ constexpr int kHardCount = 4, kHardNext = 5;   // P.heavy_next[kHardCount]: wind
 constexpr int kSelSeg = 32;      // segments of the selection work lists (one counter each)
 constexpr int kCtrStride = 32;   // ints between two counters: a cache line each
 __device__ __forceinline__ int sel_first_tile(int s, int n_tiles) { return (int)(((long long)s * n_tiles + kSelSeg - 1) / kSelSeg); }  // segment s = tiles [this, next)
-__device__ __forceinline__ int32_t* sel_counter(const Dev& P, int list, int s) { return P.heavy_count + (list * kSelSeg + s) * kCtrStride; }
-// (called by the per-span kernels, one workgroup per tile: blockIdx.x is the tile)
-__device__ __forceinline__ void list_window(const Dev& P, const UnitDev& U, int unit, int w, bool listed) {
+constexpr int kSelSlots = kMaxEp + 1;   // tile sets with selection lists of their own: all tiles (the repair rounds), the classes (the first solve)
+__device__ __forceinline__ int32_t* sel_counter(const Dev& P, const TileSet& S, int list, int s) { return P.heavy_count + ((S.slot * 4 + list) * kSelSeg + s) * kCtrStride; }
+__device__ __forceinline__ int32_t* sel_cursor(const Dev& P, const TileSet& S, int list) { return P.heavy_next + S.slot * 8 + list; }
+__device__ __forceinline__ int hard_base(const Dev& P, const TileSet& S) { return (int)((long long)S.base * P.tile_spans / (kBruteMax + 1)) + S.slot; }   // the set's share of hard_unit / hard_win
+// (called by the per-span kernels, one workgroup per tile; `at` = the tile's place in the set S)
+__device__ __forceinline__ void list_window(const Dev& P, const TileSet& S, int at, const UnitDev& U, int unit, int w, bool listed) {
     int cls = -1;   // 0 short (<= kBruteMax), 1 long (kBigWindow ..), 2 middle, 3 very long (kHugeWindow ..)
     int first = 0, m = 0;
     if (listed) {
@@ -3389,11 +3398,11 @@ __device__ __forceinline__ void list_window(const Dev& P, const UnitDev& U, int 
         m = P.w_last[U.in_off + w] - first + 1;
         cls = m <= kBruteMax ? 0 : (m < kBigWindow ? 2 : (m < kHugeWindow ? 1 : 3));
     }
-    const int s = (int)((long long)blockIdx.x * kSelSeg / gridDim.x);
-    const int s0 = wave_append(sel_counter(P, 0, s), cls == 0), s1 = wave_append(sel_counter(P, 1, s), cls == 1);
-    const int s2 = wave_append(sel_counter(P, 2, s), cls == 2), s3 = wave_append(sel_counter(P, 3, s), cls == 3);
+    const int s = (int)((long long)at * kSelSeg / S.n);
+    const int s0 = wave_append(sel_counter(P, S, 0, s), cls == 0), s1 = wave_append(sel_counter(P, S, 1, s), cls == 1);
+    const int s2 = wave_append(sel_counter(P, S, 2, s), cls == 2), s3 = wave_append(sel_counter(P, S, 3, s), cls == 3);
     if (!listed) return;
-    const int base = sel_first_tile(s, (int)gridDim.x) * P.tile_spans, end = sel_first_tile(s + 1, (int)gridDim.x) * P.tile_spans;
+    const int base = (S.base + sel_first_tile(s, S.n)) * P.tile_spans, end = (S.base + sel_first_tile(s + 1, S.n)) * P.tile_spans;
     // two arrays, each filled from both ends of the segment: short windows and very long ones share tiny_*, long and middle ones heavy_*
     // (a segment has room for every window of its tiles)
     int32_t *au = (cls == 0 || cls == 3) ? P.tiny_unit : P.heavy_unit, *aw = (cls == 0 || cls == 3) ? P.tiny_win : P.heavy_win;
@@ -3406,8 +3415,8 @@ __device__ __forceinline__ void list_window(const Dev& P, const UnitDev& U, int 
 
 // Consumers: the segment counts of one list as prefix sums in LDS (first[kSelSeg] = the list's size), and the position of item i
 struct SelSegs { int first[kSelSeg + 1]; };
-__device__ __forceinline__ void sel_segments(const Dev& P, int list, SelSegs& G) {
-    for (int s = threadIdx.x; s < kSelSeg; s += blockDim.x) G.first[s + 1] = *sel_counter(P, list, s);
+__device__ __forceinline__ void sel_segments(const Dev& P, const TileSet& S, int list, SelSegs& G) {
+    for (int s = threadIdx.x; s < kSelSeg; s += blockDim.x) G.first[s + 1] = *sel_counter(P, S, list, s);
     group_sync();
     if (threadIdx.x == 0) {
         G.first[0] = 0;
@@ -3415,11 +3424,11 @@ __device__ __forceinline__ void sel_segments(const Dev& P, int list, SelSegs& G)
     }
     group_sync();
 }
-__device__ __forceinline__ int sel_position(const Dev& P, const SelSegs& G, int item, bool from_back) {
+__device__ __forceinline__ int sel_position(const Dev& P, const TileSet& S, const SelSegs& G, int item, bool from_back) {
     int lo = 0, hi = kSelSeg - 1;   // the segment with first[s] <= item < first[s + 1]
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (G.first[mid] <= item) lo = mid; else hi = mid - 1; }
     const int off = item - G.first[lo];
-    return from_back ? sel_first_tile(lo + 1, P.n_tiles) * P.tile_spans - 1 - off : sel_first_tile(lo, P.n_tiles) * P.tile_spans + off;
+    return from_back ? (S.base + sel_first_tile(lo + 1, S.n)) * P.tile_spans - 1 - off : (S.base + sel_first_tile(lo, S.n)) * P.tile_spans + off;
 }
 
 // Fast path, one lane per incoming span.  When the best candidates (list position 0) of a window's spans
@@ -3428,9 +3437,9 @@ __device__ __forceinline__ int sel_position(const Dev& P, const SelSegs& G, int 
 // weight equals the upper bound sum-of-best-weights, and only strict improvements replace the incumbent.
 // A span whose best weight is <= 0 has no eligible candidate at all (lists are sorted) and stays unassigned
 // in every selection.  ~90-99 % of the windows end here; the others are listed for k_select_heavy.
-__global__ void __launch_bounds__(kTile) k_select_fast(Dev P) {
+__global__ void __launch_bounds__(kTile) k_select_fast(Dev P, TileSet S) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    const TileDev Tl = P.tiles[blockIdx.x];
+    const TileDev Tl = P.tiles[set_tile(S)];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
@@ -3452,20 +3461,20 @@ __global__ void __launch_bounds__(kTile) k_select_fast(Dev P) {
     }
     // the first lane that finds a clash puts the window on the work list of k_select_heavy
     const bool listed = clash && atomicExch(&P.w_conf[U.in_off + w], 1) == 0;
-    list_window(P, U, Tl.unit, w, listed);
+    list_window(P, S, (int)blockIdx.x, U, Tl.unit, w, listed);
 }
 
 // LIST 1: the long windows (kBigWindow .. kHugeWindow - 1 spans; front of the segments of heavy_*; two-word masks, 12 KB of LDS),
 // LIST 2: the middle ones (back of those segments; one word, 7 KB: 21 wavefronts per CU), LIST 3: the very long ones (back of the
 // segments of tiny_*; the full layout: 22 KB, 7 wavefronts per CU)
 template <class LDS, int LIST>
-__global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent workgroups, one deferred window at a time
+__global__ void __launch_bounds__(64) k_select_heavy(Dev P, TileSet S) {  // persistent workgroups, one deferred window at a time
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     __shared__ LDS L;
     __shared__ SelectDpT<LDS::kW, kDpCapSmall, kDpSlotsSmall> D;
     __shared__ int next_item;
     __shared__ SelSegs G;
-    sel_segments(P, LIST, G);
+    sel_segments(P, S, LIST, G);
     const int count = G.first[kSelSeg];
     if ((int)blockIdx.x >= count) return;   // nothing for this workgroup (the usual case outside heavy load)
     for (int q = threadIdx.x; q < LDS::kSlots; q += blockDim.x) L.memo[q].state = 0u;
@@ -3481,7 +3490,7 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
                                        // the first chunk of a workgroup is its own (no same-address atomic storm at kernel start)
             if (first_chunk) { chunk_pos = (int)blockIdx.x * kWorkChunk; first_chunk = false; }
             else {
-                if (threadIdx.x == 0) next_item = (int)gridDim.x * kWorkChunk + atomicAdd(&P.heavy_next[LIST], kWorkChunk);
+                if (threadIdx.x == 0) next_item = (int)gridDim.x * kWorkChunk + atomicAdd(sel_cursor(P, S, LIST), kWorkChunk);
                 group_sync();
                 chunk_pos = next_item;
                 group_sync();
@@ -3501,7 +3510,7 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
             if (item < nstatic) item = (item % kWorkChunk) * (int)gridDim.x + item / kWorkChunk;
             if (item >= count) continue;
         }
-        const int pos = sel_position(P, G, item, LIST != 1);
+        const int pos = sel_position(P, S, G, item, LIST != 1);
         const int32_t *au = LIST == 3 ? P.tiny_unit : P.heavy_unit, *aw = LIST == 3 ? P.tiny_win : P.heavy_win;
         const int unit = __builtin_amdgcn_readfirstlane(au[pos]);  // wave-uniform: scalar loads below
         const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane(aw[pos]);
@@ -3512,7 +3521,7 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
 #endif
         if (select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS, false, &D, false)) {   // (uniform) a level outgrew the tables: listed for k_select_dp
             if (threadIdx.x == 0) {
-                const int at = atomicAdd(&P.heavy_next[kHardCount], 1);
+                const int at = hard_base(P, S) + atomicAdd(sel_cursor(P, S, kHardCount), 1);
                 P.hard_unit[at] = unit; P.hard_win[at] = (int32_t)fm;
                 atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 6], 1ull);
             }
@@ -3536,19 +3545,19 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P) {  // persistent wor
 // The listed windows of up to kBruteMax spans: every component is solved by complete enumeration (select_brute), so the
 // workgroup needs neither the search stack nor the transposition table -- 1 KB of LDS, and the SIMDs fill up (the full kernel
 // is limited to seven wavefronts per CU by its 22 KB, and what it does is latency-bound).  Same procedure, same results.
-__global__ void __launch_bounds__(64) k_select_tiny(Dev P) {  // persistent workgroups, one listed window at a time
+__global__ void __launch_bounds__(64) k_select_tiny(Dev P, TileSet S) {  // persistent workgroups, one listed window at a time
     if (*P.err != 0) return;
     __shared__ SelectLdsTiny L;
     __shared__ int next_item;
     __shared__ SelSegs G;
-    sel_segments(P, 0, G);
+    sel_segments(P, S, 0, G);
     const int count = G.first[kSelSeg];
     if ((int)blockIdx.x * kWorkChunk >= count) return;
     int chunk_pos = (int)blockIdx.x * kWorkChunk, chunk_end = chunk_pos + kWorkChunk;   // the first chunk of a workgroup is its own
     TW_SEL_DECL();
     while (true) {
         if (chunk_pos == chunk_end) {
-            if (threadIdx.x == 0) next_item = (int)gridDim.x * kWorkChunk + atomicAdd(&P.heavy_next[0], kWorkChunk);
+            if (threadIdx.x == 0) next_item = (int)gridDim.x * kWorkChunk + atomicAdd(sel_cursor(P, S, 0), kWorkChunk);
             group_sync();
             chunk_pos = next_item;
             group_sync();
@@ -3556,7 +3565,7 @@ __global__ void __launch_bounds__(64) k_select_tiny(Dev P) {  // persistent work
         }
         if (chunk_pos >= count) { TW_SEL_FLUSH(); break; }
         const int item = chunk_pos++;
-        const int pos = sel_position(P, G, item, false);
+        const int pos = sel_position(P, S, G, item, false);
         const int unit = __builtin_amdgcn_readfirstlane(P.tiny_unit[pos]);
         const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane(P.tiny_win[pos]);
         const UnitDev& U = P.units[unit];
@@ -3568,12 +3577,12 @@ __global__ void __launch_bounds__(64) k_select_tiny(Dev P) {  // persistent work
 // The windows k_select_heavy gave up on (a level of a component outgrew its small tables): one workgroup of kDpThreads lanes per
 // window, the same solver on tables of kDpCap states; a component that outgrows those too is searched depth first.  Launched after
 // the three instantiations of k_select_heavy have finished; with nothing listed the workgroups leave at once.
-__global__ void __launch_bounds__(kDpThreads) k_select_dp(Dev P) {
+__global__ void __launch_bounds__(kDpThreads) k_select_dp(Dev P, TileSet S) {
     if (*P.err != 0) return;
     __shared__ SelectLds L;
     __shared__ SelectDp D;
     __shared__ int next_item;
-    const int count = P.heavy_next[kHardCount];
+    const int count = *sel_cursor(P, S, kHardCount), hb = hard_base(P, S);
     if ((int)blockIdx.x >= count) return;
     for (int q = threadIdx.x; q < SelectLds::kSlots; q += blockDim.x) L.memo[q].state = 0u;
     if (threadIdx.x == 0) L.memo_gen = 0u;
@@ -3581,11 +3590,11 @@ __global__ void __launch_bounds__(kDpThreads) k_select_dp(Dev P) {
     TW_SEL_DECL();
     int item = (int)blockIdx.x;
     while (item < count) {
-        const int unit = __builtin_amdgcn_readfirstlane(P.hard_unit[item]);
-        const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane(P.hard_win[item]);
+        const int unit = __builtin_amdgcn_readfirstlane(P.hard_unit[hb + item]);
+        const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane(P.hard_win[hb + item]);
         const UnitDev& U = P.units[unit];
         select_window_coop(P, U, unit, (int)(fm >> 6), (int)(fm & 63u) + 1, L TW_SEL_PASS, true, &D, true);
-        if (threadIdx.x == 0) next_item = (int)gridDim.x + atomicAdd(&P.heavy_next[kHardNext], 1);
+        if (threadIdx.x == 0) next_item = (int)gridDim.x + atomicAdd(sel_cursor(P, S, kHardNext), 1);
         group_sync();
         item = next_item;
         group_sync();
@@ -3607,9 +3616,9 @@ __global__ void __launch_bounds__(kDpThreads) k_select_dp(Dev P) {
 // first window never changes.  Windows that do not share candidates (perfect cuts) never interact, chains of
 // size-capped windows settle front to back; all flagged windows of all units are re-solved concurrently by the same
 // wavefront kernels as the first solve.
-__global__ void k_claim(Dev P) {
+__global__ void k_claim(Dev P, TileSet S) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    const TileDev Tl = P.tiles[blockIdx.x];
+    const TileDev Tl = P.tiles[set_tile(S)];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
@@ -3619,9 +3628,19 @@ __global__ void k_claim(Dev P) {
     for (int e = 0; e < U.E; e++) atomicMin(&P.owner[U.ep_off[e] + cand_idx(P, U, i, c, e)], w);
 }
 
-__global__ void __launch_bounds__(kTile) k_detect_gone(Dev P, int round) {
+// What a repair round resets of class E's work lists (the first round of a class that runs it on its own stream, beside the other
+// classes' enumerations: the engine's fill of the whole counter block would take their lists with it)
+__global__ void k_reset_class(Dev P, int E) {
+    const int t = threadIdx.x;
+    if (t < 2) P.heavy_in_count[t * (kMaxEp + 1) + E] = 0;
+    if (t < 8) P.heavy_in_next[t * (kMaxEp + 1) + E] = 0;
+    if (t == 0) { P.heavy_big_count[E] = 0; P.redo_count[E] = 0; P.fb_count[E] = 0; }
+}
+
+__global__ void __launch_bounds__(kTile) k_detect_gone(Dev P, TileSet S, int round) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    const TileDev Tl = P.tiles[blockIdx.x];
+    const int tile = set_tile(S);
+    const TileDev Tl = P.tiles[tile];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     const bool live = i < U.n_in;
@@ -3629,6 +3648,11 @@ __global__ void __launch_bounds__(kTile) k_detect_gone(Dev P, int round) {
     const int w = P.wid[g];
     bool changed = false, any = false, narrow = true;
     if (live) {
+        // (the words of P.gone are those of this pass once gone_valid says so: until a span's first taken candidate they read as zero --
+        // no fill of the whole array per pass, 16 B per (span, endpoint))
+        const bool valid = P.gone_valid[g] != 0;
+        static_assert(kMaxEp * kCandWords <= 32, "zero_words holds one bit per (endpoint, word)");
+        uint32_t zero_words = 0;   // words found zero while the span's words were not valid: written when the span turns valid below
         for (int e = 0; e < U.E; e++) {
             const int64_t b = ie_index(U, e, i);
             const int lo = P.c_lo[b];
@@ -3640,9 +3664,16 @@ __global__ void __launch_bounds__(kTile) k_detect_gone(Dev P, int round) {
                     bits &= bits - 1;
                     if (P.owner[U.ep_off[e] + lo + 64 * wd + r] < w) gone |= 1ull << r;
                 }
-                if (gone != P.gone[b * kCandWords + wd]) { P.gone[b * kCandWords + wd] = gone; changed = true; }
+                const uint64_t old = valid ? P.gone[b * kCandWords + wd] : 0ull;
+                if (gone != old) { P.gone[b * kCandWords + wd] = gone; changed = true; }
+                else if (!valid) zero_words |= 1u << (e * kCandWords + wd);
                 any |= gone != 0;
             }
+        }
+        if (!valid && changed) {
+            for (int q = 0; q < U.E * kCandWords; q++)
+                if ((zero_words >> q) & 1u) P.gone[ie_index(U, q / kCandWords, i) * kCandWords + q % kCandWords] = 0ull;
+            P.gone_valid[g] = 1;
         }
         if (changed && !any) P.rep[g] = 0;   // nothing of this span is taken any more: its list on all spans is its list again
         if (changed) P.w_dirty[U.in_off + w] = 1;
@@ -3650,15 +3681,20 @@ __global__ void __launch_bounds__(kTile) k_detect_gone(Dev P, int round) {
     heavy_append_rt(P, U.E, changed && any, narrow, Tl.unit, i);
     // the first lane of a window that sees a change lists the window for k_select_heavy (stamp = round: no reset between rounds)
     const bool listed = changed && atomicExch(&P.w_conf[U.in_off + w], round + 2) != round + 2;
-    list_window(P, U, Tl.unit, w, listed);
+    list_window(P, all_tiles(P), tile, U, Tl.unit, w, listed);   // (the lists of the repair rounds: over all tiles)
     const unsigned long long m = __ballot(changed);
     if (m != 0 && (threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(P.round_changed, __popcll(m));
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void k_finalize(Dev P) {
+// (idempotent but for the three counters it adds to: k_reset_stats before it runs again)
+__global__ void k_reset_stats(Dev P) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < P.n_units) { P.unit_stats[(int64_t)u * 8 + 0] = 0; P.unit_stats[(int64_t)u * 8 + 1] = 0; P.unit_stats[(int64_t)u * 8 + 3] = 0; }
+}
+__global__ void k_finalize(Dev P, TileSet S) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    const TileDev Tl = P.tiles[blockIdx.x];
+    const TileDev Tl = P.tiles[set_tile(S)];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
@@ -3675,9 +3711,9 @@ __global__ void k_finalize(Dev P) {
 }
 
 // Gap samples of the current assignment per scored slot (traceweaver_v3.py:717-762); NaN = dropped.
-__global__ void k_gaps(Dev P) {
+__global__ void k_gaps(Dev P, TileSet S) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    const TileDev Tl = P.tiles[blockIdx.x];
+    const TileDev Tl = P.tiles[set_tile(S)];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
