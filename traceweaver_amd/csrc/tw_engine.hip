@@ -104,7 +104,7 @@ struct tw_engine {
     int64_t n_ie = 0, n_gp = 0, n_slots = 0, n_gaps = 0;
     // scratch for scans / sort
     PairVI* agg_pair = nullptr;
-    int32_t* agg_i32 = nullptr;
+    int32_t *agg_i32 = nullptr, *agg_i32b = nullptr;
     uint32_t *seg_in = nullptr, *seg_out = nullptr;
     int n_seg_out = 0;
     void* sort_tmp = nullptr;
@@ -335,18 +335,17 @@ TileSet all_tiles_host(const tw_engine* e) { return TileSet{nullptr, 0, e->P.n_t
 TileSet class_tiles(const tw_engine* e, int E) { return TileSet{e->tile_ids + e->tile_cls_off[E], e->tile_cls_off[E], e->tile_cls_off[E + 1] - e->tile_cls_off[E], E}; }
 
 // CreateWindows2 + PerfectCut (traceweaver_v3.py:1020-1078) over the tiles of S on stream st: needs the candidate sets of S's spans.
+// (the running maximum of the request ends -- PerfectCut's prev_index -- depends on the spans alone: run_pass computes it over all
+// tiles on the engine's stream beside the enumerations.  The rest in five launches, k_cut_scan .. k_index_fix in tw_kernels.h)
 int launch_windows(tw_engine* e, const TileSet& S, hipStream_t st) {
     const Dev& P = e->P;
     const dim3 tiles(S.n), tb(e->tile);
-    int rc = run_scan<ScanMaxEnd>(e, S, st, e->agg_pair);
-    if (rc != TW_OK) return rc;
-    hipLaunchKernelGGL(k_perfect_cut, tiles, tb, 0, st, P, S);
-    rc = run_scan<ScanSegStart>(e, S, st, e->agg_i32);
-    if (rc != TW_OK) return rc;
-    hipLaunchKernelGGL(k_window_flags, tiles, tb, 0, st, P, S);
-    rc = run_scan<ScanWinId>(e, S, st, e->agg_i32);
-    if (rc != TW_OK) return rc;
-    hipLaunchKernelGGL(k_window_index, tiles, tb, 0, st, P, S);
+    hipLaunchKernelGGL(k_cut_scan, tiles, tb, 0, st, P, S, e->agg_i32);
+    hipLaunchKernelGGL((k_scan_spine<ScanSegStart>), dim3(P.n_units), dim3(e->coop), 0, st, P, S, e->agg_i32);
+    hipLaunchKernelGGL(k_flags_scan, tiles, tb, 0, st, P, S, (const int32_t*)e->agg_i32, e->agg_i32b);
+    hipLaunchKernelGGL((k_scan_spine<ScanWinId>), dim3(P.n_units), dim3(e->coop), 0, st, P, S, e->agg_i32b);
+    hipLaunchKernelGGL(k_index_fix, tiles, tb, 0, st, P, S, (const int32_t*)e->agg_i32b);
+    HIPCHK(hipGetLastError());
     return TW_OK;
 }
 
@@ -355,10 +354,19 @@ int launch_windows(tw_engine* e, const TileSet& S, hipStream_t st) {
 // seven wavefronts per CU, ends with its longest search) by the instantiations of k_select_heavy -- each on a stream of its own,
 // forked from and joined to st by events, so that the many short windows run beside the long searches' tail instead of before it.
 // What the searches give up on goes to one list for k_select_dp (the caller launches it when every set has joined).
-void launch_select_listed(tw_engine* e, const TileSet& S, hipStream_t st, int64_t n_spans) {
+// (fork = false: everything on st, one after the other -- the stages of the classes that end before the last one have the time, and the
+// three selection streams stay free for the class whose stage ends the pass)
+void launch_select_listed(tw_engine* e, const TileSet& S, hipStream_t st, int64_t n_spans, bool fork = true) {
     const Dev& P = e->P;
     const dim3 wave(std::min(e->coop, 64));
     const dim3 grid((unsigned)std::min<int64_t>(n_spans / 2 + 1, 4096));
+    if (!fork) {
+        hipLaunchKernelGGL(k_select_tiny, dim3((unsigned)std::min<int64_t>(n_spans / 2 + 1, 8192)), wave, 0, st, P, S);
+        hipLaunchKernelGGL((k_select_heavy<SelectLdsLvl, 3>), grid, wave, 0, st, P, S);
+        hipLaunchKernelGGL((k_select_heavy<SelectLdsBigLvl, 1>), grid, wave, 0, st, P, S);
+        hipLaunchKernelGGL((k_select_heavy<SelectLdsMidLvl, 2>), grid, wave, 0, st, P, S);
+        return;
+    }
     (void)hipEventRecord(e->post_fork[S.slot], st);
     for (int j = 0; j < 3; j++) (void)hipStreamWaitEvent(e->sel_stream[j], e->post_fork[S.slot], 0);
     hipLaunchKernelGGL((k_select_heavy<SelectLdsLvl, 3>), grid, wave, 0, e->sel_stream[0], P, S);      // the longest searches first
@@ -382,17 +390,16 @@ int launch_class_stage(tw_engine* e, int pass, int E) {
     const TileSet S = class_tiles(e, E);
     if (S.n == 0) return TW_OK;
     hipStream_t st = e->cls_stream[E];
-    if (pass == 1) { int rc = launch_windows(e, S, st); if (rc != TW_OK) return rc; }
     (void)hipStreamWaitEvent(st, e->prep_ev, 0);
+    if (pass == 1) { int rc = launch_windows(e, S, st); if (rc != TW_OK) return rc; }
     hipLaunchKernelGGL(k_select_fast, dim3(S.n), dim3(e->tile), 0, st, e->P, S);
-    launch_select_listed(e, S, st, (int64_t)e->P.heavy_in_off[E + 1] - e->P.heavy_in_off[E]);
+    int deepest = 0;
+    for (int c = 1; c <= kMaxEp; c++) if (e->tile_cls_off[c + 1] > e->tile_cls_off[c]) deepest = c;
+    launch_select_listed(e, S, st, (int64_t)e->P.heavy_in_off[E + 1] - e->P.heavy_in_off[E], E == deepest);
     launch_select_hard(e, S, st);
     const dim3 tiles(S.n), tb(e->tile);
-    hipLaunchKernelGGL(k_claim, tiles, tb, 0, st, e->P, S);
-    hipLaunchKernelGGL(k_reset_class, dim3(1), dim3(64), 0, st, e->P, E);
-    hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, st, e->P, S, 0);
-    hipLaunchKernelGGL(k_finalize, tiles, tb, 0, st, e->P, S);
-    if (pass == 1) hipLaunchKernelGGL(k_gaps, tiles, tb, 0, st, e->P, S);
+    hipLaunchKernelGGL(k_claim, tiles, tb, 0, st, e->P, S, E);
+    hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, st, e->P, S, 0, pass == 1 ? 2 : 1);
     (void)hipEventRecord(e->post_done[E], st);
     return TW_OK;
 }
@@ -564,7 +571,8 @@ int run_pass(tw_engine* e, int pass) {
     {
         // what the selection stage and the repair rounds start from: filled on the engine's stream beside the enumerations
         int rc = launch_enumerate_all(e, pass, 0, nullptr, staged, [&]() -> int {
-            if (e->skip_mode) return TW_OK;
+            if (pass == 1) { int rs = run_scan<ScanMaxEnd>(e, all_tiles_host(e), e->stream, e->agg_pair); if (rs != TW_OK) return rs; }
+            if (e->skip_mode) { HIPCHK(hipEventRecord(e->prep_ev, e->stream)); return TW_OK; }
             HIPCHK(hipMemsetAsync(P.w_conf, 0, sizeof(int32_t) * (size_t)P.n_in_total, e->stream));
             HIPCHK(hipMemsetAsync(P.gone_valid, 0, (size_t)P.n_in_total, e->stream));   // (P.gone itself is not filled: k_detect_gone)
             HIPCHK(hipMemsetAsync(P.w_dirty, 0, (size_t)P.n_in_total, e->stream));
@@ -607,9 +615,9 @@ int run_pass(tw_engine* e, int pass) {
     for (int round = 0;; round++) {
         if (!(staged && round == 0)) {   // (staged: the first round ran class by class, launch_class_stage)
             if (round > 0) HIPCHK(hipMemsetAsync(P.owner, 0x7f, sizeof(int32_t) * std::max<int64_t>(P.n_out_total, 1), e->stream));
-            hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P, all_tiles_host(e));
+            hipLaunchKernelGGL(k_claim, tiles, tb, 0, e->stream, P, all_tiles_host(e), 0);
             HIPCHK(hipMemsetAsync(e->ctr, 0, sizeof(int32_t) * (size_t)e->ctr_round_ints, e->stream));   // work lists, round_changed, frontier cursors
-            hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, e->stream, P, all_tiles_host(e), round);
+            hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, e->stream, P, all_tiles_host(e), round, 0);
         }
         int32_t changed = 0, listed[2 * (kMaxEp + 1)] = {};
         HIPCHK(hipMemcpyAsync(&changed, P.round_changed, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
@@ -1115,7 +1123,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.heavy_unit, sel_cap); ALLOC(P.heavy_win, sel_cap);
     ALLOC(P.tiny_unit, sel_cap); ALLOC(P.tiny_win, sel_cap);
     ALLOC(P.hard_unit, sel_cap / (kBruteMax + 1) + 1 + kSelSlots); ALLOC(P.hard_win, sel_cap / (kBruteMax + 1) + 1 + kSelSlots);   // (a searched window holds more than kBruteMax spans)
-    ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles);
+    ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles); ALLOC(e->agg_i32b, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
     ALLOC(e->gaps_sorted, gaps); ALLOC(e->fit_models, slots * kMaxComp * kModelStride);
     ALLOC(e->fit_uval, gaps); ALLOC(e->fit_ustart, gaps); ALLOC(e->fit_row_n, slots); ALLOC(e->fit_row_uniq, slots);
@@ -1364,8 +1372,26 @@ int fit_run(tw_engine* e) {
     HIPCHK(hipMemsetAsync(e->P.err, 0, sizeof(int32_t), e->stream));
     FitDev F = fit_dev(e);
     const int threads = e->coop >= 64 ? kFitThreads : e->coop;
-    hipLaunchKernelGGL(k_fit_seed<false>, dim3((unsigned)(e->n_slots * (kMaxComp - 1))), dim3(threads), 0, e->stream, F);
-    hipLaunchKernelGGL(k_fit_em<false>, dim3((unsigned)(e->n_slots * kMaxComp)), dim3(threads), 0, e->stream, F);
+    // Model selection: the fits of one component count depend on nothing but their own k-means start -- a stream per count (the
+    // class streams, idle between the passes), seed then EM, the largest count (the longest fits) first: the EM sweeps of one count
+    // (f64 arithmetic) run beside the k-means++ walks of another (waiting on loads).  TW_FIT_STREAMS=0: two launches over all counts.
+    static const int fit_streams = env_int("TW_FIT_STREAMS", 0);
+    if (fit_streams != 0 && kMaxComp <= kMaxEp) {
+        (void)hipEventRecord(e->cls_ev[0], e->stream);
+        for (int k = kMaxComp; k >= 1; k--) {
+            FitDev Fk = F;
+            Fk.k_only = k;
+            hipStream_t st = e->cls_stream[k];
+            (void)hipStreamWaitEvent(st, e->cls_ev[0], 0);
+            if (k >= 2) hipLaunchKernelGGL(k_fit_seed<false>, dim3((unsigned)e->n_slots), dim3(threads), 0, st, Fk);
+            hipLaunchKernelGGL(k_fit_em<false>, dim3((unsigned)e->n_slots), dim3(threads), 0, st, Fk);
+            (void)hipEventRecord(e->cls_ev[k], st);
+            (void)hipStreamWaitEvent(e->stream, e->cls_ev[k], 0);
+        }
+    } else {
+        hipLaunchKernelGGL(k_fit_seed<false>, dim3((unsigned)(e->n_slots * (kMaxComp - 1))), dim3(threads), 0, e->stream, F);
+        hipLaunchKernelGGL(k_fit_em<false>, dim3((unsigned)(e->n_slots * kMaxComp)), dim3(threads), 0, e->stream, F);
+    }
     hipLaunchKernelGGL(k_fit_select, dim3((unsigned)((e->n_slots + 63) / 64)), dim3(64), 0, e->stream, F);
     hipLaunchKernelGGL(k_fit_seed<true>, dim3((unsigned)e->n_slots), dim3(threads), 0, e->stream, F);
     hipLaunchKernelGGL(k_fit_em<true>, dim3((unsigned)e->n_slots), dim3(threads), 0, e->stream, F);

@@ -78,6 +78,7 @@ struct FitDev {
     const double* tape100;  // [kMaxComp][13] draws of the refit with n components: MT19937(100)
     int32_t* err;
     double* centres;        // [n_slots][kMaxComp][1 + kMaxComp] k-means start of every fit: mean of the samples, final centres (centred)
+    int32_t k_only;         // model selection: > 0 = this launch fits only this component count, one workgroup per row (fit_run: a stream per count)
     int32_t by_row;         // model selection: 1 = the fits of a row in neighbouring workgroups (the row's walks meet in the last-level cache), 0 = all rows' fits of one count behind one another, the largest count first
 };
 
@@ -314,8 +315,8 @@ template <bool kFull>
 __device__ __forceinline__ FitRow fit_row(const FitDev& F, bool skip1) {
     FitRow R;
     const int nfit = kFull ? 1 : (int)(gridDim.x / F.n_slots);   // counts fitted per row by this launch
-    R.q = kFull ? (int64_t)blockIdx.x : (F.by_row ? (int64_t)(blockIdx.x / nfit) : (int64_t)(blockIdx.x % F.n_slots));
-    R.k = kFull ? F.mix_n[R.q] : kMaxComp - (F.by_row ? (int)(blockIdx.x % nfit) : (int)(blockIdx.x / F.n_slots));
+    R.q = (kFull || F.k_only > 0) ? (int64_t)blockIdx.x : (F.by_row ? (int64_t)(blockIdx.x / nfit) : (int64_t)(blockIdx.x % F.n_slots));
+    R.k = kFull ? F.mix_n[R.q] : (F.k_only > 0 ? F.k_only : kMaxComp - (F.by_row ? (int)(blockIdx.x % nfit) : (int)(blockIdx.x / F.n_slots)));
     const UnitDev& U = F.units[F.slot_unit[R.q]];
     R.n_all = U.n_in;
     R.row = F.gs_off[F.slot_unit[R.q]] + (R.q - U.slot_off) * (int64_t)R.n_all;

@@ -2141,12 +2141,7 @@ __global__ void k_scan_fix(Dev P, TileSet S, const typename Tr::T* agg) {
 
 // PerfectCut(i) (traceweaver_v3.py:1024-1039): candidates of the latest-ending earlier span and of
 // span i are disjoint, and that earlier span ends no later than span i.
-__global__ void k_perfect_cut(Dev P, TileSet S) {
-    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
-    const TileDev Tl = P.tiles[set_tile(S)];
-    const UnitDev& U = P.units[Tl.unit];
-    const int i = Tl.first + threadIdx.x;
-    if (i >= U.n_in) return;
+__device__ __forceinline__ uint8_t perfect_cut(const Dev& P, const UnitDev& U, int i) {
     const int64_t g = U.in_off + i;
     uint8_t cut = 0;
     if (i >= 1 && (i <= U.n_in - 2 || (U.part & TW_PART_BEFORE_CUT))) {   // (the service's last request is never tested: traceweaver_v3.py:1059)
@@ -2169,27 +2164,44 @@ __global__ void k_perfect_cut(Dev P, TileSet S) {
             cut = disjoint ? 1 : 0;
         }
     }
-    P.pc[g] = cut;
+    return cut;
+}
+__global__ void k_perfect_cut(Dev P, TileSet S) {
+    if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
+    const TileDev Tl = P.tiles[set_tile(S)];
+    const UnitDev& U = P.units[Tl.unit];
+    const int i = Tl.first + threadIdx.x;
+    if (i >= U.n_in) return;
+    P.pc[U.in_off + i] = perfect_cut(P, U, i);
 }
 
 // Window ends (traceweaver_v3.py:1056-1076): the last span, the span before every PerfectCut, and a
 // size cut every batch_size_mis spans counted from the segment start.
+__device__ __forceinline__ uint8_t window_flag(const Dev& P, const UnitDev& U, int i, int s) {   // s = latest PerfectCut position <= i
+    const int64_t g = U.in_off + i;
+    const int n = U.n_in, B = P.batch_mis;
+    bool end = (i == n - 1);
+    if (!end && P.pc[g + 1]) end = true;  // pc is 0 outside [1, n-2] (n-1 for a part that a cut follows)
+    if (!end && i >= 1) {
+        const int d = i - s - ((s == 0 && !(U.part & TW_PART_AFTER_CUT)) ? B - 1 : B);   // (the service's first request counts twice: current_count starts at 1)
+        if (d >= 0 && d % B == 0 && !P.pc[g]) end = true;
+    }
+    return end ? 1 : 0;
+}
+__device__ __forceinline__ void window_index(const Dev& P, const UnitDev& U, int unit, int i, int count) {   // count = window ends up to and including i
+    const int64_t g = U.in_off + i;
+    const int w = count - P.win_end[g];
+    P.wid[g] = w;
+    if (P.win_end[g]) P.w_last[U.in_off + w] = i;
+    if (i == U.n_in - 1) P.unit_nwin[unit] = w + 1;
+}
 __global__ void k_window_flags(Dev P, TileSet S) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const TileDev Tl = P.tiles[set_tile(S)];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
-    const int64_t g = U.in_off + i;
-    const int n = U.n_in, B = P.batch_mis;
-    bool end = (i == n - 1);
-    if (!end && P.pc[g + 1]) end = true;  // pc is 0 outside [1, n-2] (n-1 for a part that a cut follows)
-    if (!end && i >= 1) {
-        const int s = P.seg[g];
-        const int d = i - s - ((s == 0 && !(U.part & TW_PART_AFTER_CUT)) ? B - 1 : B);   // (the service's first request counts twice: current_count starts at 1)
-        if (d >= 0 && d % B == 0 && !P.pc[g]) end = true;
-    }
-    P.win_end[g] = end ? 1 : 0;
+    P.win_end[U.in_off + i] = window_flag(P, U, i, P.seg[U.in_off + i]);
 }
 __global__ void k_window_index(Dev P, TileSet S) {  // after the ScanWinId scan: wid currently holds the inclusive count
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
@@ -2197,11 +2209,56 @@ __global__ void k_window_index(Dev P, TileSet S) {  // after the ScanWinId scan:
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
-    const int64_t g = U.in_off + i;
-    const int w = P.wid[g] - P.win_end[g];
-    P.wid[g] = w;
-    if (P.win_end[g]) P.w_last[U.in_off + w] = i;
-    if (i == U.n_in - 1) P.unit_nwin[Tl.unit] = w + 1;
+    window_index(P, U, Tl.unit, i, P.wid[U.in_off + i]);
+}
+
+// The same chain in five launches instead of nine (the window stage of a class sits between its enumeration and its selection: every
+// launch is a dependent step of the pass): PerfectCut + the tile-local scan of the cut positions; the scan's fix-up + the window
+// flags + the tile-local count of the flags; the count's fix-up + the window index.  (k_scan_spine between them as before.)
+__global__ void __launch_bounds__(kTile) k_cut_scan(Dev P, TileSet S, int32_t* agg) {
+    if (*P.err != 0) return;
+    __shared__ int32_t sh[kTile];
+    const int tile = set_tile(S);
+    const TileDev Tl = P.tiles[tile];
+    const UnitDev& U = P.units[Tl.unit];
+    const int i = Tl.first + threadIdx.x;
+    const bool live = i < U.n_in;
+    const uint8_t cut = live ? perfect_cut(P, U, i) : 0;
+    if (live) P.pc[U.in_off + i] = cut;
+    int32_t v = (live && cut) ? i : ScanSegStart::identity();
+    v = block_scan_incl(v, sh, ScanSegStart::comb);
+    if (live) P.seg[U.in_off + i] = v;
+    if (threadIdx.x == blockDim.x - 1) agg[tile] = v;
+}
+__global__ void __launch_bounds__(kTile) k_flags_scan(Dev P, TileSet S, const int32_t* agg_seg, int32_t* agg_win) {
+    if (*P.err != 0) return;
+    __shared__ int32_t sh[kTile];
+    const int tile = set_tile(S);
+    const TileDev Tl = P.tiles[tile];
+    const UnitDev& U = P.units[Tl.unit];
+    const int i = Tl.first + threadIdx.x;
+    const bool live = i < U.n_in;
+    uint8_t end = 0;
+    if (live) {
+        int32_t s = P.seg[U.in_off + i];
+        if (Tl.first != 0) s = ScanSegStart::comb(agg_seg[tile], s);   // (the fix-up of k_scan_fix; P.seg itself is not read again)
+        end = window_flag(P, U, i, s);
+        P.win_end[U.in_off + i] = end;
+    }
+    int32_t v = block_scan_incl((int32_t)end, sh, ScanWinId::comb);
+    if (live) P.wid[U.in_off + i] = v;
+    if (threadIdx.x == blockDim.x - 1) agg_win[tile] = v;
+}
+__global__ void __launch_bounds__(kTile) k_index_fix(Dev P, TileSet S, const int32_t* agg_win) {
+    if (*P.err != 0) return;
+    const int tile = set_tile(S);
+    const TileDev Tl = P.tiles[tile];
+    const UnitDev& U = P.units[Tl.unit];
+    const int i = Tl.first + threadIdx.x;
+    if (i >= U.n_in) return;
+    int32_t c = P.wid[U.in_off + i];
+    if (Tl.first != 0) c = ScanWinId::comb(agg_win[tile], c);
+    window_index(P, U, Tl.unit, i, c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3616,8 +3673,16 @@ __global__ void __launch_bounds__(kDpThreads) k_select_dp(Dev P, TileSet S) {
 // first window never changes.  Windows that do not share candidates (perfect cuts) never interact, chains of
 // size-capped windows settle front to back; all flagged windows of all units are re-solved concurrently by the same
 // wavefront kernels as the first solve.
-__global__ void k_claim(Dev P, TileSet S) {
+__device__ __forceinline__ void reset_class_lists(const Dev& P, int E, int t) {
+    if (t < 2) P.heavy_in_count[t * (kMaxEp + 1) + E] = 0;
+    if (t < 8) P.heavy_in_next[t * (kMaxEp + 1) + E] = 0;
+    if (t == 0) { P.heavy_big_count[E] = 0; P.redo_count[E] = 0; P.fb_count[E] = 0; }
+}
+// reset_E > 0 (a class' own first round, launch_class_stage): the first workgroup also resets what a repair round resets of the
+// class' work lists -- the class' enumeration is complete, k_detect_gone, which lists into them, comes after this kernel
+__global__ void k_claim(Dev P, TileSet S, int reset_E) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
+    if (reset_E > 0 && blockIdx.x == 0) reset_class_lists(P, reset_E, threadIdx.x);
     const TileDev Tl = P.tiles[set_tile(S)];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
@@ -3628,16 +3693,13 @@ __global__ void k_claim(Dev P, TileSet S) {
     for (int e = 0; e < U.E; e++) atomicMin(&P.owner[U.ep_off[e] + cand_idx(P, U, i, c, e)], w);
 }
 
-// What a repair round resets of class E's work lists (the first round of a class that runs it on its own stream, beside the other
-// classes' enumerations: the engine's fill of the whole counter block would take their lists with it)
-__global__ void k_reset_class(Dev P, int E) {
-    const int t = threadIdx.x;
-    if (t < 2) P.heavy_in_count[t * (kMaxEp + 1) + E] = 0;
-    if (t < 8) P.heavy_in_next[t * (kMaxEp + 1) + E] = 0;
-    if (t == 0) { P.heavy_big_count[E] = 0; P.redo_count[E] = 0; P.fb_count[E] = 0; }
-}
+__device__ __forceinline__ void finalize_span(const Dev& P, const UnitDev& U, int unit, int i);
+__device__ __forceinline__ void gaps_span(const Dev& P, const UnitDev& U, int unit, int i);
 
-__global__ void __launch_bounds__(kTile) k_detect_gone(Dev P, TileSet S, int round) {
+// finish (a class' own first round, in anticipation of nothing to repair): 1 = the span's parents and counters (k_finalize) at once,
+// 2 = and its gap samples (k_gaps, pass 1).  What they read of other threads' writes -- w_dirty -- only changes when the round
+// finds something to repair, and then run_pass runs both again over all tiles.
+__global__ void __launch_bounds__(kTile) k_detect_gone(Dev P, TileSet S, int round, int finish) {
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
     const int tile = set_tile(S);
     const TileDev Tl = P.tiles[tile];
@@ -3684,6 +3746,8 @@ __global__ void __launch_bounds__(kTile) k_detect_gone(Dev P, TileSet S, int rou
     list_window(P, all_tiles(P), tile, U, Tl.unit, w, listed);   // (the lists of the repair rounds: over all tiles)
     const unsigned long long m = __ballot(changed);
     if (m != 0 && (threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(P.round_changed, __popcll(m));
+    if (finish >= 1 && live) finalize_span(P, U, Tl.unit, i);
+    if (finish >= 2 && live) gaps_span(P, U, Tl.unit, i);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3698,16 +3762,19 @@ __global__ void k_finalize(Dev P, TileSet S) {
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
+    finalize_span(P, U, Tl.unit, i);
+}
+__device__ __forceinline__ void finalize_span(const Dev& P, const UnitDev& U, int unit, int i) {
     const int c = P.chosen[U.in_off + i];
     if (P.rep[U.in_off + i]) P.leaves[U.in_off + i] = P.leaves_r[U.in_off + i];   // tuples of the top_k call on the remaining spans
-    if (P.win_end[U.in_off + i] && P.w_dirty[U.in_off + P.wid[U.in_off + i]]) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 8 + 3], 1ull);
+    if (P.win_end[U.in_off + i] && P.w_dirty[U.in_off + P.wid[U.in_off + i]]) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 3], 1ull);
     for (int e = 0; e < U.E; e++) {
         const int32_t x = c >= 0 ? cand_idx(P, U, i, c, e) : -1;
         P.parent[ie_index(U, e, i)] = x <= -TW_SKIP_BASE ? -2 : x;   // skip spans: ("Skip","Skip")
     }
-    if (c != 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 8 + 0], 1ull);  // traceweaver_v3.py:1201-1207
-    if (c < 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)Tl.unit * 8 + 1], 1ull);   // traceweaver_v3.py:1217
-    if (i == 0) P.unit_stats[(int64_t)Tl.unit * 8 + 2] = P.unit_nwin[Tl.unit];
+    if (c != 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 0], 1ull);  // traceweaver_v3.py:1201-1207
+    if (c < 0) atomicAdd((unsigned long long*)&P.unit_stats[(int64_t)unit * 8 + 1], 1ull);   // traceweaver_v3.py:1217
+    if (i == 0) P.unit_stats[(int64_t)unit * 8 + 2] = P.unit_nwin[unit];
 }
 
 // Gap samples of the current assignment per scored slot (traceweaver_v3.py:717-762); NaN = dropped.
@@ -3717,8 +3784,11 @@ __global__ void k_gaps(Dev P, TileSet S) {
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
+    gaps_span(P, U, Tl.unit, i);
+}
+__device__ __forceinline__ void gaps_span(const Dev& P, const UnitDev& U, int unit, int i) {
     const int E = U.E;
-    double* out = P.gaps + P.gs_off[Tl.unit];
+    double* out = P.gaps + P.gs_off[unit];
     const int64_t ist = P.in_start[U.in_off + i], ien = P.in_end[U.in_off + i];
     int32_t x[kMaxEp];
     for (int e = 0; e < E; e++) x[e] = P.parent[ie_index(U, e, i)];
