@@ -36,7 +36,7 @@ def group_of(name):
         return "params"
     if "k_evaluate" in name or "k_count_flags" in name:
         return "evaluate"
-    if any(k in name for k in ("k_scan", "k_perfect_cut", "k_window")):
+    if any(k in name for k in ("k_scan", "k_perfect_cut", "k_window", "k_cut_scan", "k_flags_scan", "k_index_fix")):
         return "windows"
     if any(k in name for k in ("k_claim", "k_detect", "k_repair")):
         return "repair"

@@ -84,6 +84,8 @@ struct tw_engine {
     int tile_gate = 0;                         // TW_TILE_GATE (measured on the media shape: the tile kernels one after the other take 1.9 + 1.5 + 1.9 ms, beside one another 3.7 -- off)
     int stage_min_tiles = 1024;                // TW_STAGE_MIN_TILES: batches of fewer tiles per class on average join the classes after the enumeration (a stage is 17 small
                                                // launches per class: the 1 M-span Alibaba-shape slice, eight classes of 300 tiles, takes 7.8 ms per step staged and 6.4 joined)
+    int prio_min_e = 0, prio_high = 0;
+    bool prio_any = false;
     int pipeline = 1;                          // TW_CLASS_PIPELINE=0: every class joins the engine's stream after its enumeration (measurements, tests)
     std::string err;
     int state = ST_EMPTY;
@@ -122,6 +124,7 @@ struct tw_engine {
     int64_t fit_tape_cap = 0;
     bool fit_prepared = false;              // the gap rows of the resident pass-1 result are sorted and run-length compressed
     int tile_sub_max = 8;
+    int32_t hard_pass1[kMaxEp + 1] = {};    // per class: windows its stage listed for k_select_dp in pass 1 (-1 not known)
     int8_t wide_pass1[kMaxEp + 1] = {};     // per class: -1 not known, 0 / 1 = the first enumeration of pass 1 listed no / some span with wide windows
     int lean_pool = 512;                    // doubles of LDS for the pair tables of k_enumerate_lean (TW_LEAN_POOL)
     bool pass1_done = false;                // tw_run_pass1 has run on the resident batch (tw_run_pass2 reads its cut-offs, windows, tuple counts)
@@ -187,6 +190,13 @@ int dev_alloc(tw_engine* e, T** p, int64_t count) {
     HIPCHK(hipMalloc(&q, bytes));
     e->allocs.push_back(q);
     *p = (T*)q;
+    return TW_OK;
+}
+
+int ensure_class_stream(tw_engine* e, int E) {
+    if (e->cls_stream[E] != nullptr) return TW_OK;
+    if (e->prio_min_e > 0 && E >= e->prio_min_e && e->prio_any) HIPCHK(hipStreamCreateWithPriority(&e->cls_stream[E], hipStreamDefault, e->prio_high));
+    else HIPCHK(hipStreamCreate(&e->cls_stream[E]));
     return TW_OK;
 }
 
@@ -378,8 +388,10 @@ void launch_select_listed(tw_engine* e, const TileSet& S, hipStream_t st, int64_
 }
 
 // the windows the searches gave up on (kDpNodes), level by level over 256 lanes each; nothing listed: the workgroups leave at once
-void launch_select_hard(tw_engine* e, const TileSet& S, hipStream_t st) {
-    hipLaunchKernelGGL(k_select_dp, dim3(kDpCap <= 384 ? 512 : 256), dim3(std::min(e->coop, kDpThreads)), 0, st, e->P, S);   // (one / two workgroups per CU by their LDS)
+// (`few`: the set listed no such window in pass 1 -- pass 2 rarely differs, and 512 workgroups of 70 KB of LDS take 0.1-0.2 ms to come and
+// go with nothing to do; the workgroups are persistent, a small grid is only slower when the guess is wrong)
+void launch_select_hard(tw_engine* e, const TileSet& S, hipStream_t st, bool few = false) {
+    hipLaunchKernelGGL(k_select_dp, dim3(few ? 32 : (kDpCap <= 384 ? 512 : 256)), dim3(std::min(e->coop, kDpThreads)), 0, st, e->P, S);   // (one / two workgroups per CU by their LDS)
 }
 
 // What follows a class' first enumeration, on the class' stream: its windows (pass 1), the first selection of its windows, the first
@@ -396,7 +408,7 @@ int launch_class_stage(tw_engine* e, int pass, int E) {
     int deepest = 0;
     for (int c = 1; c <= kMaxEp; c++) if (e->tile_cls_off[c + 1] > e->tile_cls_off[c]) deepest = c;
     launch_select_listed(e, S, st, (int64_t)e->P.heavy_in_off[E + 1] - e->P.heavy_in_off[E], E == deepest);
-    launch_select_hard(e, S, st);
+    launch_select_hard(e, S, st, pass == 2 && e->hard_pass1[E] == 0);
     const dim3 tiles(S.n), tb(e->tile);
     hipLaunchKernelGGL(k_claim, tiles, tb, 0, st, e->P, S, E);
     hipLaunchKernelGGL(k_detect_gone, tiles, tb, 0, st, e->P, S, 0, pass == 1 ? 2 : 1);
@@ -638,11 +650,14 @@ int run_pass(tw_engine* e, int pass) {
     }
     HIPCHK(hipEventRecord(e->ev[EV_END], e->stream));
     HIPCHK(hipGetLastError());
-    int32_t kerr = 0, aw[kMaxEp + 1] = {};
+    int32_t kerr = 0, aw[kMaxEp + 1] = {}, hn[kSelSlots * 8] = {};
     HIPCHK(hipMemcpyAsync(&kerr, P.err, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     if (pass == 1) HIPCHK(hipMemcpyAsync(aw, P.any_wide, sizeof(aw), hipMemcpyDeviceToHost, e->stream));   // (which classes listed spans with wide windows: pass 2 lists the same spans)
+    if (pass == 1) HIPCHK(hipMemcpyAsync(hn, P.heavy_next, sizeof(hn), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (pass == 1) for (int E = 1; E <= kMaxEp; E++) e->wide_pass1[E] = aw[E] != 0 ? 1 : 0;
+    // (a repair round's fill of the counter block takes the stages' counts with it: not known then)
+    if (pass == 1) for (int E = 1; E <= kMaxEp; E++) e->hard_pass1[E] = (staged && e->rounds == 0) ? hn[E * 8 + kHardCount] : -1;
     float f = 0.f;
     HIPCHK(hipEventElapsedTime(&f, e->ev[EV_BEGIN], e->ev[EV_END])); e->ms[0] = f;
     HIPCHK(hipEventElapsedTime(&f, e->ev[EV_ENUM0], e->ev[EV_ENUM1])); e->ms[1] = f;
@@ -799,7 +814,7 @@ extern "C" int tw_scale_load(tw_engine* e, const int32_t* unit_factor, const int
     HIPCHK(hipMemcpyAsync(const_cast<UnitDev*>(P.units), e->units.data(), sizeof(UnitDev) * e->units.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->state = ST_LOADED; e->pass1_done = false;
-    for (int E = 0; E <= kMaxEp; E++) e->wide_pass1[E] = -1;
+    for (int E = 0; E <= kMaxEp; E++) { e->wide_pass1[E] = -1; e->hard_pass1[E] = -1; }
     return TW_OK;
 }
 
@@ -834,11 +849,11 @@ int tw_create(int device_id, tw_engine** out) {
     const int prio_min_e = env_int("TW_PRIO_MIN_E", 0);
     int prio_least = 0, prio_greatest = 0;
     if (s == hipSuccess) s = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    for (int i = 1; i <= kMaxEp && s == hipSuccess; i++)
-        s = (prio_min_e > 0 && i >= prio_min_e && prio_greatest != prio_least) ? hipStreamCreateWithPriority(&e->cls_stream[i], hipStreamDefault, prio_greatest)
-                                                                                : hipStreamCreate(&e->cls_stream[i]);
+    // (the class streams are created when a batch first holds the class, tw_load_batch: the streams of a process share its hardware
+    // queues, and a queue shared by two busy streams runs their kernels one after the other -- an engine that only ever sees three
+    // classes owns seven streams, not twelve)
+    e->prio_min_e = prio_min_e; e->prio_high = prio_greatest; e->prio_any = prio_greatest != prio_least;
     for (int i = 0; i <= kMaxEp + 1 && s == hipSuccess; i++) s = hipEventCreateWithFlags(&e->cls_ev[i], hipEventDisableTiming);
-    for (int i = 0; i < 3 && s == hipSuccess; i++) s = hipStreamCreate(&e->sel_stream[i]);
     if (s == hipSuccess) s = hipEventCreateWithFlags(&e->prep_ev, hipEventDisableTiming);
     for (int i = 0; i <= kMaxEp && s == hipSuccess; i++) {
         s = hipEventCreateWithFlags(&e->post_fork[i], hipEventDisableTiming);
@@ -993,6 +1008,10 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
             if (e->units[(size_t)u].E == cls) heavy_off_h[cls + 1] += e->units[(size_t)u].n_in;
     }
     e->tile_cls_off[kMaxEp + 1] = (int32_t)tile_ids_h.size();
+    for (int cls = 1; cls <= kMaxEp; cls++)
+        if (e->tile_cls_off[cls + 1] > e->tile_cls_off[cls]) { int rs = ensure_class_stream(e, cls); if (rs != TW_OK) return rs; }
+    for (int j = 0; j < 3; j++)
+        if (e->sel_stream[j] == nullptr) HIPCHK(hipStreamCreate(&e->sel_stream[j]));
     const int64_t n_in_total = b->unit_in_off[b->n_units], n_out_total = b->ep_off[epi];
     if (n_in_total >= (1ll << 31) || n_out_total >= (1ll << 31)) return fail(e, TW_ERR_ARG, "batch exceeds 2^31 spans");
     if (gaps >= (1ll << 31)) return fail(e, TW_ERR_ARG, "batch too large: sum of nslot*n_in must stay below 2^31");
@@ -1212,7 +1231,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipStreamSynchronize(e->stream));
     e->scaled_upload = b->unit_time_scale != nullptr;
     e->state = ST_LOADED; e->pass1_done = false;
-    for (int E = 0; E <= kMaxEp; E++) e->wide_pass1[E] = -1;
+    for (int E = 0; E <= kMaxEp; E++) { e->wide_pass1[E] = -1; e->hard_pass1[E] = -1; }
     return TW_OK;
 }
 
@@ -1379,6 +1398,7 @@ int fit_run(tw_engine* e) {
     if (fit_streams != 0 && kMaxComp <= kMaxEp) {
         (void)hipEventRecord(e->cls_ev[0], e->stream);
         for (int k = kMaxComp; k >= 1; k--) {
+            { int rs = ensure_class_stream(e, k); if (rs != TW_OK) return rs; }
             FitDev Fk = F;
             Fk.k_only = k;
             hipStream_t st = e->cls_stream[k];
