@@ -84,6 +84,8 @@ struct tw_engine {
     int tile_gate = 0;                         // TW_TILE_GATE (measured on the media shape: the tile kernels one after the other take 1.9 + 1.5 + 1.9 ms, beside one another 3.7 -- off)
     int stage_min_tiles = 1024;                // TW_STAGE_MIN_TILES: batches of fewer tiles per class on average join the classes after the enumeration (a stage is 17 small
                                                // launches per class: the 1 M-span Alibaba-shape slice, eight classes of 300 tiles, takes 7.8 ms per step staged and 6.4 joined)
+    int32_t *rank_in = nullptr, *rank_out = nullptr;   // scratch of sort_ends: rank of a span's end time less its index
+    bool class_params = false;                 // pass 1 of a staged batch: sort_ends / k_block_params per class on the class' stream
     int prio_min_e = 0, prio_high = 0;
     bool prio_any = false;
     int pipeline = 1;                          // TW_CLASS_PIPELINE=0: every class joins the engine's stream after its enumeration (measurements, tests)
@@ -248,6 +250,19 @@ int run_scan(tw_engine* e, const TileSet& S, hipStream_t st, typename Tr::T* agg
     return TW_OK;
 }
 
+TileSet all_tiles_host(const tw_engine* e) { return TileSet{nullptr, 0, e->P.n_tiles, 0}; }
+TileSet class_tiles(const tw_engine* e, int E) { return TileSet{e->tile_ids + e->tile_cls_off[E], e->tile_cls_off[E], e->tile_cls_off[E + 1] - e->tile_cls_off[E], E}; }
+
+// (no-skip batches: every endpoint list holds one span per incoming span, all lists sorted by (start, end))
+int sort_ends(tw_engine* e, const TileSet& S, hipStream_t st) {   // (the counters e->rank_in / rank_out zeroed by the caller)
+    const Dev& P = e->P;
+    const dim3 tiles(S.n), tb(e->tile);
+    hipLaunchKernelGGL(k_rank_ends, tiles, tb, 0, st, P, S, e->rank_in, e->rank_out);
+    hipLaunchKernelGGL(k_place_ends, tiles, tb, 0, st, P, S, (const int32_t*)e->rank_in, (const int32_t*)e->rank_out);
+    HIPCHK(hipGetLastError());
+    return TW_OK;
+}
+
 // mode 0: first solve on all spans (per-thread kernel, then the wavefront kernel for the spans it deferred);
 // mode 1: the spans listed by k_detect_gone, without the candidate spans earlier windows took
 // The classes (units of one endpoint count) are independent of one another and every class' kernels end in a long tail
@@ -299,6 +314,12 @@ void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
         if (lean) hipLaunchKernelGGL((k_enumerate_lean<64 * kCandWords>), dim3(g), hb, lean_bytes_w, st, P, pass, mode, part, e->lean_pool, E, E);
         else hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(g), hb, pool_bytes, st, P, pass, mode, part, pool);
     };
+    if (mode == 0 && pass == 1 && e->class_params) {   // the class' sorted end times and block parameters (run_pass)
+        const TileSet S = class_tiles(e, E);
+        (void)sort_ends(e, S, st);
+        const int64_t total = e->n_gp;
+        hipLaunchKernelGGL(k_block_params, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, total, E);
+    }
     if (mode == 0) {
         // cut-offs and work lists, the short enumerations: the tile kernel.  A class of few tiles: several workgroups per tile, until
         // the class fills the CUs twice over
@@ -341,8 +362,6 @@ void launch_fallback(tw_engine* e, int pass, int mode, const int32_t* fb) {
     (void)hipEventRecord(e->cls_ev[E], st);
 }
 
-TileSet all_tiles_host(const tw_engine* e) { return TileSet{nullptr, 0, e->P.n_tiles, 0}; }
-TileSet class_tiles(const tw_engine* e, int E) { return TileSet{e->tile_ids + e->tile_cls_off[E], e->tile_cls_off[E], e->tile_cls_off[E + 1] - e->tile_cls_off[E], E}; }
 
 // CreateWindows2 + PerfectCut (traceweaver_v3.py:1020-1078) over the tiles of S on stream st: needs the candidate sets of S's spans.
 // (the running maximum of the request ends -- PerfectCut's prev_index -- depends on the spans alone: run_pass computes it over all
@@ -539,17 +558,6 @@ int sort_rows(tw_engine* e, const Key* keys, Key* out, unsigned size, const uint
 
 // (no-skip batches: every endpoint list holds one span per incoming span, all lists sorted by (start, end).  The counters
 // borrow two per-span words that the pass writes only later: the window ids and the owner words)
-int sort_ends(tw_engine* e) {
-    const Dev& P = e->P;
-    const dim3 tiles(P.n_tiles), tb(e->tile);
-    HIPCHK(hipMemsetAsync(P.wid, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(P.n_in_total, 1), e->stream));
-    HIPCHK(hipMemsetAsync(P.owner, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(P.n_out_total, 1), e->stream));
-    hipLaunchKernelGGL(k_rank_ends, tiles, tb, 0, e->stream, P, P.wid, P.owner);
-    hipLaunchKernelGGL(k_place_ends, tiles, tb, 0, e->stream, P, (const int32_t*)P.wid, (const int32_t*)P.owner);
-    HIPCHK(hipGetLastError());
-    return TW_OK;
-}
-
 int run_pass(tw_engine* e, int pass) {
     const Dev& P = e->P;
     const dim3 tiles(P.n_tiles), tb(e->tile);
@@ -560,11 +568,24 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipMemsetAsync(P.prof + 5, 0, sizeof(unsigned long long) * 3, e->stream));    // the longest item / wavefront of THIS pass (the sums run on)
     HIPCHK(hipMemsetAsync(P.prof + 10, 0, sizeof(unsigned long long) * 3, e->stream));
 #endif
+    // Every class on its own stream: enumeration, then (staged) its windows and the first selection of its windows, while the longer
+    // enumerations of other classes are still running.  TW_CLASS_PIPELINE=0 / skip mode / small batches: the classes join after the enumeration.
+    int n_cls = 0;
+    for (int E = 1; E <= kMaxEp; E++) n_cls += e->tile_cls_off[E + 1] > e->tile_cls_off[E] ? 1 : 0;
+    const bool staged = !e->skip_mode && e->pipeline != 0 && P.n_tiles >= (int64_t)e->stage_min_tiles * std::max(n_cls, 1);
+    // pass 1, ComputeEpPairDistParams3: sorted end times and block parameters -- staged: per class, at the head of the class' chain
+    // (launch_enumerate: the class with the longest chain does not wait for the parameters of the others)
+    e->class_params = false;
     if (pass == 1 && !e->skip_mode) {
-        int rc = sort_ends(e);
-        if (rc != TW_OK) return rc;
-        const int64_t total = e->n_gp;
-        hipLaunchKernelGGL(k_block_params, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, P, total);
+        HIPCHK(hipMemsetAsync(e->rank_in, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(P.n_in_total, 1), e->stream));
+        HIPCHK(hipMemsetAsync(e->rank_out, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(P.n_out_total, 1), e->stream));
+        if (staged) e->class_params = true;
+        else {
+            int rc = sort_ends(e, all_tiles_host(e), e->stream);
+            if (rc != TW_OK) return rc;
+            const int64_t total = e->n_gp;
+            hipLaunchKernelGGL(k_block_params, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, P, total, 0);
+        }
     }
     if (e->skip_mode) {
         // ComputeEpPairDistParams3 is not called when an endpoint is short of spans (traceweaver_v3.py:1177-1178); the first
@@ -575,11 +596,6 @@ int run_pass(tw_engine* e, int pass) {
     HIPCHK(hipEventRecord(e->ev[EV_PARAMS], e->stream));
     HIPCHK(hipEventRecord(e->ev[EV_ENUM0], e->stream));
     const auto host_t1 = std::chrono::steady_clock::now();
-    // Every class on its own stream: enumeration, then (staged) its windows and the first selection of its windows, while the longer
-    // enumerations of other classes are still running.  TW_CLASS_PIPELINE=0 / skip mode: the classes join after the enumeration.
-    int n_cls = 0;
-    for (int E = 1; E <= kMaxEp; E++) n_cls += e->tile_cls_off[E + 1] > e->tile_cls_off[E] ? 1 : 0;
-    const bool staged = !e->skip_mode && e->pipeline != 0 && P.n_tiles >= (int64_t)e->stage_min_tiles * std::max(n_cls, 1);
     {
         // what the selection stage and the repair rounds start from: filled on the engine's stream beside the enumerations
         int rc = launch_enumerate_all(e, pass, 0, nullptr, staged, [&]() -> int {
@@ -1142,6 +1158,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.heavy_unit, sel_cap); ALLOC(P.heavy_win, sel_cap);
     ALLOC(P.tiny_unit, sel_cap); ALLOC(P.tiny_win, sel_cap);
     ALLOC(P.hard_unit, sel_cap / (kBruteMax + 1) + 1 + kSelSlots); ALLOC(P.hard_win, sel_cap / (kBruteMax + 1) + 1 + kSelSlots);   // (a searched window holds more than kBruteMax spans)
+    ALLOC(e->rank_in, n_in_total); ALLOC(e->rank_out, n_out_total);
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles); ALLOC(e->agg_i32b, P.n_tiles);
     ALLOC(e->seg_in, (int64_t)seg_in.size()); ALLOC(e->seg_out, (int64_t)seg_out.size());
     ALLOC(e->gaps_sorted, gaps); ALLOC(e->fit_models, slots * kMaxComp * kModelStride);
@@ -1865,8 +1882,8 @@ int tw_run_baseline(tw_engine* e, int kind, int32_t* parent_out) {
             return fail(e, TW_ERR_DEVICE, "tw_run_baseline: out of device memory");
         B.in_rank_inv = inv_in; B.out_rank_inv = inv_out;
         HIPCHK(hipDeviceSynchronize());   // (the fills above ran on the null stream)
-        hipLaunchKernelGGL(k_rank_ends, tiles, tb, 0, e->stream, P, d_in, d_out);
-        hipLaunchKernelGGL(k_place_ends, tiles, tb, 0, e->stream, P, (const int32_t*)d_in, (const int32_t*)d_out);
+        hipLaunchKernelGGL(k_rank_ends, tiles, tb, 0, e->stream, P, all_tiles_host(e), d_in, d_out);
+        hipLaunchKernelGGL(k_place_ends, tiles, tb, 0, e->stream, P, all_tiles_host(e), (const int32_t*)d_in, (const int32_t*)d_out);
         hipLaunchKernelGGL(k_base_rank_inverse, tiles, tb, 0, e->stream, P, (const int32_t*)d_in, (const int32_t*)d_out, inv_in, inv_out);
         hipLaunchKernelGGL(k_base_prepare, tiles, tb, 0, e->stream, P, B);
         hipLaunchKernelGGL(k_base_vpath, tiles, tb, 0, e->stream, P, B);

@@ -159,6 +159,9 @@ __global__ void k_rows_unpack(const unsigned long long* comp, const uint32_t* se
 // later): one thread per span walks forward over the spans that start before it ends -- as many as are in flight with it --
 // and counts; 16 B per span read once, 8 B written, 4 B of counter: a device-wide radix sort of the same keys took five
 // read + write passes (43 % of the HBM traffic of a step in round 2).  Ties keep their order (equal values: same array).
+__device__ __forceinline__ int set_tile(const TileSet& S) { return S.ids != nullptr ? S.ids[blockIdx.x] : (int)blockIdx.x; }   // the tile of this workgroup (TileSet: tw_device.h)
+__device__ __forceinline__ TileSet all_tiles(const Dev& P) { return TileSet{nullptr, 0, P.n_tiles, 0}; }
+
 __device__ __forceinline__ void rank_list(const int64_t* st, const int64_t* en, int n, int i, int32_t* delta) {
     const int64_t a = en[i];
     int cnt = 0;
@@ -166,8 +169,8 @@ __device__ __forceinline__ void rank_list(const int64_t* st, const int64_t* en, 
         if (en[j] < a) { cnt++; atomicAdd(&delta[j], -1); }
     if (cnt) atomicAdd(&delta[i], cnt);
 }
-__global__ void k_rank_ends(Dev P, int32_t* d_in, int32_t* d_out) {   // both zeroed
-    const TileDev Tl = P.tiles[blockIdx.x];
+__global__ void k_rank_ends(Dev P, TileSet S, int32_t* d_in, int32_t* d_out) {   // both zeroed
+    const TileDev Tl = P.tiles[set_tile(S)];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
@@ -175,8 +178,8 @@ __global__ void k_rank_ends(Dev P, int32_t* d_in, int32_t* d_out) {   // both ze
     for (int e = 0; e < U.E; e++)
         rank_list(P.out_start + U.ep_off[e], P.out_end + U.ep_off[e], (int)(U.ep_off[e + 1] - U.ep_off[e]), i, d_out + U.ep_off[e]);
 }
-__global__ void k_place_ends(Dev P, const int32_t* d_in, const int32_t* d_out) {
-    const TileDev Tl = P.tiles[blockIdx.x];
+__global__ void k_place_ends(Dev P, TileSet S, const int32_t* d_in, const int32_t* d_out) {
+    const TileDev Tl = P.tiles[set_tile(S)];
     const UnitDev& U = P.units[Tl.unit];
     const int i = Tl.first + threadIdx.x;
     if (i >= U.n_in) return;
@@ -188,7 +191,7 @@ __global__ void k_place_ends(Dev P, const int32_t* d_in, const int32_t* d_out) {
 // ---------------------------------------------------------------------------------------------
 // Pass-1 Gaussian parameters: one thread per (unit, 100-span block, slot).
 // mean = (sum t2 - sum t1)/n over rank-aligned sorted arrays, std = sqrt(ceil(n/10)) * tstd(batch means).
-__global__ void k_block_params(Dev P, int64_t total) {
+__global__ void k_block_params(Dev P, int64_t total, int cls) {   // cls > 0: only the units of that endpoint count (a class' launch on its own stream)
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     // locate unit by gp_off (units are few: linear/binary search on the descriptor table)
@@ -198,6 +201,7 @@ __global__ void k_block_params(Dev P, int64_t total) {
         if (P.units[mid].gp_off <= g) lo = mid; else hi = mid - 1;
     }
     const UnitDev& U = P.units[lo];
+    if (cls > 0 && U.E != cls) return;
     const int64_t r = g - U.gp_off;
     const int b = (int)(r / U.nslot), q = (int)(r % U.nslot), E = U.E;
     double* out = P.gparam + g * 4;
@@ -2089,9 +2093,6 @@ struct ScanWinId {  // inclusive count of window ends; the window id is count - 
     __device__ static void store(const Dev& P, const UnitDev& U, int i, T v) { P.wid[U.in_off + i] = v; }
     __device__ static T reload(const Dev& P, const UnitDev& U, int i) { return P.wid[U.in_off + i]; }
 };
-
-__device__ __forceinline__ int set_tile(const TileSet& S) { return S.ids != nullptr ? S.ids[blockIdx.x] : (int)blockIdx.x; }   // the tile of this workgroup
-__device__ __forceinline__ TileSet all_tiles(const Dev& P) { return TileSet{nullptr, 0, P.n_tiles, 0}; }
 
 template <class Tr>
 __global__ void k_scan_local(Dev P, TileSet S, typename Tr::T* agg) {
