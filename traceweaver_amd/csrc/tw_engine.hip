@@ -124,6 +124,7 @@ struct tw_engine {
     double *fit_tape = nullptr, *fit_tape100 = nullptr;   // uniforms of the k-means++ seedings: model-selection fits / the refit (MT19937(100))
     int64_t* fit_tape_off = nullptr;
     int64_t fit_tape_cap = 0;
+    bool fit_runs_pending = false;          // k_fit_runs is queued, its refusal flag not read yet (fit_prepare_launch / fit_prepare)
     bool fit_prepared = false;              // the gap rows of the resident pass-1 result are sorted and run-length compressed
     int tile_sub_max = 8;
     int32_t hard_pass1[kMaxEp + 1] = {};    // per class: windows its stage listed for k_select_dp in pass 1 (-1 not known)
@@ -928,7 +929,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     if (b->batch_size <= 0 || b->batch_size_mis <= 0) return fail(e, TW_ERR_ARG, "batch sizes must be positive");
     free_all(e);
     e->fit_rng = Mt19937(e->fit_seed);   // a batch's refit does not depend on what the engine solved before
-    e->fit_prepared = false; e->fit_max_n_valid = false;
+    e->fit_prepared = false; e->fit_runs_pending = false; e->fit_max_n_valid = false;
     e->units.assign((size_t)b->n_units, UnitDev{});
     e->tiles.clear();
     e->gs_off_h.assign((size_t)b->n_units, 0);
@@ -1257,7 +1258,7 @@ int tw_run_pass1(tw_engine* e) {
     if (e->state < ST_LOADED) return fail(e, TW_ERR_STATE, "tw_run_pass1 before tw_load_batch");
     HIPCHK(hipSetDevice(e->device));
     const int rc = run_pass(e, 1);
-    e->fit_prepared = false; e->fit_max_n_valid = false;
+    e->fit_prepared = false; e->fit_runs_pending = false; e->fit_max_n_valid = false;
     if (rc == TW_OK) { e->state = ST_PASS1; e->pass1_done = true; }
     return rc;
 }
@@ -1279,7 +1280,7 @@ int tw_set_gaps(tw_engine* e, const double* gaps) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->P.gaps, gaps, sizeof(double) * e->n_gaps, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->fit_prepared = false; e->fit_max_n_valid = false;
+    e->fit_prepared = false; e->fit_runs_pending = false; e->fit_max_n_valid = false;
     e->state = ST_PASS1;
     return TW_OK;
 }
@@ -1300,7 +1301,7 @@ int tw_set_gaps_device(tw_engine* e, const double* dev_gaps) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->P.gaps, dev_gaps, sizeof(double) * e->n_gaps, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->fit_prepared = false; e->fit_max_n_valid = false;
+    e->fit_prepared = false; e->fit_runs_pending = false; e->fit_max_n_valid = false;
     e->state = ST_PASS1;
     return TW_OK;
 }
@@ -1338,18 +1339,29 @@ FitDev fit_dev(tw_engine* e) {
 // Turns every scored gap row into (value, multiplicity) runs; idempotent per pass-1 result.  Default route: k_fit_runs (a hash
 // table per row in LDS, the row read once); rows it cannot take -- and TW_FIT_SORT=1 -- go the sort route below: composite-key
 // radix sort of all rows + k_fit_compress.  Both leave the same arrays (uval, ustart, row_n, row_uniq).
+// (in two halves: fit_prepare_launch queues k_fit_runs and returns -- the caller has host work of its own to do meanwhile, the
+// uniforms of the k-means++ draws -- and fit_prepare waits for it, reads whether a row was refused and runs the sort route then)
+int fit_prepare_launch(tw_engine* e) {
+    e->fit_runs_pending = false;
+    if (e->fit_prepared || env_int("TW_FIT_SORT", 0) != 0) return TW_OK;
+    int32_t* flag = (int32_t*)e->key_acc;
+    HIPCHK(hipMemsetAsync(flag, 0, sizeof(int32_t), e->stream));
+#ifdef TW_HOST_EMULATION
+    const int runs_threads = e->coop;
+#else
+    const int runs_threads = e->coop >= 64 ? kRunsThreads : e->coop;
+#endif
+    hipLaunchKernelGGL(k_fit_runs, dim3((unsigned)e->n_slots), dim3(runs_threads), 0, e->stream, fit_dev(e), flag);
+    HIPCHK(hipGetLastError());
+    e->fit_runs_pending = true;
+    return TW_OK;
+}
 int fit_prepare(tw_engine* e) {
     if (e->fit_prepared) return TW_OK;
     if (env_int("TW_FIT_SORT", 0) == 0) {
+        if (!e->fit_runs_pending) { int rl = fit_prepare_launch(e); if (rl != TW_OK) return rl; }
+        e->fit_runs_pending = false;
         int32_t* flag = (int32_t*)e->key_acc;
-        HIPCHK(hipMemsetAsync(flag, 0, sizeof(int32_t), e->stream));
-#ifdef TW_HOST_EMULATION
-        const int runs_threads = e->coop;
-#else
-        const int runs_threads = e->coop >= 64 ? kRunsThreads : e->coop;
-#endif
-        hipLaunchKernelGGL(k_fit_runs, dim3((unsigned)e->n_slots), dim3(runs_threads), 0, e->stream, fit_dev(e), flag);
-        HIPCHK(hipGetLastError());
         int32_t refused = 0;
         HIPCHK(hipMemcpyAsync(&refused, flag, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -1515,7 +1527,7 @@ int tw_fit_mixtures_seeded(tw_engine* e, const uint32_t* unit_seed) {
     if (rc != TW_OK) return rc;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipEventRecord(e->ev[EV_BEGIN], e->stream));
-    rc = fit_prepare(e);
+    rc = fit_prepare_launch(e);   // (the rows become runs while the host draws the uniforms; fit_prepare below waits for both)
     if (rc != TW_OK) return rc;
     // one block of 34 uniforms per slot: no look at the rows needed, no host round trip.  With unit seeds every unit draws from
     // a stream of its own, so its fit does not depend on which other units share the batch (sharded runs);
@@ -1537,7 +1549,9 @@ int tw_fit_mixtures_seeded(tw_engine* e, const uint32_t* unit_seed) {
     if ((int64_t)tape.size() > e->fit_tape_cap) return fail(e, TW_ERR_STATE, "tw_fit_mixtures: tape buffer smaller than the batch");
     HIPCHK(hipMemcpyAsync(e->fit_tape, tape.data(), sizeof(double) * tape.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->fit_tape_off, off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));   // (the host vectors are reused by the next call)
+    if (e->fit_prepared) HIPCHK(hipStreamSynchronize(e->stream));   // (the host vectors are reused by the next call; else fit_prepare's wait covers it)
+    rc = fit_prepare(e);
+    if (rc != TW_OK) return rc;
     return fit_run(e);
 }
 
