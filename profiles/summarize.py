@@ -137,12 +137,18 @@ def counter_report(tag, src, out, rows):
     print(open(os.path.join(out, tag + "_counters.md")).read())
 
 
+def _pass_end(name):
+    """Kernels that follow a pass: the refit's first kernel (after pass 1) and the accuracy reduction (after pass 2)."""
+    return "k_fit_runs" in name or "k_fit_compress" in name or "k_evaluate" in name
+
+
 def enumerate_wall(trace_path):
-    """Wall-clock span of the enumeration group per launch set (first start to last end of its kernels between two selection /
-    window phases), from the kernel trace.  The group's kernels run on one stream per endpoint-count class and overlap, so the
-    *sum* of their durations (the `avg ms per launch set` column) exceeds this span; bench.py's HIP events around the group measure
-    the span.  Returns (mean span ms, mean of pass-1 sets, mean of pass-2 sets) over the sets longer than 1 ms (the re-enumerations
-    of repair rounds are short sets of their own), or None."""
+    """Wall-clock span of the enumeration group per pass (first start to last end of its kernels in the pass), from the kernel trace.
+    The group's kernels run on one stream per endpoint-count class and overlap, so the *sum* of their durations (the `avg ms per launch
+    set` column) exceeds this span; since round 6 the window / selection stages of the classes that are done run inside the span too
+    (DESIGN.md 3.2).  bench.py's HIP events around the group measure the same span.  Passes are told apart by what follows them
+    (k_fit_runs after pass 1, k_evaluate after pass 2).  Returns (mean span ms, mean of pass 1, mean of pass 2) over the spans
+    longer than 1 ms, or None."""
     if not os.path.exists(trace_path):
         return None
     rows = sorted(csv.DictReader(open(trace_path)), key=lambda r: int(r["Start_Timestamp"]))
@@ -152,7 +158,7 @@ def enumerate_wall(trace_path):
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         if g == "k_enumerate":
             cur = [s, e] if cur is None else [min(cur[0], s), max(cur[1], e)]
-        elif g in ("k_select", "windows") and cur is not None:
+        elif _pass_end(r["Kernel_Name"]) and cur is not None:
             sets.append(cur)
             cur = None
     if cur:
@@ -164,26 +170,23 @@ def enumerate_wall(trace_path):
 
 
 def timeline(trace_path):
-    """Kernels of the enumeration and selection groups of the last launch set in the trace (pass 2 of the last step), in start
-    order: (short name, queue, start offset us, duration us) -- which kernels overlap and which one ends the group."""
+    """Kernels of the last pass in the trace (pass 2 of the last step: from the first enumeration kernel after the refit to the
+    accuracy reduction), enumeration, windows, selection and consumption, in start order: (short name, queue, start offset us,
+    duration us) -- which kernels overlap and which chain ends the pass."""
     if not os.path.exists(trace_path):
         return None
     rows = sorted(csv.DictReader(open(trace_path)), key=lambda r: int(r["Start_Timestamp"]))
-    last_enum = max((i for i, r in enumerate(rows) if group_of(r["Kernel_Name"]) == "k_enumerate"
-                     and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 200000), default=None)
-    if last_enum is None:
+    ends = [i for i, r in enumerate(rows) if "k_evaluate" in r["Kernel_Name"]]
+    if not ends:
         return None
-    t_end = int(rows[last_enum]["Start_Timestamp"])
-    # walk back to the start of that launch set: the first enumeration kernel after the previous selection
-    first = last_enum
-    while first > 0 and not (group_of(rows[first - 1]["Kernel_Name"]) == "k_select" and int(rows[first - 1]["End_Timestamp"]) < t_end - 1000000):
+    last = ends[-1]
+    first = last
+    while first > 0 and "k_fit" not in rows[first - 1]["Kernel_Name"] and "k_mix_consts" not in rows[first - 1]["Kernel_Name"]:
         first -= 1
     out, t0 = [], None
-    for r in rows[first:]:
+    for r in rows[first:last]:
         g = group_of(r["Kernel_Name"])
-        if g not in ("k_enumerate", "k_select"):
-            if g in ("repair", "other") and out and any(x[0].startswith("k_select") for x in out):
-                break
+        if g not in ("k_enumerate", "k_select", "windows", "repair") and "k_finalize" not in r["Kernel_Name"]:
             continue
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         t0 = s if t0 is None else t0
@@ -237,7 +240,7 @@ def main():
                         wall[0], wall[1], wall[2], bench.get("roofline", {}).get("kernel_ms", float("nan"))))
         tl = timeline(os.path.join(src, tag + "_stats", tag + "_kernel_trace.csv"))
         if tl:
-            f.write("\nTimeline of the last launch set (pass 2 of the last step), enumeration then selection; kernels on different queues overlap:\n\n"
+            f.write("\nTimeline of the last pass (pass 2 of the last step): every class on its own queue, enumeration then its window / selection / consumption stage (DESIGN.md 3.2); kernels on different queues overlap:\n\n"
                     "| kernel | queue | start us | duration us |\n|---|---|---|---|\n")
             for name, q, st, du in tl:
                 if du >= 20.0:
