@@ -44,6 +44,19 @@ def test_classes_joined_after_the_enumeration(emu_lib, monkeypatch):
     assert sum(r["repaired_windows"] for r in r1) > 0
 
 
+@pytest.mark.parametrize("stretches, staged", [(4, "0"), (8, "1000000")])
+def test_tile_kernel_in_stretches(emu_lib, monkeypatch, stretches, staged):
+    """A class of many tiles is launched in stretches (launch_enumerate): the wavefront kernel takes what a stretch's tiles listed --
+    the entries between two snapshots of the list counters -- on a second stream beside the next stretch's tile kernel.  Forced here
+    (a tile of the emulated build is one span), staged and joined: the same results."""
+    monkeypatch.setenv("TW_STRETCH_MIN_TILES", "1")
+    monkeypatch.setenv("TW_ENUM_STRETCHES", str(stretches))
+    monkeypatch.setenv("TW_STAGE_MIN_TILES", staged)
+    units, _ = parity.stress_units(parity.STRESS)
+    r1, r2, _ = parity.check_units(emu_lib, units)
+    assert sum(r["repaired_windows"] for r in r1) > 0
+
+
 def test_selection_takes_every_route_of_the_level_solver(emu_lib):
     """The selection of a component of more than four spans is solved level by level (select_dp): on the small tables of
     k_select_heavy, on the large ones of k_select_dp when a level outgrows those, by the depth-first search when a level

@@ -111,10 +111,13 @@ def test_stress_units():
     assert sum(r["repaired_windows"] for r in r1) > 0
 
 
-@pytest.mark.parametrize("env", [{"TW_STAGE_MIN_TILES": "0"}, {"TW_CLASS_PIPELINE": "0"}, {"TW_STAGE_MIN_TILES": "0", "TW_TILE_GATE": "1"}])
+@pytest.mark.parametrize("env", [{"TW_STAGE_MIN_TILES": "0"}, {"TW_CLASS_PIPELINE": "0"}, {"TW_STAGE_MIN_TILES": "0", "TW_TILE_GATE": "1"},
+                                 {"TW_STAGE_MIN_TILES": "0", "TW_STRETCH_MIN_TILES": "1", "TW_ENUM_STRETCHES": "4"}, {"TW_CLASS_PIPELINE": "0", "TW_STRETCH_MIN_TILES": "2", "TW_ENUM_STRETCHES": "8"}])
 def test_stress_units_staged_and_joined(env, monkeypatch):
     """The window / selection stage per endpoint-count class on the class' stream (forced for these small units), all classes joined
-    after the enumeration, and the tile kernels gated one after the other: the same results, bit for bit against the oracle."""
+    after the enumeration, the tile kernels gated one after the other, and the tile kernel of a class launched in stretches with the
+    wavefront kernel of a stretch's listed spans beside the next stretch (forced for these small units): the same results, bit for bit
+    against the oracle."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     units, _ = parity.stress_units(parity.STRESS)

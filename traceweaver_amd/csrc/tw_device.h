@@ -18,6 +18,7 @@ constexpr int kTopK = TW_TOPK;
 constexpr int kMaxComp = TW_MAX_COMP;
 constexpr int kMaxWin = TW_MAX_WINDOW;
 constexpr int kCandWords = TW_CAND_WORDS;
+constexpr int kEnumStretches = 8;   // most stretches a class' tile kernel is launched in (launch_enumerate: the wavefront kernel of a stretch runs beside the next stretch's tiles)
 constexpr int kTile = 128;  // incoming spans per workgroup in the per-span kernels (measured: 128 beats 64 and 256)
 constexpr int kCoop = 256;  // threads of the per-unit / per-row cooperative kernels
 constexpr int32_t kNoOwner = 0x7f7f7f7f;
@@ -139,6 +140,8 @@ struct Dev {
     int32_t* heavy_in_count;  // [2][kMaxEp+1] incoming spans deferred to k_enumerate_heavy per endpoint count E: narrow, wide windows
     int32_t* heavy_in_next;   // [4][2][kMaxEp+1] work-list cursors of the wavefront kernels: per kind of launch (the class' lists, list parts, spans listed again, fallback), instantiation (narrow, wide) and class (enum_cursor)
     int32_t heavy_in_off[kMaxEp + 2];  // class offsets into heavy_in_unit / heavy_in_idx
+    int32_t* enum_snap;         // [kMaxEp+1][kEnumStretches+1][4] list counters of class E (long, narrow, wide) after the j-th stretch of its tile kernel (k_enum_snapshot)
+    int32_t* enum_stretch_next; // [kMaxEp+1][kEnumStretches][2] work-list cursor of the wavefront kernel's launch for a stretch (narrow, wide)
     int32_t *heavy_in_unit, *heavy_in_idx;
     int32_t* heavy_big_count;   // [kMaxEp+1] narrow spans with a long enumeration: served first
     int32_t *heavy_big_unit, *heavy_big_idx;   // class offsets heavy_big_off (room for the extra entries of split spans)

@@ -77,9 +77,21 @@ struct tw_engine {
     // the window / selection stage of a class follows its enumeration on the class' stream (run_pass): the three instantiations of
     // k_select_heavy on streams of their own beside it, forked from and joined to the class' stream
     hipStream_t sel_stream[3] = {};
+    // ... and a second set for the stages of the other classes that hold a large share of the batch's spans (their searches one after the
+    // other on the class' stream were the longest chain of a pass on the nodejs shape: 4.7 + 8.7 + 1.8 ms for the three one-endpoint services)
+    hipStream_t sel_stream2[3] = {};
+    int64_t select_fork_min = 2000000;   // TW_SELECT_FORK_MIN: incoming spans of a class from which its stage forks too (0 = only the deepest class)
     hipEvent_t prep_ev = nullptr;              // the per-pass fills the selection stage needs (main stream, beside the enumerations)
     hipEvent_t post_fork[kMaxEp + 1] = {}, post_join[kMaxEp + 1][3] = {}, post_done[kMaxEp + 1] = {};
     hipEvent_t tile_ev[kMaxEp + 1] = {};       // class E's tile kernel done (launch_enumerate: gating of the classes launched after it)
+    // a class of many tiles is launched in stretches: the wavefront kernel of a stretch's listed spans on the class' second stream
+    // beside the tile kernel of the next stretch (launch_enumerate)
+    hipStream_t cls_stream2[kMaxEp + 1] = {};
+    hipEvent_t stretch_ev[kMaxEp + 1][kEnumStretches] = {}, stretch_done[kMaxEp + 1] = {};
+    int enum_stretches = 1, stretch_min_tiles = 2048;   // TW_ENUM_STRETCHES (1 = one launch: the default, see launch_enumerate), TW_STRETCH_MIN_TILES (tiles per stretch at least)
+    int heavy_grid = 4096, select_grid = 4096;          // TW_HEAVY_GRID / TW_SELECT_GRID: most persistent wavefronts of k_enumerate_heavy / k_select_heavy per launch
+    int debug_lists = 0;                                // TW_DEBUG_LISTS=1: the list counters of the first enumeration are copied to the host per class (tw_debug_worklists)
+    int32_t first_lists[3][kMaxEp + 1] = {};            // ... narrow, wide, long enumerations
     hipEvent_t gate_ev = nullptr;              // ... the last one recorded in the current launch_enumerate_all
     int tile_gate = 0;                         // TW_TILE_GATE (measured on the media shape: the tile kernels one after the other take 1.9 + 1.5 + 1.9 ms, beside one another 3.7 -- off)
     int stage_min_tiles = 1024;                // TW_STAGE_MIN_TILES: batches of fewer tiles per class on average join the classes after the enumeration (a stage is 17 small
@@ -315,6 +327,7 @@ void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
         if (lean) hipLaunchKernelGGL((k_enumerate_lean<64 * kCandWords>), dim3(g), hb, lean_bytes_w, st, P, pass, mode, part, e->lean_pool, E, E);
         else hipLaunchKernelGGL((k_enumerate_heavy<E, 64 * kCandWords>), dim3(g), hb, pool_bytes, st, P, pass, mode, part, pool);
     };
+    bool stretched = false;
     if (mode == 0 && pass == 1 && e->class_params) {   // the class' sorted end times and block parameters (run_pass)
         const TileSet S = class_tiles(e, E);
         (void)sort_ends(e, S, st);
@@ -327,22 +340,51 @@ void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
         const dim3 tile_block(e->tile >= 64 ? e->tile * e->tile_threads : e->tile);
         int sub = 1;
         while (sub < e->tile_sub_max && nt * sub < 512 && (e->tile / (sub * 2)) * (sub * 2) == e->tile && e->tile / (sub * 2) >= 8) sub *= 2;
-        if (e->tile == kTile && e->tile / sub == kSubTileSpans)   // (the instantiation with tables for a sub-tile's 16 spans: a third of the LDS)
-            hipLaunchKernelGGL((k_enumerate_tile<E, kSubTileSpans>), dim3(nt * sub), tile_block, 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt, sub);
-        else
-            hipLaunchKernelGGL((k_enumerate_tile<E>), dim3(nt * sub), tile_block, 0, st, P, pass, (const int32_t*)(e->tile_ids + e->tile_cls_off[E]), nt, sub);
+        // A class of many tiles in stretches: what a stretch's tiles listed for the wavefront kernel is enumerated on the class' second
+        // stream beside the tile kernel of the next stretch (the wavefront kernel of the whole class behind the last tile ran 1.2-1.6 ms
+        // at 1.5 wavefronts per SIMD on the media shape, a quarter of the class' chain).  Not for the classes whose wavefront kernel
+        // appends list parts behind the listed entries (E >= defer_min_e) nor for k_enumerate_lean.
+        const int ns = (!lean && !e->skip_mode && !(E >= 3 && E >= P.defer_min_e) && e->cls_stream2[E] != nullptr)
+                           ? std::max(std::min(e->enum_stretches, nt / e->stretch_min_tiles), 1) : 1;
+        stretched = ns > 1;
+        for (int j = 0; j < ns; j++) {
+            const int t0 = (int)((int64_t)nt * j / ns), t1 = (int)((int64_t)nt * (j + 1) / ns);
+            const int32_t* ids = e->tile_ids + e->tile_cls_off[E] + t0;
+            if (e->tile == kTile && e->tile / sub == kSubTileSpans)   // (the instantiation with tables for a sub-tile's 16 spans: a third of the LDS)
+                hipLaunchKernelGGL((k_enumerate_tile<E, kSubTileSpans>), dim3((t1 - t0) * sub), tile_block, 0, st, P, pass, ids, t1 - t0, sub);
+            else
+                hipLaunchKernelGGL((k_enumerate_tile<E>), dim3((t1 - t0) * sub), tile_block, 0, st, P, pass, ids, t1 - t0, sub);
+            if (ns > 1) {
+                hipLaunchKernelGGL(k_enum_snapshot, dim3(1), dim3(1), 0, st, P, E, j + 1);
+                if (j + 1 < ns) {   // (the last stretch's spans: on the class' stream itself)
+                    hipStream_t s2 = e->cls_stream2[E];
+                    (void)hipEventRecord(e->stretch_ev[E][j], st);
+                    (void)hipStreamWaitEvent(s2, e->stretch_ev[E][j], 0);
+                    hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid_for(-1, e->heavy_grid)), hb, pool_bytes, s2, P, pass, mode, (j + 1) << 8, pool);
+                } else {
+                    hipLaunchKernelGGL((k_enumerate_heavy<E, kNarrow>), dim3(grid_for(-1, e->heavy_grid)), hb, pool_bytes, st, P, pass, mode, (j + 1) << 8, pool);
+                    (void)hipEventRecord(e->stretch_done[E], e->cls_stream2[E]);
+                    (void)hipStreamWaitEvent(st, e->stretch_done[E], 0);
+                }
+            }
+        }
         if (e->tile_gate > 0 && nt >= e->tile_gate) { (void)hipEventRecord(e->tile_ev[E], st); e->gate_ev = e->tile_ev[E]; }
     }
     // the wavefront kernels of the class: the spans the tile kernel handed over (mode 1: the spans k_detect_gone listed), the long
     // enumerations first; the list parts of the spans those launches deferred (kListSplitFlag); the parts combined, the few spans whose
     // order of equal scores the parts left undecided enumerated whole.  Every launch of the chain has a work-list cursor of its own
     // (enum_cursor): nothing is reset in between.
-    if (n_narrow != 0) narrow(0, grid_for(n_narrow, 4096));
-    if (n_wide != 0) wide(0, grid_for(n_wide, 1024));
+    if (n_narrow != 0 && !stretched) narrow(0, grid_for(n_narrow, e->heavy_grid));
+    if (n_wide != 0) wide(0, grid_for(n_wide, 1024));   // (stretched: the wide instantiation once, over the whole lists)
     if (mode == 0 && E >= 3 && E >= P.defer_min_e) { narrow(3, grid_for(-1, 4096)); if (n_wide != 0) wide(3, grid_for(-1, 1024)); }
     if (mode == 0 && E > 1) {
         hipLaunchKernelGGL(k_merge_parts, dim3(256), dim3(std::min(e->coop, 64)), 0, st, P, pass, E, E);   // (34 KB of LDS a workgroup: a thousand of them ask for all there is)
         narrow(1, 256); if (n_wide != 0) wide(1, 64);
+    }
+    if (e->debug_lists != 0 && mode == 0) {
+        (void)hipMemcpyAsync(&e->first_lists[0][E], P.heavy_in_count + E, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(&e->first_lists[1][E], P.heavy_in_count + kMaxEp + 1 + E, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(&e->first_lists[2][E], P.heavy_big_count + E, sizeof(int32_t), hipMemcpyDeviceToHost, st);
     }
     (void)hipEventRecord(e->cls_ev[E], st);   // (who waits for it: launch_enumerate_all)
 }
@@ -386,10 +428,10 @@ int launch_windows(tw_engine* e, const TileSet& S, hipStream_t st) {
 // What the searches give up on goes to one list for k_select_dp (the caller launches it when every set has joined).
 // (fork = false: everything on st, one after the other -- the stages of the classes that end before the last one have the time, and the
 // three selection streams stay free for the class whose stage ends the pass)
-void launch_select_listed(tw_engine* e, const TileSet& S, hipStream_t st, int64_t n_spans, bool fork = true) {
+void launch_select_listed(tw_engine* e, const TileSet& S, hipStream_t st, int64_t n_spans, bool fork = true, bool second = false) {
     const Dev& P = e->P;
     const dim3 wave(std::min(e->coop, 64));
-    const dim3 grid((unsigned)std::min<int64_t>(n_spans / 2 + 1, 4096));
+    const dim3 grid((unsigned)std::min<int64_t>(n_spans / 2 + 1, e->select_grid));
     if (!fork) {
         hipLaunchKernelGGL(k_select_tiny, dim3((unsigned)std::min<int64_t>(n_spans / 2 + 1, 8192)), wave, 0, st, P, S);
         hipLaunchKernelGGL((k_select_heavy<SelectLdsLvl, 3>), grid, wave, 0, st, P, S);
@@ -397,12 +439,13 @@ void launch_select_listed(tw_engine* e, const TileSet& S, hipStream_t st, int64_
         hipLaunchKernelGGL((k_select_heavy<SelectLdsMidLvl, 2>), grid, wave, 0, st, P, S);
         return;
     }
+    hipStream_t* ss = second ? e->sel_stream2 : e->sel_stream;
     (void)hipEventRecord(e->post_fork[S.slot], st);
-    for (int j = 0; j < 3; j++) (void)hipStreamWaitEvent(e->sel_stream[j], e->post_fork[S.slot], 0);
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsLvl, 3>), grid, wave, 0, e->sel_stream[0], P, S);      // the longest searches first
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsBigLvl, 1>), grid, wave, 0, e->sel_stream[1], P, S);
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsMidLvl, 2>), grid, wave, 0, e->sel_stream[2], P, S);
-    for (int j = 0; j < 3; j++) (void)hipEventRecord(e->post_join[S.slot][j], e->sel_stream[j]);
+    for (int j = 0; j < 3; j++) (void)hipStreamWaitEvent(ss[j], e->post_fork[S.slot], 0);
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsLvl, 3>), grid, wave, 0, ss[0], P, S);      // the longest searches first
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsBigLvl, 1>), grid, wave, 0, ss[1], P, S);
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsMidLvl, 2>), grid, wave, 0, ss[2], P, S);
+    for (int j = 0; j < 3; j++) (void)hipEventRecord(e->post_join[S.slot][j], ss[j]);
     hipLaunchKernelGGL(k_select_tiny, dim3((unsigned)std::min<int64_t>(n_spans / 2 + 1, 8192)), wave, 0, st, P, S);
     for (int j = 0; j < 3; j++) (void)hipStreamWaitEvent(st, e->post_join[S.slot][j], 0);
 }
@@ -427,7 +470,9 @@ int launch_class_stage(tw_engine* e, int pass, int E) {
     hipLaunchKernelGGL(k_select_fast, dim3(S.n), dim3(e->tile), 0, st, e->P, S);
     int deepest = 0;
     for (int c = 1; c <= kMaxEp; c++) if (e->tile_cls_off[c + 1] > e->tile_cls_off[c]) deepest = c;
-    launch_select_listed(e, S, st, (int64_t)e->P.heavy_in_off[E + 1] - e->P.heavy_in_off[E], E == deepest);
+    const int64_t n_cls = (int64_t)e->P.heavy_in_off[E + 1] - e->P.heavy_in_off[E];
+    const bool second = E != deepest && e->select_fork_min > 0 && n_cls >= e->select_fork_min && e->sel_stream2[0] != nullptr;
+    launch_select_listed(e, S, st, n_cls, E == deepest || second, second);
     launch_select_hard(e, S, st, pass == 2 && e->hard_pass1[E] == 0);
     const dim3 tiles(S.n), tb(e->tile);
     hipLaunchKernelGGL(k_claim, tiles, tb, 0, st, e->P, S, E);
@@ -876,10 +921,18 @@ int tw_create(int device_id, tw_engine** out) {
         s = hipEventCreateWithFlags(&e->post_fork[i], hipEventDisableTiming);
         if (s == hipSuccess) s = hipEventCreateWithFlags(&e->tile_ev[i], hipEventDisableTiming);
         if (s == hipSuccess) s = hipEventCreateWithFlags(&e->post_done[i], hipEventDisableTiming);
+        if (s == hipSuccess) s = hipEventCreateWithFlags(&e->stretch_done[i], hipEventDisableTiming);
+        for (int j = 0; j < kEnumStretches && s == hipSuccess; j++) s = hipEventCreateWithFlags(&e->stretch_ev[i][j], hipEventDisableTiming);
         for (int j = 0; j < 3 && s == hipSuccess; j++) s = hipEventCreateWithFlags(&e->post_join[i][j], hipEventDisableTiming);
     }
     e->pipeline = env_int("TW_CLASS_PIPELINE", 1);
     e->tile_gate = env_int("TW_TILE_GATE", 0);
+    e->enum_stretches = std::min(std::max(env_int("TW_ENUM_STRETCHES", 1), 1), kEnumStretches);
+    e->heavy_grid = std::max(env_int("TW_HEAVY_GRID", 4096), 64);
+    e->select_grid = std::max(env_int("TW_SELECT_GRID", 4096), 64);
+    e->debug_lists = env_int("TW_DEBUG_LISTS", 0);
+    e->select_fork_min = (int64_t)env_int("TW_SELECT_FORK_MIN", 2000000);
+    e->stretch_min_tiles = std::max(env_int("TW_STRETCH_MIN_TILES", 2048), 1);
     e->stage_min_tiles = env_int("TW_STAGE_MIN_TILES", 1024);
     e->tile_sub_max = std::max(env_int("TW_TILE_SUB", 8), 1);   // workgroups per tile for classes of few tiles (1 = never)
     e->lean_pool = std::min(std::max(env_int("TW_LEAN_POOL", 512), 1), 4096);
@@ -903,13 +956,19 @@ void tw_destroy(tw_engine* e) {
         if (e->cls_ev[i]) (void)hipEventDestroy(e->cls_ev[i]);
     for (int i = 1; i <= kMaxEp; i++)
         if (e->cls_stream[i]) (void)hipStreamDestroy(e->cls_stream[i]);
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 3; i++) {
         if (e->sel_stream[i]) (void)hipStreamDestroy(e->sel_stream[i]);
+        if (e->sel_stream2[i]) (void)hipStreamDestroy(e->sel_stream2[i]);
+    }
     if (e->prep_ev) (void)hipEventDestroy(e->prep_ev);
     for (int i = 0; i <= kMaxEp; i++) {
         if (e->post_fork[i]) (void)hipEventDestroy(e->post_fork[i]);
         if (e->tile_ev[i]) (void)hipEventDestroy(e->tile_ev[i]);
         if (e->post_done[i]) (void)hipEventDestroy(e->post_done[i]);
+        if (e->stretch_done[i]) (void)hipEventDestroy(e->stretch_done[i]);
+        for (int j = 0; j < kEnumStretches; j++)
+            if (e->stretch_ev[i][j]) (void)hipEventDestroy(e->stretch_ev[i][j]);
+        if (e->cls_stream2[i]) (void)hipStreamDestroy(e->cls_stream2[i]);
         for (int j = 0; j < 3; j++)
             if (e->post_join[i][j]) (void)hipEventDestroy(e->post_join[i][j]);
     }
@@ -1026,9 +1085,21 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     }
     e->tile_cls_off[kMaxEp + 1] = (int32_t)tile_ids_h.size();
     for (int cls = 1; cls <= kMaxEp; cls++)
-        if (e->tile_cls_off[cls + 1] > e->tile_cls_off[cls]) { int rs = ensure_class_stream(e, cls); if (rs != TW_OK) return rs; }
+        if (e->tile_cls_off[cls + 1] > e->tile_cls_off[cls]) {
+            int rs = ensure_class_stream(e, cls); if (rs != TW_OK) return rs;
+            if (e->enum_stretches > 1 && e->tile_cls_off[cls + 1] - e->tile_cls_off[cls] >= 2 * e->stretch_min_tiles && e->cls_stream2[cls] == nullptr)
+                HIPCHK(hipStreamCreate(&e->cls_stream2[cls]));
+        }
     for (int j = 0; j < 3; j++)
         if (e->sel_stream[j] == nullptr) HIPCHK(hipStreamCreate(&e->sel_stream[j]));
+    {   // (the second set only for a batch that has such a class: every stream takes a share of the hardware queues)
+        bool want = false;
+        int deepest = 0;
+        for (int cls = 1; cls <= kMaxEp; cls++) if (e->tile_cls_off[cls + 1] > e->tile_cls_off[cls]) deepest = cls;
+        for (int cls = 1; cls < deepest; cls++) want |= e->select_fork_min > 0 && heavy_off_h[cls + 1] - heavy_off_h[cls] >= e->select_fork_min;
+        for (int j = 0; j < 3 && want; j++)
+            if (e->sel_stream2[j] == nullptr) HIPCHK(hipStreamCreate(&e->sel_stream2[j]));
+    }
     const int64_t n_in_total = b->unit_in_off[b->n_units], n_out_total = b->ep_off[epi];
     if (n_in_total >= (1ll << 31) || n_out_total >= (1ll << 31)) return fail(e, TW_ERR_ARG, "batch exceeds 2^31 spans");
     if (gaps >= (1ll << 31)) return fail(e, TW_ERR_ARG, "batch too large: sum of nslot*n_in must stay below 2^31");
@@ -1141,6 +1212,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
         e->ctr_round_ints = at;
         const int64_t o_pu = take(kMaxEp + 1), o_sc = take(kMaxEp + 1), o_dc = take(kMaxEp + 1), o_du = take(1), o_err = take(1), o_nd = take(P.n_units), o_us = take((int64_t)P.n_units * 16);
         const int64_t o_dr = take(kMaxEp + 1), o_ft = take(kMaxEp + 1), o_aw = take(kMaxEp + 1);
+        const int64_t o_es = take((kMaxEp + 1) * (kEnumStretches + 1) * 4), o_en = take((kMaxEp + 1) * kEnumStretches * 2);
         const int64_t o_fn = take(kFrontierSlots), o_fb = take(P.frontier_big_slots), o_pb = take(kPairSlots);   // flags of the tuple-list pools (given back by the kernels themselves)
         e->ctr_pass_ints = at;
         auto place = [=](void* q) {
@@ -1151,6 +1223,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
             D.defer_count = c + o_dc; D.defer_used = c + o_du;
             D.part_used = c + o_pu; D.split_count = c + o_sc; D.err = c + o_err; D.unit_ndirty = c + o_nd;
             D.redo_count = c + o_rd; D.fb_count = c + o_fc; D.defer_refused = c + o_dr; D.fb_total = c + o_ft; D.pair_busy = c + o_pb; D.any_wide = c + o_aw;
+            D.enum_snap = c + o_es; D.enum_stretch_next = c + o_en;
             D.unit_stats = (int64_t*)(c + o_us);
         };
         if (e->arena_open) e->arena_req.emplace_back(place, ((size_t)at * sizeof(int32_t) + 255) / 256 * 256);   // (placed by arena_commit, like the rest)
@@ -1979,6 +2052,8 @@ int tw_debug_worklists(tw_engine* e, int32_t* out) {
     out[0] = 0;
     for (int k = 0; k < 4 * kSelSeg; k++) out[0] += sel_all[k * kCtrStride];
     for (int k = 0; k <= kMaxEp; k++) out[1 + k] = both[k] + both[kMaxEp + 1 + k];
+    if (e->debug_lists != 0)   // (the first enumeration's lists, as its chain left them: narrow + wide + long enumerations)
+        for (int k = 1; k <= kMaxEp; k++) out[1 + k] = e->first_lists[0][k] + e->first_lists[1][k] + e->first_lists[2][k];
     int32_t split[kMaxEp + 1];   // [0] spans listed again after the merge, [E >= 2] split spans of the class
     HIPCHK(hipMemcpy(split, e->P.split_count, sizeof(split), hipMemcpyDeviceToHost));
     out[2 + kMaxEp] = 0; out[3 + kMaxEp] = split[0];

@@ -33,6 +33,20 @@ __device__ __forceinline__ int wave_append(int32_t* counter, bool pred) {
     base = __shfl(base, leader);
     return pred ? base + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
 }
+// `n` consecutive units of a budget that is handed out by a bump counter: the first of them, or -1 when they do not fit.  By
+// compare-and-swap: a refusal changes nothing.  (Adding first and subtracting on refusal hands the same units out twice -- A adds,
+// B adds behind A and is served, A is refused and subtracts, C is served from where A began: inside B's units.  Two split spans then
+// shared scratch slots, and one of them came back with another span's tuples, about once in sixty batches of the stress units.)
+__device__ __forceinline__ int bump_reserve(int32_t* counter, int n, int budget) {
+    int old = atomicAdd(counter, 0);
+    while (old + n <= budget) {
+        const int seen = atomicCAS(counter, old, old + n);
+        if (seen == old) return old;
+        old = seen;
+    }
+    return -1;
+}
+
 // Barrier of a workgroup that is a single wavefront: LDS operations of one wavefront execute in program order, so
 // only the compiler has to be kept from reordering.  (__syncthreads() would also wait for every outstanding global
 // load/store -- the release fence at workgroup scope -- which costs microseconds per use in the work-list kernels.)
@@ -459,8 +473,8 @@ __device__ __forceinline__ bool heavy_append(const Dev& P, bool pred, bool narro
         want = want > kMaxCandParts ? kMaxCandParts : want;
         nparts = (int)(want > first_cands ? first_cands : want);
         if (nparts >= 2) {   // the class' budget of extra list entries (two scratch slots go with each)
-            const int old = atomicAdd(&P.part_used[E], nparts - 1);
-            if (old + nparts - 1 > (P.part_off[E + 1] - P.part_off[E]) / 2) { atomicAdd(&P.part_used[E], -(nparts - 1)); atomicAdd(&P.defer_refused[E], 1); nparts = 1; }   // (refused: the share goes back, the refusal is counted)
+            const int old = bump_reserve(&P.part_used[E], nparts - 1, (P.part_off[E + 1] - P.part_off[E]) / 2);
+            if (old < 0) { atomicAdd(&P.defer_refused[E], 1); nparts = 1; }   // (refused -- a smaller request may still fit --, and counted)
             else slot_base = P.part_off[E] + 2 * old;
         } else nparts = 1;
     }
@@ -689,11 +703,23 @@ __device__ __forceinline__ int32_t* enum_cursor(const Dev& P, int part, bool wid
     return P.heavy_in_next + ((kind * 2 + (wide ? 1 : 0)) * (kMaxEp + 1) + E);
 }
 
+// What the tile kernel of class E has listed when the launch before this one has ended: the end of stretch `j - 1` of the class' lists
+// (stretch 0 starts at 0: the snapshots are zeroed with the counter block of the pass)
+__global__ void k_enum_snapshot(Dev P, int E, int j) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int32_t* snap = P.enum_snap + (E * (kEnumStretches + 1) + j) * 4;
+    snap[0] = P.heavy_big_count[E]; snap[1] = P.heavy_in_count[E]; snap[2] = P.heavy_in_count[kMaxEp + 1 + E];
+}
+
 template <int E, int W>
-__global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy(Dev P, int pass, int mode, int part, int pool) {
+__global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy(Dev P, int pass, int mode, int part_arg, int pool) {
     // part: 0 = the class' lists, the long enumerations first (one launch serves both); 1 = only the long ones (the split spans
     // that k_merge_parts lists again); 2 = only the others.  `pool` = doubles of dynamic LDS for the pair-term tables.
+    // part_arg = part | (stretch + 1) << 8: a launch of part 0 that serves one stretch of the class' lists -- the entries the tile
+    // kernel appended between two snapshots of the list counters (k_enum_snapshot; launch_enumerate runs such launches beside the
+    // tile kernel of the class' following tiles instead of behind the last one)
     if (*P.err != 0) return;  // an earlier kernel of this pass reported an error: its outputs are not usable
+    const int part = part_arg & 255, stretch = (part_arg >> 8) - 1;
     static_assert(W == kNarrow || W == 64 * kCandWords, "one instantiation per half of the work list");
     constexpr bool kWide = W != kNarrow;
     constexpr int kList = kWide ? kMaxEp + 1 + E : E;
@@ -714,10 +740,14 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
     const int t = threadIdx.x, nt = blockDim.x;
     // part 3: the list parts of the deferred spans (see kListSplitFlag), appended behind the class' listed entries by the launch before
     // part 4: what k_enumerate_lean left to this kernel (P.fb_*: entries in the format of the list of long enumerations)
-    const int defer_base = part == 3 ? P.heavy_big_count[E] : 0;
-    const int n_big = part == 2 ? 0 : (part == 3 ? P.defer_count[E] : (part == 1 ? P.redo_count[E] : (part == 4 ? P.fb_count[E] : P.heavy_big_count[E])));   // (both instantiations walk the list of long enumerations; each takes its own)
-    const int count = n_big + ((part == 0 || part == 2) ? P.heavy_in_count[kList] : 0);
-    int32_t* next_counter = enum_cursor(P, part, kWide, E);   // (a cursor per kind of launch: nothing to reset between the launches of a class)
+    const int32_t* snap = stretch >= 0 ? P.enum_snap + (E * (kEnumStretches + 1) + stretch) * 4 : nullptr;   // [0] long enumerations, [1] narrow, [2] wide entries listed so far
+    const int big_lo = stretch >= 0 ? snap[0] : 0, in_lo = stretch >= 0 ? snap[kWide ? 2 : 1] : 0;
+    const int defer_base = part == 3 ? P.heavy_big_count[E] : big_lo;
+    const int n_big = stretch >= 0 ? snap[4] - big_lo
+                                   : (part == 2 ? 0 : (part == 3 ? P.defer_count[E] : (part == 1 ? P.redo_count[E] : (part == 4 ? P.fb_count[E] : P.heavy_big_count[E]))));   // (both instantiations walk the list of long enumerations; each takes its own)
+    const int count = n_big + (stretch >= 0 ? snap[4 + (kWide ? 2 : 1)] - in_lo : ((part == 0 || part == 2) ? P.heavy_in_count[kList] : 0));
+    int32_t* next_counter = stretch >= 0 ? P.enum_stretch_next + (E * kEnumStretches + stretch) * 2 + (kWide ? 1 : 0)
+                                         : enum_cursor(P, part, kWide, E);   // (a cursor per kind of launch: nothing to reset between the launches of a class)
     const int32_t *big_unit = part == 4 ? P.fb_unit : P.heavy_big_unit, *big_idx = part == 4 ? P.fb_idx : P.heavy_big_idx;
     const int32_t *big_part = part == 4 ? P.fb_part : P.heavy_big_part, *big_slot_of = part == 4 ? P.fb_slot : P.heavy_big_slot;
     const int nstatic = (int)gridDim.x * kWorkChunk;
@@ -747,7 +777,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
         // wave-uniform by construction; telling the compiler so turns every access to the unit descriptor below
         // into a scalar load (SGPRs, constant cache) instead of 64 lanes loading the same address
         const bool from_big = item < n_big;
-        const int pos = from_big ? P.heavy_big_off[E] + defer_base + item : (kWide ? P.heavy_in_off[E + 1] - 1 - (item - n_big) : P.heavy_in_off[E] + (item - n_big));
+        const int pos = from_big ? P.heavy_big_off[E] + defer_base + item : (kWide ? P.heavy_in_off[E + 1] - 1 - (in_lo + item - n_big) : P.heavy_in_off[E] + in_lo + (item - n_big));
         const int unit = __builtin_amdgcn_readfirstlane((from_big ? big_unit : P.heavy_in_unit)[pos]);
         const int i_raw = __builtin_amdgcn_readfirstlane((from_big ? big_idx : P.heavy_in_idx)[pos]);
         const int i = i_raw & ~kIdxReplayFlag;
@@ -1000,14 +1030,17 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_HEAVY_ATTR k_enumerate_heavy
             auto defer_reserve = [&](int np, int n) -> bool {
                 int got = -1, at = 0;
                 if (t == 0 && np >= 2) {
-                    const int old = atomicAdd(&P.part_used[E], np);   // (the span's own entry stays on the list: every part is an extra one)
                     // (a full arena is not asked again: the counter stays below 2^31 however many spans of a very large batch would like
-                    // to defer -- what can be added beyond the cap is bounded by the lists resident at a time)
-                    if (old + np <= (P.part_off[E + 1] - P.part_off[E]) / 2 && atomicAdd(P.defer_used, 0) < P.defer_cap) {
+                    // to defer -- what can be added beyond the cap is bounded by the lists resident at a time.  The arena first: what it
+                    // hands out is never given back, the class' budget is only taken when the list has its room)
+                    if (atomicAdd(&P.part_used[E], 0) + np <= (P.part_off[E + 1] - P.part_off[E]) / 2 && atomicAdd(P.defer_used, 0) < P.defer_cap) {
                         at = atomicAdd(P.defer_used, n);
-                        if (at >= 0 && (long long)at + n <= (long long)P.defer_cap) got = P.part_off[E] + 2 * old;
+                        if (at >= 0 && (long long)at + n <= (long long)P.defer_cap) {
+                            const int old = bump_reserve(&P.part_used[E], np, (P.part_off[E + 1] - P.part_off[E]) / 2);   // (the span's own entry stays on the list: every part is an extra one)
+                            if (old >= 0) got = P.part_off[E] + 2 * old;
+                        }
                     }
-                    if (got < 0) { atomicAdd(&P.part_used[E], -np); atomicAdd(&P.defer_refused[E], 1); }   // a refusal gives its share of the budget back (a smaller request may still fit) and is counted
+                    if (got < 0) atomicAdd(&P.defer_refused[E], 1);   // (refused -- a smaller request may still fit --, and counted)
                 }
                 defer_slot = __shfl(got, 0); defer_at = __shfl(at, 0); defer_np = np;
                 return defer_slot >= 0;
@@ -1805,6 +1838,39 @@ __device__ __forceinline__ unsigned long long lane_value(unsigned long long v, i
 #endif
 __device__ __forceinline__ double lane_value(double v, int j) { return __longlong_as_double((long long)lane_value((unsigned long long)__double_as_longlong(v), j)); }
 
+// list.sort(reverse=True) of a few (score, tuple) entries under Python's order `lt` -- a strict partial order (tuples whose first
+// differing spans start together are incomparable), so the steps of CPython's sort are followed one by one: reverse, count_run +
+// binary insertion, reverse.
+template <class LT>
+__device__ __forceinline__ void py_sort_desc(double* hs, unsigned long long* hx, int n, const LT& lt) {
+    auto reverse = [&](int m) {
+        for (int i = 0, j = m - 1; i < j; i++, j--) {
+            const double a = hs[i]; hs[i] = hs[j]; hs[j] = a;
+            const unsigned long long b = hx[i]; hx[i] = hx[j]; hx[j] = b;
+        }
+    };
+    if (n < 2) return;
+    reverse(n);
+    int run = 2;
+    if (lt(hs[1], hx[1], hs[0], hx[0])) {
+        for (int i = 2; i < n; i++, run++) if (!lt(hs[i], hx[i], hs[i - 1], hx[i - 1])) break;
+        reverse(run);
+    } else {
+        for (int i = 2; i < n; i++, run++) if (lt(hs[i], hx[i], hs[i - 1], hx[i - 1])) break;
+    }
+    for (int start = run; start < n; start++) {
+        int l = 0, r = start;
+        const double ps = hs[start]; const unsigned long long px = hx[start];
+        do {
+            const int p = l + ((r - l) >> 1);
+            if (lt(ps, px, hs[p], hx[p])) r = p; else l = p + 1;
+        } while (l < r);
+        for (int p = start; p > l; p--) { hs[p] = hs[p - 1]; hx[p] = hx[p - 1]; }
+        hs[l] = ps; hx[l] = px;
+    }
+    reverse(n);
+}
+
 struct MergeHeap {
     double* hs;                      // [kTopK + 1] scores
     unsigned long long* hx;          // [kTopK + 1] positions in the cut-off windows, 8 bits per endpoint
@@ -1850,33 +1916,8 @@ struct MergeHeap {
             if (n > 0) { hs[0] = ls; hx[0] = lx; siftup(0); }
         }
     }
-    __device__ void reverse(int m) {
-        for (int i = 0, j = m - 1; i < j; i++, j--) {
-            const double a = hs[i]; hs[i] = hs[j]; hs[j] = a;
-            const unsigned long long b = hx[i]; hx[i] = hx[j]; hx[j] = b;
-        }
-    }
-    __device__ void sort_desc() {   // list.sort(reverse=True) of <= 5 entries: reverse, count_run + binary insertion, reverse
-        if (n < 2) return;
-        reverse(n);
-        int run = 2;
-        if (lt(hs[1], hx[1], hs[0], hx[0])) {
-            for (int i = 2; i < n; i++, run++) if (!lt(hs[i], hx[i], hs[i - 1], hx[i - 1])) break;
-            reverse(run);
-        } else {
-            for (int i = 2; i < n; i++, run++) if (lt(hs[i], hx[i], hs[i - 1], hx[i - 1])) break;
-        }
-        for (int start = run; start < n; start++) {
-            int l = 0, r = start;
-            const double ps = hs[start]; const unsigned long long px = hx[start];
-            do {
-                const int p = l + ((r - l) >> 1);
-                if (lt(ps, px, hs[p], hx[p])) r = p; else l = p + 1;
-            } while (l < r);
-            for (int p = start; p > l; p--) { hs[p] = hs[p - 1]; hx[p] = hx[p - 1]; }
-            hs[l] = ps; hx[l] = px;
-        }
-        reverse(n);
+    __device__ void sort_desc() {   // list.sort(reverse=True) of <= 5 entries
+        py_sort_desc(hs, hx, n, [&](double sa, unsigned long long xa, double sb, unsigned long long xb) { return lt(sa, xa, sb, xb); });
     }
 };
 

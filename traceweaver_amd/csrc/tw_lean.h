@@ -407,13 +407,16 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
                     auto defer_reserve = [&](int np, int n) -> bool {
                         int got = -1, at = 0;
                         if (t == 0 && np >= 2) {
-                            const int old = atomicAdd(&P.part_used[E], np);   // (the span's own entry stays on the list: every part is an extra one)
-                            bool ok = old + np <= (P.part_off[E + 1] - P.part_off[E]) / 2 && atomicAdd(P.defer_used, 0) < P.defer_cap;
+                            // (the arena first -- what it hands out is never given back --, the class' budget by compare-and-swap: bump_reserve)
+                            bool ok = atomicAdd(&P.part_used[E], 0) + np <= (P.part_off[E + 1] - P.part_off[E]) / 2 && atomicAdd(P.defer_used, 0) < P.defer_cap;
                             if (ok) {
                                 at = atomicAdd(P.defer_used, n);
-                                if (at >= 0 && (long long)at + n <= (long long)P.defer_cap) got = P.part_off[E] + 2 * old;
+                                if (at >= 0 && (long long)at + n <= (long long)P.defer_cap) {
+                                    const int old = bump_reserve(&P.part_used[E], np, (P.part_off[E + 1] - P.part_off[E]) / 2);   // (the span's own entry stays on the list: every part is an extra one)
+                                    if (old >= 0) got = P.part_off[E] + 2 * old;
+                                }
                             }
-                            if (got < 0) { atomicAdd(&P.part_used[E], -np); atomicAdd(&P.defer_refused[E], 1); }   // (a refusal gives its share of the budget back)
+                            if (got < 0) atomicAdd(&P.defer_refused[E], 1);   // (refused -- a smaller request may still fit --, and counted)
                         }
                         defer_slot = __shfl(got, 0); defer_at = __shfl(at, 0); defer_np = np;
                         return defer_slot >= 0;

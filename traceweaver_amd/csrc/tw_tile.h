@@ -35,6 +35,16 @@ namespace tw {
 #define TW_TILE_MAX 256
 #endif
 constexpr int kTileMax = TW_TILE_MAX;   // largest enumeration (product of the contained candidates) the tile kernel takes itself
+#ifndef TW_TILE_REPLAY_MAX
+#define TW_TILE_REPLAY_MAX 256
+#endif
+constexpr int kTileReplayMax = TW_TILE_REPLAY_MAX;   // most feasible tuples of a span whose heap its own thread replays (phase 5b); the others go to the wavefront kernel
+// items of a span before those of endpoint e (contained candidates per endpoint, 8 bits each, in pk)
+__device__ __forceinline__ int pos_base(unsigned long long pk, int e) {
+    int acc = 0;
+    for (int f = 0; f < e; f++) acc += (int)((pk >> (8 * f)) & 255ull);
+    return acc;
+}
 #ifndef TW_TILE_ITEMS
 #define TW_TILE_ITEMS 768
 #define TW_TILE_GRID 1024
@@ -492,6 +502,50 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
             P.tk_score[tks_index(U, k, si)] = g_sc[g];
 #pragma unroll
             for (int e = 0; e < E; e++) P.tk_idx[tk_index(U, k, e, si)] = s_A[e] + ix[e];
+        }
+        // ---- 5b. a span whose top five the ranks do not decide (s_amb: equal scores, tuples Python's order does not compare --
+        // millisecond-granular traces have them in a third of their spans): the reference's procedure itself, by the span's own
+        // thread -- CPython's heap over the span's tuples in enumeration order (traceweaver_v3.py:304-307), then its list.sort --
+        // on the scores of phase 4.  (Such a span used to go to the wavefront kernel, which staged its windows and evaluated its terms
+        // again for a wavefront's ~90 us: 10.7 of the 29 ms of a pass on the nodejs shape at 14.4 M spans.)  The term tables of the
+        // segment are free by now: kTopK + 1 slots of each per span hold the heap for the sort.
+        group_sync();   // (the lanes above skip the tuples of undecided spans: s_amb is cleared only when all have passed)
+        if (live && t >= seg && t < send && mine && s_amb[t] && (t + 1) * (kTopK + 1) <= C::kItems && s_leaves[t] <= kTileReplayMax) {
+            RegHeap RH;
+            RH.clear(E);
+            const unsigned long long pk = s_cn[t];
+            auto start_of = [&](int e, int pos) -> int32_t { return sl_st[e][it_idx[s_item0[t] - it0 + pos_base(pk, e) + pos]]; };
+            uint32_t real = 1;
+#pragma unroll
+            for (int e = 0; e < E; e++) real *= (uint32_t)((pk >> (8 * e)) & 255ull);
+            const int gs = s_grid0[t] - g0;
+            for (uint32_t gi = 0; gi < real; gi++) {
+                const double sc = g_sc[gs + gi];
+                if (!(sc == sc) || RH.below_root(sc)) continue;   // infeasible / strictly below the root of a full heap: the push leaves the array as it is
+                unsigned long long x = 0;
+                uint32_t rest = gi;
+#pragma unroll
+                for (int e = E - 1; e >= 0; e--) {
+                    const uint32_t c = (uint32_t)((pk >> (8 * e)) & 255ull);
+                    const uint32_t q = c == 1 ? rest : div_small(rest, c);
+                    x |= (unsigned long long)(rest - q * c) << (8 * e);
+                    rest = q;
+                }
+                RH.push(sc, x, start_of);
+            }
+            double* hs = t_root + t * (kTopK + 1);
+            unsigned long long* hx = reinterpret_cast<unsigned long long*>(t_close + t * (kTopK + 1));
+#pragma unroll
+            for (int k = 0; k < kTopK; k++) { hs[k] = RH.s[k]; hx[k] = RH.x[k]; }
+            py_sort_desc(hs, hx, RH.n, [&](double sa, unsigned long long xa, double sb, unsigned long long xb) { return RH.lt(sa, xa, sb, xb, start_of); });
+            const int si = first + t;
+            for (int k = 0; k < RH.n; k++) {
+                P.tk_score[tks_index(U, k, si)] = hs[k];
+#pragma unroll
+                for (int e = 0; e < E; e++)
+                    P.tk_idx[tk_index(U, k, e, si)] = s_A[e] + (int)it_idx[s_item0[t] - it0 + pos_base(pk, e) + (int)((hx[k] >> (8 * e)) & 255ull)];
+            }
+            s_amb[t] = 0;   // (read again only by this thread: below, and when the tile hands its undecided spans on)
         }
         if (live && t >= seg && t < send && mine && !s_amb[t]) {
             // a span's list has min(5, feasible tuples) entries in every pass; the unused entries keep the -1 / NaN
