@@ -191,6 +191,21 @@ def test_nodejs_fileio_shape_at_scale():
         parity.assert_assignment_properties(u, r["parent"])
 
 
+def test_nodejs_fileio_shape_staged_with_alternating_classes(monkeypatch):
+    """Two replicas of the config 3 shape -- units of one and two endpoints alternate in the batch -- with every class' window / selection /
+    consumption stage on the class' own stream (launch_class_stage; forced: batches this small join their classes).  A class' first
+    round of the span consumption lists the windows to repair (by tile number) while the other class is still working through the lists
+    of its first solve (by the tiles' order within the class): with both in one pair of arrays a window was solved twice and another
+    not at all, differently from run to run.  Held to the oracle in full, three times."""
+    monkeypatch.setenv("TW_STAGE_MIN_TILES", "0")
+    units, _ = synth.make_nodejs_workload(17, 20000, concurrency=4.0, replicas=2)
+    assert [u.E for u in units] == [1, 2, 1, 1, 1, 2, 1, 1]
+    for _ in range(3):
+        r1, r2, _ = parity.check_units(None, units)
+        assert sum(r["repaired_windows"] for r in r1 + r2) > 0
+        assert sum(r["budget_windows"] for r in r1 + r2) == 0
+
+
 def fitted_tables(lib_path, units):
     from traceweaver_amd.engine import Engine
 

@@ -136,6 +136,7 @@ struct Dev {
     int32_t* heavy_next;    // [tile set slot][8] next unclaimed item of every selection list of the set; [0][4], [0][5]: see hard_unit
     int32_t *heavy_unit, *heavy_win;
     int32_t *tiny_unit, *tiny_win;
+    int32_t *rheavy_unit, *rheavy_win, *rtiny_unit, *rtiny_win;   // ... of the repair rounds (slot 0: list_window)
     int32_t *hard_unit, *hard_win;   // windows k_select_heavy gave up on, for k_select_dp (count and cursor: heavy_next[4], [5])
     int32_t* heavy_in_count;  // [2][kMaxEp+1] incoming spans deferred to k_enumerate_heavy per endpoint count E: narrow, wide windows
     int32_t* heavy_in_next;   // [4][2][kMaxEp+1] work-list cursors of the wavefront kernels: per kind of launch (the class' lists, list parts, spans listed again, fallback), instantiation (narrow, wide) and class (enum_cursor)

@@ -80,7 +80,7 @@ struct tw_engine {
     // ... and a second set for the stages of the other classes that hold a large share of the batch's spans (their searches one after the
     // other on the class' stream were the longest chain of a pass on the nodejs shape: 4.7 + 8.7 + 1.8 ms for the three one-endpoint services)
     hipStream_t sel_stream2[3] = {};
-    int64_t select_fork_min = 2000000;   // TW_SELECT_FORK_MIN: incoming spans of a class from which its stage forks too (0 = only the deepest class)
+    int64_t select_fork_min = 0;         // TW_SELECT_FORK_MIN: incoming spans of a class from which its stage forks too (0 = only the deepest class)
     hipEvent_t prep_ev = nullptr;              // the per-pass fills the selection stage needs (main stream, beside the enumerations)
     hipEvent_t post_fork[kMaxEp + 1] = {}, post_join[kMaxEp + 1][3] = {}, post_done[kMaxEp + 1] = {};
     hipEvent_t tile_ev[kMaxEp + 1] = {};       // class E's tile kernel done (launch_enumerate: gating of the classes launched after it)
@@ -285,10 +285,16 @@ int sort_ends(tw_engine* e, const TileSet& S, hipStream_t st) {   // (the counte
 // Extra work-list entries of a class for the parts of its split enumerations.  Up to four endpoints few spans are split (an eighth of
 // the class + 64 was never short); in the deep call graphs most wavefront-enumerated spans are, and a budget that runs out leaves
 // whichever spans come last unsplit -- single wavefronts then hold the class' kernel for milliseconds (round 5: 3 of its 4 ms).
+// (Round 6, with the budget kept exactly -- bump_reserve in tw_kernels.h: the media shape at eight requests in flight asks for parts
+// for 2 400 of its 20 000 four-endpoint spans and an eighth of the class serves 520 of them; serving all of them -- TW_PART_BUDGET_SHALLOW
+// = 2 entries per span, like the deep classes -- is no faster: 10.5 vs 9.5 ms per step, k_merge_parts then replays 2 400 spans' logs.
+// One-endpoint classes never split: no budget.)
 int64_t part_extra(int cls, int64_t n_cls) {
     if (n_cls <= 0) return 0;
-    static const int deep = env_int("TW_PART_BUDGET_DEEP", 2);
-    return (cls >= 5 && deep > 0 ? n_cls * deep : n_cls / 8) + 64;
+    static const int deep = env_int("TW_PART_BUDGET_DEEP", 2), shallow = env_int("TW_PART_BUDGET_SHALLOW", 0);
+    if (cls <= 1) return 64;
+    const int mult = cls >= 5 ? deep : shallow;
+    return (mult > 0 ? n_cls * mult : n_cls / 8) + 64;
 }
 
 // `listed` (mode 1 only): the class' entries of heavy_in_count as the host read them with the round's change count -- a class, or an
@@ -931,7 +937,7 @@ int tw_create(int device_id, tw_engine** out) {
     e->heavy_grid = std::max(env_int("TW_HEAVY_GRID", 4096), 64);
     e->select_grid = std::max(env_int("TW_SELECT_GRID", 4096), 64);
     e->debug_lists = env_int("TW_DEBUG_LISTS", 0);
-    e->select_fork_min = (int64_t)env_int("TW_SELECT_FORK_MIN", 2000000);
+    e->select_fork_min = (int64_t)env_int("TW_SELECT_FORK_MIN", 0);
     e->stretch_min_tiles = std::max(env_int("TW_STRETCH_MIN_TILES", 2048), 1);
     e->stage_min_tiles = env_int("TW_STAGE_MIN_TILES", 1024);
     e->tile_sub_max = std::max(env_int("TW_TILE_SUB", 8), 1);   // workgroups per tile for classes of few tiles (1 = never)
@@ -1179,10 +1185,14 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     ALLOC(P.heavy_in_unit, n_in_total); ALLOC(P.heavy_in_idx, n_in_total);
     {   // long enumerations: a list entry per span plus the extra entries of the split ones (an eighth of the class + 64), two
         // scratch slots per extra entry
-        int64_t big_total = 0, slots = 0;
+        int64_t big_total = 0, slots = 0, want = 0;
+        for (int cls = 0; cls <= kMaxEp; cls++) want += 2 * part_extra(cls, heavy_off_h[cls + 1] - heavy_off_h[cls]);
+        // (a scratch slot is 4.4 KB, most of it the log of a part in log mode: at most TW_PART_SLOTS_MAX slots, 16 M = 70 GB, whatever the batch)
+        static const int64_t slots_max = (int64_t)std::max(env_int("TW_PART_SLOTS_MAX", 16 << 20), 1024);
         for (int cls = 0; cls <= kMaxEp; cls++) {
             const int64_t n_cls = heavy_off_h[cls + 1] - heavy_off_h[cls];
-            const int64_t extra = part_extra(cls, n_cls);
+            int64_t extra = part_extra(cls, n_cls);
+            if (want > slots_max && extra > 64) extra = std::max<int64_t>((int64_t)((double)extra * (double)slots_max / (double)want), std::min<int64_t>(n_cls / 8 + 64, extra));
             P.heavy_big_off[cls] = (int32_t)big_total; P.part_off[cls] = (int32_t)slots;
             big_total += n_cls + extra; slots += 2 * extra;
         }
@@ -1231,6 +1241,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     }
     ALLOC(P.heavy_unit, sel_cap); ALLOC(P.heavy_win, sel_cap);
     ALLOC(P.tiny_unit, sel_cap); ALLOC(P.tiny_win, sel_cap);
+    ALLOC(P.rheavy_unit, sel_cap); ALLOC(P.rheavy_win, sel_cap); ALLOC(P.rtiny_unit, sel_cap); ALLOC(P.rtiny_win, sel_cap);
     ALLOC(P.hard_unit, sel_cap / (kBruteMax + 1) + 1 + kSelSlots); ALLOC(P.hard_win, sel_cap / (kBruteMax + 1) + 1 + kSelSlots);   // (a searched window holds more than kBruteMax spans)
     ALLOC(e->rank_in, n_in_total); ALLOC(e->rank_out, n_out_total);
     ALLOC(e->agg_pair, P.n_tiles); ALLOC(e->agg_i32, P.n_tiles); ALLOC(e->agg_i32b, P.n_tiles);

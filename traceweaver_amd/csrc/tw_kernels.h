@@ -33,18 +33,16 @@ __device__ __forceinline__ int wave_append(int32_t* counter, bool pred) {
     base = __shfl(base, leader);
     return pred ? base + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
 }
-// `n` consecutive units of a budget that is handed out by a bump counter: the first of them, or -1 when they do not fit.  By
-// compare-and-swap: a refusal changes nothing.  (Adding first and subtracting on refusal hands the same units out twice -- A adds,
-// B adds behind A and is served, A is refused and subtracts, C is served from where A began: inside B's units.  Two split spans then
-// shared scratch slots, and one of them came back with another span's tuples, about once in sixty batches of the stress units.)
+// `n` consecutive units of a budget that is handed out by a bump counter: the first of them, or -1 when they do not fit.  What is
+// added is never taken back.  (Subtracting on refusal hands the same units out twice -- A adds, B adds behind A and is served, A is
+// refused and subtracts, C is served from where A began: inside B's units.  Two split spans then shared scratch slots, and one of them
+// came back with another span's tuples, about once in sixty batches of the stress units.  A compare-and-swap loop is exact but takes
+// turns: 2 400 lanes asking at once held the tile kernel of the media shape at eight requests in flight for 13 ms.)  A request that
+// finds the budget spent does not add -- the counter stays near the budget whatever the batch --; one that overshoots leaves a hole.
 __device__ __forceinline__ int bump_reserve(int32_t* counter, int n, int budget) {
-    int old = atomicAdd(counter, 0);
-    while (old + n <= budget) {
-        const int seen = atomicCAS(counter, old, old + n);
-        if (seen == old) return old;
-        old = seen;
-    }
-    return -1;
+    if (atomicAdd(counter, 0) + n > budget) return -1;
+    const int old = atomicAdd(counter, n);
+    return old + n <= budget ? old : -1;
 }
 
 // Barrier of a workgroup that is a single wavefront: LDS operations of one wavefront execute in program order, so
@@ -3504,7 +3502,13 @@ __device__ __forceinline__ void list_window(const Dev& P, const TileSet& S, int 
     const int base = (S.base + sel_first_tile(s, S.n)) * P.tile_spans, end = (S.base + sel_first_tile(s + 1, S.n)) * P.tile_spans;
     // two arrays, each filled from both ends of the segment: short windows and very long ones share tiny_*, long and middle ones heavy_*
     // (a segment has room for every window of its tiles)
-    int32_t *au = (cls == 0 || cls == 3) ? P.tiny_unit : P.heavy_unit, *aw = (cls == 0 || cls == 3) ? P.tiny_win : P.heavy_win;
+    // (the lists of the repair rounds -- slot 0, positions by tile number -- have arrays of their own: a class' first round of the span
+    // consumption lists into them while other classes are still working through the lists of their first solve, whose positions follow
+    // the tiles' order by class.  In one pair of arrays those entries overwrote one another whenever units of different endpoint counts
+    // alternate in the batch: a window was then solved twice and another not at all, differently from run to run)
+    const bool rep = S.slot == 0;
+    int32_t *au = (cls == 0 || cls == 3) ? (rep ? P.rtiny_unit : P.tiny_unit) : (rep ? P.rheavy_unit : P.heavy_unit);
+    int32_t *aw = (cls == 0 || cls == 3) ? (rep ? P.rtiny_win : P.tiny_win) : (rep ? P.rheavy_win : P.heavy_win);
     const int pos = cls == 0 ? base + s0 : (cls == 1 ? base + s1 : (cls == 2 ? end - 1 - s2 : end - 1 - s3));
     // (the window as its first span and its size, 26 + 6 bits: the consumer's chain of dependent loads -- item, unit, window
     // bounds, candidates -- is what a short window costs)
@@ -3610,7 +3614,8 @@ __global__ void __launch_bounds__(64) k_select_heavy(Dev P, TileSet S) {  // per
             if (item >= count) continue;
         }
         const int pos = sel_position(P, S, G, item, LIST != 1);
-        const int32_t *au = LIST == 3 ? P.tiny_unit : P.heavy_unit, *aw = LIST == 3 ? P.tiny_win : P.heavy_win;
+        const bool rep = S.slot == 0;
+        const int32_t *au = LIST == 3 ? (rep ? P.rtiny_unit : P.tiny_unit) : (rep ? P.rheavy_unit : P.heavy_unit), *aw = LIST == 3 ? (rep ? P.rtiny_win : P.tiny_win) : (rep ? P.rheavy_win : P.heavy_win);
         const int unit = __builtin_amdgcn_readfirstlane(au[pos]);  // wave-uniform: scalar loads below
         const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane(aw[pos]);
         const UnitDev& U = P.units[unit];
@@ -3665,8 +3670,8 @@ __global__ void __launch_bounds__(64) k_select_tiny(Dev P, TileSet S) {  // pers
         if (chunk_pos >= count) { TW_SEL_FLUSH(); break; }
         const int item = chunk_pos++;
         const int pos = sel_position(P, S, G, item, false);
-        const int unit = __builtin_amdgcn_readfirstlane(P.tiny_unit[pos]);
-        const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane(P.tiny_win[pos]);
+        const int unit = __builtin_amdgcn_readfirstlane((S.slot == 0 ? P.rtiny_unit : P.tiny_unit)[pos]);
+        const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane((S.slot == 0 ? P.rtiny_win : P.tiny_win)[pos]);
         const UnitDev& U = P.units[unit];
         const int first = (int)(fm >> 6), last = first + (int)(fm & 63u);
         select_window_coop(P, U, unit, first, last - first + 1, L TW_SEL_PASS, false);   // (complete enumeration only: no search nodes to report)

@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(kHeavyThreads) TW_LEAN_ATTR k_enumerate_lean(D
                     auto defer_reserve = [&](int np, int n) -> bool {
                         int got = -1, at = 0;
                         if (t == 0 && np >= 2) {
-                            // (the arena first -- what it hands out is never given back --, the class' budget by compare-and-swap: bump_reserve)
+                            // (the arena first -- what it hands out is never given back --, the class' budget by bump_reserve, which takes nothing back either)
                             bool ok = atomicAdd(&P.part_used[E], 0) + np <= (P.part_off[E + 1] - P.part_off[E]) / 2 && atomicAdd(P.defer_used, 0) < P.defer_cap;
                             if (ok) {
                                 at = atomicAdd(P.defer_used, n);

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
     __shared__ uint16_t it_idx[C::kItems];                // slice position of the item's candidate
     __shared__ double g_sc[C::kGrid];
     __shared__ uint8_t g_span[C::kGrid], g_rank[C::kGrid];   // the tuple's span (tile-local) / its rank; an infeasible grid point has score NaN
-    __shared__ int32_t s_segend;
+    __shared__ int32_t s_segend, s_anyamb;                 // ... any span of the segment whose top five the ranks do not decide (phase 5b)
     const bool live = t < ns;
     const int i = first + (live ? t : 0);
     const int64_t base = P.in_start[U.in_off + first];
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
     };
     // ---- segments of the tile: as many spans as the tables hold ------------------------------------------------------
     for (int seg = 0; seg < ns;) {
-        if (t == 0) s_segend = ns;
+        if (t == 0) { s_segend = ns; s_anyamb = 0; }
         group_sync();
         if (live && t >= seg && (s_item0[t + 1] - s_item0[seg] > C::kItems || s_grid0[t + 1] - s_grid0[seg] > C::kGrid)) atomicMin(&s_segend, t);
         group_sync();
@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
                         else if (ord == 0) partner = true;
                     }
                 }
-                if (partner && rank < kTopK) s_amb[s] = 1;
+                if (partner && rank < kTopK) { s_amb[s] = 1; s_anyamb = 1; }
             }
             g_rank[g] = (uint8_t)(rank < kTopK ? rank : kTopK);
         }
@@ -509,8 +509,8 @@ __global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, c
         // on the scores of phase 4.  (Such a span used to go to the wavefront kernel, which staged its windows and evaluated its terms
         // again for a wavefront's ~90 us: 10.7 of the 29 ms of a pass on the nodejs shape at 14.4 M spans.)  The term tables of the
         // segment are free by now: kTopK + 1 slots of each per span hold the heap for the sort.
-        group_sync();   // (the lanes above skip the tuples of undecided spans: s_amb is cleared only when all have passed)
-        if (live && t >= seg && t < send && mine && s_amb[t] && (t + 1) * (kTopK + 1) <= C::kItems && s_leaves[t] <= kTileReplayMax) {
+        if (s_anyamb != 0) group_sync();   // (the lanes above skip the tuples of undecided spans: s_amb is cleared only when all have passed; the flag is the same for all since the barrier after the ranks)
+        if (s_anyamb != 0 && live && t >= seg && t < send && mine && s_amb[t] && (t + 1) * (kTopK + 1) <= C::kItems && s_leaves[t] <= kTileReplayMax) {
             RegHeap RH;
             RH.clear(E);
             const unsigned long long pk = s_cn[t];
