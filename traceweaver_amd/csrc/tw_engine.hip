@@ -384,7 +384,10 @@ void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
     if (n_wide != 0) wide(0, grid_for(n_wide, 1024));   // (stretched: the wide instantiation once, over the whole lists)
     if (mode == 0 && E >= 3 && E >= P.defer_min_e) { narrow(3, grid_for(-1, 4096)); if (n_wide != 0) wide(3, grid_for(-1, 1024)); }
     if (mode == 0 && E > 1) {
-        hipLaunchKernelGGL(k_merge_parts, dim3(256), dim3(std::min(e->coop, 64)), 0, st, P, pass, E, E);   // (34 KB of LDS a workgroup: a thousand of them ask for all there is)
+        // (34 KB of LDS a workgroup: a thousand of them ask for all there is -- which a class of a million spans and more is given; measured
+        // on the two-endpoint class of the nodejs shape at 14.4 M spans, whose merge takes 2.3 ms with 256: no change to the step, the
+        // class' chain is not the longest of that pass)
+        hipLaunchKernelGGL(k_merge_parts, dim3(cap >= (1 << 20) ? 1024 : 256), dim3(std::min(e->coop, 64)), 0, st, P, pass, E, E);
         narrow(1, 256); if (n_wide != 0) wide(1, 64);
     }
     if (e->debug_lists != 0 && mode == 0) {

@@ -107,8 +107,15 @@ __device__ __forceinline__ double score_term_gap(const Scorer& S, int slot, long
 #define TW_TILE_FLUSH() do {} while (0)
 #endif
 
+// (phase 5b's heap in registers took the kernel from 64 to 135 registers for four endpoints: three workgroups per CU where the LDS lets four
+// in, 20.0 -> 20.3 ms on the headline.  Up to four endpoints the compiler is held to four wavefronts per SIMD -- 128 registers)
+#ifdef TW_HOST_EMULATION
+#define TW_TILE_ATTR
+#else
+#define TW_TILE_ATTR __attribute__((amdgpu_waves_per_eu(E <= 4 ? 4 : 2)))
+#endif
 template <int E, int SPANS = kTile>
-__global__ void __launch_bounds__(4 * kTile) k_enumerate_tile(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e, int sub_tiles) {
+__global__ void __launch_bounds__(4 * kTile) TW_TILE_ATTR k_enumerate_tile(Dev P, int pass, const int32_t* tile_ids, int n_tiles_e, int sub_tiles) {
     if (*P.err != 0) return;  // e.g. NaN parameters (hazard H3): nothing downstream is meaningful
     typedef TileCfg<E, SPANS> C;
     constexpr int SL = C::kSlice;
