@@ -206,6 +206,37 @@ def test_nodejs_fileio_shape_staged_with_alternating_classes(monkeypatch):
         assert sum(r["budget_windows"] for r in r1 + r2) == 0
 
 
+@pytest.mark.parametrize("shape", ["media_concurrency8", "nodejs"])
+def test_staged_joined_and_single_queue_runs_agree_at_scale(shape, monkeypatch):
+    """The whole chain (pass 1, the device's refit, pass 2) on a few hundred thousand requests with windows to repair: the per-class stages on
+    the classes' streams, all classes joined after the enumeration, and the staged pass again -- the same parents, bit for bit.  (Round 6: the
+    staged route differed from run to run on such batches until the repair rounds' lists got arrays of their own; on the GPU box the same
+    comparison was made at 2.5-8 M spans with one and four hardware queues as well, profiles/HISTORY.md.)"""
+    from traceweaver_amd.engine import Engine
+
+    if shape == "nodejs":
+        units, _ = synth.make_nodejs_workload(23, 50000, concurrency=4.0, replicas=2)
+    else:
+        units, _ = synth.make_workload(23, 20000, services=synth.MEDIA_SERVICES, replicas=2, concurrency=8.0)
+    outs = []
+    for env in ({"TW_STAGE_MIN_TILES": "0"}, {"TW_CLASS_PIPELINE": "0"}, {"TW_STAGE_MIN_TILES": "0"}):
+        for k in ("TW_STAGE_MIN_TILES", "TW_CLASS_PIPELINE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = Engine(0)
+        eng.load(units)
+        eng.run_pass1()
+        eng.fit_mixtures()
+        eng.run_pass2()
+        res = eng.results(2, fields=("parent", "unit_stats"))
+        eng.close()
+        assert sum(int(r["repaired_windows"]) for r in res) > 0
+        assert sum(int(r["budget_windows"]) for r in res) == 0
+        outs.append(np.concatenate([np.asarray(r["parent"]).ravel() for r in res]))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 def fitted_tables(lib_path, units):
     from traceweaver_amd.engine import Engine
 
