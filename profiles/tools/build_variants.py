@@ -41,6 +41,8 @@ VARIANTS = {
     "lean3": ["-DTW_LEAN_ATTR=__attribute__((amdgpu_waves_per_eu(3,3)))"],   # round 6: k_enumerate_lean held to 168 / 128 registers
     "lean4": ["-DTW_LEAN_ATTR=__attribute__((amdgpu_waves_per_eu(4,4)))"],
     "lean2": ["-DTW_LEAN_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"],
+    "dp96": ["-DTW_DP_CAP=96", "-DTW_DP_SLOTS=128"],       # round 6: tables of k_select_dp (states a level, hash slots): LDS per workgroup 69 -> 34 / 46 KB
+    "dp192": ["-DTW_DP_CAP=192", "-DTW_DP_SLOTS=256"],
 }
 
 
