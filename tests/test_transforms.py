@@ -239,6 +239,32 @@ def test_gpu_engine_on_scaled_units(oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_engine_repeats_itself_on_scaled_stress_units():
+    """The same batch sixty times, every result compared with the first run's, bit for bit.  These units exhaust the budget of extra list
+    entries of their four-endpoint class (spans refused parts) while their tiles run as sub-tiles side by side: the batch on which a
+    refusal that gave its share back by subtraction handed scratch slots out twice -- a split span then came back with another span's
+    tuples in one run of thirty (round 6, bump_reserve in tw_kernels.h)."""
+    units = _scaled_stress_units()
+    first = None
+    for it in range(60):
+        eng = Engine(0)
+        eng.load(units)
+        eng.run_pass1()
+        if it == 0:
+            w = eng.worklists()
+            assert w["split_spans"] > 0 and w["parts_refused"] > 0, w
+        res = eng.results(1)
+        eng.close()
+        cur = [(np.asarray(r["topk_idx"]), np.asarray(r["topk_score"]), np.asarray(r["topk_n"]), np.asarray(r["parent"])) for r in res]
+        if first is None:
+            first = cur
+            continue
+        for k, (a, b) in enumerate(zip(first, cur)):
+            for x, y, what in zip(a, b, ("top-5 tuples", "scores", "candidate counts", "parents")):
+                assert np.array_equal(x, y, equal_nan=True), "run %d, unit %d: %s differ from the first run's" % (it, k, what)
+
+
+@pytest.mark.gpu
 def test_gpu_engine_on_scaled_stress_units():
     r1, r2, _ = parity.check_units(None, _scaled_stress_units())
     assert sum(r["repaired_windows"] for r in r1) > 0
