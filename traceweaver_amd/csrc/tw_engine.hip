@@ -437,23 +437,36 @@ int launch_windows(tw_engine* e, const TileSet& S, hipStream_t st) {
 // What the searches give up on goes to one list for k_select_dp (the caller launches it when every set has joined).
 // (fork = false: everything on st, one after the other -- the stages of the classes that end before the last one have the time, and the
 // three selection streams stay free for the class whose stage ends the pass)
+// the three instantiations of k_select_heavy with room for EMAX endpoints per candidate (SelectLdsT: what a workgroup holds in LDS decides
+// how many windows the GPU searches at a time)
+template <int EMAX>
+void launch_select_heavy3(tw_engine* e, const TileSet& S, dim3 grid, dim3 wave, hipStream_t s0, hipStream_t s1, hipStream_t s2) {
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsLvlE<EMAX>, 3>), grid, wave, 0, s0, e->P, S);      // the longest searches first
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsBigLvlE<EMAX>, 1>), grid, wave, 0, s1, e->P, S);
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsMidLvlE<EMAX>, 2>), grid, wave, 0, s2, e->P, S);
+}
+void launch_select_heavy3(tw_engine* e, const TileSet& S, dim3 grid, dim3 wave, hipStream_t s0, hipStream_t s1, hipStream_t s2) {
+    int emax = S.slot;   // a class' tile set: its endpoint count; all tiles: the batch's largest
+    if (emax == 0)
+        for (int c = 1; c <= kMaxEp; c++) if (e->tile_cls_off[c + 1] > e->tile_cls_off[c]) emax = c;
+    if (emax <= 2) launch_select_heavy3<2>(e, S, grid, wave, s0, s1, s2);
+    else if (emax <= 4) launch_select_heavy3<4>(e, S, grid, wave, s0, s1, s2);
+    else launch_select_heavy3<kMaxEp>(e, S, grid, wave, s0, s1, s2);
+}
+
 void launch_select_listed(tw_engine* e, const TileSet& S, hipStream_t st, int64_t n_spans, bool fork = true, bool second = false) {
     const Dev& P = e->P;
     const dim3 wave(std::min(e->coop, 64));
     const dim3 grid((unsigned)std::min<int64_t>(n_spans / 2 + 1, e->select_grid));
     if (!fork) {
         hipLaunchKernelGGL(k_select_tiny, dim3((unsigned)std::min<int64_t>(n_spans / 2 + 1, 8192)), wave, 0, st, P, S);
-        hipLaunchKernelGGL((k_select_heavy<SelectLdsLvl, 3>), grid, wave, 0, st, P, S);
-        hipLaunchKernelGGL((k_select_heavy<SelectLdsBigLvl, 1>), grid, wave, 0, st, P, S);
-        hipLaunchKernelGGL((k_select_heavy<SelectLdsMidLvl, 2>), grid, wave, 0, st, P, S);
+        launch_select_heavy3(e, S, grid, wave, st, st, st);
         return;
     }
     hipStream_t* ss = second ? e->sel_stream2 : e->sel_stream;
     (void)hipEventRecord(e->post_fork[S.slot], st);
     for (int j = 0; j < 3; j++) (void)hipStreamWaitEvent(ss[j], e->post_fork[S.slot], 0);
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsLvl, 3>), grid, wave, 0, ss[0], P, S);      // the longest searches first
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsBigLvl, 1>), grid, wave, 0, ss[1], P, S);
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsMidLvl, 2>), grid, wave, 0, ss[2], P, S);
+    launch_select_heavy3(e, S, grid, wave, ss[0], ss[1], ss[2]);
     for (int j = 0; j < 3; j++) (void)hipEventRecord(e->post_join[S.slot][j], ss[j]);
     hipLaunchKernelGGL(k_select_tiny, dim3((unsigned)std::min<int64_t>(n_spans / 2 + 1, 8192)), wave, 0, st, P, S);
     for (int j = 0; j < 3; j++) (void)hipStreamWaitEvent(st, e->post_join[S.slot][j], 0);

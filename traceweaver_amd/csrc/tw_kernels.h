@@ -2400,13 +2400,17 @@ constexpr int kMemoSlots = TW_MEMO_SLOTS;      // transposition table entries (L
 // have no larger component: k_select_tiny, 1 KB instead of 22 KB of LDS per wavefront)
 // DFS = false leaves out what only the depth-first search needs (transposition table, matching relaxation): the layouts of
 // k_select_heavy, whose components are solved level by level (select_dp) or handed to k_select_dp -- more workgroups per CU
-template <int MW, bool SEARCH, bool DFS = true>
+// EMAX: most endpoints of the units the layout serves -- the candidates' span indices are a fifth to a third of a layout, and the
+// selection kernels hold as many windows at a time as their LDS lets them (k_select_heavy on the three-word layout: 18 KB with room
+// for eight endpoints, 14 KB for two; the launches pick the instantiation by the tile set's largest endpoint count)
+template <int MW, bool SEARCH, bool DFS = true, int EMAX = kMaxEp>
 struct SelectLdsT {
     static constexpr bool kSearch = SEARCH, kDfs = DFS;
+    static constexpr int kEmax = EMAX;
     // transposition table entries by layout (TW_MEMO_MID / TW_MEMO_BIG: the windows of 5-7 and 8-15 spans)
     static constexpr int kS = SEARCH ? MW : 1, kSlots = !(SEARCH && DFS) ? 1 : (MW <= 8 ? TW_MEMO_MID : (MW <= 16 ? TW_MEMO_BIG : kMemoSlots));
     static constexpr int kW = SEARCH ? (MW * kTopK + 63) / 64 : 1;   // words of a mask over all candidates of a component
-    int32_t idx[MW][kTopK][kMaxEp];
+    int32_t idx[MW][kTopK][EMAX];
     sel_w w[MW][kTopK];  // sel_weight(score); <= 0 means not eligible
     sel_w ub[kS + 1];
     sel_w red_val[kCoop / 64];
@@ -2446,9 +2450,12 @@ struct SelectLdsT {
 typedef SelectLdsT<kMaxWin, true> SelectLds;
 typedef SelectLdsT<kBruteMax, false> SelectLdsTiny;
 // k_select_heavy: the three window classes without the depth-first search's tables
-typedef SelectLdsT<kMaxWin, true, false> SelectLdsLvl;        // kHugeWindow .. kMaxWin spans: three-word masks
-typedef SelectLdsT<kHugeWindow, true, false> SelectLdsBigLvl; // windows of kBigWindow <= m < kHugeWindow spans: two-word masks
-typedef SelectLdsT<kBigWindow, true, false> SelectLdsMidLvl;  // windows of kBruteMax < m < kBigWindow spans: one-word masks
+template <int EMAX> using SelectLdsLvlE = SelectLdsT<kMaxWin, true, false, EMAX>;        // kHugeWindow .. kMaxWin spans: three-word masks
+template <int EMAX> using SelectLdsBigLvlE = SelectLdsT<kHugeWindow, true, false, EMAX>; // windows of kBigWindow <= m < kHugeWindow spans: two-word masks
+template <int EMAX> using SelectLdsMidLvlE = SelectLdsT<kBigWindow, true, false, EMAX>;  // windows of kBruteMax < m < kBigWindow spans: one-word masks
+typedef SelectLdsLvlE<kMaxEp> SelectLdsLvl;
+typedef SelectLdsBigLvlE<kMaxEp> SelectLdsBigLvl;
+typedef SelectLdsMidLvlE<kMaxEp> SelectLdsMidLvl;
 
 template <class LDS>
 __device__ inline bool lds_share(const LDS& L, int E, int b1, int k1, int b2, int k2) {
@@ -3267,7 +3274,7 @@ __device__ bool select_window_coop(const Dev& P, const UnitDev& U, int unit, int
         }
         L.w[b][k] = k < n ? sel_weight(sc) : 0;
 #pragma unroll
-        for (int e = 0; e < kMaxEp; e++) if (e < E) L.idx[b][k][e] = k < n ? ix[e] : -1 - q;
+        for (int e = 0; e < LDS::kEmax; e++) if (e < E) L.idx[b][k][e] = k < n ? ix[e] : -1 - q;
         if (k == 0) { L.ncand[b] = (uint8_t)n; L.comp[b] = (uint8_t)b; L.pick[b] = -1; }
     }
     if (t == 0) { L.budget_hit = 0; L.nodes_total = 0ull; }
