@@ -89,7 +89,7 @@ struct tw_engine {
     hipStream_t cls_stream2[kMaxEp + 1] = {};
     hipEvent_t stretch_ev[kMaxEp + 1][kEnumStretches] = {}, stretch_done[kMaxEp + 1] = {};
     int enum_stretches = 1, stretch_min_tiles = 2048;   // TW_ENUM_STRETCHES (1 = one launch: the default, see launch_enumerate), TW_STRETCH_MIN_TILES (tiles per stretch at least)
-    int heavy_grid = 4096, select_grid = 4096;          // TW_HEAVY_GRID / TW_SELECT_GRID: most persistent wavefronts of k_enumerate_heavy / k_select_heavy per launch
+    int heavy_grid = 4096, select_grid = 0;             // TW_HEAVY_GRID: most persistent wavefronts of k_enumerate_heavy per launch; TW_SELECT_GRID: of k_select_heavy (0 = by the layout's LDS, select_heavy_grid)
     int debug_lists = 0;                                // TW_DEBUG_LISTS=1: the list counters of the first enumeration are copied to the host per class (tw_debug_worklists)
     int32_t first_lists[3][kMaxEp + 1] = {};            // ... narrow, wide, long enumerations
     hipEvent_t gate_ev = nullptr;              // ... the last one recorded in the current launch_enumerate_all
@@ -439,25 +439,36 @@ int launch_windows(tw_engine* e, const TileSet& S, hipStream_t st) {
 // three selection streams stay free for the class whose stage ends the pass)
 // the three instantiations of k_select_heavy with room for EMAX endpoints per candidate (SelectLdsT: what a workgroup holds in LDS decides
 // how many windows the GPU searches at a time)
-template <int EMAX>
-void launch_select_heavy3(tw_engine* e, const TileSet& S, dim3 grid, dim3 wave, hipStream_t s0, hipStream_t s1, hipStream_t s2) {
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsLvlE<EMAX>, 3>), grid, wave, 0, s0, e->P, S);      // the longest searches first
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsBigLvlE<EMAX>, 1>), grid, wave, 0, s1, e->P, S);
-    hipLaunchKernelGGL((k_select_heavy<SelectLdsMidLvlE<EMAX>, 2>), grid, wave, 0, s2, e->P, S);
+// Persistent workgroups of one wavefront each, as many as the CUs hold at a time by the layout's LDS (the window's data + the small tables
+// of the level solver): 2 800 / 4 300 / 6 100 for the three layouts of a two-endpoint class.  (One figure for all three, 4 096, left the
+// small layouts short of wavefronts and gave the large one a second round: nodejs shape at 14.4 M spans 40.9 -> 39.2 ms with 6 144, 41.4
+// with 8 192.)  TW_SELECT_GRID > 0 is that one figure again.
+template <class LDS>
+unsigned select_heavy_grid(const tw_engine* e, dim3 most) {
+    if (e->select_grid > 0) return std::min<unsigned>(most.x, (unsigned)e->select_grid);
+    const size_t lds = sizeof(LDS) + sizeof(SelectDpT<LDS::kW, kDpCapSmall, kDpSlotsSmall>) + 512;
+    const unsigned resident = 256u * (unsigned)std::max<size_t>((160u * 1024u) / lds, 1);
+    return std::max(std::min(most.x, std::min(resident, 8192u)), 1u);
 }
-void launch_select_heavy3(tw_engine* e, const TileSet& S, dim3 grid, dim3 wave, hipStream_t s0, hipStream_t s1, hipStream_t s2) {
+template <int EMAX>
+void launch_select_heavy3(tw_engine* e, const TileSet& S, dim3 most, dim3 wave, hipStream_t s0, hipStream_t s1, hipStream_t s2) {
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsLvlE<EMAX>, 3>), dim3(select_heavy_grid<SelectLdsLvlE<EMAX>>(e, most)), wave, 0, s0, e->P, S);      // the longest searches first
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsBigLvlE<EMAX>, 1>), dim3(select_heavy_grid<SelectLdsBigLvlE<EMAX>>(e, most)), wave, 0, s1, e->P, S);
+    hipLaunchKernelGGL((k_select_heavy<SelectLdsMidLvlE<EMAX>, 2>), dim3(select_heavy_grid<SelectLdsMidLvlE<EMAX>>(e, most)), wave, 0, s2, e->P, S);
+}
+void launch_select_heavy3(tw_engine* e, const TileSet& S, dim3 most, dim3 wave, hipStream_t s0, hipStream_t s1, hipStream_t s2) {
     int emax = S.slot;   // a class' tile set: its endpoint count; all tiles: the batch's largest
     if (emax == 0)
         for (int c = 1; c <= kMaxEp; c++) if (e->tile_cls_off[c + 1] > e->tile_cls_off[c]) emax = c;
-    if (emax <= 2) launch_select_heavy3<2>(e, S, grid, wave, s0, s1, s2);
-    else if (emax <= 4) launch_select_heavy3<4>(e, S, grid, wave, s0, s1, s2);
-    else launch_select_heavy3<kMaxEp>(e, S, grid, wave, s0, s1, s2);
+    if (emax <= 2) launch_select_heavy3<2>(e, S, most, wave, s0, s1, s2);
+    else if (emax <= 4) launch_select_heavy3<4>(e, S, most, wave, s0, s1, s2);
+    else launch_select_heavy3<kMaxEp>(e, S, most, wave, s0, s1, s2);
 }
 
 void launch_select_listed(tw_engine* e, const TileSet& S, hipStream_t st, int64_t n_spans, bool fork = true, bool second = false) {
     const Dev& P = e->P;
     const dim3 wave(std::min(e->coop, 64));
-    const dim3 grid((unsigned)std::min<int64_t>(n_spans / 2 + 1, e->select_grid));
+    const dim3 grid((unsigned)std::min<int64_t>(n_spans / 2 + 1, 1 << 20));   // (what the set could need at most; launch_select_heavy3 sizes each layout's launch)
     if (!fork) {
         hipLaunchKernelGGL(k_select_tiny, dim3((unsigned)std::min<int64_t>(n_spans / 2 + 1, 8192)), wave, 0, st, P, S);
         launch_select_heavy3(e, S, grid, wave, st, st, st);
@@ -951,7 +962,7 @@ int tw_create(int device_id, tw_engine** out) {
     e->tile_gate = env_int("TW_TILE_GATE", 0);
     e->enum_stretches = std::min(std::max(env_int("TW_ENUM_STRETCHES", 1), 1), kEnumStretches);
     e->heavy_grid = std::max(env_int("TW_HEAVY_GRID", 4096), 64);
-    e->select_grid = std::max(env_int("TW_SELECT_GRID", 4096), 64);
+    e->select_grid = std::max(env_int("TW_SELECT_GRID", 0), 0);
     e->debug_lists = env_int("TW_DEBUG_LISTS", 0);
     e->select_fork_min = (int64_t)env_int("TW_SELECT_FORK_MIN", 0);
     e->stretch_min_tiles = std::max(env_int("TW_STRETCH_MIN_TILES", 2048), 1);
