@@ -141,6 +141,7 @@ struct tw_engine {
     int tile_sub_max = 8;
     int32_t hard_pass1[kMaxEp + 1] = {};    // per class: windows its stage listed for k_select_dp in pass 1 (-1 not known)
     int8_t wide_pass1[kMaxEp + 1] = {};     // per class: -1 not known, 0 / 1 = the first enumeration of pass 1 listed no / some span with wide windows
+    int32_t split_pass1[kMaxEp + 1] = {};   // per class: spans the first enumeration of pass 1 cut into parts (-1 not known): sizes the merge launch of pass 2 (a guess that only costs time when wrong)
     int lean_pool = 512;                    // doubles of LDS for the pair tables of k_enumerate_lean (TW_LEAN_POOL)
     bool pass1_done = false;                // tw_run_pass1 has run on the resident batch (tw_run_pass2 reads its cut-offs, windows, tuple counts)
     std::vector<int32_t> fit_max_n;         // per slot min(5, #unique), 0 = nothing to fit (host copy, tw_fit_rows)
@@ -384,11 +385,14 @@ void launch_enumerate(tw_engine* e, int pass, int mode, const int32_t* listed) {
     if (n_wide != 0) wide(0, grid_for(n_wide, 1024));   // (stretched: the wide instantiation once, over the whole lists)
     if (mode == 0 && E >= 3 && E >= P.defer_min_e) { narrow(3, grid_for(-1, 4096)); if (n_wide != 0) wide(3, grid_for(-1, 1024)); }
     if (mode == 0 && E > 1) {
-        // (34 KB of LDS a workgroup: a thousand of them ask for all there is -- which a class of a million spans and more is given; measured
-        // on the two-endpoint class of the nodejs shape at 14.4 M spans, whose merge takes 2.3 ms with 256: no change to the step, the
-        // class' chain is not the longest of that pass)
-        hipLaunchKernelGGL(k_merge_parts, dim3(cap >= (1 << 20) ? 1024 : 256), dim3(std::min(e->coop, 64)), 0, st, P, pass, E, E);
-        narrow(1, 256); if (n_wide != 0) wide(1, 64);
+        // (34 KB of LDS a workgroup: a thousand of them ask for all there is -- and wait for it while the selection kernels of other
+        // classes hold the CUs' LDS: the launch for the two-endpoint class of the nodejs shape at 14.4 M spans, which has nothing to merge,
+        // lasted 0.9-2.3 ms.  Pass 2 cuts the same spans as pass 1 -- the cuts follow the candidates' containment and the tuple counts --:
+        // its launch is sized by pass 1's count; the workgroups stride over the records, so a wrong guess only costs time)
+        const int nsplit = (pass == 2 && mode == 0) ? e->split_pass1[E] : -1;
+        const int merge_grid = nsplit < 0 ? (cap >= (1 << 20) ? 1024 : 256) : std::max(std::min(nsplit, 1024), 8);
+        hipLaunchKernelGGL(k_merge_parts, dim3(merge_grid), dim3(std::min(e->coop, 64)), 0, st, P, pass, E, E);
+        narrow(1, nsplit == 0 ? 8 : 256); if (n_wide != 0) wide(1, nsplit == 0 ? 8 : 64);
     }
     if (e->debug_lists != 0 && mode == 0) {
         (void)hipMemcpyAsync(&e->first_lists[0][E], P.heavy_in_count + E, sizeof(int32_t), hipMemcpyDeviceToHost, st);
@@ -745,12 +749,14 @@ int run_pass(tw_engine* e, int pass) {
     }
     HIPCHK(hipEventRecord(e->ev[EV_END], e->stream));
     HIPCHK(hipGetLastError());
-    int32_t kerr = 0, aw[kMaxEp + 1] = {}, hn[kSelSlots * 8] = {};
+    int32_t kerr = 0, aw[kMaxEp + 1] = {}, hn[kSelSlots * 8] = {}, sc[kMaxEp + 1] = {};
     HIPCHK(hipMemcpyAsync(&kerr, P.err, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     if (pass == 1) HIPCHK(hipMemcpyAsync(aw, P.any_wide, sizeof(aw), hipMemcpyDeviceToHost, e->stream));   // (which classes listed spans with wide windows: pass 2 lists the same spans)
     if (pass == 1) HIPCHK(hipMemcpyAsync(hn, P.heavy_next, sizeof(hn), hipMemcpyDeviceToHost, e->stream));
+    if (pass == 1) HIPCHK(hipMemcpyAsync(sc, P.split_count, sizeof(sc), hipMemcpyDeviceToHost, e->stream));   // (the pass' total per class: not reset by the repair rounds)
     HIPCHK(hipStreamSynchronize(e->stream));
     if (pass == 1) for (int E = 1; E <= kMaxEp; E++) e->wide_pass1[E] = aw[E] != 0 ? 1 : 0;
+    if (pass == 1) for (int E = 1; E <= kMaxEp; E++) e->split_pass1[E] = sc[E];
     // (a repair round's fill of the counter block takes the stages' counts with it: not known then)
     if (pass == 1) for (int E = 1; E <= kMaxEp; E++) e->hard_pass1[E] = (staged && e->rounds == 0) ? hn[E * 8 + kHardCount] : -1;
     float f = 0.f;
@@ -909,7 +915,7 @@ extern "C" int tw_scale_load(tw_engine* e, const int32_t* unit_factor, const int
     HIPCHK(hipMemcpyAsync(const_cast<UnitDev*>(P.units), e->units.data(), sizeof(UnitDev) * e->units.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->state = ST_LOADED; e->pass1_done = false;
-    for (int E = 0; E <= kMaxEp; E++) { e->wide_pass1[E] = -1; e->hard_pass1[E] = -1; }
+    for (int E = 0; E <= kMaxEp; E++) { e->wide_pass1[E] = -1; e->hard_pass1[E] = -1; e->split_pass1[E] = -1; }
     return TW_OK;
 }
 
@@ -1360,7 +1366,7 @@ int tw_load_batch(tw_engine* e, const tw_batch* b, int spans_on_device) {
     HIPCHK(hipStreamSynchronize(e->stream));
     e->scaled_upload = b->unit_time_scale != nullptr;
     e->state = ST_LOADED; e->pass1_done = false;
-    for (int E = 0; E <= kMaxEp; E++) { e->wide_pass1[E] = -1; e->hard_pass1[E] = -1; }
+    for (int E = 0; E <= kMaxEp; E++) { e->wide_pass1[E] = -1; e->hard_pass1[E] = -1; e->split_pass1[E] = -1; }
     return TW_OK;
 }
 
